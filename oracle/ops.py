@@ -1,0 +1,345 @@
+"""Oracle primitives (TEST INFRASTRUCTURE - see oracle/__init__.py).
+
+torch-CPU restatement of the MLX ops the reference hot path calls.  Every
+function cites the reference call site (paths relative to
+/root/reference/mlx_vlm/).
+
+Accumulation / rounding policy ("typed graph" emulation).  The reference runs
+every tensor in the checkpoint dtype T (bf16 for the benchmark) and MLX ops
+round their result to T.  We emulate that on CPU by computing each op in fp32
+from T inputs and rounding ONCE at the op boundary, i.e. at the points where
+the reference materialises a T tensor:
+  * nn.Linear / addmm ......... fp32 accumulate, +bias in fp32, one rounding
+  * nn.LayerNorm (mx.fast) .... fp32 stats and affine, one rounding
+  * nn.RMSNorm (mx.fast) ...... fp32 stats; y = T(w * T(x * rsqrt(ms+eps)))
+                                (normalised value is cast to T before the
+                                weight multiply, as HF Qwen2RMSNorm does)
+  * GELU / SiLU / mul / add ... fp32 math per elementary op, rounded per op
+  * mx.fast.sdpa .............. fp32 scores+softmax, P*V in fp32, one rounding
+  * M-RoPE fused path ......... fp32 angle/cos/sin/rotation, one rounding
+                                (rope_utils.py:589-603,640-643)
+  * logits .................... T;  logprobs = T(logits - T(logsumexp)) (ar.py:368)
+With T = float32 every rounding is the identity and the functions are the
+plain fp32 math, which is what is checked against HuggingFace.
+These MLX-internal rounding points are NOT observable from the reference tree
+("parity unpinned", oracle/__init__.py); kernels are compared with the
+tolerances stated in tests/.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+F32 = torch.float32
+
+
+# --------------------------------------------------------------------------
+# dense ops
+# --------------------------------------------------------------------------
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None):
+    """nn.Linear: y = x @ W.T + b (models/qwen2_vl/vision.py:129-130,168-169;
+    language.py:52-55; mlp.py:9-11).  fp32 accumulate, one rounding."""
+    y = x.to(F32) @ w.to(F32).T
+    if b is not None:
+        y = y + b.to(F32)
+    return y.to(x.dtype)
+
+
+def layer_norm(x, w, b, eps: float = 1e-6):
+    """nn.LayerNorm(eps=1e-6) (vision.py:109,180-181) -> mx.fast.layer_norm."""
+    xf = x.to(F32)
+    mean = xf.mean(-1, keepdim=True)
+    var = ((xf - mean) ** 2).mean(-1, keepdim=True)
+    y = (xf - mean) * torch.rsqrt(var + eps)
+    y = y * w.to(F32) + b.to(F32)
+    return y.to(x.dtype)
+
+
+def rms_norm(x, w, eps: float = 1e-6):
+    """nn.RMSNorm (language.py:130-133,168) -> mx.fast.rms_norm."""
+    xf = x.to(F32)
+    inv = torch.rsqrt((xf * xf).mean(-1, keepdim=True) + eps)
+    xn = (xf * inv).to(x.dtype)
+    return (w.to(F32) * xn.to(F32)).to(x.dtype)
+
+
+def add(a, b):
+    """residual add in T (vision.py:188-193; language.py:151-153)."""
+    return (a.to(F32) + b.to(F32)).to(a.dtype)
+
+
+def gelu_fast(x):
+    """nn.GELU(approx="fast") = x * sigmoid(1.702 x) (vision.py:167; MLX docs)."""
+    xf = x.to(F32)
+    return (xf * torch.sigmoid(1.702 * xf)).to(x.dtype)
+
+
+def gelu_erf(x):
+    """nn.GELU() exact erf form (vision.py:112)."""
+    xf = x.to(F32)
+    return (0.5 * xf * (1.0 + torch.erf(xf * (1.0 / math.sqrt(2.0))))).to(x.dtype)
+
+
+def swiglu(gate, up):
+    """swiglu = silu(gate) * x (activations.py:7-9); silu(x) = x * sigmoid(x).
+    Typed graph: sigmoid -> T, x*sig -> T, *up -> T."""
+    T = gate.dtype
+    gf = gate.to(F32)
+    sig = torch.sigmoid(gf).to(T)
+    silu = (gf * sig.to(F32)).to(T)
+    return (silu.to(F32) * up.to(F32)).to(T)
+
+
+def sdpa(q, k, v, scale: float, causal: bool = False, q_offset: int = 0,
+         key_mask: Optional[torch.Tensor] = None):
+    """mx.fast.scaled_dot_product_attention (vision.py:154; base.py:366-373).
+
+    q [B,Hq,Lq,D], k/v [B,Hkv,Lk,D] (GQA: Hq % Hkv == 0, query head h uses kv
+    head h // (Hq//Hkv)).  `causal`: key j visible to query i iff
+    j <= i + q_offset, q_offset = Lk - Lq (cache.py:24-42 create_causal_mask).
+    `key_mask` [B,Lk] bool: False = padded key (cache.py:1071-1074).
+    fp32 scores and softmax, fp32 P*V, one rounding to q.dtype."""
+    B, Hq, Lq, D = q.shape
+    Hkv = k.shape[1]
+    rep = Hq // Hkv
+    qf = q.to(F32)
+    kf = k.to(F32).repeat_interleave(rep, dim=1)
+    vf = v.to(F32).repeat_interleave(rep, dim=1)
+    s = (qf @ kf.transpose(-1, -2)) * scale
+    Lk = k.shape[2]
+    if causal:
+        i = torch.arange(Lq)[:, None] + q_offset
+        j = torch.arange(Lk)[None, :]
+        s = s.masked_fill(~(j <= i), float("-inf"))
+    if key_mask is not None:
+        s = s.masked_fill(~key_mask[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return (p @ vf).to(q.dtype)
+
+
+# --------------------------------------------------------------------------
+# rotary embeddings
+# --------------------------------------------------------------------------
+def vision_inv_freq(dim: int, theta: float = 10000.0):
+    """VisionRotaryEmbedding (vision.py:53-65); dim = head_dim // 2."""
+    return 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=F32) / dim))
+
+
+def vision_rot_pos_ids(grid_thw: np.ndarray, merge: int = 2) -> np.ndarray:
+    """VisionModel.rot_pos_emb integer part (vision.py:219-247): (h, w) index of
+    every patch in merge-window order.  -> int64 [N, 2]."""
+    out = []
+    for t, h, w in np.asarray(grid_thw).tolist():
+        hpos = np.repeat(np.arange(h)[:, None], w, axis=1)
+        wpos = np.repeat(np.arange(w)[None, :], h, axis=0)
+
+        def mw(a):
+            a = a.reshape(h // merge, merge, w // merge, merge)
+            return a.transpose(0, 2, 1, 3).reshape(-1)
+
+        hw = np.stack([mw(hpos), mw(wpos)], axis=-1)
+        out.append(np.tile(hw, (t, 1)))
+    return np.concatenate(out, axis=0).astype(np.int64)
+
+
+def vision_rotary_freqs(grid_thw: np.ndarray, head_dim: int, merge: int = 2):
+    """rot_pos_emb (vision.py:219-255): freqs[N, head_dim//2] fp32 =
+    concat(freq(h_pos), freq(w_pos))."""
+    pos = vision_rot_pos_ids(grid_thw, merge)
+    inv = vision_inv_freq(head_dim // 2)
+    max_grid = int(np.asarray(grid_thw)[:, 1:].max())
+    seq = torch.arange(max_grid, dtype=F32)
+    full = torch.outer(seq, inv)  # [max_grid, head_dim//4]
+    f = full[torch.from_numpy(pos)]  # [N, 2, head_dim//4]
+    return f.reshape(pos.shape[0], -1)
+
+
+def apply_rotary_pos_emb_vision(x, freqs):
+    """apply_rotary_pos_emb_vision (vision.py:35-50).  x [N, H, D] (T),
+    freqs [N, D/2] fp32.  cos/sin tiled x2 along D; rotate_half; fp32 math."""
+    cos = torch.cos(freqs)[:, None, :].repeat(1, 1, 2)
+    sin = torch.sin(freqs)[:, None, :].repeat(1, 1, 2)
+    xf = x.to(F32)
+    d = x.shape[-1] // 2
+    rot = torch.cat([-xf[..., d:], xf[..., :d]], dim=-1)
+    return (xf * cos + rot * sin).to(x.dtype)
+
+
+def mrope_inv_freq(dim: int, base: float):
+    """compute_inv_freq (rope_utils.py:1042-1043)."""
+    return 1.0 / (base ** (torch.arange(0, dim, 2).to(F32) / dim))
+
+
+def chunked_position_selector(mrope_section: Sequence[int], freq_dim: int):
+    """_chunked_position_selector (rope_utils.py:519-526): frequency index f ->
+    position axis (0=t, 1=h, 2=w)."""
+    sel = [0] * freq_dim
+    off = mrope_section[0]
+    for dim, length in enumerate(mrope_section[1:], start=1):
+        for idx in range(off, min(off + length, freq_dim)):
+            sel[idx] = dim
+        off += length
+    return torch.tensor(sel, dtype=torch.int64)
+
+
+def mrope_apply(x, position_ids, inv_freq, selector, mode: str = "fused"):
+    """M-RoPE, half-split pairing, style "chunked".
+
+    x [B, H, L, D]; position_ids [3, B, L] or [B, L] (ints).
+    mode "fused": the Metal kernel's numerics (rope_utils.py:567-651):
+        angle = float(pos[sel[f]]) * inv_freq[f]; c, s in fp32;
+        out[d] = T(x_d c - x_p s), out[d+D/2] = T(x_p c + x_d s).
+    mode "fallback": the non-Metal path (rope_utils.py:1235-1241,1486-1504 with
+        compute_dtype=None): cos/sin rounded to T first, rotation in T-typed
+        ops (mul -> T, mul -> T, add -> T)."""
+    B, H, L, D = x.shape
+    half = D // 2
+    pos = position_ids
+    if pos.dim() == 2:
+        ang = pos.to(F32)[..., None] * inv_freq  # [B, L, half]
+    else:
+        p = pos[selector]  # [half, B, L]
+        ang = p.permute(1, 2, 0).to(F32) * inv_freq
+    c = torch.cos(ang)[:, None]  # [B,1,L,half]
+    s = torch.sin(ang)[:, None]
+    if mode == "fused":
+        xf = x.to(F32)
+        xd, xp = xf[..., :half], xf[..., half:]
+        return torch.cat([xd * c - xp * s, xp * c + xd * s], dim=-1).to(x.dtype)
+    T = x.dtype
+    c = torch.cat([c, c], -1).to(T)
+    s = torch.cat([s, s], -1).to(T)
+    rot = torch.cat([-x[..., half:], x[..., :half]], dim=-1)
+    a = (x.to(F32) * c.to(F32)).to(T)
+    b = (rot.to(F32) * s.to(F32)).to(T)
+    return (a.to(F32) + b.to(F32)).to(T)
+
+
+# --------------------------------------------------------------------------
+# KV cache (models/cache.py:337-393 KVCache)
+# --------------------------------------------------------------------------
+class KVCache:
+    """Contiguous [B, Hkv, S, D] K and V, 256-step growth (cache.py:338-367)."""
+
+    step = 256
+
+    def __init__(self):
+        self.keys = None
+        self.values = None
+        self.offset = 0
+
+    def update_and_fetch(self, keys, values):
+        prev = self.offset
+        if self.keys is None or (prev + keys.shape[2]) > self.keys.shape[2]:
+            B, H, _, D = keys.shape
+            n_steps = (self.step + keys.shape[2] - 1) // self.step
+            new_k = torch.zeros(B, H, n_steps * self.step, D, dtype=keys.dtype)
+            new_v = torch.zeros(B, H, n_steps * self.step, values.shape[3], dtype=values.dtype)
+            if self.keys is not None:
+                if prev % self.step != 0:
+                    self.keys = self.keys[..., :prev, :]
+                    self.values = self.values[..., :prev, :]
+                self.keys = torch.cat([self.keys, new_k], dim=2)
+                self.values = torch.cat([self.values, new_v], dim=2)
+            else:
+                self.keys, self.values = new_k, new_v
+        self.offset += keys.shape[2]
+        self.keys[..., prev:self.offset, :] = keys
+        self.values[..., prev:self.offset, :] = values
+        return self.keys[..., :self.offset, :], self.values[..., :self.offset, :]
+
+    @property
+    def state(self):
+        return self.keys[..., :self.offset, :], self.values[..., :self.offset, :]
+
+    def trim(self, n):
+        n = min(self.offset, n)
+        self.offset -= n
+        return n
+
+
+# --------------------------------------------------------------------------
+# sampling (generate/ar.py:368; sample_utils.py)
+# --------------------------------------------------------------------------
+def logprobs_from_logits(logits):
+    """logprobs = logits - logsumexp(logits) in the logits dtype (ar.py:368)."""
+    T = logits.dtype
+    lse = torch.logsumexp(logits.to(F32), dim=-1, keepdim=True).to(T)
+    return (logits.to(F32) - lse.to(F32)).to(T)
+
+
+def argmax_first(x):
+    """mx.argmax (sample_utils.py:63-64): lowest index among ties."""
+    xf = x.to(F32)
+    m = xf.max(dim=-1, keepdim=True).values
+    idx = torch.arange(x.shape[-1]).expand_as(xf)
+    big = torch.full_like(idx, x.shape[-1])
+    return torch.where(xf == m, idx, big).min(dim=-1).values
+
+
+def apply_top_k(logprobs, top_k: int):
+    """_apply_top_k (sample_utils.py:169-175): keep the k largest, rest -inf.
+    Ties at the k-th value: argpartition keeps an arbitrary subset; the oracle
+    keeps the lowest indices (stable descending sort) and says so."""
+    xf = logprobs.to(F32)
+    order = torch.sort(-xf, dim=-1, stable=True).indices
+    out = xf.clone()
+    out.scatter_(-1, order[..., top_k:], float("-inf"))
+    return out.to(logprobs.dtype)
+
+
+def apply_top_p(logprobs, top_p: float):
+    """apply_top_p (sample_utils.py:289-318): ascending sort, cumulative probs,
+    keep tokens whose cumulative prob (inclusive) > 1 - top_p."""
+    xf = logprobs.to(F32)
+    probs = torch.exp(xf)
+    order = torch.sort(xf, dim=-1, stable=True).indices
+    sp = torch.gather(probs, -1, order)
+    cum = torch.cumsum(sp, dim=-1)
+    inv = torch.empty_like(order)
+    inv.scatter_(-1, order, torch.arange(order.shape[-1]).expand_as(order))
+    cum = torch.gather(cum, -1, inv)
+    return torch.where(cum > 1 - top_p, xf, torch.full_like(xf, float("-inf"))).to(logprobs.dtype)
+
+
+def apply_min_p(logprobs, min_p: float, min_tokens_to_keep: int = 1):
+    """_apply_min_p (sample_utils.py:266-286)."""
+    xf = logprobs.to(F32)
+    top = xf.max(dim=-1, keepdim=True).values
+    remove = xf < (top + math.log(min_p))
+    if min_tokens_to_keep > 1:
+        keep = torch.topk(xf, min_tokens_to_keep, dim=-1).indices
+        remove.scatter_(-1, keep, False)
+    return torch.where(remove, torch.full_like(xf, float("-inf")), xf).to(logprobs.dtype)
+
+
+def hash_uniform(seed: int, step: int, row: int, idx: np.ndarray) -> np.ndarray:
+    """Counter-based uniform in (0,1) used by OUR categorical sampler (the MLX
+    RNG stream, sample_utils.py:385-387 mx.random.categorical, is not
+    reproducible outside MLX - SURVEY.md §7.6).  32-bit mix of
+    (seed, step, row, idx); restated bit-for-bit by the HIP kernel."""
+    M = np.uint64(0xFFFFFFFF)
+    x = (np.uint64(seed) ^ np.uint64(0x9E3779B9)) & M
+    x = (x + (np.uint64(step) + np.uint64(1)) * np.uint64(0x85EBCA6B)) & M
+    x = (x ^ ((np.uint64(row) + np.uint64(1)) * np.uint64(0xC2B2AE35))) & M
+    x = (x + idx.astype(np.uint64) * np.uint64(0x27D4EB2F)) & M
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & M
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & M
+    x ^= x >> np.uint64(16)
+    return ((x >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+
+
+def categorical_gumbel(logprobs, temp: float, seed: int, step: int, row: int = 0):
+    """categorical_sampling(logits, temp) = categorical(logits / temp)
+    (sample_utils.py:385-387) by the Gumbel-max trick (which is what
+    mx.random.categorical does) with OUR hash RNG.  logprobs [V]."""
+    x = logprobs.to(F32).numpy() * np.float32(1.0 / temp)
+    u = hash_uniform(seed, step, row, np.arange(x.shape[-1]))
+    g = -np.log(-np.log(u.astype(np.float32))).astype(np.float32)
+    z = (x + g).astype(np.float32)
+    return int(np.argmax(z))
