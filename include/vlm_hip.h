@@ -1,0 +1,229 @@
+/* vlm_hip.h - C ABI of libvlm_hip.so, the MI355X (gfx950) operator library that
+ * replaces the MLX ops on mlx-vlm's generate hot path (Qwen2-VL first).
+ *
+ * The reference (Blaizzy/mlx-vlm v0.6.15, /root/reference) has NO FFI/plugin ABI
+ * of its own: its model code calls straight into the `mlx` Python runtime.  The
+ * drop-in boundary is therefore the set of MLX operators that path invokes
+ * (SURVEY.md par. 8b); every entry point below names the reference call site it
+ * replaces.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless marked (host); the caller owns
+ *     every buffer; bf16 tensors are raw 16-bit words; "ld*" / "*_stride" are
+ *     leading dimensions in ELEMENTS
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     every function only enqueues work and returns
+ *   - return value: 0 = VLM_OK; 1 = bad argument; 2 = unsupported shape;
+ *     1000 + hipError_t = a HIP launch error.  No exceptions cross the ABI.
+ *   - no global state; functions are re-entrant; one stream per engine thread
+ *     (the reference's contract: one thread-local generation stream,
+ *     mlx_vlm/generate/common.py:32)
+ */
+#ifndef VLM_HIP_H_
+#define VLM_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* epilogue flags for vlm_gemm_bf16 / vlm_gemv_bf16 (rounded to bf16 at the same
+ * points as the reference's typed graph: after bias, after activation, after
+ * the residual add) */
+#define VLM_EPI_NONE 0
+#define VLM_EPI_BIAS 1       /* + bias[n]                           nn.Linear(bias=True) */
+#define VLM_EPI_GELU_FAST 2  /* x*sigmoid(1.702x)                   vision.py:167        */
+#define VLM_EPI_GELU_ERF 4   /* exact erf GELU                      vision.py:112        */
+#define VLM_EPI_RESIDUAL 8   /* + res[m][n]                         vision.py:188-193, language.py:151-153 */
+#define VLM_EPI_SWIGLU 16    /* W rows interleaved (gate_j, up_j): out[j] = silu(g)*u   mlp.py:6-14, activations.py:7-9 */
+
+int vlm_abi_version(void);
+
+/* C[M,N] = epi(A[M,K] . W[N,K]^T), bf16 in / fp32 MFMA accumulate / bf16 out.
+ * Replaces nn.Linear (mlx_vlm/models/qwen2_vl/vision.py:110-120,129-130,137,161,168-173;
+ * language.py:52-55,76,120; models/mlp.py:9-14), embed_tokens.as_linear / lm_head
+ * (language.py:514-517) and the Conv3d patch projection (vision.py:83-101).
+ * K % 8 == 0, N % 8 == 0.  With VLM_EPI_SWIGLU, C is [M, N/2]. */
+int vlm_gemm_bf16(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
+                  int lda, int ldw, int ldc, int ldres, int epilogue, void* stream);
+
+/* y[M,N] = epi(x[M,K] . W[N,K]^T) for the decode step, M in {1,2,4,8}; weight streaming.
+ * norm_w != NULL fuses y = f(RMSNorm(x; norm_w, eps)) (language.py:130-133,149-153,200).
+ * Same reference call sites as vlm_gemm_bf16 at L == 1. */
+int vlm_gemv_bf16(const void* x, const void* W, const void* bias, const void* res, const void* norm_w, void* y, int M,
+                  int N, int K, int ldx, int ldw, int ldy, int ldres, float eps, int epilogue, void* stream);
+
+/* nn.LayerNorm(eps) -> mx.fast.layer_norm (vision.py:109,180-181). dim % 8 == 0, dim <= 8192 */
+int vlm_layernorm(const void* x, const void* w, const void* b, void* y, int rows, int dim, float eps, void* stream);
+
+/* nn.RMSNorm -> mx.fast.rms_norm (language.py:130-133,168) with the residual add of
+ * language.py:151-153 fused: h = x + res (res may be NULL), y = rmsnorm(h) * w, h_out = h (may be NULL) */
+int vlm_rmsnorm_residual(const void* x, const void* res, const void* w, void* y, void* h_out, int rows, int dim,
+                         float eps, void* stream);
+
+/* apply_rotary_pos_emb_vision (vision.py:35-50) in place on q and k of qkv [N][3][H][D];
+ * cos_tab / sin_tab fp32 [N][D/2] (cos / sin of VisionModel.rot_pos_emb, vision.py:219-255) */
+int vlm_rope2d_vision(void* qkv, const void* cos_tab, const void* sin_tab, int N, int H, int D, int ld, void* stream);
+
+/* M-RoPE (MRoPERotaryEmbedding.apply_rotary, fused-kernel numerics: rope_utils.py:567-651,
+ * 1243-1286, selector 519-526) applied in place to the q and k heads of
+ * qkv [T][(Hq + 2 Hkv) * D], fused with KVCache.update_and_fetch (cache.py:345-367): the rotated
+ * k and the v of token t are written to slot kv_slot[t] of sequence kv_seq[t] (NULL: seq = t) in
+ * the paged pools (page = block_table[seq][slot / 64]).  pos_* int32 [T] (t, h, w axes; pass the
+ * same pointer three times for text).  sec0 / sec1 = mrope_section[0..1].  kpool == NULL: rope only.
+ * K pool [page][Hkv][D/8][64][8], V pool [page][Hkv][64][D] (bf16). */
+int vlm_mrope_kvwrite(void* qkv, int ld, int T, int Hq, int Hkv, int D, const void* pos_t, const void* pos_h,
+                      const void* pos_w, const void* inv_freq, int sec0, int sec1, const void* kv_seq,
+                      const void* kv_slot, const void* block_table, int max_pages, void* kpool, void* vpool,
+                      void* stream);
+
+/* mx.fast.scaled_dot_product_attention on the prefill path: varlen segments (cu_seqlens int32
+ * [nseg+1]), mask=None (vision.py:148-158) or mask="causal" (base.py:214-228,366-373), GQA.
+ * q/k/v/out are token-major with the given token strides; head h of token t at ptr + t*stride + h*D.
+ * total_qblocks = sum_s ceil(len_s / 128) (host).  D in {64, 80, 128}. */
+int vlm_attn_prefill(const void* q, const void* k, const void* v, void* out, int q_stride, int k_stride, int v_stride,
+                     int o_stride, const void* cu_seqlens, int nseg, int total_qblocks, int Hq, int Hkv, int D,
+                     float scale, int causal, void* stream);
+
+/* the same op at L == 1 over the paged cache (base.py:366-373 from language.py:115-118).
+ * q [B][Hq*D] (row stride ldq); kv_len int32 [B] (+ kv_len_add) keys per sequence;
+ * part_o fp32 [B][Hq][nsplit][D], part_ml fp32 [B][Hq][nsplit][2] workspaces; out [B][Hq*D]. D == 128. */
+int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, const void* vpool, const void* block_table,
+                          int max_pages, const void* kv_len, int kv_len_add, int B, int Hq, int Hkv, int D,
+                          float scale, int nsplit, void* part_o, void* part_ml, void* out, int ldo, void* stream);
+
+/* nn.Embedding (language.py:164,179): out[t] = table[ids[t]] */
+int vlm_embed_gather(const void* ids, const void* table, void* out, int T, int D, int ldo, int vocab, void* stream);
+
+/* Model.merge_input_ids_with_image_features (qwen2_vl.py:78-148): dst[dst_rows[i]] = src[i] */
+int vlm_scatter_image_rows(const void* src, const void* dst_rows, void* dst, int n, int D, int ld_src, int ld_dst,
+                           void* stream);
+
+/* pixel_values.astype(bf16) (qwen2_vl.py:44-45) with zero padding of the row to ld_dst */
+int vlm_cast_f32_bf16_pad(const void* src, void* dst, int rows, int cols, int ld_src, int ld_dst, void* stream);
+
+/* decode-loop bookkeeping kept on the device (cache.py:362 offset += 1; language.py:476-509
+ * pos = offset + rope_delta): ctx[b]++, pos[b]++, out_ring[step % ring_len][b] = tok[b], step++ */
+int vlm_decode_advance(void* ctx, void* pos, const void* tok, void* out_ring, int ring_len, void* step, int B,
+                       void* stream);
+
+/* ar.py:368 logprobs = logits - logsumexp (bf16) -> logprobs [B][V] (may be NULL when greedy);
+ * temperature == 0: argmax, lowest index on ties (sample_utils.py:63-64);
+ * else top_p (289-318) -> min_p (266-286) -> top_k (169-175) -> categorical(logprobs/temp) (385-387)
+ * by Gumbel-max with a counter-hash RNG keyed by (seed, *step_ptr, row, index).
+ * scratch bf16 [B][ldlp] is required when temperature > 0. */
+size_t vlm_sample_workspace_bytes(int B);
+int vlm_sample(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
+               void* workspace, float temperature, float top_p, float min_p, int top_k, unsigned seed,
+               const void* step_ptr, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Model-level engine: the layer loops of Qwen2Model / VisionModel run natively so that a decode
+ * step is ~150 back-to-back launches with no host code in between and can be captured in a
+ * hipGraph (the reference keeps the loop in Python and relies on MLX's lazy graph + async_eval,
+ * mlx_vlm/generate/ar.py:474-508).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vlm_llm_config {
+  int hidden, n_layers, inter, n_heads, n_kv_heads, head_dim, vocab;
+  float rms_eps;
+  int mrope_sec0, mrope_sec1; /* mrope_section[0], [1] */
+} vlm_llm_config;
+
+typedef struct vlm_llm_layer {
+  const void *ln1_w, *wqkv, *bqkv, *wo, *ln2_w, *wgu /* interleaved gate/up rows */, *wdown;
+} vlm_llm_layer;
+
+typedef struct vlm_llm_globals {
+  const void *embed, *final_norm_w, *lm_head /* == embed when tied */, *inv_freq /* fp32 [head_dim/2] */;
+} vlm_llm_globals;
+
+typedef struct vlm_kv_pool {
+  void *kpool, *vpool;      /* layer 0 base */
+  size_t layer_stride;      /* elements between consecutive layers' pools */
+  const void* block_table;  /* int32 [n_seq][max_pages] */
+  int max_pages;
+} vlm_kv_pool;
+
+/* prefill over T tokens (all sequences concatenated).  h [T][hidden] holds the input
+ * embeddings and is the residual stream (overwritten).  Workspaces are caller-owned:
+ * xn [T][hidden], qkv [T][(Hq+2Hkv)*D], attn [T][Hq*D], act [T][inter].
+ * last_rows int32 [n_last]: rows of h whose logits are wanted (the reference computes all L rows
+ * and keeps [:, -1], ar.py:358); logits [n_last][vocab]; xlast [n_last][hidden] workspace. */
+typedef struct vlm_prefill_args {
+  void* h;
+  int T;
+  const void *pos_t, *pos_h, *pos_w; /* int32 [T] */
+  const void *kv_seq, *kv_slot;      /* int32 [T] */
+  const void* cu_seqlens;            /* int32 [nseg+1] */
+  int nseg, total_qblocks;
+  void *xn, *qkv, *attn, *act;
+  const void* last_rows;
+  int n_last;
+  void *xlast, *logits;
+} vlm_prefill_args;
+
+/* one decode step for B sequences (B in {1,2,4,8}); every buffer is device resident so the
+ * step can be replayed from a graph: tok int32 [B] (in: token to feed, out: sampled token),
+ * pos / ctx int32 [B] (rope position / keys in cache, advanced by the step), step int32 [1]. */
+typedef struct vlm_decode_args {
+  int B;
+  void *tok, *pos, *ctx, *step;
+  void *h, *qkv, *attn, *act, *logits, *logprobs, *scratch;
+  void *part_o, *part_ml, *sample_ws;
+  void* out_ring; /* int32 [ring_len][B] sampled-token history (may be NULL) */
+  int ring_len, nsplit;
+  float temperature, top_p, min_p;
+  int top_k;
+  unsigned seed;
+} vlm_decode_args;
+
+int vlm_llm_create(const vlm_llm_config* cfg, void** handle);          /* (host) */
+int vlm_llm_destroy(void* handle);
+int vlm_llm_set_layer(void* handle, int layer, const vlm_llm_layer* w);
+int vlm_llm_set_globals(void* handle, const vlm_llm_globals* g);
+int vlm_llm_set_kv(void* handle, const vlm_kv_pool* kv);
+int vlm_llm_prefill(void* handle, const vlm_prefill_args* a, void* stream);
+int vlm_llm_decode_step(void* handle, const vlm_decode_args* a, void* stream);
+/* embeddings -> logits only (no sampling, no advance): language_model(y, cache=...) at L == 1 */
+int vlm_llm_decode_forward(void* handle, const vlm_decode_args* a, void* stream);
+/* capture vlm_llm_decode_step into a hipGraph owned by the handle / replay it */
+int vlm_llm_decode_graph_build(void* handle, const vlm_decode_args* a, void* stream);
+int vlm_llm_decode_graph_launch(void* handle, void* stream);
+/* number of kernel launches in one decode step (for reporting) */
+int vlm_llm_decode_launches(void* handle);
+
+typedef struct vlm_vit_config {
+  int depth, embed_dim, n_heads, mlp_hidden, patch_k /* padded K of the patch GEMM */, merge /* 2 */, out_dim;
+  float ln_eps;
+} vlm_vit_config;
+
+typedef struct vlm_vit_block {
+  const void *ln1_w, *ln1_b, *wqkv, *bqkv, *wproj, *bproj, *ln2_w, *ln2_b, *wfc1, *bfc1, *wfc2, *bfc2;
+} vlm_vit_block;
+
+typedef struct vlm_vit_globals {
+  const void *wpatch /* [embed_dim][patch_k] */, *ln_q_w, *ln_q_b, *wm0, *bm0, *wm2, *bm2;
+} vlm_vit_globals;
+
+/* VisionModel.__call__ (vision.py:257-290): patches bf16 [N][patch_k] -> out bf16 [N/merge^2][out_dim].
+ * Workspaces: x [N][E], xn [N][E], qkv [N][3E], attn [N][E], mlp [N][mlp_hidden], mrg [N/4][4E]. */
+typedef struct vlm_vit_args {
+  const void* patches;
+  int N;
+  const void *cos_tab, *sin_tab; /* fp32 [N][head_dim/2] */
+  const void* cu_seqlens;
+  int nseg, total_qblocks;
+  void *x, *xn, *qkv, *attn, *mlp, *mrg, *out;
+} vlm_vit_args;
+
+int vlm_vit_create(const vlm_vit_config* cfg, void** handle);
+int vlm_vit_destroy(void* handle);
+int vlm_vit_set_block(void* handle, int i, const vlm_vit_block* w);
+int vlm_vit_set_globals(void* handle, const vlm_vit_globals* g);
+int vlm_vit_forward(void* handle, const vlm_vit_args* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLM_HIP_H_ */

@@ -1,0 +1,137 @@
+"""ctypes binding of libvlm_hip.so (include/vlm_hip.h).
+
+There is NO fallback: if the HIP library is missing or does not export a symbol
+the import of any compute path raises - a product path that silently ran on a
+CPU/eager substitute would void every parity claim.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvlm_hip.so")
+
+c_void_p, c_int, c_float, c_uint, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_uint, C.c_size_t
+
+
+class LlmConfig(C.Structure):
+    _fields_ = [("hidden", c_int), ("n_layers", c_int), ("inter", c_int), ("n_heads", c_int), ("n_kv_heads", c_int),
+                ("head_dim", c_int), ("vocab", c_int), ("rms_eps", c_float), ("mrope_sec0", c_int), ("mrope_sec1", c_int)]
+
+
+class LlmLayer(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("ln1_w", "wqkv", "bqkv", "wo", "ln2_w", "wgu", "wdown")]
+
+
+class LlmGlobals(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("embed", "final_norm_w", "lm_head", "inv_freq")]
+
+
+class KvPool(C.Structure):
+    _fields_ = [("kpool", c_void_p), ("vpool", c_void_p), ("layer_stride", c_size_t), ("block_table", c_void_p),
+                ("max_pages", c_int)]
+
+
+class PrefillArgs(C.Structure):
+    _fields_ = [("h", c_void_p), ("T", c_int), ("pos_t", c_void_p), ("pos_h", c_void_p), ("pos_w", c_void_p),
+                ("kv_seq", c_void_p), ("kv_slot", c_void_p), ("cu_seqlens", c_void_p), ("nseg", c_int),
+                ("total_qblocks", c_int), ("xn", c_void_p), ("qkv", c_void_p), ("attn", c_void_p), ("act", c_void_p),
+                ("last_rows", c_void_p), ("n_last", c_int), ("xlast", c_void_p), ("logits", c_void_p)]
+
+
+class DecodeArgs(C.Structure):
+    _fields_ = [("B", c_int), ("tok", c_void_p), ("pos", c_void_p), ("ctx", c_void_p), ("step", c_void_p),
+                ("h", c_void_p), ("qkv", c_void_p), ("attn", c_void_p), ("act", c_void_p), ("logits", c_void_p),
+                ("logprobs", c_void_p), ("scratch", c_void_p), ("part_o", c_void_p), ("part_ml", c_void_p),
+                ("sample_ws", c_void_p), ("out_ring", c_void_p), ("ring_len", c_int), ("nsplit", c_int),
+                ("temperature", c_float), ("top_p", c_float), ("min_p", c_float), ("top_k", c_int), ("seed", c_uint)]
+
+
+class VitConfig(C.Structure):
+    _fields_ = [("depth", c_int), ("embed_dim", c_int), ("n_heads", c_int), ("mlp_hidden", c_int), ("patch_k", c_int),
+                ("merge", c_int), ("out_dim", c_int), ("ln_eps", c_float)]
+
+
+class VitBlock(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("ln1_w", "ln1_b", "wqkv", "bqkv", "wproj", "bproj", "ln2_w", "ln2_b", "wfc1",
+                                        "bfc1", "wfc2", "bfc2")]
+
+
+class VitGlobals(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("wpatch", "ln_q_w", "ln_q_b", "wm0", "bm0", "wm2", "bm2")]
+
+
+class VitArgs(C.Structure):
+    _fields_ = [("patches", c_void_p), ("N", c_int), ("cos_tab", c_void_p), ("sin_tab", c_void_p),
+                ("cu_seqlens", c_void_p), ("nseg", c_int), ("total_qblocks", c_int), ("x", c_void_p), ("xn", c_void_p),
+                ("qkv", c_void_p), ("attn", c_void_p), ("mlp", c_void_p), ("mrg", c_void_p), ("out", c_void_p)]
+
+
+P = C.POINTER
+# name -> (restype, argtypes); every symbol include/vlm_hip.h declares
+SIGNATURES = {
+    "vlm_abi_version": (c_int, []),
+    "vlm_gemm_bf16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    "vlm_gemv_bf16": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_float, c_int, c_void_p]),
+    "vlm_layernorm": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p]),
+    "vlm_rmsnorm_residual": (c_int, [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p]),
+    "vlm_rope2d_vision": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "vlm_mrope_kvwrite": (c_int, [c_void_p] + [c_int] * 5 + [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 3 + [c_int]
+                          + [c_void_p] * 3),
+    "vlm_attn_prefill": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] + [c_int] * 5 + [c_float, c_int, c_void_p]),
+    "vlm_attn_decode_paged": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 5
+                              + [c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "vlm_embed_gather": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "vlm_scatter_image_rows": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "vlm_cast_f32_bf16_pad": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),
+    "vlm_decode_advance": (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_int, c_void_p]),
+    "vlm_sample_workspace_bytes": (c_size_t, [c_int]),
+    "vlm_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float,
+                           c_float, c_float, c_int, c_uint, c_void_p, c_void_p]),
+    "vlm_llm_create": (c_int, [P(LlmConfig), P(c_void_p)]),
+    "vlm_llm_destroy": (c_int, [c_void_p]),
+    "vlm_llm_set_layer": (c_int, [c_void_p, c_int, P(LlmLayer)]),
+    "vlm_llm_set_globals": (c_int, [c_void_p, P(LlmGlobals)]),
+    "vlm_llm_set_kv": (c_int, [c_void_p, P(KvPool)]),
+    "vlm_llm_prefill": (c_int, [c_void_p, P(PrefillArgs), c_void_p]),
+    "vlm_llm_decode_step": (c_int, [c_void_p, P(DecodeArgs), c_void_p]),
+    "vlm_llm_decode_forward": (c_int, [c_void_p, P(DecodeArgs), c_void_p]),
+    "vlm_llm_decode_graph_build": (c_int, [c_void_p, P(DecodeArgs), c_void_p]),
+    "vlm_llm_decode_graph_launch": (c_int, [c_void_p, c_void_p]),
+    "vlm_llm_decode_launches": (c_int, [c_void_p]),
+    "vlm_vit_create": (c_int, [P(VitConfig), P(c_void_p)]),
+    "vlm_vit_destroy": (c_int, [c_void_p]),
+    "vlm_vit_set_block": (c_int, [c_void_p, c_int, P(VitBlock)]),
+    "vlm_vit_set_globals": (c_int, [c_void_p, P(VitGlobals)]),
+    "vlm_vit_forward": (c_int, [c_void_p, P(VitArgs), c_void_p]),
+}
+
+_lib = None
+
+
+class VlmHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libvlm_hip.so once; raise loudly when it is absent (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VlmHipError(
+                f"{LIB_PATH} not found - the HIP operator library is required (no CPU fallback). "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `python mlx-vlm_amd/build.py`.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        kind = {1: "bad argument", 2: "unsupported shape"}.get(rc, f"HIP error {rc - 1000}" if rc >= 1000 else "error")
+        raise VlmHipError(f"libvlm_hip {what} failed: rc={rc} ({kind})")

@@ -1,0 +1,83 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
+// Wave = 64 lanes everywhere; bf16 is handled as raw 16-bit words with
+// round-to-nearest-even conversion (v_cvt_pk_bf16_f32 on gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // storage type of a bf16 element
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+// 16-byte non-temporal (streaming) load: weights that ONE CU reads once (decode GEMV)
+__device__ __forceinline__ uint4 nt_load16(const void* p) {
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+#define VLM_OK 0
+#define VLM_ERR_ARG 1
+#define VLM_ERR_SHAPE 2
+#define VLM_ERR_HIP 1000
+
+#define VLM_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) return VLM_ERR_HIP + (int)e__;    \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// fp32 -> bf16, round to nearest even (NaN preserved) - same rule as torch/MLX.
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+// round a float through bf16 (typed-graph emulation of a materialised T tensor)
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` = >=16 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// nn.GELU(approx="fast") : x * sigmoid(1.702 x)        (reference vision.py:167)
+__device__ __forceinline__ float gelu_fast_(float x) { return x * sigmoidf_(1.702f * x); }
+// nn.GELU() exact erf form                              (reference vision.py:112)
+__device__ __forceinline__ float gelu_erf_(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// swiglu typed graph: sig -> T, g*sig -> T, *u -> T      (reference activations.py:7-9)
+__device__ __forceinline__ float swiglu_(float g, float u) {
+  float sig = rbf(sigmoidf_(g));
+  float silu = rbf(g * sig);
+  return silu * u;
+}
+
+static inline int vlm_cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,275 @@
+// Native layer loops for the Qwen2-VL hot path on MI355X: ViT forward, LLM prefill
+// and the per-token decode step (optionally captured in a hipGraph), composed from
+// the operator entry points of this library.
+//
+// Mirrors (behaviour, not code):
+//   VisionModel.__call__ / Qwen2VLVisionBlock / PatchMerger
+//       reference mlx_vlm/models/qwen2_vl/vision.py:105-120,177-194,257-290
+//   Qwen2Model / Qwen2VLDecoderLayer / Attention / LanguageModel logits
+//       reference mlx_vlm/models/qwen2_vl/language.py:66-120,136-154,170-200,514-517
+//   the decode loop body of generate_step (reference mlx_vlm/generate/ar.py:334-389,498-508)
+// The reference keeps these loops in Python over MLX's lazy graph; here one call
+// enqueues the whole chain on a HIP stream with no host work in between.
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/vlm_hip.h"
+
+#define TRY(expr)            \
+  do {                       \
+    int rc__ = (expr);       \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+namespace {
+
+struct Llm {
+  vlm_llm_config cfg;
+  std::vector<vlm_llm_layer> layers;
+  vlm_llm_globals g{};
+  vlm_kv_pool kv{};
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  int launches = 0;
+};
+
+struct Vit {
+  vlm_vit_config cfg;
+  std::vector<vlm_vit_block> blocks;
+  vlm_vit_globals g{};
+};
+
+inline char* off(void* p, size_t bytes) { return static_cast<char*>(p) + bytes; }
+
+}  // namespace
+
+extern "C" int vlm_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------ LLM
+extern "C" int vlm_llm_create(const vlm_llm_config* cfg, void** handle) {
+  if (!cfg || !handle) return 1;
+  if (cfg->hidden <= 0 || cfg->n_layers <= 0 || cfg->n_heads <= 0 || cfg->n_kv_heads <= 0 || cfg->head_dim <= 0) return 1;
+  Llm* m = new (std::nothrow) Llm();
+  if (!m) return 1;
+  m->cfg = *cfg;
+  m->layers.resize(cfg->n_layers);
+  *handle = m;
+  return 0;
+}
+
+extern "C" int vlm_llm_destroy(void* handle) {
+  Llm* m = static_cast<Llm*>(handle);
+  if (!m) return 1;
+  if (m->exec) (void)hipGraphExecDestroy(m->exec);
+  if (m->graph) (void)hipGraphDestroy(m->graph);
+  delete m;
+  return 0;
+}
+
+extern "C" int vlm_llm_set_layer(void* handle, int layer, const vlm_llm_layer* w) {
+  Llm* m = static_cast<Llm*>(handle);
+  if (!m || !w || layer < 0 || layer >= m->cfg.n_layers) return 1;
+  m->layers[layer] = *w;
+  return 0;
+}
+
+extern "C" int vlm_llm_set_globals(void* handle, const vlm_llm_globals* g) {
+  Llm* m = static_cast<Llm*>(handle);
+  if (!m || !g) return 1;
+  m->g = *g;
+  return 0;
+}
+
+extern "C" int vlm_llm_set_kv(void* handle, const vlm_kv_pool* kv) {
+  Llm* m = static_cast<Llm*>(handle);
+  if (!m || !kv) return 1;
+  m->kv = *kv;
+  return 0;
+}
+
+extern "C" int vlm_llm_prefill(void* handle, const vlm_prefill_args* a, void* stream) {
+  Llm* m = static_cast<Llm*>(handle);
+  if (!m || !a || !a->h || a->T <= 0) return 1;
+  const vlm_llm_config& c = m->cfg;
+  const int D = c.hidden, hd = c.head_dim, Hq = c.n_heads, Hkv = c.n_kv_heads;
+  const int QKV = (Hq + 2 * Hkv) * hd, T = a->T;
+  const float scale = 1.0f / sqrtf((float)hd);
+  for (int i = 0; i < c.n_layers; ++i) {
+    const vlm_llm_layer& w = m->layers[i];
+    // xn = RMSNorm(h)
+    TRY(vlm_rmsnorm_residual(a->h, nullptr, w.ln1_w, a->xn, nullptr, T, D, c.rms_eps, stream));
+    // qkv = xn Wqkv^T + b
+    TRY(vlm_gemm_bf16(a->xn, w.wqkv, w.bqkv, nullptr, a->qkv, T, QKV, D, D, D, QKV, 0, VLM_EPI_BIAS, stream));
+    // M-RoPE on q, k in place + paged KV write
+    void* kp = m->kv.kpool ? off(m->kv.kpool, (size_t)i * m->kv.layer_stride * 2) : nullptr;
+    void* vp = m->kv.vpool ? off(m->kv.vpool, (size_t)i * m->kv.layer_stride * 2) : nullptr;
+    TRY(vlm_mrope_kvwrite(a->qkv, QKV, T, Hq, Hkv, hd, a->pos_t, a->pos_h, a->pos_w, m->g.inv_freq, c.mrope_sec0,
+                          c.mrope_sec1, a->kv_seq, a->kv_slot, m->kv.block_table, m->kv.max_pages, kp, vp, stream));
+    // causal flash attention over each sequence
+    TRY(vlm_attn_prefill(a->qkv, off(a->qkv, (size_t)Hq * hd * 2), off(a->qkv, (size_t)(Hq + Hkv) * hd * 2), a->attn, QKV,
+                         QKV, QKV, Hq * hd, a->cu_seqlens, a->nseg, a->total_qblocks, Hq, Hkv, hd, scale, 1, stream));
+    // h = h + attn Wo^T
+    TRY(vlm_gemm_bf16(a->attn, w.wo, nullptr, a->h, a->h, T, D, Hq * hd, Hq * hd, Hq * hd, D, D, VLM_EPI_RESIDUAL, stream));
+    // xn = RMSNorm(h); act = swiglu(xn Wgu^T); h = h + act Wdown^T
+    TRY(vlm_rmsnorm_residual(a->h, nullptr, w.ln2_w, a->xn, nullptr, T, D, c.rms_eps, stream));
+    TRY(vlm_gemm_bf16(a->xn, w.wgu, nullptr, nullptr, a->act, T, 2 * c.inter, D, D, D, c.inter, 0, VLM_EPI_SWIGLU, stream));
+    TRY(vlm_gemm_bf16(a->act, w.wdown, nullptr, a->h, a->h, T, D, c.inter, c.inter, c.inter, D, D, VLM_EPI_RESIDUAL, stream));
+  }
+  if (a->n_last > 0) {
+    if (!a->last_rows || !a->xlast || !a->logits) return 1;
+    // gather the wanted rows, final norm, lm_head on those rows only (reference: all L rows, ar.py:358)
+    // gather = embed_gather over the residual stream viewed as a table of T rows
+    TRY(vlm_embed_gather(a->last_rows, a->h, a->xlast, a->n_last, D, D, T, stream));
+    TRY(vlm_rmsnorm_residual(a->xlast, nullptr, m->g.final_norm_w, a->xlast, nullptr, a->n_last, D, c.rms_eps, stream));
+    TRY(vlm_gemm_bf16(a->xlast, m->g.lm_head, nullptr, nullptr, a->logits, a->n_last, c.vocab, D, D, D, c.vocab, 0,
+                      VLM_EPI_NONE, stream));
+  }
+  return 0;
+}
+
+static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* launches, bool sample) {
+  const vlm_llm_config& c = m->cfg;
+  const int D = c.hidden, hd = c.head_dim, Hq = c.n_heads, Hkv = c.n_kv_heads, B = a->B;
+  const int QKV = (Hq + 2 * Hkv) * hd;
+  const float scale = 1.0f / sqrtf((float)hd);
+  int n = 0;
+  // h = embed[tok]
+  TRY(vlm_embed_gather(a->tok, m->g.embed, a->h, B, D, D, c.vocab, stream)); ++n;
+  for (int i = 0; i < c.n_layers; ++i) {
+    const vlm_llm_layer& w = m->layers[i];
+    // qkv = RMSNorm(h) Wqkv^T + b   (norm fused as GEMV prologue)
+    TRY(vlm_gemv_bf16(a->h, w.wqkv, w.bqkv, nullptr, w.ln1_w, a->qkv, B, QKV, D, D, D, QKV, 0, c.rms_eps, VLM_EPI_BIAS, stream)); ++n;
+    void* kp = off(m->kv.kpool, (size_t)i * m->kv.layer_stride * 2);
+    void* vp = off(m->kv.vpool, (size_t)i * m->kv.layer_stride * 2);
+    // rope at pos[b], write k/v at slot ctx[b] of sequence b
+    TRY(vlm_mrope_kvwrite(a->qkv, QKV, B, Hq, Hkv, hd, a->pos, a->pos, a->pos, m->g.inv_freq, c.mrope_sec0, c.mrope_sec1,
+                          nullptr, a->ctx, m->kv.block_table, m->kv.max_pages, kp, vp, stream)); ++n;
+    TRY(vlm_attn_decode_paged(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale,
+                              a->nsplit, a->part_o, a->part_ml, a->attn, Hq * hd, stream)); n += 2;
+    // h = h + attn Wo^T
+    TRY(vlm_gemv_bf16(a->attn, w.wo, nullptr, a->h, nullptr, a->h, B, D, Hq * hd, Hq * hd, Hq * hd, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
+    // act = swiglu(RMSNorm(h) Wgu^T)
+    TRY(vlm_gemv_bf16(a->h, w.wgu, nullptr, nullptr, w.ln2_w, a->act, B, 2 * c.inter, D, D, D, c.inter, 0, c.rms_eps, VLM_EPI_SWIGLU, stream)); ++n;
+    // h = h + act Wdown^T
+    TRY(vlm_gemv_bf16(a->act, w.wdown, nullptr, a->h, nullptr, a->h, B, D, c.inter, c.inter, c.inter, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
+  }
+  // logits = RMSNorm(h) lm_head^T
+  TRY(vlm_gemv_bf16(a->h, m->g.lm_head, nullptr, nullptr, m->g.final_norm_w, a->logits, B, c.vocab, D, D, D, c.vocab, 0,
+                    c.rms_eps, VLM_EPI_NONE, stream)); ++n;
+  if (sample) {
+    TRY(vlm_sample(a->logits, c.vocab, B, c.vocab, a->logprobs, a->scratch, c.vocab, a->tok, a->sample_ws, a->temperature,
+                   a->top_p, a->min_p, a->top_k, a->seed, a->step, stream)); n += 3;
+    TRY(vlm_decode_advance(a->ctx, a->pos, a->tok, a->out_ring, a->ring_len, a->step, B, stream)); ++n;
+  }
+  if (launches) *launches = n;
+  return 0;
+}
+
+extern "C" int vlm_llm_decode_step(void* handle, const vlm_decode_args* a, void* stream) {
+  Llm* m = static_cast<Llm*>(handle);
+  if (!m || !a || a->B <= 0 || !m->kv.kpool) return 1;
+  return decode_impl(m, a, stream, &m->launches, true);
+}
+
+// embeddings -> logits only (the module-contract path: language_model(y, cache=...) at L == 1;
+// the caller samples and advances ctx/pos itself)
+extern "C" int vlm_llm_decode_forward(void* handle, const vlm_decode_args* a, void* stream) {
+  Llm* m = static_cast<Llm*>(handle);
+  if (!m || !a || a->B <= 0 || !m->kv.kpool) return 1;
+  return decode_impl(m, a, stream, nullptr, false);
+}
+
+extern "C" int vlm_llm_decode_graph_build(void* handle, const vlm_decode_args* a, void* stream) {
+  Llm* m = static_cast<Llm*>(handle);
+  if (!m || !a || a->B <= 0 || !m->kv.kpool || !stream) return 1;
+  if (m->exec) { (void)hipGraphExecDestroy(m->exec); m->exec = nullptr; }
+  if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) return 1000 + (int)e;
+  int rc = decode_impl(m, a, stream, &m->launches, true);
+  hipGraph_t g = nullptr;
+  e = hipStreamEndCapture(st, &g);
+  if (rc != 0) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess) return 1000 + (int)e;
+  m->graph = g;
+  e = hipGraphInstantiate(&m->exec, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) return 1000 + (int)e;
+  return 0;
+}
+
+extern "C" int vlm_llm_decode_graph_launch(void* handle, void* stream) {
+  Llm* m = static_cast<Llm*>(handle);
+  if (!m || !m->exec) return 1;
+  hipError_t e = hipGraphLaunch(m->exec, (hipStream_t)stream);
+  return e == hipSuccess ? 0 : 1000 + (int)e;
+}
+
+extern "C" int vlm_llm_decode_launches(void* handle) {
+  Llm* m = static_cast<Llm*>(handle);
+  return m ? m->launches : -1;
+}
+
+// ------------------------------------------------------------------ ViT
+extern "C" int vlm_vit_create(const vlm_vit_config* cfg, void** handle) {
+  if (!cfg || !handle || cfg->depth <= 0 || cfg->embed_dim <= 0 || cfg->n_heads <= 0) return 1;
+  Vit* v = new (std::nothrow) Vit();
+  if (!v) return 1;
+  v->cfg = *cfg;
+  v->blocks.resize(cfg->depth);
+  *handle = v;
+  return 0;
+}
+
+extern "C" int vlm_vit_destroy(void* handle) {
+  Vit* v = static_cast<Vit*>(handle);
+  if (!v) return 1;
+  delete v;
+  return 0;
+}
+
+extern "C" int vlm_vit_set_block(void* handle, int i, const vlm_vit_block* w) {
+  Vit* v = static_cast<Vit*>(handle);
+  if (!v || !w || i < 0 || i >= v->cfg.depth) return 1;
+  v->blocks[i] = *w;
+  return 0;
+}
+
+extern "C" int vlm_vit_set_globals(void* handle, const vlm_vit_globals* g) {
+  Vit* v = static_cast<Vit*>(handle);
+  if (!v || !g) return 1;
+  v->g = *g;
+  return 0;
+}
+
+extern "C" int vlm_vit_forward(void* handle, const vlm_vit_args* a, void* stream) {
+  Vit* v = static_cast<Vit*>(handle);
+  if (!v || !a || !a->patches || a->N <= 0) return 1;
+  const vlm_vit_config& c = v->cfg;
+  const int E = c.embed_dim, H = c.n_heads, hd = E / H, N = a->N, MH = c.mlp_hidden;
+  const int mm = c.merge * c.merge;
+  if (N % mm != 0) return 2;
+  const float scale = 1.0f / sqrtf((float)hd);
+  // patch projection (Conv3d with stride == kernel is a GEMM)
+  TRY(vlm_gemm_bf16(a->patches, v->g.wpatch, nullptr, nullptr, a->x, N, E, c.patch_k, c.patch_k, c.patch_k, E, 0, VLM_EPI_NONE, stream));
+  for (int i = 0; i < c.depth; ++i) {
+    const vlm_vit_block& w = v->blocks[i];
+    TRY(vlm_layernorm(a->x, w.ln1_w, w.ln1_b, a->xn, N, E, c.ln_eps, stream));
+    TRY(vlm_gemm_bf16(a->xn, w.wqkv, w.bqkv, nullptr, a->qkv, N, 3 * E, E, E, E, 3 * E, 0, VLM_EPI_BIAS, stream));
+    TRY(vlm_rope2d_vision(a->qkv, a->cos_tab, a->sin_tab, N, H, hd, 3 * E, stream));
+    TRY(vlm_attn_prefill(a->qkv, off(a->qkv, (size_t)E * 2), off(a->qkv, (size_t)2 * E * 2), a->attn, 3 * E, 3 * E, 3 * E, E,
+                         a->cu_seqlens, a->nseg, a->total_qblocks, H, H, hd, scale, 0, stream));
+    TRY(vlm_gemm_bf16(a->attn, w.wproj, w.bproj, a->x, a->x, N, E, E, E, E, E, E, VLM_EPI_BIAS | VLM_EPI_RESIDUAL, stream));
+    TRY(vlm_layernorm(a->x, w.ln2_w, w.ln2_b, a->xn, N, E, c.ln_eps, stream));
+    TRY(vlm_gemm_bf16(a->xn, w.wfc1, w.bfc1, nullptr, a->mlp, N, MH, E, E, E, MH, 0, VLM_EPI_BIAS | VLM_EPI_GELU_FAST, stream));
+    TRY(vlm_gemm_bf16(a->mlp, w.wfc2, w.bfc2, a->x, a->x, N, E, MH, MH, MH, E, E, VLM_EPI_BIAS | VLM_EPI_RESIDUAL, stream));
+  }
+  // PatchMerger: LN -> [N/4, 4E] -> Linear + GELU(erf) -> Linear
+  TRY(vlm_layernorm(a->x, v->g.ln_q_w, v->g.ln_q_b, a->xn, N, E, c.ln_eps, stream));
+  const int Nm = N / mm, EM = E * mm;
+  TRY(vlm_gemm_bf16(a->xn, v->g.wm0, v->g.bm0, nullptr, a->mrg, Nm, EM, EM, EM, EM, EM, 0, VLM_EPI_BIAS | VLM_EPI_GELU_ERF, stream));
+  TRY(vlm_gemm_bf16(a->mrg, v->g.wm2, v->g.bm2, nullptr, a->out, Nm, c.out_dim, EM, EM, EM, c.out_dim, 0, VLM_EPI_BIAS, stream));
+  return 0;
+}

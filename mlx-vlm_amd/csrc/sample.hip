@@ -1,0 +1,321 @@
+// Sampler kernels for gfx950 over the vocabulary row (V = 151,936 for Qwen2-VL):
+//   logprobs = logits - logsumexp(logits)          (reference mlx_vlm/generate/ar.py:368)
+//   greedy   = argmax(logprobs), lowest index wins  (reference mlx_vlm/sample_utils.py:63-64)
+//   top-p / min-p / top-k filters                   (sample_utils.py:289-318, 266-286, 169-175)
+//   categorical(logprobs / temp) by Gumbel-max      (sample_utils.py:385-387)
+// The row is 300 KB: everything is a couple of passes of 16-byte loads with
+// wavefront-shuffle reductions; logprobs are produced in the logits dtype (bf16)
+// exactly as the reference does (lse rounded to bf16, then the difference rounded).
+//
+// Because logprobs are bf16 there are only 65,536 distinct keys: top-k and top-p
+// are done EXACTLY with a 64 Ki-bin histogram (count and probability mass per
+// key) instead of a sort - a radix-select that fits the LDS-less L2-resident row.
+#include "common.cuh"
+#include "../../include/vlm_hip.h"
+
+namespace {
+
+constexpr int NBLK = 64;  // blocks per vocabulary row
+
+// order-preserving map bf16 bits -> uint16 (ascending)
+__device__ __forceinline__ uint32_t bf_key(bf16_t b) { return (b & 0x8000u) ? (uint32_t)(~b & 0xffffu) : (uint32_t)(b | 0x8000u); }
+__device__ __forceinline__ bf16_t key_bf(uint32_t k) { return (k & 0x8000u) ? (bf16_t)(k & 0x7fffu) : (bf16_t)(~k & 0xffffu); }
+
+__global__ __launch_bounds__(256) void lse_partial_kernel(const bf16_t* __restrict__ logits, int ld, int V,
+                                                          float* __restrict__ ws) {
+  __shared__ float red[16];
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const int per = ((V + NBLK - 1) / NBLK + 7) & ~7;
+  const int lo = blk * per, hi = min(V, lo + per);
+  const bf16_t* row = logits + (size_t)b * ld;
+  float m = -INFINITY;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) m = fmaxf(m, bf2f(row[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+  if (m > -INFINITY)
+    for (int i = lo + threadIdx.x; i < hi; i += 256) s += expf(bf2f(row[i]) - m);
+  s = block_sum(s, red + 4);
+  if (threadIdx.x == 0) { ws[((size_t)b * NBLK + blk) * 2] = m; ws[((size_t)b * NBLK + blk) * 2 + 1] = s; }
+}
+
+// logprobs (bf16) + per-block argmax candidate
+__global__ __launch_bounds__(256) void logprob_argmax_kernel(const bf16_t* __restrict__ logits, int ld, int V,
+                                                             const float* __restrict__ ws, bf16_t* __restrict__ logprobs,
+                                                             int ldlp, float* __restrict__ cand_v, int* __restrict__ cand_i) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int b = blockIdx.y, blk = blockIdx.x;
+  float m = -INFINITY;
+  for (int i = 0; i < NBLK; ++i) m = fmaxf(m, ws[((size_t)b * NBLK + i) * 2]);
+  float s = 0.f;
+  for (int i = 0; i < NBLK; ++i) {
+    const float mi = ws[((size_t)b * NBLK + i) * 2];
+    if (mi > -INFINITY) s += ws[((size_t)b * NBLK + i) * 2 + 1] * expf(mi - m);
+  }
+  const float lse = rbf(m + logf(s));          // logsumexp materialised in the logits dtype
+  const int per = ((V + NBLK - 1) / NBLK + 7) & ~7;
+  const int lo = blk * per, hi = min(V, lo + per);
+  const bf16_t* row = logits + (size_t)b * ld;
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    const bf16_t lpb = f2bf(bf2f(row[i]) - lse);
+    if (logprobs) logprobs[(size_t)b * ldlp + i] = lpb;
+    const float lp = bf2f(lpb);
+    if (lp > best || (lp == best && i < besti)) { best = lp; besti = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(besti, o, 64);
+    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = besti; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < besti)) { best = sv[w]; besti = si[w]; }
+    cand_v[(size_t)b * NBLK + blk] = best;
+    cand_i[(size_t)b * NBLK + blk] = besti;
+  }
+}
+
+__global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restrict__ cand_v, const int* __restrict__ cand_i,
+                                                          int* __restrict__ tok) {
+  const int b = blockIdx.x;
+  float best = cand_v[(size_t)b * NBLK + threadIdx.x];
+  int besti = cand_i[(size_t)b * NBLK + threadIdx.x];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(besti, o, 64);
+    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+  }
+  if (threadIdx.x == 0) tok[b] = besti;
+}
+
+// ------------------------------------------------------------------------------------------
+// General sampler: one 1024-thread workgroup per row (the row is L2 resident).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float hash_uniform(uint32_t seed, uint32_t step, uint32_t row, uint32_t idx) {
+  uint32_t x = seed ^ 0x9E3779B9u;
+  x += (step + 1u) * 0x85EBCA6Bu;
+  x ^= (row + 1u) * 0xC2B2AE35u;
+  x += idx * 0x27D4EB2Fu;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+// exclusive prefix over the 1024 threads of the block (thread order); `total` = block sum
+template <typename T>
+__device__ __forceinline__ T block_excl_scan(T v, T* lds /* >= 17 */, T* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const T n = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += n;
+  }
+  __syncthreads();
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    T run = 0;
+    for (int w = 0; w < 16; ++w) { const T t = lds[w]; lds[w] = run; run += t; }
+    lds[16] = run;
+  }
+  __syncthreads();
+  *total = lds[16];
+  return inc - v + lds[wave];
+}
+
+constexpr bf16_t NEG_INF_BF = 0xff80u;
+
+// Among the elements whose key == tk (in index order) keep ranks [keep_lo, keep_hi), mask the rest.
+__device__ __forceinline__ void mask_equal_by_rank(bf16_t* lp, int V, uint32_t tk, uint32_t keep_lo, uint32_t keep_hi,
+                                                   uint32_t* lds) {
+  const int chunk = (V + 1023) / 1024;
+  const int lo = threadIdx.x * chunk, hi = min(V, lo + chunk);
+  uint32_t cnt = 0;
+  for (int i = lo; i < hi; ++i) cnt += (bf_key(lp[i]) == tk);
+  uint32_t total;
+  uint32_t rank = block_excl_scan<uint32_t>(cnt, lds, &total);
+  for (int i = lo; i < hi; ++i)
+    if (bf_key(lp[i]) == tk) {
+      if (rank < keep_lo || rank >= keep_hi) lp[i] = NEG_INF_BF;
+      ++rank;
+    }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __restrict__ lp_in, bf16_t* __restrict__ lp_all,
+                                                             int ldlp, int V, uint32_t* __restrict__ hist_all,
+                                                             float top_p, float min_p, int top_k, float temp,
+                                                             uint32_t seed, const int* __restrict__ step_ptr,
+                                                             int* __restrict__ tok) {
+  __shared__ float red[32];
+  __shared__ int redi[32];
+  __shared__ uint32_t s_thr_key, s_thr_keep;
+  __shared__ float s_f;
+  __shared__ uint32_t scan_u[17];
+  __shared__ float scan_f[17];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  bf16_t* lp = lp_all + (size_t)b * ldlp;           // scratch copy that the filters mask in place
+  uint32_t* hist = hist_all + (size_t)b * 65536;
+  for (int i = tid; i < V; i += 1024) lp[i] = lp_in[(size_t)b * ldlp + i];
+  __syncthreads();
+
+  auto build_hist = [&]() {
+    for (int i = tid; i < 65536; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < V; i += 1024) atomicAdd(&hist[bf_key(lp[i])], 1u);
+    __syncthreads();
+  };
+
+  // ---- top-p (sample_utils.py:289-318): keep x_i iff cumulative prob (ascending, inclusive) > 1 - top_p
+  if (top_p > 0.f && top_p < 1.f) {
+    build_hist();
+    // each thread owns 64 consecutive keys (ascending); prefix of the probability mass over threads
+    float mass = 0.f;
+    for (int j = 0; j < 64; ++j) {
+      const uint32_t k = tid * 64 + j, c = hist[k];
+      if (c) mass += (float)c * expf(bf2f(key_bf(k)));
+    }
+    float total;
+    float cum = block_excl_scan<float>(mass, scan_f, &total);
+    const float thr = 1.f - top_p;
+    if (tid == 0) { s_thr_key = 65536; s_thr_keep = 0; }
+    __syncthreads();
+    if (cum <= thr && cum + mass > thr) {   // the crossing is inside this thread's keys (first such thread only)
+      for (int j = 0; j < 64; ++j) {
+        const uint32_t k = tid * 64 + j, c = hist[k];
+        if (!c) continue;
+        const float pk = expf(bf2f(key_bf(k)));
+        if (pk == 0.f) continue;
+        if (cum + (float)c * pk > thr) {
+          uint32_t r = 0;
+          while (r < c && !(cum + (float)(r + 1) * pk > thr)) ++r;
+          s_thr_key = k; s_thr_keep = c - r;
+          break;
+        }
+        cum += (float)c * pk;
+      }
+    }
+    __syncthreads();
+    const uint32_t tk = s_thr_key, keep = s_thr_keep;
+    if (tk < 65536) {
+      const uint32_t c = hist[tk];
+      // ascending stable sort: equal keys are in index order and the cumulative grows with the index,
+      // so the LAST `keep` of the bin survive
+      if (keep < c) mask_equal_by_rank(lp, V, tk, c - keep, c, scan_u);
+      for (int i = tid; i < V; i += 1024)
+        if (bf_key(lp[i]) < tk) lp[i] = NEG_INF_BF;
+    }
+    __syncthreads();
+  }
+
+  // ---- min-p (sample_utils.py:266-286): drop x < max + log(min_p)
+  if (min_p > 0.f) {
+    float m = -INFINITY;
+    for (int i = tid; i < V; i += 1024) m = fmaxf(m, bf2f(lp[i]));
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+      float mm = red[0];
+      for (int w = 1; w < 16; ++w) mm = fmaxf(mm, red[w]);
+      s_f = mm + logf(min_p);
+    }
+    __syncthreads();
+    const float thr = s_f;
+    for (int i = tid; i < V; i += 1024)
+      if (bf2f(lp[i]) < thr) lp[i] = NEG_INF_BF;
+    __syncthreads();
+  }
+
+  // ---- top-k (sample_utils.py:169-175): keep the k largest (ties at the k-th value: lowest indices)
+  if (top_k > 0 && top_k < V) {
+    build_hist();
+    // descending walk: thread t owns keys 65535 - 64 t - j
+    uint32_t cnt = 0;
+    for (int j = 0; j < 64; ++j) cnt += hist[65535 - (tid * 64 + j)];
+    uint32_t total;
+    uint32_t acc = block_excl_scan<uint32_t>(cnt, scan_u, &total);
+    if (tid == 0) { s_thr_key = 0; s_thr_keep = 0xffffffffu; }
+    __syncthreads();
+    if (acc < (uint32_t)top_k && acc + cnt >= (uint32_t)top_k) {
+      for (int j = 0; j < 64; ++j) {
+        const uint32_t k = 65535 - (tid * 64 + j), c = hist[k];
+        if (acc + c >= (uint32_t)top_k) { s_thr_key = k; s_thr_keep = (uint32_t)top_k - acc; break; }
+        acc += c;
+      }
+    }
+    __syncthreads();
+    const uint32_t tk = s_thr_key, keep = s_thr_keep;
+    if (keep != 0xffffffffu) {
+      if (keep < hist[tk]) mask_equal_by_rank(lp, V, tk, 0, keep, scan_u);
+      for (int i = tid; i < V; i += 1024)
+        if (bf_key(lp[i]) < tk) lp[i] = NEG_INF_BF;
+    }
+    __syncthreads();
+  }
+
+  // ---- categorical(logprobs / temp) via Gumbel-max with the counter hash RNG
+  const uint32_t step = (uint32_t)(step_ptr ? *step_ptr : 0);
+  const float it = 1.0f / temp;
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int i = tid; i < V; i += 1024) {
+    const float x = bf2f(lp[i]) * it;
+    const float u = hash_uniform(seed, step, (uint32_t)b, (uint32_t)i);
+    const float z = x + (-logf(-logf(u)));
+    if (z > best || (z == best && i < besti)) { best = z; besti = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(besti, o, 64);
+    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+  }
+  if ((tid & 63) == 0) { red[tid >> 6] = best; redi[tid >> 6] = besti; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (red[w] > best || (red[w] == best && redi[w] < besti)) { best = red[w]; besti = redi[w]; }
+    tok[b] = besti;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t vlm_sample_workspace_bytes(int B) { return (size_t)B * (NBLK * 4 * sizeof(float) + 65536 * sizeof(uint32_t)); }
+
+// workspace layout: [B][NBLK][2] f32 lse partials | [B][NBLK] f32 cand_v | [B][NBLK] i32 cand_i | [B][65536] u32 hist
+extern "C" int vlm_sample(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
+                          void* workspace, float temperature, float top_p, float min_p, int top_k, unsigned seed,
+                          const void* step_ptr, void* stream) {
+  if (!logits || !tok || !workspace || B <= 0 || V <= 0) return VLM_ERR_ARG;
+  if (temperature < 0.f) return VLM_ERR_ARG;
+  if (temperature > 0.f && (!logprobs || !scratch)) return VLM_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  float* cand_v = ws + (size_t)B * NBLK * 2;
+  int* cand_i = (int*)(cand_v + (size_t)B * NBLK);
+  uint32_t* hist = (uint32_t*)(cand_i + (size_t)B * NBLK);
+  hipLaunchKernelGGL(lse_partial_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws);
+  VLM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(logprob_argmax_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws,
+                     (bf16_t*)logprobs, ldlp, cand_v, cand_i);
+  VLM_CHECK_LAUNCH();
+  if (temperature == 0.f) {
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(B), dim3(64), 0, st, cand_v, cand_i, (int*)tok);
+  } else {
+    hipLaunchKernelGGL(sample_filter_kernel, dim3(B), dim3(1024), 0, st, (const bf16_t*)logprobs, (bf16_t*)scratch, ldlp,
+                       V, hist, top_p, min_p, top_k, temperature, seed, (const int*)step_ptr, (int*)tok);
+  }
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}

@@ -1,0 +1,397 @@
+"""Generation engine with the reference's Python API for the hot path:
+
+    generate_step    reference mlx_vlm/generate/ar.py:151-515
+    stream_generate  reference mlx_vlm/generate/dispatch.py:694-1105
+    generate         reference mlx_vlm/generate/dispatch.py:1108-1228
+    batch_generate   reference mlx_vlm/generate/ar.py:2890-3096 (static batches)
+    GenerationResult reference mlx_vlm/generate/common.py:216-240
+
+The device work of a decode step is one hipGraph replay (embedding gather ->
+28 x [RMSNorm+QKV GEMV, M-RoPE + paged KV write, split-K paged attention, o_proj
+GEMV + residual, RMSNorm + gate/up GEMV + SwiGLU, down GEMV + residual] -> final
+norm + lm_head GEMV -> logsumexp/sample -> position advance), all state device
+resident.  The host only enqueues replays `lookahead` steps ahead of the token it
+is handing to the caller and reads tokens back through pinned memory - the same
+double-buffering contract as the reference's mx.async_eval one-step lookahead
+(ar.py:498-508), generalised to a configurable depth.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Any, Callable, Generator, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import ops
+from .models import cache as cache_mod
+from .sample_utils import Sampler, make_sampler
+
+DEFAULT_MAX_TOKENS = 2048          # reference generate/common.py:19-24
+DEFAULT_TEMPERATURE = 0.0
+DEFAULT_TOP_P = 1.0
+DEFAULT_TOP_K = 0
+DEFAULT_MIN_P = 0.0
+DEFAULT_PREFILL_STEP_SIZE = 2048
+
+
+@dataclass
+class GenerationResult:
+    text: str = ""
+    token: Optional[int] = None
+    logprobs: Optional[Any] = None
+    prompt_tokens: int = 0
+    generation_tokens: int = 0
+    total_tokens: int = 0
+    prompt_tps: float = 0.0
+    generation_tps: float = 0.0
+    peak_memory: float = 0.0
+    cached_tokens: int = 0
+    finish_reason: Optional[str] = None
+
+
+@dataclass
+class BatchStats:
+    """reference ar.py:863-884"""
+    prompt_tokens: int = 0
+    prompt_tps: float = 0.0
+    prompt_time: float = 0.0
+    generation_tokens: int = 0
+    generation_tps: float = 0.0
+    generation_time: float = 0.0
+    peak_memory: float = 0.0
+
+
+@dataclass
+class BatchResponse:
+    """reference ar.py:887-902"""
+    texts: List[str]
+    stats: BatchStats
+    tokens: List[List[int]] = field(default_factory=list)
+    image_sizes: Optional[List[Tuple[int, int]]] = None
+
+
+def _peak_gb():
+    return torch.cuda.max_memory_allocated() / 1e9 if torch.cuda.is_available() else 0.0
+
+
+class _TokenPipe:
+    """Pinned-memory token read-back: one slot + event per generated token index."""
+
+    def __init__(self, B: int, cap: int):
+        self.buf = torch.empty(cap, B, dtype=torch.int32).pin_memory()
+        self.events: List[Optional[torch.cuda.Event]] = [None] * cap
+        self.cap = cap
+
+    def push(self, idx: int, src: torch.Tensor):
+        self.buf[idx % self.cap].copy_(src, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[idx % self.cap] = ev
+
+    def get(self, idx: int) -> np.ndarray:
+        self.events[idx % self.cap].synchronize()
+        return self.buf[idx % self.cap].numpy().copy()
+
+
+def _resolve_sampler(sampler, temperature, top_p, min_p, top_k, seed) -> Sampler:
+    if sampler is None:
+        return make_sampler(temp=temperature, top_p=top_p, min_p=min_p, top_k=top_k, seed=seed)
+    if isinstance(sampler, Sampler):
+        return sampler
+    raise NotImplementedError("custom Python sampler callables are not supported by the fused decode graph; "
+                              "pass a mlx_vlm_amd.sample_utils.Sampler (make_sampler)")
+
+
+def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEFAULT_MAX_TOKENS,
+                  temperature: float = DEFAULT_TEMPERATURE, top_p: float = DEFAULT_TOP_P, min_p: float = DEFAULT_MIN_P,
+                  top_k: int = DEFAULT_TOP_K, prompt_cache: Optional[List[Any]] = None, sampler=None,
+                  logits_processors=None, prefill_step_size: Optional[int] = DEFAULT_PREFILL_STEP_SIZE,
+                  seed: Optional[int] = None, lookahead: int = 4, return_logprobs: bool = True, use_graph: bool = True,
+                  **kwargs) -> Generator[Tuple[int, Any], None, None]:
+    """Yield (token, logprobs) like the reference's generate_step (ar.py:151-515) for ONE sequence.
+
+    input_ids [1, L]; pixel_values / mask as produced by prepare_inputs; extra kwargs
+    (image_grid_thw, ...) are forwarded to model.get_input_embeddings.  logprobs is a device
+    bf16 [V] tensor (None when return_logprobs=False)."""
+    if logits_processors:
+        raise NotImplementedError("logits_processors are outside the built hot path (SURVEY §8a21)")
+    for k in ("repetition_penalty", "presence_penalty", "frequency_penalty", "logit_bias"):
+        if kwargs.pop(k, None):
+            raise NotImplementedError(f"{k} is outside the built hot path")
+    for k in ("repetition_context_size", "presence_context_size", "frequency_context_size", "max_kv_size", "kv_bits",
+              "kv_group_size", "quantized_kv_start", "draft_model", "verbose", "thinking_budget_criteria",
+              "kv_quant_scheme", "prompt_cache_checkpoint", "prompt_cache_checkpoint_len"):
+        kwargs.pop(k, None)
+    smp = _resolve_sampler(sampler, temperature, top_p, min_p, top_k, seed)
+    sargs = smp.engine_args()
+    lm = model.language_model
+
+    ids = input_ids.detach().cpu().numpy() if isinstance(input_ids, torch.Tensor) else np.asarray(input_ids)
+    if ids.ndim == 1:
+        ids = ids[None]
+    if ids.shape[0] != 1:
+        raise ValueError("generate_step handles one sequence; use batch_generate for batches")
+
+    f = model.get_input_embeddings(ids, pixel_values, mask=mask, **kwargs)
+    own_cache = prompt_cache is None
+    if own_cache:
+        prompt_cache = cache_mod.make_prompt_cache(lm)
+    emb = f.inputs_embeds
+    L = emb.shape[1]
+    pos = np.asarray(f.position_ids)
+    if pos.ndim == 2:
+        pos = np.broadcast_to(pos[None], (3,) + pos.shape)
+    logits = lm.prefill(emb.reshape(L, -1), pos.reshape(3, L), [prompt_cache], [L], "last", reserve_extra=max_tokens + 2)
+    step0 = torch.zeros(1, dtype=torch.int32, device=logits.device)
+    tok0, lp0 = ops.sample(logits, step=step0, want_logprobs=return_logprobs, **sargs)
+
+    deltas = np.asarray(f.rope_deltas).reshape(-1)[:1]
+    st = lm.decode_begin([prompt_cache], tok0, deltas, max_new_tokens=max_tokens + 1)
+    st.step.fill_(1)  # sampling step counter: token 0 used step 0
+    seq = prompt_cache[0]._seq
+    base_offset = seq.offset
+
+    lookahead = max(1, min(int(lookahead), st.ring_len - 1))
+    pipe = _TokenPipe(1, cap=lookahead + 2)
+    pipe.push(0, tok0)
+    lps: List[Optional[torch.Tensor]] = [lp0[0] if lp0 is not None else None] + [None] * (lookahead + 1)
+    issued = 0   # decode steps enqueued; step s (0-based) produces generated token s + 1
+    n = 0
+    try:
+        while n < max_tokens:
+            while issued < min(n + lookahead, max_tokens - 1):
+                lm.decode_run(st, 1, sargs, use_graph=use_graph)
+                issued += 1
+                pipe.push(issued, st.tok)
+                if return_logprobs:
+                    lps[issued % (lookahead + 2)] = st.logprobs[0].clone()
+            tok = int(pipe.get(n)[0])
+            yield tok, lps[n % (lookahead + 2)]
+            n += 1
+    finally:
+        # the cache holds prompt + the tokens that were FED back (every yielded token except the last)
+        seq.offset = base_offset + max(0, min(n, issued + 1) - 1)
+        if own_cache:
+            seq.release()
+
+
+# ---------------------------------------------------------------------------------------------
+def _tokenizer_of(processor):
+    return processor.tokenizer if hasattr(processor, "tokenizer") else processor
+
+
+def stream_generate(model, processor, prompt: Optional[str] = None, image=None, audio=None, video=None,
+                    **kwargs) -> Generator[GenerationResult, None, None]:
+    """reference dispatch.py:694-1105 (no APC / vision-cache / prefix-cache reuse: SURVEY §2.1 out of scope).
+    Timing semantics kept: prompt_tps = prompt tokens / wall time to the first token (ViT + projector + LLM
+    prefill + first sample); generation_tps = tokens / wall time since the first token."""
+    from .utils import make_streaming_detokenizer, prepare_inputs
+
+    tokenizer = _tokenizer_of(processor) if processor is not None else None
+    kwargs.pop("verbose", None)
+    skip_special_tokens = kwargs.pop("skip_special_tokens", False)
+    skip_ids = set(tokenizer.all_special_ids) if (skip_special_tokens and hasattr(tokenizer, "all_special_ids")) else set()
+    for k in ("thinking_budget", "thinking_end_token", "thinking_start_token", "enable_thinking", "resize_shape",
+              "vision_cache", "prompt_cache_state", "apc_manager", "apc_tenant", "eos_tokens", "stopping_criteria"):
+        kwargs.pop(k, None)
+    if audio or video:
+        raise NotImplementedError("audio / video inputs are outside the built hot path")
+
+    if kwargs.get("input_ids", None) is not None:          # pre-tokenised bypass, dispatch.py:759-762
+        input_ids = kwargs.pop("input_ids")
+        pixel_values = kwargs.pop("pixel_values", None)
+        mask = kwargs.pop("mask", None)
+    else:
+        inputs = prepare_inputs(processor, images=image, prompts=prompt)
+        input_ids = inputs["input_ids"]
+        pixel_values = inputs.get("pixel_values")
+        mask = inputs.get("attention_mask")
+        kwargs.update({k: v for k, v in inputs.items() if k not in ("input_ids", "pixel_values", "attention_mask")})
+
+    ids = np.asarray(input_ids if not isinstance(input_ids, torch.Tensor) else input_ids.cpu())
+    total_prompt_tokens = int(ids.size)
+    detok = make_streaming_detokenizer(processor) if processor is not None else None
+    stop = getattr(tokenizer, "stopping_criteria", None) if tokenizer is not None else None
+
+    gen = generate_step(ids, model, pixel_values, mask, **kwargs)
+    tic = time.perf_counter()
+    finish_reason = None
+    token, logprobs, n = None, None, -1
+    prompt_tps = 0.0
+    for n, (token, logprobs) in enumerate(gen):
+        if n == 0:
+            prompt_time = time.perf_counter() - tic
+            prompt_tps = total_prompt_tokens / prompt_time
+            tic = time.perf_counter()
+        if stop is not None and stop(token):
+            finish_reason = "stop"
+            break
+        if detok is not None:
+            detok.add_token(token, skip_special_token_ids=skip_ids)
+        yield GenerationResult(text=detok.last_segment if detok else "", token=token, logprobs=logprobs,
+                               prompt_tokens=total_prompt_tokens, generation_tokens=n + 1,
+                               total_tokens=total_prompt_tokens + n + 1, prompt_tps=prompt_tps,
+                               generation_tps=(n + 1) / max(time.perf_counter() - tic, 1e-9), peak_memory=_peak_gb())
+    else:
+        finish_reason = "length"
+    gen.close()
+    if n < 0:
+        yield GenerationResult(prompt_tokens=total_prompt_tokens, total_tokens=total_prompt_tokens,
+                               peak_memory=_peak_gb(), finish_reason="length")
+        return
+    if detok is not None:
+        detok.finalize()
+    yield GenerationResult(text=detok.last_segment if detok else "", token=token, logprobs=logprobs,
+                           prompt_tokens=total_prompt_tokens, generation_tokens=n + 1,
+                           total_tokens=total_prompt_tokens + n + 1, prompt_tps=prompt_tps,
+                           generation_tps=(n + 1) / max(time.perf_counter() - tic, 1e-9), peak_memory=_peak_gb(),
+                           finish_reason=finish_reason)
+
+
+def generate(model, processor, prompt: Optional[str] = None, image=None, audio=None, video=None, verbose: bool = False,
+             **kwargs) -> GenerationResult:
+    """reference dispatch.py:1108-1228."""
+    tokenizer = _tokenizer_of(processor) if processor is not None else None
+    eos_tokens = kwargs.get("eos_tokens", None)
+    stopping_criteria = kwargs.get("stopping_criteria", None)
+    if tokenizer is not None and hasattr(tokenizer, "stopping_criteria"):
+        if eos_tokens is not None:
+            tokenizer.stopping_criteria.add_eos_token_ids(eos_tokens)
+        elif stopping_criteria is not None:
+            if not callable(stopping_criteria):
+                raise ValueError("stopping_criteria must be an instance of StoppingCriteria or a callable")
+            tokenizer.stopping_criteria = stopping_criteria
+        else:
+            tokenizer.stopping_criteria.reset(model.config.eos_token_id)
+    text, last = "", None
+    for r in stream_generate(model, processor, prompt, image, audio, video, **kwargs):
+        if verbose:
+            print(r.text, end="", flush=True)
+        text += r.text
+        last = r
+    if last is None:
+        return GenerationResult(text=text, peak_memory=_peak_gb())
+    if verbose:
+        print("\n" + "=" * 10)
+        print(f"Prompt: {last.prompt_tokens} tokens, {last.prompt_tps:.3f} tokens-per-sec")
+        print(f"Generation: {last.generation_tokens} tokens, {last.generation_tps:.3f} tokens-per-sec")
+        print(f"Peak memory: {last.peak_memory:.3f} GB")
+    return GenerationResult(text=text, token=last.token, logprobs=last.logprobs, prompt_tokens=last.prompt_tokens,
+                            generation_tokens=last.generation_tokens, total_tokens=last.total_tokens,
+                            prompt_tps=last.prompt_tps, generation_tps=last.generation_tps, peak_memory=last.peak_memory,
+                            cached_tokens=last.cached_tokens, finish_reason=last.finish_reason)
+
+
+# ---------------------------------------------------------------------------------------------
+def batch_generate_ids(model, input_ids_list: List[np.ndarray], pixel_values_list: List[Any], grids: List[Any], *,
+                       max_tokens: int = 128, stop_ids=(), sampler: Optional[Sampler] = None, lookahead: int = 4,
+                       use_graph: bool = True) -> Tuple[List[List[int]], BatchStats]:
+    """Pre-tokenised batched generation: the requests are processed in decode batches of up to 8 sequences.
+    One ViT call over the concatenated patches of the batch (as the reference does per shape group,
+    ar.py:3165-3167), one varlen LLM prefill, then batched graph decode.  -> (tokens per request, stats)."""
+    lm = model.language_model
+    smp = sampler or make_sampler()
+    sargs = smp.engine_args()
+    stats = BatchStats()
+    outs: List[List[int]] = [[] for _ in input_ids_list]
+    stop_ids = set(stop_ids)
+    order = list(range(len(input_ids_list)))
+    i = 0
+    while i < len(order):
+        rem = len(order) - i
+        B = 8 if rem >= 8 else 4 if rem >= 4 else 2 if rem >= 2 else 1
+        idxs = order[i:i + B]
+        i += B
+        t0 = time.perf_counter()
+        embs, poss, lens, deltas = [], [], [], []
+        pix = [pixel_values_list[j] for j in idxs if pixel_values_list[j] is not None]
+        feats_all = None
+        if pix:
+            grid_all = np.concatenate([np.asarray(grids[j]) for j in idxs if pixel_values_list[j] is not None], axis=0)
+            pv = torch.cat([torch.as_tensor(p) for p in pix], dim=0)
+            feats_all = model.vision_tower(pv, grid_all)
+        foff = 0
+        mm = model.config.vision_config.spatial_merge_size ** 2
+        for j in idxs:
+            ids = np.asarray(input_ids_list[j]).reshape(1, -1)
+            emb = lm.embed_tokens(ids)
+            if pixel_values_list[j] is not None:
+                nfeat = int(np.prod(np.asarray(grids[j]), axis=1).sum()) // mm
+                emb = model.merge_input_ids_with_image_features(model.config.image_token_id, model.config.video_token_id,
+                                                                feats_all[foff:foff + nfeat], emb, ids)
+                foff += nfeat
+                p, d = lm.get_rope_index(ids, np.asarray(grids[j]), None, None)
+            else:
+                p, d = lm.get_rope_index(ids)
+                p = np.broadcast_to(p[None], (3,) + p.shape)
+            embs.append(emb.reshape(ids.shape[1], -1))
+            poss.append(np.asarray(p).reshape(3, -1))
+            lens.append(ids.shape[1])
+            deltas.append(int(np.asarray(d).reshape(-1)[0]))
+        caches = lm.make_cache_batch(len(idxs))
+        logits = lm.prefill(torch.cat(embs, dim=0), np.concatenate(poss, axis=1), caches, lens, "last",
+                            reserve_extra=max_tokens + 2)
+        step0 = torch.zeros(1, dtype=torch.int32, device=logits.device)
+        tok0, _ = ops.sample(logits, step=step0, want_logprobs=False, **sargs)
+        st = lm.decode_begin(caches, tok0, deltas, max_new_tokens=max_tokens + 1)
+        st.step.fill_(1)
+        pipe = _TokenPipe(B, cap=lookahead + 2)
+        pipe.push(0, tok0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        stats.prompt_tokens += int(sum(lens))
+        stats.prompt_time += t1 - t0
+        done = [False] * B
+        issued, n = 0, 0
+        while n < max_tokens and not all(done):
+            while issued < min(n + lookahead, max_tokens - 1):
+                lm.decode_run(st, 1, sargs, use_graph=use_graph)
+                issued += 1
+                pipe.push(issued, st.tok)
+            toks = pipe.get(n)
+            for b, j in enumerate(idxs):
+                if done[b]:
+                    continue
+                t = int(toks[b])
+                if t in stop_ids:
+                    done[b] = True
+                    continue
+                outs[j].append(t)
+                stats.generation_tokens += 1
+            n += 1
+        torch.cuda.synchronize()
+        stats.generation_time += time.perf_counter() - t1
+        for c in caches:
+            c[0]._seq.release()
+    stats.prompt_tps = stats.prompt_tokens / max(stats.prompt_time, 1e-9)
+    stats.generation_tps = stats.generation_tokens / max(stats.generation_time, 1e-9)
+    stats.peak_memory = _peak_gb()
+    return outs, stats
+
+
+def batch_generate(model, processor, images=None, audios=None, prompts: Optional[List[str]] = None, max_tokens: int = 128,
+                   verbose: bool = False, group_by_shape: bool = True, track_image_sizes: bool = True, **kwargs) -> BatchResponse:
+    """reference ar.py:2890-3096: prompts (+ one image each) -> BatchResponse.  Requests are tokenised on the host,
+    then run through batch_generate_ids (static decode batches of up to 8)."""
+    from .utils import prepare_inputs
+
+    if audios:
+        raise NotImplementedError("audio inputs are outside the built hot path")
+    prompts = list(prompts or [])
+    images = list(images) if images is not None else [None] * len(prompts)
+    tokenizer = _tokenizer_of(processor)
+    ids_l, pix_l, grid_l = [], [], []
+    for p, im in zip(prompts, images):
+        inp = prepare_inputs(processor, images=im, prompts=p)
+        ids_l.append(np.asarray(inp["input_ids"]).reshape(-1))
+        pix_l.append(inp.get("pixel_values"))
+        grid_l.append(inp.get("image_grid_thw"))
+    stop = getattr(tokenizer, "stopping_criteria", None)
+    stop_ids = tuple(getattr(stop, "eos_token_ids", ()) or ())
+    smp = _resolve_sampler(kwargs.pop("sampler", None), kwargs.pop("temperature", 0.0), kwargs.pop("top_p", 1.0),
+                           kwargs.pop("min_p", 0.0), kwargs.pop("top_k", 0), kwargs.pop("seed", None))
+    toks, stats = batch_generate_ids(model, ids_l, pix_l, grid_l, max_tokens=max_tokens, stop_ids=stop_ids, sampler=smp)
+    texts = [tokenizer.decode(t) if hasattr(tokenizer, "decode") else "" for t in toks]
+    return BatchResponse(texts=texts, stats=stats, tokens=toks)

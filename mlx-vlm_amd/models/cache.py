@@ -1,0 +1,178 @@
+"""Paged KV cache for the MI355X engine, with the reference's cache facade.
+
+The reference keeps one contiguous [B, Hkv, S, D] K and V per layer and grows
+it by 256-token steps with zeros+concat (mlx_vlm/models/cache.py:337-439
+KVCache; make_prompt_cache cache.py:45-70).  Here ALL layers of ALL sequences
+share two preallocated pools (288 GB of HBM make preallocation the natural
+choice) addressed through a block table, 64 tokens per page:
+
+    K pool [layer][page][Hkv][D/8][64][8]      V pool [layer][page][Hkv][64][D]
+
+The objects handed to user code keep the reference's contract (`offset`,
+`state`, `is_trimmable/trim`, `size`, `empty`, `nbytes`, one object per layer
+from `make_prompt_cache`), so a `prompt_cache=` can be passed in and out of
+generate_step as in the reference (GenerateKwargs.prompt_cache).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+PAGE = 64
+
+
+class KVPool:
+    """Device pools + page allocator + block table for one language model."""
+
+    def __init__(self, n_layers: int, n_kv_heads: int, head_dim: int, max_tokens: int = 32768, max_seqs: int = 64,
+                 max_pages_per_seq: Optional[int] = None, device="cuda", dtype=torch.bfloat16):
+        self.n_layers, self.n_kv_heads, self.head_dim = n_layers, n_kv_heads, head_dim
+        self.n_pages = (max_tokens + PAGE - 1) // PAGE
+        self.max_seqs = max_seqs
+        self.max_pages = max_pages_per_seq or self.n_pages
+        self.device = device
+        per_layer = self.n_pages * n_kv_heads * PAGE * head_dim
+        # zero-filled: never-written slots must not hold NaN bit patterns
+        self.kpool = torch.zeros(n_layers, per_layer, dtype=dtype, device=device)
+        self.vpool = torch.zeros(n_layers, per_layer, dtype=dtype, device=device)
+        self.layer_stride = per_layer
+        self.block_table_host = np.zeros((max_seqs, self.max_pages), dtype=np.int32)
+        self.block_table = torch.zeros(max_seqs, self.max_pages, dtype=torch.int32, device=device)
+        self._free_pages = list(range(self.n_pages - 1, -1, -1))
+        self._free_seqs = set(range(max_seqs))
+
+    # ---- allocation (host side; the block table row is re-uploaded when it changes)
+    def new_seq(self) -> int:
+        return self.new_seqs(1)[0]
+
+    def new_seqs(self, n: int) -> List[int]:
+        """n CONSECUTIVE block-table rows (a decode batch indexes rows by batch position)."""
+        free = sorted(self._free_seqs)
+        for i in range(len(free) - n + 1):
+            if free[i + n - 1] - free[i] == n - 1:
+                rows = free[i:i + n]
+                self._free_seqs.difference_update(rows)
+                return rows
+        raise RuntimeError(f"KVPool: no {n} consecutive free sequence slots")
+
+    def free_seq(self, seq: int, pages: List[int]):
+        self._free_pages.extend(pages)
+        self._free_seqs.add(seq)
+
+    def ensure(self, seq: int, pages: List[int], n_tokens: int):
+        """Make sure `seq` owns pages for n_tokens tokens."""
+        need = (n_tokens + PAGE - 1) // PAGE
+        if need > self.max_pages:
+            raise RuntimeError(f"KVPool: sequence needs {need} pages > max_pages_per_seq {self.max_pages}")
+        grew = False
+        while len(pages) < need:
+            if not self._free_pages:
+                raise RuntimeError("KVPool: out of KV pages")
+            p = self._free_pages.pop()
+            self.block_table_host[seq, len(pages)] = p
+            pages.append(p)
+            grew = True
+        if grew:
+            self.block_table[seq].copy_(torch.from_numpy(self.block_table_host[seq]), non_blocking=False)
+
+    @property
+    def nbytes(self):
+        return self.kpool.numel() * self.kpool.element_size() * 2
+
+    def layer_views(self, layer: int):
+        H, D = self.n_kv_heads, self.head_dim
+        k = self.kpool[layer].view(self.n_pages, H, D // 8, PAGE, 8)
+        v = self.vpool[layer].view(self.n_pages, H, PAGE, D)
+        return k, v
+
+
+class PagedSequence:
+    """One sequence's share of the pool (all layers advance together)."""
+
+    def __init__(self, pool: KVPool, seq: Optional[int] = None):
+        self.pool = pool
+        self.seq = pool.new_seq() if seq is None else seq
+        self.pages: List[int] = []
+        self.offset = 0          # tokens stored (== the reference's KVCache.offset)
+        self.released = False
+
+    def reserve(self, n_total_tokens: int):
+        self.pool.ensure(self.seq, self.pages, n_total_tokens)
+
+    def release(self):
+        if not self.released:
+            self.pool.free_seq(self.seq, self.pages)
+            self.pages = []
+            self.released = True
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class KVCache:
+    """Per-layer facade with the reference's KVCache interface (cache.py:337-439)."""
+
+    step = 256  # kept for interface parity; pages are 64 tokens
+
+    def __init__(self, seq: PagedSequence, layer: int):
+        self._seq = seq
+        self._layer = layer
+
+    @property
+    def offset(self):
+        return self._seq.offset
+
+    @offset.setter
+    def offset(self, v):
+        self._seq.offset = int(v)
+
+    def size(self):
+        return self._seq.offset
+
+    def empty(self):
+        return self._seq.offset == 0
+
+    def is_trimmable(self):
+        return True
+
+    def trim(self, n):
+        # all layer views share the sequence: only layer 0 moves the offset so that
+        # `for c in cache: c.trim(n)` (reference dispatch.py:868-870) trims once
+        n = min(self._seq.offset, n)
+        if self._layer == 0:
+            self._seq.offset -= n
+        return n
+
+    @property
+    def state(self):
+        """Materialise contiguous (keys, values) [1, Hkv, S, D] from the pages (debug / interop)."""
+        pool, S = self._seq.pool, self._seq.offset
+        kp, vp = pool.layer_views(self._layer)
+        H, D = pool.n_kv_heads, pool.head_dim
+        if S == 0:
+            z = torch.zeros(1, H, 0, D, dtype=kp.dtype, device=kp.device)
+            return z, z.clone()
+        pages = torch.tensor(self._seq.pages, dtype=torch.long, device=kp.device)
+        k = kp[pages]                       # [np, H, D/8, 64, 8]
+        k = k.permute(1, 0, 3, 2, 4).reshape(H, -1, D)[:, :S]
+        v = vp[pages].permute(1, 0, 2, 3).reshape(H, -1, D)[:, :S]
+        return k[None].contiguous(), v[None].contiguous()
+
+    @property
+    def nbytes(self):
+        return len(self._seq.pages) * PAGE * self._seq.pool.n_kv_heads * self._seq.pool.head_dim * 2 * 2
+
+    def make_mask(self, N, return_array=False, window_size=None):
+        return None if N == 1 else "causal"
+
+
+def make_prompt_cache(model, max_kv_size: Optional[int] = None):
+    """reference cache.py:45-70: defer to model.make_cache() when present."""
+    if hasattr(model, "make_cache"):
+        return model.make_cache()
+    raise ValueError("make_prompt_cache: the language model must provide make_cache() (paged pool owner)")

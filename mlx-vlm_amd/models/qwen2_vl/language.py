@@ -1,0 +1,429 @@
+"""Qwen2-VL language model on MI355X - host mirror of the reference's
+mlx_vlm/models/qwen2_vl/language.py (LanguageModel: same call contract,
+get_rope_index, rope-delta position rule) on top of the native engine
+(csrc/engine.hip): prefill = MFMA GEMMs + causal flash attention + paged KV
+write, decode = weight-streaming GEMV chain + paged split-K attention, both
+enqueued by ONE native call per forward.
+
+Differences from the reference that the contract allows:
+  * `supports_logits_to_keep = True` (reference hook, generate/ar.py:340-341):
+    with logits_to_keep=1 only the last row goes through the lm_head instead of
+    all L rows (the reference computes all and slices [:, -1], ar.py:358).
+  * `make_cache()` (reference hook, cache.py:57-58) returns per-layer views of
+    one paged sequence instead of 28 independent contiguous KVCache objects.
+  * position ids are built on the host from host-resident ids / grids and
+    uploaded once; the reference does the same work with per-token Python
+    loops and .item() syncs (language.py:242-382).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from ... import _lib, ops
+from ..._lib import check
+from ..base import LanguageModelOutput
+from ..cache import PAGE, KVCache, KVPool, PagedSequence
+from .config import ModelConfig, TextConfig
+
+
+def _to_np(x):
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+class DecodeState:
+    """Device-resident state of a batch of B decoding sequences (what one graph replay reads/writes)."""
+
+    def __init__(self, lm: "LanguageModel", B: int, nsplit: int = 8, ring_len: int = 64):
+        t, dev = lm.args, lm.device
+        D, hd, Hq, Hkv = t.hidden_size, lm.head_dim, t.num_attention_heads, t.num_key_value_heads
+        bf, i32 = torch.bfloat16, torch.int32
+        self.B, self.nsplit, self.ring_len = B, nsplit, ring_len
+        self.tok = torch.zeros(B, dtype=i32, device=dev)
+        self.pos = torch.zeros(B, dtype=i32, device=dev)
+        self.ctx = torch.zeros(B, dtype=i32, device=dev)
+        self.step = torch.zeros(1, dtype=i32, device=dev)
+        self.h = torch.empty(B, D, dtype=bf, device=dev)
+        self.qkv = torch.empty(B, (Hq + 2 * Hkv) * hd, dtype=bf, device=dev)
+        self.attn = torch.empty(B, Hq * hd, dtype=bf, device=dev)
+        self.act = torch.empty(B, t.intermediate_size, dtype=bf, device=dev)
+        self.logits = torch.empty(B, t.vocab_size, dtype=bf, device=dev)
+        self.logprobs = torch.empty(B, t.vocab_size, dtype=bf, device=dev)
+        self.scratch = torch.empty(B, t.vocab_size, dtype=bf, device=dev)
+        self.part_o = torch.empty(B, Hq, nsplit, hd, dtype=torch.float32, device=dev)
+        self.part_ml = torch.empty(B, Hq, nsplit, 2, dtype=torch.float32, device=dev)
+        self.sample_ws = ops.sample_workspace(B, dev)
+        self.out_ring = torch.zeros(ring_len, B, dtype=i32, device=dev)
+        self.graph_key = None
+
+    def args(self, temperature=0.0, top_p=1.0, min_p=0.0, top_k=0, seed=0, with_logprobs=True):
+        p = lambda t: t.data_ptr()  # noqa: E731
+        return _lib.DecodeArgs(self.B, p(self.tok), p(self.pos), p(self.ctx), p(self.step), p(self.h), p(self.qkv),
+                               p(self.attn), p(self.act), p(self.logits),
+                               p(self.logprobs) if (with_logprobs or temperature > 0) else None, p(self.scratch),
+                               p(self.part_o), p(self.part_ml), p(self.sample_ws), p(self.out_ring), self.ring_len,
+                               self.nsplit, float(temperature), float(top_p), float(min_p), int(top_k),
+                               int(seed) & 0xFFFFFFFF)
+
+
+class LanguageModel:
+    supports_logits_to_keep = True
+
+    def __init__(self, args: TextConfig, config: ModelConfig, device="cuda", kv_pool_tokens: int = 32768,
+                 max_seqs: int = 64):
+        self.args = args
+        self.config = config
+        self.model_type = args.model_type
+        self.device = device
+        self._rope_deltas = None
+        self._position_ids = None
+        self._handle = None
+        self._w: Dict[str, torch.Tensor] = {}
+        self._kv_pool_tokens, self._max_seqs = kv_pool_tokens, max_seqs
+        self.pool: Optional[KVPool] = None
+        self._decode_states: Dict[int, DecodeState] = {}
+        sec = list((args.rope_scaling or {}).get("mrope_section", [16, 24, 24]))
+        self.mrope_section = sec
+
+    # ------------------------------------------------------------------ properties (reference language.py:520-530)
+    @property
+    def layers(self):
+        return list(range(self.args.num_hidden_layers))
+
+    @property
+    def head_dim(self):
+        return self.args.hidden_size // self.args.num_attention_heads
+
+    @property
+    def n_kv_heads(self):
+        return self.args.num_key_value_heads
+
+    # ------------------------------------------------------------------ weights
+    def load_weights(self, W: Dict[str, torch.Tensor]):
+        """W: names relative to `language_model.` (`model.layers.i....`, `model.embed_tokens.weight`, `lm_head.weight`).
+        Packs q/k/v into one [Hq*D + 2*Hkv*D, hidden] matrix and interleaves gate/up rows (g0,u0,g1,u1,...) so the
+        SwiGLU product is an epilogue of one GEMM/GEMV."""
+        t, dev = self.args, self.device
+        L = _lib.lib()
+        bf = torch.bfloat16
+
+        def g(name):
+            return W[name].to(device=dev, dtype=bf)
+
+        cfg = _lib.LlmConfig(t.hidden_size, t.num_hidden_layers, t.intermediate_size, t.num_attention_heads,
+                             t.num_key_value_heads, self.head_dim, t.vocab_size, float(t.rms_norm_eps),
+                             int(self.mrope_section[0]), int(self.mrope_section[1]))
+        h = C.c_void_p()
+        check(L.vlm_llm_create(C.byref(cfg), C.byref(h)), "llm_create")
+        self._handle = h
+        for i in range(t.num_hidden_layers):
+            p = f"model.layers.{i}."
+            wqkv = torch.cat([g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"),
+                              g(p + "self_attn.v_proj.weight")], dim=0).contiguous()
+            bqkv = torch.cat([g(p + "self_attn.q_proj.bias"), g(p + "self_attn.k_proj.bias"),
+                              g(p + "self_attn.v_proj.bias")], dim=0).contiguous()
+            gate, up = g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")
+            wgu = torch.stack([gate, up], dim=1).reshape(2 * t.intermediate_size, t.hidden_size).contiguous()
+            ws = dict(ln1=g(p + "input_layernorm.weight").contiguous(), wqkv=wqkv, bqkv=bqkv,
+                      wo=g(p + "self_attn.o_proj.weight").contiguous(),
+                      ln2=g(p + "post_attention_layernorm.weight").contiguous(), wgu=wgu,
+                      wdown=g(p + "mlp.down_proj.weight").contiguous())
+            for k, v in ws.items():
+                self._w[f"{i}.{k}"] = v
+            lay = _lib.LlmLayer(ws["ln1"].data_ptr(), wqkv.data_ptr(), bqkv.data_ptr(), ws["wo"].data_ptr(),
+                                ws["ln2"].data_ptr(), wgu.data_ptr(), ws["wdown"].data_ptr())
+            check(L.vlm_llm_set_layer(h, i, C.byref(lay)), "llm_set_layer")
+        embed = g("model.embed_tokens.weight").contiguous()
+        head = embed if t.tie_word_embeddings else g("lm_head.weight").contiguous()
+        norm = g("model.norm.weight").contiguous()
+        hd = self.head_dim
+        # compute_inv_freq (reference rope_utils.py:1042-1043), fp32 on the host
+        inv_freq = (1.0 / (t.rope_theta ** (torch.arange(0, hd, 2).to(torch.float32) / hd))).to(dev)
+        self._w.update(embed=embed, head=head, norm=norm, inv_freq=inv_freq)
+        gl = _lib.LlmGlobals(embed.data_ptr(), norm.data_ptr(), head.data_ptr(), inv_freq.data_ptr())
+        check(L.vlm_llm_set_globals(h, C.byref(gl)), "llm_set_globals")
+        self._init_pool()
+
+    def _init_pool(self):
+        t = self.args
+        self.pool = KVPool(t.num_hidden_layers, t.num_key_value_heads, self.head_dim, self._kv_pool_tokens,
+                           self._max_seqs, device=self.device)
+        kv = _lib.KvPool(self.pool.kpool.data_ptr(), self.pool.vpool.data_ptr(), self.pool.layer_stride,
+                         self.pool.block_table.data_ptr(), self.pool.max_pages)
+        check(_lib.lib().vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _lib.lib().vlm_llm_destroy(self._handle)
+        except Exception:
+            pass
+
+    @property
+    def embed_tokens_weight(self):
+        return self._w["embed"]
+
+    def embed_tokens(self, input_ids) -> torch.Tensor:
+        """nn.Embedding (reference language.py:164,179).  input_ids [B, L] -> [B, L, D]"""
+        ids = torch.as_tensor(_to_np(input_ids), dtype=torch.int32).to(self.device)
+        B, Lq = ids.shape
+        out = ops.embed_gather(ids.reshape(-1), self._w["embed"])
+        return out.view(B, Lq, -1)
+
+    # ------------------------------------------------------------------ cache
+    def make_cache(self) -> List[KVCache]:
+        seq = PagedSequence(self.pool)
+        return [KVCache(seq, i) for i in range(self.args.num_hidden_layers)]
+
+    def make_cache_batch(self, n: int) -> List[List[KVCache]]:
+        """n caches on consecutive block-table rows (what a decode batch needs)."""
+        rows = self.pool.new_seqs(n)
+        return [[KVCache(s, i) for i in range(self.args.num_hidden_layers)]
+                for s in (PagedSequence(self.pool, r) for r in rows)]
+
+    # ------------------------------------------------------------------ get_rope_index (reference language.py:216-402)
+    def get_rope_index(self, input_ids, image_grid_thw=None, video_grid_thw=None, attention_mask=None):
+        cfg = self.config
+        input_ids = _to_np(input_ids)
+        image_grid_thw, video_grid_thw = _to_np(image_grid_thw), _to_np(video_grid_thw)
+        attention_mask = _to_np(attention_mask)
+        B, L = input_ids.shape
+        ms = cfg.vision_config.spatial_merge_size
+        img_id, vid_id, vstart = cfg.image_token_id, cfg.video_token_id, cfg.vision_start_token_id
+        if image_grid_thw is not None or video_grid_thw is not None:
+            if attention_mask is None:
+                attention_mask = np.ones_like(input_ids)
+            position_ids = np.ones((3, B, L), dtype=np.int64)
+            deltas = []
+            ii = vi = 0
+            for i in range(B):
+                row_mask = attention_mask[i]
+                toks = input_ids[i][row_mask == 1]
+                tl = toks.tolist()
+                starts = np.nonzero(toks[:-1] == vstart)[0]
+                vision_tokens = toks[starts + 1]
+                image_nums = int((vision_tokens == img_id).sum())
+                video_nums = int((vision_tokens == vid_id).sum())
+                chunks: List[np.ndarray] = []
+                st, cur_max = 0, -1
+                ri, rv = image_nums, video_nums
+                for _ in range(image_nums + video_nums):
+                    ed_image = tl.index(img_id, st) if (img_id in tl and ri > 0) else len(tl) + 1
+                    ed_video = tl.index(vid_id, st) if (vid_id in tl and rv > 0) else len(tl) + 1
+                    if ed_image < ed_video:
+                        t_, h_, w_ = [int(x) for x in image_grid_thw[ii]]
+                        ii += 1
+                        ri -= 1
+                        ed = ed_image
+                    else:
+                        t_, h_, w_ = [int(x) for x in video_grid_thw[vi]]
+                        vi += 1
+                        rv -= 1
+                        ed = ed_video
+                    gt, gh, gw = t_, h_ // ms, w_ // ms
+                    text_len = ed - st
+                    st_idx = cur_max + 1
+                    chunks.append(np.broadcast_to(np.arange(text_len)[None], (3, text_len)) + st_idx)
+                    tix = np.broadcast_to(np.arange(gt)[:, None], (gt, gh * gw)).reshape(-1)
+                    hix = np.broadcast_to(np.arange(gh)[None, :, None], (gt, gh, gw)).reshape(-1)
+                    wix = np.broadcast_to(np.arange(gw)[None, None, :], (gt, gh, gw)).reshape(-1)
+                    vis = np.stack([tix, hix, wix]) + text_len + st_idx
+                    chunks.append(vis)
+                    cur_max = int(vis.max())   # == llm_pos_ids_list[-1].max() in the reference
+                    st = ed + gt * gh * gw
+                if st < len(tl):
+                    st_idx = cur_max + 1
+                    text_len = len(tl) - st
+                    chunks.append(np.broadcast_to(np.arange(text_len)[None], (3, text_len)) + st_idx)
+                if not chunks:
+                    deltas.append(0)
+                    continue
+                llm_positions = np.concatenate(chunks, axis=1).reshape(3, -1)
+                position_ids[:, i, row_mask == 1] = llm_positions
+                deltas.append(int(llm_positions.max()) + 1 - len(tl))
+            return position_ids, np.array(deltas, dtype=np.int64).reshape(-1, 1)
+        if attention_mask is not None:
+            am = attention_mask.astype(np.int64)
+            position_ids = np.cumsum(am, axis=-1) - 1
+            position_ids = np.where(am == 0, 1, position_ids)
+            deltas = position_ids.max(axis=-1, keepdims=True) + 1 - am.shape[-1]
+            return position_ids, deltas
+        position_ids = np.broadcast_to(np.arange(L)[None], (B, L)).astype(np.int64)
+        return position_ids, np.zeros((B, 1), dtype=np.int64)
+
+    # ------------------------------------------------------------------ prefill over concatenated sequences
+    def prefill(self, inputs_embeds: torch.Tensor, position_ids: np.ndarray, caches: List[List[KVCache]],
+                lengths: List[int], logits_rows: str = "last", reserve_extra: int = 0) -> torch.Tensor:
+        """inputs_embeds [T, D] (sequences concatenated, lengths[i] tokens each); position_ids int [3, T];
+        caches[i] = the layer views of sequence i (appended after their current offset).
+        -> logits [n_seq, V] (logits_rows == "last") or [T, V] ("all")."""
+        t, dev = self.args, self.device
+        T, D = inputs_embeds.shape
+        hd, Hq, Hkv = self.head_dim, t.num_attention_heads, t.num_key_value_heads
+        seqs = [c[0]._seq for c in caches]
+        for s in seqs:
+            if s.offset != 0:
+                raise NotImplementedError("prefill onto a non-empty cache (prefix reuse / chunked prefill) is not built yet")
+        cu = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
+        kv_seq = np.concatenate([np.full(n, s.seq, dtype=np.int32) for n, s in zip(lengths, seqs)])
+        kv_slot = np.concatenate([np.arange(n, dtype=np.int32) for n in lengths])
+        for n, s in zip(lengths, seqs):
+            s.reserve(n + reserve_extra)
+        kv = self._kv_struct(0)   # prefill addresses block-table rows by absolute sequence id
+        check(_lib.lib().vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
+        nqb = int(sum((n + 127) // 128 for n in lengths))
+        pos = np.ascontiguousarray(position_ids, dtype=np.int32)
+        i32 = torch.int32
+        pos_d = torch.from_numpy(pos).to(dev)
+        meta = torch.from_numpy(np.concatenate([kv_seq, kv_slot, cu])).to(dev)
+        kv_seq_d, kv_slot_d, cu_d = meta[:T], meta[T:2 * T], meta[2 * T:]
+        if logits_rows == "last":
+            rows = (cu[1:] - 1).astype(np.int32)
+        else:
+            rows = np.arange(T, dtype=np.int32)
+        rows_d = torch.from_numpy(rows).to(dev)
+        bf = torch.bfloat16
+        h = inputs_embeds.contiguous()
+        xn = torch.empty(T, D, dtype=bf, device=dev)
+        qkv = torch.empty(T, (Hq + 2 * Hkv) * hd, dtype=bf, device=dev)
+        attn = torch.empty(T, Hq * hd, dtype=bf, device=dev)
+        act = torch.empty(T, t.intermediate_size, dtype=bf, device=dev)
+        xlast = torch.empty(len(rows), D, dtype=bf, device=dev)
+        logits = torch.empty(len(rows), t.vocab_size, dtype=bf, device=dev)
+        a = _lib.PrefillArgs(h.data_ptr(), T, pos_d[0].data_ptr(), pos_d[1].data_ptr(), pos_d[2].data_ptr(),
+                             kv_seq_d.data_ptr(), kv_slot_d.data_ptr(), cu_d.data_ptr(), len(lengths), nqb,
+                             xn.data_ptr(), qkv.data_ptr(), attn.data_ptr(), act.data_ptr(), rows_d.data_ptr(),
+                             len(rows), xlast.data_ptr(), logits.data_ptr())
+        check(_lib.lib().vlm_llm_prefill(self._handle, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              "llm_prefill")
+        for n, s in zip(lengths, seqs):
+            s.offset += n
+        self._keep = (h, xn, qkv, attn, act, xlast, pos_d, meta, rows_d)  # keep alive until the stream has run
+        return logits
+
+    # ------------------------------------------------------------------ decode
+    def decode_state(self, B: int) -> DecodeState:
+        st = self._decode_states.get(B)
+        if st is None:
+            st = DecodeState(self, B)
+            self._decode_states[B] = st
+        return st
+
+    def decode_begin(self, caches: List[List[KVCache]], first_tokens, rope_deltas, max_new_tokens: int) -> DecodeState:
+        """Bind B sequences (B in {1,2,4,8}) to the device decode state: tok = first sampled tokens,
+        ctx = cache offsets, pos = offset + rope_delta (reference language.py:476-509)."""
+        B = len(caches)
+        st = self.decode_state(B)
+        seqs = [c[0]._seq for c in caches]
+        for s in seqs:
+            s.reserve(s.offset + max_new_tokens + 1)
+        # the engine indexes block-table rows by batch row: sequences must sit in rows 0..B-1 of a view
+        rows = [s.seq for s in seqs]
+        if rows != list(range(rows[0], rows[0] + B)):
+            raise RuntimeError("decode batch needs consecutive KV sequence slots")
+        st.seq_row0 = rows[0]
+        ctx = np.array([s.offset for s in seqs], dtype=np.int32)
+        pos = ctx + np.asarray(rope_deltas, dtype=np.int64).reshape(-1).astype(np.int32)
+        host = np.concatenate([pos, ctx, np.zeros(1, np.int32)])
+        dev = torch.from_numpy(host).to(self.device)
+        st.pos.copy_(dev[:B]); st.ctx.copy_(dev[B:2 * B]); st.step.copy_(dev[2 * B:])
+        if isinstance(first_tokens, torch.Tensor):
+            st.tok.copy_(first_tokens.reshape(-1).to(torch.int32))
+        else:
+            st.tok.copy_(torch.from_numpy(np.asarray(first_tokens, dtype=np.int32).reshape(-1)).to(self.device))
+        st.seqs = seqs
+        return st
+
+    def _kv_struct(self, row0: int):
+        bt = self.pool.block_table[row0:]
+        return _lib.KvPool(self.pool.kpool.data_ptr(), self.pool.vpool.data_ptr(), self.pool.layer_stride,
+                           bt.data_ptr(), self.pool.max_pages)
+
+    def decode_run(self, st: DecodeState, n_steps: int, sampler_args: dict, use_graph: bool = True):
+        """Enqueue n_steps decode steps (graph replays when use_graph)."""
+        L = _lib.lib()
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        kv = self._kv_struct(st.seq_row0)
+        check(L.vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
+        args = st.args(**sampler_args)
+        if use_graph:
+            key = (st.seq_row0, tuple(sorted(sampler_args.items())))
+            if st.graph_key != key or getattr(self, "_graph_owner", None) is not st:
+                check(L.vlm_llm_decode_graph_build(self._handle, C.byref(args), stream), "decode_graph_build")
+                st.graph_key = key
+                self._graph_owner = st
+            for _ in range(n_steps):
+                check(L.vlm_llm_decode_graph_launch(self._handle, stream), "decode_graph_launch")
+        else:
+            for _ in range(n_steps):
+                check(L.vlm_llm_decode_step(self._handle, C.byref(args), stream), "decode_step")
+        for s in st.seqs:
+            s.offset += n_steps
+
+    # ------------------------------------------------------------------ module contract (reference language.py:404-518)
+    def __call__(self, inputs, inputs_embeds=None, mask=None, cache=None, **kwargs):
+        position_ids = kwargs.pop("position_ids", None)
+        pixel_values = kwargs.pop("pixel_values", None)
+        image_grid_thw = kwargs.pop("image_grid_thw", None)
+        video_grid_thw = kwargs.pop("video_grid_thw", None)
+        rope_deltas_kw = kwargs.pop("rope_deltas", None)
+        logits_to_keep = kwargs.pop("logits_to_keep", None)
+        if pixel_values is not None:
+            self._rope_deltas = None
+            self._position_ids = None
+        if rope_deltas_kw is not None:
+            self._rope_deltas = _to_np(rope_deltas_kw)
+        ids = _to_np(inputs)
+        if ids.ndim == 1:
+            ids = ids[None]
+        B, Lq = ids.shape
+        if cache is None:
+            cache = self.make_cache()
+            if B != 1:
+                raise NotImplementedError("cache=None is only supported for B == 1")
+        caches = [cache] if isinstance(cache[0], KVCache) else cache
+        cache_offset = caches[0][0].offset
+
+        if Lq == 1 and cache_offset > 0 and inputs_embeds is None and B in (1, 2, 4, 8):
+            # decode: pos = cache offset + rope delta (language.py:476-509); logits only
+            deltas = self._rope_deltas if self._rope_deltas is not None else np.zeros((B, 1), dtype=np.int64)
+            deltas = np.broadcast_to(np.asarray(deltas).reshape(-1, 1), (B, 1)) if np.asarray(deltas).size == 1 else deltas
+            st = self.decode_begin(caches, ids.reshape(-1), deltas[:B], max_new_tokens=1)
+            kv = self._kv_struct(st.seq_row0)
+            check(_lib.lib().vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
+            args = st.args()
+            check(_lib.lib().vlm_llm_decode_forward(self._handle, C.byref(args),
+                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), "decode_forward")
+            for s in st.seqs:
+                s.offset += 1
+            return LanguageModelOutput(logits=st.logits.clone().view(B, 1, -1))
+
+        # prefill path
+        if position_ids is None:
+            if self._position_ids is not None and cache_offset > 0:
+                p = self._position_ids
+                position_ids = p[..., cache_offset:cache_offset + Lq]
+            else:
+                position_ids, rope_deltas = self.get_rope_index(ids, image_grid_thw, video_grid_thw, _to_np(mask))
+                self._rope_deltas = rope_deltas
+                self._position_ids = position_ids
+        pos = _to_np(position_ids)
+        if pos.ndim == 2:
+            pos = np.broadcast_to(pos[None], (3,) + pos.shape)
+        if pos.shape[-1] > Lq:
+            pos = pos[..., cache_offset:cache_offset + Lq]
+        if inputs_embeds is None:
+            inputs_embeds = self.embed_tokens(ids)
+        emb = inputs_embeds.reshape(B * Lq, -1)
+        pos_flat = pos.reshape(3, B * Lq)
+        logits = self.prefill(emb, pos_flat, caches, [Lq] * B, logits_rows="last" if logits_to_keep == 1 else "all")
+        if logits_to_keep == 1:
+            return LanguageModelOutput(logits=logits.view(B, 1, -1))
+        return LanguageModelOutput(logits=logits.view(B, Lq, -1))

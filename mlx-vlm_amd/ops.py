@@ -1,0 +1,163 @@
+"""Thin torch-tensor front end of the C ABI (include/vlm_hip.h).
+
+torch is plumbing only here: it owns device memory and the HIP stream; every
+computation below is a call into libvlm_hip.so.  Tensors must be CUDA(HIP)
+resident, contiguous along the last dim and bf16 unless stated otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+EPI_NONE, EPI_BIAS, EPI_GELU_FAST, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2, 4, 8, 16
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.VlmHipError("libvlm_hip ops need device tensors (there is no CPU fallback)")
+
+
+def gemm(a, w, bias=None, res=None, out=None, epilogue=EPI_NONE):
+    """out[M,N(/2)] = epi(a[M,K] @ w[N,K].T)"""
+    _dev(a, w, bias, res, out)
+    M, K = a.shape
+    N = w.shape[0]
+    n_out = N // 2 if epilogue & EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.bfloat16, device=a.device)
+    check(_lib.lib().vlm_gemm_bf16(_p(a), _p(w), _p(bias), _p(res), _p(out), M, N, K, a.stride(0), w.stride(0),
+                                   out.stride(0), res.stride(0) if res is not None else 0, epilogue, _stream()), "gemm")
+    return out
+
+
+def gemv(x, w, bias=None, res=None, norm_w=None, out=None, eps=1e-6, epilogue=EPI_NONE):
+    _dev(x, w, bias, res, norm_w, out)
+    M, K = x.shape
+    N = w.shape[0]
+    n_out = N // 2 if epilogue & EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().vlm_gemv_bf16(_p(x), _p(w), _p(bias), _p(res), _p(norm_w), _p(out), M, N, K, x.stride(0),
+                                   w.stride(0), out.stride(0), res.stride(0) if res is not None else 0, eps, epilogue,
+                                   _stream()), "gemv")
+    return out
+
+
+def layernorm(x, w, b, eps=1e-6, out=None):
+    _dev(x, w, b)
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.lib().vlm_layernorm(_p(x), _p(w), _p(b), _p(out), x.shape[0], x.shape[1], eps, _stream()), "layernorm")
+    return out
+
+
+def rmsnorm(x, w, eps=1e-6, res=None, out=None, h_out=None):
+    _dev(x, w, res)
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.lib().vlm_rmsnorm_residual(_p(x), _p(res), _p(w), _p(out), _p(h_out), x.shape[0], x.shape[1], eps,
+                                          _stream()), "rmsnorm")
+    return out
+
+
+def rope2d_vision_(qkv, cos_tab, sin_tab, n_heads):
+    """in place on qkv [N, 3*H*D]; cos/sin fp32 [N, D/2]"""
+    _dev(qkv, cos_tab, sin_tab)
+    N = qkv.shape[0]
+    D = qkv.shape[1] // (3 * n_heads)
+    check(_lib.lib().vlm_rope2d_vision(_p(qkv), _p(cos_tab), _p(sin_tab), N, n_heads, D, qkv.stride(0), _stream()), "rope2d")
+    return qkv
+
+
+def mrope_kvwrite_(qkv, Hq, Hkv, D, pos_t, pos_h, pos_w, inv_freq, sec0, sec1, kv_seq=None, kv_slot=None,
+                   block_table=None, kpool=None, vpool=None):
+    _dev(qkv, pos_t, inv_freq)
+    T = qkv.shape[0]
+    max_pages = block_table.shape[1] if block_table is not None else 0
+    check(_lib.lib().vlm_mrope_kvwrite(_p(qkv), qkv.stride(0), T, Hq, Hkv, D, _p(pos_t), _p(pos_h), _p(pos_w),
+                                       _p(inv_freq), sec0, sec1, _p(kv_seq), _p(kv_slot), _p(block_table), max_pages,
+                                       _p(kpool), _p(vpool), _stream()), "mrope_kvwrite")
+    return qkv
+
+
+def attn_prefill(q, k, v, cu_seqlens, total_qblocks, Hq, Hkv, D, scale, causal, out=None):
+    """q/k/v: 2-D views [T, *] whose data_ptr points at head 0 of token 0 and stride(0) is the token stride."""
+    _dev(q, k, v, cu_seqlens)
+    T = q.shape[0]
+    if out is None:
+        out = torch.empty(T, Hq * D, dtype=torch.bfloat16, device=q.device)
+    check(_lib.lib().vlm_attn_prefill(_p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
+                                      _p(cu_seqlens), cu_seqlens.numel() - 1, total_qblocks, Hq, Hkv, D, scale,
+                                      1 if causal else 0, _stream()), "attn_prefill")
+    return out
+
+
+def attn_decode_paged(q, kpool, vpool, block_table, kv_len, kv_len_add, Hq, Hkv, D, scale, nsplit, out=None):
+    _dev(q, kpool, vpool, block_table, kv_len)
+    B = q.shape[0]
+    part_o = torch.empty(B, Hq, nsplit, D, dtype=torch.float32, device=q.device)
+    part_ml = torch.empty(B, Hq, nsplit, 2, dtype=torch.float32, device=q.device)
+    if out is None:
+        out = torch.empty(B, Hq * D, dtype=torch.bfloat16, device=q.device)
+    check(_lib.lib().vlm_attn_decode_paged(_p(q), q.stride(0), _p(kpool), _p(vpool), _p(block_table),
+                                           block_table.shape[1], _p(kv_len), kv_len_add, B, Hq, Hkv, D, scale, nsplit,
+                                           _p(part_o), _p(part_ml), _p(out), out.stride(0), _stream()), "attn_decode")
+    return out
+
+
+def embed_gather(ids, table, out=None):
+    _dev(ids, table)
+    T = ids.numel()
+    if out is None:
+        out = torch.empty(T, table.shape[1], dtype=table.dtype, device=table.device)
+    check(_lib.lib().vlm_embed_gather(_p(ids), _p(table), _p(out), T, table.shape[1], out.stride(0), table.shape[0],
+                                      _stream()), "embed_gather")
+    return out
+
+
+def scatter_rows_(src, dst_rows, dst):
+    _dev(src, dst_rows, dst)
+    check(_lib.lib().vlm_scatter_image_rows(_p(src), _p(dst_rows), _p(dst), src.shape[0], src.shape[1], src.stride(0),
+                                            dst.stride(0), _stream()), "scatter_rows")
+    return dst
+
+
+def cast_pad(src_f32, ld_dst):
+    _dev(src_f32)
+    rows, cols = src_f32.shape
+    out = torch.empty(rows, ld_dst, dtype=torch.bfloat16, device=src_f32.device)
+    check(_lib.lib().vlm_cast_f32_bf16_pad(_p(src_f32), _p(out), rows, cols, src_f32.stride(0), ld_dst, _stream()), "cast_pad")
+    return out
+
+
+def sample_workspace(B, device):
+    return torch.empty(_lib.lib().vlm_sample_workspace_bytes(B), dtype=torch.uint8, device=device)
+
+
+def sample(logits, temperature=0.0, top_p=1.0, min_p=0.0, top_k=0, seed=0, step=None, want_logprobs=True, ws=None):
+    """-> (tokens int32 [B], logprobs bf16 [B,V] or None)"""
+    _dev(logits)
+    B, V = logits.shape
+    tok = torch.empty(B, dtype=torch.int32, device=logits.device)
+    lp = torch.empty(B, V, dtype=torch.bfloat16, device=logits.device) if (want_logprobs or temperature > 0) else None
+    scratch = torch.empty(B, V, dtype=torch.bfloat16, device=logits.device) if temperature > 0 else None
+    if ws is None:
+        ws = sample_workspace(B, logits.device)
+    check(_lib.lib().vlm_sample(_p(logits), logits.stride(0), B, V, _p(lp), _p(scratch), V, _p(tok), _p(ws),
+                                float(temperature), float(top_p), float(min_p), int(top_k), int(seed) & 0xFFFFFFFF,
+                                _p(step), _stream()), "sample")
+    return tok, lp

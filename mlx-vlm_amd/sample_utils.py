@@ -1,0 +1,58 @@
+"""Sampler front end - same constructor surface as the reference's
+mlx_vlm/sample_utils.py:10-89 (make_sampler), but instead of composing Python
+closures over mx ops it returns a `Sampler` SPEC that the engine hands to the
+fused HIP sampler (csrc/sample.hip: logsumexp -> top-p -> min-p -> top-k ->
+Gumbel-max categorical, in the reference's filter order).  The spec is callable
+on a logprobs tensor too, for code written against the reference API.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+
+@dataclass
+class Sampler:
+    temp: float = 0.0
+    top_p: float = 0.0
+    min_p: float = 0.0
+    top_k: int = 0
+    seed: int = 0
+    _calls: int = 0
+
+    @property
+    def greedy(self) -> bool:
+        return self.temp == 0
+
+    def engine_args(self) -> dict:
+        return dict(temperature=float(self.temp), top_p=float(self.top_p if 0 < self.top_p < 1 else 1.0),
+                    min_p=float(self.min_p), top_k=int(self.top_k), seed=int(self.seed))
+
+    def __call__(self, logprobs: torch.Tensor) -> torch.Tensor:
+        """logprobs [B, V] (already normalised) -> tokens [B]; runs the same HIP kernel (the extra
+        logsumexp pass is the identity on normalised input)."""
+        from . import ops
+
+        x = logprobs if logprobs.dim() == 2 else logprobs[None]
+        step = torch.tensor([self._calls], dtype=torch.int32, device=x.device)
+        self._calls += 1
+        tok, _ = ops.sample(x.to(torch.bfloat16).contiguous(), step=step, want_logprobs=False, **self.engine_args())
+        return tok
+
+
+def make_sampler(temp: float = 0.0, top_p: float = 0.0, min_p: float = 0.0, min_tokens_to_keep: int = 1,
+                 top_k: int = 0, top_n_sigma: float = 0.0, p_less: bool = False, typical_p: float = 1.0,
+                 xtc_probability: float = 0.0, xtc_threshold: float = 0.0, xtc_special_tokens=None,
+                 seed: Optional[int] = None) -> Sampler:
+    """reference sample_utils.py:10-89.  argmax when temp == 0; otherwise filters in the
+    reference's order (top-p, min-p, top-k) then categorical(logprobs / temp).
+    top-n-sigma / p-less / typical-p / XTC (SURVEY §8a21 'exotic samplers: next') are not built."""
+    if top_n_sigma > 0.0 or p_less or (0.0 < typical_p < 1.0) or xtc_probability > 0.0:
+        raise NotImplementedError("top_n_sigma / p_less / typical_p / xtc samplers are outside the built hot path")
+    if min_tokens_to_keep != 1:
+        raise NotImplementedError("min_tokens_to_keep > 1 is not built")
+    if not (0 <= min_p <= 1.0):
+        raise ValueError(f"`min_p` has to be a float in the [0, 1] interval, but is {min_p}")
+    return Sampler(temp=temp, top_p=top_p, min_p=min_p, top_k=top_k, seed=0 if seed is None else int(seed))

@@ -1,0 +1,74 @@
+"""Synthetic checkpoints at real dims (there is no network for
+real ones): Linear / Embedding ~ N(0, 0.02^2), norm weights 1, biases 0, bf16,
+generated directly on the device with a seeded torch generator."""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+QWEN2_VL_2B = dict(
+    model_type="qwen2_vl", hidden_size=1536, num_hidden_layers=28, intermediate_size=8960, num_attention_heads=12,
+    num_key_value_heads=2, rms_norm_eps=1e-6, vocab_size=151936, rope_theta=1000000.0,
+    rope_scaling={"type": "mrope", "mrope_section": [16, 24, 24]}, tie_word_embeddings=True,
+    image_token_id=151655, video_token_id=151656, vision_start_token_id=151652,
+    vision_config=dict(model_type="qwen2_vl", depth=32, embed_dim=1280, hidden_size=1536, num_heads=16, patch_size=14,
+                       mlp_ratio=4, in_channels=3, spatial_merge_size=2, temporal_patch_size=2),
+)
+
+QWEN2_VL_7B = dict(
+    QWEN2_VL_2B, hidden_size=3584, intermediate_size=18944, num_attention_heads=28, num_key_value_heads=4,
+    vocab_size=152064, tie_word_embeddings=False,
+    vision_config=dict(QWEN2_VL_2B["vision_config"], hidden_size=3584),
+)
+
+
+def weight_shapes(cfg) -> Dict[str, tuple]:
+    """name -> shape for a qwen2_vl ModelConfig, sanitized names (reference qwen2_vl.py:179-190)."""
+    t, v = cfg.text_config, cfg.vision_config
+    E, D = v.embed_dim, t.hidden_size
+    hd = D // t.num_attention_heads
+    H = int(E * v.mlp_ratio)
+    M = E * v.spatial_merge_size ** 2
+    pd = v.in_channels * v.temporal_patch_size * v.patch_size * v.patch_size
+    s: Dict[str, tuple] = {"vision_tower.patch_embed.proj.weight": (E, pd)}
+    for i in range(v.depth):
+        p = f"vision_tower.blocks.{i}."
+        s.update({p + "norm1.weight": (E,), p + "norm1.bias": (E,), p + "norm2.weight": (E,), p + "norm2.bias": (E,),
+                  p + "attn.qkv.weight": (3 * E, E), p + "attn.qkv.bias": (3 * E,), p + "attn.proj.weight": (E, E),
+                  p + "attn.proj.bias": (E,), p + "mlp.fc1.weight": (H, E), p + "mlp.fc1.bias": (H,),
+                  p + "mlp.fc2.weight": (E, H), p + "mlp.fc2.bias": (E,)})
+    p = "vision_tower.merger."
+    s.update({p + "ln_q.weight": (E,), p + "ln_q.bias": (E,), p + "mlp.0.weight": (M, M), p + "mlp.0.bias": (M,),
+              p + "mlp.2.weight": (v.hidden_size, M), p + "mlp.2.bias": (v.hidden_size,)})
+    s["language_model.model.embed_tokens.weight"] = (t.vocab_size, D)
+    for i in range(t.num_hidden_layers):
+        p = f"language_model.model.layers.{i}."
+        s.update({p + "input_layernorm.weight": (D,), p + "post_attention_layernorm.weight": (D,),
+                  p + "self_attn.q_proj.weight": (t.num_attention_heads * hd, D), p + "self_attn.q_proj.bias": (t.num_attention_heads * hd,),
+                  p + "self_attn.k_proj.weight": (t.num_key_value_heads * hd, D), p + "self_attn.k_proj.bias": (t.num_key_value_heads * hd,),
+                  p + "self_attn.v_proj.weight": (t.num_key_value_heads * hd, D), p + "self_attn.v_proj.bias": (t.num_key_value_heads * hd,),
+                  p + "self_attn.o_proj.weight": (D, t.num_attention_heads * hd),
+                  p + "mlp.gate_proj.weight": (t.intermediate_size, D), p + "mlp.up_proj.weight": (t.intermediate_size, D),
+                  p + "mlp.down_proj.weight": (D, t.intermediate_size)})
+    s["language_model.model.norm.weight"] = (D,)
+    if not t.tie_word_embeddings:
+        s["language_model.lm_head.weight"] = (t.vocab_size, D)
+    return s
+
+
+def random_weights(cfg, seed: int = 0, device="cuda", dtype=torch.bfloat16, std: float = 0.02, fill: bool = True):
+    """fill=False allocates only (receiving side of the RCCL weight broadcast)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    W: Dict[str, torch.Tensor] = {}
+    for name, shape in weight_shapes(cfg).items():
+        if not fill:
+            W[name] = torch.empty(shape, dtype=dtype, device=device)
+        elif name.endswith("norm1.weight") or name.endswith("norm2.weight") or name.endswith("ln_q.weight") \
+                or name.endswith("layernorm.weight") or name.endswith("model.norm.weight"):
+            W[name] = torch.ones(shape, dtype=dtype, device=device)
+        elif name.endswith(".bias"):
+            W[name] = torch.zeros(shape, dtype=dtype, device=device)
+        else:
+            W[name] = (torch.randn(shape, generator=g, device=device, dtype=torch.float32) * std).to(dtype)
+    return W

@@ -1,0 +1,212 @@
+"""Loading / IO / prompt plumbing with the reference's surface for the hot path:
+
+    load, load_model, load_config      reference mlx_vlm/utils.py:1065-1119, 736-987, 1175-1210
+    get_model_and_args                 reference mlx_vlm/utils.py:588-635 (MODEL_REMAPPING 34-62)
+    prepare_inputs                     reference mlx_vlm/utils.py:1918-2136 (single image + prompt)
+    StoppingCriteria                   reference mlx_vlm/utils.py:2191-2249
+    make_streaming_detokenizer         reference mlx_vlm/tokenizer_utils.py:406-410 (naive variant 19-86)
+
+Host-only code: safetensors -> torch tensors -> Model.load_weights (device packing).
+"""
+from __future__ import annotations
+
+import glob
+import importlib
+import json
+import os
+from typing import Any, Dict, List, Optional, Union
+
+import numpy as np
+import torch
+
+MODEL_REMAPPING = {"qwen2_5_vl": "qwen2_vl"} if False else {}   # only qwen2_vl is built this round
+
+
+def get_model_and_args(config: dict):
+    """reference utils.py:588-635"""
+    model_type = config["model_type"].lower()
+    model_type = MODEL_REMAPPING.get(model_type, model_type)
+    try:
+        arch = importlib.import_module(f"{__package__}.models.{model_type}")
+    except ImportError as e:
+        raise ValueError(f"Model type {model_type} not supported.") from e
+    return arch, model_type
+
+
+def load_config(model_path: str) -> dict:
+    """reference utils.py:1175-1210"""
+    p = os.path.join(model_path, "config.json")
+    if not os.path.exists(p):
+        raise FileNotFoundError(f"Config not found at {model_path}")
+    with open(p) as f:
+        config = json.load(f)
+    g = os.path.join(model_path, "generation_config.json")
+    if os.path.exists(g):
+        try:
+            with open(g) as f:
+                gen = json.load(f)
+            if "eos_token_id" in gen:
+                config["eos_token_id"] = gen["eos_token_id"]
+        except Exception:
+            pass
+    return config
+
+
+def load_model(model_path: str, lazy: bool = False, device="cuda", **kwargs):
+    """reference utils.py:736-987: config -> model class -> sanitize -> load_weights."""
+    from safetensors.torch import load_file
+
+    config = load_config(model_path)
+    files = sorted(glob.glob(os.path.join(model_path, "*.safetensors")))
+    if not files:
+        raise FileNotFoundError(f"No safetensors found in {model_path}")
+    weights: Dict[str, torch.Tensor] = {}
+    for f in files:
+        weights.update(load_file(f))
+    if config.get("quantization"):
+        raise NotImplementedError("MLX affine-quantized checkpoints are a 'next' row (SURVEY §8f.2)")
+    arch, _ = get_model_and_args(config)
+    mc = arch.ModelConfig.from_dict(config)
+    model = arch.Model(mc, device=device, **kwargs)
+    weights = model.sanitize(weights)
+    vt = {k: v for k, v in weights.items() if k.startswith("vision_tower.")}
+    vt = {"vision_tower." + k: v for k, v in model.vision_tower.sanitize(
+        {k[len("vision_tower."):]: v for k, v in vt.items()}).items()}
+    weights = {**{k: v for k, v in weights.items() if not k.startswith("vision_tower.")}, **vt}
+    model.load_weights(weights)
+    return model
+
+
+def load(path_or_hf_repo: str, adapter_path=None, lazy: bool = False, revision=None, strict: bool = True, **kwargs):
+    """reference utils.py:1065-1119 -> (model, processor).  Local paths only (no network in this build)."""
+    if adapter_path is not None:
+        raise NotImplementedError("LoRA adapters are out of scope (SURVEY §2.1 trainer)")
+    if not os.path.isdir(path_or_hf_repo):
+        raise FileNotFoundError(f"{path_or_hf_repo} is not a local model directory")
+    model = load_model(path_or_hf_repo, lazy=lazy, **kwargs)
+    processor = load_processor(path_or_hf_repo, model.config)
+    return model, processor
+
+
+def load_processor(model_path: str, config):
+    """reference utils.py:1243-1276: processor with .tokenizer, .detokenizer and tokenizer.stopping_criteria."""
+    from transformers import AutoTokenizer
+
+    from .models.qwen2_vl.processing_qwen2_vl import Qwen2VLImageProcessor, Qwen2VLProcessor
+
+    tok = AutoTokenizer.from_pretrained(model_path)
+    ip_kwargs = {}
+    pp = os.path.join(model_path, "preprocessor_config.json")
+    if os.path.exists(pp):
+        with open(pp) as f:
+            pc = json.load(f)
+        for k in ("image_mean", "image_std", "min_pixels", "max_pixels", "patch_size", "temporal_patch_size", "merge_size"):
+            if k in pc:
+                ip_kwargs[k] = pc[k]
+    proc = Qwen2VLProcessor(Qwen2VLImageProcessor(**ip_kwargs), tok)
+    eos = config.eos_token_id if getattr(config, "eos_token_id", None) is not None else tok.eos_token_id
+    tok.stopping_criteria = StoppingCriteria(eos if isinstance(eos, list) else [eos], tok)
+    return proc
+
+
+class StoppingCriteria:
+    """reference utils.py:2191-2249"""
+
+    def __init__(self, eos_token_ids: List[int], tokenizer=None, additional_eos_token_ids: Optional[List[int]] = None):
+        self.tokenizer = tokenizer
+        self.additional_eos_token_ids = list(dict.fromkeys(additional_eos_token_ids or ()))
+        self.reset(eos_token_ids)
+
+    def add_eos_token_ids(self, new_eos_token_ids: Union[int, str, List[Union[int, str]], None] = None):
+        if new_eos_token_ids is None:
+            return
+        if self.tokenizer is None:
+            raise ValueError("Processor is not provided")
+        if isinstance(new_eos_token_ids, (str, int)):
+            new_eos_token_ids = [new_eos_token_ids]
+        resolved = []
+        for token in new_eos_token_ids:
+            if isinstance(token, int):
+                resolved.append(token)
+            elif isinstance(token, str):
+                resolved.append(self.tokenizer.encode(" " + token, add_special_tokens=False)[-1])
+        self.eos_token_ids.extend(resolved)
+
+    def reset(self, eos_token_ids: Optional[List[int]] = None):
+        eos_token_ids = eos_token_ids if eos_token_ids is not None else self.tokenizer.eos_token_ids
+        if isinstance(eos_token_ids, int):
+            eos_token_ids = [eos_token_ids]
+        resolved = list(eos_token_ids)
+        resolved.extend(t for t in self.additional_eos_token_ids if t not in resolved)
+        if getattr(self, "eos_token_ids", None) != resolved:
+            self.eos_token_ids = resolved
+
+    def __call__(self, input_ids) -> bool:
+        return input_ids in self.eos_token_ids
+
+
+class NaiveStreamingDetokenizer:
+    """reference tokenizer_utils.py:19-86 (NaiveStreamingDetokenizer): decode the running token list,
+    emit the new text once it no longer ends in an incomplete UTF-8 sequence."""
+
+    def __init__(self, tokenizer):
+        self._tokenizer = tokenizer
+        self.reset()
+
+    def reset(self):
+        self.offset = 0
+        self.tokens: List[int] = []
+        self._text = ""
+        self._current_tokens: List[int] = []
+        self._current_text = ""
+
+    def add_token(self, token, skip_special_token_ids=()):
+        if token in skip_special_token_ids:
+            return
+        self._current_tokens.append(token)
+        self.tokens.append(token)
+
+    def finalize(self):
+        self._text += self._tokenizer.decode(self._current_tokens)
+        self._current_tokens = []
+        self._current_text = ""
+
+    @property
+    def text(self):
+        if self._current_tokens:
+            self._current_text = self._tokenizer.decode(self._current_tokens)
+            if self._current_text.endswith("�"):
+                self._current_text = self._current_text[:-1]
+        if self._current_text and self._current_text[-1] == "\n":
+            self._text += self._current_text
+            self._current_tokens.clear()
+            self._current_text = ""
+        return self._text + self._current_text
+
+    @property
+    def last_segment(self):
+        text = self.text
+        seg = text[self.offset:]
+        self.offset = len(text)
+        return seg
+
+
+def make_streaming_detokenizer(processor):
+    tok = processor.tokenizer if hasattr(processor, "tokenizer") else processor
+    if not hasattr(tok, "decode"):
+        return None
+    return NaiveStreamingDetokenizer(tok)
+
+
+def prepare_inputs(processor, images=None, prompts=None, **kwargs) -> Dict[str, Any]:
+    """reference utils.py:1918-2136, single-sequence form: -> input_ids [1, L] (np.int64), attention_mask,
+    pixel_values [N, C*T*ps*ps] f32, image_grid_thw [n_img, 3]."""
+    if images is not None and not isinstance(images, (list, tuple)):
+        images = [images]
+    imgs = None
+    if images:
+        from .models.qwen2_vl.processing_qwen2_vl import load_image
+
+        imgs = [load_image(im) for im in images]
+    out = processor(images=imgs, text=prompts if isinstance(prompts, str) else list(prompts))
+    return {k: v for k, v in out.items()}

@@ -1,0 +1,64 @@
+"""Shared test helpers: build the product model (HIP) and the oracle from the same seeded weights."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import image_processor as oip
+from oracle import qwen2_vl as oq
+
+
+def model_config_from_oracle(cfg: oq.Cfg):
+    from mlx_vlm_amd.models.qwen2_vl import ModelConfig
+
+    t, v = cfg.text, cfg.vision
+    d = dict(
+        model_type="qwen2_vl", hidden_size=t.hidden_size, num_hidden_layers=t.num_hidden_layers,
+        intermediate_size=t.intermediate_size, num_attention_heads=t.num_attention_heads,
+        num_key_value_heads=t.num_key_value_heads, rms_norm_eps=t.rms_norm_eps, vocab_size=t.vocab_size,
+        rope_theta=t.rope_theta, rope_scaling={"type": "mrope", "mrope_section": list(t.mrope_section)},
+        tie_word_embeddings=t.tie_word_embeddings, image_token_id=cfg.image_token_id,
+        video_token_id=cfg.video_token_id, vision_start_token_id=cfg.vision_start_token_id,
+        vision_config=dict(model_type="qwen2_vl", depth=v.depth, embed_dim=v.embed_dim, hidden_size=v.hidden_size,
+                           num_heads=v.num_heads, patch_size=v.patch_size, mlp_ratio=v.mlp_ratio,
+                           in_channels=v.in_channels, spatial_merge_size=v.spatial_merge_size,
+                           temporal_patch_size=v.temporal_patch_size),
+    )
+    return ModelConfig.from_dict(d)
+
+
+def build_product_model(cfg: oq.Cfg, W, device="cuda", **kw):
+    from mlx_vlm_amd.models.qwen2_vl import Model
+
+    m = Model(model_config_from_oracle(cfg), device=device, **kw)
+    m.load_weights(W)
+    return m
+
+
+def synth_request(cfg: oq.Cfg, sizes, n_text=12, seed=0, text_hi=1000):
+    """-> (input_ids [1,L] int64, pixel_values f32 [N,1176], grid_thw [n,3])"""
+    rng = np.random.default_rng(seed)
+    imgs = [rng.integers(0, 256, (3, h, w), dtype=np.uint8) for (h, w) in sizes]
+    pix, thw = oip.process(imgs)
+    ids = []
+    for _ in imgs:
+        ids += [cfg.vision_start_token_id, cfg.image_token_id, cfg.vision_start_token_id + 1]
+    ids += rng.integers(3, text_hi, n_text).tolist()
+    ids = oip.expand_image_placeholders(ids, cfg.image_token_id, thw)
+    return np.array([ids], dtype=np.int64), pix, thw
+
+
+def bf16_close(a: torch.Tensor, b: torch.Tensor, ulps: float = 2.0, frac_exact: float = 0.0, atol_rms: float = 2e-3):
+    """bf16 comparison: |a-b| <= ulps * 2^-8 * max(|b|, rms*...) element-wise; returns (ok, report)."""
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    rms = float(b.pow(2).mean().sqrt()) + 1e-30
+    tol = ulps * (2.0 ** -8) * b.abs() + atol_rms * rms
+    err = (a - b).abs()
+    bad = err > tol
+    nbad = int(bad.sum())
+    exact = float((a == b).float().mean())
+    rep = f"max_err={float(err.max()):.4g} rms={rms:.4g} bad={nbad}/{a.numel()} exact={exact:.3f}"
+    ok = nbad == 0 and exact >= frac_exact and bool(torch.isfinite(a).all())
+    return ok, rep

