@@ -230,7 +230,7 @@ def main():
         extras = dict(kernels=kr, vit336=(ips336, dt336), vit448=(ips448, dt448))
     cpu = None
     if rank == 0 and ws == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(os.cpu_count() or 1)
+        cpu = cpu_baseline(min(os.cpu_count() or 1, 32))
 
     if rank == 0:
         t = cfg.text_config

@@ -182,16 +182,23 @@ extern "C" int vlm_llm_decode_forward(void* handle, const vlm_decode_args* a, vo
 }
 
 extern "C" int vlm_llm_decode_graph_build(void* handle, const vlm_decode_args* a, void* stream) {
+  // `stream` is unused for the capture itself: capturing on the (legacy) default stream is illegal, so the
+  // step is recorded on a private capture stream (nothing executes during capture) and the instantiated
+  // graph can then be launched on any stream.
+  (void)stream;
   Llm* m = static_cast<Llm*>(handle);
-  if (!m || !a || a->B <= 0 || !m->kv.kpool || !stream) return 1;
+  if (!m || !a || a->B <= 0 || !m->kv.kpool) return 1;
   if (m->exec) { (void)hipGraphExecDestroy(m->exec); m->exec = nullptr; }
   if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
-  hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+  hipStream_t cap = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking);
   if (e != hipSuccess) return 1000 + (int)e;
-  int rc = decode_impl(m, a, stream, &m->launches, true);
+  e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) { (void)hipStreamDestroy(cap); return 1000 + (int)e; }
+  int rc = decode_impl(m, a, (void*)cap, &m->launches, true);
   hipGraph_t g = nullptr;
-  e = hipStreamEndCapture(st, &g);
+  e = hipStreamEndCapture(cap, &g);
+  (void)hipStreamDestroy(cap);
   if (rc != 0) { if (g) (void)hipGraphDestroy(g); return rc; }
   if (e != hipSuccess) return 1000 + (int)e;
   m->graph = g;
