@@ -54,6 +54,20 @@ int vlm_gemm_bf16(const void* A, const void* W, const void* bias, const void* re
 int vlm_gemv_bf16(const void* x, const void* W, const void* bias, const void* res, const void* norm_w, void* y, int M,
                   int N, int K, int ldx, int ldw, int ldy, int ldres, float eps, int epilogue, void* stream);
 
+/* Decode-step fusions built on the same kernels (one decoder layer = 5 launches):
+ * vlm_gemv_qkv_rope_kvwrite: qkv = RMSNorm(h) Wqkv^T + b (language.py:52-54,76,149), then M-RoPE on the q and k
+ *   heads at pos[m] (rope_utils.py:567-651; a decoded text token has equal t/h/w positions, language.py:476-509)
+ *   and KVCache.update_and_fetch (cache.py:345-367): rotated q -> qkv[m][0 : Hq*D], rotated k and v -> slot[m] of
+ *   sequence m in the paged pools.  pos / slot int32 [M] on the device.
+ * vlm_gemv_attn_out: h += merge(attention split partials) Wo^T (language.py:115-120,151): the split-K merge of
+ *   vlm_attn_decode_paged is the GEMV prologue, the residual add its epilogue. */
+int vlm_gemv_qkv_rope_kvwrite(const void* h, const void* norm_w, float eps, const void* Wqkv, const void* bqkv,
+                              void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D, const void* pos,
+                              const void* slot, const void* inv_freq, const void* block_table, int max_pages,
+                              void* kpool, void* vpool, void* stream);
+int vlm_gemv_attn_out(const void* part_o, const void* part_ml, int nsplit, const void* Wo, void* h, int ldh, int M,
+                      int N, int Hq, int D, void* stream);
+
 /* nn.LayerNorm(eps) -> mx.fast.layer_norm (vision.py:109,180-181). dim % 8 == 0, dim <= 8192 */
 int vlm_layernorm(const void* x, const void* w, const void* b, void* y, int rows, int dim, float eps, void* stream);
 
@@ -88,7 +102,8 @@ int vlm_attn_prefill(const void* q, const void* k, const void* v, void* out, int
 
 /* the same op at L == 1 over the paged cache (base.py:366-373 from language.py:115-118).
  * q [B][Hq*D] (row stride ldq); kv_len int32 [B] (+ kv_len_add) keys per sequence;
- * part_o fp32 [B][Hq][nsplit][D], part_ml fp32 [B][Hq][nsplit][2] workspaces; out [B][Hq*D]. D == 128. */
+ * part_o fp32 [B][Hq][nsplit][D], part_ml fp32 [B][Hq][nsplit][2] receive the per-split partials; out [B][Hq*D]
+ * (bf16) gets the merged result, or pass out == NULL and merge in vlm_gemv_attn_out.  D == 128. */
 int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, const void* vpool, const void* block_table,
                           int max_pages, const void* kv_len, int kv_len_add, int B, int Hq, int Hkv, int D,
                           float scale, int nsplit, void* part_o, void* part_ml, void* out, int ldo, void* stream);

@@ -74,6 +74,9 @@ SIGNATURES = {
     "vlm_abi_version": (c_int, []),
     "vlm_gemm_bf16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     "vlm_gemv_bf16": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_float, c_int, c_void_p]),
+    "vlm_gemv_qkv_rope_kvwrite": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p] + [c_int] * 6
+                                  + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p]),
+    "vlm_gemv_attn_out": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "vlm_layernorm": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p]),
     "vlm_rmsnorm_residual": (c_int, [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p]),
     "vlm_rope2d_vision": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),

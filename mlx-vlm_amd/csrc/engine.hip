@@ -139,17 +139,24 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
   TRY(vlm_embed_gather(a->tok, m->g.embed, a->h, B, D, D, c.vocab, stream)); ++n;
   for (int i = 0; i < c.n_layers; ++i) {
     const vlm_llm_layer& w = m->layers[i];
-    // qkv = RMSNorm(h) Wqkv^T + b   (norm fused as GEMV prologue)
-    TRY(vlm_gemv_bf16(a->h, w.wqkv, w.bqkv, nullptr, w.ln1_w, a->qkv, B, QKV, D, D, D, QKV, 0, c.rms_eps, VLM_EPI_BIAS, stream)); ++n;
     void* kp = off(m->kv.kpool, (size_t)i * m->kv.layer_stride * 2);
     void* vp = off(m->kv.vpool, (size_t)i * m->kv.layer_stride * 2);
-    // rope at pos[b], write k/v at slot ctx[b] of sequence b
-    TRY(vlm_mrope_kvwrite(a->qkv, QKV, B, Hq, Hkv, hd, a->pos, a->pos, a->pos, m->g.inv_freq, c.mrope_sec0, c.mrope_sec1,
-                          nullptr, a->ctx, m->kv.block_table, m->kv.max_pages, kp, vp, stream)); ++n;
-    TRY(vlm_attn_decode_paged(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale,
-                              a->nsplit, a->part_o, a->part_ml, a->attn, Hq * hd, stream)); n += 2;
-    // h = h + attn Wo^T
-    TRY(vlm_gemv_bf16(a->attn, w.wo, nullptr, a->h, nullptr, a->h, B, D, Hq * hd, Hq * hd, Hq * hd, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
+    // [RMSNorm + qkv GEMV + bias + M-RoPE at pos[b] + k/v write at slot ctx[b]] in one launch
+    TRY(vlm_gemv_qkv_rope_kvwrite(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos, a->ctx,
+                                  m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, stream)); ++n;
+    // attention over the pages (the new token is already in the cache: kv_len = ctx + 1)
+    if (a->nsplit == 1) {
+      // short contexts: one workgroup per (sequence, kv head) -> final bf16 vector, plain o_proj GEMV + residual
+      TRY(vlm_attn_decode_paged(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale, 1,
+                                a->part_o, a->part_ml, a->attn, Hq * hd, stream)); ++n;
+      TRY(vlm_gemv_bf16(a->attn, w.wo, nullptr, a->h, nullptr, a->h, B, D, Hq * hd, Hq * hd, Hq * hd, D, D, 0.f,
+                        VLM_EPI_RESIDUAL, stream)); ++n;
+    } else {
+      // long contexts: split-K partials, merged in the o_proj GEMV prologue
+      TRY(vlm_attn_decode_paged(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale,
+                                a->nsplit, a->part_o, a->part_ml, nullptr, 0, stream)); ++n;
+      TRY(vlm_gemv_attn_out(a->part_o, a->part_ml, a->nsplit, w.wo, a->h, D, B, D, Hq, hd, stream)); ++n;
+    }
     // act = swiglu(RMSNorm(h) Wgu^T)
     TRY(vlm_gemv_bf16(a->h, w.wgu, nullptr, nullptr, w.ln2_w, a->act, B, 2 * c.inter, D, D, D, c.inter, 0, c.rms_eps, VLM_EPI_SWIGLU, stream)); ++n;
     // h = h + act Wdown^T

@@ -1,160 +1,466 @@
-// Decode-time weight-streaming GEMV for gfx950 (HBM-bound):
-//     y[m][n] = epilogue( sum_k x[m][k] * W[n][k] ),   m < MB <= 8
+// Decode-time weight-streaming GEMV family for gfx950 (HBM-bound):
+//     y[m][n] = epilogue( sum_k prologue(x)[m][k] * W[n][k] ),   m < MB <= 8
 //
 // Replaces the nn.Linear calls of the reference's per-token decode step
 // (mlx_vlm/models/qwen2_vl/language.py:52-55,76,120 q/k/v/o projections;
 //  mlp.py:9-14 + activations.py:7-9 SwiGLU MLP; language.py:514-517 lm_head /
-//  embed_tokens.as_linear) with, optionally, the preceding nn.RMSNorm
-//  (language.py:130-133,149-153,200) fused in as a prologue and the residual
-//  add (language.py:151-153) / SiLU-gated product fused in as epilogues.
+//  embed_tokens.as_linear) with their neighbours fused in:
+//    prologues  RMSNorm of the residual stream (language.py:130-133,149-153,200);
+//               merge of the split-K attention partials (the tail of
+//               mx.fast.scaled_dot_product_attention, base.py:366-373)
+//    epilogues  bias; residual add (language.py:151-153); SwiGLU on interleaved
+//               gate/up rows; M-RoPE (fused-kernel numerics, rope_utils.py:567-651)
+//               + paged KV write (KVCache.update_and_fetch, cache.py:345-367)
+// so a decoder layer is 5 launches: [norm+qkv+rope+kv] [attention] [merge+o_proj+res]
+// [norm+gate/up+swiglu] [down+res].
 //
-// Design (CDNA4): no LDS round trip for the weights - each lane streams 16-byte
-// (8 x bf16) non-temporal loads of R weight rows straight into VGPRs while the
-// activation chunk is read once per k-step (L1/L2 resident, or LDS when the
-// RMSNorm prologue produced it), v_dot2c_f32_bf16 accumulates in fp32, and the
-// R x MB partial sums are reduced with wavefront xor-shuffles.  One wave owns R
-// consecutive output rows, so epilogues (bias, residual, swiglu on interleaved
-// gate/up rows) are race-free and in-place safe.
+// Design (CDNA4).  No LDS round trip for weights: each lane streams 16-byte
+// non-temporal loads of its weight rows straight into VGPRs, and ALL of a wave's
+// weight loads are issued BEFORE the prologue runs, so the HBM stream overlaps
+// the (latency-bound) norm / merge prologue instead of waiting behind it.
+//   * row-wave kernel (K <= 3584): one wave owns R full rows; the activation
+//     vector is produced once per workgroup into LDS; v_dot2c_f32_bf16 in fp32;
+//     wavefront xor-shuffle reductions.
+//   * split-K kernel (large K, e.g. the 8960-wide down projection): the 4 waves of
+//     a workgroup split K for RW rows (N / RW workgroups keep all 256 CUs busy),
+//     partial sums meet in LDS.
 #include "common.cuh"
 #include "../../include/vlm_hip.h"
 
 namespace {
 
-__device__ __forceinline__ float dot8(const uint4& w, const uint4& x, float acc) {
-  acc = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&w.x), *reinterpret_cast<const bf16x2_t*>(&x.x), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&w.y), *reinterpret_cast<const bf16x2_t*>(&x.y), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&w.z), *reinterpret_cast<const bf16x2_t*>(&x.z), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&w.w), *reinterpret_cast<const bf16x2_t*>(&x.w), acc, false);
+enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_ATTN = 2 };
+constexpr int EPI_ROPE_KV = 1 << 10;   // internal epilogue id (qkv projection)
+
+struct RopeKvArgs {
+  const int* pos;            // [M] rope position (all three M-RoPE axes are equal for a decoded text token)
+  const int* slot;           // [M] KV slot (= tokens already in the cache)
+  const float* inv_freq;     // [D/2]
+  const int* block_table;    // [M][max_pages]
+  int max_pages, Hq, Hkv, D;
+  bf16_t* kpool;             // [page][Hkv][D/8][64][8]
+  bf16_t* vpool;             // [page][Hkv][64][D]
+};
+
+struct AttnProArgs {
+  const float* part_o;       // [M][Hq][S][D]
+  const float* part_ml;      // [M][Hq][S][2]
+  int S, Hq, D;
+};
+
+__device__ __forceinline__ u32x4_t ntl(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)); }
+
+// NOTE: __builtin_bit_cast on a vector-ELEMENT lvalue (w.y) silently reads element 0 with this
+// compiler (hipcc / clang 22, verified in the .s: four identical v_dot2c); copy to a scalar first.
+__device__ __forceinline__ float dot2(unsigned w, unsigned x, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w), __builtin_bit_cast(bf16x2_t, x), acc, false);
+}
+__device__ __forceinline__ float dot8(const u32x4_t w, const u32x4_t x, float acc) {
+  const unsigned w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+  acc = dot2(w0, x0, acc);
+  acc = dot2(w1, x1, acc);
+  acc = dot2(w2, x2, acc);
+  acc = dot2(w3, x3, acc);
   return acc;
 }
 
-template <int R, int MB, bool NORM, int EPI>
-__global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W,
-                                                   const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
-                                                   const bf16_t* __restrict__ norm_w, bf16_t* __restrict__ y, int N, int K,
-                                                   int ldx, int ldw, int ldy, int ldres, float eps) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// ------------------------------------------------------------------------------------------
+// row-wave kernel: K <= 512 * KC
+// ------------------------------------------------------------------------------------------
+template <int R, int KC, int MB, int PRO, int EPI>
+__global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W,
+                                                           const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                           const bf16_t* __restrict__ norm_w, bf16_t* __restrict__ y, int N,
+                                                           int K, int ldx, int ldw, int ldy, int ldres, float eps,
+                                                           RopeKvArgs rk, AttnProArgs ap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // xs[MB][K] bf16
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nchunk = K >> 3;
+  const int gw = blockIdx.x * 4 + wave;
 
-  if (NORM) {
-    // prologue: xs[m][:] = T(w * T(x[m] * rsqrt(mean(x^2) + eps)))  -> LDS (bf16)
-    const uint4* wr = reinterpret_cast<const uint4*>(norm_w);
-    for (int m = wave; m < MB; m += 4) {
-      const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)m * ldx);
+  // ---- which rows does this wave own?
+  int row[R];
+  bool rope_pair = false;
+  int rope_head = 0, rope_j = 0;
+  if (EPI == EPI_ROPE_KV) {
+    const int half = rk.D >> 1, n_pair = (rk.Hq + rk.Hkv) * half;
+    if (gw < n_pair) {
+      rope_pair = true;
+      rope_head = gw / half;
+      rope_j = gw % half;
+      row[0] = rope_head * rk.D + rope_j;
+      row[R - 1] = row[0] + half;
+    } else {
+      row[0] = (rk.Hq + rk.Hkv) * rk.D + 2 * (gw - n_pair);
+      row[R - 1] = row[0] + 1;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) row[r] = gw * R + r;
+  }
+  const bool active = row[0] < N;
+
+  // ---- loads are returned in issue order (vmcnt), so the SMALL latency-critical ones go first: the
+  //      activation row for the norm prologue and the epilogue operands; then every weight load of the
+  //      wave.  The prologue then only waits for its own (oldest) loads while the weights keep streaming.
+  u32x4_t xv[KC];
+  uint4 nwv[KC];
+  if (PRO == PRO_RMSNORM) {
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      // branch-free (clamped address + select on the data): a load under a divergent branch makes hipcc
+      // fall back to s_waitcnt vmcnt(0) instead of a counted wait
+      const int ch = lane + 64 * c, chc = min(ch, nchunk - 1);
+      xv[c] = *reinterpret_cast<const u32x4_t*>(x + (size_t)(wave % MB) * ldx + (size_t)chc * 8);   // masked at use
+      nwv[c] = reinterpret_cast<const uint4*>(norm_w)[chc];
+    }
+  }
+  // epilogue operands (bias / residual / rope position, slot, page) for the lane that will store
+  // (raw values only - any arithmetic on them here would force a wait before the weight loads are issued)
+  bf16_t e_b0 = 0, e_b1 = 0, e_r = 0;
+  int e_pos = 0, e_slot = 0;
+  float e_if = 0.f;
+  if (EPI == EPI_ROPE_KV) {
+    const int mm = min(lane, MB - 1), r0 = min(row[0], N - 1), r1 = min(row[R - 1], N - 1);
+    e_b0 = bias[r0];
+    e_b1 = bias[r1];
+    e_slot = rk.slot[mm];
+    e_pos = rk.pos[mm];
+    e_if = rk.inv_freq[rope_j];
+  } else if (!(EPI & VLM_EPI_SWIGLU)) {
+    const int ll = min(lane, R * MB - 1), r = ll / MB, m = ll % MB;
+    int rr = row[0];
+#pragma unroll
+    for (int q = 1; q < R; ++q) rr = (r == q) ? row[q] : rr;
+    rr = min(rr, N - 1);
+    if (EPI & VLM_EPI_BIAS) e_b0 = bias[rr];
+    if (EPI & VLM_EPI_RESIDUAL) e_r = res[(size_t)m * ldres + rr];
+  }
+
+  __builtin_amdgcn_sched_barrier(0);   // keep the issue order: small loads, THEN the weight stream, THEN math
+  u32x4_t wv[R][KC];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bf16_t* wr = W + (size_t)min(row[r], N - 1) * ldw;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const int ch = lane + 64 * c;
+      wv[r][c] = ntl(wr + (size_t)min(ch, nchunk - 1) * 8);   // clamped; the x chunk is masked instead
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- prologue: activation vector(s) -> LDS as bf16
+  if (PRO == PRO_RMSNORM) {
+    // every wave normalises row (wave % MB) - straight-line code, so the x loads above stay ahead of the
+    // weight loads and get a counted wait; waves >= MB duplicate the (tiny) work and just do not store
+#pragma unroll
+    for (int round = 0; round < (MB + 3) / 4; ++round) {
+      const int m = round * 4 + (round == 0 ? wave % MB : wave);
+      if (round > 0) {   // MB == 8: rows 4..7 are fetched here
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          const int ch = lane + 64 * c;
+          const u32x4_t t = *reinterpret_cast<const u32x4_t*>(x + (size_t)m * ldx + (size_t)min(ch, nchunk - 1) * 8);
+          xv[c] = ch < nchunk ? t : u32x4_t{0, 0, 0, 0};
+        }
+      }
       float s = 0.f;
-      for (int c = lane; c < nchunk; c += 64) {
-        const uint4 u = xr[c];
-        const float v[8] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y), bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        if (lane + 64 * c >= nchunk) xv[c] = u32x4_t{0, 0, 0, 0};
+        const float v[8] = {bf_lo(xv[c][0]), bf_hi(xv[c][0]), bf_lo(xv[c][1]), bf_hi(xv[c][1]),
+                            bf_lo(xv[c][2]), bf_hi(xv[c][2]), bf_lo(xv[c][3]), bf_hi(xv[c][3])};
 #pragma unroll
         for (int j = 0; j < 8; ++j) s += v[j] * v[j];
       }
       const float inv = rsqrtf(wave_sum(s) / (float)K + eps);
       uint4* xs = reinterpret_cast<uint4*>(smem + (size_t)m * K * 2);
-      for (int c = lane; c < nchunk; c += 64) {
-        const uint4 u = xr[c], wu = wr[c];
+      const bool writer = round > 0 || wave < MB;
+      // pin the norm-weight registers here: otherwise hipcc sinks their loads into the store branch below,
+      // behind the weight stream, and waits vmcnt(0) for them
+#pragma unroll
+      for (int c = 0; c < KC; ++c) asm volatile("" : "+v"(nwv[c].x), "+v"(nwv[c].y), "+v"(nwv[c].z), "+v"(nwv[c].w));
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const int ch = lane + 64 * c;
+        const u32x4_t u = xv[c];
+        const uint4 wu = nwv[c];   // used unconditionally so its load is not sunk into the branch below
         uint4 o;
-        o.x = pack_bf2(bf_lo(wu.x) * rbf(bf_lo(u.x) * inv), bf_hi(wu.x) * rbf(bf_hi(u.x) * inv));
-        o.y = pack_bf2(bf_lo(wu.y) * rbf(bf_lo(u.y) * inv), bf_hi(wu.y) * rbf(bf_hi(u.y) * inv));
-        o.z = pack_bf2(bf_lo(wu.z) * rbf(bf_lo(u.z) * inv), bf_hi(wu.z) * rbf(bf_hi(u.z) * inv));
-        o.w = pack_bf2(bf_lo(wu.w) * rbf(bf_lo(u.w) * inv), bf_hi(wu.w) * rbf(bf_hi(u.w) * inv));
-        xs[c] = o;
+        o.x = pack_bf2(bf_lo(wu.x) * rbf(bf_lo(u[0]) * inv), bf_hi(wu.x) * rbf(bf_hi(u[0]) * inv));
+        o.y = pack_bf2(bf_lo(wu.y) * rbf(bf_lo(u[1]) * inv), bf_hi(wu.y) * rbf(bf_hi(u[1]) * inv));
+        o.z = pack_bf2(bf_lo(wu.z) * rbf(bf_lo(u[2]) * inv), bf_hi(wu.z) * rbf(bf_hi(u[2]) * inv));
+        o.w = pack_bf2(bf_lo(wu.w) * rbf(bf_lo(u[3]) * inv), bf_hi(wu.w) * rbf(bf_hi(u[3]) * inv));
+        if (writer && ch < nchunk) xs[ch] = o;
       }
     }
+  } else if (PRO == PRO_ATTN) {
+    // x[m][h*D + d] = sum_s f_s O_s[d],  f_s = e^{m_s - M} / sum_t e^{m_t - M} l_t   (merge of the attention splits)
+    // three short phases so that every global load of a phase is independent (one memory round trip each):
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
+    float* mls = reinterpret_cast<float*>(smem + (size_t)MB * K * 2);   // [MB*Hq][S][2] -> f in slot 0
+    const int HD = ap.Hq * ap.D, nml = MB * ap.Hq * ap.S * 2;
+    for (int i = tid; i < nml; i += 256) mls[i] = ap.part_ml[i];
     __syncthreads();
+    if (tid < MB * ap.Hq) {
+      float* r = mls + (size_t)tid * ap.S * 2;
+      float mm = -INFINITY;
+      for (int s = 0; s < ap.S; ++s) mm = fmaxf(mm, r[2 * s]);
+      float ll = 0.f;
+      for (int s = 0; s < ap.S; ++s) ll += (r[2 * s] == -INFINITY) ? 0.f : __expf(r[2 * s] - mm) * r[2 * s + 1];
+      const float il = 1.0f / ll;
+      for (int s = 0; s < ap.S; ++s) r[2 * s] = (r[2 * s] == -INFINITY) ? 0.f : __expf(r[2 * s] - mm) * il;
+    }
+    __syncthreads();
+    for (int i = tid; i < MB * HD; i += 256) {
+      const int m = i / HD, hd = i % HD, h = hd / ap.D, d = hd % ap.D;
+      const size_t base = ((size_t)m * ap.Hq + h) * ap.S;
+      const float* f = mls + base * 2;
+      float acc = 0.f;
+#pragma unroll 8
+      for (int s = 0; s < ap.S; ++s) acc += f[2 * s] * ap.part_o[(base + s) * ap.D + d];
+      xs[(size_t)m * K + hd] = f2bf(acc);
+    }
+  } else {
+    for (int i = tid; i < MB * nchunk; i += 256) {
+      const int m = i / nchunk, ch = i % nchunk;
+      reinterpret_cast<uint4*>(smem + (size_t)m * K * 2)[ch] = reinterpret_cast<const uint4*>(x + (size_t)m * ldx)[ch];
+    }
   }
-
-  const int row0 = (blockIdx.x * 4 + wave) * R;
-  if (row0 >= N) return;
-  const uint4* wrow[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) wrow[r] = reinterpret_cast<const uint4*>(W + (size_t)min(row0 + r, N - 1) * ldw);
+  __syncthreads();
+  if (!active) return;
 
   float acc[R][MB];
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
-
-#pragma unroll 2
-  for (int c = lane; c < nchunk; c += 64) {
-    uint4 wv[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) wv[r] = nt_load16(wrow[r] + c);
-    uint4 xv[MB];
+  for (int c = 0; c < KC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunk) {
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-      if (NORM) xv[m] = *reinterpret_cast<const uint4*>(smem + ((size_t)m * K + (size_t)c * 8) * 2);
-      else xv[m] = *reinterpret_cast<const uint4*>(x + (size_t)m * ldx + (size_t)c * 8);
+      for (int m = 0; m < MB; ++m) {
+        const u32x4_t xv = *reinterpret_cast<const u32x4_t*>(smem + ((size_t)m * K + (size_t)ch * 8) * 2);
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r][m] = dot8(wv[r][c], xv, acc[r][m]);
+      }
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-      for (int m = 0; m < MB; ++m) acc[r][m] = dot8(wv[r], xv[m], acc[r][m]);
   }
-
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int m = 0; m < MB; ++m) acc[r][m] = wave_sum(acc[r][m]);
 
+  if (EPI == EPI_ROPE_KV) {
+    // R == 2: (d, d + D/2) of one q/k head, or two consecutive v rows.  Lane m stores batch row m.
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      a0 = (lane == m) ? acc[0][m] : a0;
+      a1 = (lane == m) ? acc[R - 1][m] : a1;
+    }
+    if (lane < MB) {
+      const int m = lane;
+      const float y0 = rbf(a0 + bf2f(e_b0)), y1 = rbf(a1 + bf2f(e_b1));
+      const size_t e_page = (size_t)rk.block_table[(size_t)m * rk.max_pages + (e_slot >> 6)];
+      const int e_within = e_slot & 63;
+      if (rope_pair) {
+        float sn, cs;
+        sincosf((float)e_pos * e_if, &sn, &cs);
+        const float o0 = y0 * cs - y1 * sn, o1 = y1 * cs + y0 * sn;
+        if (rope_head < rk.Hq) {
+          y[(size_t)m * ldy + row[0]] = f2bf(o0);
+          y[(size_t)m * ldy + row[R - 1]] = f2bf(o1);
+        } else {
+          const int g = rope_head - rk.Hq, d0 = rope_j, d1 = rope_j + (rk.D >> 1);
+          bf16_t* kb = rk.kpool + (e_page * rk.Hkv + g) * (size_t)(rk.D >> 3) * 512;
+          kb[((size_t)(d0 >> 3) * 64 + e_within) * 8 + (d0 & 7)] = f2bf(o0);
+          kb[((size_t)(d1 >> 3) * 64 + e_within) * 8 + (d1 & 7)] = f2bf(o1);
+        }
+      } else {
+        const int vr = row[0] - (rk.Hq + rk.Hkv) * rk.D, g = vr / rk.D, d = vr % rk.D;
+        bf16_t* vb = rk.vpool + ((e_page * rk.Hkv + g) * 64 + e_within) * (size_t)rk.D + d;
+        *reinterpret_cast<uint32_t*>(vb) = pack_bf2(y0, y1);
+      }
+    }
+    return;
+  }
   if (EPI & VLM_EPI_SWIGLU) {
-    // rows (2j, 2j+1) of W are (gate_j, up_j); R is even
 #pragma unroll
     for (int r = 0; r < R; r += 2)
 #pragma unroll
-      for (int m = 0; m < MB; ++m) {
-        if (lane == (r >> 1) * MB + m && row0 + r + 1 < N) {
-          const float o = swiglu_(rbf(acc[r][m]), rbf(acc[r + 1][m]));
-          y[(size_t)m * ldy + ((row0 + r) >> 1)] = f2bf(o);
-        }
-      }
+      for (int m = 0; m < MB; ++m)
+        if (lane == (r >> 1) * MB + m && row[r] + 1 < N)
+          y[(size_t)m * ldy + (row[r] >> 1)] = f2bf(swiglu_(rbf(acc[r][m]), rbf(acc[r + 1][m])));
     return;
   }
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-      if (lane == r * MB + m && row0 + r < N) {
+    for (int m = 0; m < MB; ++m)
+      if (lane == r * MB + m && row[r] < N) {
         float v = acc[r][m];
-        if (EPI & VLM_EPI_BIAS) v += bf2f(bias[row0 + r]);
-        if (EPI & VLM_EPI_RESIDUAL) v = rbf(v) + bf2f(res[(size_t)m * ldres + row0 + r]);
-        y[(size_t)m * ldy + row0 + r] = f2bf(v);
+        if (EPI & VLM_EPI_BIAS) v += bf2f(e_b0);
+        if (EPI & VLM_EPI_RESIDUAL) v = rbf(v) + bf2f(e_r);
+        y[(size_t)m * ldy + row[r]] = f2bf(v);
       }
-    }
 }
 
-template <int R, int MB, bool NORM, int EPI>
-int launch(const void* x, const void* W, const void* bias, const void* res, const void* norm_w, void* y, int N, int K,
-           int ldx, int ldw, int ldy, int ldres, float eps, hipStream_t st) {
-  const int grid = vlm_cdiv(N, 4 * R);
-  const size_t lds = NORM ? (size_t)MB * K * 2 : 0;
-  hipLaunchKernelGGL((gemv_kernel<R, MB, NORM, EPI>), dim3(grid), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)W,
-                     (const bf16_t*)bias, (const bf16_t*)res, (const bf16_t*)norm_w, (bf16_t*)y, N, K, ldx, ldw, ldy, ldres, eps);
+// ------------------------------------------------------------------------------------------
+// split-K kernel: K <= 2048 * NI; the 4 waves of a workgroup split K for RW rows
+// ------------------------------------------------------------------------------------------
+template <int RW, int NI, int MB, int EPI>
+__global__ __launch_bounds__(256) void gemv_splitk_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W,
+                                                          const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                          bf16_t* __restrict__ y, int N, int K, int ldx, int ldw, int ldy,
+                                                          int ldres) {
+  __shared__ float red[4][RW][MB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nchunk = K >> 3;
+  const int row0 = blockIdx.x * RW;
+  // small latency-critical loads first (loads return in issue order): activations + epilogue operands
+  u32x4_t xv[MB][NI];
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int ch = tid + 256 * i;
+      xv[m][i] = *reinterpret_cast<const u32x4_t*>(x + (size_t)m * ldx + (size_t)min(ch, nchunk - 1) * 8);   // masked at use
+    }
+  bf16_t e_b = 0, e_r = 0;   // raw: no arithmetic before the weight loads are issued
+  {
+    const int tt = min(tid, RW * MB - 1), rr = min(row0 + tt / MB, N - 1);
+    if (EPI & VLM_EPI_BIAS) e_b = bias[rr];
+    if (EPI & VLM_EPI_RESIDUAL) e_r = res[(size_t)(tt % MB) * ldres + rr];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  u32x4_t wv[RW][NI];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const bf16_t* wr = W + (size_t)min(row0 + r, N - 1) * ldw;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int ch = tid + 256 * i;
+      wv[r][i] = ntl(wr + (size_t)min(ch, nchunk - 1) * 8);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float acc[RW][MB];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const u32x4_t xm = (tid + 256 * i < nchunk) ? xv[m][i] : u32x4_t{0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < RW; ++r) acc[r][m] = dot8(wv[r][i], xm, acc[r][m]);
+    }
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const float s = wave_sum(acc[r][m]);
+      if (lane == 0) red[wave][r][m] = s;
+    }
+  __syncthreads();
+  if (tid < RW * MB) {
+    const int r = tid / MB, m = tid % MB;
+    if (row0 + r < N) {
+      float v = red[0][r][m] + red[1][r][m] + red[2][r][m] + red[3][r][m];
+      if (EPI & VLM_EPI_BIAS) v += bf2f(e_b);
+      if (EPI & VLM_EPI_RESIDUAL) v = rbf(v) + bf2f(e_r);
+      y[(size_t)m * ldy + row0 + r] = f2bf(v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+struct Args {
+  const void *x, *W, *bias, *res, *norm_w;
+  void* y;
+  int N, K, ldx, ldw, ldy, ldres;
+  float eps;
+  RopeKvArgs rk;
+  AttnProArgs ap;
+  hipStream_t st;
+};
+
+inline int launch_err() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
 }
 
-template <int MB, bool NORM, int EPI>
-int launch_r(const void* x, const void* W, const void* bias, const void* res, const void* norm_w, void* y, int N, int K,
-             int ldx, int ldw, int ldy, int ldres, float eps, hipStream_t st) {
-  // enough rows per wave to amortise the x reads, but keep >= ~2 workgroups per CU
-  if (N >= 8192 && MB <= 4) return launch<4, MB, NORM, EPI>(x, W, bias, res, norm_w, y, N, K, ldx, ldw, ldy, ldres, eps, st);
-  return launch<2, MB, NORM, EPI>(x, W, bias, res, norm_w, y, N, K, ldx, ldw, ldy, ldres, eps, st);
+template <int R, int KC, int MB, int PRO, int EPI>
+int launch_rw(const Args& a, int n_waves) {
+  const int grid = vlm_cdiv(n_waves, 4);
+  const size_t lds = (size_t)MB * a.K * 2 + (PRO == PRO_ATTN ? (size_t)MB * a.ap.Hq * a.ap.S * 2 * sizeof(float) : 0);
+  hipLaunchKernelGGL((gemv_rowwave_kernel<R, KC, MB, PRO, EPI>), dim3(grid), dim3(256), lds, a.st, (const bf16_t*)a.x,
+                     (const bf16_t*)a.W, (const bf16_t*)a.bias, (const bf16_t*)a.res, (const bf16_t*)a.norm_w,
+                     (bf16_t*)a.y, a.N, a.K, a.ldx, a.ldw, a.ldy, a.ldres, a.eps, a.rk, a.ap);
+  return launch_err();
 }
 
-template <bool NORM, int EPI>
-int launch_m(int M, const void* x, const void* W, const void* bias, const void* res, const void* norm_w, void* y, int N,
-             int K, int ldx, int ldw, int ldy, int ldres, float eps, hipStream_t st) {
+template <int KC, int MB, int PRO, int EPI>
+int launch_rw_r(const Args& a) {
+  // R = 4 rows per wave once there are enough rows to give every CU several workgroups
+  if (EPI != EPI_ROPE_KV && a.N >= 8192 && MB <= 4 && KC <= 3) return launch_rw<4, KC, MB, PRO, EPI>(a, vlm_cdiv(a.N, 4));
+  if (EPI == EPI_ROPE_KV) {
+    const int waves = (a.rk.Hq + a.rk.Hkv) * (a.rk.D / 2) + a.rk.Hkv * a.rk.D / 2;
+    return launch_rw<2, KC, MB, PRO, EPI>(a, waves);
+  }
+  return launch_rw<2, KC, MB, PRO, EPI>(a, vlm_cdiv(a.N, 2));
+}
+
+template <int MB, int PRO, int EPI>
+int launch_rw_k(const Args& a) {
+  if (a.K <= 512 * 3) return launch_rw_r<3, MB, PRO, EPI>(a);
+  if (a.K <= 512 * 7) return launch_rw_r<7, MB, PRO, EPI>(a);
+  return VLM_ERR_SHAPE;
+}
+
+template <int PRO, int EPI>
+int launch_rw_m(int M, const Args& a) {
   switch (M) {
-    case 1: return launch_r<1, NORM, EPI>(x, W, bias, res, norm_w, y, N, K, ldx, ldw, ldy, ldres, eps, st);
-    case 2: return launch_r<2, NORM, EPI>(x, W, bias, res, norm_w, y, N, K, ldx, ldw, ldy, ldres, eps, st);
-    case 3: case 4: {
-      // M==3 runs as 4 with the caller's buffers padded to 4 rows
-      if (M == 3) return VLM_ERR_SHAPE;
-      return launch_r<4, NORM, EPI>(x, W, bias, res, norm_w, y, N, K, ldx, ldw, ldy, ldres, eps, st);
-    }
-    case 8: return launch_r<8, NORM, EPI>(x, W, bias, res, norm_w, y, N, K, ldx, ldw, ldy, ldres, eps, st);
+    case 1: return launch_rw_k<1, PRO, EPI>(a);
+    case 2: return launch_rw_k<2, PRO, EPI>(a);
+    case 4: return launch_rw_k<4, PRO, EPI>(a);
+    case 8: return launch_rw_k<8, PRO, EPI>(a);
+    default: return VLM_ERR_SHAPE;
+  }
+}
+
+template <int RW, int NI, int MB, int EPI>
+int launch_sk(const Args& a) {
+  hipLaunchKernelGGL((gemv_splitk_kernel<RW, NI, MB, EPI>), dim3(vlm_cdiv(a.N, RW)), dim3(256), 0, a.st, (const bf16_t*)a.x,
+                     (const bf16_t*)a.W, (const bf16_t*)a.bias, (const bf16_t*)a.res, (bf16_t*)a.y, a.N, a.K, a.ldx, a.ldw,
+                     a.ldy, a.ldres);
+  return launch_err();
+}
+
+template <int MB, int EPI>
+int launch_sk_k(const Args& a) {
+  const int ni = vlm_cdiv(a.K, 2048);
+  if (MB <= 2) {
+    if (ni <= 5) return launch_sk<4, 5, MB, EPI>(a);
+    if (ni <= 10) return launch_sk<2, 10, MB, EPI>(a);
+  } else {
+    if (ni <= 5) return launch_sk<2, 5, MB, EPI>(a);
+    if (ni <= 10) return launch_sk<1, 10, MB, EPI>(a);
+  }
+  return VLM_ERR_SHAPE;
+}
+
+template <int EPI>
+int launch_sk_m(int M, const Args& a) {
+  switch (M) {
+    case 1: return launch_sk_k<1, EPI>(a);
+    case 2: return launch_sk_k<2, EPI>(a);
+    case 4: return launch_sk_k<4, EPI>(a);
+    case 8: return launch_sk_k<8, EPI>(a);
     default: return VLM_ERR_SHAPE;
   }
 }
@@ -169,24 +475,58 @@ extern "C" int vlm_gemv_bf16(const void* x, const void* W, const void* bias, con
   if ((epilogue & VLM_EPI_RESIDUAL) && !res) return VLM_ERR_ARG;
   if (K % 8 != 0 || ldx % 8 != 0 || ldw % 8 != 0) return VLM_ERR_SHAPE;
   if ((epilogue & VLM_EPI_SWIGLU) && (N % 2 != 0)) return VLM_ERR_SHAPE;
-  if (norm_w && (size_t)M * K * 2 > 64 * 1024) return VLM_ERR_SHAPE;
-  hipStream_t st = (hipStream_t)stream;
-#define GO(NORMV, E) return launch_m<NORMV, E>(M, x, W, bias, res, norm_w, y, N, K, ldx, ldw, ldy, ldres, eps, st)
-  if (norm_w) {
+  if ((size_t)M * K * 2 > 64 * 1024 && (norm_w || K <= 3584)) return VLM_ERR_SHAPE;
+  Args a{x, W, bias, res, norm_w, y, N, K, ldx, ldw, ldy, ldres, eps, RopeKvArgs{}, AttnProArgs{}, (hipStream_t)stream};
+  if (K <= 3584) {
+#define GO(P, E) return launch_rw_m<P, E>(M, a)
+    if (norm_w) {
+      switch (epilogue) {
+        case VLM_EPI_NONE: GO(PRO_RMSNORM, VLM_EPI_NONE);
+        case VLM_EPI_BIAS: GO(PRO_RMSNORM, VLM_EPI_BIAS);
+        case VLM_EPI_SWIGLU: GO(PRO_RMSNORM, VLM_EPI_SWIGLU);
+        default: return VLM_ERR_ARG;
+      }
+    }
     switch (epilogue) {
-      case VLM_EPI_NONE: GO(true, VLM_EPI_NONE);
-      case VLM_EPI_BIAS: GO(true, VLM_EPI_BIAS);
-      case VLM_EPI_SWIGLU: GO(true, VLM_EPI_SWIGLU);
+      case VLM_EPI_NONE: GO(PRO_NONE, VLM_EPI_NONE);
+      case VLM_EPI_BIAS: GO(PRO_NONE, VLM_EPI_BIAS);
+      case VLM_EPI_RESIDUAL: GO(PRO_NONE, VLM_EPI_RESIDUAL);
+      case VLM_EPI_SWIGLU: GO(PRO_NONE, VLM_EPI_SWIGLU);
       default: return VLM_ERR_ARG;
     }
-  } else {
-    switch (epilogue) {
-      case VLM_EPI_NONE: GO(false, VLM_EPI_NONE);
-      case VLM_EPI_BIAS: GO(false, VLM_EPI_BIAS);
-      case VLM_EPI_RESIDUAL: GO(false, VLM_EPI_RESIDUAL);
-      case VLM_EPI_SWIGLU: GO(false, VLM_EPI_SWIGLU);
-      default: return VLM_ERR_ARG;
-    }
-  }
 #undef GO
+  }
+  if (norm_w) return VLM_ERR_SHAPE;   // the norm prologue needs the row-wave kernel (K <= 3584)
+  switch (epilogue) {
+    case VLM_EPI_NONE: return launch_sk_m<VLM_EPI_NONE>(M, a);
+    case VLM_EPI_BIAS: return launch_sk_m<VLM_EPI_BIAS>(M, a);
+    case VLM_EPI_RESIDUAL: return launch_sk_m<VLM_EPI_RESIDUAL>(M, a);
+    default: return VLM_ERR_ARG;
+  }
+}
+
+extern "C" int vlm_gemv_qkv_rope_kvwrite(const void* h, const void* norm_w, float eps, const void* Wqkv,
+                                         const void* bqkv, void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D,
+                                         const void* pos, const void* slot, const void* inv_freq,
+                                         const void* block_table, int max_pages, void* kpool, void* vpool,
+                                         void* stream) {
+  if (!h || !norm_w || !Wqkv || !bqkv || !qkv || !pos || !slot || !inv_freq || !block_table || !kpool || !vpool)
+    return VLM_ERR_ARG;
+  if (hidden % 8 || D % 16 || hidden > 3584 || (size_t)M * hidden * 2 > 64 * 1024) return VLM_ERR_SHAPE;
+  const int N = (Hq + 2 * Hkv) * D;
+  Args a{h, Wqkv, bqkv, nullptr, norm_w, qkv, N, hidden, hidden, hidden, ldq, 0, eps,
+         RopeKvArgs{(const int*)pos, (const int*)slot, (const float*)inv_freq, (const int*)block_table, max_pages, Hq, Hkv,
+                    D, (bf16_t*)kpool, (bf16_t*)vpool},
+         AttnProArgs{}, (hipStream_t)stream};
+  return launch_rw_m<PRO_RMSNORM, EPI_ROPE_KV>(M, a);
+}
+
+extern "C" int vlm_gemv_attn_out(const void* part_o, const void* part_ml, int nsplit, const void* Wo, void* h, int ldh,
+                                 int M, int N, int Hq, int D, void* stream) {
+  if (!part_o || !part_ml || !Wo || !h || nsplit <= 0) return VLM_ERR_ARG;
+  const int K = Hq * D;
+  if (K % 8 || K > 3584 || (size_t)M * K * 2 > 64 * 1024) return VLM_ERR_SHAPE;
+  Args a{nullptr, Wo, nullptr, h, nullptr, h, N, K, K, K, ldh, ldh, 0.f, RopeKvArgs{},
+         AttnProArgs{(const float*)part_o, (const float*)part_ml, nsplit, Hq, D}, (hipStream_t)stream};
+  return launch_rw_m<PRO_ATTN, VLM_EPI_RESIDUAL>(M, a);
 }

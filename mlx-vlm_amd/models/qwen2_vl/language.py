@@ -41,11 +41,11 @@ def _to_np(x):
 class DecodeState:
     """Device-resident state of a batch of B decoding sequences (what one graph replay reads/writes)."""
 
-    def __init__(self, lm: "LanguageModel", B: int, nsplit: int = 8, ring_len: int = 64):
+    def __init__(self, lm: "LanguageModel", B: int, nsplit: int = 32, ring_len: int = 64):
         t, dev = lm.args, lm.device
         D, hd, Hq, Hkv = t.hidden_size, lm.head_dim, t.num_attention_heads, t.num_key_value_heads
         bf, i32 = torch.bfloat16, torch.int32
-        self.B, self.nsplit, self.ring_len = B, nsplit, ring_len
+        self.B, self.nsplit, self.ring_len = B, nsplit, ring_len   # nsplit: buffers sized for the max, see decode_begin
         self.tok = torch.zeros(B, dtype=i32, device=dev)
         self.pos = torch.zeros(B, dtype=i32, device=dev)
         self.ctx = torch.zeros(B, dtype=i32, device=dev)
@@ -324,6 +324,12 @@ class LanguageModel:
         seqs = [c[0]._seq for c in caches]
         for s in seqs:
             s.reserve(s.offset + max_new_tokens + 1)
+        # attention decomposition for this generation: up to 2048 tokens one workgroup per (sequence, kv head)
+        # walks the pages itself (nsplit = 1, no merge pass); beyond that, split-K with one workgroup per
+        # page-stride (<= 32 splits) merged in the o_proj prologue
+        max_total = max(s.offset for s in seqs) + max_new_tokens + 1
+        G = self.args.num_attention_heads // self.args.num_key_value_heads
+        st.nsplit = 1 if (max_total <= 2048 and G <= 7) else max(2, min(32, (max_total + 8 * PAGE - 1) // (8 * PAGE)))
         # the engine indexes block-table rows by batch row: sequences must sit in rows 0..B-1 of a view
         rows = [s.seq for s in seqs]
         if rows != list(range(rows[0], rows[0] + B)):
@@ -354,7 +360,7 @@ class LanguageModel:
         check(L.vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
         args = st.args(**sampler_args)
         if use_graph:
-            key = (st.seq_row0, tuple(sorted(sampler_args.items())))
+            key = (st.seq_row0, st.nsplit, tuple(sorted(sampler_args.items())))
             if st.graph_key != key or getattr(self, "_graph_owner", None) is not st:
                 check(L.vlm_llm_decode_graph_build(self._handle, C.byref(args), stream), "decode_graph_build")
                 st.graph_key = key

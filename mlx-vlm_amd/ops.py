@@ -57,6 +57,28 @@ def gemv(x, w, bias=None, res=None, norm_w=None, out=None, eps=1e-6, epilogue=EP
     return out
 
 
+def gemv_qkv_rope_kvwrite(h, norm_w, wqkv, bqkv, Hq, Hkv, D, pos, slot, inv_freq, block_table, kpool, vpool, eps=1e-6,
+                          out=None):
+    """decode-step fusion: RMSNorm + qkv GEMV + bias + M-RoPE + paged KV write.  -> qkv [M, (Hq+2Hkv)*D] (q part valid)"""
+    _dev(h, norm_w, wqkv, bqkv, pos, slot, inv_freq, block_table, kpool, vpool)
+    M, K = h.shape
+    if out is None:
+        out = torch.zeros(M, (Hq + 2 * Hkv) * D, dtype=torch.bfloat16, device=h.device)
+    check(_lib.lib().vlm_gemv_qkv_rope_kvwrite(_p(h), _p(norm_w), eps, _p(wqkv), _p(bqkv), _p(out), out.stride(0), M, K,
+                                               Hq, Hkv, D, _p(pos), _p(slot), _p(inv_freq), _p(block_table),
+                                               block_table.shape[1], _p(kpool), _p(vpool), _stream()), "gemv_qkv_rope_kvwrite")
+    return out
+
+
+def gemv_attn_out_(part_o, part_ml, wo, h, Hq, D):
+    """h += merge(partials) @ wo.T   (in place on the residual stream)"""
+    _dev(part_o, part_ml, wo, h)
+    M, N = h.shape
+    check(_lib.lib().vlm_gemv_attn_out(_p(part_o), _p(part_ml), part_o.shape[2], _p(wo), _p(h), h.stride(0), M, N, Hq, D,
+                                       _stream()), "gemv_attn_out")
+    return h
+
+
 def layernorm(x, w, b, eps=1e-6, out=None):
     _dev(x, w, b)
     if out is None:
@@ -106,17 +128,20 @@ def attn_prefill(q, k, v, cu_seqlens, total_qblocks, Hq, Hkv, D, scale, causal, 
     return out
 
 
-def attn_decode_paged(q, kpool, vpool, block_table, kv_len, kv_len_add, Hq, Hkv, D, scale, nsplit, out=None):
+def attn_decode_paged(q, kpool, vpool, block_table, kv_len, kv_len_add, Hq, Hkv, D, scale, nsplit, out=None,
+                      merge=True):
+    """merge=True -> bf16 [B, Hq*D]; merge=False -> (part_o, part_ml) for gemv_attn_out_"""
     _dev(q, kpool, vpool, block_table, kv_len)
     B = q.shape[0]
     part_o = torch.empty(B, Hq, nsplit, D, dtype=torch.float32, device=q.device)
     part_ml = torch.empty(B, Hq, nsplit, 2, dtype=torch.float32, device=q.device)
-    if out is None:
+    if merge and out is None:
         out = torch.empty(B, Hq * D, dtype=torch.bfloat16, device=q.device)
     check(_lib.lib().vlm_attn_decode_paged(_p(q), q.stride(0), _p(kpool), _p(vpool), _p(block_table),
                                            block_table.shape[1], _p(kv_len), kv_len_add, B, Hq, Hkv, D, scale, nsplit,
-                                           _p(part_o), _p(part_ml), _p(out), out.stride(0), _stream()), "attn_decode")
-    return out
+                                           _p(part_o), _p(part_ml), _p(out) if merge else None,
+                                           out.stride(0) if merge else 0, _stream()), "attn_decode")
+    return out if merge else (part_o, part_ml)
 
 
 def embed_gather(ids, table, out=None):

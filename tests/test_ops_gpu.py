@@ -243,7 +243,8 @@ def test_attn_prefill_forced_rescale_spike(vops):
     assert ok, rep
 
 
-@pytest.mark.parametrize("lens,nsplit", [([1, 130], 8), ([700, 64], 4), ([65], 1), ([2000, 1, 63, 64], 8)])
+@pytest.mark.parametrize("lens,nsplit", [([1, 130], 8), ([700, 64], 4), ([65], 1), ([2000, 1, 63, 64], 8),
+                                         ([640], 1), ([513, 1100], 1), ([1, 64, 65, 2047], 1)])
 def test_attn_decode_paged(vops, lens, nsplit):
     """fp32 P.V in the kernel: 2 ulps + small floor."""
     B, Hq, Hkv, D = len(lens), 12, 2, 128
@@ -363,3 +364,74 @@ def test_sample_categorical_matches_oracle_hash_rng(vops):
             ref = O.categorical_gumbel(lp[b], 0.8, seed=7, step=s, row=b)
             agree += int(int(tok[b]) == ref)
     assert agree >= 78, agree   # logf/expf ulp differences may flip a near-tie
+
+
+# ------------------------------------------------------------------ decode-step fusions
+@pytest.mark.parametrize("M", [1, 4])
+def test_gemv_qkv_rope_kvwrite_fused(vops, M):
+    """[RMSNorm + qkv GEMV + bias + M-RoPE + paged KV write] vs the oracle ops chained (2 ulps: GEMV order + rope)."""
+    Hq, Hkv, D, K = 12, 2, 128, 1536
+    h = rnd(M, K, seed=60)
+    nw = (1 + 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(61))).to(BF)
+    wqkv, bqkv = rnd((Hq + 2 * Hkv) * D, K, seed=62, scale=0.05), rnd((Hq + 2 * Hkv) * D, seed=63, scale=0.3)
+    pos = torch.tensor([37, 1000, 5, 2047][:M], dtype=torch.int32)
+    slot = torch.tensor([70, 3, 64, 129][:M], dtype=torch.int32)
+    inv = O.mrope_inv_freq(D, 1e6)
+    sel = O.chunked_position_selector([16, 24, 24], D // 2)
+    qkv = O.linear(O.rms_norm(h, nw, 1e-6), wqkv, bqkv).view(M, Hq + 2 * Hkv, D)
+    p3 = pos.long()[None, :, None].expand(3, M, 1)
+    qr = O.mrope_apply(qkv[:, :Hq][:, :, None], p3, inv, sel, "fused")[:, :, 0]
+    kr = O.mrope_apply(qkv[:, Hq:Hq + Hkv][:, :, None], p3, inv, sel, "fused")[:, :, 0]
+    n_pages, max_pages = 16, 4
+    bt = (torch.arange(M * max_pages, dtype=torch.int32).reshape(M, max_pages) * 3 + 1) % n_pages
+    kpool = torch.zeros(n_pages, Hkv, D // 8, 64, 8, dtype=BF, device="cuda")
+    vpool = torch.zeros(n_pages, Hkv, 64, D, dtype=BF, device="cuda")
+    out = vops.gemv_qkv_rope_kvwrite(h.cuda(), nw.cuda(), wqkv.cuda(), bqkv.cuda(), Hq, Hkv, D, pos.cuda(), slot.cuda(),
+                                     inv.cuda(), bt.cuda(), kpool, vpool)
+    ok, rep = bf16_close(out.view(M, Hq + 2 * Hkv, D)[:, :Hq], qr, ulps=2)
+    assert ok, rep
+    kp = kpool.cpu().permute(0, 1, 3, 2, 4).reshape(n_pages, Hkv, 64, D)
+    vp = vpool.cpu()
+    for m in range(M):
+        page, within = int(bt[m, int(slot[m]) // 64]), int(slot[m]) % 64
+        ok, rep = bf16_close(kp[page, :, within], kr[m], ulps=2)
+        assert ok, (m, rep)
+        ok, rep = bf16_close(vp[page, :, within], qkv[m, Hq + Hkv:], ulps=2)
+        assert ok, (m, rep)
+    # nothing else was written
+    assert int((kpool != 0).sum().cpu()) <= M * Hkv * D and int((vpool != 0).sum().cpu()) <= M * Hkv * D
+
+
+@pytest.mark.parametrize("lens,nsplit", [([300], 5), ([700, 64, 1, 130], 8), ([1000, 999], 16)])
+def test_attn_decode_partials_plus_gemv_attn_out(vops, lens, nsplit):
+    """split partials -> merge fused as the o_proj GEMV prologue -> residual add, vs oracle sdpa + linear + add."""
+    B, Hq, Hkv, D, N = len(lens), 12, 2, 128, 1536
+    scale = D ** -0.5
+    max_pages = max((n + 63) // 64 for n in lens)
+    n_pages = sum((n + 63) // 64 for n in lens) + 1
+    bt = torch.zeros(B, max_pages, dtype=torch.int32)
+    kpool = torch.zeros(n_pages, Hkv, D // 8, 64, 8, dtype=BF)
+    vpool = torch.zeros(n_pages, Hkv, 64, D, dtype=BF)
+    q = rnd(B, Hq * D, seed=70)
+    refs, page = [], 0
+    for b, n in enumerate(lens):
+        k, v = rnd(n, Hkv, D, seed=71 + b), rnd(n, Hkv, D, seed=81 + b)
+        for p in range((n + 63) // 64):
+            bt[b, p] = page
+            m = min(64, n - p * 64)
+            kpool[page, :, :, :m, :] = k[p * 64:p * 64 + m].permute(1, 0, 2).reshape(Hkv, m, D // 8, 8).permute(0, 2, 1, 3)
+            vpool[page, :, :m, :] = v[p * 64:p * 64 + m].permute(1, 0, 2)
+            page += 1
+        refs.append(O.sdpa(q[b].view(1, Hq, 1, D), k.permute(1, 0, 2)[None], v.permute(1, 0, 2)[None], scale)[0, :, 0])
+    attn = torch.stack(refs).reshape(B, Hq * D)
+    if B == 3:
+        pytest.skip("B must be 1/2/4/8")
+    wo, h = rnd(N, Hq * D, seed=90, scale=0.05), rnd(B, N, seed=91)
+    ref = O.add(h, O.linear(attn, wo))
+    kv_len = torch.tensor(lens, dtype=torch.int32).cuda()
+    po, pml = vops.attn_decode_paged(q.cuda(), kpool.cuda(), vpool.cuda(), bt.cuda(), kv_len, 0, Hq, Hkv, D, scale, nsplit,
+                                     merge=False)
+    hh = h.cuda().clone()
+    out = vops.gemv_attn_out_(po, pml, wo.cuda(), hh, Hq, D)
+    ok, rep = bf16_close(out, ref, ulps=2, atol_rms=4e-3)
+    assert ok, rep
