@@ -80,4 +80,11 @@ __device__ __forceinline__ float swiglu_(float g, float u) {
   return silu * u;
 }
 
+// V pool key-slot order inside a 64-token page (see attn_decode.hip): keys of each 32-block are stored in
+// the k-slot order of the P.V MFMA so that a V^T operand fragment is one contiguous 16-byte load.
+__host__ __device__ __forceinline__ int vlm_vslot(int within) {
+  const int kk = within & 31;
+  return (within & 32) + 8 * ((kk & 15) >> 2) + 4 * (kk >> 4) + (kk & 3);
+}
+
 static inline int vlm_cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -39,7 +39,7 @@ struct RopeKvArgs {
   const int* block_table;    // [M][max_pages]
   int max_pages, Hq, Hkv, D;
   bf16_t* kpool;             // [page][Hkv][D/8][64][8]
-  bf16_t* vpool;             // [page][Hkv][64][D]
+  bf16_t* vpool;             // [page][Hkv][D][64 key slots]
 };
 
 struct AttnProArgs {
@@ -280,8 +280,9 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
         }
       } else {
         const int vr = row[0] - (rk.Hq + rk.Hkv) * rk.D, g = vr / rk.D, d = vr % rk.D;
-        bf16_t* vb = rk.vpool + ((e_page * rk.Hkv + g) * 64 + e_within) * (size_t)rk.D + d;
-        *reinterpret_cast<uint32_t*>(vb) = pack_bf2(y0, y1);
+        bf16_t* vb = rk.vpool + ((e_page * rk.Hkv + g) * (size_t)rk.D + d) * 64 + vlm_vslot(e_within);   // [D][64 slots]
+        vb[0] = f2bf(y0);
+        vb[64] = f2bf(y1);
       }
     }
     return;

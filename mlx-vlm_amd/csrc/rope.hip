@@ -12,7 +12,8 @@
 // Paged KV layout (ours; 64 tokens per page, sized for decode reads):
 //   K pool: [page][Hkv][D/8][64][8]  - a wave reading one 8-wide d-chunk of the
 //           64 keys of a page issues one contiguous 1 KiB load (lane = key)
-//   V pool: [page][Hkv][64][D]       - row-major rows for the P.V pass
+//   V pool: [page][Hkv][D][64 slots] - transposed, key slots in the k-slot order of the decode P.V MFMA
+//           (vlm_vslot), so a V^T operand fragment (d = lane&15, 8 key slots) is one 16-byte load
 #include "common.cuh"
 #include "../../include/vlm_hip.h"
 
@@ -115,7 +116,11 @@ __global__ __launch_bounds__(256) void mrope_kvwrite_kernel(
     const int vi = it - rot_items;
     const int g = vi / (D >> 3), c = vi % (D >> 3);
     const uint4 v = *reinterpret_cast<const uint4*>(row + (size_t)(Hq + Hkv + g) * D + c * 8);
-    *reinterpret_cast<uint4*>(vpool + (((size_t)page * Hkv + g) * 64 + within) * D + c * 8) = v;
+    bf16_t* vb = vpool + (((size_t)page * Hkv + g) * D + c * 8) * 64 + vlm_vslot(within);   // [D][64 slots]
+    vb[0 * 64] = (bf16_t)(v.x & 0xffffu); vb[1 * 64] = (bf16_t)(v.x >> 16);
+    vb[2 * 64] = (bf16_t)(v.y & 0xffffu); vb[3 * 64] = (bf16_t)(v.y >> 16);
+    vb[4 * 64] = (bf16_t)(v.z & 0xffffu); vb[5 * 64] = (bf16_t)(v.z >> 16);
+    vb[6 * 64] = (bf16_t)(v.w & 0xffffu); vb[7 * 64] = (bf16_t)(v.w >> 16);
   }
 }
 

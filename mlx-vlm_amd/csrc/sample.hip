@@ -48,13 +48,12 @@ __global__ __launch_bounds__(256) void logprob_argmax_kernel(const bf16_t* __res
   __shared__ float sv[4];
   __shared__ int si[4];
   const int b = blockIdx.y, blk = blockIdx.x;
-  float m = -INFINITY;
-  for (int i = 0; i < NBLK; ++i) m = fmaxf(m, ws[((size_t)b * NBLK + i) * 2]);
-  float s = 0.f;
-  for (int i = 0; i < NBLK; ++i) {
-    const float mi = ws[((size_t)b * NBLK + i) * 2];
-    if (mi > -INFINITY) s += ws[((size_t)b * NBLK + i) * 2 + 1] * expf(mi - m);
-  }
+  // merge the NBLK (= 64 = one wavefront) partials: lane i takes partial i, shuffle reductions - every wave
+  // does it redundantly (a serial loop of 128 dependent L2 loads cost ~10 us here)
+  const int li = threadIdx.x & 63;
+  const float pm = ws[((size_t)b * NBLK + li) * 2], ps = ws[((size_t)b * NBLK + li) * 2 + 1];
+  const float m = wave_max(pm);
+  const float s = wave_sum(pm > -INFINITY ? ps * expf(pm - m) : 0.f);
   const float lse = rbf(m + logf(s));          // logsumexp materialised in the logits dtype
   const int per = ((V + NBLK - 1) / NBLK + 7) & ~7;
   const int lo = blk * per, hi = min(V, lo + per);

@@ -6,7 +6,7 @@ KVCache; make_prompt_cache cache.py:45-70).  Here ALL layers of ALL sequences
 share two preallocated pools (288 GB of HBM make preallocation the natural
 choice) addressed through a block table, 64 tokens per page:
 
-    K pool [layer][page][Hkv][D/8][64][8]      V pool [layer][page][Hkv][64][D]
+    K pool [layer][page][Hkv][D/8][64][8]      V pool [layer][page][Hkv][D][64 key slots]
 
 The objects handed to user code keep the reference's contract (`offset`,
 `state`, `is_trimmable/trim`, `size`, `empty`, `nbytes`, one object per layer
@@ -21,6 +21,8 @@ import numpy as np
 import torch
 
 PAGE = 64
+# V key-slot order inside a page (csrc/common.cuh vlm_vslot): slot of token `w` of the page
+VSLOT = [(w & 32) + 8 * (((w & 31) & 15) >> 2) + 4 * ((w & 31) >> 4) + (w & 3) for w in range(PAGE)]
 
 
 class KVPool:
@@ -84,7 +86,7 @@ class KVPool:
     def layer_views(self, layer: int):
         H, D = self.n_kv_heads, self.head_dim
         k = self.kpool[layer].view(self.n_pages, H, D // 8, PAGE, 8)
-        v = self.vpool[layer].view(self.n_pages, H, PAGE, D)
+        v = self.vpool[layer].view(self.n_pages, H, D, PAGE)
         return k, v
 
 
@@ -160,7 +162,8 @@ class KVCache:
         pages = torch.tensor(self._seq.pages, dtype=torch.long, device=kp.device)
         k = kp[pages]                       # [np, H, D/8, 64, 8]
         k = k.permute(1, 0, 3, 2, 4).reshape(H, -1, D)[:, :S]
-        v = vp[pages].permute(1, 0, 2, 3).reshape(H, -1, D)[:, :S]
+        slots = torch.tensor(VSLOT, dtype=torch.long, device=vp.device)
+        v = vp[pages][..., slots].permute(1, 0, 3, 2).reshape(H, -1, D)[:, :S]      # [np,H,D,64] -> token order
         return k[None].contiguous(), v[None].contiguous()
 
     @property

@@ -328,8 +328,7 @@ class LanguageModel:
         # walks the pages itself (nsplit = 1, no merge pass); beyond that, split-K with one workgroup per
         # page-stride (<= 32 splits) merged in the o_proj prologue
         max_total = max(s.offset for s in seqs) + max_new_tokens + 1
-        G = self.args.num_attention_heads // self.args.num_key_value_heads
-        st.nsplit = 1 if (max_total <= 2048 and G <= 7) else max(2, min(32, (max_total + 8 * PAGE - 1) // (8 * PAGE)))
+        st.nsplit = 1 if max_total <= 2048 else max(2, min(32, (max_total + 16 * PAGE - 1) // (16 * PAGE)))
         # the engine indexes block-table rows by batch row: sequences must sit in rows 0..B-1 of a view
         rows = [s.seq for s in seqs]
         if rows != list(range(rows[0], rows[0] + B)):

@@ -16,6 +16,17 @@ import torch
 from oracle import ops as O
 from tests.helpers import bf16_close
 
+# V pool key-slot order inside a page (csrc/common.cuh vlm_vslot)
+VSLOT = [(w & 32) + 8 * (((w & 31) & 15) >> 2) + 4 * ((w & 31) >> 4) + (w & 3) for w in range(64)]
+
+
+def v_to_pool(v_tokens):
+    """[m <= 64 tokens, Hkv, D] -> [Hkv, D, 64 slots] page image (unwritten slots NaN-free zeros)"""
+    m, H, D = v_tokens.shape
+    out = torch.zeros(H, D, 64, dtype=v_tokens.dtype)
+    out[:, :, VSLOT[:m]] = v_tokens.permute(1, 2, 0)
+    return out
+
 pytestmark = pytest.mark.gpu
 
 BF = torch.bfloat16
@@ -173,7 +184,7 @@ def test_mrope_kvwrite_prefill_and_pages(vops):
     n_pages, max_pages = 8, 4
     bt = torch.tensor([[3, 1, 0, 0], [6, 0, 0, 0]], dtype=torch.int32)
     kpool = torch.zeros(n_pages, Hkv, D // 8, 64, 8, dtype=BF, device="cuda")
-    vpool = torch.zeros(n_pages, Hkv, 64, D, dtype=BF, device="cuda")
+    vpool = torch.zeros(n_pages, Hkv, D, 64, dtype=BF, device="cuda")
     out = vops.mrope_kvwrite_(qkv.cuda().clone(), Hq, Hkv, D, pos[0].int().cuda(), pos[1].int().cuda(), pos[2].int().cuda(),
                               inv.cuda(), 16, 24, kv_seq.cuda(), kv_slot.cuda(), bt.cuda(), kpool, vpool)
     o = out.view(T, Hq + 2 * Hkv, D)
@@ -184,7 +195,7 @@ def test_mrope_kvwrite_prefill_and_pages(vops):
     assert torch.equal(o[:, Hq + Hkv:].cpu(), x[:, Hq + Hkv:])
     # page contents == what the kernel left in the qkv buffer (bit-exact copies, layout check)
     kp = kpool.cpu().permute(0, 1, 3, 2, 4).reshape(n_pages, Hkv, 64, D)
-    vp = vpool.cpu()
+    vp = vpool.cpu()[..., VSLOT].permute(0, 1, 3, 2)      # [page, Hkv, D, slot] -> [page, Hkv, token, D]
     oc = o.cpu()
     for t in range(T):
         s, slot = int(kv_seq[t]), int(kv_slot[t])
@@ -246,7 +257,7 @@ def test_attn_prefill_forced_rescale_spike(vops):
 @pytest.mark.parametrize("lens,nsplit", [([1, 130], 8), ([700, 64], 4), ([65], 1), ([2000, 1, 63, 64], 8),
                                          ([640], 1), ([513, 1100], 1), ([1, 64, 65, 2047], 1)])
 def test_attn_decode_paged(vops, lens, nsplit):
-    """fp32 P.V in the kernel: 2 ulps + small floor."""
+    """P rounded to bf16 for the P.V MFMA (as in the prefill flash kernel): 2 ulps + 2% of the output rms."""
     B, Hq, Hkv, D = len(lens), 12, 2, 128
     scale = D ** -0.5
     g = torch.Generator().manual_seed(27)
@@ -255,7 +266,7 @@ def test_attn_decode_paged(vops, lens, nsplit):
     perm = torch.randperm(n_pages, generator=g).tolist()
     bt = torch.zeros(B, max_pages, dtype=torch.int32)
     kpool = torch.full((n_pages, Hkv, D // 8, 64, 8), float("nan"), dtype=BF)   # unwritten slots hold NaN on purpose
-    vpool = torch.full((n_pages, Hkv, 64, D), float("nan"), dtype=BF)
+    vpool = torch.full((n_pages, Hkv, D, 64), float("nan"), dtype=BF)
     q = rnd(B, Hq * D, seed=28)
     refs = []
     for b, n in enumerate(lens):
@@ -266,13 +277,13 @@ def test_attn_decode_paged(vops, lens, nsplit):
             m = min(64, n - p * 64)
             kk = k[p * 64:p * 64 + m]                       # [m, Hkv, D]
             kpool[page, :, :, :m, :] = kk.permute(1, 0, 2).reshape(Hkv, m, D // 8, 8).permute(0, 2, 1, 3)
-            vpool[page, :, :m, :] = v[p * 64:p * 64 + m].permute(1, 0, 2)
+            vpool[page][:, :, VSLOT[:m]] = v[p * 64:p * 64 + m].permute(1, 2, 0)
         qb = q[b].view(1, Hq, 1, D)
         refs.append(O.sdpa(qb, k.permute(1, 0, 2)[None], v.permute(1, 0, 2)[None], scale)[0, :, 0])
     ref = torch.stack(refs).reshape(B, Hq * D)
     kv_len = torch.tensor(lens, dtype=torch.int32)
     out = vops.attn_decode_paged(q.cuda(), kpool.cuda(), vpool.cuda(), bt.cuda(), kv_len.cuda(), 0, Hq, Hkv, D, scale, nsplit)
-    ok, rep = bf16_close(out, ref, ulps=2, atol_rms=2e-3)
+    ok, rep = bf16_close(out, ref, ulps=2, atol_rms=2e-2)
     assert ok, rep
 
 
@@ -385,13 +396,13 @@ def test_gemv_qkv_rope_kvwrite_fused(vops, M):
     n_pages, max_pages = 16, 4
     bt = (torch.arange(M * max_pages, dtype=torch.int32).reshape(M, max_pages) * 3 + 1) % n_pages
     kpool = torch.zeros(n_pages, Hkv, D // 8, 64, 8, dtype=BF, device="cuda")
-    vpool = torch.zeros(n_pages, Hkv, 64, D, dtype=BF, device="cuda")
+    vpool = torch.zeros(n_pages, Hkv, D, 64, dtype=BF, device="cuda")
     out = vops.gemv_qkv_rope_kvwrite(h.cuda(), nw.cuda(), wqkv.cuda(), bqkv.cuda(), Hq, Hkv, D, pos.cuda(), slot.cuda(),
                                      inv.cuda(), bt.cuda(), kpool, vpool)
     ok, rep = bf16_close(out.view(M, Hq + 2 * Hkv, D)[:, :Hq], qr, ulps=2)
     assert ok, rep
     kp = kpool.cpu().permute(0, 1, 3, 2, 4).reshape(n_pages, Hkv, 64, D)
-    vp = vpool.cpu()
+    vp = vpool.cpu()[..., VSLOT].permute(0, 1, 3, 2)
     for m in range(M):
         page, within = int(bt[m, int(slot[m]) // 64]), int(slot[m]) % 64
         ok, rep = bf16_close(kp[page, :, within], kr[m], ulps=2)
@@ -402,7 +413,7 @@ def test_gemv_qkv_rope_kvwrite_fused(vops, M):
     assert int((kpool != 0).sum().cpu()) <= M * Hkv * D and int((vpool != 0).sum().cpu()) <= M * Hkv * D
 
 
-@pytest.mark.parametrize("lens,nsplit", [([300], 5), ([700, 64, 1, 130], 8), ([1000, 999], 16)])
+@pytest.mark.parametrize("lens,nsplit", [([300], 2), ([700, 64, 1, 130], 3), ([5000, 999], 4)])
 def test_attn_decode_partials_plus_gemv_attn_out(vops, lens, nsplit):
     """split partials -> merge fused as the o_proj GEMV prologue -> residual add, vs oracle sdpa + linear + add."""
     B, Hq, Hkv, D, N = len(lens), 12, 2, 128, 1536
@@ -411,7 +422,7 @@ def test_attn_decode_partials_plus_gemv_attn_out(vops, lens, nsplit):
     n_pages = sum((n + 63) // 64 for n in lens) + 1
     bt = torch.zeros(B, max_pages, dtype=torch.int32)
     kpool = torch.zeros(n_pages, Hkv, D // 8, 64, 8, dtype=BF)
-    vpool = torch.zeros(n_pages, Hkv, 64, D, dtype=BF)
+    vpool = torch.zeros(n_pages, Hkv, D, 64, dtype=BF)
     q = rnd(B, Hq * D, seed=70)
     refs, page = [], 0
     for b, n in enumerate(lens):
@@ -420,7 +431,7 @@ def test_attn_decode_partials_plus_gemv_attn_out(vops, lens, nsplit):
             bt[b, p] = page
             m = min(64, n - p * 64)
             kpool[page, :, :, :m, :] = k[p * 64:p * 64 + m].permute(1, 0, 2).reshape(Hkv, m, D // 8, 8).permute(0, 2, 1, 3)
-            vpool[page, :, :m, :] = v[p * 64:p * 64 + m].permute(1, 0, 2)
+            vpool[page][:, :, VSLOT[:m]] = v[p * 64:p * 64 + m].permute(1, 2, 0)
             page += 1
         refs.append(O.sdpa(q[b].view(1, Hq, 1, D), k.permute(1, 0, 2)[None], v.permute(1, 0, 2)[None], scale)[0, :, 0])
     attn = torch.stack(refs).reshape(B, Hq * D)
@@ -433,5 +444,5 @@ def test_attn_decode_partials_plus_gemv_attn_out(vops, lens, nsplit):
                                      merge=False)
     hh = h.cuda().clone()
     out = vops.gemv_attn_out_(po, pml, wo.cuda(), hh, Hq, D)
-    ok, rep = bf16_close(out, ref, ulps=2, atol_rms=4e-3)
+    ok, rep = bf16_close(out, ref, ulps=2, atol_rms=1e-2)
     assert ok, rep
