@@ -48,6 +48,10 @@ int vlm_abi_version(void);
 int vlm_gemm_bf16(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
                   int lda, int ldw, int ldc, int ldres, int epilogue, void* stream);
 
+/* test / A-B knob for vlm_gemm_bf16 tile staging: 0 = automatic (global_load_lds DMA when K % 64 == 0),
+ * 1 = always global -> VGPR -> LDS.  Results are identical. */
+int vlm_gemm_set_staging(int mode);
+
 /* y[M,N] = epi(x[M,K] . W[N,K]^T) for the decode step, M in {1,2,4,8}; weight streaming.
  * norm_w != NULL fuses y = f(RMSNorm(x; norm_w, eps)) (language.py:130-133,149-153,200).
  * Same reference call sites as vlm_gemm_bf16 at L == 1. */

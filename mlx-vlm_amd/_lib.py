@@ -73,6 +73,7 @@ P = C.POINTER
 SIGNATURES = {
     "vlm_abi_version": (c_int, []),
     "vlm_gemm_bf16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    "vlm_gemm_set_staging": (c_int, [c_int]),
     "vlm_gemv_bf16": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_float, c_int, c_void_p]),
     "vlm_gemv_qkv_rope_kvwrite": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p] + [c_int] * 6
                                   + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p]),

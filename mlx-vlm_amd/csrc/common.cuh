@@ -68,7 +68,9 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigmoid on the hardware transcendental units (v_exp_f32 + v_rcp_f32, ~1-2 ulp): the GEMM epilogues apply it
+// to every output element, where the accurate expf + IEEE divide cost more than the bias/activation traffic
+__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 // nn.GELU(approx="fast") : x * sigmoid(1.702 x)        (reference vision.py:167)
 __device__ __forceinline__ float gelu_fast_(float x) { return x * sigmoidf_(1.702f * x); }
 // nn.GELU() exact erf form                              (reference vision.py:112)

@@ -23,12 +23,17 @@
 
 namespace {
 
+bool g_force_regstage = false;   // test hook (vlm_gemm_set_staging): exercise the register-staged kernel
+
 constexpr int BK = 64;          // k elements per LDS tile
 constexpr int ROWB = BK * 2;    // bytes per tile row (128)
 
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
 
-template <int BM, int BN, int EPI>
+// GLDS = true: tiles are staged with global_load_lds_dwordx4 (HBM -> LDS DMA, no VGPR round trip, no ds_write
+// pass).  The DMA writes lane-linear (wave base + lane*16 B), so the XOR slot swizzle is applied on the per-lane
+// SOURCE address and the LDS image is exactly the one the register-staged path builds.  Needs K % 64 == 0.
+template <int BM, int BN, int EPI, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                         const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
                                                         bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldw,
@@ -86,13 +91,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (K + BK - 1) / BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1) < nk;
-    if (more) gload(kt + 1);
-    const char* as = smem + (kt & 1) * STAGE;
+  auto compute = [&](int buf) {
+    const char* as = smem + buf * STAGE;
     const char* ws = as + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -114,57 +114,125 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
         for (int j = 0; j < MT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
     }
-    if (more) lstore((kt + 1) & 1);
+  };
+
+  if (GLDS) {
+    constexpr int A_IT = BM / 32, W_IT = BN / 32;   // 1 KiB (8 rows) DMA pieces per wave
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+    const int rl = lane >> 3, sp = lane & 7;
+    const bf16_t* asrc[A_IT];
+    const bf16_t* wsrc[W_IT];
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) {
+      const int row = 8 * (uw * A_IT + j) + rl;
+      asrc[j] = A + (size_t)min(m0 + row, M - 1) * lda + ((sp ^ ((row >> 1) & 7)) << 3);
+    }
+#pragma unroll
+    for (int j = 0; j < W_IT; ++j) {
+      const int row = 8 * (uw * W_IT + j) + rl;
+      wsrc[j] = W + (size_t)min(n0 + row, N - 1) * ldw + ((sp ^ ((row >> 1) & 7)) << 3);
+    }
+    auto issue = [&](int kt, int buf) {
+      char* as = smem + buf * STAGE;
+      char* ws = as + A_BYTES;
+#pragma unroll
+      for (int j = 0; j < A_IT; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[j] + (size_t)kt * BK),
+                                         (__attribute__((address_space(3))) void*)(as + (uw * A_IT + j) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int j = 0; j < W_IT; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + (size_t)kt * BK),
+                                         (__attribute__((address_space(3))) void*)(ws + (uw * W_IT + j) * 1024), 16, 0, 0);
+    };
+    issue(0, 0);
+    __syncthreads();   // hipcc drains vmcnt(0) for the in-flight LDS DMA before the barrier
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+      compute(kt & 1);
+      __syncthreads();
+    }
+  } else {
+    gload(0);
+    lstore(0);
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = (kt + 1) < nk;
+      if (more) gload(kt + 1);
+      compute(kt & 1);
+      if (more) lstore((kt + 1) & 1);
+      __syncthreads();
+    }
   }
 
-  // epilogue: lane holds D^T[n = nb + (lane>>4)*4 + r][m = mb + (lane&15)]
+  // ---- epilogue.  Lane holds D^T[n = nb + (lane>>4)*4 + r][m = mb + (lane&15)].  Bias / activation are applied
+  //      in registers (rounded to bf16 at the reference's points), the tile is transposed through LDS (free after
+  //      the k loop) and written with fully coalesced 16-byte stores; the residual is added in that pass from
+  //      equally coalesced 16-byte loads.
+  constexpr bool SWI = (EPI & VLM_EPI_SWIGLU) != 0;
+  constexpr int OUT_N = SWI ? BN / 2 : BN;      // output columns of this tile
+  constexpr int C_LD = OUT_N + 8;               // padded row (elements)
+  bf16_t* cs = reinterpret_cast<bf16_t*>(smem);
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
-    const int m = m0 + wm * WM + j * 16 + (lane & 15);
-    if (m >= M) continue;
+    const int ml = wm * WM + j * 16 + (lane & 15);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      const int n = n0 + wn * WN + i * 16 + (lane >> 4) * 4;
-      if (n >= N) continue;
+      const int nl = wn * WN + i * 16 + (lane >> 4) * 4;
+      const int n = min(n0 + nl, N - 4);
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       if (EPI & VLM_EPI_BIAS) {
         const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
         v[0] += bf_lo(b.x); v[1] += bf_hi(b.x); v[2] += bf_lo(b.y); v[3] += bf_hi(b.y);
       }
-      if (EPI & VLM_EPI_SWIGLU) {
+      if (SWI) {
         // interleaved (gate, up) rows of W -> N/2 outputs
         const float o0 = swiglu_(rbf(v[0]), rbf(v[1])), o1 = swiglu_(rbf(v[2]), rbf(v[3]));
-        *reinterpret_cast<uint32_t*>(C + (size_t)m * ldc + (n >> 1)) = pack_bf2(o0, o1);
-        continue;
-      }
-      if (EPI & VLM_EPI_GELU_FAST) {
+        *reinterpret_cast<uint32_t*>(cs + ml * C_LD + (nl >> 1)) = pack_bf2(o0, o1);
+      } else {
+        if (EPI & VLM_EPI_GELU_FAST) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_fast_(rbf(v[r]));
-      }
-      if (EPI & VLM_EPI_GELU_ERF) {
+          for (int r = 0; r < 4; ++r) v[r] = gelu_fast_(rbf(v[r]));
+        }
+        if (EPI & VLM_EPI_GELU_ERF) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_(rbf(v[r]));
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf_(rbf(v[r]));
+        }
+        uint2 o;
+        o.x = pack_bf2(v[0], v[1]);
+        o.y = pack_bf2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(cs + ml * C_LD + nl) = o;
       }
-      if (EPI & VLM_EPI_RESIDUAL) {
-        const uint2 rr = *reinterpret_cast<const uint2*>(res + (size_t)m * ldres + n);
-        v[0] = rbf(v[0]) + bf_lo(rr.x); v[1] = rbf(v[1]) + bf_hi(rr.x);
-        v[2] = rbf(v[2]) + bf_lo(rr.y); v[3] = rbf(v[3]) + bf_hi(rr.y);
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int CPR = OUT_N / 8;                // 16-byte chunks per tile row
+    const int n_out = SWI ? (N >> 1) : N, n0o = SWI ? (n0 >> 1) : n0;
+#pragma unroll 2
+    for (int c = tid; c < BM * CPR; c += 256) {
+      const int row = c / CPR, cc = c % CPR;
+      const int m = m0 + row, n = n0o + cc * 8;
+      if (m < M && n < n_out) {
+        uint4 u = *reinterpret_cast<const uint4*>(cs + row * C_LD + cc * 8);
+        if (EPI & VLM_EPI_RESIDUAL) {
+          const uint4 r = *reinterpret_cast<const uint4*>(res + (size_t)m * ldres + n);
+          u.x = pack_bf2(bf_lo(u.x) + bf_lo(r.x), bf_hi(u.x) + bf_hi(r.x));
+          u.y = pack_bf2(bf_lo(u.y) + bf_lo(r.y), bf_hi(u.y) + bf_hi(r.y));
+          u.z = pack_bf2(bf_lo(u.z) + bf_lo(r.z), bf_hi(u.z) + bf_hi(r.z));
+          u.w = pack_bf2(bf_lo(u.w) + bf_lo(r.w), bf_hi(u.w) + bf_hi(r.w));
+        }
+        *reinterpret_cast<uint4*>(C + (size_t)m * ldc + n) = u;
       }
-      uint2 o;
-      o.x = pack_bf2(v[0], v[1]);
-      o.y = pack_bf2(v[2], v[3]);
-      *reinterpret_cast<uint2*>(C + (size_t)m * ldc + n) = o;
     }
   }
 }
 
-template <int BM, int BN, int EPI>
+template <int BM, int BN, int EPI, bool GLDS>
 int launch_cfg(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
                int ldw, int ldc, int ldres, hipStream_t st) {
   const int tiles_m = vlm_cdiv(M, BM), tiles_n = vlm_cdiv(N, BN), nwg = tiles_m * tiles_n;
   const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI>), dim3(nwg), dim3(256), lds, st, (const bf16_t*)A, (const bf16_t*)W,
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, GLDS>), dim3(nwg), dim3(256), lds, st, (const bf16_t*)A, (const bf16_t*)W,
                      (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
@@ -173,23 +241,35 @@ int launch_cfg(const void* A, const void* W, const void* bias, const void* res, 
 template <int EPI>
 int launch_epi(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
                int ldw, int ldc, int ldres, hipStream_t st) {
-  // pick the largest tile that still yields >= ~1 workgroup per CU (256 CUs)
+  // pick the largest tile that still yields >= ~1 workgroup per CU (256 CUs); LDS-DMA staging when K % 64 == 0
   const long t128 = (long)vlm_cdiv(M, 128) * vlm_cdiv(N, 128);
   const long t64n = (long)vlm_cdiv(M, 64) * vlm_cdiv(N, 128);
-  if (t128 >= 200) return launch_cfg<128, 128, EPI>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
-  if (t64n >= 200) return launch_cfg<64, 128, EPI>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
-  return launch_cfg<64, 64, EPI>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
+  const bool glds = (K % BK == 0) && !g_force_regstage;
+#define CFG(BMV, BNV)                                                                                            \
+  (glds ? launch_cfg<BMV, BNV, EPI, true>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st)                \
+        : launch_cfg<BMV, BNV, EPI, false>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st))
+  if (t128 >= 200) return CFG(128, 128);
+  if (t64n >= 200) return CFG(64, 128);
+  return CFG(64, 64);
+#undef CFG
 }
 
 }  // namespace
+
+// 0 = automatic (LDS DMA when K % 64 == 0), 1 = always stage through registers.  Test / A-B knob only.
+extern "C" int vlm_gemm_set_staging(int mode) {
+  g_force_regstage = (mode == 1);
+  return VLM_OK;
+}
 
 extern "C" int vlm_gemm_bf16(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N,
                              int K, int lda, int ldw, int ldc, int ldres, int epilogue, void* stream) {
   if (!A || !W || !C || M < 0 || N <= 0 || K <= 0) return VLM_ERR_ARG;
   if ((epilogue & VLM_EPI_BIAS) && !bias) return VLM_ERR_ARG;
   if ((epilogue & VLM_EPI_RESIDUAL) && !res) return VLM_ERR_ARG;
-  if (K % 8 != 0 || N % 8 != 0 || lda % 8 != 0 || ldw % 8 != 0 || ldc % 4 != 0) return VLM_ERR_SHAPE;
-  if ((epilogue & VLM_EPI_RESIDUAL) && ldres % 4 != 0) return VLM_ERR_SHAPE;
+  if (K % 8 != 0 || N % 8 != 0 || lda % 8 != 0 || ldw % 8 != 0 || ldc % 8 != 0) return VLM_ERR_SHAPE;
+  if ((epilogue & VLM_EPI_RESIDUAL) && ldres % 8 != 0) return VLM_ERR_SHAPE;
+  if ((epilogue & VLM_EPI_SWIGLU) && N % 16 != 0) return VLM_ERR_SHAPE;
   if (M == 0) return VLM_OK;
   hipStream_t st = (hipStream_t)stream;
 #define GO(E) return launch_epi<E>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st)

@@ -186,3 +186,8 @@ def sample(logits, temperature=0.0, top_p=1.0, min_p=0.0, top_k=0, seed=0, step=
                                 float(temperature), float(top_p), float(min_p), int(top_k), int(seed) & 0xFFFFFFFF,
                                 _p(step), _stream()), "sample")
     return tok, lp
+
+
+def gemm_set_staging(mode: int):
+    """0 = automatic (LDS DMA when K % 64 == 0), 1 = always register staging (test / A-B knob)."""
+    check(_lib.lib().vlm_gemm_set_staging(int(mode)), "gemm_set_staging")

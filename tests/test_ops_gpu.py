@@ -446,3 +446,17 @@ def test_attn_decode_partials_plus_gemv_attn_out(vops, lens, nsplit):
     out = vops.gemv_attn_out_(po, pml, wo.cuda(), hh, Hq, D)
     ok, rep = bf16_close(out, ref, ulps=2, atol_rms=1e-2)
     assert ok, rep
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 3840, 1280), (300, 640, 320), (77, 1280, 1216), (130, 1536, 8960)])
+def test_gemm_lds_dma_staging_equals_register_staging(vops, M, N, K):
+    """global_load_lds (source-swizzled DMA) and global->VGPR->LDS staging build the same LDS image: bit-identical C."""
+    a, w, b = rnd(M, K, seed=100).cuda(), rnd(N, K, seed=101, scale=0.05).cuda(), rnd(N, seed=102).cuda()
+    try:
+        vops.gemm_set_staging(1)
+        ref = vops.gemm(a, w, bias=b, epilogue=vops.EPI_BIAS | vops.EPI_GELU_FAST)
+        vops.gemm_set_staging(0)
+        out = vops.gemm(a, w, bias=b, epilogue=vops.EPI_BIAS | vops.EPI_GELU_FAST)
+    finally:
+        vops.gemm_set_staging(0)
+    assert torch.equal(out, ref)
