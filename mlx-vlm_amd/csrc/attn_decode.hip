@@ -24,6 +24,8 @@
 //     partials that the o_proj GEMV prologue (vlm_gemv_attn_out) or the combine kernel merges.
 // fp32 scores / statistics / accumulation; P is rounded to bf16 for the second MFMA (as in the prefill
 // flash kernel; tolerance stated in tests).
+#include <stdlib.h>
+
 #include "common.cuh"
 #include "../../include/vlm_hip.h"
 
@@ -33,7 +35,7 @@ constexpr int HD = 128;   // head_dim supported by the decode path
 constexpr int PAGE = 64;
 
 // NW waves per workgroup: 16 (one round covers 1024 tokens of context); 8 when G == 8 (LDS merge buffer <= 64 KB)
-template <int G, int NW>
+template <int G, int NW, bool STAMPS>
 __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
     const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ kpool, const bf16_t* __restrict__ vpool,
     const int* __restrict__ block_table, int max_pages, const int* __restrict__ kv_len, int kv_len_add, int Hq, int Hkv,
@@ -45,6 +47,16 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
   const int b = blockIdx.x / Hkv, g = blockIdx.x % Hkv, s = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int head = lane & 15, gq = lane >> 4;
+  // debug timeline (VLM_ATTN_STAMPS=1): 100 MHz wall clock stamps of wave 0 / 15 of workgroup 0 -> part_o
+  unsigned long long t0 = 0;
+  auto stamp = [&](int i) {
+    if (STAMPS && blockIdx.x == 0 && (wave == 0 || wave == NW - 1) && lane == 0) {
+      const unsigned long long t = wall_clock64();
+      if (i == 0) t0 = t;
+      part_o[(wave == 0 ? 0 : 16) + i] = (float)(t - t0) * 0.01f;   // microseconds since the wave started
+    }
+  };
+  stamp(0);
   // the context length is only needed for masking and for the loop bound: it is loaded here but the first
   // page's table entry and K/V loads below do not wait for it (block-table rows are zero-initialised and the
   // pools are fully mapped, so a speculative load of an unused page is harmless)
@@ -67,9 +79,15 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
 #pragma unroll
   for (int i = 0; i < 8; ++i) ot[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
+  stamp(1);
 
-  for (int pi = s * NW + wave; pi < npages; pi += nsplit * NW) {
-    const size_t page = (size_t)block_table[(size_t)b * max_pages + pi];
+  // The first page's table entry is fetched at kernel entry and its K/V loads are issued WITHOUT waiting for the
+  // context length (measured: each dependent first-touch load costs 2-4 us here, and len -> table -> K/V was a
+  // chain of three).  Block-table rows are zero-initialised and the pools fully mapped, so the speculative loads
+  // of a wave that turns out to have no page are harmless.
+  int pi = s * NW + wave;
+  size_t page = (size_t)block_table[(size_t)b * max_pages + min(pi, max_pages - 1)];
+  for (bool first_it = true; first_it || pi < npages; first_it = false) {
     const bf16_t* kp = kpool + (page * Hkv + g) * (size_t)(HD / 8) * PAGE * 8 + ((size_t)gq * PAGE + head) * 8;
     const bf16_t* vp = vpool + (page * Hkv + g) * (size_t)HD * PAGE + (size_t)head * PAGE + 8 * gq;
     // ---- every operand fragment of the page: 16 + 16 loads of 16 B, all in flight
@@ -84,7 +102,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
 #pragma unroll
       for (int u = 0; u < 2; ++u)
         vf[dt][u] = *reinterpret_cast<const u32x4_t*>(vp + (size_t)(16 * dt) * PAGE + 32 * u);
+    if (pi >= npages) break;   // (first iteration only) this wave has no page: drop the speculative loads
 
+    stamp(2);
     // ---- S^T = K . Q^T : st[t][r] = score(key = 16t + 4gq + r, head = lane&15)
     f32x4_t st[4];
 #pragma unroll
@@ -94,6 +114,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
       for (int ds = 0; ds < 4; ++ds)
         st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[t][ds]), qf[ds], st[t], 0, 0, 0);
     }
+    if (STAMPS) { asm volatile("" :: "v"(st[3][3])); stamp(3); }
     float mt = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -119,6 +140,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
       }
     l_run = l_run * alpha + ls;     // per-lane partial (keys of this gq); lanes of one head are summed at the end
     m_run = m_new;
+    stamp(4);
     // ---- P^T fragments: k-slot 8gq + j of step u  <-  tile 2u (j < 4) / tile 2u+1 (j >= 4), register j & 3
     bf16x8_t pb[2];
 #pragma unroll
@@ -144,8 +166,11 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
         ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pb[u], ot[dt], 0, 0, 0);
       }
     }
+    pi += nsplit * NW;
+    if (pi < npages) page = (size_t)block_table[(size_t)b * max_pages + pi];
   }
 
+  if (STAMPS) { asm volatile("" :: "v"(ot[7][3])); stamp(5); }
   // ---- merge the waves of the workgroup: ot[dt][r] = O^T[d = 16dt + 4gq + r][head]
   l_run += __shfl_xor(l_run, 16, 64);
   l_run += __shfl_xor(l_run, 32, 64);
@@ -155,7 +180,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
       *reinterpret_cast<float4*>(&red_o[wave][head][16 * dt + 4 * gq]) = make_float4(ot[dt][0], ot[dt][1], ot[dt][2], ot[dt][3]);
     if (gq == 0) { red_m[wave][head] = m_run; red_l[wave][head] = l_run; }
   }
+  stamp(6);
   __syncthreads();
+  stamp(7);
   for (int i = tid; i < G * HD; i += NW * 64) {
     const int gg = i / HD, d = i % HD;
     float mm = -INFINITY;
@@ -177,6 +204,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
       if (d == 0) { part_ml[hidx * 2] = mm * 0.69314718055994530942f; part_ml[hidx * 2 + 1] = ll; }
     }
   }
+  stamp(8);
 }
 
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ part_o,
@@ -211,8 +239,15 @@ extern "C" int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, 
   const float sl2 = scale * 1.44269504088896340736f;
   dim3 grid(B * Hkv, nsplit);
   bf16_t* direct = nsplit == 1 ? (bf16_t*)out : nullptr;
+  static const bool stamps = getenv("VLM_ATTN_STAMPS") != nullptr && part_o != nullptr;   // debug timeline
 #define GO(GV)                                                                                                          \
-  hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, (GV <= 7 ? 16 : 8)>), grid, dim3((GV <= 7 ? 16 : 8) * 64), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)kpool,     \
+  if (stamps)                                                                                                           \
+    hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, (GV <= 7 ? 16 : 8), true>), grid, dim3((GV <= 7 ? 16 : 8) * 64), 0, st, \
+                       (const bf16_t*)q, ldq, (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)block_table,      \
+                       max_pages, (const int*)kv_len, kv_len_add, Hq, Hkv, sl2, nsplit, (float*)part_o, (float*)part_ml, \
+                       direct, ldo);                                                                                    \
+  else                                                                                                                  \
+  hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, (GV <= 7 ? 16 : 8), false>), grid, dim3((GV <= 7 ? 16 : 8) * 64), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)kpool,     \
                      (const bf16_t*)vpool, (const int*)block_table, max_pages, (const int*)kv_len, kv_len_add, Hq, Hkv,  \
                      sl2, nsplit, (float*)part_o, (float*)part_ml, direct, ldo)
   switch (G) {

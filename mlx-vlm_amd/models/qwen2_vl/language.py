@@ -26,7 +26,7 @@ import torch
 from ... import _lib, ops
 from ..._lib import check
 from ..base import LanguageModelOutput
-from ..cache import PAGE, KVCache, KVPool, PagedSequence
+from ..cache import PAGE, Arena, KVCache, KVPool, PagedSequence
 from .config import ModelConfig, TextConfig
 
 
@@ -46,21 +46,22 @@ class DecodeState:
         D, hd, Hq, Hkv = t.hidden_size, lm.head_dim, t.num_attention_heads, t.num_key_value_heads
         bf, i32 = torch.bfloat16, torch.int32
         self.B, self.nsplit, self.ring_len = B, nsplit, ring_len   # nsplit: buffers sized for the max, see decode_begin
-        self.tok = torch.zeros(B, dtype=i32, device=dev)
-        self.pos = torch.zeros(B, dtype=i32, device=dev)
-        self.ctx = torch.zeros(B, dtype=i32, device=dev)
-        self.step = torch.zeros(1, dtype=i32, device=dev)
-        self.h = torch.empty(B, D, dtype=bf, device=dev)
-        self.qkv = torch.empty(B, (Hq + 2 * Hkv) * hd, dtype=bf, device=dev)
-        self.attn = torch.empty(B, Hq * hd, dtype=bf, device=dev)
-        self.act = torch.empty(B, t.intermediate_size, dtype=bf, device=dev)
+        A = lm.arena.alloc
+        self.tok = A(B, i32, zero=True)
+        self.pos = A(B, i32, zero=True)
+        self.ctx = A(B, i32, zero=True)
+        self.step = A(1, i32, zero=True)
+        self.h = A((B, D), bf)
+        self.qkv = A((B, (Hq + 2 * Hkv) * hd), bf)
+        self.attn = A((B, Hq * hd), bf)
+        self.act = A((B, t.intermediate_size), bf)
+        self.part_ml = A((B, Hq, nsplit, 2), torch.float32)
+        self.out_ring = A((ring_len, B), i32, zero=True)
         self.logits = torch.empty(B, t.vocab_size, dtype=bf, device=dev)
         self.logprobs = torch.empty(B, t.vocab_size, dtype=bf, device=dev)
         self.scratch = torch.empty(B, t.vocab_size, dtype=bf, device=dev)
         self.part_o = torch.empty(B, Hq, nsplit, hd, dtype=torch.float32, device=dev)
-        self.part_ml = torch.empty(B, Hq, nsplit, 2, dtype=torch.float32, device=dev)
         self.sample_ws = ops.sample_workspace(B, dev)
-        self.out_ring = torch.zeros(ring_len, B, dtype=i32, device=dev)
         self.graph_key = None
 
     def args(self, temperature=0.0, top_p=1.0, min_p=0.0, top_k=0, seed=0, with_logprobs=True):
@@ -117,6 +118,9 @@ class LanguageModel:
         def g(name):
             return W[name].to(device=dev, dtype=bf)
 
+        # small tensors (norm weights, biases, rope table, decode state, block table) live in ONE arena
+        small_bytes = t.num_hidden_layers * (2 * t.hidden_size + (t.num_attention_heads + 2 * t.num_key_value_heads) * self.head_dim) * 2
+        self.arena = Arena(small_bytes + (8 << 20), device=dev)
         cfg = _lib.LlmConfig(t.hidden_size, t.num_hidden_layers, t.intermediate_size, t.num_attention_heads,
                              t.num_key_value_heads, self.head_dim, t.vocab_size, float(t.rms_norm_eps),
                              int(self.mrope_section[0]), int(self.mrope_section[1]))
@@ -131,9 +135,10 @@ class LanguageModel:
                               g(p + "self_attn.v_proj.bias")], dim=0).contiguous()
             gate, up = g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")
             wgu = torch.stack([gate, up], dim=1).reshape(2 * t.intermediate_size, t.hidden_size).contiguous()
-            ws = dict(ln1=g(p + "input_layernorm.weight").contiguous(), wqkv=wqkv, bqkv=bqkv,
+            bqkv = self.arena.put(bqkv)
+            ws = dict(ln1=self.arena.put(g(p + "input_layernorm.weight")), wqkv=wqkv, bqkv=bqkv,
                       wo=g(p + "self_attn.o_proj.weight").contiguous(),
-                      ln2=g(p + "post_attention_layernorm.weight").contiguous(), wgu=wgu,
+                      ln2=self.arena.put(g(p + "post_attention_layernorm.weight")), wgu=wgu,
                       wdown=g(p + "mlp.down_proj.weight").contiguous())
             for k, v in ws.items():
                 self._w[f"{i}.{k}"] = v
@@ -142,10 +147,10 @@ class LanguageModel:
             check(L.vlm_llm_set_layer(h, i, C.byref(lay)), "llm_set_layer")
         embed = g("model.embed_tokens.weight").contiguous()
         head = embed if t.tie_word_embeddings else g("lm_head.weight").contiguous()
-        norm = g("model.norm.weight").contiguous()
+        norm = self.arena.put(g("model.norm.weight"))
         hd = self.head_dim
         # compute_inv_freq (reference rope_utils.py:1042-1043), fp32 on the host
-        inv_freq = (1.0 / (t.rope_theta ** (torch.arange(0, hd, 2).to(torch.float32) / hd))).to(dev)
+        inv_freq = self.arena.put((1.0 / (t.rope_theta ** (torch.arange(0, hd, 2).to(torch.float32) / hd))).to(dev))
         self._w.update(embed=embed, head=head, norm=norm, inv_freq=inv_freq)
         gl = _lib.LlmGlobals(embed.data_ptr(), norm.data_ptr(), head.data_ptr(), inv_freq.data_ptr())
         check(L.vlm_llm_set_globals(h, C.byref(gl)), "llm_set_globals")
@@ -154,7 +159,8 @@ class LanguageModel:
     def _init_pool(self):
         t = self.args
         self.pool = KVPool(t.num_hidden_layers, t.num_key_value_heads, self.head_dim, self._kv_pool_tokens,
-                           self._max_seqs, device=self.device)
+                           self._max_seqs, max_pages_per_seq=min(512, (self._kv_pool_tokens + PAGE - 1) // PAGE),
+                           device=self.device, arena=self.arena)
         kv = _lib.KvPool(self.pool.kpool.data_ptr(), self.pool.vpool.data_ptr(), self.pool.layer_stride,
                          self.pool.block_table.data_ptr(), self.pool.max_pages)
         check(_lib.lib().vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
