@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvlm_hip.so")
+LIB_PATH = os.environ.get("VLM_HIP_LIB") or os.path.join(_HERE, "lib", "libvlm_hip.so")
 
 c_void_p, c_int, c_float, c_uint, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_uint, C.c_size_t
 

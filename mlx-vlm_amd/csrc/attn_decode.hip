@@ -57,23 +57,36 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
     }
   };
   stamp(0);
-  // the context length is only needed for masking and for the loop bound: it is loaded here but the first
-  // page's table entry and K/V loads below do not wait for it (block-table rows are zero-initialised and the
-  // pools are fully mapped, so a speculative load of an unused page is harmless)
-  const int len = kv_len[b] + kv_len_add;
-  const int npages = (len + PAGE - 1) / PAGE;
+  // Latency plan (the kernel is a chain of dependent first-touch loads, 1-2 us each, so the chain is kept at
+  // three links: kernel arguments -> {table entry, context length, Q} -> K/V):
+  //   * every kernel argument is pulled into SGPRs in ONE scalar-load batch at entry (the empty asm "uses" them;
+  //     otherwise the compiler fetches them lazily in three separate round trips);
+  //   * the context length is read through the vector memory path (inline asm; the explicit vmcnt(0) at the top
+  //     of the page loop covers it): as a scalar load its wait would also block the kernel-argument loads
+  //     (scalar loads return out of order, lgkmcnt(0) is the only wait), a volatile load is waited for at once;
+  //   * the first page's table entry is the FIRST vector load, Q and the length follow; vector loads return in
+  //     order, so the K/V address computation waits for the table entry only;
+  //   * heads >= G of the 16-wide MFMA N dimension read head G-1 again instead of a select-to-zero on loaded
+  //     data (their columns are never written), so nothing waits on Q before the first MFMA;
+  //   * every wave processes its first page UNCONDITIONALLY (do-while): a wave whose page lies beyond the context
+  //     computes on masked scores (m = -inf, l = 0, O = 0) and drops out in the merge.  Block-table rows are
+  //     zero-initialised and the pools fully mapped, so its loads are harmless.
+  asm volatile("" ::"s"(q), "s"(kpool), "s"(vpool), "s"(block_table), "s"(kv_len), "s"(part_o), "s"(part_ml), "s"(out));
+  asm volatile("" ::"s"(ldq), "s"(max_pages), "s"(kv_len_add), "s"(Hq), "s"(Hkv), "s"(scale_log2), "s"(nsplit), "s"(ldo));
+  int pi = s * NW + wave;
+  const int* trow = block_table + (size_t)b * max_pages;
+  size_t page = (size_t)trow[min(pi, max_pages - 1)];
+  int len_raw;
+  asm volatile("global_load_dword %0, %1, off" : "=v"(len_raw) : "v"(kv_len + b) : "memory");
 
-  // Q fragments (B operand of S^T): head = lane&15, d = 32*ds + 8*gq .. +8; zero rows for head >= G
+  // Q fragments (B operand of S^T): head = lane&15, d = 32*ds + 8*gq .. +8
   bf16x8_t qf[4];
   {
     const bf16_t* qr = q + (size_t)b * ldq + (size_t)(g * G + min(head, G - 1)) * HD + 8 * gq;
 #pragma unroll
-    for (int ds = 0; ds < 4; ++ds) {
-      u32x4_t t = *reinterpret_cast<const u32x4_t*>(qr + 32 * ds);
-      if (head >= G) t = u32x4_t{0, 0, 0, 0};
-      qf[ds] = __builtin_bit_cast(bf16x8_t, t);
-    }
+    for (int ds = 0; ds < 4; ++ds) qf[ds] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(qr + 32 * ds));
   }
+  __builtin_amdgcn_sched_barrier(0);
 
   f32x4_t ot[8];
 #pragma unroll
@@ -81,13 +94,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
   float m_run = -INFINITY, l_run = 0.f;
   stamp(1);
 
-  // The first page's table entry is fetched at kernel entry and its K/V loads are issued WITHOUT waiting for the
-  // context length (measured: each dependent first-touch load costs 2-4 us here, and len -> table -> K/V was a
-  // chain of three).  Block-table rows are zero-initialised and the pools fully mapped, so the speculative loads
-  // of a wave that turns out to have no page are harmless.
-  int pi = s * NW + wave;
-  size_t page = (size_t)block_table[(size_t)b * max_pages + min(pi, max_pages - 1)];
-  for (bool first_it = true; first_it || pi < npages; first_it = false) {
+  int len = 0, npages = 0;
+  do {
+    // table entry (+ context length and Q on the first pass) have landed; later passes: next_page, long since
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(len_raw), "+v"(page)::"memory");
     const bf16_t* kp = kpool + (page * Hkv + g) * (size_t)(HD / 8) * PAGE * 8 + ((size_t)gq * PAGE + head) * 8;
     const bf16_t* vp = vpool + (page * Hkv + g) * (size_t)HD * PAGE + (size_t)head * PAGE + 8 * gq;
     // ---- every operand fragment of the page: 16 + 16 loads of 16 B, all in flight
@@ -102,7 +112,13 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
 #pragma unroll
       for (int u = 0; u < 2; ++u)
         vf[dt][u] = *reinterpret_cast<const u32x4_t*>(vp + (size_t)(16 * dt) * PAGE + 32 * u);
-    if (pi >= npages) break;   // (first iteration only) this wave has no page: drop the speculative loads
+    // the next page's table entry rides behind them (clamped index: unconditional, no dependent wait later)
+    pi += nsplit * NW;
+    const size_t next_page = (size_t)trow[min(pi, max_pages - 1)];
+    __builtin_amdgcn_sched_barrier(0);   // all 32 loads are in flight before anything waits on one of them
+    const int pc = pi - nsplit * NW;     // the page being processed
+    len = __builtin_amdgcn_readfirstlane(len_raw) + kv_len_add;
+    npages = (len + PAGE - 1) / PAGE;
 
     stamp(2);
     // ---- S^T = K . Q^T : st[t][r] = score(key = 16t + 4gq + r, head = lane&15)
@@ -120,21 +136,22 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = pi * PAGE + 16 * t + 4 * gq + r;
+        const int key = pc * PAGE + 16 * t + 4 * gq + r;
         const float sv = key < len ? st[t][r] * scale_log2 : -INFINITY;
         st[t][r] = sv;
         mt = fmaxf(mt, sv);
       }
     mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));          // the page has >= 1 valid key: finite
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float m_new = fmaxf(m_run, mt);
-    const float alpha = exp2f(m_run - m_new);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;    // a wave with no valid key yet: p = exp2(-inf - 0) = 0
+    const float alpha = exp2f(m_run - m_use);
     float ls = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = exp2f(st[t][r] - m_new);
+        const float p = exp2f(st[t][r] - m_use);
         st[t][r] = p;
         ls += p;
       }
@@ -158,7 +175,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
       for (int u = 0; u < 2; ++u) {
         u32x4_t vv = vf[dt][u];
         // slots 8gq + j: keys 32u + 4gq + j (j<4) and 32u + 16 + 4gq + (j-4); mask whole words by validity
-        const int k0 = pi * PAGE + 32 * u + 4 * gq, k1 = k0 + 16;
+        const int k0 = pc * PAGE + 32 * u + 4 * gq, k1 = k0 + 16;
         vv[0] = (k0 + 1 < len) ? vv[0] : ((k0 < len) ? (vv[0] & 0xffffu) : 0u);
         vv[1] = (k0 + 3 < len) ? vv[1] : ((k0 + 2 < len) ? (vv[1] & 0xffffu) : 0u);
         vv[2] = (k1 + 1 < len) ? vv[2] : ((k1 < len) ? (vv[2] & 0xffffu) : 0u);
@@ -166,9 +183,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
         ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pb[u], ot[dt], 0, 0, 0);
       }
     }
-    pi += nsplit * NW;
-    if (pi < npages) page = (size_t)block_table[(size_t)b * max_pages + pi];
-  }
+    if (pi >= npages) break;
+    page = next_page;
+  } while (true);
 
   if (STAMPS) { asm volatile("" :: "v"(ot[7][3])); stamp(5); }
   // ---- merge the waves of the workgroup: ot[dt][r] = O^T[d = 16dt + 4gq + r][head]
@@ -242,12 +259,12 @@ extern "C" int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, 
   static const bool stamps = getenv("VLM_ATTN_STAMPS") != nullptr && part_o != nullptr;   // debug timeline
 #define GO(GV)                                                                                                          \
   if (stamps)                                                                                                           \
-    hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, (GV <= 7 ? 16 : 8), true>), grid, dim3((GV <= 7 ? 16 : 8) * 64), 0, st, \
+    hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, 8, true>), grid, dim3(8 * 64), 0, st, \
                        (const bf16_t*)q, ldq, (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)block_table,      \
                        max_pages, (const int*)kv_len, kv_len_add, Hq, Hkv, sl2, nsplit, (float*)part_o, (float*)part_ml, \
                        direct, ldo);                                                                                    \
   else                                                                                                                  \
-  hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, (GV <= 7 ? 16 : 8), false>), grid, dim3((GV <= 7 ? 16 : 8) * 64), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)kpool,     \
+  hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, 8, false>), grid, dim3(8 * 64), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)kpool,     \
                      (const bf16_t*)vpool, (const int*)block_table, max_pages, (const int*)kv_len, kv_len_add, Hq, Hkv,  \
                      sl2, nsplit, (float*)part_o, (float*)part_ml, direct, ldo)
   switch (G) {

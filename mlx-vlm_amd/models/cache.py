@@ -31,14 +31,14 @@ class Arena:
     buffer costs ~4.5 us (address-translation miss), and a decode kernel touches several of them in a dependent
     chain; with everything small inside one 2 MB-aligned region a kernel pays that once."""
 
-    def __init__(self, nbytes: int, device="cuda"):
-        self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    def __init__(self, nbytes: int, device="cuda", zero: bool = True):
+        self.buf = (torch.zeros if zero else torch.empty)(nbytes, dtype=torch.uint8, device=device)
         self.off = 0
 
-    def alloc(self, shape, dtype, zero: bool = False) -> torch.Tensor:
+    def alloc(self, shape, dtype, zero: bool = False, align: int = 256) -> torch.Tensor:
         shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
         n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
-        start = (self.off + 255) // 256 * 256
+        start = (self.off + align - 1) // align * align
         if start + n > self.buf.numel():
             raise RuntimeError(f"Arena exhausted: need {n} bytes at {start} of {self.buf.numel()}")
         self.off = start + n

@@ -17,6 +17,8 @@ Differences from the reference that the contract allows:
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Dict, List, Optional
 
@@ -121,6 +123,22 @@ class LanguageModel:
         # small tensors (norm weights, biases, rope table, decode state, block table) live in ONE arena
         small_bytes = t.num_hidden_layers * (2 * t.hidden_size + (t.num_attention_heads + 2 * t.num_key_value_heads) * self.head_dim) * 2
         self.arena = Arena(small_bytes + (8 << 20), device=dev)
+        # ... and the big matrices live in ONE allocation too, in the order a decode step streams them, so the
+        # driver can map the region with large page fragments (A/B knob: VLM_WEIGHT_ARENA=0 -> separate tensors)
+        qkv_rows = (t.num_attention_heads + 2 * t.num_key_value_heads) * self.head_dim
+        per_layer = (qkv_rows + t.hidden_size + 3 * t.intermediate_size) * t.hidden_size * 2
+        n_big = t.num_hidden_layers * per_layer + (1 if t.tie_word_embeddings else 2) * t.vocab_size * t.hidden_size * 2
+        use_wa = os.environ.get("VLM_WEIGHT_ARENA", "1") != "0"
+        self.warena = Arena(n_big + (4 * t.num_hidden_layers + 4) * 4096, device=dev, zero=False) if use_wa else None
+
+        def big(x):
+            x = x.contiguous()
+            if self.warena is None:
+                return x
+            out = self.warena.alloc(x.shape, x.dtype, align=4096)
+            out.copy_(x)
+            return out
+
         cfg = _lib.LlmConfig(t.hidden_size, t.num_hidden_layers, t.intermediate_size, t.num_attention_heads,
                              t.num_key_value_heads, self.head_dim, t.vocab_size, float(t.rms_norm_eps),
                              int(self.mrope_section[0]), int(self.mrope_section[1]))
@@ -129,24 +147,25 @@ class LanguageModel:
         self._handle = h
         for i in range(t.num_hidden_layers):
             p = f"model.layers.{i}."
-            wqkv = torch.cat([g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"),
-                              g(p + "self_attn.v_proj.weight")], dim=0).contiguous()
+            wqkv = big(torch.cat([g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"),
+                                  g(p + "self_attn.v_proj.weight")], dim=0))
             bqkv = torch.cat([g(p + "self_attn.q_proj.bias"), g(p + "self_attn.k_proj.bias"),
                               g(p + "self_attn.v_proj.bias")], dim=0).contiguous()
             gate, up = g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")
-            wgu = torch.stack([gate, up], dim=1).reshape(2 * t.intermediate_size, t.hidden_size).contiguous()
+            wo = big(g(p + "self_attn.o_proj.weight"))
+            wgu = big(torch.stack([gate, up], dim=1).reshape(2 * t.intermediate_size, t.hidden_size))
+            del gate, up
             bqkv = self.arena.put(bqkv)
-            ws = dict(ln1=self.arena.put(g(p + "input_layernorm.weight")), wqkv=wqkv, bqkv=bqkv,
-                      wo=g(p + "self_attn.o_proj.weight").contiguous(),
+            ws = dict(ln1=self.arena.put(g(p + "input_layernorm.weight")), wqkv=wqkv, bqkv=bqkv, wo=wo,
                       ln2=self.arena.put(g(p + "post_attention_layernorm.weight")), wgu=wgu,
-                      wdown=g(p + "mlp.down_proj.weight").contiguous())
+                      wdown=big(g(p + "mlp.down_proj.weight")))
             for k, v in ws.items():
                 self._w[f"{i}.{k}"] = v
             lay = _lib.LlmLayer(ws["ln1"].data_ptr(), wqkv.data_ptr(), bqkv.data_ptr(), ws["wo"].data_ptr(),
                                 ws["ln2"].data_ptr(), wgu.data_ptr(), ws["wdown"].data_ptr())
             check(L.vlm_llm_set_layer(h, i, C.byref(lay)), "llm_set_layer")
-        embed = g("model.embed_tokens.weight").contiguous()
-        head = embed if t.tie_word_embeddings else g("lm_head.weight").contiguous()
+        embed = big(g("model.embed_tokens.weight"))
+        head = embed if t.tie_word_embeddings else big(g("lm_head.weight"))
         norm = self.arena.put(g("model.norm.weight"))
         hd = self.head_dim
         # compute_inv_freq (reference rope_utils.py:1042-1043), fp32 on the host
@@ -335,6 +354,8 @@ class LanguageModel:
         # page-stride (<= 32 splits) merged in the o_proj prologue
         max_total = max(s.offset for s in seqs) + max_new_tokens + 1
         st.nsplit = 1 if max_total <= 2048 else max(2, min(32, (max_total + 16 * PAGE - 1) // (16 * PAGE)))
+        if os.environ.get("VLM_DECODE_NSPLIT"):     # A/B knob for measurements
+            st.nsplit = max(1, min(32, int(os.environ["VLM_DECODE_NSPLIT"])))
         # the engine indexes block-table rows by batch row: sequences must sit in rows 0..B-1 of a view
         rows = [s.seq for s in seqs]
         if rows != list(range(rows[0], rows[0] + B)):
