@@ -37,10 +37,12 @@ constexpr int PAGE = 64;
 // NW waves per workgroup: 16 (one round covers 1024 tokens of context); 8 when G == 8 (LDS merge buffer <= 64 KB)
 template <int G, int NW, bool STAMPS>
 __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
-    const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ kpool, const bf16_t* __restrict__ vpool,
-    const int* __restrict__ block_table, int max_pages, const int* __restrict__ kv_len, int kv_len_add, int Hq, int Hkv,
-    float scale_log2, int nsplit, float* __restrict__ part_o, float* __restrict__ part_ml, bf16_t* __restrict__ out,
-    int ldo) {
+    // the first 14 dwords are everything the first loads need: with -amdgpu-kernarg-preload-count=16 they are in
+    // SGPRs at wave start (no scalar-load round trip before the table / length / Q loads)
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ kpool, const bf16_t* __restrict__ vpool,
+    const int* __restrict__ block_table, const int* __restrict__ kv_len, int ldq, int max_pages, int Hkv, int kv_len_add,
+    int Hq, float scale_log2, int nsplit, int ldo, float* __restrict__ part_o, float* __restrict__ part_ml,
+    bf16_t* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) float red_o[NW][G][HD];
   __shared__ float red_m[NW][G], red_l[NW][G];
 
@@ -71,8 +73,6 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
   //   * every wave processes its first page UNCONDITIONALLY (do-while): a wave whose page lies beyond the context
   //     computes on masked scores (m = -inf, l = 0, O = 0) and drops out in the merge.  Block-table rows are
   //     zero-initialised and the pools fully mapped, so its loads are harmless.
-  asm volatile("" ::"s"(q), "s"(kpool), "s"(vpool), "s"(block_table), "s"(kv_len), "s"(part_o), "s"(part_ml), "s"(out));
-  asm volatile("" ::"s"(ldq), "s"(max_pages), "s"(kv_len_add), "s"(Hq), "s"(Hkv), "s"(scale_log2), "s"(nsplit), "s"(ldo));
   int pi = s * NW + wave;
   const int* trow = block_table + (size_t)b * max_pages;
   size_t page = (size_t)trow[min(pi, max_pages - 1)];
@@ -260,13 +260,13 @@ extern "C" int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, 
 #define GO(GV)                                                                                                          \
   if (stamps)                                                                                                           \
     hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, 8, true>), grid, dim3(8 * 64), 0, st, \
-                       (const bf16_t*)q, ldq, (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)block_table,      \
-                       max_pages, (const int*)kv_len, kv_len_add, Hq, Hkv, sl2, nsplit, (float*)part_o, (float*)part_ml, \
-                       direct, ldo);                                                                                    \
+                       (const bf16_t*)q, (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)block_table,           \
+                       (const int*)kv_len, ldq, max_pages, Hkv, kv_len_add, Hq, sl2, nsplit, ldo, (float*)part_o,       \
+                       (float*)part_ml, direct);                                                                        \
   else                                                                                                                  \
-  hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, 8, false>), grid, dim3(8 * 64), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)kpool,     \
-                     (const bf16_t*)vpool, (const int*)block_table, max_pages, (const int*)kv_len, kv_len_add, Hq, Hkv,  \
-                     sl2, nsplit, (float*)part_o, (float*)part_ml, direct, ldo)
+  hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, 8, false>), grid, dim3(8 * 64), 0, st, (const bf16_t*)q,              \
+                     (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)block_table, (const int*)kv_len, ldq,       \
+                     max_pages, Hkv, kv_len_add, Hq, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, direct)
   switch (G) {
     case 1: GO(1); break;
     case 2: GO(2); break;
