@@ -71,10 +71,21 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // sigmoid on the hardware transcendental units (v_exp_f32 + v_rcp_f32, ~1-2 ulp): the GEMM epilogues apply it
 // to every output element, where the accurate expf + IEEE divide cost more than the bias/activation traffic
 __device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// The activations follow the reference's typed graph (pinned by running the reference's files over
+// oracle/mlx_shim, tests/test_oracle_ref_golden.py): every elementary MLX op rounds to bf16 and a python scalar is
+// converted to bf16 BEFORE the op (weak typing), so 1.702 is 1.703125 and sqrt(2) is 1.4140625 here.
+// x is the bf16-rounded linear output; the caller rounds the returned value once more.
 // nn.GELU(approx="fast") : x * sigmoid(1.702 x)        (reference vision.py:167)
-__device__ __forceinline__ float gelu_fast_(float x) { return x * sigmoidf_(1.702f * x); }
-// nn.GELU() exact erf form                              (reference vision.py:112)
-__device__ __forceinline__ float gelu_erf_(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_fast_(float x) {
+  const float t = rbf(1.703125f * x);
+  return x * rbf(sigmoidf_(t));
+}
+// nn.GELU() : x * (1 + erf(x / sqrt(2))) / 2            (reference vision.py:112)
+__device__ __forceinline__ float gelu_erf_(float x) {
+  const float t = rbf(x / 1.4140625f);
+  const float o = rbf(1.0f + rbf(erff(t)));
+  return 0.5f * rbf(x * o);
+}
 // swiglu typed graph: sig -> T, g*sig -> T, *u -> T      (reference activations.py:7-9)
 __device__ __forceinline__ float swiglu_(float g, float u) {
   float sig = rbf(sigmoidf_(g));

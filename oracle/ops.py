@@ -14,16 +14,18 @@ the reference materialises a T tensor:
   * nn.RMSNorm (mx.fast) ...... fp32 stats; y = T(w * T(x * rsqrt(ms+eps)))
                                 (normalised value is cast to T before the
                                 weight multiply, as HF Qwen2RMSNorm does)
-  * GELU / SiLU / mul / add ... fp32 math per elementary op, rounded per op
+  * GELU / SiLU / mul / add ... fp32 math per elementary op, rounded per op; python scalars are converted to T
+                                before the op (MLX weak typing: 1.702 * x multiplies by T(1.702))
   * mx.fast.sdpa .............. fp32 scores+softmax, P*V in fp32, one rounding
   * M-RoPE fused path ......... fp32 angle/cos/sin/rotation, one rounding
                                 (rope_utils.py:589-603,640-643)
   * logits .................... T;  logprobs = T(logits - T(logsumexp)) (ar.py:368)
 With T = float32 every rounding is the identity and the functions are the
 plain fp32 math, which is what is checked against HuggingFace.
-These MLX-internal rounding points are NOT observable from the reference tree
-("parity unpinned", oracle/__init__.py); kernels are compared with the
-tolerances stated in tests/.
+The rounding points are pinned by executing the reference's own files over
+oracle/mlx_shim (tests/test_oracle_ref_golden.py: bit-exact in bf16); what stays
+unpinned is the accumulation order inside MLX's kernels (oracle/__init__.py), so
+the HIP kernels are compared with the tolerances stated in tests/.
 """
 from __future__ import annotations
 
@@ -71,16 +73,30 @@ def add(a, b):
     return (a.to(F32) + b.to(F32)).to(a.dtype)
 
 
+def _c(v: float, T):
+    """a python scalar as MLX sees it next to an array of dtype T: converted to T first (weak typing)."""
+    return torch.tensor(v, dtype=T).to(F32)
+
+
 def gelu_fast(x):
-    """nn.GELU(approx="fast") = x * sigmoid(1.702 x) (vision.py:167; MLX docs)."""
+    """nn.GELU(approx="fast") = x * sigmoid(1.702 * x) (vision.py:167; mlx.nn.gelu_fast_approx).
+    Typed graph (pinned by running the reference over oracle/mlx_shim): T(1.702) * x -> T, sigmoid -> T, x * s -> T."""
+    T = x.dtype
     xf = x.to(F32)
-    return (xf * torch.sigmoid(1.702 * xf)).to(x.dtype)
+    t1 = (_c(1.702, T) * xf).to(T)
+    sg = torch.sigmoid(t1.to(F32)).to(T)
+    return (xf * sg.to(F32)).to(T)
 
 
 def gelu_erf(x):
-    """nn.GELU() exact erf form (vision.py:112)."""
+    """nn.GELU() = x * (1 + erf(x / sqrt(2))) / 2 (vision.py:112; mlx.nn.gelu), every elementary op rounded to T."""
+    T = x.dtype
     xf = x.to(F32)
-    return (0.5 * xf * (1.0 + torch.erf(xf * (1.0 / math.sqrt(2.0))))).to(x.dtype)
+    t1 = (xf / _c(math.sqrt(2.0), T)).to(T)
+    e = torch.erf(t1.to(F32)).to(T)
+    o = (1.0 + e.to(F32)).to(T)
+    m = (xf * o.to(F32)).to(T)
+    return (m.to(F32) / 2.0).to(T)
 
 
 def swiglu(gate, up):

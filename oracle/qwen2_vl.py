@@ -221,9 +221,9 @@ def patch_merger(W, cfg: Cfg, x):
     return ops.linear(x, W[p + "mlp.2.weight"], W[p + "mlp.2.bias"])
 
 
-def vision_tower(W, cfg: Cfg, pixel_values, grid_thw, return_blocks: bool = False):
-    """VisionModel.__call__ (vision.py:257-290)."""
-    x = patch_embed(W, cfg, pixel_values)
+def vision_tower(W, cfg: Cfg, pixel_values, grid_thw, return_blocks: bool = False, patch_embeds=None):
+    """VisionModel.__call__ (vision.py:257-290).  `patch_embeds` (tests only): start from given PatchEmbed outputs."""
+    x = patch_embed(W, cfg, pixel_values) if patch_embeds is None else patch_embeds
     hd = cfg.vision.embed_dim // cfg.vision.num_heads
     freqs = ops.vision_rotary_freqs(grid_thw, hd, cfg.vision.spatial_merge_size)
     cu = vision_cu_seqlens(grid_thw)

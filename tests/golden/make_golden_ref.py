@@ -1,0 +1,199 @@
+"""Golden vectors produced by the REFERENCE'S OWN Python files (run once, in the build container).
+
+    python tests/golden/make_golden_ref.py        # needs /root/reference; writes tests/golden/qwen2_vl_tiny_ref.npz
+
+The reference (mlx-vlm) is pure Python over Apple's `mlx`, which cannot be installed here.  This script puts
+`oracle/mlx_shim` (a torch-CPU stand-in for mlx.core / mlx.nn / mlx.utils, see its README) on sys.path and then
+imports and RUNS the reference's files for the Qwen2-VL path unchanged from /root/reference:
+
+    mlx_vlm/models/qwen2_vl/{config,vision,language,qwen2_vl}.py
+    mlx_vlm/models/{base,cache,rope_utils,mlp,activations}.py
+    mlx_vlm/sample_utils.py
+
+on the tiny config + seeded weights of tests/golden/make_golden.py, in fp32 and in bf16.  The package
+`__init__`s of mlx_vlm are NOT executed (they pull the whole server / tokenizer stack); `mlx_vlm.turboquant`
+and the HF-processor patch module are stubbed - neither is on the executed path.
+
+What is recorded per case: vision-tower output, merged input embeddings, position ids + rope deltas, prefill
+logits, 8 greedy decode steps through the reference's KVCache (tokens + per-step logits); plus rope-index tables
+for text-only / left-padded batches and the sampler filters (top-k / top-p / min-p) on fixed log-probs.
+Nothing here is read at test time on the GPU box: only the .npz travels.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("VLM_REFERENCE_ROOT", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle", "mlx_shim"))
+
+
+def import_reference():
+    """-> (mx, qwen2_vl module, cache module, sample_utils module) from the reference tree, unmodified."""
+    import mlx.core as mx  # the shim
+
+    def pkg(name, path):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        m.__package__ = name
+        sys.modules[name] = m
+        return m
+
+    pkg("mlx_vlm", os.path.join(REF, "mlx_vlm"))
+    pkg("mlx_vlm.models", os.path.join(REF, "mlx_vlm", "models"))
+    pkg("mlx_vlm.models.qwen2_vl", os.path.join(REF, "mlx_vlm", "models", "qwen2_vl"))
+    # not on the executed path: KV-quantisation codecs and the HF processor patch
+    tq = types.ModuleType("mlx_vlm.turboquant")
+    for n in ("BatchTurboQuantKVCache", "TurboQuantKVCache", "HybridQuantKVCache"):
+        setattr(tq, n, type(n, (), {}))
+    tq._state_length = lambda s: s[0].shape[-2]
+    tq.turboquant_enabled = lambda *a, **k: False
+    sys.modules["mlx_vlm.turboquant"] = tq
+    sys.modules["mlx_vlm.models.qwen2_vl.processing_qwen2_vl"] = types.ModuleType(
+        "mlx_vlm.models.qwen2_vl.processing_qwen2_vl")
+    import importlib
+
+    q = importlib.import_module("mlx_vlm.models.qwen2_vl.qwen2_vl")
+    cfgm = importlib.import_module("mlx_vlm.models.qwen2_vl.config")
+    cache = importlib.import_module("mlx_vlm.models.cache")
+    su = importlib.import_module("mlx_vlm.sample_utils")
+    for m in (q, cfgm, cache, su):
+        assert m.__file__.startswith(REF), m.__file__
+    return mx, q, cfgm, cache, su
+
+
+def ref_config(cfgm, cfg):
+    t, v = cfg.text, cfg.vision
+    # HF Qwen2-VL config.json layout: text parameters at the root (config.py:71-77 copies them into text_config)
+    d = dict(
+        model_type="qwen2_vl", hidden_size=t.hidden_size, num_hidden_layers=t.num_hidden_layers,
+        intermediate_size=t.intermediate_size, num_attention_heads=t.num_attention_heads,
+        num_key_value_heads=t.num_key_value_heads, vocab_size=t.vocab_size, rms_norm_eps=t.rms_norm_eps,
+        rope_theta=t.rope_theta, max_position_embeddings=32768,
+        rope_scaling={"type": "mrope", "mrope_section": list(t.mrope_section)},
+        tie_word_embeddings=t.tie_word_embeddings,
+        vision_config=dict(model_type="qwen2_vl", depth=v.depth, embed_dim=v.embed_dim, hidden_size=v.hidden_size,
+                           num_heads=v.num_heads, mlp_ratio=v.mlp_ratio, patch_size=v.patch_size,
+                           spatial_merge_size=v.spatial_merge_size, temporal_patch_size=v.temporal_patch_size,
+                           in_channels=v.in_channels),
+        image_token_id=cfg.image_token_id, video_token_id=cfg.video_token_id,
+        vision_start_token_id=cfg.vision_start_token_id,
+    )
+    mc = cfgm.ModelConfig.from_dict(d)
+    if isinstance(mc.text_config, dict):
+        mc.text_config = cfgm.TextConfig.from_dict(mc.text_config)
+    if isinstance(mc.vision_config, dict):
+        mc.vision_config = cfgm.VisionConfig.from_dict(mc.vision_config)
+    return mc
+
+
+def f32(a):
+    return np.asarray(a._t.to(torch.float32).numpy()) if hasattr(a, "_t") else np.asarray(a, dtype=np.float32)
+
+
+def main():
+    from oracle import qwen2_vl as oq
+    sys.path.insert(0, HERE)
+    from make_golden import make_inputs
+
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    mx, q, cfgm, cache_mod, su = import_reference()
+    cfg = oq.tiny_cfg()
+    mc = ref_config(cfgm, cfg)
+    blob = {}
+    cases = {"one_image": [(56, 84)], "two_images": [(56, 56), (84, 56)]}
+    for dt_name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        W = oq.random_weights(cfg, seed=1234, dtype=torch.float32, std=0.05, embed_std=0.2)
+        model = q.Model(mc)
+        weights = {k: mx.array(w.to(dt)) for k, w in W.items()}
+        weights = model.sanitize(weights) if hasattr(model, "sanitize") else weights
+        weights = model.vision_tower.sanitize(weights)
+        model.load_weights(list(weights.items()), strict=True)
+        for name, sizes in cases.items():
+            imgs, pix, thw, ids = make_inputs(cfg, sizes, seed=len(sizes))
+            input_ids = mx.array(ids.astype(np.int32))
+            pixel_values = mx.array(pix.astype(np.float32))
+            grid = mx.array(thw.astype(np.int32))
+            feats = model.vision_tower(pixel_values.astype(dt), grid, output_hidden_states=False)
+            patches = model.vision_tower.patch_embed(pixel_values.astype(dt))
+            emb = model.get_input_embeddings(input_ids, pixel_values, image_grid_thw=grid)
+            kv = [cache_mod.KVCache() for _ in model.language_model.layers]
+            out = model.language_model(input_ids, inputs_embeds=emb.inputs_embeds, cache=kv, position_ids=emb.position_ids,
+                                       pixel_values=pixel_values, image_grid_thw=grid, rope_deltas=emb.rope_deltas)
+            # the reference's generate_step hands position_ids only for the prompt; decode positions come from
+            # cache offset + rope_deltas (language.py:476-509).  Drive that loop exactly as ar.py:_step does.
+            logits = out.logits
+            step_logits, toks = [], []
+            y = mx.argmax(logits[:, -1, :], axis=-1)
+            for _ in range(8):
+                toks.append(int(y.item()))
+                o = model.language_model(y[None] if y.ndim == 1 else y, cache=kv)
+                step_logits.append(f32(o.logits[0, -1]))
+                y = mx.argmax(o.logits[:, -1, :], axis=-1)
+            p = f"{name}.{dt_name}."
+            blob[p + "ref_image_features"] = f32(feats)
+            blob[p + "ref_patch_embed"] = f32(patches)
+            blob[p + "ref_inputs_embeds"] = f32(emb.inputs_embeds[0])
+            blob[p + "ref_prefill_logits"] = f32(logits[0])
+            blob[p + "ref_decode_logits"] = np.stack(step_logits)
+            blob[p + "ref_greedy"] = np.array(toks, dtype=np.int64)
+            blob[p + "ref_kv_offset"] = np.array([kv[0].offset], dtype=np.int64)
+            if dt_name == "f32":
+                blob[name + ".ref_position_ids"] = np.asarray(emb.position_ids._t.numpy()).astype(np.int64)
+                blob[name + ".ref_rope_deltas"] = np.asarray(emb.rope_deltas._t.numpy()).astype(np.int64).reshape(-1)
+                blob[name + ".input_ids"] = ids
+                blob[name + ".grid_thw"] = thw
+                blob[name + ".sizes"] = np.array(sizes, dtype=np.int64)
+            print(p, "feats", blob[p + "ref_image_features"].shape, "logits", blob[p + "ref_prefill_logits"].shape,
+                  "greedy", toks)
+
+    # ---- rope index: text only, and a left-padded batch (language.py:216-402)
+    lm = model.language_model
+    tid = mx.array(np.array([[5, 6, 7, 8, 9, 10], [2, 2, 11, 12, 13, 14]], dtype=np.int32))
+    am = mx.array(np.array([[1, 1, 1, 1, 1, 1], [0, 0, 1, 1, 1, 1]], dtype=np.int32))
+    pos, delta = lm.get_rope_index(tid, attention_mask=am)
+    blob["text_padded.input_ids"] = np.asarray(tid._t.numpy()).astype(np.int64)
+    blob["text_padded.attention_mask"] = np.asarray(am._t.numpy()).astype(np.int64)
+    blob["text_padded.ref_position_ids"] = np.asarray(pos._t.numpy()).astype(np.int64)
+    blob["text_padded.ref_rope_deltas"] = np.asarray(delta._t.numpy()).astype(np.int64).reshape(-1)
+    pos, delta = lm.get_rope_index(tid)
+    blob["text_only.ref_position_ids"] = np.asarray(pos._t.numpy()).astype(np.int64)
+    blob["text_only.ref_rope_deltas"] = np.asarray(delta._t.numpy()).astype(np.int64).reshape(-1)
+    # image + left padding in one batch row (mask-aware path, language.py:236-374)
+    imgs, pix, thw, ids = make_inputs(cfg, [(56, 56)], seed=5)
+    row = ids[0].tolist()
+    padded = np.array([[2, 2, 2] + row], dtype=np.int32)
+    mask = np.array([[0, 0, 0] + [1] * len(row)], dtype=np.int32)
+    pos, delta = lm.get_rope_index(mx.array(padded), mx.array(thw.astype(np.int32)), None, mx.array(mask))
+    blob["image_padded.input_ids"] = padded.astype(np.int64)
+    blob["image_padded.attention_mask"] = mask.astype(np.int64)
+    blob["image_padded.grid_thw"] = thw
+    blob["image_padded.ref_position_ids"] = np.asarray(pos._t.numpy()).astype(np.int64)
+    blob["image_padded.ref_rope_deltas"] = np.asarray(delta._t.numpy()).astype(np.int64).reshape(-1)
+
+    # ---- sampler filters on fixed log-probs (sample_utils.py:149-175,266-318)
+    g = torch.Generator().manual_seed(77)
+    logits = torch.randn(3, 257, generator=g) * 3.0
+    lp = logits - torch.logsumexp(logits, -1, keepdim=True)
+    blob["sampler.logprobs"] = lp.numpy()
+    blob["sampler.top_k_5"] = f32(su.apply_top_k(mx.array(lp), 5))
+    blob["sampler.top_p_0.9"] = f32(su.apply_top_p(mx.array(lp), 0.9))
+    blob["sampler.top_p_0.5"] = f32(su.apply_top_p(mx.array(lp), 0.5))
+    blob["sampler.min_p_0.05"] = f32(su.apply_min_p(mx.array(lp), 0.05))
+    blob["sampler.greedy"] = np.asarray(su.make_sampler(temp=0.0)(mx.array(lp))._t.numpy()).astype(np.int64)
+
+    out = os.path.join(HERE, "qwen2_vl_tiny_ref.npz")
+    np.savez_compressed(out, **blob)
+    print("wrote", out, os.path.getsize(out), "bytes;", len(blob), "arrays")
+
+
+if __name__ == "__main__":
+    main()
