@@ -20,12 +20,12 @@ remains unpinned.
   * Pin 1 - the reference itself, run in this container (tests/golden/make_golden_ref.py ->
     tests/golden/qwen2_vl_tiny_ref.npz, checked by tests/test_oracle_ref_golden.py): the reference's files
     mlx_vlm/models/qwen2_vl/{config,vision,language,qwen2_vl}.py, models/{base,cache,rope_utils,mlp,
-    activations}.py and sample_utils.py are imported UNMODIFIED from /root/reference and executed over
+    activations}.py, sample_utils.py and generate/{ar,common}.py (generate_step) are imported UNMODIFIED from /root/reference and executed over
     `oracle/mlx_shim`, a torch-CPU stand-in that restates MLX's published op semantics (typed arrays, per-op
     rounding, weak-typed python scalars, fp32-accumulating matmul / fast ops).  Against those vectors the
     oracle is bit-exact in bf16 on the whole language-model path (prefill, KVCache decode, rope deltas), on the
     vision tower from the patch embeddings on, on the embedding merge, the rope-index tables (image, text-only,
-    left-padded) and the sampler filters; the patch-embed contraction agrees to 1 bf16 ulp (summation order).
+    left-padded), the sampler filters and generate_step's tokens + bf16 logprobs on a text prompt; the patch-embed contraction agrees to 1 bf16 ulp (summation order).
     This pins the reference's GRAPH: op order, reshapes, dtype casts, rounding points, cache and position logic.
   * Pin 2 - an independent implementation (tests/golden/make_golden.py -> qwen2_vl_tiny_hf.npz): HuggingFace
     transformers 5.15 `Qwen2VLForConditionalGeneration` in fp32 (same checkpoint format).  The reference-over-

@@ -823,6 +823,14 @@ def set_default_stream(s):
     return None
 
 
+def new_thread_local_stream(device=None):
+    return Stream()
+
+
+def concat(arrays, axis=0, stream=None):
+    return concatenate(arrays, axis)
+
+
 @contextlib.contextmanager
 def stream(s=None):
     yield

@@ -8,7 +8,7 @@ imports and RUNS the reference's files for the Qwen2-VL path unchanged from /roo
 
     mlx_vlm/models/qwen2_vl/{config,vision,language,qwen2_vl}.py
     mlx_vlm/models/{base,cache,rope_utils,mlp,activations}.py
-    mlx_vlm/sample_utils.py
+    mlx_vlm/sample_utils.py, mlx_vlm/generate/ar.py (generate_step) + generate/common.py
 
 on the tiny config + seeded weights of tests/golden/make_golden.py, in fp32 and in bf16.  The package
 `__init__`s of mlx_vlm are NOT executed (they pull the whole server / tokenizer stack); `mlx_vlm.turboquant`
@@ -58,14 +58,34 @@ def import_reference():
     sys.modules["mlx_vlm.turboquant"] = tq
     sys.modules["mlx_vlm.models.qwen2_vl.processing_qwen2_vl"] = types.ModuleType(
         "mlx_vlm.models.qwen2_vl.processing_qwen2_vl")
+    # generate/ar.py (generate_step) drags in the server / tokenizer / speculative stack at import time; none of it
+    # is executed by generate_step for a plain greedy run, so those modules are empty stand-ins
+    pkg("mlx_vlm.generate", os.path.join(REF, "mlx_vlm", "generate"))
+    pkg("mlx_vlm.speculative", os.path.join(REF, "mlx_vlm", "_not_imported_"))
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+
+    stub("mlx_vlm.apc")
+    stub("mlx_vlm.kv_quant", from_legacy=lambda *a, **k: None)
+    stub("mlx_vlm.prompt_utils", apply_chat_template=None)
+    stub("mlx_vlm.speculative.utils", make_speculative_prompt_cache=None, run_speculative_rounds=None,
+         run_speculative_server_rounds=None, speculative_hidden_state=None,
+         speculative_prefill_kwargs=lambda *a, **k: {})
+    stub("mlx_vlm.utils", group_images_by_shape=None, prepare_inputs=None, should_add_special_tokens=None)
     import importlib
 
     q = importlib.import_module("mlx_vlm.models.qwen2_vl.qwen2_vl")
     cfgm = importlib.import_module("mlx_vlm.models.qwen2_vl.config")
     cache = importlib.import_module("mlx_vlm.models.cache")
     su = importlib.import_module("mlx_vlm.sample_utils")
-    for m in (q, cfgm, cache, su):
+    ar = importlib.import_module("mlx_vlm.generate.ar")
+    for m in (q, cfgm, cache, su, ar):
         assert m.__file__.startswith(REF), m.__file__
+    q._generate_ar = ar
     return mx, q, cfgm, cache, su
 
 
@@ -154,6 +174,27 @@ def main():
                 blob[name + ".sizes"] = np.array(sizes, dtype=np.int64)
             print(p, "feats", blob[p + "ref_image_features"].shape, "logits", blob[p + "ref_prefill_logits"].shape,
                   "greedy", toks)
+
+    # ---- the reference's generate_step itself (generate/ar.py:151-515), greedy, bf16 model (the last one built)
+    ar = q._generate_ar
+    imgs, pix, thw, ids = make_inputs(cfg, cases["one_image"], seed=1)
+    toks, lps = [], []
+    for tok, lp in ar.generate_step(mx.array(ids.astype(np.int32)), model, mx.array(pix.astype(np.float32)), None,
+                                    max_tokens=8, temperature=0.0, image_grid_thw=mx.array(thw.astype(np.int32))):
+        toks.append(int(tok))
+        lps.append(f32(lp))
+        assert lp.dtype == mx.bfloat16
+    blob["generate_step.image.tokens"] = np.array(toks, dtype=np.int64)
+    blob["generate_step.image.logprobs"] = np.stack(lps)
+    text_ids = np.random.default_rng(11).integers(3, 1000, (1, 19)).astype(np.int32)
+    toks, lps = [], []
+    for tok, lp in ar.generate_step(mx.array(text_ids), model, None, None, max_tokens=8, temperature=0.0):
+        toks.append(int(tok))
+        lps.append(f32(lp))
+    blob["generate_step.text.input_ids"] = text_ids.astype(np.int64)
+    blob["generate_step.text.tokens"] = np.array(toks, dtype=np.int64)
+    blob["generate_step.text.logprobs"] = np.stack(lps)
+    print("generate_step image", blob["generate_step.image.tokens"].tolist(), "text", toks)
 
     # ---- rope index: text only, and a left-padded batch (language.py:216-402)
     lm = model.language_model

@@ -152,3 +152,26 @@ def test_fused_rope_mode_stays_within_reference_self_consistency():
     a = oq.qwen2_model(W, cfg, emb, None, pos, "fused")
     b = oq.qwen2_model(W, cfg, emb, None, pos, "fallback")
     np.testing.assert_allclose(a.numpy(), b.numpy(), atol=1e-4, rtol=0)
+
+
+def test_generate_step_text_prompt_is_bit_exact_vs_reference():
+    """The reference's generate_step (generate/ar.py:151-515) itself, greedy, bf16, text-only prompt: tokens and
+    every bf16 logprob (logits - logsumexp, ar.py:368) identical."""
+    cfg, W = weights(torch.bfloat16)
+    ids = R["generate_step.text.input_ids"]
+    toks, lg = oq.generate_greedy(W, cfg, ids, None, None, max_tokens=8, rope_mode="fallback", return_logits=True)
+    assert toks == R["generate_step.text.tokens"].tolist()
+    lp = ops.logprobs_from_logits(lg)
+    assert lp.dtype == torch.bfloat16
+    assert np.array_equal(lp.float().numpy(), R["generate_step.text.logprobs"])
+
+
+def test_generate_step_image_prompt_matches_reference():
+    cfg, W = weights(torch.bfloat16)
+    case = "one_image"
+    pix, thw, ids = torch.from_numpy(G[case + ".pixel_values"]), R[case + ".grid_thw"], R[case + ".input_ids"]
+    toks, lg = oq.generate_greedy(W, cfg, ids, pix, thw, max_tokens=8, rope_mode="fallback", return_logits=True)
+    assert toks == R["generate_step.image.tokens"].tolist()
+    lp = ops.logprobs_from_logits(lg).float().numpy()
+    ref = R["generate_step.image.logprobs"]
+    assert np.abs(lp - ref).max() <= 4 * 2.0 ** -7 * np.abs(ref).max()      # patch-embed summation order only
