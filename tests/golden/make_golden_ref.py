@@ -231,6 +231,32 @@ def main():
     blob["sampler.min_p_0.05"] = f32(su.apply_min_p(mx.array(lp), 0.05))
     blob["sampler.greedy"] = np.asarray(su.make_sampler(temp=0.0)(mx.array(lp))._t.numpy()).astype(np.int64)
 
+    # ---- the reference's own image processor (models/qwen3_vl/processing_qwen3_vl.py:182-205,302-378; Qwen2-VL
+    #      uses it with patch 14): smart resize table + patchified pixel rows for the two HF-golden test images
+    import importlib
+    import zlib
+
+    m = types.ModuleType("mlx_vlm.models.qwen3_vl")
+    m.__path__ = [os.path.join(REF, "mlx_vlm", "models", "qwen3_vl")]
+    sys.modules["mlx_vlm.models.qwen3_vl"] = m
+    ip3 = importlib.import_module("mlx_vlm.models.qwen3_vl.processing_qwen3_vl")
+    assert ip3.__file__.startswith(REF)
+    from PIL import Image
+
+    G = np.load(os.path.join(HERE, "qwen2_vl_tiny_hf.npz"))
+    proc = ip3.Qwen3VLImageProcessor(patch_size=14, merge_size=2, temporal_patch_size=2, min_pixels=56 * 56,
+                                     max_pixels=14 * 14 * 4 * 1280, image_mean=[0.5, 0.5, 0.5], image_std=[0.5, 0.5, 0.5])
+    for tag in ("ip_a", "ip_b"):
+        o = proc([Image.fromarray(G[tag + ".image_hwc"])])
+        pv = np.ascontiguousarray(np.asarray(o["pixel_values"], dtype=np.float32))
+        blob[tag + ".ref_grid_thw"] = np.asarray(o["image_grid_thw"], dtype=np.int64)
+        blob[tag + ".ref_pixel_values"] = pv if pv.shape[0] <= 128 else pv[:0]
+        blob[tag + ".ref_pixel_values_rowsum"] = pv.astype(np.float64).sum(axis=1)
+        blob[tag + ".ref_pixel_values_crc32"] = np.array([zlib.crc32(pv.tobytes())], dtype=np.int64)
+    sr = [[h, w, *ip3._smart_resize_image(h, w, factor=28, min_pixels=56 * 56, max_pixels=14 * 14 * 4 * 1280)]
+          for (h, w) in [(336, 336), (448, 448), (100, 333), (1080, 1920), (30, 40), (2000, 3000), (57, 500)]]
+    blob["smart_resize.ref_table"] = np.array(sr, dtype=np.int64)
+
     out = os.path.join(HERE, "qwen2_vl_tiny_ref.npz")
     np.savez_compressed(out, **blob)
     print("wrote", out, os.path.getsize(out), "bytes;", len(blob), "arrays")

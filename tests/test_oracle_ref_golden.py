@@ -175,3 +175,27 @@ def test_generate_step_image_prompt_matches_reference():
     lp = ops.logprobs_from_logits(lg).float().numpy()
     ref = R["generate_step.image.logprobs"]
     assert np.abs(lp - ref).max() <= 4 * 2.0 ** -7 * np.abs(ref).max()      # patch-embed summation order only
+
+
+@pytest.mark.parametrize("tag", ["ip_a", "ip_b"])
+def test_image_processor_is_bit_exact_vs_reference(tag):
+    """The reference's own Qwen3VLImageProcessor (processing_qwen3_vl.py:302-378, PIL bicubic) on the two test
+    images: grid, every pixel row (crc32 of the float32 bytes) identical."""
+    import zlib
+
+    from oracle import image_processor as ip
+
+    im = G[tag + ".image_hwc"]
+    pv, thw = ip.process([im.transpose(2, 0, 1)])
+    assert thw.tolist() == R[tag + ".ref_grid_thw"].tolist()
+    pv = np.ascontiguousarray(pv.astype(np.float32))
+    assert zlib.crc32(pv.tobytes()) == int(R[tag + ".ref_pixel_values_crc32"][0])
+    if R[tag + ".ref_pixel_values"].shape[0]:
+        assert np.array_equal(pv, R[tag + ".ref_pixel_values"])
+
+
+def test_smart_resize_matches_reference_table():
+    from oracle import image_processor as ip
+
+    for h, w, rh, rw in R["smart_resize.ref_table"].tolist():
+        assert ip.smart_resize(h, w) == (rh, rw)
