@@ -62,7 +62,8 @@ int vlm_gemv_bf16(const void* x, const void* W, const void* bias, const void* re
  * vlm_gemv_qkv_rope_kvwrite: qkv = RMSNorm(h) Wqkv^T + b (language.py:52-54,76,149), then M-RoPE on the q and k
  *   heads at pos[m] (rope_utils.py:567-651; a decoded text token has equal t/h/w positions, language.py:476-509)
  *   and KVCache.update_and_fetch (cache.py:345-367): rotated q -> qkv[m][0 : Hq*D], rotated k and v -> slot[m] of
- *   sequence m in the paged pools.  pos / slot int32 [M] on the device.
+ *   sequence m in the paged pools.  pos / slot int32 [M] on the device.  block_table == NULL selects the identity
+ *   layout: row m owns pages [m * max_pages, (m + 1) * max_pages) of the pools as passed (no table load).
  * vlm_gemv_attn_out: h += merge(attention split partials) Wo^T (language.py:115-120,151): the split-K merge of
  *   vlm_attn_decode_paged is the GEMV prologue, the residual add its epilogue. */
 int vlm_gemv_qkv_rope_kvwrite(const void* h, const void* norm_w, float eps, const void* Wqkv, const void* bqkv,
@@ -100,7 +101,9 @@ int vlm_mrope_kvwrite(void* qkv, int ld, int T, int Hq, int Hkv, int D, const vo
 /* mx.fast.scaled_dot_product_attention on the prefill path: varlen segments (cu_seqlens int32
  * [nseg+1]), mask=None (vision.py:148-158) or mask="causal" (base.py:214-228,366-373), GQA.
  * q/k/v/out are token-major with the given token strides; head h of token t at ptr + t*stride + h*D.
- * total_qblocks = sum_s ceil(len_s / 128) (host).  D in {64, 80, 128}. */
+ * total_qblocks = sum_s ceil(len_s / 128) (host).  D in {64, 80, 128}.
+ * causal: bit 0 = causal mask; bit 1 = hint "all segments have the same length" (enables an XCD-local
+ * placement of the query blocks of one (segment, head); results are identical with or without it). */
 int vlm_attn_prefill(const void* q, const void* k, const void* v, void* out, int q_stride, int k_stride, int v_stride,
                      int o_stride, const void* cu_seqlens, int nseg, int total_qblocks, int Hq, int Hkv, int D,
                      float scale, int causal, void* stream);
@@ -108,7 +111,9 @@ int vlm_attn_prefill(const void* q, const void* k, const void* v, void* out, int
 /* the same op at L == 1 over the paged cache (base.py:366-373 from language.py:115-118).
  * q [B][Hq*D] (row stride ldq); kv_len int32 [B] (+ kv_len_add) keys per sequence;
  * part_o fp32 [B][Hq][nsplit][D], part_ml fp32 [B][Hq][nsplit][2] receive the per-split partials; out [B][Hq*D]
- * (bf16) gets the merged result, or pass out == NULL and merge in vlm_gemv_attn_out.  D == 128. */
+ * (bf16) gets the merged result, or pass out == NULL and merge in vlm_gemv_attn_out.  D == 128.
+ * block_table == NULL: identity layout - sequence b owns pages [b * max_pages, (b + 1) * max_pages) of the pools as
+ * passed, page numbers are computed instead of loaded (one dependent memory round trip less). */
 int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, const void* vpool, const void* block_table,
                           int max_pages, const void* kv_len, int kv_len_add, int B, int Hq, int Hkv, int D,
                           float scale, int nsplit, void* part_o, void* part_ml, void* out, int ldo, void* stream);
@@ -161,7 +166,7 @@ typedef struct vlm_llm_globals {
 typedef struct vlm_kv_pool {
   void *kpool, *vpool;      /* layer 0 base */
   size_t layer_stride;      /* elements between consecutive layers' pools */
-  const void* block_table;  /* int32 [n_seq][max_pages] */
+  const void* block_table;  /* int32 [n_seq][max_pages]; NULL for decode over an identity-layout pool */
   int max_pages;
 } vlm_kv_pool;
 
@@ -235,6 +240,7 @@ typedef struct vlm_vit_args {
   const void* cu_seqlens;
   int nseg, total_qblocks;
   void *x, *xn, *qkv, *attn, *mlp, *mrg, *out;
+  int uniform_segments;          /* 1: all segments have the same length (vlm_attn_prefill placement hint) */
 } vlm_vit_args;
 
 int vlm_vit_create(const vlm_vit_config* cfg, void** handle);

@@ -65,7 +65,8 @@ class VitGlobals(C.Structure):
 class VitArgs(C.Structure):
     _fields_ = [("patches", c_void_p), ("N", c_int), ("cos_tab", c_void_p), ("sin_tab", c_void_p),
                 ("cu_seqlens", c_void_p), ("nseg", c_int), ("total_qblocks", c_int), ("x", c_void_p), ("xn", c_void_p),
-                ("qkv", c_void_p), ("attn", c_void_p), ("mlp", c_void_p), ("mrg", c_void_p), ("out", c_void_p)]
+                ("qkv", c_void_p), ("attn", c_void_p), ("mlp", c_void_p), ("mrg", c_void_p), ("out", c_void_p),
+                ("uniform_segments", c_int)]
 
 
 P = C.POINTER

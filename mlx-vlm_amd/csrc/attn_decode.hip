@@ -35,7 +35,7 @@ constexpr int HD = 128;   // head_dim supported by the decode path
 constexpr int PAGE = 64;
 
 // NW waves per workgroup: 16 (one round covers 1024 tokens of context); 8 when G == 8 (LDS merge buffer <= 64 KB)
-template <int G, int NW, bool STAMPS>
+template <int G, int NW, bool STAMPS, bool IDENT>
 __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
     // the first 14 dwords are everything the first loads need: with -amdgpu-kernarg-preload-count=16 they are in
     // SGPRs at wave start (no scalar-load round trip before the table / length / Q loads)
@@ -73,9 +73,11 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
   //   * every wave processes its first page UNCONDITIONALLY (do-while): a wave whose page lies beyond the context
   //     computes on masked scores (m = -inf, l = 0, O = 0) and drops out in the merge.  Block-table rows are
   //     zero-initialised and the pools fully mapped, so its loads are harmless.
+  // IDENT (block_table == NULL): sequence b owns pages [b * max_pages, (b + 1) * max_pages) of the pools as passed -
+  // no table load at all, the K/V loads are the first loads of the kernel
   int pi = s * NW + wave;
-  const int* trow = block_table + (size_t)b * max_pages;
-  size_t page = (size_t)trow[min(pi, max_pages - 1)];
+  const int* trow = IDENT ? nullptr : block_table + (size_t)b * max_pages;
+  size_t page = IDENT ? (size_t)b * max_pages + min(pi, max_pages - 1) : (size_t)trow[min(pi, max_pages - 1)];
   int len_raw;
   asm volatile("global_load_dword %0, %1, off" : "=v"(len_raw) : "v"(kv_len + b) : "memory");
 
@@ -96,8 +98,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
 
   int len = 0, npages = 0;
   do {
-    // table entry (+ context length and Q on the first pass) have landed; later passes: next_page, long since
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(len_raw), "+v"(page)::"memory");
+    // table entry (+ context length and Q on the first pass) have landed; later passes: next_page, long since.
+    // IDENT: nothing to wait for - the page number is arithmetic, K/V go out right behind the length / Q loads
+    if (!IDENT) asm volatile("s_waitcnt vmcnt(0)" : "+v"(len_raw), "+v"(page)::"memory");
     const bf16_t* kp = kpool + (page * Hkv + g) * (size_t)(HD / 8) * PAGE * 8 + ((size_t)gq * PAGE + head) * 8;
     const bf16_t* vp = vpool + (page * Hkv + g) * (size_t)HD * PAGE + (size_t)head * PAGE + 8 * gq;
     // ---- every operand fragment of the page: 16 + 16 loads of 16 B, all in flight
@@ -114,11 +117,13 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
         vf[dt][u] = *reinterpret_cast<const u32x4_t*>(vp + (size_t)(16 * dt) * PAGE + 32 * u);
     // the next page's table entry rides behind them (clamped index: unconditional, no dependent wait later)
     pi += nsplit * NW;
-    const size_t next_page = (size_t)trow[min(pi, max_pages - 1)];
+    const size_t next_page = IDENT ? (size_t)b * max_pages + min(pi, max_pages - 1) : (size_t)trow[min(pi, max_pages - 1)];
     __builtin_amdgcn_sched_barrier(0);   // all 32 loads are in flight before anything waits on one of them
     const int pc = pi - nsplit * NW;     // the page being processed
-    len = __builtin_amdgcn_readfirstlane(len_raw) + kv_len_add;
-    npages = (len + PAGE - 1) / PAGE;
+    if (!IDENT) {
+      len = __builtin_amdgcn_readfirstlane(len_raw) + kv_len_add;
+      npages = (len + PAGE - 1) / PAGE;
+    }
 
     stamp(2);
     // ---- S^T = K . Q^T : st[t][r] = score(key = 16t + 4gq + r, head = lane&15)
@@ -131,6 +136,13 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
         st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[t][ds]), qf[ds], st[t], 0, 0, 0);
     }
     if (STAMPS) { asm volatile("" :: "v"(st[3][3])); stamp(3); }
+    if (IDENT) {
+      // the length load is older than every K load (vector loads return in order) and the MFMAs above have
+      // consumed K: at most the 16 V loads are still in flight
+      asm volatile("s_waitcnt vmcnt(16)" : "+v"(len_raw)::"memory");
+      len = __builtin_amdgcn_readfirstlane(len_raw) + kv_len_add;
+      npages = (len + PAGE - 1) / PAGE;
+    }
     float mt = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -246,7 +258,7 @@ extern "C" int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, 
                                      const void* block_table, int max_pages, const void* kv_len, int kv_len_add, int B,
                                      int Hq, int Hkv, int D, float scale, int nsplit, void* part_o, void* part_ml,
                                      void* out, int ldo, void* stream) {
-  if (!q || !kpool || !vpool || !block_table || !kv_len) return VLM_ERR_ARG;
+  if (!q || !kpool || !vpool || !kv_len || max_pages <= 0) return VLM_ERR_ARG;   // block_table == NULL: identity layout
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || nsplit <= 0 || Hq % Hkv != 0) return VLM_ERR_ARG;
   if (nsplit > 1 && (!part_o || !part_ml)) return VLM_ERR_ARG;
   if (nsplit == 1 && !out) return VLM_ERR_ARG;
@@ -256,17 +268,23 @@ extern "C" int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, 
   const float sl2 = scale * 1.44269504088896340736f;
   dim3 grid(B * Hkv, nsplit);
   bf16_t* direct = nsplit == 1 ? (bf16_t*)out : nullptr;
-  static const bool stamps = getenv("VLM_ATTN_STAMPS") != nullptr && part_o != nullptr;   // debug timeline
+  static const bool stamps_env = getenv("VLM_ATTN_STAMPS") != nullptr;
+  const bool stamps = stamps_env && part_o != nullptr && block_table != nullptr;   // debug timeline
 #define GO(GV)                                                                                                          \
   if (stamps)                                                                                                           \
-    hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, 8, true>), grid, dim3(8 * 64), 0, st, \
+    hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, 8, true, false>), grid, dim3(8 * 64), 0, st, \
                        (const bf16_t*)q, (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)block_table,           \
                        (const int*)kv_len, ldq, max_pages, Hkv, kv_len_add, Hq, sl2, nsplit, ldo, (float*)part_o,       \
                        (float*)part_ml, direct);                                                                        \
   else                                                                                                                  \
-  hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, 8, false>), grid, dim3(8 * 64), 0, st, (const bf16_t*)q,              \
-                     (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)block_table, (const int*)kv_len, ldq,       \
-                     max_pages, Hkv, kv_len_add, Hq, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, direct)
+  if (!block_table)                                                                                                     \
+    hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, 8, false, true>), grid, dim3(8 * 64), 0, st, (const bf16_t*)q,      \
+                       (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)nullptr, (const int*)kv_len, ldq,        \
+                       max_pages, Hkv, kv_len_add, Hq, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, direct);      \
+  else                                                                                                                  \
+    hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, 8, false, false>), grid, dim3(8 * 64), 0, st, (const bf16_t*)q,     \
+                       (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)block_table, (const int*)kv_len, ldq,    \
+                       max_pages, Hkv, kv_len_add, Hq, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, direct)
   switch (G) {
     case 1: GO(1); break;
     case 2: GO(2); break;

@@ -37,7 +37,7 @@ template <int D, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(
     const bf16_t* __restrict__ qp, const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp, bf16_t* __restrict__ op,
     int q_stride, int k_stride, int v_stride, int o_stride, const int* __restrict__ cu, int nseg, int Hq, int Hkv,
-    float scale_log2) {
+    float scale_log2, int uniform_nqb) {
   constexpr int DP = (D + 31) / 32 * 32;   // padded head dim for the O^T tiles
   constexpr int NKS = D / 16;              // k-steps of the S^T product
   constexpr int NDB = DP / 32;             // 32-wide d blocks of O^T
@@ -50,16 +50,28 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
   __shared__ __attribute__((aligned(16))) bf16_t Ks[BKV * K_LD];
   __shared__ __attribute__((aligned(16))) bf16_t Vt[DP * VT_LD];
 
-  // ---- locate (segment, q block) ----
-  int bid = blockIdx.x, seg = 0, qb = 0;
-  for (; seg < nseg; ++seg) {
-    const int nb = (cu[seg + 1] - cu[seg] + BQ - 1) / BQ;
-    if (bid < nb) { qb = bid; break; }
-    bid -= nb;
+  // ---- locate (segment, head, q block) ----
+  int seg = 0, qb = 0, head = blockIdx.y;
+  if (uniform_nqb > 0) {
+    // every segment has uniform_nqb query blocks and nseg * Hq % 8 == 0 (checked on the host): workgroups are
+    // dispatched round-robin over the 8 XCDs, so give all query blocks of one (segment, head) the same
+    // id % 8 - its K/V rows are then fetched into ONE XCD's L2 instead of up to uniform_nqb of them
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, i = lin >> 3;
+    const int pair = xcd + 8 * (i / uniform_nqb);
+    qb = i % uniform_nqb;
+    seg = pair / Hq;
+    head = pair % Hq;
+  } else {
+    int bid = blockIdx.x;
+    for (; seg < nseg; ++seg) {
+      const int nb = (cu[seg + 1] - cu[seg] + BQ - 1) / BQ;
+      if (bid < nb) { qb = bid; break; }
+      bid -= nb;
+    }
+    if (seg >= nseg) return;
   }
-  if (seg >= nseg) return;
   const int seg_start = cu[seg], seg_len = cu[seg + 1] - seg_start;
-  const int head = blockIdx.y, kvh = head / (Hq / Hkv);
+  const int kvh = head / (Hq / Hkv);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   __builtin_assume(tid >= 0 && tid < 256);
   const int qrow = qb * BQ + wave * 32 + (lane & 31);          // row inside the segment
@@ -159,36 +171,52 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
     }
 
     // ---- online softmax (q = lane&31 is lane-local; lane^32 holds the other keys) ----
+    // The loop is VALU-bound (22 MFMAs per tile vs the element-wise work on 32 scores per lane), so the
+    // element-wise part is kept to one fma + one v_exp_f32 + one add per score:
+    //   * masking (segment end / causal diagonal) only on the tiles that need it (wave-uniform test);
+    //   * the softmax scale is folded into the exponent: p = exp2(s * scale_log2 - m), the running max is
+    //     taken on the raw scores;
+    //   * "deferred max": the reference max m_run only moves when some row's tile max exceeds it by more
+    //     than 2^8 (log2 domain) - P stays <= 256, exact in the normalised result, and the O / l rescale
+    //     (48 accumulator registers) runs on a few tiles per query block instead of every tile.
+    const bool need_mask = (j0 + BKV > seg_len) || (CAUSAL && j0 + BKV - 1 > qb * BQ + wave * 32);
+    if (need_mask) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = j0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const bool ok = key < seg_len && (!CAUSAL || key <= qrow);
+          st[kb][r] = ok ? st[kb][r] : -INFINITY;
+        }
+    }
     float mt = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = j0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const bool ok = key < seg_len && (!CAUSAL || key <= qrow);
-        const float s = ok ? st[kb][r] * scale_log2 : -INFINITY;
-        st[kb][r] = s;
-        mt = fmaxf(mt, s);
-      }
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = exp2f(m_run - m_use);
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[kb][r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2;         // scale_log2 > 0
+    if (__any(mt > m_run + 8.0f)) {                                // wave-uniform: move the reference max
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);   // m_run = -inf -> 0
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+    }
+    const float neg_m = (m_run == -INFINITY) ? 0.f : -m_run;
     float ls = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(st[kb][r] - m_use);
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[kb][r], scale_log2, neg_m));
         st[kb][r] = p;
         ls += p;
       }
-    l_run = l_run * alpha + ls;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < NDB; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+    l_run += ls;
 
     // ---- P fragments (B operand of O^T): registers 8m..8m+7 of block kb ----
     bf16x8_t pf[2][2];
@@ -255,10 +283,14 @@ extern "C" int vlm_attn_prefill(const void* q, const void* k, const void* v, voi
   hipStream_t st = (hipStream_t)stream;
   const float sl2 = scale * 1.44269504088896340736f;
   dim3 grid(total_qblocks, Hq), block(256);
+  // bit 1 of `causal`: the caller asserts that all segments have the same length -> XCD-local placement
+  const bool uniform = (causal & 2) != 0 && total_qblocks % nseg == 0 && ((long)nseg * Hq) % 8 == 0;
+  const int uniform_nqb = uniform ? total_qblocks / nseg : 0;
+  causal &= 1;
 #define GO(DV, CV)                                                                                                    \
   hipLaunchKernelGGL((attn_prefill_kernel<DV, CV>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,            \
                      (const bf16_t*)v, (bf16_t*)out, q_stride, k_stride, v_stride, o_stride, (const int*)cu_seqlens,  \
-                     nseg, Hq, Hkv, sl2)
+                     nseg, Hq, Hkv, sl2, uniform_nqb)
   if (D == 80 && !causal) GO(80, false);
   else if (D == 80 && causal) GO(80, true);
   else if (D == 128 && !causal) GO(128, false);

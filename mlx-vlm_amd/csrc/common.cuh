@@ -39,8 +39,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;
   return *reinterpret_cast<bf16_t*>(&b);
 }
+// two fp32 -> packed bf16x2 in ONE v_cvt_pk_bf16_f32 (the scalar casts cost a convert + shift + or each)
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  typedef float f32x2_t_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2v_t_ __attribute__((ext_vector_type(2)));
+  const f32x2_t_ v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v_t_));
 }
 // round a float through bf16 (typed-graph emulation of a materialised T tensor)
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }

@@ -274,7 +274,7 @@ extern "C" int vlm_vit_forward(void* handle, const vlm_vit_args* a, void* stream
     TRY(vlm_gemm_bf16(a->xn, w.wqkv, w.bqkv, nullptr, a->qkv, N, 3 * E, E, E, E, 3 * E, 0, VLM_EPI_BIAS, stream));
     TRY(vlm_rope2d_vision(a->qkv, a->cos_tab, a->sin_tab, N, H, hd, 3 * E, stream));
     TRY(vlm_attn_prefill(a->qkv, off(a->qkv, (size_t)E * 2), off(a->qkv, (size_t)2 * E * 2), a->attn, 3 * E, 3 * E, 3 * E, E,
-                         a->cu_seqlens, a->nseg, a->total_qblocks, H, H, hd, scale, 0, stream));
+                         a->cu_seqlens, a->nseg, a->total_qblocks, H, H, hd, scale, a->uniform_segments ? 2 : 0, stream));
     TRY(vlm_gemm_bf16(a->attn, w.wproj, w.bproj, a->x, a->x, N, E, E, E, E, E, E, VLM_EPI_BIAS | VLM_EPI_RESIDUAL, stream));
     TRY(vlm_layernorm(a->x, w.ln2_w, w.ln2_b, a->xn, N, E, c.ln_eps, stream));
     TRY(vlm_gemm_bf16(a->xn, w.wfc1, w.bfc1, nullptr, a->mlp, N, MH, E, E, E, MH, 0, VLM_EPI_BIAS | VLM_EPI_GELU_FAST, stream));

@@ -263,7 +263,10 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
     if (lane < MB) {
       const int m = lane;
       const float y0 = rbf(a0 + bf2f(e_b0)), y1 = rbf(a1 + bf2f(e_b1));
-      const size_t e_page = (size_t)rk.block_table[(size_t)m * rk.max_pages + (e_slot >> 6)];
+      // block_table == NULL: identity layout (sequence m owns pages [m * max_pages, (m + 1) * max_pages)) - no
+      // dependent table load at the tail of the kernel
+      const size_t e_page = rk.block_table ? (size_t)rk.block_table[(size_t)m * rk.max_pages + (e_slot >> 6)]
+                                           : (size_t)m * rk.max_pages + (e_slot >> 6);
       const int e_within = e_slot & 63;
       if (rope_pair) {
         float sn, cs;
@@ -511,7 +514,7 @@ extern "C" int vlm_gemv_qkv_rope_kvwrite(const void* h, const void* norm_w, floa
                                          const void* pos, const void* slot, const void* inv_freq,
                                          const void* block_table, int max_pages, void* kpool, void* vpool,
                                          void* stream) {
-  if (!h || !norm_w || !Wqkv || !bqkv || !qkv || !pos || !slot || !inv_freq || !block_table || !kpool || !vpool)
+  if (!h || !norm_w || !Wqkv || !bqkv || !qkv || !pos || !slot || !inv_freq || !kpool || !vpool || max_pages <= 0)
     return VLM_ERR_ARG;
   if (hidden % 8 || D % 16 || hidden > 3584 || (size_t)M * hidden * 2 > 64 * 1024) return VLM_ERR_SHAPE;
   const int N = (Hq + 2 * Hkv) * D;

@@ -56,13 +56,29 @@ class Arena:
 class KVPool:
     """Device pools + page allocator + block table for one language model."""
 
+    IDENTITY_BUDGET = 16 << 30   # bytes of KV the "auto" layout may reserve for the identity mapping
+
     def __init__(self, n_layers: int, n_kv_heads: int, head_dim: int, max_tokens: int = 32768, max_seqs: int = 64,
                  max_pages_per_seq: Optional[int] = None, device="cuda", dtype=torch.bfloat16,
-                 arena: Optional["Arena"] = None):
+                 arena: Optional["Arena"] = None, layout: str = "auto"):
+        """layout: "paged"    - pages come from a shared free list, kernels walk the block table;
+                   "identity" - sequence slot s owns pages [s * max_pages, (s + 1) * max_pages): the block table is
+                                still filled (prefill and generic callers use it) but the decode kernels are told
+                                so (block_table = NULL) and compute page numbers instead of loading them - one
+                                dependent memory round trip less per decode attention / KV write;
+                   "auto"     - identity when max_seqs * max_pages of KV fits IDENTITY_BUDGET."""
         self.n_layers, self.n_kv_heads, self.head_dim = n_layers, n_kv_heads, head_dim
         self.n_pages = (max_tokens + PAGE - 1) // PAGE
         self.max_seqs = max_seqs
         self.max_pages = max_pages_per_seq or self.n_pages
+        page_bytes = 2 * n_layers * n_kv_heads * PAGE * head_dim * torch.empty((), dtype=dtype).element_size()
+        if layout == "auto":
+            layout = "identity" if max_seqs * self.max_pages * page_bytes <= self.IDENTITY_BUDGET else "paged"
+        if layout not in ("identity", "paged"):
+            raise ValueError(f"KVPool layout {layout!r}")
+        self.identity = layout == "identity"
+        if self.identity:
+            self.n_pages = max_seqs * self.max_pages
         self.device = device
         per_layer = self.n_pages * n_kv_heads * PAGE * head_dim
         # zero-filled: never-written slots must not hold NaN bit patterns
@@ -90,7 +106,8 @@ class KVPool:
         raise RuntimeError(f"KVPool: no {n} consecutive free sequence slots")
 
     def free_seq(self, seq: int, pages: List[int]):
-        self._free_pages.extend(pages)
+        if not self.identity:
+            self._free_pages.extend(pages)
         self._free_seqs.add(seq)
 
     def ensure(self, seq: int, pages: List[int], n_tokens: int):
@@ -100,9 +117,12 @@ class KVPool:
             raise RuntimeError(f"KVPool: sequence needs {need} pages > max_pages_per_seq {self.max_pages}")
         grew = False
         while len(pages) < need:
-            if not self._free_pages:
+            if self.identity:
+                p = seq * self.max_pages + len(pages)
+            elif not self._free_pages:
                 raise RuntimeError("KVPool: out of KV pages")
-            p = self._free_pages.pop()
+            else:
+                p = self._free_pages.pop()
             self.block_table_host[seq, len(pages)] = p
             pages.append(p)
             grew = True

@@ -80,7 +80,7 @@ class LanguageModel:
     supports_logits_to_keep = True
 
     def __init__(self, args: TextConfig, config: ModelConfig, device="cuda", kv_pool_tokens: int = 32768,
-                 max_seqs: int = 64):
+                 max_seqs: int = 64, kv_layout: str = "auto"):
         self.args = args
         self.config = config
         self.model_type = args.model_type
@@ -90,6 +90,7 @@ class LanguageModel:
         self._handle = None
         self._w: Dict[str, torch.Tensor] = {}
         self._kv_pool_tokens, self._max_seqs = kv_pool_tokens, max_seqs
+        self._kv_layout = os.environ.get("VLM_KV_LAYOUT", kv_layout)   # env: A/B knob for measurements
         self.pool: Optional[KVPool] = None
         self._decode_states: Dict[int, DecodeState] = {}
         sec = list((args.rope_scaling or {}).get("mrope_section", [16, 24, 24]))
@@ -179,7 +180,7 @@ class LanguageModel:
         t = self.args
         self.pool = KVPool(t.num_hidden_layers, t.num_key_value_heads, self.head_dim, self._kv_pool_tokens,
                            self._max_seqs, max_pages_per_seq=min(512, (self._kv_pool_tokens + PAGE - 1) // PAGE),
-                           device=self.device, arena=self.arena)
+                           device=self.device, arena=self.arena, layout=self._kv_layout)
         kv = _lib.KvPool(self.pool.kpool.data_ptr(), self.pool.vpool.data_ptr(), self.pool.layer_stride,
                          self.pool.block_table.data_ptr(), self.pool.max_pages)
         check(_lib.lib().vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
@@ -373,16 +374,23 @@ class LanguageModel:
         st.seqs = seqs
         return st
 
-    def _kv_struct(self, row0: int):
-        bt = self.pool.block_table[row0:]
-        return _lib.KvPool(self.pool.kpool.data_ptr(), self.pool.vpool.data_ptr(), self.pool.layer_stride,
-                           bt.data_ptr(), self.pool.max_pages)
+    def _kv_struct(self, row0: int, decode: bool = False):
+        """The pool as the engine sees it for batch rows row0, row0+1, ...  Decode over an identity-layout pool:
+        no block table (NULL) and pool pointers advanced to row0's region - the kernels compute
+        page = row * max_pages + index instead of loading it."""
+        pool = self.pool
+        if decode and pool.identity:
+            off = row0 * pool.max_pages * pool.n_kv_heads * PAGE * pool.head_dim * pool.kpool.element_size()
+            return _lib.KvPool(pool.kpool.data_ptr() + off, pool.vpool.data_ptr() + off, pool.layer_stride, None,
+                               pool.max_pages)
+        bt = pool.block_table[row0:]
+        return _lib.KvPool(pool.kpool.data_ptr(), pool.vpool.data_ptr(), pool.layer_stride, bt.data_ptr(), pool.max_pages)
 
     def decode_run(self, st: DecodeState, n_steps: int, sampler_args: dict, use_graph: bool = True):
         """Enqueue n_steps decode steps (graph replays when use_graph)."""
         L = _lib.lib()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        kv = self._kv_struct(st.seq_row0)
+        kv = self._kv_struct(st.seq_row0, decode=True)
         check(L.vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
         args = st.args(**sampler_args)
         if use_graph:
@@ -428,7 +436,7 @@ class LanguageModel:
             deltas = self._rope_deltas if self._rope_deltas is not None else np.zeros((B, 1), dtype=np.int64)
             deltas = np.broadcast_to(np.asarray(deltas).reshape(-1, 1), (B, 1)) if np.asarray(deltas).size == 1 else deltas
             st = self.decode_begin(caches, ids.reshape(-1), deltas[:B], max_new_tokens=1)
-            kv = self._kv_struct(st.seq_row0)
+            kv = self._kv_struct(st.seq_row0, decode=True)
             check(_lib.lib().vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
             args = st.args()
             check(_lib.lib().vlm_llm_decode_forward(self._handle, C.byref(args),

@@ -133,7 +133,7 @@ class VisionModel:
             cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
             nqb = int(sum((l + 127) // 128 for l in lens))
             hit = (torch.cos(freqs).to(self.device), torch.sin(freqs).to(self.device),
-                   torch.from_numpy(cu).to(self.device), len(lens), nqb)
+                   torch.from_numpy(cu).to(self.device), len(lens), nqb, int(len(set(lens)) == 1))
             if len(self._tab_cache) > 64:
                 self._tab_cache.clear()
             self._tab_cache[key] = hit
@@ -154,7 +154,7 @@ class VisionModel:
         if hidden_states.dtype != torch.float32:
             hidden_states = hidden_states.to(torch.float32)
         x = ops.cast_pad(hidden_states.contiguous(), self.patch_k)
-        cos, sin, cu, nseg, nqb = self._tables(grid_thw)
+        cos, sin, cu, nseg, nqb, uniform = self._tables(grid_thw)
         E, dev = c.embed_dim, self.device
         mm = c.spatial_merge_size ** 2
         bf = torch.bfloat16
@@ -164,7 +164,7 @@ class VisionModel:
         out = torch.empty(N // mm, c.hidden_size, dtype=bf, device=dev)
         a = _lib.VitArgs(x.data_ptr(), N, cos.data_ptr(), sin.data_ptr(), cu.data_ptr(), nseg, nqb, ws["x"].data_ptr(),
                          ws["xn"].data_ptr(), ws["qkv"].data_ptr(), ws["attn"].data_ptr(), ws["mlp"].data_ptr(),
-                         mrg.data_ptr(), out.data_ptr())
+                         mrg.data_ptr(), out.data_ptr(), uniform)
         check(_lib.lib().vlm_vit_forward(self._handle, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
               "vit_forward")
         return out

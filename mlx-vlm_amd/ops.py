@@ -58,15 +58,17 @@ def gemv(x, w, bias=None, res=None, norm_w=None, out=None, eps=1e-6, epilogue=EP
 
 
 def gemv_qkv_rope_kvwrite(h, norm_w, wqkv, bqkv, Hq, Hkv, D, pos, slot, inv_freq, block_table, kpool, vpool, eps=1e-6,
-                          out=None):
-    """decode-step fusion: RMSNorm + qkv GEMV + bias + M-RoPE + paged KV write.  -> qkv [M, (Hq+2Hkv)*D] (q part valid)"""
+                          out=None, max_pages=None):
+    """decode-step fusion: RMSNorm + qkv GEMV + bias + M-RoPE + paged KV write.  -> qkv [M, (Hq+2Hkv)*D] (q part valid)
+    block_table None: identity layout (row m owns pages [m*max_pages, (m+1)*max_pages) of the pools as passed)."""
     _dev(h, norm_w, wqkv, bqkv, pos, slot, inv_freq, block_table, kpool, vpool)
     M, K = h.shape
     if out is None:
         out = torch.zeros(M, (Hq + 2 * Hkv) * D, dtype=torch.bfloat16, device=h.device)
     check(_lib.lib().vlm_gemv_qkv_rope_kvwrite(_p(h), _p(norm_w), eps, _p(wqkv), _p(bqkv), _p(out), out.stride(0), M, K,
                                                Hq, Hkv, D, _p(pos), _p(slot), _p(inv_freq), _p(block_table),
-                                               block_table.shape[1], _p(kpool), _p(vpool), _stream()), "gemv_qkv_rope_kvwrite")
+                                               block_table.shape[1] if block_table is not None else int(max_pages),
+                                               _p(kpool), _p(vpool), _stream()), "gemv_qkv_rope_kvwrite")
     return out
 
 
@@ -116,21 +118,23 @@ def mrope_kvwrite_(qkv, Hq, Hkv, D, pos_t, pos_h, pos_w, inv_freq, sec0, sec1, k
     return qkv
 
 
-def attn_prefill(q, k, v, cu_seqlens, total_qblocks, Hq, Hkv, D, scale, causal, out=None):
-    """q/k/v: 2-D views [T, *] whose data_ptr points at head 0 of token 0 and stride(0) is the token stride."""
+def attn_prefill(q, k, v, cu_seqlens, total_qblocks, Hq, Hkv, D, scale, causal, out=None, uniform_segments=False):
+    """q/k/v: 2-D views [T, *] whose data_ptr points at head 0 of token 0 and stride(0) is the token stride.
+    uniform_segments: placement hint (all segments the same length); results are identical."""
     _dev(q, k, v, cu_seqlens)
     T = q.shape[0]
     if out is None:
         out = torch.empty(T, Hq * D, dtype=torch.bfloat16, device=q.device)
     check(_lib.lib().vlm_attn_prefill(_p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
                                       _p(cu_seqlens), cu_seqlens.numel() - 1, total_qblocks, Hq, Hkv, D, scale,
-                                      1 if causal else 0, _stream()), "attn_prefill")
+                                      (1 if causal else 0) | (2 if uniform_segments else 0), _stream()), "attn_prefill")
     return out
 
 
 def attn_decode_paged(q, kpool, vpool, block_table, kv_len, kv_len_add, Hq, Hkv, D, scale, nsplit, out=None,
-                      merge=True):
-    """merge=True -> bf16 [B, Hq*D]; merge=False -> (part_o, part_ml) for gemv_attn_out_"""
+                      merge=True, max_pages=None):
+    """merge=True -> bf16 [B, Hq*D]; merge=False -> (part_o, part_ml) for gemv_attn_out_
+    block_table None: identity layout (row b owns pages [b*max_pages, (b+1)*max_pages) of the pools as passed)."""
     _dev(q, kpool, vpool, block_table, kv_len)
     B = q.shape[0]
     part_o = torch.empty(B, Hq, nsplit, D, dtype=torch.float32, device=q.device)
@@ -138,7 +142,8 @@ def attn_decode_paged(q, kpool, vpool, block_table, kv_len, kv_len_add, Hq, Hkv,
     if merge and out is None:
         out = torch.empty(B, Hq * D, dtype=torch.bfloat16, device=q.device)
     check(_lib.lib().vlm_attn_decode_paged(_p(q), q.stride(0), _p(kpool), _p(vpool), _p(block_table),
-                                           block_table.shape[1], _p(kv_len), kv_len_add, B, Hq, Hkv, D, scale, nsplit,
+                                           block_table.shape[1] if block_table is not None else int(max_pages),
+                                           _p(kv_len), kv_len_add, B, Hq, Hkv, D, scale, nsplit,
                                            _p(part_o), _p(part_ml), _p(out) if merge else None,
                                            out.stride(0) if merge else 0, _stream()), "attn_decode")
     return out if merge else (part_o, part_ml)

@@ -224,3 +224,83 @@ def test_sampling_temperature_reproducible_and_varied(tiny):
     b = [t for t, _ in generate_step(ids, model, None, None, max_tokens=12, temperature=1.0, top_p=0.95, seed=5)]
     c = [t for t, _ in generate_step(ids, model, None, None, max_tokens=12, temperature=1.0, top_p=0.95, seed=6)]
     assert a == b and a != c
+
+
+# ---- against vectors produced by the REFERENCE'S OWN files (tests/golden/make_golden_ref.py; only the .npz is read)
+RG = np.load(os.path.join(os.path.dirname(__file__), "golden", "qwen2_vl_tiny_ref.npz"))
+
+
+@pytest.mark.parametrize("case", ["one_image", "two_images"])
+def test_reference_golden_bf16_prefill_and_greedy_through_hip_path(tiny, case):
+    """bf16 reference vectors (reference code over oracle/mlx_shim): HIP image features, last-row prefill logprobs and
+    8 greedy tokens.  Tolerance: 2 bf16 ulps + 3 % of the rms (fp32 accumulation order; the reference vectors use
+    the pure-MLX rope path, the kernels the fused kernel's fp32 numerics - within the reference's own 1e-4 contract)."""
+    from mlx_vlm_amd.generate import generate_step
+
+    cfg, W, model = tiny
+    p = case + ".bf16."
+    pix, thw, ids = G[case + ".pixel_values"], RG[case + ".grid_thw"], RG[case + ".input_ids"]
+    feats = model.vision_tower(torch.from_numpy(pix), thw)
+    e = _rel_rms_err(feats, torch.from_numpy(RG[p + "ref_image_features"]))
+    assert e < 2e-2, e
+    toks, lps = [], []
+    for t, lp in generate_step(ids, model, torch.from_numpy(pix), None, max_tokens=8, temperature=0.0, image_grid_thw=thw):
+        toks.append(t)
+        lps.append(lp.float().cpu())
+    ref_logits = torch.from_numpy(np.concatenate([RG[p + "ref_prefill_logits"][-1:], RG[p + "ref_decode_logits"]]))
+    ok, n, margin = _tie_aware_equal(toks, RG[p + "ref_greedy"].tolist(), ref_logits, tol=3e-2)
+    assert ok, (toks, RG[p + "ref_greedy"].tolist(), n, margin)
+    ref_lp0 = O.logprobs_from_logits(ref_logits[0][None].to(BF))[0]
+    ok, rep = bf16_close(lps[0], ref_lp0, ulps=2, atol_rms=3e-2)
+    assert ok, rep
+
+
+def test_reference_generate_step_text_golden_through_hip_path(tiny):
+    """The reference's generate_step on a text prompt (tokens + bf16 logprobs of every step)."""
+    from mlx_vlm_amd.generate import generate_step
+
+    cfg, W, model = tiny
+    ids = RG["generate_step.text.input_ids"]
+    toks, lps = [], []
+    for t, lp in generate_step(ids, model, None, None, max_tokens=8, temperature=0.0):
+        toks.append(t)
+        lps.append(lp.float().cpu())
+    ref_lp = torch.from_numpy(RG["generate_step.text.logprobs"])
+    ok, n, margin = _tie_aware_equal(toks, RG["generate_step.text.tokens"].tolist(), ref_lp, tol=3e-2)
+    assert ok, (toks, RG["generate_step.text.tokens"].tolist(), n, margin)
+    for i in range(len(toks)):
+        if toks[: i + 1] != RG["generate_step.text.tokens"].tolist()[: i + 1]:
+            break
+        ok, rep = bf16_close(lps[i], ref_lp[i].to(BF), ulps=2, atol_rms=3e-2)
+        assert ok, (i, rep)
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_paged_and_identity_kv_layouts_generate_the_same_tokens(B):
+    """The identity layout (decode kernels compute page numbers) and the shared-free-list paged layout (kernels walk
+    the block table) are two placements of the same cache: identical tokens and first-step logprobs."""
+    from mlx_vlm_amd.generate import batch_generate_ids, generate_step
+
+    cfg = oq.tiny_cfg()
+    W = oq.random_weights(cfg, seed=1234, dtype=BF, std=0.05, embed_std=0.2)
+    outs = []
+    for layout in ("identity", "paged"):
+        model = build_product_model(cfg, W, kv_pool_tokens=4096, max_seqs=4, kv_layout=layout)
+        assert model.language_model.pool.identity == (layout == "identity")
+        if B == 1:
+            ids, pix, thw = synth_request(cfg, [(56, 84)], n_text=14, seed=8)
+            toks, lp0 = [], None
+            for t, lp in generate_step(ids, model, torch.from_numpy(pix), None, max_tokens=70, temperature=0.0,
+                                       image_grid_thw=thw):
+                toks.append(t)
+                lp0 = lp.float().cpu() if lp0 is None else lp0
+            outs.append((toks, lp0))
+        else:
+            reqs = [synth_request(cfg, [(56, 84)], n_text=10 + 3 * i, seed=20 + i) for i in range(B)]
+            toks, _ = batch_generate_ids(model, [r[0].reshape(-1) for r in reqs], [torch.from_numpy(r[1]) for r in reqs],
+                                         [r[2] for r in reqs], max_tokens=40)
+            outs.append(([list(t) for t in toks], None))
+        del model
+    assert outs[0][0] == outs[1][0]
+    if outs[0][1] is not None:
+        assert torch.equal(outs[0][1], outs[1][1])

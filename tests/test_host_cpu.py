@@ -151,7 +151,7 @@ def test_model_config_from_dict_root_level_text_config():
 def test_kv_pool_allocator_cpu():
     from mlx_vlm_amd.models.cache import KVCache, KVPool, PagedSequence
 
-    pool = KVPool(2, 1, 128, max_tokens=64 * 6, max_seqs=4, device="cpu")
+    pool = KVPool(2, 1, 128, max_tokens=64 * 6, max_seqs=4, device="cpu", layout="paged")
     a, b = PagedSequence(pool), PagedSequence(pool)
     assert (a.seq, b.seq) == (0, 1)
     a.reserve(65)
@@ -166,6 +166,25 @@ def test_kv_pool_allocator_cpu():
     b.offset = 10
     assert [x.trim(3) for x in c] == [3, 3] and b.offset == 7     # trims once (views share the sequence)
     assert c[0].state[0].shape == (1, 1, 7, 128)
+
+
+def test_kv_pool_identity_layout_cpu():
+    """identity layout: slot s owns pages [s*max_pages, (s+1)*max_pages); the block table is still filled."""
+    from mlx_vlm_amd.models.cache import KVPool, PagedSequence
+
+    pool = KVPool(2, 1, 128, max_tokens=64 * 6, max_seqs=4, device="cpu")          # "auto" -> identity (tiny)
+    assert pool.identity and pool.n_pages == 4 * pool.max_pages
+    a, b = PagedSequence(pool), PagedSequence(pool)
+    a.reserve(130)
+    b.reserve(64 * 6)
+    assert a.pages == [0, 1, 2] and b.pages == [pool.max_pages + i for i in range(6)]
+    assert pool.block_table[1, :6].tolist() == b.pages
+    with pytest.raises(RuntimeError):
+        b.reserve(64 * 6 + 1)                   # beyond max_pages_per_seq
+    a.release()
+    c = PagedSequence(pool)
+    c.reserve(1)
+    assert c.seq == 0 and c.pages == [0]        # the slot's region is reused, never another slot's
 
 
 def test_shard_requests_partition():

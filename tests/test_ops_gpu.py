@@ -460,3 +460,72 @@ def test_gemm_lds_dma_staging_equals_register_staging(vops, M, N, K):
     finally:
         vops.gemm_set_staging(0)
     assert torch.equal(out, ref)
+
+
+# ------------------------------------------------------------------ identity KV layout (block_table == NULL)
+@pytest.mark.parametrize("lens,nsplit", [([1], 1), ([130, 64], 1), ([700, 65, 512, 3], 1), ([1500, 2048], 2)])
+def test_attn_decode_identity_layout_equals_block_table_path(vops, lens, nsplit):
+    """row b owns pages [b*max_pages, (b+1)*max_pages): same bits as walking an identity block table."""
+    B, Hq, Hkv, D = len(lens), 12, 2, 128
+    scale = D ** -0.5
+    max_pages = max((n + 63) // 64 for n in lens) + 1
+    kpool = (torch.randn(B * max_pages, Hkv, D // 8, 64, 8, generator=torch.Generator().manual_seed(5)) * 0.5).to(BF).cuda()
+    vpool = (torch.randn(B * max_pages, Hkv, D, 64, generator=torch.Generator().manual_seed(6)) * 0.5).to(BF).cuda()
+    q = rnd(B, Hq * D, seed=7).cuda()
+    kv_len = torch.tensor(lens, dtype=torch.int32).cuda()
+    bt = torch.arange(B * max_pages, dtype=torch.int32).reshape(B, max_pages).cuda()
+    ref = vops.attn_decode_paged(q, kpool, vpool, bt, kv_len, 0, Hq, Hkv, D, scale, nsplit)
+    out = vops.attn_decode_paged(q, kpool, vpool, None, kv_len, 0, Hq, Hkv, D, scale, nsplit, max_pages=max_pages)
+    assert torch.equal(out, ref)
+
+
+def test_gemv_qkv_kvwrite_identity_layout_equals_block_table_path(vops):
+    M, Hq, Hkv, D, K = 4, 12, 2, 128, 1536
+    h = rnd(M, K, seed=60).cuda()
+    nw = (1 + 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(61))).to(BF).cuda()
+    wqkv, bqkv = rnd((Hq + 2 * Hkv) * D, K, seed=62, scale=0.05).cuda(), rnd((Hq + 2 * Hkv) * D, seed=63, scale=0.3).cuda()
+    pos = torch.tensor([37, 1000, 5, 2047], dtype=torch.int32).cuda()
+    slot = torch.tensor([70, 3, 64, 129], dtype=torch.int32).cuda()
+    inv = O.mrope_inv_freq(D, 1e6).cuda()
+    max_pages = 4
+    bt = torch.arange(M * max_pages, dtype=torch.int32).reshape(M, max_pages).cuda()
+    res = []
+    for table in (bt, None):
+        kpool = torch.zeros(M * max_pages, Hkv, D // 8, 64, 8, dtype=BF, device="cuda")
+        vpool = torch.zeros(M * max_pages, Hkv, D, 64, dtype=BF, device="cuda")
+        out = vops.gemv_qkv_rope_kvwrite(h, nw, wqkv, bqkv, Hq, Hkv, D, pos, slot, inv, table, kpool, vpool,
+                                         max_pages=max_pages)
+        res.append((out[:, :Hq * D].clone(), kpool, vpool))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    assert int((res[1][1] != 0).sum()) > 0
+
+
+@pytest.mark.parametrize("D,H,nseg,L", [(80, 16, 4, 576), (128, 8, 2, 300), (80, 4, 6, 129)])
+def test_attn_prefill_uniform_segment_placement_is_bit_identical(vops, D, H, nseg, L):
+    """bit 1 of `causal` only changes which workgroup computes which (segment, head, q block)."""
+    T = nseg * L
+    qkv = rnd(T, 3 * H * D, seed=31).cuda()
+    cu = torch.arange(0, T + 1, L, dtype=torch.int32).cuda()
+    nqb = nseg * ((L + 127) // 128)
+    a = vops.attn_prefill(qkv, qkv[:, H * D:], qkv[:, 2 * H * D:], cu, nqb, H, H, D, D ** -0.5, False)
+    b = vops.attn_prefill(qkv, qkv[:, H * D:], qkv[:, 2 * H * D:], cu, nqb, H, H, D, D ** -0.5, False, uniform_segments=True)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_attn_prefill_deferred_max_slow_ramp(vops, causal):
+    """scores that creep up tile after tile by less than the deferred-max threshold (2^8), then jump: the
+    reference max lags behind the true running max and P reaches ~2^8 before the rescale fires."""
+    T, H, D = 640, 2, 128
+    q, k, v = rnd(T, H, D, seed=34), rnd(T, H, D, seed=35), rnd(T, H, D, seed=36)
+    base = q[3].float()
+    for t in range(T):      # key t aligned with query 3, strength growing with t: +~1.5 (log2) per 64-key tile
+        k[t] = (base * (0.02 + 0.0009 * t) / (base.norm(dim=-1, keepdim=True) / D ** 0.5)).to(BF)
+    k[600] = (base * 6.0 / (base.norm(dim=-1, keepdim=True) / D ** 0.5)).to(BF)      # late spike > threshold
+    ref = _ref_attn_varlen(q, k, v, [T], D ** -0.5, causal)
+    qkv = torch.cat([q.reshape(T, -1), k.reshape(T, -1), v.reshape(T, -1)], dim=1).cuda()
+    cu = torch.tensor([0, T], dtype=torch.int32).cuda()
+    out = vops.attn_prefill(qkv, qkv[:, H * D:], qkv[:, 2 * H * D:], cu, 5, H, H, D, D ** -0.5, causal)
+    ok, rep = bf16_close(out.view(T, H, D), ref, ulps=2, atol_rms=2e-2)
+    assert ok, rep
