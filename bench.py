@@ -168,6 +168,29 @@ def cpu_baseline(threads):
                        f"x28/{LS} layers; vision = {VS} of 32 ViT blocks + merger on one 448x448 image, extrapolated x32/{VS}")}
 
 
+DECODE_KERNELS = ("gemv_rowwave_kernel", "gemv_splitk_kernel", "attn_decode_mfma_kernel", "attn_decode_combine_kernel",
+                  "lse_partial_kernel", "logprob_argmax_kernel", "argmax_final_kernel", "embed_gather_kernel",
+                  "decode_advance_kernel", "sample_filter_kernel")
+GATE_UP_KERNEL = "gemv_rowwave_kernel<4, 3, 1, 1, 16>"     # name as rocprofv3 prints it (R=4 rows/wave, RMSNorm prologue, SwiGLU)
+
+
+def pmc_traffic():
+    """HBM bytes per launch from the committed --pmc pass (scripts/final_round.sh -> profiles/r01_pmc_traffic.json:
+    (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of MI355X_MICROARCH.md).  bench.py cannot collect
+    hardware counters itself; None when the file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    d = json.load(open(path))
+    gu = d.get(GATE_UP_KERNEL, {}).get("hbm_bytes_per_launch")
+    steps = d.get("decode_advance_kernel", {}).get("launches", 0)
+    per_tok = None
+    if steps:
+        per_tok = sum(v.get("hbm_bytes_per_launch", 0.0) * v["launches"] for k, v in d.items()
+                      if k.startswith(DECODE_KERNELS)) / steps
+    return gu, per_tok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,6 +261,7 @@ def main():
         ctx_mid = int(req[0].shape[1]) + args.max_tokens // 2
         bytes_per_token = 2 * lm_params + 28672 * ctx_mid + 28672
         step_gbs = bytes_per_token / (us_per_token * 1e-6) / 1e9
+        traffic_gu, traffic_tok = pmc_traffic()
         out = {
             "metric": "decode tokens/sec + vision-prefill images/sec, Qwen2-VL-2B", "value": decode_tps, "unit": "tokens/s",
             "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -252,14 +276,14 @@ def main():
             "e2e_tokens_per_s": ws * ntok / wall,
             "load_s": load_s,
             "roofline_decode_step": {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": step_gbs / HBM_PEAK_GBS, "traffic": None,
+                                     "frac": step_gbs / HBM_PEAK_GBS, "traffic": traffic_tok,
                                      "algorithmic_bytes_per_token": bytes_per_token},
         }
         if extras:
             k = extras["kernels"]["gemv_gate_up_swiglu"]
-            out["roofline"] = {"bound": "hbm", "kernel": "gemv_kernel<4,1,NORM,SWIGLU> (gate/up + SwiGLU, 28 launches/token)",
+            out["roofline"] = {"bound": "hbm", "kernel": GATE_UP_KERNEL + " (RMSNorm + gate/up GEMV + SwiGLU, 28 launches/token)",
                                "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["GBps"] / HBM_PEAK_GBS,
-                               "traffic": None, "bytes_per_launch": k["bytes_per_launch"], "us_per_launch": k["us_per_launch"]}
+                               "traffic": traffic_gu, "bytes_per_launch": k["bytes_per_launch"], "us_per_launch": k["us_per_launch"]}
             out["kernel_rooflines"] = extras["kernels"]
             ips336, dt336 = extras["vit336"]
             ips448, dt448 = extras["vit448"]
