@@ -1,0 +1,272 @@
+// 256x256x64 bf16 MFMA GEMM for gfx950, software-pipelined at workgroup level ("phased" schedule).
+//
+// Same contract as gemm_bf16.hip (C[M,N] = epilogue(A[M,K] . W[N,K]^T), same fragments, same accumulation order
+// per output element -> BIT-IDENTICAL results), used by vlm_gemm_bf16 for the large prefill GEMMs
+// (reference nn.Linear call sites: mlx_vlm/models/qwen2_vl/vision.py:129-130,168-173; language.py:52-55,120;
+// mlp.py:9-14).  What changes is the schedule - the 128x128 kernel stalls at every K tile (ds_read -> MFMA in
+// every wave at once, one barrier, repeat); here:
+//   * 8 waves (2 along M x 4 along N), each a 128x64 output block = 8x4 fragments of 16x16 (128 accumulator regs);
+//   * a K tile is consumed in 4 PHASES of 16 MFMAs (one 32-row quarter of the wave's block x all 4 column
+//     fragments x K = 64); the W fragments of a K tile are read from LDS once (phase 1), an A quarter per phase;
+//   * the two wave rows run HALF A PHASE APART (the M-row-1 waves execute one extra barrier up front): on every
+//     SIMD one wave issues ds_reads while the other one issues MFMAs, so the LDS pipe and the matrix pipe are both
+//     busy all the time (waves w and w+4 share a SIMD);
+//   * operands arrive by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip), two K tiles resident (128 KiB),
+//     every region refilled exactly two phases after its last read, i.e. 6 phases (~1.5 K tiles) before its next
+//     use, ordered by COUNTED vmcnt waits (never 0 in the loop) one phase before the reading phase.
+//
+// Phase p of a wave:   ds_read(p) ; DMA issue(p) ; s_waitcnt vmcnt(N_p) ; BARRIER ; lgkmcnt(0) ; 16 MFMA ; BARRIER
+// Barriers are numbered globally b = 0, 1, ...; wave row 0 runs phase p between barriers (2p-1, 2p+1), wave row 1
+// between (2p, 2p+2).
+//   RAW (DMA -> ds_read): a region read in phase p'' was waited for (every wave, its own pieces) in phase p''-1,
+//     i.e. before barrier 2p''-2 / 2p''-1 <= the barrier that precedes the first read of phase p''.
+//   WAR (ds_read -> DMA): reads of phase p are complete (lgkmcnt(0)) before barrier 2p+1 (row 0) / 2p+2 (row 1);
+//     the refill is issued in phase p+2, after barrier 2p+3 / 2p+4.
+// DMA issue list (T = current K tile, tile index clamped at the end so the counts never change):
+//   phase 1: A rows [64,96) of T+1     phase 2: A rows [96,128) of T+1
+//   phase 3: W (all) and A rows [0,32) of T+2     phase 4: A rows [32,64) of T+2
+// = 1, 1, 5, 1 wave-instructions of 1 KiB; the waits are vmcnt(9), (9), (13), (9) (derivation in DESIGN.md).
+#include "common.cuh"
+#include "../../include/vlm_hip.h"
+
+namespace {
+
+constexpr int TB = 256;                 // tile edge (M and N)
+constexpr int BK = 64;
+constexpr int ROWB = BK * 2;            // bytes per LDS row
+constexpr int HALF = 128 * ROWB;        // one 128-row half tile: 16 KiB
+constexpr int STAGE = 4 * HALF;         // A0 A1 W0 W1: 64 KiB per K tile
+constexpr int C_LD = TB + 8;            // padded bf16 row of the epilogue tile
+constexpr int LDS_BYTES = TB * C_LD * 2;   // 135168 >= 2 * STAGE
+
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+#define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define BARRIER()                       \
+  do {                                  \
+    __builtin_amdgcn_sched_barrier(0);  \
+    __builtin_amdgcn_s_barrier();       \
+    __builtin_amdgcn_sched_barrier(0);  \
+  } while (0)
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                      const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                      bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldw,
+                                                      int ldc, int ldres, int tiles_n, int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // XCD-aware bijective remap: blocks with the same (bid % 8) share an L2.
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (bid / tiles_n) * TB, n0 = (bid % tiles_n) * TB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = uw >> 2, wc = uw & 3;          // wave row (M half) / wave column (64-wide N quarter)
+  const int nk = K / BK;
+
+  // ---- DMA sources: lane l of a 1 KiB piece covers row (l >> 3), k-slot (l & 7) ^ swizzle(row)
+  const int rl = lane >> 3, sp = lane & 7;
+  const bf16_t* wsrc[4];   // W pieces 4*uw .. 4*uw+3: half (uw >> 2), rows 8*((uw & 3)*4 + j) .. +8
+  const bf16_t* asrc[4];   // A quarter q: half (uw >> 2), rows 32*q + 8*(uw & 3) .. +8
+  int wdst[4], adst[4];    // LDS byte offsets inside a stage
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int prow = 8 * ((uw & 3) * 4 + j);                 // piece's first row inside its half
+    const int row = prow + rl;
+    wsrc[j] = W + (size_t)min(n0 + (uw >> 2) * 128 + row, N - 1) * ldw + ((sp ^ ((row >> 1) & 7)) << 3);
+    wdst[j] = 2 * HALF + (uw >> 2) * HALF + prow * ROWB;
+    const int arow0 = 32 * j + 8 * (uw & 3);
+    const int arow = arow0 + rl;
+    asrc[j] = A + (size_t)min(m0 + (uw >> 2) * 128 + arow, M - 1) * lda + ((sp ^ ((arow >> 1) & 7)) << 3);
+    adst[j] = (uw >> 2) * HALF + arow0 * ROWB;
+  }
+  auto dma = [&](const bf16_t* src, int kt, int lds_byte) {
+    const int ktc = min(kt, nk - 1);   // past the end: a harmless reload (keeps the vmcnt arithmetic uniform)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)ktc * BK),
+                                     (__attribute__((address_space(3))) void*)(smem + lds_byte), 16, 0, 0);
+  };
+  auto issue_w = [&](int kt) {
+    const int base = (kt & 1) * STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma(wsrc[j], kt, base + wdst[j]);
+  };
+  auto issue_a = [&](int kt, int q) { dma(asrc[q], kt, (kt & 1) * STAGE + adst[q]); };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: the issue order of the steady state (see header), then the wait of "phase 4 of tile -1"
+  issue_w(0); issue_a(0, 0); issue_a(0, 1); issue_a(0, 2); issue_a(0, 3);
+  issue_w(1); issue_a(1, 0); issue_a(1, 1);
+  VMCNT(9);
+  BARRIER();
+  if (wr == 1) BARRIER();   // the second wave row runs half a phase behind
+
+  bf16x8_t wf[4][2], af[2][2];
+  const int fr = lane & 15, fs = lane >> 4;
+  auto read_w = [&](int kt) {
+    const char* ws = smem + (kt & 1) * STAGE + 2 * HALF + (wc >> 1) * HALF;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        wf[n][ks] = *reinterpret_cast<const bf16x8_t*>(ws + lds_off((wc & 1) * 64 + n * 16 + fr, ks * 4 + fs));
+  };
+  auto read_a = [&](int kt, int q) {
+    const char* as = smem + (kt & 1) * STAGE + wr * HALF;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        af[m][ks] = *reinterpret_cast<const bf16x8_t*>(as + lds_off(q * 32 + m * 16 + fr, ks * 4 + fs));
+  };
+
+#define MFMA_PHASE(Q)                                                                                              \
+  do {                                                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+      _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                                \
+        _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                              \
+          acc[2 * (Q) + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n][ks], af[m][ks], acc[2 * (Q) + m][n], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                                 \
+  } while (0)
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // ---- phase 1
+    read_w(kt);
+    read_a(kt, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_a(kt + 1, 2);
+    VMCNT(9);
+    BARRIER();
+    LGKM0();
+    MFMA_PHASE(0);
+    BARRIER();
+    // ---- phase 2
+    read_a(kt, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_a(kt + 1, 3);
+    VMCNT(9);
+    BARRIER();
+    LGKM0();
+    MFMA_PHASE(1);
+    BARRIER();
+    // ---- phase 3
+    read_a(kt, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_w(kt + 2);
+    issue_a(kt + 2, 0);
+    VMCNT(13);
+    BARRIER();
+    LGKM0();
+    MFMA_PHASE(2);
+    BARRIER();
+    // ---- phase 4
+    read_a(kt, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_a(kt + 2, 1);
+    VMCNT(9);
+    BARRIER();
+    LGKM0();
+    MFMA_PHASE(3);
+    BARRIER();
+  }
+#undef MFMA_PHASE
+  if (wr == 0) BARRIER();   // barrier counts must match across the workgroup
+  VMCNT(0);                 // the clamped reloads past the last K tile still target LDS
+  BARRIER();
+
+  // ---- epilogue (as gemm_bf16.hip): lane holds D^T[n = nb + fs*4 + r][m = mb + fr]; bias / activation in registers
+  //      with the reference's rounding points, tile transposed through LDS, coalesced 16-byte stores (+ residual).
+  bf16_t* cs = reinterpret_cast<bf16_t*>(smem);
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int ml = wr * 128 + mi * 16 + fr;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int nl = wc * 64 + ni * 16 + fs * 4;
+      const int n = min(n0 + nl, N - 4);
+      float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+      if (EPI & VLM_EPI_BIAS) {
+        const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
+        v[0] += bf_lo(b.x); v[1] += bf_hi(b.x); v[2] += bf_lo(b.y); v[3] += bf_hi(b.y);
+      }
+      if (EPI & VLM_EPI_GELU_FAST) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_fast_(rbf(v[r]));
+      }
+      if (EPI & VLM_EPI_GELU_ERF) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_(rbf(v[r]));
+      }
+      uint2 o;
+      o.x = pack_bf2(v[0], v[1]);
+      o.y = pack_bf2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(cs + ml * C_LD + nl) = o;
+    }
+  }
+  __syncthreads();
+  constexpr int CPR = TB / 8;   // 16-byte chunks per tile row
+#pragma unroll 2
+  for (int c = tid; c < TB * CPR; c += 512) {
+    const int row = c / CPR, cc = c % CPR;
+    const int m = m0 + row, n = n0 + cc * 8;
+    if (m < M && n < N) {
+      uint4 u = *reinterpret_cast<const uint4*>(cs + row * C_LD + cc * 8);
+      if (EPI & VLM_EPI_RESIDUAL) {
+        const uint4 r = *reinterpret_cast<const uint4*>(res + (size_t)m * ldres + n);
+        u.x = pack_bf2(bf_lo(u.x) + bf_lo(r.x), bf_hi(u.x) + bf_hi(r.x));
+        u.y = pack_bf2(bf_lo(u.y) + bf_lo(r.y), bf_hi(u.y) + bf_hi(r.y));
+        u.z = pack_bf2(bf_lo(u.z) + bf_lo(r.z), bf_hi(u.z) + bf_hi(r.z));
+        u.w = pack_bf2(bf_lo(u.w) + bf_lo(r.w), bf_hi(u.w) + bf_hi(r.w));
+      }
+      *reinterpret_cast<uint4*>(C + (size_t)m * ldc + n) = u;
+    }
+  }
+}
+
+template <int EPI>
+int launch256(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
+              int ldw, int ldc, int ldres, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return VLM_ERR_HIP + (int)e;
+    attr_set = true;
+  }
+  const int tiles_m = vlm_cdiv(M, TB), tiles_n = vlm_cdiv(N, TB), nwg = tiles_m * tiles_n;
+  hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(nwg), dim3(512), LDS_BYTES, st, (const bf16_t*)A, (const bf16_t*)W,
+                     (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
+}
+
+}  // namespace
+
+// Internal entry (C++ linkage, called by vlm_gemm_bf16's dispatcher).  Returns -1 when the shape / epilogue is not
+// one this kernel takes (the caller then uses the 128x128 kernel).  Needs K % 64 == 0, K >= 128, N % 8 == 0.
+int vlm_gemm256_try(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
+                    int lda, int ldw, int ldc, int ldres, int epilogue, void* stream) {
+  if (K % BK != 0 || K < 2 * BK || N < 8) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  switch (epilogue) {
+    case VLM_EPI_NONE: return launch256<VLM_EPI_NONE>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
+    case VLM_EPI_BIAS: return launch256<VLM_EPI_BIAS>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
+    case VLM_EPI_BIAS | VLM_EPI_GELU_FAST:
+      return launch256<VLM_EPI_BIAS | VLM_EPI_GELU_FAST>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
+    case VLM_EPI_BIAS | VLM_EPI_GELU_ERF:
+      return launch256<VLM_EPI_BIAS | VLM_EPI_GELU_ERF>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
+    case VLM_EPI_BIAS | VLM_EPI_RESIDUAL:
+      return launch256<VLM_EPI_BIAS | VLM_EPI_RESIDUAL>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
+    case VLM_EPI_RESIDUAL: return launch256<VLM_EPI_RESIDUAL>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
+    default: return -1;   // SwiGLU pairs stay on the 128x128 kernel
+  }
+}

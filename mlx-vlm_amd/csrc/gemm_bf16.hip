@@ -21,9 +21,14 @@
 #include "common.cuh"
 #include "../../include/vlm_hip.h"
 
+// gemm256_bf16.hip: the 256x256 phased kernel (-1: shape / epilogue not taken)
+int vlm_gemm256_try(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
+                    int lda, int ldw, int ldc, int ldres, int epilogue, void* stream);
+
 namespace {
 
 bool g_force_regstage = false;   // test hook (vlm_gemm_set_staging): exercise the register-staged kernel
+int g_tile256 = 0;               // 0 = automatic, -1 = never use the 256x256 phased kernel, 1 = whenever it is legal
 
 constexpr int BK = 64;          // k elements per LDS tile
 constexpr int ROWB = BK * 2;    // bytes per tile row (128)
@@ -256,9 +261,12 @@ int launch_epi(const void* A, const void* W, const void* bias, const void* res, 
 
 }  // namespace
 
-// 0 = automatic (LDS DMA when K % 64 == 0), 1 = always stage through registers.  Test / A-B knob only.
+// 0 = automatic (LDS DMA when K % 64 == 0; 256x256 phased kernel for large shapes), 1 = always stage through
+// registers (128x128 kernel), 2 = LDS DMA but never the 256x256 kernel, 3 = 256x256 kernel whenever it is legal.
+// Test / A-B knob only.
 extern "C" int vlm_gemm_set_staging(int mode) {
   g_force_regstage = (mode == 1);
+  g_tile256 = mode == 3 ? 1 : (mode == 1 || mode == 2) ? -1 : 0;
   return VLM_OK;
 }
 
@@ -272,6 +280,18 @@ extern "C" int vlm_gemm_bf16(const void* A, const void* W, const void* bias, con
   if ((epilogue & VLM_EPI_SWIGLU) && N % 16 != 0) return VLM_ERR_SHAPE;
   if (M == 0) return VLM_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (A && W && C && M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 &&
+      (!(epilogue & VLM_EPI_RESIDUAL) || (res && ldres % 8 == 0)) && (!(epilogue & VLM_EPI_BIAS) || bias) && g_tile256 >= 0) {
+    // measured on MI355X (scripts/gemm_bench.py 2 3): the phased 256x256 kernel wins from ~120 tiles up (140 tiles:
+    // 566 vs 432 TF; 180: 838 vs 772; 540: 869 vs 828; 720: 1073-1087 vs 895-921 TF) and loses below (60 tiles:
+    // 326-421 vs 471-530 TF), where the 128x128 kernel spreads the work over more CUs.  (g_tile256 == 1: test hook.)
+    const long t256 = (long)vlm_cdiv(M, 256) * vlm_cdiv(N, 256);
+    const bool fills = t256 >= 120;
+    if (g_tile256 == 1 || fills) {
+      const int rc = vlm_gemm256_try(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, epilogue, stream);
+      if (rc >= 0) return rc;
+    }
+  }
 #define GO(E) return launch_epi<E>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st)
   switch (epilogue) {
     case VLM_EPI_NONE: GO(VLM_EPI_NONE);

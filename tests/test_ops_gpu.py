@@ -529,3 +529,47 @@ def test_attn_prefill_deferred_max_slow_ramp(vops, causal):
     out = vops.attn_prefill(qkv, qkv[:, H * D:], qkv[:, 2 * H * D:], cu, 5, H, H, D, D ** -0.5, causal)
     ok, rep = bf16_close(out.view(T, H, D), ref, ulps=2, atol_rms=2e-2)
     assert ok, rep
+
+
+# ------------------------------------------------------------------ 256x256 phased GEMM (gemm256_bf16.hip)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 1280), (300, 520, 192), (1000, 264, 64 * 5), (9216, 1280, 1280),
+                                   (777, 1536, 8960)])
+@pytest.mark.parametrize("epi", ["none", "bias", "bias_gelu_fast", "bias_res"])
+def test_gemm256_phased_kernel_is_bit_identical_to_128_kernel(vops, M, N, K, epi):
+    """Same fragments, same per-element accumulation order -> the phased 256x256 schedule must reproduce the 128x128
+    kernel bit for bit, including ragged M / N edges; repeated launches screen for LDS-DMA ordering races."""
+    a, w = rnd(M, K, seed=110).cuda(), rnd(N, K, seed=111, scale=0.05).cuda()
+    b, r = rnd(N, seed=112).cuda(), rnd(M, N, seed=113).cuda()
+    kw = {"none": dict(), "bias": dict(bias=b, epilogue=vops.EPI_BIAS),
+          "bias_gelu_fast": dict(bias=b, epilogue=vops.EPI_BIAS | vops.EPI_GELU_FAST),
+          "bias_res": dict(bias=b, res=r, epilogue=vops.EPI_BIAS | vops.EPI_RESIDUAL)}[epi]
+    try:
+        vops.gemm_set_staging(2)
+        ref = vops.gemm(a, w, **kw)
+        vops.gemm_set_staging(3)
+        for it in range(6):
+            out = vops.gemm(a, w, **kw)
+            assert torch.equal(out, ref), f"iteration {it}: {int((out != ref).sum())} elements differ"
+    finally:
+        vops.gemm_set_staging(0)
+
+
+def test_gemm256_under_memory_pressure_race_screen(vops):
+    """a concurrent copy stream perturbs DMA landing order; results must not change"""
+    M, N, K = 2048, 2048, 2048
+    a, w = rnd(M, K, seed=120).cuda(), rnd(N, K, seed=121, scale=0.05).cuda()
+    big = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+    dst = torch.empty_like(big)
+    try:
+        vops.gemm_set_staging(2)
+        ref = vops.gemm(a, w)
+        vops.gemm_set_staging(3)
+        side = torch.cuda.Stream()
+        for it in range(8):
+            with torch.cuda.stream(side):
+                dst.copy_(big, non_blocking=True)
+            out = vops.gemm(a, w)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), f"iteration {it}"
+    finally:
+        vops.gemm_set_staging(0)
