@@ -51,6 +51,59 @@ __device__ __forceinline__ int lds_off(int row, int slot) { return row * ROWB + 
   } while (0)
 
 template <int EPI>
+__device__ __forceinline__ void epilogue256(f32x4_t (&acc)[8][4], char* smem, const bf16_t* __restrict__ bias,
+                                            const bf16_t* __restrict__ res, bf16_t* __restrict__ C, int M, int N, int ldc,
+                                            int ldres, int m0, int n0, int wr, int wc, int fr, int fs, int tid) {
+  // ---- epilogue (as gemm_bf16.hip): lane holds D^T[n = nb + fs*4 + r][m = mb + fr]; bias / activation in registers
+  //      with the reference's rounding points, tile transposed through LDS, coalesced 16-byte stores (+ residual).
+  bf16_t* cs = reinterpret_cast<bf16_t*>(smem);
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int ml = wr * 128 + mi * 16 + fr;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int nl = wc * 64 + ni * 16 + fs * 4;
+      const int n = min(n0 + nl, N - 4);
+      float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+      if (EPI & VLM_EPI_BIAS) {
+        const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
+        v[0] += bf_lo(b.x); v[1] += bf_hi(b.x); v[2] += bf_lo(b.y); v[3] += bf_hi(b.y);
+      }
+      if (EPI & VLM_EPI_GELU_FAST) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_fast_(rbf(v[r]));
+      }
+      if (EPI & VLM_EPI_GELU_ERF) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_(rbf(v[r]));
+      }
+      uint2 o;
+      o.x = pack_bf2(v[0], v[1]);
+      o.y = pack_bf2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(cs + ml * C_LD + nl) = o;
+    }
+  }
+  __syncthreads();
+  constexpr int CPR = TB / 8;   // 16-byte chunks per tile row
+#pragma unroll 2
+  for (int c = tid; c < TB * CPR; c += 512) {
+    const int row = c / CPR, cc = c % CPR;
+    const int m = m0 + row, n = n0 + cc * 8;
+    if (m < M && n < N) {
+      uint4 u = *reinterpret_cast<const uint4*>(cs + row * C_LD + cc * 8);
+      if (EPI & VLM_EPI_RESIDUAL) {
+        const uint4 r = *reinterpret_cast<const uint4*>(res + (size_t)m * ldres + n);
+        u.x = pack_bf2(bf_lo(u.x) + bf_lo(r.x), bf_hi(u.x) + bf_hi(r.x));
+        u.y = pack_bf2(bf_lo(u.y) + bf_lo(r.y), bf_hi(u.y) + bf_hi(r.y));
+        u.z = pack_bf2(bf_lo(u.z) + bf_lo(r.z), bf_hi(u.z) + bf_hi(r.z));
+        u.w = pack_bf2(bf_lo(u.w) + bf_lo(r.w), bf_hi(u.w) + bf_hi(r.w));
+      }
+      *reinterpret_cast<uint4*>(C + (size_t)m * ldc + n) = u;
+    }
+  }
+}
+
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                       const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
                                                       bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldw,
@@ -183,54 +236,147 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
   VMCNT(0);                 // the clamped reloads past the last K tile still target LDS
   BARRIER();
 
-  // ---- epilogue (as gemm_bf16.hip): lane holds D^T[n = nb + fs*4 + r][m = mb + fr]; bias / activation in registers
-  //      with the reference's rounding points, tile transposed through LDS, coalesced 16-byte stores (+ residual).
-  bf16_t* cs = reinterpret_cast<bf16_t*>(smem);
-#pragma unroll
-  for (int mi = 0; mi < 8; ++mi) {
-    const int ml = wr * 128 + mi * 16 + fr;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int nl = wc * 64 + ni * 16 + fs * 4;
-      const int n = min(n0 + nl, N - 4);
-      float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-      if (EPI & VLM_EPI_BIAS) {
-        const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
-        v[0] += bf_lo(b.x); v[1] += bf_hi(b.x); v[2] += bf_lo(b.y); v[3] += bf_hi(b.y);
-      }
-      if (EPI & VLM_EPI_GELU_FAST) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_fast_(rbf(v[r]));
-      }
-      if (EPI & VLM_EPI_GELU_ERF) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_(rbf(v[r]));
-      }
-      uint2 o;
-      o.x = pack_bf2(v[0], v[1]);
-      o.y = pack_bf2(v[2], v[3]);
-      *reinterpret_cast<uint2*>(cs + ml * C_LD + nl) = o;
-    }
-  }
-  __syncthreads();
-  constexpr int CPR = TB / 8;   // 16-byte chunks per tile row
-#pragma unroll 2
-  for (int c = tid; c < TB * CPR; c += 512) {
-    const int row = c / CPR, cc = c % CPR;
-    const int m = m0 + row, n = n0 + cc * 8;
-    if (m < M && n < N) {
-      uint4 u = *reinterpret_cast<const uint4*>(cs + row * C_LD + cc * 8);
-      if (EPI & VLM_EPI_RESIDUAL) {
-        const uint4 r = *reinterpret_cast<const uint4*>(res + (size_t)m * ldres + n);
-        u.x = pack_bf2(bf_lo(u.x) + bf_lo(r.x), bf_hi(u.x) + bf_hi(r.x));
-        u.y = pack_bf2(bf_lo(u.y) + bf_lo(r.y), bf_hi(u.y) + bf_hi(r.y));
-        u.z = pack_bf2(bf_lo(u.z) + bf_lo(r.z), bf_hi(u.z) + bf_hi(r.z));
-        u.w = pack_bf2(bf_lo(u.w) + bf_lo(r.w), bf_hi(u.w) + bf_hi(r.w));
-      }
-      *reinterpret_cast<uint4*>(C + (size_t)m * ldc + n) = u;
-    }
-  }
+  epilogue256<EPI>(acc, smem, bias, res, C, M, N, ldc, ldres, m0, n0, wr, wc, fr, fs, tid);
 }
+
+// ---- variant B: the same tile and fragments, TWO phases of 32 MFMAs per K tile (half the barriers per MFMA).
+// With only two phases a region cannot wait two phases for its refill and still arrive in time, so ALL DMA is issued
+// by the wave row that runs half a phase behind (row 1): its issue point in phase p+1 lies after barrier 2p+2, by
+// which every wave's reads of phase p are complete - a refill ONE phase after the last read is safe from there.
+//   phase 1 (T): read W(T) + A rows [0,64);  row 1 issues A rows [64,128) of T+1 (4 x 1 KiB per wave)
+//   phase 2 (T): read A rows [64,128);       row 1 issues W(T+2) and A rows [0,64) of T+2 (8 + 4 per wave)
+// Every piece is waited for one phase before it is read; 16 newer pieces are outstanding then -> vmcnt(16) always.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256b_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                       const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                       bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldw,
+                                                       int ldc, int ldres, int tiles_n, int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (bid / tiles_n) * TB, n0 = (bid % tiles_n) * TB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = uw >> 2, wc = uw & 3;
+  const int nk = K / BK;
+  const int g = uw & 3;                          // DMA issuer index among the row-1 waves
+  const int rl = lane >> 3, sp = lane & 7;
+
+  // piece tables of issuer g: W pieces 8g..8g+7 (half g>>1, rows 8*((g&1)*8 + j)); A_lo / A_hi pieces 4g..4g+3
+  // (half g>>1, rows 8*((g&1)*4 + j) (+64))
+  const bf16_t* wsrc[8];
+  const bf16_t* alsrc[4];
+  const bf16_t* ahsrc[4];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int row = 8 * ((g & 1) * 8 + j) + rl;
+    wsrc[j] = W + (size_t)min(n0 + (g >> 1) * 128 + row, N - 1) * ldw + ((sp ^ ((row >> 1) & 7)) << 3);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 8 * ((g & 1) * 4 + j) + rl;
+    alsrc[j] = A + (size_t)min(m0 + (g >> 1) * 128 + row, M - 1) * lda + ((sp ^ ((row >> 1) & 7)) << 3);
+    const int rowh = row + 64;
+    ahsrc[j] = A + (size_t)min(m0 + (g >> 1) * 128 + rowh, M - 1) * lda + ((sp ^ ((rowh >> 1) & 7)) << 3);
+  }
+  auto dma = [&](const bf16_t* src, int kt, int lds_byte) {
+    const int ktc = min(kt, nk - 1);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)ktc * BK),
+                                     (__attribute__((address_space(3))) void*)(smem + lds_byte), 16, 0, 0);
+  };
+  auto issue_w = [&](int kt) {
+    const int base = (kt & 1) * STAGE + 2 * HALF + (g >> 1) * HALF + (g & 1) * 8 * 8 * ROWB;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dma(wsrc[j], kt, base + j * 8 * ROWB);
+  };
+  auto issue_alo = [&](int kt) {
+    const int base = (kt & 1) * STAGE + (g >> 1) * HALF + (g & 1) * 4 * 8 * ROWB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma(alsrc[j], kt, base + j * 8 * ROWB);
+  };
+  auto issue_ahi = [&](int kt) {
+    const int base = (kt & 1) * STAGE + (g >> 1) * HALF + 64 * ROWB + (g & 1) * 4 * 8 * ROWB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma(ahsrc[j], kt, base + j * 8 * ROWB);
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  if (wr == 1) {   // prologue in steady-state issue order
+    issue_w(0); issue_alo(0); issue_ahi(0);
+    issue_w(1); issue_alo(1);
+  }
+  VMCNT(16);
+  BARRIER();
+  if (wr == 1) BARRIER();
+
+  bf16x8_t wf[4][2], af[4][2];
+  const int fr = lane & 15, fs = lane >> 4;
+  auto read_w = [&](int kt) {
+    const char* ws = smem + (kt & 1) * STAGE + 2 * HALF + (wc >> 1) * HALF;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        wf[n][ks] = *reinterpret_cast<const bf16x8_t*>(ws + lds_off((wc & 1) * 64 + n * 16 + fr, ks * 4 + fs));
+  };
+  auto read_a = [&](int kt, int hh) {
+    const char* as = smem + (kt & 1) * STAGE + wr * HALF;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        af[m][ks] = *reinterpret_cast<const bf16x8_t*>(as + lds_off(hh * 64 + m * 16 + fr, ks * 4 + fs));
+  };
+#define MFMA_PHASE_B(HH)                                                                                           \
+  do {                                                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+      _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                                \
+        _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                              \
+          acc[4 * (HH) + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n][ks], af[m][ks], acc[4 * (HH) + m][n], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                                 \
+  } while (0)
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // ---- phase 1
+    read_w(kt);
+    read_a(kt, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) issue_ahi(kt + 1);
+    VMCNT(16);
+    BARRIER();
+    LGKM0();
+    MFMA_PHASE_B(0);
+    BARRIER();
+    // ---- phase 2
+    read_a(kt, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) {
+      issue_w(kt + 2);
+      issue_alo(kt + 2);
+    }
+    VMCNT(16);
+    BARRIER();
+    LGKM0();
+    MFMA_PHASE_B(1);
+    BARRIER();
+  }
+#undef MFMA_PHASE_B
+  if (wr == 0) BARRIER();
+  VMCNT(0);
+  BARRIER();
+  epilogue256<EPI>(acc, smem, bias, res, C, M, N, ldc, ldres, m0, n0, wr, wc, fr, fs, tid);
+}
+
+int g_variant = 0;   // 0 = 4 phases of 16 MFMAs per K tile, 1 = 2 phases of 32 (vlm_gemm256_set_variant, A/B knob)
 
 template <int EPI>
 int launch256(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
@@ -239,10 +385,17 @@ int launch256(const void* A, const void* W, const void* bias, const void* res, v
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256b_kernel<EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return VLM_ERR_HIP + (int)e;
     attr_set = true;
   }
   const int tiles_m = vlm_cdiv(M, TB), tiles_n = vlm_cdiv(N, TB), nwg = tiles_m * tiles_n;
+  if (g_variant == 1)
+    hipLaunchKernelGGL((gemm256b_kernel<EPI>), dim3(nwg), dim3(512), LDS_BYTES, st, (const bf16_t*)A, (const bf16_t*)W,
+                       (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg);
+  else
   hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(nwg), dim3(512), LDS_BYTES, st, (const bf16_t*)A, (const bf16_t*)W,
                      (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg);
   hipError_t e = hipGetLastError();
@@ -250,6 +403,8 @@ int launch256(const void* A, const void* W, const void* bias, const void* res, v
 }
 
 }  // namespace
+
+void vlm_gemm256_set_variant(int v) { g_variant = v; }
 
 // Internal entry (C++ linkage, called by vlm_gemm_bf16's dispatcher).  Returns -1 when the shape / epilogue is not
 // one this kernel takes (the caller then uses the 128x128 kernel).  Needs K % 64 == 0, K >= 128, N % 8 == 0.

@@ -25,6 +25,8 @@
 int vlm_gemm256_try(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
                     int lda, int ldw, int ldc, int ldres, int epilogue, void* stream);
 
+void vlm_gemm256_set_variant(int v);
+
 namespace {
 
 bool g_force_regstage = false;   // test hook (vlm_gemm_set_staging): exercise the register-staged kernel
@@ -263,10 +265,12 @@ int launch_epi(const void* A, const void* W, const void* bias, const void* res, 
 
 // 0 = automatic (LDS DMA when K % 64 == 0; 256x256 phased kernel for large shapes), 1 = always stage through
 // registers (128x128 kernel), 2 = LDS DMA but never the 256x256 kernel, 3 = 256x256 kernel whenever it is legal.
+// 4 = as 3 with the 2-phase variant of the 256x256 kernel, 5 = automatic with the 2-phase variant.
 // Test / A-B knob only.
 extern "C" int vlm_gemm_set_staging(int mode) {
   g_force_regstage = (mode == 1);
-  g_tile256 = mode == 3 ? 1 : (mode == 1 || mode == 2) ? -1 : 0;
+  g_tile256 = (mode == 3 || mode == 4) ? 1 : (mode == 1 || mode == 2) ? -1 : 0;
+  vlm_gemm256_set_variant((mode == 4 || mode == 5) ? 1 : 0);
   return VLM_OK;
 }
 

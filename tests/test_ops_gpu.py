@@ -535,7 +535,8 @@ def test_attn_prefill_deferred_max_slow_ramp(vops, causal):
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 1280), (300, 520, 192), (1000, 264, 64 * 5), (9216, 1280, 1280),
                                    (777, 1536, 8960)])
 @pytest.mark.parametrize("epi", ["none", "bias", "bias_gelu_fast", "bias_res"])
-def test_gemm256_phased_kernel_is_bit_identical_to_128_kernel(vops, M, N, K, epi):
+@pytest.mark.parametrize("variant", [3, 4])
+def test_gemm256_phased_kernel_is_bit_identical_to_128_kernel(vops, M, N, K, epi, variant):
     """Same fragments, same per-element accumulation order -> the phased 256x256 schedule must reproduce the 128x128
     kernel bit for bit, including ragged M / N edges; repeated launches screen for LDS-DMA ordering races."""
     a, w = rnd(M, K, seed=110).cuda(), rnd(N, K, seed=111, scale=0.05).cuda()
@@ -546,7 +547,7 @@ def test_gemm256_phased_kernel_is_bit_identical_to_128_kernel(vops, M, N, K, epi
     try:
         vops.gemm_set_staging(2)
         ref = vops.gemm(a, w, **kw)
-        vops.gemm_set_staging(3)
+        vops.gemm_set_staging(variant)     # 3: four phases of 16 MFMAs per K tile, 4: two phases of 32
         for it in range(6):
             out = vops.gemm(a, w, **kw)
             assert torch.equal(out, ref), f"iteration {it}: {int((out != ref).sum())} elements differ"
@@ -554,7 +555,8 @@ def test_gemm256_phased_kernel_is_bit_identical_to_128_kernel(vops, M, N, K, epi
         vops.gemm_set_staging(0)
 
 
-def test_gemm256_under_memory_pressure_race_screen(vops):
+@pytest.mark.parametrize("variant", [3, 4])
+def test_gemm256_under_memory_pressure_race_screen(vops, variant):
     """a concurrent copy stream perturbs DMA landing order; results must not change"""
     M, N, K = 2048, 2048, 2048
     a, w = rnd(M, K, seed=120).cuda(), rnd(N, K, seed=121, scale=0.05).cuda()
@@ -563,7 +565,7 @@ def test_gemm256_under_memory_pressure_race_screen(vops):
     try:
         vops.gemm_set_staging(2)
         ref = vops.gemm(a, w)
-        vops.gemm_set_staging(3)
+        vops.gemm_set_staging(variant)
         side = torch.cuda.Stream()
         for it in range(8):
             with torch.cuda.stream(side):
