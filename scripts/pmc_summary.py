@@ -3,7 +3,9 @@
 
 hbm_bytes = (k * FETCH_SIZE + WRITE_SIZE) * 1024 with k = 2: on gfx950 this rocprofv3 reports exactly half the
 bytes of a wide coalesced streaming read in FETCH_SIZE (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported.
-usage: pmc_summary.py <db> [out.json]"""
+FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950 ("exceeds the capabilities of the hardware"), so they come
+from two runs of the same command; pass both databases.
+usage: pmc_summary.py <out.json> <db> [<db> ...]"""
 import json
 import re
 import sqlite3
@@ -16,14 +18,15 @@ def short(n):
     return re.sub(r"\(.*", "", n).replace("void ", "").strip()
 
 
-def main(db, out=None):
-    con = sqlite3.connect(db)
-    rows = con.execute("select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection "
-                       "group by kernel_name, counter_name").fetchall()
+def main(out, *dbs):
     res = {}
-    for name, ctr, n, avg, tot in rows:
-        d = res.setdefault(short(name), {"launches": n})
-        d[ctr] = avg
+    for db in dbs:
+        con = sqlite3.connect(db)
+        rows = con.execute("select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection "
+                           "group by kernel_name, counter_name").fetchall()
+        for name, ctr, n, avg, tot in rows:
+            d = res.setdefault(short(name), {"launches": n})
+            d[ctr] = avg
     for k, d in res.items():
         f, w = d.get("FETCH_SIZE"), d.get("WRITE_SIZE")
         if f is not None and w is not None:
@@ -37,4 +40,4 @@ def main(db, out=None):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:3])
+    main(*sys.argv[1:])
