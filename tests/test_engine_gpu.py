@@ -304,3 +304,39 @@ def test_paged_and_identity_kv_layouts_generate_the_same_tokens(B):
     assert outs[0][0] == outs[1][0]
     if outs[0][1] is not None:
         assert torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("dims", ["2B", "7B"])
+def test_real_width_two_layer_model_vs_oracle(dims):
+    """Qwen2-VL-2B / -7B layer WIDTHS (hidden 1536 / 3584, GQA 12:2 / 28:4, inter 8960 / 18944, untied head for 7B,
+    full-width ViT blocks with 16 heads of 80) at depth 2 and a small vocabulary: the shapes the kernels are tuned
+    for (row-wave and split-K GEMVs, G = 6 / 7 decode attention, 256x256 GEMM on the ViT) against the oracle."""
+    from mlx_vlm_amd.generate import generate_step
+
+    if dims == "2B":
+        text = oq.TextCfg(hidden_size=1536, num_hidden_layers=2, intermediate_size=8960, num_attention_heads=12,
+                          num_key_value_heads=2, vocab_size=2048, tie_word_embeddings=True)
+        hid = 1536
+    else:
+        text = oq.TextCfg(hidden_size=3584, num_hidden_layers=2, intermediate_size=18944, num_attention_heads=28,
+                          num_key_value_heads=4, vocab_size=2048, tie_word_embeddings=False)
+        hid = 3584
+    cfg = oq.Cfg(text=text, vision=oq.VisionCfg(depth=2, embed_dim=1280, hidden_size=hid, num_heads=16),
+                 image_token_id=2001, video_token_id=2002, vision_start_token_id=2003)
+    W = oq.random_weights(cfg, seed=77, dtype=BF, std=0.02, embed_std=0.2)
+    model = build_product_model(cfg, W, kv_pool_tokens=4096, max_seqs=4)
+    ids, pix, thw = synth_request(cfg, [(112, 168)], n_text=20, seed=5, text_hi=2000)
+    feats = model.vision_tower(torch.from_numpy(pix), thw)
+    ref_feats = oq.vision_tower(W, cfg, torch.from_numpy(pix).to(BF), thw)
+    assert _rel_rms_err(feats, ref_feats) < 2e-2
+    n_new = 12
+    ref_toks, ref_logits = oq.generate_greedy(W, cfg, ids, torch.from_numpy(pix).to(BF), thw, max_tokens=n_new,
+                                              return_logits=True)
+    toks, lps = [], []
+    for t, lp in generate_step(ids, model, torch.from_numpy(pix), None, max_tokens=n_new, temperature=0.0, image_grid_thw=thw):
+        toks.append(t)
+        lps.append(lp.float().cpu())
+    ok, n, margin = _tie_aware_equal(toks, ref_toks, ref_logits, tol=3e-2)
+    assert ok, (toks, ref_toks, n, margin)
+    ok, rep = bf16_close(lps[0], O.logprobs_from_logits(ref_logits[0][None])[0], ulps=2, atol_rms=3e-2)
+    assert ok, rep
