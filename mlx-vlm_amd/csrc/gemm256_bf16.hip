@@ -38,6 +38,7 @@ constexpr int HALF = 128 * ROWB;        // one 128-row half tile: 16 KiB
 constexpr int STAGE = 4 * HALF;         // A0 A1 W0 W1: 64 KiB per K tile
 constexpr int C_LD = TB + 8;            // padded bf16 row of the epilogue tile
 constexpr int LDS_BYTES = TB * C_LD * 2;   // 135168 >= 2 * STAGE
+constexpr int GROUP_M = 4;              // tile rows per group of the in-XCD tile order
 
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
 
@@ -103,7 +104,9 @@ __device__ __forceinline__ void epilogue256(f32x4_t (&acc)[8][4], char* smem, co
   }
 }
 
-template <int EPI>
+// ABL (ablation builds, scripts/gemm_bench.py): 1 = no DMA in the K loop, 2 = no ds_reads in the K loop,
+// 3 = no barriers in the K loop - WRONG results, timing probes only.
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                       const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
                                                       bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldw,
@@ -115,7 +118,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int m0 = (bid / tiles_n) * TB, n0 = (bid % tiles_n) * TB;
+  // grouped order inside the XCD's range: the ~32 tiles an XCD runs at once form a GROUP_M x 8 block (4 A row-blocks
+  // + 8 W row-blocks through its L2) instead of 1 x 32 (1 + 32): measured 1160 -> see DESIGN.md at 8192^3
+  int pid_m, pid_n;
+  {
+    const int tiles_m = nwg / tiles_n, per_group = GROUP_M * tiles_n, gid = bid / per_group;
+    const int first_m = gid * GROUP_M, gsz = min(tiles_m - first_m, GROUP_M), r = bid - gid * per_group;
+    pid_m = first_m + r % gsz;
+    pid_n = r / gsz;
+  }
+  const int m0 = pid_m * TB, n0 = pid_n * TB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = uw >> 2, wc = uw & 3;          // wave row (M half) / wave column (64-wide N quarter)
@@ -138,6 +150,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
     adst[j] = (uw >> 2) * HALF + arow0 * ROWB;
   }
   auto dma = [&](const bf16_t* src, int kt, int lds_byte) {
+    if (ABL == 1 && kt >= 2) return;
     const int ktc = min(kt, nk - 1);   // past the end: a harmless reload (keeps the vmcnt arithmetic uniform)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)ktc * BK),
                                      (__attribute__((address_space(3))) void*)(smem + lds_byte), 16, 0, 0);
@@ -165,6 +178,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
   bf16x8_t wf[4][2], af[2][2];
   const int fr = lane & 15, fs = lane >> 4;
   auto read_w = [&](int kt) {
+    if (ABL == 2 && kt >= 1) return;
     const char* ws = smem + (kt & 1) * STAGE + 2 * HALF + (wc >> 1) * HALF;
 #pragma unroll
     for (int n = 0; n < 4; ++n)
@@ -173,6 +187,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
         wf[n][ks] = *reinterpret_cast<const bf16x8_t*>(ws + lds_off((wc & 1) * 64 + n * 16 + fr, ks * 4 + fs));
   };
   auto read_a = [&](int kt, int q) {
+    if (ABL == 2 && kt >= 1) return;
     const char* as = smem + (kt & 1) * STAGE + wr * HALF;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -181,6 +196,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
         af[m][ks] = *reinterpret_cast<const bf16x8_t*>(as + lds_off(q * 32 + m * 16 + fr, ks * 4 + fs));
   };
 
+#define LOOPBAR()            \
+  do {                       \
+    if (ABL != 3) BARRIER(); \
+  } while (0)
 #define MFMA_PHASE(Q)                                                                                              \
   do {                                                                                                             \
     __builtin_amdgcn_s_setprio(1);                                                                                 \
@@ -198,40 +217,41 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
     __builtin_amdgcn_sched_barrier(0);
     issue_a(kt + 1, 2);
     VMCNT(9);
-    BARRIER();
+    LOOPBAR();
     LGKM0();
     MFMA_PHASE(0);
-    BARRIER();
+    LOOPBAR();
     // ---- phase 2
     read_a(kt, 1);
     __builtin_amdgcn_sched_barrier(0);
     issue_a(kt + 1, 3);
     VMCNT(9);
-    BARRIER();
+    LOOPBAR();
     LGKM0();
     MFMA_PHASE(1);
-    BARRIER();
+    LOOPBAR();
     // ---- phase 3
     read_a(kt, 2);
     __builtin_amdgcn_sched_barrier(0);
     issue_w(kt + 2);
     issue_a(kt + 2, 0);
     VMCNT(13);
-    BARRIER();
+    LOOPBAR();
     LGKM0();
     MFMA_PHASE(2);
-    BARRIER();
+    LOOPBAR();
     // ---- phase 4
     read_a(kt, 3);
     __builtin_amdgcn_sched_barrier(0);
     issue_a(kt + 2, 1);
     VMCNT(9);
-    BARRIER();
+    LOOPBAR();
     LGKM0();
     MFMA_PHASE(3);
-    BARRIER();
+    LOOPBAR();
   }
 #undef MFMA_PHASE
+#undef LOOPBAR
   if (wr == 0) BARRIER();   // barrier counts must match across the workgroup
   VMCNT(0);                 // the clamped reloads past the last K tile still target LDS
   BARRIER();
@@ -257,7 +277,14 @@ __global__ __launch_bounds__(512) void gemm256b_kernel(const bf16_t* __restrict_
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int m0 = (bid / tiles_n) * TB, n0 = (bid % tiles_n) * TB;
+  int pid_m, pid_n;
+  {
+    const int tiles_m = nwg / tiles_n, per_group = GROUP_M * tiles_n, gid = bid / per_group;
+    const int first_m = gid * GROUP_M, gsz = min(tiles_m - first_m, GROUP_M), r = bid - gid * per_group;
+    pid_m = first_m + r % gsz;
+    pid_n = r / gsz;
+  }
+  const int m0 = pid_m * TB, n0 = pid_n * TB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = uw >> 2, wc = uw & 3;
@@ -392,7 +419,23 @@ int launch256(const void* A, const void* W, const void* bias, const void* res, v
     attr_set = true;
   }
   const int tiles_m = vlm_cdiv(M, TB), tiles_n = vlm_cdiv(N, TB), nwg = tiles_m * tiles_n;
-  if (g_variant == 1)
+  if (g_variant >= 11 && g_variant <= 13 && EPI == VLM_EPI_NONE) {
+    static bool abl_attr = false;
+    if (!abl_attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<VLM_EPI_NONE, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<VLM_EPI_NONE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<VLM_EPI_NONE, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      abl_attr = true;
+    }
+#define ABL_GO(V)                                                                                                         \
+  hipLaunchKernelGGL((gemm256_kernel<VLM_EPI_NONE, V>), dim3(nwg), dim3(512), LDS_BYTES, st, (const bf16_t*)A,            \
+                     (const bf16_t*)W, (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, \
+                     tiles_n, nwg)
+    if (g_variant == 11) ABL_GO(1);
+    else if (g_variant == 12) ABL_GO(2);
+    else ABL_GO(3);
+#undef ABL_GO
+  } else if (g_variant == 1)
     hipLaunchKernelGGL((gemm256b_kernel<EPI>), dim3(nwg), dim3(512), LDS_BYTES, st, (const bf16_t*)A, (const bf16_t*)W,
                        (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg);
   else

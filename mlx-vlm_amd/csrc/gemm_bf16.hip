@@ -56,7 +56,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  // grouped order inside the XCD's range: the tiles an XCD runs at once (~64: 2 workgroups per CU) form an 8 x 8
+  // block - 8 A row-blocks + 8 W row-blocks through its L2 instead of 1-2 + 64
+  int pid_m, pid_n;
+  {
+    constexpr int GROUP_M = 8;
+    const int tiles_m = nwg / tiles_n, per_group = GROUP_M * tiles_n, gid = bid / per_group;
+    const int first_m = gid * GROUP_M, gsz = min(tiles_m - first_m, GROUP_M), r = bid - gid * per_group;
+    pid_m = first_m + r % gsz;
+    pid_n = r / gsz;
+  }
+  const int m0 = pid_m * BM, n0 = pid_n * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
@@ -270,7 +280,8 @@ int launch_epi(const void* A, const void* W, const void* bias, const void* res, 
 extern "C" int vlm_gemm_set_staging(int mode) {
   g_force_regstage = (mode == 1);
   g_tile256 = (mode == 3 || mode == 4) ? 1 : (mode == 1 || mode == 2) ? -1 : 0;
-  vlm_gemm256_set_variant((mode == 4 || mode == 5) ? 1 : 0);
+  vlm_gemm256_set_variant((mode == 4 || mode == 5) ? 1 : (mode >= 11 && mode <= 13) ? mode : 0);   // 11-13: ablation probes
+  if (mode >= 11 && mode <= 13) g_tile256 = 1;
   return VLM_OK;
 }
 
