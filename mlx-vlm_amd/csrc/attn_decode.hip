@@ -268,8 +268,12 @@ extern "C" int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, 
   const float sl2 = scale * 1.44269504088896340736f;
   dim3 grid(B * Hkv, nsplit);
   bf16_t* direct = nsplit == 1 ? (bf16_t*)out : nullptr;
+#ifdef VLM_ATTN_TIMELINE   // debug build only (-DVLM_ATTN_TIMELINE): wave timeline stamps overwrite part_o
   static const bool stamps_env = getenv("VLM_ATTN_STAMPS") != nullptr;
-  const bool stamps = stamps_env && part_o != nullptr && block_table != nullptr;   // debug timeline
+  const bool stamps = stamps_env && part_o != nullptr && block_table != nullptr;
+#else
+  const bool stamps = false;
+#endif   // debug timeline
 #define GO(GV)                                                                                                          \
   if (stamps)                                                                                                           \
     hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, 8, true, false>), grid, dim3(8 * 64), 0, st, \

@@ -419,6 +419,7 @@ int launch256(const void* A, const void* W, const void* bias, const void* res, v
     attr_set = true;
   }
   const int tiles_m = vlm_cdiv(M, TB), tiles_n = vlm_cdiv(N, TB), nwg = tiles_m * tiles_n;
+#ifdef VLM_GEMM_ABLATION   // timing probes with WRONG results: never in the shipped library (build with -DVLM_GEMM_ABLATION)
   if (g_variant >= 11 && g_variant <= 13 && EPI == VLM_EPI_NONE) {
     static bool abl_attr = false;
     if (!abl_attr) {
@@ -435,7 +436,9 @@ int launch256(const void* A, const void* W, const void* bias, const void* res, v
     else if (g_variant == 12) ABL_GO(2);
     else ABL_GO(3);
 #undef ABL_GO
-  } else if (g_variant == 1)
+  } else
+#endif
+  if (g_variant == 1)
     hipLaunchKernelGGL((gemm256b_kernel<EPI>), dim3(nwg), dim3(512), LDS_BYTES, st, (const bf16_t*)A, (const bf16_t*)W,
                        (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg);
   else

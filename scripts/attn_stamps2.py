@@ -1,5 +1,5 @@
 import os, sys
-os.environ["VLM_ATTN_STAMPS"] = "1"
+os.environ["VLM_ATTN_STAMPS"] = "1"   # needs a library built with -DVLM_ATTN_TIMELINE (debug timeline stamps)
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mlx_vlm_amd import ops
