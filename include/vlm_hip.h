@@ -48,8 +48,10 @@ int vlm_abi_version(void);
 int vlm_gemm_bf16(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
                   int lda, int ldw, int ldc, int ldres, int epilogue, void* stream);
 
-/* test / A-B knob for vlm_gemm_bf16 tile staging: 0 = automatic (global_load_lds DMA when K % 64 == 0),
- * 1 = always global -> VGPR -> LDS.  Results are identical. */
+/* test / A-B knob for vlm_gemm_bf16 kernel selection: 0 = automatic (LDS-DMA staging when K % 64 == 0; the phased
+ * 256x256 kernel from ~120 tiles up), 1 = 128x128 kernel with global -> VGPR -> LDS staging, 2 = 128x128 kernel with
+ * LDS-DMA staging, 3 = 256x256 phased kernel whenever legal (K % 64 == 0, K >= 128, no SwiGLU), 4 = its 2-phase
+ * variant, 5 = automatic with the 2-phase variant.  Results are bit-identical in every mode. */
 int vlm_gemm_set_staging(int mode);
 
 /* y[M,N] = epi(x[M,K] . W[N,K]^T) for the decode step, M in {1,2,4,8}; weight streaming.
