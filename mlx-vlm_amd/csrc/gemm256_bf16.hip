@@ -51,19 +51,21 @@ __device__ __forceinline__ int lds_off(int row, int slot) { return row * ROWB + 
     __builtin_amdgcn_sched_barrier(0);  \
   } while (0)
 
-template <int EPI>
-__device__ __forceinline__ void epilogue256(f32x4_t (&acc)[8][4], char* smem, const bf16_t* __restrict__ bias,
+template <int EPI, int NF = 4>
+__device__ __forceinline__ void epilogue256(f32x4_t (&acc)[8][NF], char* smem, const bf16_t* __restrict__ bias,
                                             const bf16_t* __restrict__ res, bf16_t* __restrict__ C, int M, int N, int ldc,
                                             int ldres, int m0, int n0, int wr, int wc, int fr, int fs, int tid) {
   // ---- epilogue (as gemm_bf16.hip): lane holds D^T[n = nb + fs*4 + r][m = mb + fr]; bias / activation in registers
   //      with the reference's rounding points, tile transposed through LDS, coalesced 16-byte stores (+ residual).
+  constexpr int TN = 64 * NF;          // tile width: 256 or 192 columns
+  constexpr int C_LDN = TN + 8;
   bf16_t* cs = reinterpret_cast<bf16_t*>(smem);
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
     const int ml = wr * 128 + mi * 16 + fr;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int nl = wc * 64 + ni * 16 + fs * 4;
+    for (int ni = 0; ni < NF; ++ni) {
+      const int nl = wc * 16 * NF + ni * 16 + fs * 4;
       const int n = min(n0 + nl, N - 4);
       float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
       if (EPI & VLM_EPI_BIAS) {
@@ -81,17 +83,17 @@ __device__ __forceinline__ void epilogue256(f32x4_t (&acc)[8][4], char* smem, co
       uint2 o;
       o.x = pack_bf2(v[0], v[1]);
       o.y = pack_bf2(v[2], v[3]);
-      *reinterpret_cast<uint2*>(cs + ml * C_LD + nl) = o;
+      *reinterpret_cast<uint2*>(cs + ml * C_LDN + nl) = o;
     }
   }
   __syncthreads();
-  constexpr int CPR = TB / 8;   // 16-byte chunks per tile row
+  constexpr int CPR = TN / 8;   // 16-byte chunks per tile row
 #pragma unroll 2
   for (int c = tid; c < TB * CPR; c += 512) {
     const int row = c / CPR, cc = c % CPR;
     const int m = m0 + row, n = n0 + cc * 8;
     if (m < M && n < N) {
-      uint4 u = *reinterpret_cast<const uint4*>(cs + row * C_LD + cc * 8);
+      uint4 u = *reinterpret_cast<const uint4*>(cs + row * C_LDN + cc * 8);
       if (EPI & VLM_EPI_RESIDUAL) {
         const uint4 r = *reinterpret_cast<const uint4*>(res + (size_t)m * ldres + n);
         u.x = pack_bf2(bf_lo(u.x) + bf_lo(r.x), bf_hi(u.x) + bf_hi(r.x));
@@ -106,7 +108,10 @@ __device__ __forceinline__ void epilogue256(f32x4_t (&acc)[8][4], char* smem, co
 
 // ABL (ablation builds, scripts/gemm_bench.py): 1 = no DMA in the K loop, 2 = no ds_reads in the K loop,
 // 3 = no barriers in the K loop - WRONG results, timing probes only.
-template <int EPI, int ABL = 0>
+// NF = 16-column fragments per wave: 4 -> 256x256 tile, 3 -> 256x192 (used when it fills the last round of workgroups
+// better: N = 3840 of the ViT qkv projection gives 36 x 20 = 720 tiles = 2.8 rounds instead of 540 = 2.1).  W pieces per
+// wave and phase 3's issue count become NF and NF + 1, the counted waits NF + 5 / 2 NF + 5.
+template <int EPI, int ABL = 0, int NF = 4>
 __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                       const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
                                                       bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldw,
@@ -127,23 +132,27 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
     pid_m = first_m + r % gsz;
     pid_n = r / gsz;
   }
-  const int m0 = pid_m * TB, n0 = pid_n * TB;
+  constexpr int WH = 32 * NF;                   // rows of one W half tile (128 or 96)
+  const int m0 = pid_m * TB, n0 = pid_n * 64 * NF;
   const int tid = threadIdx.x, lane = tid & 63;
   const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = uw >> 2, wc = uw & 3;          // wave row (M half) / wave column (64-wide N quarter)
+  const int wr = uw >> 2, wc = uw & 3;          // wave row (M half) / wave column (16*NF-wide N quarter)
   const int nk = K / BK;
 
   // ---- DMA sources: lane l of a 1 KiB piece covers row (l >> 3), k-slot (l & 7) ^ swizzle(row)
   const int rl = lane >> 3, sp = lane & 7;
-  const bf16_t* wsrc[4];   // W pieces 4*uw .. 4*uw+3: half (uw >> 2), rows 8*((uw & 3)*4 + j) .. +8
+  const bf16_t* wsrc[NF];  // W pieces NF*uw .. NF*uw+NF-1: half (uw >> 2), rows 8*((uw & 3)*NF + j) .. +8
   const bf16_t* asrc[4];   // A quarter q: half (uw >> 2), rows 32*q + 8*(uw & 3) .. +8
-  int wdst[4], adst[4];    // LDS byte offsets inside a stage
+  int wdst[NF], adst[4];   // LDS byte offsets inside a stage
+#pragma unroll
+  for (int j = 0; j < NF; ++j) {
+    const int prow = 8 * ((uw & 3) * NF + j);                // piece's first row inside its half
+    const int row = prow + rl;
+    wsrc[j] = W + (size_t)min(n0 + (uw >> 2) * WH + row, N - 1) * ldw + ((sp ^ ((row >> 1) & 7)) << 3);
+    wdst[j] = 2 * HALF + (uw >> 2) * HALF + prow * ROWB;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int prow = 8 * ((uw & 3) * 4 + j);                 // piece's first row inside its half
-    const int row = prow + rl;
-    wsrc[j] = W + (size_t)min(n0 + (uw >> 2) * 128 + row, N - 1) * ldw + ((sp ^ ((row >> 1) & 7)) << 3);
-    wdst[j] = 2 * HALF + (uw >> 2) * HALF + prow * ROWB;
     const int arow0 = 32 * j + 8 * (uw & 3);
     const int arow = arow0 + rl;
     asrc[j] = A + (size_t)min(m0 + (uw >> 2) * 128 + arow, M - 1) * lda + ((sp ^ ((arow >> 1) & 7)) << 3);
@@ -158,33 +167,43 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
   auto issue_w = [&](int kt) {
     const int base = (kt & 1) * STAGE;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dma(wsrc[j], kt, base + wdst[j]);
+    for (int j = 0; j < NF; ++j) dma(wsrc[j], kt, base + wdst[j]);
   };
   auto issue_a = [&](int kt, int q) { dma(asrc[q], kt, (kt & 1) * STAGE + adst[q]); };
 
-  f32x4_t acc[8][4];
+  f32x4_t acc[8][NF];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NF; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+#define WAIT_A()              \
+  do {                        \
+    if (NF == 4) VMCNT(9);    \
+    else VMCNT(8);            \
+  } while (0)   /* NF + 5 */
+#define WAIT_B()              \
+  do {                        \
+    if (NF == 4) VMCNT(13);   \
+    else VMCNT(11);           \
+  } while (0)   /* 2 NF + 5 */
   // ---- prologue: the issue order of the steady state (see header), then the wait of "phase 4 of tile -1"
   issue_w(0); issue_a(0, 0); issue_a(0, 1); issue_a(0, 2); issue_a(0, 3);
   issue_w(1); issue_a(1, 0); issue_a(1, 1);
-  VMCNT(9);
+  WAIT_A();
   BARRIER();
   if (wr == 1) BARRIER();   // the second wave row runs half a phase behind
 
-  bf16x8_t wf[4][2], af[2][2];
+  bf16x8_t wf[NF][2], af[2][2];
   const int fr = lane & 15, fs = lane >> 4;
   auto read_w = [&](int kt) {
     if (ABL == 2 && kt >= 1) return;
     const char* ws = smem + (kt & 1) * STAGE + 2 * HALF + (wc >> 1) * HALF;
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+    for (int n = 0; n < NF; ++n)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
-        wf[n][ks] = *reinterpret_cast<const bf16x8_t*>(ws + lds_off((wc & 1) * 64 + n * 16 + fr, ks * 4 + fs));
+        wf[n][ks] = *reinterpret_cast<const bf16x8_t*>(ws + lds_off((wc & 1) * 16 * NF + n * 16 + fr, ks * 4 + fs));
   };
   auto read_a = [&](int kt, int q) {
     if (ABL == 2 && kt >= 1) return;
@@ -205,7 +224,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
     __builtin_amdgcn_s_setprio(1);                                                                                 \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
       _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                                \
-        _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                              \
+        _Pragma("unroll") for (int n = 0; n < NF; ++n)                                                             \
           acc[2 * (Q) + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n][ks], af[m][ks], acc[2 * (Q) + m][n], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                                 \
   } while (0)
@@ -216,7 +235,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
     read_a(kt, 0);
     __builtin_amdgcn_sched_barrier(0);
     issue_a(kt + 1, 2);
-    VMCNT(9);
+    WAIT_A();
     LOOPBAR();
     LGKM0();
     MFMA_PHASE(0);
@@ -225,7 +244,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
     read_a(kt, 1);
     __builtin_amdgcn_sched_barrier(0);
     issue_a(kt + 1, 3);
-    VMCNT(9);
+    WAIT_A();
     LOOPBAR();
     LGKM0();
     MFMA_PHASE(1);
@@ -235,7 +254,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
     __builtin_amdgcn_sched_barrier(0);
     issue_w(kt + 2);
     issue_a(kt + 2, 0);
-    VMCNT(13);
+    WAIT_B();
     LOOPBAR();
     LGKM0();
     MFMA_PHASE(2);
@@ -244,7 +263,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
     read_a(kt, 3);
     __builtin_amdgcn_sched_barrier(0);
     issue_a(kt + 2, 1);
-    VMCNT(9);
+    WAIT_A();
     LOOPBAR();
     LGKM0();
     MFMA_PHASE(3);
@@ -252,11 +271,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
   }
 #undef MFMA_PHASE
 #undef LOOPBAR
+#undef WAIT_A
+#undef WAIT_B
   if (wr == 0) BARRIER();   // barrier counts must match across the workgroup
   VMCNT(0);                 // the clamped reloads past the last K tile still target LDS
   BARRIER();
 
-  epilogue256<EPI>(acc, smem, bias, res, C, M, N, ldc, ldres, m0, n0, wr, wc, fr, fs, tid);
+  epilogue256<EPI, NF>(acc, smem, bias, res, C, M, N, ldc, ldres, m0, n0, wr, wc, fr, fs, tid);
 }
 
 // ---- variant B: the same tile and fragments, TWO phases of 32 MFMAs per K tile (half the barriers per MFMA).
@@ -404,21 +425,49 @@ __global__ __launch_bounds__(512) void gemm256b_kernel(const bf16_t* __restrict_
 }
 
 int g_variant = 0;   // 0 = 4 phases of 16 MFMAs per K tile, 1 = 2 phases of 32 (vlm_gemm256_set_variant, A/B knob)
+int g_nf = 0;        // 0 = pick the tile width (256 / 192) by last-round fill, 3 / 4 = forced (tests)
+
+template <int EPI, int NF>
+int launch256_nf(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
+                 int ldw, int ldc, int ldres, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, 0, NF>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return VLM_ERR_HIP + (int)e;
+    attr_set = true;
+  }
+  const int tiles_m = vlm_cdiv(M, TB), tiles_n = vlm_cdiv(N, 64 * NF), nwg = tiles_m * tiles_n;
+  hipLaunchKernelGGL((gemm256_kernel<EPI, 0, NF>), dim3(nwg), dim3(512), LDS_BYTES, st, (const bf16_t*)A, (const bf16_t*)W,
+                     (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
+}
+
+// fraction of the machine doing useful work: occupancy of the workgroup rounds (256 CUs, one workgroup each) x the
+// fraction of the tiles' columns that exist
+inline double tile_score(int M, int N, int tn) {
+  const long tiles = (long)vlm_cdiv(M, TB) * vlm_cdiv(N, tn), rounds = (tiles + 255) / 256;
+  return (double)tiles / (double)(rounds * 256) * ((double)N / ((double)vlm_cdiv(N, tn) * tn));
+}
 
 template <int EPI>
 int launch256(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
               int ldw, int ldc, int ldres, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256b_kernel<EPI>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return VLM_ERR_HIP + (int)e;
-    attr_set = true;
+  if (g_variant == 1) {
+    static bool attr_b = false;
+    if (!attr_b) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256b_kernel<EPI>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (e != hipSuccess) return VLM_ERR_HIP + (int)e;
+      attr_b = true;
+    }
+    const int tiles_m = vlm_cdiv(M, TB), tiles_n = vlm_cdiv(N, TB), nwg = tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm256b_kernel<EPI>), dim3(nwg), dim3(512), LDS_BYTES, st, (const bf16_t*)A, (const bf16_t*)W,
+                       (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
   }
-  const int tiles_m = vlm_cdiv(M, TB), tiles_n = vlm_cdiv(N, TB), nwg = tiles_m * tiles_n;
 #ifdef VLM_GEMM_ABLATION   // timing probes with WRONG results: never in the shipped library (build with -DVLM_GEMM_ABLATION)
   if (g_variant >= 11 && g_variant <= 13 && EPI == VLM_EPI_NONE) {
     static bool abl_attr = false;
@@ -428,6 +477,7 @@ int launch256(const void* A, const void* W, const void* bias, const void* res, v
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<VLM_EPI_NONE, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
       abl_attr = true;
     }
+    const int tiles_m = vlm_cdiv(M, TB), tiles_n = vlm_cdiv(N, TB), nwg = tiles_m * tiles_n;
 #define ABL_GO(V)                                                                                                         \
   hipLaunchKernelGGL((gemm256_kernel<VLM_EPI_NONE, V>), dim3(nwg), dim3(512), LDS_BYTES, st, (const bf16_t*)A,            \
                      (const bf16_t*)W, (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, \
@@ -436,21 +486,21 @@ int launch256(const void* A, const void* W, const void* bias, const void* res, v
     else if (g_variant == 12) ABL_GO(2);
     else ABL_GO(3);
 #undef ABL_GO
-  } else
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
+  }
 #endif
-  if (g_variant == 1)
-    hipLaunchKernelGGL((gemm256b_kernel<EPI>), dim3(nwg), dim3(512), LDS_BYTES, st, (const bf16_t*)A, (const bf16_t*)W,
-                       (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg);
-  else
-  hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(nwg), dim3(512), LDS_BYTES, st, (const bf16_t*)A, (const bf16_t*)W,
-                     (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg);
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
+  // 256x192 tiles when they keep more of the machine busy (ViT qkv: N = 3840 -> 720 tiles = 2.8 rounds instead of
+  // 540 = 2.1; N = 1280 -> 252 tiles = one full round instead of 180); 3 % handicap for the smaller tile
+  const bool nf3 = g_nf == 3 || (g_nf == 0 && 0.97 * tile_score(M, N, 192) > tile_score(M, N, 256));
+  return nf3 ? launch256_nf<EPI, 3>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st)
+             : launch256_nf<EPI, 4>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
 }
 
 }  // namespace
 
 void vlm_gemm256_set_variant(int v) { g_variant = v; }
+void vlm_gemm256_set_nf(int nf) { g_nf = nf; }
 
 // Internal entry (C++ linkage, called by vlm_gemm_bf16's dispatcher).  Returns -1 when the shape / epilogue is not
 // one this kernel takes (the caller then uses the 128x128 kernel).  Needs K % 64 == 0, K >= 128, N % 8 == 0.

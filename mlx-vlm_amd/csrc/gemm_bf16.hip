@@ -26,6 +26,7 @@ int vlm_gemm256_try(const void* A, const void* W, const void* bias, const void* 
                     int lda, int ldw, int ldc, int ldres, int epilogue, void* stream);
 
 void vlm_gemm256_set_variant(int v);
+void vlm_gemm256_set_nf(int nf);
 
 namespace {
 
@@ -275,11 +276,13 @@ int launch_epi(const void* A, const void* W, const void* bias, const void* res, 
 
 // 0 = automatic (LDS DMA when K % 64 == 0; 256x256 phased kernel for large shapes), 1 = always stage through
 // registers (128x128 kernel), 2 = LDS DMA but never the 256x256 kernel, 3 = 256x256 kernel whenever it is legal.
-// 4 = as 3 with the 2-phase variant of the 256x256 kernel, 5 = automatic with the 2-phase variant.
+// 4 = as 3 with the 2-phase variant of the 256x256 kernel, 5 = automatic with the 2-phase variant,
+// 6 / 7 = as 3 with the tile width forced to 192 / 256 (3 picks it by last-round fill).
 // Test / A-B knob only.
 extern "C" int vlm_gemm_set_staging(int mode) {
   g_force_regstage = (mode == 1);
-  g_tile256 = (mode == 3 || mode == 4) ? 1 : (mode == 1 || mode == 2) ? -1 : 0;
+  g_tile256 = (mode == 3 || mode == 4 || mode == 6 || mode == 7) ? 1 : (mode == 1 || mode == 2) ? -1 : 0;
+  vlm_gemm256_set_nf(mode == 6 ? 3 : mode == 7 ? 4 : 0);
   vlm_gemm256_set_variant((mode == 4 || mode == 5) ? 1 : 0);
 #ifdef VLM_GEMM_ABLATION
   if (mode >= 11 && mode <= 13) {   // ablation probes (wrong results; see gemm256_bf16.hip)

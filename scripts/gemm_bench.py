@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """GEMM micro-benchmark (HIP events): TFLOP/s of vlm_gemm_bf16 on the ViT / prefill shapes and 4096^3.
 usage: gemm_bench.py [staging modes ...]   (0 auto, 1 register-staged 128 kernel, 2 LDS-DMA 128 kernel, 3 256x256 phased,
-4 its 2-phase variant; 11-13 = ablation probes, only in a library built with -DVLM_GEMM_ABLATION)"""
+4 its 2-phase variant, 6 / 7 256x192 / 256x256 tiles forced; 11-13 = ablation probes, only in a library built with -DVLM_GEMM_ABLATION)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

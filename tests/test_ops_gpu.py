@@ -535,7 +535,7 @@ def test_attn_prefill_deferred_max_slow_ramp(vops, causal):
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 1280), (300, 520, 192), (1000, 264, 64 * 5), (9216, 1280, 1280),
                                    (777, 1536, 8960)])
 @pytest.mark.parametrize("epi", ["none", "bias", "bias_gelu_fast", "bias_res"])
-@pytest.mark.parametrize("variant", [3, 4])
+@pytest.mark.parametrize("variant", [4, 6, 7])
 def test_gemm256_phased_kernel_is_bit_identical_to_128_kernel(vops, M, N, K, epi, variant):
     """Same fragments, same per-element accumulation order -> the phased 256x256 schedule must reproduce the 128x128
     kernel bit for bit, including ragged M / N edges; repeated launches screen for LDS-DMA ordering races."""
@@ -547,7 +547,7 @@ def test_gemm256_phased_kernel_is_bit_identical_to_128_kernel(vops, M, N, K, epi
     try:
         vops.gemm_set_staging(2)
         ref = vops.gemm(a, w, **kw)
-        vops.gemm_set_staging(variant)     # 3: four phases of 16 MFMAs per K tile, 4: two phases of 32
+        vops.gemm_set_staging(variant)     # 4: two phases of 32 MFMAs; 6 / 7: four phases of 16, 256x192 / 256x256 tiles
         for it in range(6):
             out = vops.gemm(a, w, **kw)
             assert torch.equal(out, ref), f"iteration {it}: {int((out != ref).sum())} elements differ"
@@ -555,7 +555,7 @@ def test_gemm256_phased_kernel_is_bit_identical_to_128_kernel(vops, M, N, K, epi
         vops.gemm_set_staging(0)
 
 
-@pytest.mark.parametrize("variant", [3, 4])
+@pytest.mark.parametrize("variant", [4, 6, 7])
 def test_gemm256_under_memory_pressure_race_screen(vops, variant):
     """a concurrent copy stream perturbs DMA landing order; results must not change"""
     M, N, K = 2048, 2048, 2048
