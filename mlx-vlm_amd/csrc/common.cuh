@@ -72,9 +72,12 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
-// sigmoid on the hardware transcendental units (v_exp_f32 + v_rcp_f32, ~1-2 ulp): the GEMM epilogues apply it
-// to every output element, where the accurate expf + IEEE divide cost more than the bias/activation traffic
-__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// sigmoid on the hardware transcendental units: v_exp_f32 + v_rcp_f32 (~1 ulp each; the result is rounded to bf16
+// by the caller).  NOT __frcp_rn / 1.0f/x: those compile to the IEEE division sequence (v_div_scale, v_div_fmas,
+// v_div_fixup + 4 fma, found in the GEMM epilogue's .s) and made the bias+GELU epilogue cost a quarter of the tile.
+__device__ __forceinline__ float sigmoidf_(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
+}
 // The activations follow the reference's typed graph (pinned by running the reference's files over
 // oracle/mlx_shim, tests/test_oracle_ref_golden.py): every elementary MLX op rounds to bf16 and a python scalar is
 // converted to bf16 BEFORE the op (weak typing), so 1.702 is 1.703125 and sqrt(2) is 1.4140625 here.
