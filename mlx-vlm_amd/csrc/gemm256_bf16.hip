@@ -26,6 +26,8 @@
 //   phase 1: A rows [64,96) of T+1     phase 2: A rows [96,128) of T+1
 //   phase 3: W (all) and A rows [0,32) of T+2     phase 4: A rows [32,64) of T+2
 // = 1, 1, 5, 1 wave-instructions of 1 KiB; the waits are vmcnt(9), (9), (13), (9) (derivation in DESIGN.md).
+#include <stdlib.h>
+
 #include "common.cuh"
 #include "../../include/vlm_hip.h"
 
@@ -115,7 +117,7 @@ template <int EPI, int ABL = 0, int NF = 4>
 __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                       const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
                                                       bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldw,
-                                                      int ldc, int ldres, int tiles_n, int nwg) {
+                                                      int ldc, int ldres, int tiles_n, int nwg, int group_m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware bijective remap: blocks with the same (bid % 8) share an L2.
   int bid = blockIdx.x;
@@ -123,12 +125,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  // grouped order inside the XCD's range: the ~32 tiles an XCD runs at once form a GROUP_M x 8 block (4 A row-blocks
-  // + 8 W row-blocks through its L2) instead of 1 x 32 (1 + 32): measured 1160 -> see DESIGN.md at 8192^3
+  // grouped order inside the XCD's range: the ~32 tiles an XCD runs at once form a group_m x (32 / group_m) block
+  // (4 A row-blocks + 8 W row-blocks through its L2 instead of 1 + 32): 8192^3 1160 -> 1409 TF
   int pid_m, pid_n;
   {
-    const int tiles_m = nwg / tiles_n, per_group = GROUP_M * tiles_n, gid = bid / per_group;
-    const int first_m = gid * GROUP_M, gsz = min(tiles_m - first_m, GROUP_M), r = bid - gid * per_group;
+    const int tiles_m = nwg / tiles_n, per_group = group_m * tiles_n, gid = bid / per_group;
+    const int first_m = gid * group_m, gsz = min(tiles_m - first_m, group_m), r = bid - gid * per_group;
     pid_m = first_m + r % gsz;
     pid_n = r / gsz;
   }
@@ -438,8 +440,10 @@ int launch256_nf(const void* A, const void* W, const void* bias, const void* res
     attr_set = true;
   }
   const int tiles_m = vlm_cdiv(M, TB), tiles_n = vlm_cdiv(N, 64 * NF), nwg = tiles_m * tiles_n;
+  static const int group_m = getenv("VLM_GEMM_GROUP_M") ? atoi(getenv("VLM_GEMM_GROUP_M")) : GROUP_M;   // A/B knob
   hipLaunchKernelGGL((gemm256_kernel<EPI, 0, NF>), dim3(nwg), dim3(512), LDS_BYTES, st, (const bf16_t*)A, (const bf16_t*)W,
-                     (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg);
+                     (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg,
+                     group_m > 0 ? group_m : GROUP_M);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
 }
@@ -481,7 +485,7 @@ int launch256(const void* A, const void* W, const void* bias, const void* res, v
 #define ABL_GO(V)                                                                                                         \
   hipLaunchKernelGGL((gemm256_kernel<VLM_EPI_NONE, V>), dim3(nwg), dim3(512), LDS_BYTES, st, (const bf16_t*)A,            \
                      (const bf16_t*)W, (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, \
-                     tiles_n, nwg)
+                     tiles_n, nwg, GROUP_M)
     if (g_variant == 11) ABL_GO(1);
     else if (g_variant == 12) ABL_GO(2);
     else ABL_GO(3);

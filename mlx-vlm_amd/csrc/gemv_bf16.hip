@@ -115,6 +115,31 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
       nwv[c] = reinterpret_cast<const uint4*>(norm_w)[chc];
     }
   }
+  // PRO_ATTN fast path (<= 4 splits, MB <= 2): the split merge is one 8-element chunk of x per thread; its loads
+  // (m/l pairs + the partial O rows) are independent of everything, so they go out here, ahead of the weight stream
+  // - the merge then costs no extra memory round trip (the first version merged through LDS in three dependent
+  // phases and made this kernel 8 us slower than the plain o_proj)
+  constexpr int AT_IT = (PRO == PRO_ATTN && MB <= 2) ? MB : 1;     // chunks per thread: MB * K / 8 <= 256 * MB
+  const bool at_fast = PRO == PRO_ATTN && MB <= 2 && ap.S <= 4;
+  float4 at_o[AT_IT][4][2];
+  float2 at_ml[AT_IT][4];
+  if (PRO == PRO_ATTN && MB <= 2) {
+    if (at_fast) {
+#pragma unroll
+      for (int it = 0; it < AT_IT; ++it) {
+        const int item = min(tid + 256 * it, MB * nchunk - 1), m = item / nchunk, hd = (item % nchunk) * 8;
+        const size_t base = ((size_t)m * ap.Hq + hd / ap.D) * ap.S;
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+          const size_t e = base + min(sp, ap.S - 1);
+          at_ml[it][sp] = *reinterpret_cast<const float2*>(ap.part_ml + e * 2);
+          const float4* po = reinterpret_cast<const float4*>(ap.part_o + e * ap.D + hd % ap.D);
+          at_o[it][sp][0] = po[0];
+          at_o[it][sp][1] = po[1];
+        }
+      }
+    }
+  }
   // epilogue operands (bias / residual / rope position, slot, page) for the lane that will store
   // (raw values only - any arithmetic on them here would force a wait before the weight loads are issued)
   bf16_t e_b0 = 0, e_b1 = 0, e_r = 0;
@@ -194,9 +219,40 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
         if (writer && ch < nchunk) xs[ch] = o;
       }
     }
-  } else if (PRO == PRO_ATTN) {
+  } else if (PRO == PRO_ATTN && MB <= 2 && at_fast) {
     // x[m][h*D + d] = sum_s f_s O_s[d],  f_s = e^{m_s - M} / sum_t e^{m_t - M} l_t   (merge of the attention splits)
-    // three short phases so that every global load of a phase is independent (one memory round trip each):
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
+#pragma unroll
+    for (int it = 0; it < AT_IT; ++it) {
+      const int item = tid + 256 * it;
+      float mm = -INFINITY;
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) mm = fmaxf(mm, sp < ap.S ? at_ml[it][sp].x : -INFINITY);
+      float f[4], ll = 0.f;
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        f[sp] = (sp < ap.S && at_ml[it][sp].x != -INFINITY) ? __expf(at_ml[it][sp].x - mm) : 0.f;
+        ll += f[sp] * at_ml[it][sp].y;
+      }
+      const float il = 1.0f / ll;
+      float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        const float fs = f[sp] * il;
+        const float4 a = at_o[it][sp][0], b = at_o[it][sp][1];
+        acc8[0] += fs * a.x; acc8[1] += fs * a.y; acc8[2] += fs * a.z; acc8[3] += fs * a.w;
+        acc8[4] += fs * b.x; acc8[5] += fs * b.y; acc8[6] += fs * b.z; acc8[7] += fs * b.w;
+      }
+      if (item < MB * nchunk) {
+        uint4 o;
+        o.x = pack_bf2(acc8[0], acc8[1]); o.y = pack_bf2(acc8[2], acc8[3]);
+        o.z = pack_bf2(acc8[4], acc8[5]); o.w = pack_bf2(acc8[6], acc8[7]);
+        reinterpret_cast<uint4*>(xs)[item] = o;     // item = m * nchunk + chunk: xs is [MB][K]
+      }
+    }
+  } else if (PRO == PRO_ATTN) {
+    // general form (more splits / rows): three short phases so that every global load of a phase is independent
+    // (one memory round trip each)
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
     float* mls = reinterpret_cast<float*>(smem + (size_t)MB * K * 2);   // [MB*Hq][S][2] -> f in slot 0
     const int HD = ap.Hq * ap.D, nml = MB * ap.Hq * ap.S * 2;
