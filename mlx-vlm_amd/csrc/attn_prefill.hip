@@ -47,8 +47,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
   constexpr int VIT = (BKV / 2) * (D / 8); // (key pair, d-chunk) items in a V tile
   constexpr int V_PER = (VIT + 255) / 256;
 
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[BKV * K_LD];
-  __shared__ __attribute__((aligned(16))) bf16_t Vt[DP * VT_LD];
+  // double-buffered: tile t+1 is written while the other waves may still read tile t -> ONE barrier per tile
+  __shared__ __attribute__((aligned(16))) bf16_t Ks2[2][BKV * K_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t Vt2[2][DP * VT_LD];
 
   // ---- locate (segment, head, q block) ----
   int seg = 0, qb = 0, head = blockIdx.y;
@@ -111,7 +112,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
       rv1[i] = *reinterpret_cast<const u32x4_t*>(v1);
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int buf) {
+    bf16_t* Ks = Ks2[buf];
+    bf16_t* Vt = Vt2[buf];
 #pragma unroll
     for (int i = 0; i < K_PER; ++i) {
       const int c = tid + 256 * i;
@@ -145,16 +148,37 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
     for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  if (ntiles > 0) {
-    gload(0);
-    lstore();
-  }
+  if (ntiles > 0) gload(0);
+  // Q is loop-invariant but was produced by vector loads: hipcc's waitcnt insertion keeps "Q may still be in flight"
+  // alive around the loop back-edge and puts COUNTED vmcnt waits in front of the QK^T MFMAs of EVERY iteration -
+  // counted against the newest loads, i.e. the MFMAs wait for the next tile's global loads (the prefetch distance of
+  // one tile was really zero; found in the .s).  Drain once here and re-define Q through an empty asm.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[ks]));
+  if (ntiles > 0) lstore(0);
   __syncthreads();
 
+  // L2 prefetch two tiles ahead: one 4-byte load per thread touches the cache lines of tile t+2's K and V rows
+  // (row = tid / 4; lines at byte 0 / 128 of the K slice and of the V slice), so that the real 16-byte loads of the
+  // next iteration find them in L2 instead of paying the HBM latency with a prefetch distance of a single tile
+  // (register staging cannot run two tiles ahead: 28 more VGPRs do not exist here).  The value is only "used" to keep
+  // the load alive.
+  uint32_t pf_sink = 0;
+  const int pf_row = tid >> 2;
+  const bf16_t* pf_base = ((tid & 2) ? vbase : kbase) + (tid & 1) * 64;
   for (int t = 0; t < ntiles; ++t) {
     const bool more = (t + 1) < ntiles;
     if (more) gload(t + 1);
+    uint32_t pf_val = 0;
+    if (t + 2 < ntiles) {
+      const int r = min((t + 2) * BKV + pf_row, seg_len - 1);
+      pf_val = *reinterpret_cast<const uint32_t*>(pf_base + (size_t)r * ((tid & 2) ? v_stride : k_stride));
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the loads up here (hipcc otherwise sinks the prefetch next to its use)
     const int j0 = t * BKV;
+    const bf16_t* Ks = Ks2[t & 1];
+    const bf16_t* Vt = Vt2[t & 1];
 
     // ---- S^T = K . Q^T for two 32-key blocks ----
     f32x16_t st[2];
@@ -245,13 +269,15 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
         }
     }
 
-    __syncthreads();   // every wave is done reading this tile
-    if (more) {
-      lstore();
-      __syncthreads();
-    }
+    // hipcc otherwise hoists the register-only part of lstore (the V^T pair packing) up between the QK^T MFMAs - with
+    // the s_waitcnt vmcnt it needs: the MFMAs then wait for the NEXT tile's global loads (found in the .s)
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) lstore((t + 1) & 1);   // the other buffer: last read in iteration t-1, one barrier ago
+    __syncthreads();
+    pf_sink += pf_val;   // consumed only here, behind the staging loads' own wait: the prefetch never stalls anything
   }
 
+  asm volatile("" ::"v"(pf_sink));
   // ---- normalise and store: lane holds O^T[d = db*32 + (r&3) + 8(r>>2) + 4h][q = lane&31] ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
