@@ -51,8 +51,9 @@ int vlm_gemm_bf16(const void* A, const void* W, const void* bias, const void* re
 /* test / A-B knob for vlm_gemm_bf16 kernel selection: 0 = automatic (LDS-DMA staging when K % 64 == 0; the phased
  * 256x256 kernel from ~120 tiles up), 1 = 128x128 kernel with global -> VGPR -> LDS staging, 2 = 128x128 kernel with
  * LDS-DMA staging, 3 = 256x256 phased kernel whenever legal (K % 64 == 0, K >= 128, no SwiGLU), 4 = its 2-phase
- * variant, 5 = automatic with the 2-phase variant, 6 / 7 = as 3 with 256x192 / 256x256 tiles forced.  Results are
- * bit-identical in every mode. */
+ * variant, 5 = automatic with the 2-phase variant, 6 / 7 = as 3 with 256x192 / 256x256 tiles forced, 8 = as 2 (named
+ * "no split-K"), 9 = 128 kernel family with split-K x4 forced.  Modes 1-8 are bit-identical to each other; split-K (automatic
+ * for few tiles and K >= 2048, or mode 9) sums fp32 partials of K ranges and agrees to fp32 summation order. */
 int vlm_gemm_set_staging(int mode);
 
 /* y[M,N] = epi(x[M,K] . W[N,K]^T) for the decode step, M in {1,2,4,8}; weight streaming.

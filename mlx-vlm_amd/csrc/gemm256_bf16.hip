@@ -74,6 +74,12 @@ __device__ __forceinline__ void epilogue256(f32x4_t (&acc)[8][NF], char* smem, c
         const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
         v[0] += bf_lo(b.x); v[1] += bf_hi(b.x); v[2] += bf_lo(b.y); v[3] += bf_hi(b.y);
       }
+      if (EPI & VLM_EPI_SWIGLU) {
+        // interleaved (gate, up) rows of W -> N/2 outputs (reference mlp.py:9-14, activations.py:7-9)
+        const float o0 = swiglu_(rbf(v[0]), rbf(v[1])), o1 = swiglu_(rbf(v[2]), rbf(v[3]));
+        *reinterpret_cast<uint32_t*>(cs + ml * C_LDN + (nl >> 1)) = pack_bf2(o0, o1);
+        continue;
+      }
       if (EPI & VLM_EPI_GELU_FAST) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_fast_(rbf(v[r]));
@@ -89,12 +95,14 @@ __device__ __forceinline__ void epilogue256(f32x4_t (&acc)[8][NF], char* smem, c
     }
   }
   __syncthreads();
-  constexpr int CPR = TN / 8;   // 16-byte chunks per tile row
+  constexpr bool SWI = (EPI & VLM_EPI_SWIGLU) != 0;
+  constexpr int CPR = (SWI ? TN / 2 : TN) / 8;   // 16-byte chunks per output tile row
+  const int n_out = SWI ? (N >> 1) : N, n0o = SWI ? (n0 >> 1) : n0;
 #pragma unroll 2
   for (int c = tid; c < TB * CPR; c += 512) {
     const int row = c / CPR, cc = c % CPR;
-    const int m = m0 + row, n = n0 + cc * 8;
-    if (m < M && n < N) {
+    const int m = m0 + row, n = n0o + cc * 8;
+    if (m < M && n < n_out) {
       uint4 u = *reinterpret_cast<const uint4*>(cs + row * C_LDN + cc * 8);
       if (EPI & VLM_EPI_RESIDUAL) {
         const uint4 r = *reinterpret_cast<const uint4*>(res + (size_t)m * ldres + n);
@@ -522,6 +530,9 @@ int vlm_gemm256_try(const void* A, const void* W, const void* bias, const void* 
     case VLM_EPI_BIAS | VLM_EPI_RESIDUAL:
       return launch256<VLM_EPI_BIAS | VLM_EPI_RESIDUAL>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
     case VLM_EPI_RESIDUAL: return launch256<VLM_EPI_RESIDUAL>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
-    default: return -1;   // SwiGLU pairs stay on the 128x128 kernel
+    case VLM_EPI_SWIGLU:
+      if (N % 16 != 0) return -1;
+      return launch256<VLM_EPI_SWIGLU>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
+    default: return -1;
   }
 }

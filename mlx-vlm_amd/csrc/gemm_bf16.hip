@@ -18,6 +18,8 @@
 // are applied in-register with the same bf16 rounding points as the reference's
 // typed graph (oracle/ops.py).  Workgroup ids are remapped so that each XCD (own
 // L2) walks a contiguous range of tiles.
+#include <algorithm>
+
 #include "common.cuh"
 #include "../../include/vlm_hip.h"
 
@@ -41,12 +43,21 @@ __device__ __forceinline__ int lds_off(int row, int slot) { return row * ROWB + 
 // GLDS = true: tiles are staged with global_load_lds_dwordx4 (HBM -> LDS DMA, no VGPR round trip, no ds_write
 // pass).  The DMA writes lane-linear (wave base + lane*16 B), so the XOR slot swizzle is applied on the per-lane
 // SOURCE address and the LDS image is exactly the one the register-staged path builds.  Needs K % 64 == 0.
-template <int BM, int BN, int EPI, bool GLDS>
+// PARTIAL (split-K, small M x N with a long K - the LLM down projection at prompt length): blockIdx.y selects a K range
+// of kchunk elements; the workgroup writes its fp32 accumulators to part[split][M][N] (C reinterpreted) and
+// splitk_reduce_kernel sums the splits in a fixed order and applies the epilogue.
+template <int BM, int BN, int EPI, bool GLDS, bool PARTIAL = false>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                         const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
                                                         bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldw,
-                                                        int ldc, int ldres, int tiles_n, int nwg) {
+                                                        int ldc, int ldres, int tiles_n, int nwg, int kchunk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ksplit = PARTIAL ? (int)blockIdx.y : 0;
+  if (PARTIAL) {
+    A += (size_t)ksplit * kchunk;
+    W += (size_t)ksplit * kchunk;
+    K = min(kchunk, K - ksplit * kchunk);
+  }
   constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16;
   constexpr int A_PER = BM * 8 / 256, W_PER = BN * 8 / 256;
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
@@ -186,6 +197,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   //      in registers (rounded to bf16 at the reference's points), the tile is transposed through LDS (free after
   //      the k loop) and written with fully coalesced 16-byte stores; the residual is added in that pass from
   //      equally coalesced 16-byte loads.
+  if (PARTIAL) {
+    float* part = reinterpret_cast<float*>(C) + (size_t)ksplit * M * N;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int m = m0 + wm * WM + j * 16 + (lane & 15);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int n = n0 + wn * WN + i * 16 + (lane >> 4) * 4;
+        if (m < M && n < N)   // N % 8 == 0 and n % 4 == 0: the float4 is inside the row
+          *reinterpret_cast<float4*>(part + (size_t)m * N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+    return;
+  }
   constexpr bool SWI = (EPI & VLM_EPI_SWIGLU) != 0;
   constexpr int OUT_N = SWI ? BN / 2 : BN;      // output columns of this tile
   constexpr int C_LD = OUT_N + 8;               // padded row (elements)
@@ -245,13 +270,88 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   }
 }
 
+// sum of the split-K partials (fixed order: deterministic) + the epilogue of gemm_bf16_kernel, 8 columns per thread
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits,
+                                                            const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                            bf16_t* __restrict__ C, int M, int N, int ldc, int ldres) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x, per_row = N >> 3;
+  if (idx >= (long)M * per_row) return;
+  const int m = (int)(idx / per_row), n = (int)(idx % per_row) * 8;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < splits; ++s) {
+    const float4* p = reinterpret_cast<const float4*>(part + ((size_t)s * M + m) * N + n);
+    const float4 a = p[0], b = p[1];
+    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+  }
+  if (EPI & VLM_EPI_BIAS) {
+    const uint4 b = *reinterpret_cast<const uint4*>(bias + n);
+    v[0] += bf_lo(b.x); v[1] += bf_hi(b.x); v[2] += bf_lo(b.y); v[3] += bf_hi(b.y);
+    v[4] += bf_lo(b.z); v[5] += bf_hi(b.z); v[6] += bf_lo(b.w); v[7] += bf_hi(b.w);
+  }
+  if (EPI & VLM_EPI_GELU_FAST) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = gelu_fast_(rbf(v[r]));
+  }
+  if (EPI & VLM_EPI_GELU_ERF) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = gelu_erf_(rbf(v[r]));
+  }
+  uint4 u;
+  u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
+  if (EPI & VLM_EPI_RESIDUAL) {
+    const uint4 r = *reinterpret_cast<const uint4*>(res + (size_t)m * ldres + n);
+    u.x = pack_bf2(bf_lo(u.x) + bf_lo(r.x), bf_hi(u.x) + bf_hi(r.x));
+    u.y = pack_bf2(bf_lo(u.y) + bf_lo(r.y), bf_hi(u.y) + bf_hi(r.y));
+    u.z = pack_bf2(bf_lo(u.z) + bf_lo(r.z), bf_hi(u.z) + bf_hi(r.z));
+    u.w = pack_bf2(bf_lo(u.w) + bf_lo(r.w), bf_hi(u.w) + bf_hi(r.w));
+  }
+  *reinterpret_cast<uint4*>(C + (size_t)m * ldc + n) = u;
+}
+
+// per-process fp32 workspace of the split-K path (grown on demand; never (re)allocated while the stream is capturing)
+float* g_splitk_ws = nullptr;
+size_t g_splitk_ws_bytes = 0;
+int g_splitk = 0;   // 0 = automatic, -1 = never (vlm_gemm_set_staging mode 8), n > 1 = forced split count (test hook, 9: 4)
+
+bool splitk_workspace(size_t bytes, hipStream_t st) {
+  if (bytes <= g_splitk_ws_bytes) return true;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+  if (hipDeviceSynchronize() != hipSuccess) return false;   // nobody may still read the old buffer
+  if (g_splitk_ws) (void)hipFree(g_splitk_ws);
+  g_splitk_ws = nullptr;
+  g_splitk_ws_bytes = 0;
+  const size_t want = bytes + (bytes >> 1);
+  if (hipMalloc(reinterpret_cast<void**>(&g_splitk_ws), want) != hipSuccess) return false;
+  g_splitk_ws_bytes = want;
+  return true;
+}
+
+template <int EPI>
+int launch_splitk(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
+                  int ldw, int ldc, int ldres, int splits, hipStream_t st) {
+  const int kchunk = vlm_cdiv(vlm_cdiv(K, splits), BK) * BK;
+  splits = vlm_cdiv(K, kchunk);
+  const int tiles_m = vlm_cdiv(M, 64), tiles_n = vlm_cdiv(N, 64), nwg = tiles_m * tiles_n;
+  const size_t lds = 2 * (size_t)(64 + 64) * ROWB;
+  hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, VLM_EPI_NONE, true, true>), dim3(nwg, splits), dim3(256), lds, st,
+                     (const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
+                     reinterpret_cast<bf16_t*>(g_splitk_ws), M, N, K, lda, ldw, N, 0, tiles_n, nwg, kchunk);
+  const long items = (long)M * (N >> 3);
+  hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
+                     (const float*)g_splitk_ws, splits, (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, ldc, ldres);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
+}
+
 template <int BM, int BN, int EPI, bool GLDS>
 int launch_cfg(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
                int ldw, int ldc, int ldres, hipStream_t st) {
   const int tiles_m = vlm_cdiv(M, BM), tiles_n = vlm_cdiv(N, BN), nwg = tiles_m * tiles_n;
   const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
   hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, GLDS>), dim3(nwg), dim3(256), lds, st, (const bf16_t*)A, (const bf16_t*)W,
-                     (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg);
+                     (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg, 0);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
 }
@@ -263,6 +363,15 @@ int launch_epi(const void* A, const void* W, const void* bias, const void* res, 
   const long t128 = (long)vlm_cdiv(M, 128) * vlm_cdiv(N, 128);
   const long t64n = (long)vlm_cdiv(M, 64) * vlm_cdiv(N, 128);
   const bool glds = (K % BK == 0) && !g_force_regstage;
+  // split-K: few 64x64 tiles and a long K (LLM down projection at prompt length: 168 tiles x 140 K tiles, measured
+  // 106 TF) -> enough (tile, K range) workgroups to fill the chip, fp32 partials summed by splitk_reduce_kernel
+  if (glds && !(EPI & VLM_EPI_SWIGLU) && g_splitk >= 0 && N % 8 == 0) {
+    const long t64 = (long)vlm_cdiv(M, 64) * vlm_cdiv(N, 64);
+    int splits = g_splitk > 1 ? g_splitk : 0;
+    if (!splits && t64 < 256 && K >= 2048) splits = (int)std::min<long>(8, std::max<long>(2, (512 + t64 - 1) / t64));
+    if (splits > 1 && K / splits >= 4 * BK && splitk_workspace((size_t)splits * M * N * sizeof(float), st))
+      return launch_splitk<EPI>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, splits, st);
+  }
 #define CFG(BMV, BNV)                                                                                            \
   (glds ? launch_cfg<BMV, BNV, EPI, true>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st)                \
         : launch_cfg<BMV, BNV, EPI, false>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st))
@@ -277,11 +386,13 @@ int launch_epi(const void* A, const void* W, const void* bias, const void* res, 
 // 0 = automatic (LDS DMA when K % 64 == 0; 256x256 phased kernel for large shapes), 1 = always stage through
 // registers (128x128 kernel), 2 = LDS DMA but never the 256x256 kernel, 3 = 256x256 kernel whenever it is legal.
 // 4 = as 3 with the 2-phase variant of the 256x256 kernel, 5 = automatic with the 2-phase variant,
-// 6 / 7 = as 3 with the tile width forced to 192 / 256 (3 picks it by last-round fill).
+// 6 / 7 = as 3 with the tile width forced to 192 / 256 (3 picks it by last-round fill),
+// 8 = LDS-DMA 128 kernel, never split-K; 9 = 128 kernel with split-K x4 forced (modes 1 / 2 also disable split-K).
 // Test / A-B knob only.
 extern "C" int vlm_gemm_set_staging(int mode) {
   g_force_regstage = (mode == 1);
-  g_tile256 = (mode == 3 || mode == 4 || mode == 6 || mode == 7) ? 1 : (mode == 1 || mode == 2) ? -1 : 0;
+  g_tile256 = (mode == 3 || mode == 4 || mode == 6 || mode == 7) ? 1 : (mode == 1 || mode == 2 || mode == 8 || mode == 9) ? -1 : 0;
+  g_splitk = (mode == 1 || mode == 2 || mode == 8) ? -1 : mode == 9 ? 4 : 0;   // 8: no split-K, 9: split-K x4 forced
   vlm_gemm256_set_nf(mode == 6 ? 3 : mode == 7 ? 4 : 0);
   vlm_gemm256_set_variant((mode == 4 || mode == 5) ? 1 : 0);
 #ifdef VLM_GEMM_ABLATION

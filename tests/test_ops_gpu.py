@@ -455,11 +455,43 @@ def test_gemm_lds_dma_staging_equals_register_staging(vops, M, N, K):
     try:
         vops.gemm_set_staging(1)
         ref = vops.gemm(a, w, bias=b, epilogue=vops.EPI_BIAS | vops.EPI_GELU_FAST)
-        vops.gemm_set_staging(0)
+        vops.gemm_set_staging(2)      # same kernel with LDS-DMA staging (no 256 kernel, no split-K)
         out = vops.gemm(a, w, bias=b, epilogue=vops.EPI_BIAS | vops.EPI_GELU_FAST)
     finally:
         vops.gemm_set_staging(0)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(386, 1536, 8960, 0), (130, 1536, 8960, 0), (200, 264, 2048, 9), (64, 640, 4096, 9)])
+@pytest.mark.parametrize("epi", ["res", "bias", "bias_gelu_fast"])
+def test_gemm_split_k(vops, M, N, K, mode, epi):
+    """split-K (fp32 partials per K range, summed in a fixed order, epilogue in the reduce kernel): vs the oracle
+    within 2 ulps (the fp32 summation order differs from the single-pass kernel), deterministic across launches;
+    mode 0 = the automatic dispatch takes it for these shapes, 9 = forced x4."""
+    a, w = rnd(M, K, seed=130).cuda(), rnd(N, K, seed=131, scale=0.03).cuda()
+    b, r = rnd(N, seed=132).cuda(), rnd(M, N, seed=133).cuda()
+    lin = O.linear(a.cpu(), w.cpu(), None if epi == "res" else b.cpu())
+    if epi == "res":
+        ref, kw = O.add(lin, r.cpu()), dict(res=r, epilogue=vops.EPI_RESIDUAL)
+    elif epi == "bias":
+        ref, kw = lin, dict(bias=b, epilogue=vops.EPI_BIAS)
+    else:
+        ref, kw = O.gelu_fast(lin), dict(bias=b, epilogue=vops.EPI_BIAS | vops.EPI_GELU_FAST)
+    try:
+        vops.gemm_set_staging(mode)
+        out1 = vops.gemm(a, w, **kw)
+        out2 = vops.gemm(a, w, **kw)
+        vops.gemm_set_staging(8)
+        single = vops.gemm(a, w, **kw)
+    finally:
+        vops.gemm_set_staging(0)
+    assert torch.equal(out1, out2)
+    ok, rep = bf16_close(out1, ref, ulps=2)
+    assert ok, rep
+    # vs the single-pass kernel: a 1-ulp difference of the rounded linear output can become 2 ulps after the
+    # residual add / activation rounds again
+    ok, rep = bf16_close(out1, single, ulps=2, atol_rms=2e-3)
+    assert ok, rep
 
 
 # ------------------------------------------------------------------ identity KV layout (block_table == NULL)
@@ -534,7 +566,7 @@ def test_attn_prefill_deferred_max_slow_ramp(vops, causal):
 # ------------------------------------------------------------------ 256x256 phased GEMM (gemm256_bf16.hip)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 1280), (300, 520, 192), (1000, 264, 64 * 5), (9216, 1280, 1280),
                                    (777, 1536, 8960)])
-@pytest.mark.parametrize("epi", ["none", "bias", "bias_gelu_fast", "bias_res"])
+@pytest.mark.parametrize("epi", ["none", "bias", "bias_gelu_fast", "bias_res", "swiglu"])
 @pytest.mark.parametrize("variant", [4, 6, 7])
 def test_gemm256_phased_kernel_is_bit_identical_to_128_kernel(vops, M, N, K, epi, variant):
     """Same fragments, same per-element accumulation order -> the phased 256x256 schedule must reproduce the 128x128
@@ -543,7 +575,10 @@ def test_gemm256_phased_kernel_is_bit_identical_to_128_kernel(vops, M, N, K, epi
     b, r = rnd(N, seed=112).cuda(), rnd(M, N, seed=113).cuda()
     kw = {"none": dict(), "bias": dict(bias=b, epilogue=vops.EPI_BIAS),
           "bias_gelu_fast": dict(bias=b, epilogue=vops.EPI_BIAS | vops.EPI_GELU_FAST),
-          "bias_res": dict(bias=b, res=r, epilogue=vops.EPI_BIAS | vops.EPI_RESIDUAL)}[epi]
+          "bias_res": dict(bias=b, res=r, epilogue=vops.EPI_BIAS | vops.EPI_RESIDUAL),
+          "swiglu": dict(epilogue=vops.EPI_SWIGLU)}[epi]
+    if epi == "swiglu" and N % 16:
+        pytest.skip("SwiGLU pairs need N % 16 == 0")
     try:
         vops.gemm_set_staging(2)
         ref = vops.gemm(a, w, **kw)
