@@ -173,12 +173,37 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + (size_t)kt * BK),
                                          (__attribute__((address_space(3))) void*)(ws + (uw * W_IT + j) * 1024), 16, 0, 0);
     };
-    issue(0, 0);
-    __syncthreads();   // hipcc drains vmcnt(0) for the in-flight LDS DMA before the barrier
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-      compute(kt & 1);
-      __syncthreads();
+    if constexpr (BM == 64 && BN == 64) {
+      // 64x64 tiles carry ~100 cycles of MFMA per K tile: with one tile of prefetch every iteration waited a full
+      // memory latency (~0.8 us per K tile measured on the M = 386 prefill GEMMs).  Four 16 KiB stages, three tiles in
+      // flight, COUNTED waits (4 DMA instructions per wave and tile; tile indices clamped at the end so the count
+      // never changes), raw barriers (__syncthreads would drain vmcnt(0)).  Stage kt % 4 is refilled with tile kt + 4
+      // in iteration kt + 1, after the barrier that ends its last read.
+      constexpr int NS = 4, PER = A_IT + W_IT;
+      static_assert(PER == 4, "vmcnt immediates below assume 4 DMA instructions per wave and tile");
+      issue(0, 0);
+      issue(min(1, nk - 1), 1);
+      issue(min(2, nk - 1), 2);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 landed (tiles 1, 2 may be in flight)
+      __builtin_amdgcn_s_barrier();
+      for (int kt = 0; kt < nk; ++kt) {
+        issue(min(kt + 3, nk - 1), (kt + 3) % NS);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(kt % NS);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile kt + 1 landed (this wave's pieces) ...
+        __builtin_amdgcn_s_barrier();                       // ... and everybody's; stage kt % 4 is free again
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // clamped reloads still target LDS
+      __builtin_amdgcn_s_barrier();
+    } else {
+      issue(0, 0);
+      __syncthreads();   // hipcc drains vmcnt(0) for the in-flight LDS DMA before the barrier
+      for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        compute(kt & 1);
+        __syncthreads();
+      }
     }
   } else {
     gload(0);
@@ -334,7 +359,7 @@ int launch_splitk(const void* A, const void* W, const void* bias, const void* re
   const int kchunk = vlm_cdiv(vlm_cdiv(K, splits), BK) * BK;
   splits = vlm_cdiv(K, kchunk);
   const int tiles_m = vlm_cdiv(M, 64), tiles_n = vlm_cdiv(N, 64), nwg = tiles_m * tiles_n;
-  const size_t lds = 2 * (size_t)(64 + 64) * ROWB;
+  const size_t lds = 4 * (size_t)(64 + 64) * ROWB;   // four stages (see the 64x64 K loop)
   hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, VLM_EPI_NONE, true, true>), dim3(nwg, splits), dim3(256), lds, st,
                      (const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
                      reinterpret_cast<bf16_t*>(g_splitk_ws), M, N, K, lda, ldw, N, 0, tiles_n, nwg, kchunk);
@@ -349,7 +374,7 @@ template <int BM, int BN, int EPI, bool GLDS>
 int launch_cfg(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
                int ldw, int ldc, int ldres, hipStream_t st) {
   const int tiles_m = vlm_cdiv(M, BM), tiles_n = vlm_cdiv(N, BN), nwg = tiles_m * tiles_n;
-  const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
+  const size_t lds = ((BM == 64 && BN == 64 && GLDS) ? 4 : 2) * (size_t)(BM + BN) * ROWB;
   hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, GLDS>), dim3(nwg), dim3(256), lds, st, (const bf16_t*)A, (const bf16_t*)W,
                      (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg, 0);
   hipError_t e = hipGetLastError();
