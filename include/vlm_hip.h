@@ -52,7 +52,7 @@ int vlm_gemm_bf16(const void* A, const void* W, const void* bias, const void* re
  * 256x256 kernel from ~120 tiles up), 1 = 128x128 kernel with global -> VGPR -> LDS staging, 2 = 128x128 kernel with
  * LDS-DMA staging, 3 = 256x256 phased kernel whenever legal (K % 64 == 0, K >= 128, no SwiGLU), 4 = its 2-phase
  * variant, 5 = automatic with the 2-phase variant, 6 / 7 = as 3 with 256x192 / 256x256 tiles forced, 8 = as 2 (named
- * "no split-K"), 9 = 128 kernel family with split-K x4 forced.  Modes 1-8 are bit-identical to each other; split-K (automatic
+ * "no split-K"), 9 = 128 kernel family with split-K x4 forced, 10 = as 3 with the persistent tile loop.  Modes 1-8 are bit-identical to each other; split-K (automatic
  * for few tiles and K >= 2048, or mode 9) sums fp32 partials of K ranges and agrees to fp32 summation order. */
 int vlm_gemm_set_staging(int mode);
 

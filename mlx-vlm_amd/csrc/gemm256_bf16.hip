@@ -290,6 +290,230 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
   epilogue256<EPI, NF>(acc, smem, bias, res, C, M, N, ldc, ldres, m0, n0, wr, wc, fr, fs, tid);
 }
 
+// ---- persistent form of the 4-phase kernel: min(tiles, 256) workgroups walk the tiles (tile = b, b + grid, ...: the same
+// XCD every time).  After a tile's K loop the NEXT tile's first 14 LDS-DMA pieces are issued BEFORE the epilogue, which
+// runs out of a separate 17 KiB LDS chunk (32 rows at a time, 2 barriers per chunk) - the ~2 us of cold DMA latency at
+// the start of a tile and the bias/activation/store pass at its end overlap instead of adding up (K = 1280 shapes have
+// only 20 K tiles per tile to amortise them over).
+template <int EPI, int NF>
+__global__ __launch_bounds__(512) void gemm256p_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                       const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                       bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldw,
+                                                       int ldc, int ldres, int tiles_n, int nwg, int group_m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int WH = 32 * NF, TN = 64 * NF, C_LDN = TN + 8;
+  constexpr bool SWI = (EPI & VLM_EPI_SWIGLU) != 0;
+  bf16_t* cs = reinterpret_cast<bf16_t*>(smem + 2 * STAGE);     // epilogue chunk: 32 rows x (TN + 8)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = uw >> 2, wc = uw & 3;
+  const int nk = K / BK;
+  const int rl = lane >> 3, sp = lane & 7, fr = lane & 15, fs = lane >> 4;
+  const int tiles_m = nwg / tiles_n;
+
+  auto coords = [&](int tile, int& m0, int& n0) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = tile & 7, idx = tile >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int per_group = group_m * tiles_n, gid = bid / per_group;
+    const int first_m = gid * group_m, gsz = min(tiles_m - first_m, group_m), rr = bid - gid * per_group;
+    m0 = (first_m + rr % gsz) * TB;
+    n0 = (rr / gsz) * TN;
+  };
+  const bf16_t* wsrc[NF];
+  const bf16_t* asrc[4];
+  int wdst[NF], adst[4];
+#pragma unroll
+  for (int j = 0; j < NF; ++j) wdst[j] = 2 * HALF + (uw >> 2) * HALF + 8 * ((uw & 3) * NF + j) * ROWB;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) adst[j] = (uw >> 2) * HALF + (32 * j + 8 * (uw & 3)) * ROWB;
+  auto sources = [&](int m0, int n0) {
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+      const int row = 8 * ((uw & 3) * NF + j) + rl;
+      wsrc[j] = W + (size_t)min(n0 + (uw >> 2) * WH + row, N - 1) * ldw + ((sp ^ ((row >> 1) & 7)) << 3);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int arow = 32 * j + 8 * (uw & 3) + rl;
+      asrc[j] = A + (size_t)min(m0 + (uw >> 2) * 128 + arow, M - 1) * lda + ((sp ^ ((arow >> 1) & 7)) << 3);
+    }
+  };
+  auto dma = [&](const bf16_t* src, int kt, int lds_byte) {
+    const int ktc = min(kt, nk - 1);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)ktc * BK),
+                                     (__attribute__((address_space(3))) void*)(smem + lds_byte), 16, 0, 0);
+  };
+  auto issue_w = [&](int kt) {
+    const int base = (kt & 1) * STAGE;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) dma(wsrc[j], kt, base + wdst[j]);
+  };
+  auto issue_a = [&](int kt, int q) { dma(asrc[q], kt, (kt & 1) * STAGE + adst[q]); };
+  auto prologue = [&]() {
+    issue_w(0); issue_a(0, 0); issue_a(0, 1); issue_a(0, 2); issue_a(0, 3);
+    issue_w(1); issue_a(1, 0); issue_a(1, 1);
+  };
+#define WAIT_A()              \
+  do {                        \
+    if (NF == 4) VMCNT(9);    \
+    else VMCNT(8);            \
+  } while (0)
+#define WAIT_B()              \
+  do {                        \
+    if (NF == 4) VMCNT(13);   \
+    else VMCNT(11);           \
+  } while (0)
+
+  bf16x8_t wf[NF][2], af[2][2];
+  auto read_w = [&](int kt) {
+    const char* ws = smem + (kt & 1) * STAGE + 2 * HALF + (wc >> 1) * HALF;
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        wf[n][ks] = *reinterpret_cast<const bf16x8_t*>(ws + lds_off((wc & 1) * 16 * NF + n * 16 + fr, ks * 4 + fs));
+  };
+  auto read_a = [&](int kt, int q) {
+    const char* as = smem + (kt & 1) * STAGE + wr * HALF;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        af[m][ks] = *reinterpret_cast<const bf16x8_t*>(as + lds_off(q * 32 + m * 16 + fr, ks * 4 + fs));
+  };
+
+  int tile = blockIdx.x, m0, n0;
+  coords(tile, m0, n0);
+  sources(m0, n0);
+  prologue();
+  while (true) {
+    WAIT_A();
+    BARRIER();
+    if (wr == 1) BARRIER();
+    f32x4_t acc[8][NF];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#define MFMA_PHASE_P(Q)                                                                                            \
+  do {                                                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+      _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                                \
+        _Pragma("unroll") for (int n = 0; n < NF; ++n)                                                             \
+          acc[2 * (Q) + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n][ks], af[m][ks], acc[2 * (Q) + m][n], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                                 \
+  } while (0)
+    for (int kt = 0; kt < nk; ++kt) {
+      read_w(kt);
+      read_a(kt, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_a(kt + 1, 2);
+      WAIT_A();
+      BARRIER();
+      LGKM0();
+      MFMA_PHASE_P(0);
+      BARRIER();
+      read_a(kt, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_a(kt + 1, 3);
+      WAIT_A();
+      BARRIER();
+      LGKM0();
+      MFMA_PHASE_P(1);
+      BARRIER();
+      read_a(kt, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_w(kt + 2);
+      issue_a(kt + 2, 0);
+      WAIT_B();
+      BARRIER();
+      LGKM0();
+      MFMA_PHASE_P(2);
+      BARRIER();
+      read_a(kt, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_a(kt + 2, 1);
+      WAIT_A();
+      BARRIER();
+      LGKM0();
+      MFMA_PHASE_P(3);
+      BARRIER();
+    }
+#undef MFMA_PHASE_P
+    if (wr == 0) BARRIER();
+    VMCNT(0);      // the clamped reloads past the last K tile must have LANDED before the next tile's pieces go to the
+    BARRIER();     // same LDS addresses (two DMAs to one address may land in either order)
+
+    const int next = tile + (int)gridDim.x;
+    const bool has_next = next < nwg;
+    int m0n = 0, n0n = 0;
+    if (has_next) {
+      coords(next, m0n, n0n);
+      sources(m0n, n0n);
+      prologue();           // flies under the epilogue below
+    }
+    // ---- epilogue in 8 chunks of 32 rows (m fragment mi of both wave rows) through the separate LDS chunk
+    const int n_out = SWI ? (N >> 1) : N, n0o = SWI ? (n0 >> 1) : n0;
+    constexpr int CPR = (SWI ? TN / 2 : TN) / 8;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      const int ml = wr * 16 + fr;
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni) {
+        const int nl = wc * 16 * NF + ni * 16 + fs * 4;
+        const int n = min(n0 + nl, N - 4);
+        float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+        if (EPI & VLM_EPI_BIAS) {
+          const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
+          v[0] += bf_lo(b.x); v[1] += bf_hi(b.x); v[2] += bf_lo(b.y); v[3] += bf_hi(b.y);
+        }
+        if (SWI) {
+          const float o0 = swiglu_(rbf(v[0]), rbf(v[1])), o1 = swiglu_(rbf(v[2]), rbf(v[3]));
+          *reinterpret_cast<uint32_t*>(cs + ml * C_LDN + (nl >> 1)) = pack_bf2(o0, o1);
+          continue;
+        }
+        if (EPI & VLM_EPI_GELU_FAST) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_fast_(rbf(v[r]));
+        }
+        if (EPI & VLM_EPI_GELU_ERF) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf_(rbf(v[r]));
+        }
+        uint2 o;
+        o.x = pack_bf2(v[0], v[1]);
+        o.y = pack_bf2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(cs + ml * C_LDN + nl) = o;
+      }
+      LGKM0();      // raw barriers: __syncthreads() would also drain vmcnt(0), i.e. wait here for the next tile's DMA
+      BARRIER();
+      for (int c = tid; c < 32 * CPR; c += 512) {
+        const int row = c / CPR, cc = c % CPR;
+        const int m = m0 + (row >> 4) * 128 + mi * 16 + (row & 15), n = n0o + cc * 8;
+        if (m < M && n < n_out) {
+          uint4 u = *reinterpret_cast<const uint4*>(cs + row * C_LDN + cc * 8);
+          if (EPI & VLM_EPI_RESIDUAL) {
+            const uint4 r = *reinterpret_cast<const uint4*>(res + (size_t)m * ldres + n);
+            u.x = pack_bf2(bf_lo(u.x) + bf_lo(r.x), bf_hi(u.x) + bf_hi(r.x));
+            u.y = pack_bf2(bf_lo(u.y) + bf_lo(r.y), bf_hi(u.y) + bf_hi(r.y));
+            u.z = pack_bf2(bf_lo(u.z) + bf_lo(r.z), bf_hi(u.z) + bf_hi(r.z));
+            u.w = pack_bf2(bf_lo(u.w) + bf_lo(r.w), bf_hi(u.w) + bf_hi(r.w));
+          }
+          *reinterpret_cast<uint4*>(C + (size_t)m * ldc + n) = u;
+        }
+      }
+      BARRIER();    // the chunk's ds_reads have returned (their data went into the stores above)
+    }
+    if (!has_next) break;
+    tile = next;
+    m0 = m0n;
+    n0 = n0n;
+  }
+#undef WAIT_A
+#undef WAIT_B
+}
+
 // ---- variant B: the same tile and fragments, TWO phases of 32 MFMAs per K tile (half the barriers per MFMA).
 // With only two phases a region cannot wait two phases for its refill and still arrive in time, so ALL DMA is issued
 // by the wave row that runs half a phase behind (row 1): its issue point in phase p+1 lies after barrier 2p+2, by
@@ -437,6 +661,8 @@ __global__ __launch_bounds__(512) void gemm256b_kernel(const bf16_t* __restrict_
 int g_variant = 0;   // 0 = 4 phases of 16 MFMAs per K tile, 1 = 2 phases of 32 (vlm_gemm256_set_variant, A/B knob)
 int g_nf = 0;        // 0 = pick the tile width (256 / 192) by last-round fill, 3 / 4 = forced (tests)
 
+int g_persist = 0;   // 1 = persistent tile loop with the next tile's DMA under the epilogue (A/B knob; default below)
+
 template <int EPI, int NF>
 int launch256_nf(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
                  int ldw, int ldc, int ldres, hipStream_t st) {
@@ -448,6 +674,21 @@ int launch256_nf(const void* A, const void* W, const void* bias, const void* res
     attr_set = true;
   }
   const int tiles_m = vlm_cdiv(M, TB), tiles_n = vlm_cdiv(N, 64 * NF), nwg = tiles_m * tiles_n;
+  if (g_persist == 1 && nwg > 256) {
+    static bool attr_p = false;
+    constexpr int LDS_P = 2 * STAGE + 32 * (64 * NF + 8) * 2;
+    if (!attr_p) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<EPI, NF>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_P);
+      if (e != hipSuccess) return VLM_ERR_HIP + (int)e;
+      attr_p = true;
+    }
+    hipLaunchKernelGGL((gemm256p_kernel<EPI, NF>), dim3(256), dim3(512), LDS_P, st, (const bf16_t*)A, (const bf16_t*)W,
+                       (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg,
+                       GROUP_M);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
+  }
   static const int group_m = getenv("VLM_GEMM_GROUP_M") ? atoi(getenv("VLM_GEMM_GROUP_M")) : GROUP_M;   // A/B knob
   hipLaunchKernelGGL((gemm256_kernel<EPI, 0, NF>), dim3(nwg), dim3(512), LDS_BYTES, st, (const bf16_t*)A, (const bf16_t*)W,
                      (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg,
@@ -513,6 +754,7 @@ int launch256(const void* A, const void* W, const void* bias, const void* res, v
 
 void vlm_gemm256_set_variant(int v) { g_variant = v; }
 void vlm_gemm256_set_nf(int nf) { g_nf = nf; }
+void vlm_gemm256_set_persist(int p) { g_persist = p; }
 
 // Internal entry (C++ linkage, called by vlm_gemm_bf16's dispatcher).  Returns -1 when the shape / epilogue is not
 // one this kernel takes (the caller then uses the 128x128 kernel).  Needs K % 64 == 0, K >= 128, N % 8 == 0.

@@ -29,6 +29,7 @@ int vlm_gemm256_try(const void* A, const void* W, const void* bias, const void* 
 
 void vlm_gemm256_set_variant(int v);
 void vlm_gemm256_set_nf(int nf);
+void vlm_gemm256_set_persist(int p);
 
 namespace {
 
@@ -416,9 +417,10 @@ int launch_epi(const void* A, const void* W, const void* bias, const void* res, 
 // Test / A-B knob only.
 extern "C" int vlm_gemm_set_staging(int mode) {
   g_force_regstage = (mode == 1);
-  g_tile256 = (mode == 3 || mode == 4 || mode == 6 || mode == 7) ? 1 : (mode == 1 || mode == 2 || mode == 8 || mode == 9) ? -1 : 0;
+  g_tile256 = (mode == 3 || mode == 4 || mode == 6 || mode == 7 || mode == 10) ? 1 : (mode == 1 || mode == 2 || mode == 8 || mode == 9) ? -1 : 0;
   g_splitk = (mode == 1 || mode == 2 || mode == 8) ? -1 : mode == 9 ? 4 : 0;   // 8: no split-K, 9: split-K x4 forced
   vlm_gemm256_set_nf(mode == 6 ? 3 : mode == 7 ? 4 : 0);
+  vlm_gemm256_set_persist(mode == 10 ? 1 : 0);   // 10: 256 kernel forced, persistent tile loop
   vlm_gemm256_set_variant((mode == 4 || mode == 5) ? 1 : 0);
 #ifdef VLM_GEMM_ABLATION
   if (mode >= 11 && mode <= 13) {   // ablation probes (wrong results; see gemm256_bf16.hip)

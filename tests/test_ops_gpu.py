@@ -565,9 +565,9 @@ def test_attn_prefill_deferred_max_slow_ramp(vops, causal):
 
 # ------------------------------------------------------------------ 256x256 phased GEMM (gemm256_bf16.hip)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 1280), (300, 520, 192), (1000, 264, 64 * 5), (9216, 1280, 1280),
-                                   (777, 1536, 8960)])
+                                   (777, 1536, 8960), (4100, 5120, 1280)])
 @pytest.mark.parametrize("epi", ["none", "bias", "bias_gelu_fast", "bias_res", "swiglu"])
-@pytest.mark.parametrize("variant", [4, 6, 7])
+@pytest.mark.parametrize("variant", [4, 6, 7, 10])
 def test_gemm256_phased_kernel_is_bit_identical_to_128_kernel(vops, M, N, K, epi, variant):
     """Same fragments, same per-element accumulation order -> the phased 256x256 schedule must reproduce the 128x128
     kernel bit for bit, including ragged M / N edges; repeated launches screen for LDS-DMA ordering races."""
@@ -582,7 +582,7 @@ def test_gemm256_phased_kernel_is_bit_identical_to_128_kernel(vops, M, N, K, epi
     try:
         vops.gemm_set_staging(2)
         ref = vops.gemm(a, w, **kw)
-        vops.gemm_set_staging(variant)     # 4: two phases of 32 MFMAs; 6 / 7: four phases of 16, 256x192 / 256x256 tiles
+        vops.gemm_set_staging(variant)     # 4: two phases of 32 MFMAs; 6 / 7: four phases of 16, 256x192 / 256x256 tiles; 10: persistent tile loop
         for it in range(6):
             out = vops.gemm(a, w, **kw)
             assert torch.equal(out, ref), f"iteration {it}: {int((out != ref).sum())} elements differ"
@@ -590,10 +590,10 @@ def test_gemm256_phased_kernel_is_bit_identical_to_128_kernel(vops, M, N, K, epi
         vops.gemm_set_staging(0)
 
 
-@pytest.mark.parametrize("variant", [4, 6, 7])
+@pytest.mark.parametrize("variant", [4, 6, 7, 10])
 def test_gemm256_under_memory_pressure_race_screen(vops, variant):
     """a concurrent copy stream perturbs DMA landing order; results must not change"""
-    M, N, K = 2048, 2048, 2048
+    M, N, K = (2048, 2048, 2048) if variant != 10 else (6144, 4096, 1024)     # 10: > 256 tiles -> persistent loop
     a, w = rnd(M, K, seed=120).cuda(), rnd(N, K, seed=121, scale=0.05).cuda()
     big = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
     dst = torch.empty_like(big)
