@@ -257,6 +257,22 @@ def main():
           for (h, w) in [(336, 336), (448, 448), (100, 333), (1080, 1920), (30, 40), (2000, 3000), (57, 500)]]
     blob["smart_resize.ref_table"] = np.array(sr, dtype=np.int64)
 
+    # ---- checkpoint key remap + conv-weight layout (Model.sanitize qwen2_vl.py:179-190, VisionModel.sanitize
+    #      vision.py:292-310) on the HF Qwen2-VL checkpoint key layout
+    hf_keys = (["visual.patch_embed.proj.weight", "visual.merger.ln_q.weight", "visual.merger.mlp.0.bias",
+                "visual.blocks.0.attn.qkv.weight", "visual.blocks.1.mlp.fc2.bias", "visual.blocks.0.norm1.weight",
+                "model.embed_tokens.weight", "model.norm.weight", "lm_head.weight",
+                "model.layers.0.self_attn.q_proj.bias", "model.layers.1.mlp.down_proj.weight",
+                "model.layers.0.input_layernorm.weight", "model.layers.1.post_attention_layernorm.weight"])
+    gen = torch.Generator().manual_seed(5)
+    hf_w = {k: mx.array(torch.randn(4, 3, 2, 6, 6, generator=gen) if k.endswith("patch_embed.proj.weight")
+                        else torch.randn(3, generator=gen)) for k in hf_keys}
+    san = model.vision_tower.sanitize(model.sanitize(dict(hf_w)))
+    blob["sanitize.hf_keys"] = np.array(hf_keys)
+    blob["sanitize.ref_keys"] = np.array(list(san.keys()))
+    blob["sanitize.hf_conv"] = f32(hf_w["visual.patch_embed.proj.weight"])
+    blob["sanitize.ref_conv"] = f32(san["vision_tower.patch_embed.proj.weight"])
+
     out = os.path.join(HERE, "qwen2_vl_tiny_ref.npz")
     np.savez_compressed(out, **blob)
     print("wrote", out, os.path.getsize(out), "bytes;", len(blob), "arrays")

@@ -199,3 +199,21 @@ def test_smart_resize_matches_reference_table():
 
     for h, w, rh, rw in R["smart_resize.ref_table"].tolist():
         assert ip.smart_resize(h, w) == (rh, rw)
+
+
+def test_checkpoint_sanitize_matches_reference():
+    """Product Model.sanitize + VisionModel.sanitize (host code, CPU) vs the reference's own on the HF Qwen2-VL key
+    layout: same key names in the same order, same conv-weight layout (O,C,T,H,W) -> (O,T,H,W,C)."""
+    from mlx_vlm_amd.models.qwen2_vl.qwen2_vl import Model
+    from mlx_vlm_amd.models.qwen2_vl.vision import VisionModel
+
+    hf_keys = [str(k) for k in R["sanitize.hf_keys"]]
+    w = {k: (torch.from_numpy(R["sanitize.hf_conv"]) if k.endswith("patch_embed.proj.weight") else torch.zeros(3))
+         for k in hf_keys}
+    san = VisionModel.sanitize(None, Model.sanitize(None, w))
+    assert list(san.keys()) == [str(k) for k in R["sanitize.ref_keys"]]
+    assert np.array_equal(san["vision_tower.patch_embed.proj.weight"].numpy(), R["sanitize.ref_conv"])
+    # and the oracle's own sanitize
+    o = oq.sanitize(w)
+    assert set(o.keys()) == set(san.keys())
+    assert np.array_equal(o["vision_tower.patch_embed.proj.weight"].numpy(), R["sanitize.ref_conv"])
