@@ -273,6 +273,29 @@ def main():
     blob["sanitize.hf_conv"] = f32(hf_w["visual.patch_embed.proj.weight"])
     blob["sanitize.ref_conv"] = f32(san["vision_tower.patch_embed.proj.weight"])
 
+    # ---- NaiveStreamingDetokenizer (tokenizer_utils.py:71-118; needs no mlx) on a byte-level toy tokenizer: multi-byte
+    #      UTF-8 characters arrive split across tokens, newlines flush
+    tu = importlib.import_module("mlx_vlm.tokenizer_utils")
+    assert tu.__file__.startswith(REF)
+
+    class ByteTok:
+        def decode(self, toks):
+            return bytes(toks).decode("utf-8", errors="replace")
+
+    text = "héllo wörld\n日本語 ok\nfin 🙂!"
+    toks = list(text.encode("utf-8"))
+    det = tu.NaiveStreamingDetokenizer(ByteTok())
+    det.reset()
+    segs = []
+    for t in toks:
+        det.add_token(t)
+        segs.append(det.last_segment)
+    det.finalize()
+    segs.append(det.last_segment)
+    blob["detok.tokens"] = np.array(toks, dtype=np.int64)
+    blob["detok.ref_segments"] = np.array(segs)
+    blob["detok.ref_text"] = np.array([det.text])
+
     out = os.path.join(HERE, "qwen2_vl_tiny_ref.npz")
     np.savez_compressed(out, **blob)
     print("wrote", out, os.path.getsize(out), "bytes;", len(blob), "arrays")

@@ -217,3 +217,24 @@ def test_checkpoint_sanitize_matches_reference():
     o = oq.sanitize(w)
     assert set(o.keys()) == set(san.keys())
     assert np.array_equal(o["vision_tower.patch_embed.proj.weight"].numpy(), R["sanitize.ref_conv"])
+
+
+def test_streaming_detokenizer_matches_reference():
+    """Product NaiveStreamingDetokenizer vs the reference's (tokenizer_utils.py:71-118) segment by segment on a
+    byte-level toy tokenizer (split multi-byte characters, newline flushes)."""
+    from mlx_vlm_amd.utils import NaiveStreamingDetokenizer
+
+    class ByteTok:
+        def decode(self, toks):
+            return bytes(toks).decode("utf-8", errors="replace")
+
+    det = NaiveStreamingDetokenizer(ByteTok())
+    det.reset()
+    segs = []
+    for t in R["detok.tokens"].tolist():
+        det.add_token(t)
+        segs.append(det.last_segment)
+    det.finalize()
+    segs.append(det.last_segment)
+    assert segs == [str(x) for x in R["detok.ref_segments"]]
+    assert det.text == str(R["detok.ref_text"][0])
