@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
   // ---- loads are returned in issue order (vmcnt), so the SMALL latency-critical ones go first: the
   //      activation row for the norm prologue and the epilogue operands; then every weight load of the
   //      wave.  The prologue then only waits for its own (oldest) loads while the weights keep streaming.
-  u32x4_t xv[KC];
+  u32x4_t xv[KC], xv2[MB > 4 ? KC : 1];
   uint4 nwv[KC];
   if (PRO == PRO_RMSNORM) {
 #pragma unroll
@@ -113,6 +113,9 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
       const int ch = lane + 64 * c, chc = min(ch, nchunk - 1);
       xv[c] = *reinterpret_cast<const u32x4_t*>(x + (size_t)(wave % MB) * ldx + (size_t)chc * 8);   // masked at use
       nwv[c] = reinterpret_cast<const uint4*>(norm_w)[chc];
+      // MB == 8: this wave also normalises row 4 + wave; its loads go out HERE, ahead of the weight stream (issued
+      // after it they would return behind every weight load of the wave - vector loads return in order)
+      if (MB > 4) xv2[c] = *reinterpret_cast<const u32x4_t*>(x + (size_t)(4 + wave) * ldx + (size_t)chc * 8);
     }
   }
   // PRO_ATTN fast path (<= 4 splits, MB <= 2): the split merge is one 8-element chunk of x per thread; its loads
@@ -182,13 +185,9 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
 #pragma unroll
     for (int round = 0; round < (MB + 3) / 4; ++round) {
       const int m = round * 4 + (round == 0 ? wave % MB : wave);
-      if (round > 0) {   // MB == 8: rows 4..7 are fetched here
+      if (round > 0) {   // MB == 8: rows 4..7 (loaded up front)
 #pragma unroll
-        for (int c = 0; c < KC; ++c) {
-          const int ch = lane + 64 * c;
-          const u32x4_t t = *reinterpret_cast<const u32x4_t*>(x + (size_t)m * ldx + (size_t)min(ch, nchunk - 1) * 8);
-          xv[c] = ch < nchunk ? t : u32x4_t{0, 0, 0, 0};
-        }
+        for (int c = 0; c < KC; ++c) xv[c] = xv2[MB > 4 ? c : 0];
       }
       float s = 0.f;
 #pragma unroll
@@ -467,7 +466,7 @@ int launch_rw(const Args& a, int n_waves) {
 template <int KC, int MB, int PRO, int EPI>
 int launch_rw_r(const Args& a) {
   // R = 4 rows per wave once there are enough rows to give every CU several workgroups
-  if (EPI != EPI_ROPE_KV && a.N >= 8192 && MB <= 4 && KC <= 3) return launch_rw<4, KC, MB, PRO, EPI>(a, vlm_cdiv(a.N, 4));
+  if (EPI != EPI_ROPE_KV && a.N >= 8192 && KC <= 3) return launch_rw<4, KC, MB, PRO, EPI>(a, vlm_cdiv(a.N, 4));
   if (EPI == EPI_ROPE_KV) {
     const int waves = (a.rk.Hq + a.rk.Hkv) * (a.rk.D / 2) + a.rk.Hkv * a.rk.D / 2;
     return launch_rw<2, KC, MB, PRO, EPI>(a, waves);
