@@ -395,3 +395,18 @@ def batch_generate(model, processor, images=None, audios=None, prompts: Optional
     toks, stats = batch_generate_ids(model, ids_l, pix_l, grid_l, max_tokens=max_tokens, stop_ids=stop_ids, sampler=smp)
     texts = [tokenizer.decode(t) if hasattr(tokenizer, "decode") else "" for t in toks]
     return BatchResponse(texts=texts, stats=stats, tokens=toks)
+
+
+# `mlx_vlm_amd.generate` names both this module and the function (as in the reference, where the package's eager
+# `from .generate import generate` rebinds the name).  The package imports lazily, so once this module is loaded the
+# import system binds the MODULE on the package; make it callable so `from mlx_vlm_amd import generate` works in either order.
+import sys as _sys
+import types as _types
+
+
+class _CallableModule(_types.ModuleType):
+    def __call__(self, *args, **kwargs):
+        return generate(*args, **kwargs)
+
+
+_sys.modules[__name__].__class__ = _CallableModule

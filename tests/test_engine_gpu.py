@@ -340,3 +340,90 @@ def test_real_width_two_layer_model_vs_oracle(dims):
     assert ok, (toks, ref_toks, n, margin)
     ok, rep = bf16_close(lps[0], O.logprobs_from_logits(ref_logits[0][None])[0], ulps=2, atol_rms=3e-2)
     assert ok, rep
+
+
+def _write_tiny_checkpoint(tmp_path, cfg, W):
+    """HF Qwen2-VL layout on disk: config.json (text parameters at the root), model.safetensors with the classic HF
+    key names (visual.* / model.* ; conv weight (O,C,T,H,W)), a WordLevel tokenizer with the special vision tokens."""
+    import json
+
+    from safetensors.torch import save_file
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+
+    t, v = cfg.text, cfg.vision
+    conf = dict(model_type="qwen2_vl", hidden_size=t.hidden_size, num_hidden_layers=t.num_hidden_layers,
+                intermediate_size=t.intermediate_size, num_attention_heads=t.num_attention_heads,
+                num_key_value_heads=t.num_key_value_heads, vocab_size=t.vocab_size, rms_norm_eps=t.rms_norm_eps,
+                rope_theta=t.rope_theta, rope_scaling={"type": "mrope", "mrope_section": list(t.mrope_section)},
+                tie_word_embeddings=t.tie_word_embeddings, image_token_id=cfg.image_token_id,
+                video_token_id=cfg.video_token_id, vision_start_token_id=cfg.vision_start_token_id, eos_token_id=[1],
+                vision_config=dict(model_type="qwen2_vl", depth=v.depth, embed_dim=v.embed_dim, hidden_size=v.hidden_size,
+                                   num_heads=v.num_heads, patch_size=v.patch_size, mlp_ratio=int(v.mlp_ratio),
+                                   in_channels=v.in_channels, spatial_merge_size=v.spatial_merge_size,
+                                   temporal_patch_size=v.temporal_patch_size))
+    (tmp_path / "config.json").write_text(json.dumps(conf))
+    hf = {}
+    for k, w in W.items():
+        w = w.contiguous()
+        if k.startswith("vision_tower."):
+            hk = "visual." + k[len("vision_tower."):]
+            if "patch_embed.proj.weight" in k:
+                w = w.permute(0, 4, 1, 2, 3).contiguous()          # (O,T,H,W,C) -> HF (O,C,T,H,W)
+        elif k.startswith("language_model.model."):
+            hk = "model." + k[len("language_model.model."):]
+        else:
+            hk = "lm_head." + k[len("language_model.lm_head."):]
+        hf[hk] = w
+    save_file(hf, str(tmp_path / "model.safetensors"))
+    vocab = {f"t{i}": i for i in range(t.vocab_size)}
+    for name, idx in (("<unk>", 0), ("<eos>", 1), ("<pad>", 2)):      # specials match as substrings: keep them off the "tN" words
+        del vocab[f"t{idx}"]
+        vocab[name] = idx
+    for name, idx in (("<|image_pad|>", cfg.image_token_id), ("<|video_pad|>", cfg.video_token_id),
+                      ("<|vision_start|>", cfg.vision_start_token_id), ("<|vision_end|>", cfg.vision_start_token_id + 1)):
+        del vocab[f"t{idx}"]
+        vocab[name] = idx
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    fast = PreTrainedTokenizerFast(tokenizer_object=tok, eos_token="<eos>", pad_token="<pad>", unk_token="<unk>")
+    # special (added) tokens are split out before pre-tokenisation: the expanded "<|image_pad|><|image_pad|>..." run has no spaces
+    fast.add_special_tokens({"additional_special_tokens": ["<|image_pad|>", "<|video_pad|>", "<|vision_start|>", "<|vision_end|>"]})
+    fast.save_pretrained(str(tmp_path))
+    (tmp_path / "preprocessor_config.json").write_text(json.dumps(dict(image_mean=[0.5] * 3, image_std=[0.5] * 3)))
+
+
+def test_load_and_generate_user_api_end_to_end(tmp_path):
+    """load(path) -> (model, processor); generate(model, processor, prompt, image=...) through tokenizer, image processor,
+    placeholder expansion, ViT, prefill, graph decode, detokenizer - against the oracle on the same checkpoint."""
+    from mlx_vlm_amd import generate, load, stream_generate
+
+    cfg = oq.tiny_cfg()
+    W = oq.random_weights(cfg, seed=4321, dtype=BF, std=0.05, embed_std=0.2)
+    _write_tiny_checkpoint(tmp_path, cfg, W)
+    model, processor = load(str(tmp_path), kv_pool_tokens=4096, max_seqs=4)
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (100, 150, 3), dtype=np.uint8)          # not a multiple of 28: exercises smart resize
+    words = " ".join(f"t{int(i)}" for i in rng.integers(3, 1000, 9))
+    prompt = f"<|vision_start|> <|image_pad|> <|vision_end|> {words}"
+    out = generate(model, processor, prompt, image=img, max_tokens=10, temperature=0.0)
+    # the oracle on the same inputs
+    from oracle import image_processor as oip
+    pix, thw = oip.process([img.transpose(2, 0, 1)])
+    n_img = int(thw.prod()) // 4
+    ids = [cfg.vision_start_token_id] + [cfg.image_token_id] * n_img + [cfg.vision_start_token_id + 1] + \
+          [int(w[1:]) for w in words.split()]
+    ref_toks, ref_logits = oq.generate_greedy(W, cfg, np.array([ids]), torch.from_numpy(pix).to(BF), thw, max_tokens=10,
+                                              return_logits=True)
+    assert out.prompt_tokens == len(ids)
+    chunks = list(stream_generate(model, processor, prompt, image=img, max_tokens=10, temperature=0.0))
+    assert chunks[-1].finish_reason is not None          # closing chunk re-yields the last token with the flushed text
+    got = [r.token for r in chunks[:-1]]
+    if 1 in ref_toks:                      # <eos> stops generation like the reference's StoppingCriteria
+        ref_toks = ref_toks[:ref_toks.index(1)]
+    ok, n, margin = _tie_aware_equal(got[:len(ref_toks)], ref_toks, ref_logits, tol=3e-2)
+    assert ok, (got, ref_toks, n, margin)
+    # streamed text segments concatenate to the tokenizer's own decode of the generated ids (reference tokenizer_utils.py:19-86)
+    segs = "".join(r.text for r in chunks)
+    assert segs.split() == processor.tokenizer.decode(got).split() and out.text == segs
+    assert out.finish_reason in ("stop", "length") and out.generation_tokens >= 1 and out.prompt_tps > 0

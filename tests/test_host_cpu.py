@@ -230,3 +230,38 @@ def test_dp_path_gloo_world_size_2(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29613", str(script)],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "GLOO_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_load_errors_match_reference_contract(tmp_path):
+    """FileNotFoundError without a local directory / safetensors (reference utils.py:781-801,1209-1210), ValueError for an
+    unknown model_type (utils.py:633-635)."""
+    import json
+
+    from mlx_vlm_amd import load
+
+    with pytest.raises(FileNotFoundError):
+        load(str(tmp_path / "missing"))
+    (tmp_path / "config.json").write_text(json.dumps(dict(model_type="qwen2_vl")))
+    with pytest.raises(FileNotFoundError):
+        load(str(tmp_path))
+    from safetensors.torch import save_file
+
+    save_file({"x": torch.zeros(1)}, str(tmp_path / "model.safetensors"))
+    (tmp_path / "config.json").write_text(json.dumps(dict(model_type="not_a_model")))
+    with pytest.raises(ValueError):
+        load(str(tmp_path))
+
+
+def test_package_level_names_are_callable_in_any_import_order():
+    """`from mlx_vlm_amd import generate` after the submodule was imported (load() does that) must still be callable."""
+    import importlib
+
+    import mlx_vlm_amd
+
+    importlib.import_module("mlx_vlm_amd.generate")
+    importlib.import_module("mlx_vlm_amd.utils")
+    for name in ("load", "generate", "stream_generate", "batch_generate", "generate_step", "prepare_inputs"):
+        assert callable(getattr(mlx_vlm_amd, name)), name
+    from mlx_vlm_amd.generate import generate as fn
+
+    assert fn.__name__ == "generate"
