@@ -1,0 +1,373 @@
+"""Continuous batching over the paged KV pool: `BatchGenerator` with the reference's interface
+(mlx_vlm/generate/ar.py:2178-2887: insert / next / remove / stats / has_work, `GenerationBatch.Response` 937-943,
+`PromptProgress` 906-913, finish rules 1313-1316).
+
+What differs from the reference is the mechanism, not the contract.  The reference keeps one left-padded contiguous
+KV tensor per layer for the whole batch and re-packs it whenever the membership changes (`filter` / `extend`,
+cache.py:1100-1201).  Here every sequence owns pages of the pool; the batch owns a small block table with one row
+per batch row, so
+
+  * a finished request leaves by releasing its pages and, if it was not the last row, the last row takes its place:
+    one table row and three 4-byte state words are copied - no KV bytes move and nothing is padded;
+  * a new request joins after ONE varlen prefill launch over all admitted prompts (one ViT call over all their
+    images), by writing its first sampled token / position / context length into the next free row;
+  * a decode step is one hipGraph replay over the first 1, 2, 4 or 8 rows (the widths the weight-streaming kernels
+    are built for); rows past the live ones point at a scratch page.  The engine keeps one graph per width.
+
+The host never waits for the step in flight: `next()` returns the tokens that were the INPUTS of the step launched
+by the previous call (their copy to pinned memory was enqueued before that step), then enqueues the next step - the
+reference's `mx.async_eval` double buffering (ar.py:1044-1141), with the stop decision one step behind as there.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .models.cache import PAGE, PagedSequence
+from .models.qwen2_vl.language import DecodeState
+from .sample_utils import Sampler, make_sampler
+
+MAX_ROWS = 8          # widest decode step of the engine's GEMV kernels
+WIDTHS = (1, 2, 4, 8)
+
+
+@dataclass
+class PromptProgress:
+    """reference ar.py:906-913"""
+    uid: int
+    prompt_tokens: int
+    prompt_tps: float = 0.0
+    prompt_time: float = 0.0
+    cached_tokens: int = 0
+
+
+@dataclass
+class _Row:
+    uid: int
+    seq: PagedSequence
+    max_tokens: int
+    prompt_tokens: int
+    num_tokens: int = 0
+
+
+class BatchGenerator:
+    """`insert(prompts)` queues token-id prompts (shortest first, ar.py:2620-2623); every `next()` reports one token
+    per running request and advances the batch by one step.  `model` is the full `Model` (vision tower + language
+    model): per-request `prompt_kwargs` carry `pixel_values` / `image_grid_thw` and the ViT runs inside the admission
+    prefill.  Quantised KV, APC, speculative drafts and logits processors are outside the built path and are
+    rejected, not ignored."""
+
+    @dataclass
+    class Response:
+        uid: int
+        token: int
+        token_logprob: float
+        finish_reason: Optional[str]
+        top_logprobs: Optional[List[Tuple[int, float]]] = None
+
+    def __init__(self, model, processor=None, *, max_tokens: int = 128, stop_tokens=None,
+                 sampler: Optional[Sampler] = None, completion_batch_size: int = MAX_ROWS,
+                 prefill_batch_size: int = MAX_ROWS, compute_logprobs: bool = True, use_graph: bool = True, **kwargs):
+        unsupported = {k: v for k, v in kwargs.items() if v not in (None, False, 0, [], ())
+                       and k not in ("prefill_step_size", "kv_group_size", "kv_quant_scheme", "quantized_kv_start",
+                                     "greedy_sampling", "stream")}
+        if unsupported:
+            raise NotImplementedError(f"BatchGenerator: outside the built path: {sorted(unsupported)}")
+        self.model = model
+        self.lm = model.language_model
+        self.processor = processor
+        self.tokenizer = getattr(processor, "tokenizer", processor)
+        self.max_tokens = max_tokens
+        self.compute_logprobs = compute_logprobs
+        self.use_graph = use_graph
+        self.completion_batch_size = max(1, min(int(completion_batch_size), MAX_ROWS))
+        self.prefill_batch_size = max(1, int(prefill_batch_size))
+        self.sampler = sampler or make_sampler()
+        if not isinstance(self.sampler, Sampler):
+            raise TypeError("BatchGenerator samples on the device: pass a mlx_vlm_amd.sample_utils.Sampler (make_sampler)")
+        self._sargs = self.sampler.engine_args()
+        crit = getattr(self.tokenizer, "stopping_criteria", None)
+        self._stop = set(getattr(crit, "eos_token_ids", ()) or ())
+        self._stop.update(int(t) for t in (stop_tokens or ()))
+        self.uid_count = 0
+        self._unprocessed_sequences: List[tuple] = []
+        self._rows: List[_Row] = []
+        self._closed = False
+
+        lm, dev, cap = self.lm, self.lm.device, self.completion_batch_size
+        self._st = self._borrow_state(lm, cap)
+        pool = lm.pool
+        self._table = torch.zeros(cap, pool.max_pages, dtype=torch.int32, device=dev)
+        self._scratch_seq = PagedSequence(pool)          # one page nobody reads: where idle rows write their k / v
+        self._scratch_seq.reserve(1)
+        self._idle_row = torch.full((pool.max_pages,), self._scratch_seq.pages[0], dtype=torch.int32, device=dev)
+        self._table[:] = self._idle_row
+        self._lp = torch.zeros(cap, dtype=torch.float32, device=dev)      # logprob of the token sitting in st.tok
+        self._pin_tok = torch.empty(2, cap, dtype=torch.int32).pin_memory()
+        self._pin_lp = torch.empty(2, cap, dtype=torch.float32).pin_memory()
+        self._inflight: Optional[Tuple[int, torch.cuda.Event, List[int]]] = None
+        self._calls = 0
+        self._idle_steps = 0
+        self._width = 0
+
+        self._prompt_tokens_counter = 0
+        self._prompt_time_counter = 0.0
+        self._gen_tokens_counter = 0
+        self._gen_time_counter = 0.0
+        self._steps_counter = 0
+
+    @staticmethod
+    def _borrow_state(lm, cap: int) -> DecodeState:
+        """Decode states are carved from the model's bump arena (never returned): generators re-use a parked one."""
+        parked = lm.__dict__.setdefault("_batch_states", [])
+        for st in parked:
+            if st.B == cap and not getattr(st, "in_use", False):
+                break
+        else:
+            st = DecodeState(lm, cap)
+            parked.append(st)
+        st.in_use = True
+        for buf in (st.tok, st.pos, st.ctx, st.step):
+            buf.zero_()
+        return st
+
+    # ------------------------------------------------------------------ queue (reference ar.py:2584-2670)
+    def insert(self, prompts, max_tokens=None, prompt_kwargs: Optional[List[dict]] = None, logits_processors=None,
+               thinking_budget_criteria=None) -> List[int]:
+        if logits_processors or thinking_budget_criteria:
+            raise NotImplementedError("logits processors / thinking budgets are outside the built path")
+        if max_tokens is None or isinstance(max_tokens, int):
+            max_tokens = [max_tokens or self.max_tokens] * len(prompts)
+        if prompt_kwargs is None:
+            prompt_kwargs = [{}] * len(prompts)
+        if len(max_tokens) != len(prompts) or len(prompt_kwargs) != len(prompts):
+            raise ValueError("max_tokens / prompt_kwargs must have one entry per prompt")
+        uids = []
+        for p, m, kw in zip(prompts, max_tokens, prompt_kwargs):
+            ids = np.asarray(p, dtype=np.int64).reshape(-1)
+            if ids.size == 0:
+                raise ValueError("empty prompt")
+            self._unprocessed_sequences.append((self.uid_count, ids, int(m), dict(kw or {})))
+            uids.append(self.uid_count)
+            self.uid_count += 1
+        self._unprocessed_sequences.sort(key=lambda x: len(x[1]))
+        return uids
+
+    def remove(self, uid) -> bool:
+        for i, item in enumerate(self._unprocessed_sequences):
+            if item[0] == uid:
+                self._unprocessed_sequences.pop(i)
+                return True
+        for r, row in enumerate(self._rows):
+            if row.uid == uid:
+                self._drop_rows([r])
+                return True
+        return False
+
+    @property
+    def unprocessed_prompts(self):
+        return self._unprocessed_sequences
+
+    @property
+    def has_pending_prompts(self) -> bool:
+        return len(self._unprocessed_sequences) > 0
+
+    @property
+    def has_work(self) -> bool:
+        return bool(self._rows) or bool(self._unprocessed_sequences) or self._inflight is not None
+
+    def __len__(self):
+        return len(self._rows)
+
+    def stats(self):
+        from .generate import BatchStats, _peak_gb
+
+        s = BatchStats()
+        s.prompt_tokens = self._prompt_tokens_counter
+        s.prompt_time = self._prompt_time_counter
+        s.prompt_tps = self._prompt_tokens_counter / self._prompt_time_counter if self._prompt_time_counter > 0 else 0
+        s.generation_tokens = self._gen_tokens_counter
+        s.generation_time = self._gen_time_counter
+        s.generation_tps = self._gen_tokens_counter / self._gen_time_counter if self._gen_time_counter > 0 else 0
+        s.peak_memory = _peak_gb()
+        return s
+
+    def close(self):
+        if self._closed:
+            return
+        self._closed = True
+        torch.cuda.synchronize()
+        for row in self._rows:
+            row.seq.release()
+        self._rows = []
+        self._scratch_seq.release()
+        self._inflight = None
+        self._st.in_use = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ membership
+    def _drop_rows(self, gone: List[int]):
+        """Release the sequences in batch rows `gone`; keep the live rows dense by moving rows from the end into the
+        holes (stream-ordered after the step in flight)."""
+        st = self._st
+        gone_set = set(gone)
+        for r in gone:
+            self._rows[r].seq.release()
+        live_after = len(self._rows) - len(gone)
+        movers = [r for r in range(live_after, len(self._rows)) if r not in gone_set]
+        holes = sorted(r for r in gone if r < live_after)
+        for dst, src in zip(holes, movers):
+            for buf in (st.tok, st.pos, st.ctx, self._lp):
+                buf[dst:dst + 1].copy_(buf[src:src + 1])
+            self._table[dst].copy_(self._table[src])
+            self._rows[dst] = self._rows[src]
+        del self._rows[live_after:]
+        self._table[live_after:] = self._idle_row
+        self._park_idle_rows()
+
+    def _park_idle_rows(self):
+        """Rows past the live ones keep running inside a 2/4/8-wide step: context 0 on the scratch page."""
+        n = len(self._rows)
+        if n < self._st.B:
+            self._st.ctx[n:].zero_()
+            self._st.pos[n:].zero_()
+            self._st.tok[n:].zero_()
+        self._idle_steps = 0
+
+    def _admit(self) -> List[PromptProgress]:
+        """Prefill as many queued prompts as there are free rows (one ViT call, one varlen prefill launch)."""
+        from .generate import embed_requests
+
+        free = self.completion_batch_size - len(self._rows)
+        n = min(free, self.prefill_batch_size, len(self._unprocessed_sequences))
+        if n <= 0:
+            return []
+        lm, st = self.lm, self._st
+        batch, self._unprocessed_sequences = self._unprocessed_sequences[:n], self._unprocessed_sequences[n:]
+        tic = time.perf_counter()
+        ids_l = [b[1] for b in batch]
+        pix_l = [b[3].get("pixel_values") for b in batch]
+        grid_l = [b[3].get("image_grid_thw") for b in batch]
+        emb, pos, lens, deltas = embed_requests(self.model, ids_l, pix_l, grid_l)
+        caches = [lm.make_cache() for _ in batch]
+        for c, L, b in zip(caches, lens, batch):
+            c[0]._seq.reserve(L + b[2] + 2)          # prompt + every token it may generate + the step in flight
+        logits = lm.prefill(emb, pos, caches, lens, "last")
+        step0 = torch.zeros(1, dtype=torch.int32, device=logits.device)
+        tok0, lp0 = ops.sample(logits, step=step0, want_logprobs=self.compute_logprobs, **self._sargs)
+        r0 = len(self._rows)
+        ctx = np.asarray(lens, dtype=np.int32)
+        posn = ctx + np.asarray(deltas, dtype=np.int32)
+        state = torch.from_numpy(np.stack([posn, ctx])).to(lm.device)
+        st.tok[r0:r0 + n].copy_(tok0)
+        st.pos[r0:r0 + n].copy_(state[0])
+        st.ctx[r0:r0 + n].copy_(state[1])
+        if self.compute_logprobs:
+            self._lp[r0:r0 + n].copy_(lp0.gather(1, tok0.long()[:, None]).reshape(-1).float())
+        for i, (c, b, L) in enumerate(zip(caches, batch, lens)):
+            seq = c[0]._seq
+            self._table[r0 + i].copy_(lm.pool.block_table[seq.seq])
+            self._rows.append(_Row(uid=b[0], seq=seq, max_tokens=b[2], prompt_tokens=L))
+        torch.cuda.current_stream().synchronize()        # prompt time is wall time to the first token, as in the reference
+        dt = time.perf_counter() - tic
+        self._prompt_tokens_counter += int(sum(lens))
+        self._prompt_time_counter += dt
+        return [PromptProgress(uid=b[0], prompt_tokens=L, prompt_tps=L / dt if dt > 0 else 0.0, prompt_time=dt)
+                for b, L in zip(batch, lens)]
+
+    # ------------------------------------------------------------------ one scheduling round
+    def next(self):
+        """-> (prompt_responses, generation_responses), reference ar.py:2705-2887."""
+        tic = time.perf_counter()
+        responses: List[BatchGenerator.Response] = []
+        if self._inflight is not None:
+            slot, ev, uids = self._inflight
+            self._inflight = None
+            ev.synchronize()
+            toks, lps = self._pin_tok[slot].numpy(), self._pin_lp[slot].numpy()
+            live = {row.uid: r for r, row in enumerate(self._rows)}
+            gone = []
+            for i, uid in enumerate(uids):
+                r = live.get(uid)
+                if r is None:                      # removed by the caller since the snapshot
+                    continue
+                row = self._rows[r]
+                row.num_tokens += 1
+                tok = int(toks[i])
+                reason = "stop" if tok in self._stop else "length" if row.num_tokens >= row.max_tokens else None
+                if reason is not None:
+                    gone.append(r)
+                responses.append(self.Response(uid, tok, float(lps[i]) if self.compute_logprobs else 0.0, reason))
+            self._gen_tokens_counter += len(responses)
+            if gone:
+                self._drop_rows(gone)
+        decoding = bool(self._rows) or bool(responses)
+        t_admit = time.perf_counter()
+        prompt_responses = self._admit() if len(self._rows) < self.completion_batch_size else []
+        t_admit = time.perf_counter() - t_admit
+        if self._rows:
+            self._launch_step()
+        if decoding:
+            self._gen_time_counter += time.perf_counter() - tic - t_admit
+        return prompt_responses, responses
+
+    def _launch_step(self):
+        st, n = self._st, len(self._rows)
+        width = next(w for w in WIDTHS if w >= n)
+        if width != self._width or self._idle_steps >= 4 * PAGE:
+            self._width = width
+            self._park_idle_rows()
+        slot = self._calls & 1
+        self._calls += 1
+        self._pin_tok[slot, :n].copy_(st.tok[:n], non_blocking=True)
+        if self.compute_logprobs:
+            self._pin_lp[slot, :n].copy_(self._lp[:n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._inflight = (slot, ev, [row.uid for row in self._rows])
+        longest = max(row.prompt_tokens + row.max_tokens for row in self._rows) + 2
+        st.nsplit = 1 if longest <= 2048 else max(2, min(32, (longest + 16 * PAGE - 1) // (16 * PAGE)))
+        self.lm.decode_step_rows(st, width, self._table, self._sargs, use_graph=self.use_graph,
+                                 with_logprobs=self.compute_logprobs)
+        if self.compute_logprobs:
+            self._lp[:n].copy_(st.logprobs[:n].gather(1, st.tok[:n].long()[:, None]).reshape(-1).float())
+        for row in self._rows:
+            row.seq.offset += 1
+        self._idle_steps += 1
+        self._steps_counter += 1
+
+
+def generate_batch_continuous(model, input_ids_list, pixel_values_list, grids, *, max_tokens=128, stop_ids=(),
+                              sampler: Optional[Sampler] = None, batch_size: int = MAX_ROWS, use_graph: bool = True):
+    """The reference's `_generate_batch` loop (ar.py:3212-3232) over the continuous generator: every request is queued
+    at once, the generator keeps up to `batch_size` of them decoding and admits the next ones as rows free up.
+    -> (tokens per request without the stop token, BatchStats)"""
+    gen = BatchGenerator(model, None, max_tokens=max_tokens, stop_tokens=set(stop_ids), sampler=sampler,
+                         completion_batch_size=batch_size, prefill_batch_size=batch_size, compute_logprobs=False,
+                         use_graph=use_graph)
+    kw: List[Dict[str, Any]] = [dict(pixel_values=p, image_grid_thw=g) if p is not None else {}
+                                for p, g in zip(pixel_values_list, grids)]
+    uids = gen.insert([np.asarray(i).reshape(-1) for i in input_ids_list], max_tokens, prompt_kwargs=kw)
+    results = {u: [] for u in uids}
+    tic = time.perf_counter()
+    while gen.has_work:
+        _, out = gen.next()
+        for r in out:
+            if r.finish_reason != "stop":
+                results[r.uid].append(r.token)
+    total = time.perf_counter() - tic
+    stats = gen.stats()
+    gen.close()
+    stats.generation_time = max(total - stats.prompt_time, 1e-9)
+    stats.generation_tps = stats.generation_tokens / stats.generation_time
+    return [results[u] for u in uids], stats

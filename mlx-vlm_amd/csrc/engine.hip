@@ -25,15 +25,45 @@
 
 namespace {
 
+// One captured decode step.  The key is everything the captured launches bake in: the argument block and the
+// KV-pool view (both plain pointers / scalars).  A continuous batch changes width (1/2/4/8 rows) as requests come
+// and go, and a single-stream generate may interleave with it: each shape keeps its graph instead of re-capturing.
+struct DecodeGraph {
+  vlm_decode_args args;
+  vlm_kv_pool kv;
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  int launches;
+  unsigned long long last_use;
+};
+constexpr size_t MAX_DECODE_GRAPHS = 16;
+
 struct Llm {
   vlm_llm_config cfg;
   std::vector<vlm_llm_layer> layers;
   vlm_llm_globals g{};
   vlm_kv_pool kv{};
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
+  std::vector<DecodeGraph> graphs;
+  hipGraphExec_t exec = nullptr;      // the graph selected by the last vlm_llm_decode_graph_build
+  unsigned long long tick = 0;
   int launches = 0;
 };
+
+inline bool same_key(const DecodeGraph& g, const vlm_decode_args& a, const vlm_kv_pool& kv) {
+  const vlm_decode_args& b = g.args;
+  return a.B == b.B && a.tok == b.tok && a.pos == b.pos && a.ctx == b.ctx && a.step == b.step && a.h == b.h &&
+         a.qkv == b.qkv && a.attn == b.attn && a.act == b.act && a.logits == b.logits && a.logprobs == b.logprobs &&
+         a.scratch == b.scratch && a.part_o == b.part_o && a.part_ml == b.part_ml && a.sample_ws == b.sample_ws &&
+         a.out_ring == b.out_ring && a.ring_len == b.ring_len && a.nsplit == b.nsplit && a.temperature == b.temperature &&
+         a.top_p == b.top_p && a.min_p == b.min_p && a.top_k == b.top_k && a.seed == b.seed && kv.kpool == g.kv.kpool &&
+         kv.vpool == g.kv.vpool && kv.layer_stride == g.kv.layer_stride && kv.block_table == g.kv.block_table &&
+         kv.max_pages == g.kv.max_pages;
+}
+
+inline void drop_graph(DecodeGraph& g) {
+  if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (g.graph) (void)hipGraphDestroy(g.graph);
+}
 
 struct Vit {
   vlm_vit_config cfg;
@@ -62,8 +92,7 @@ extern "C" int vlm_llm_create(const vlm_llm_config* cfg, void** handle) {
 extern "C" int vlm_llm_destroy(void* handle) {
   Llm* m = static_cast<Llm*>(handle);
   if (!m) return 1;
-  if (m->exec) (void)hipGraphExecDestroy(m->exec);
-  if (m->graph) (void)hipGraphDestroy(m->graph);
+  for (DecodeGraph& g : m->graphs) drop_graph(g);
   delete m;
   return 0;
 }
@@ -195,22 +224,38 @@ extern "C" int vlm_llm_decode_graph_build(void* handle, const vlm_decode_args* a
   (void)stream;
   Llm* m = static_cast<Llm*>(handle);
   if (!m || !a || a->B <= 0 || !m->kv.kpool) return 1;
-  if (m->exec) { (void)hipGraphExecDestroy(m->exec); m->exec = nullptr; }
-  if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+  for (DecodeGraph& g : m->graphs) {
+    if (same_key(g, *a, m->kv)) {
+      g.last_use = ++m->tick;
+      m->exec = g.exec;
+      m->launches = g.launches;
+      return 0;
+    }
+  }
+  m->exec = nullptr;
   hipStream_t cap = nullptr;
   hipError_t e = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking);
   if (e != hipSuccess) return 1000 + (int)e;
   e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) { (void)hipStreamDestroy(cap); return 1000 + (int)e; }
-  int rc = decode_impl(m, a, (void*)cap, &m->launches, true);
-  hipGraph_t g = nullptr;
-  e = hipStreamEndCapture(cap, &g);
+  DecodeGraph ng{*a, m->kv, nullptr, nullptr, 0, ++m->tick};
+  int rc = decode_impl(m, a, (void*)cap, &ng.launches, true);
+  e = hipStreamEndCapture(cap, &ng.graph);
   (void)hipStreamDestroy(cap);
-  if (rc != 0) { if (g) (void)hipGraphDestroy(g); return rc; }
-  if (e != hipSuccess) return 1000 + (int)e;
-  m->graph = g;
-  e = hipGraphInstantiate(&m->exec, g, nullptr, nullptr, 0);
-  if (e != hipSuccess) return 1000 + (int)e;
+  if (rc != 0) { drop_graph(ng); return rc; }
+  if (e != hipSuccess) { drop_graph(ng); return 1000 + (int)e; }
+  e = hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) { drop_graph(ng); return 1000 + (int)e; }
+  if (m->graphs.size() >= MAX_DECODE_GRAPHS) {      // evict the least recently selected one
+    size_t lru = 0;
+    for (size_t i = 1; i < m->graphs.size(); ++i)
+      if (m->graphs[i].last_use < m->graphs[lru].last_use) lru = i;
+    drop_graph(m->graphs[lru]);
+    m->graphs.erase(m->graphs.begin() + (long)lru);
+  }
+  m->graphs.push_back(ng);
+  m->exec = ng.exec;
+  m->launches = ng.launches;
   return 0;
 }
 

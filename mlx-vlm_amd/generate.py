@@ -285,6 +285,39 @@ def generate(model, processor, prompt: Optional[str] = None, image=None, audio=N
 
 
 # ---------------------------------------------------------------------------------------------
+def embed_requests(model, input_ids_list, pixel_values_list, grids):
+    """Input embeddings of several requests for ONE varlen prefill: one ViT call over the concatenated patches of all
+    images (as the reference does per shape group, ar.py:3165-3167), features scattered into each request's
+    placeholder rows, per-request M-RoPE positions.  -> (embeds [sum L, D], position_ids [3, sum L], lengths, rope deltas)"""
+    lm = model.language_model
+    embs, poss, lens, deltas = [], [], [], []
+    has_pix = [p is not None for p in pixel_values_list]
+    feats_all = None
+    if any(has_pix):
+        grid_all = np.concatenate([np.asarray(g) for g, h in zip(grids, has_pix) if h], axis=0)
+        pv = torch.cat([torch.as_tensor(p) for p, h in zip(pixel_values_list, has_pix) if h], dim=0)
+        feats_all = model.vision_tower(pv, grid_all)
+    foff = 0
+    mm = model.config.vision_config.spatial_merge_size ** 2
+    for ids, pix, grid in zip(input_ids_list, pixel_values_list, grids):
+        ids = np.asarray(ids).reshape(1, -1)
+        emb = lm.embed_tokens(ids)
+        if pix is not None:
+            nfeat = int(np.prod(np.asarray(grid), axis=1).sum()) // mm
+            emb = model.merge_input_ids_with_image_features(model.config.image_token_id, model.config.video_token_id,
+                                                            feats_all[foff:foff + nfeat], emb, ids)
+            foff += nfeat
+            p, d = lm.get_rope_index(ids, np.asarray(grid), None, None)
+        else:
+            p, d = lm.get_rope_index(ids)
+            p = np.broadcast_to(p[None], (3,) + p.shape)
+        embs.append(emb.reshape(ids.shape[1], -1))
+        poss.append(np.asarray(p).reshape(3, -1))
+        lens.append(ids.shape[1])
+        deltas.append(int(np.asarray(d).reshape(-1)[0]))
+    return torch.cat(embs, dim=0), np.concatenate(poss, axis=1), lens, deltas
+
+
 def batch_generate_ids(model, input_ids_list: List[np.ndarray], pixel_values_list: List[Any], grids: List[Any], *,
                        max_tokens: int = 128, stop_ids=(), sampler: Optional[Sampler] = None, lookahead: int = 4,
                        use_graph: bool = True) -> Tuple[List[List[int]], BatchStats]:
@@ -305,34 +338,10 @@ def batch_generate_ids(model, input_ids_list: List[np.ndarray], pixel_values_lis
         idxs = order[i:i + B]
         i += B
         t0 = time.perf_counter()
-        embs, poss, lens, deltas = [], [], [], []
-        pix = [pixel_values_list[j] for j in idxs if pixel_values_list[j] is not None]
-        feats_all = None
-        if pix:
-            grid_all = np.concatenate([np.asarray(grids[j]) for j in idxs if pixel_values_list[j] is not None], axis=0)
-            pv = torch.cat([torch.as_tensor(p) for p in pix], dim=0)
-            feats_all = model.vision_tower(pv, grid_all)
-        foff = 0
-        mm = model.config.vision_config.spatial_merge_size ** 2
-        for j in idxs:
-            ids = np.asarray(input_ids_list[j]).reshape(1, -1)
-            emb = lm.embed_tokens(ids)
-            if pixel_values_list[j] is not None:
-                nfeat = int(np.prod(np.asarray(grids[j]), axis=1).sum()) // mm
-                emb = model.merge_input_ids_with_image_features(model.config.image_token_id, model.config.video_token_id,
-                                                                feats_all[foff:foff + nfeat], emb, ids)
-                foff += nfeat
-                p, d = lm.get_rope_index(ids, np.asarray(grids[j]), None, None)
-            else:
-                p, d = lm.get_rope_index(ids)
-                p = np.broadcast_to(p[None], (3,) + p.shape)
-            embs.append(emb.reshape(ids.shape[1], -1))
-            poss.append(np.asarray(p).reshape(3, -1))
-            lens.append(ids.shape[1])
-            deltas.append(int(np.asarray(d).reshape(-1)[0]))
+        emb_cat, pos_cat, lens, deltas = embed_requests(model, [input_ids_list[j] for j in idxs],
+                                                        [pixel_values_list[j] for j in idxs], [grids[j] for j in idxs])
         caches = lm.make_cache_batch(len(idxs))
-        logits = lm.prefill(torch.cat(embs, dim=0), np.concatenate(poss, axis=1), caches, lens, "last",
-                            reserve_extra=max_tokens + 2)
+        logits = lm.prefill(emb_cat, pos_cat, caches, lens, "last", reserve_extra=max_tokens + 2)
         step0 = torch.zeros(1, dtype=torch.int32, device=logits.device)
         tok0, _ = ops.sample(logits, step=step0, want_logprobs=False, **sargs)
         st = lm.decode_begin(caches, tok0, deltas, max_new_tokens=max_tokens + 1)

@@ -66,9 +66,10 @@ class DecodeState:
         self.sample_ws = ops.sample_workspace(B, dev)
         self.graph_key = None
 
-    def args(self, temperature=0.0, top_p=1.0, min_p=0.0, top_k=0, seed=0, with_logprobs=True):
+    def args(self, temperature=0.0, top_p=1.0, min_p=0.0, top_k=0, seed=0, with_logprobs=True, B=None):
+        """B < self.B: the step runs over the first B rows (every buffer is row-major, a prefix is a valid state)."""
         p = lambda t: t.data_ptr()  # noqa: E731
-        return _lib.DecodeArgs(self.B, p(self.tok), p(self.pos), p(self.ctx), p(self.step), p(self.h), p(self.qkv),
+        return _lib.DecodeArgs(self.B if B is None else int(B), p(self.tok), p(self.pos), p(self.ctx), p(self.step), p(self.h), p(self.qkv),
                                p(self.attn), p(self.act), p(self.logits),
                                p(self.logprobs) if (with_logprobs or temperature > 0) else None, p(self.scratch),
                                p(self.part_o), p(self.part_ml), p(self.sample_ws), p(self.out_ring), self.ring_len,
@@ -406,6 +407,29 @@ class LanguageModel:
                 check(L.vlm_llm_decode_step(self._handle, C.byref(args), stream), "decode_step")
         for s in st.seqs:
             s.offset += n_steps
+
+    def decode_step_rows(self, st: DecodeState, B: int, block_table: torch.Tensor, sampler_args: dict,
+                         use_graph: bool = True, with_logprobs: bool = True):
+        """One decode step over rows 0..B-1 of `st` (B in {1, 2, 4, 8}), addressing the KV pool through the caller's own
+        `block_table` (int32 [>= B, max_pages]).  A continuous batch keeps such a table so that a sequence changes
+        batch row by copying one table row - no KV bytes move (the reference's `filter`/`extend` copy the caches,
+        cache.py:1100-1201).  Graphs are cached per (B, nsplit, table, sampler) inside the engine."""
+        L = _lib.lib()
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        pool = self.pool
+        kv = _lib.KvPool(pool.kpool.data_ptr(), pool.vpool.data_ptr(), pool.layer_stride, block_table.data_ptr(),
+                         pool.max_pages)
+        check(L.vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
+        args = st.args(B=B, with_logprobs=with_logprobs, **sampler_args)
+        if use_graph:
+            key = ("rows", B, st.nsplit, block_table.data_ptr(), with_logprobs, tuple(sorted(sampler_args.items())))
+            if st.graph_key != key or getattr(self, "_graph_owner", None) is not st:
+                check(L.vlm_llm_decode_graph_build(self._handle, C.byref(args), stream), "decode_graph_build")
+                st.graph_key = key
+                self._graph_owner = st
+            check(L.vlm_llm_decode_graph_launch(self._handle, stream), "decode_graph_launch")
+        else:
+            check(L.vlm_llm_decode_step(self._handle, C.byref(args), stream), "decode_step")
 
     # ------------------------------------------------------------------ module contract (reference language.py:404-518)
     def __call__(self, inputs, inputs_embeds=None, mask=None, cache=None, **kwargs):

@@ -427,3 +427,127 @@ def test_load_and_generate_user_api_end_to_end(tmp_path):
     segs = "".join(r.text for r in chunks)
     assert segs.split() == processor.tokenizer.decode(got).split() and out.text == segs
     assert out.finish_reason in ("stop", "length") and out.generation_tokens >= 1 and out.prompt_tps > 0
+
+
+# ---- continuous batching: BatchGenerator over the paged pool
+def _mixed_requests(cfg, n, seed0=40):
+    reqs = []
+    for i in range(n):
+        if i % 3 == 2:
+            reqs.append((np.random.default_rng(seed0 + i).integers(3, 1000, (1, 6 + 2 * i)), None, None))
+        else:
+            reqs.append(synth_request(cfg, [(56, 56 + 28 * (i % 2))], n_text=5 + i, seed=seed0 + i))
+    return reqs
+
+
+def _single_runs(model, reqs, max_tokens):
+    from mlx_vlm_amd.generate import generate_step
+
+    outs = []
+    for (ids, pix, thw), m in zip(reqs, max_tokens):
+        kw = dict(image_grid_thw=thw) if thw is not None else {}
+        outs.append([(t, float(lp[t])) for t, lp in generate_step(ids, model, torch.from_numpy(pix) if pix is not None else None,
+                                                                 None, max_tokens=m, **kw)])
+    return outs
+
+
+def _insert_all(gen, reqs, max_tokens):
+    kw = [dict(pixel_values=torch.from_numpy(p), image_grid_thw=g) if p is not None else {} for _, p, g in reqs]
+    return gen.insert([r[0].reshape(-1) for r in reqs], list(max_tokens), prompt_kwargs=kw)
+
+
+def test_batch_generator_continuous_equals_single_requests(tiny):
+    """11 requests (images and text, different lengths, different max_tokens) through 4 decode rows: rows finish at
+    different steps, the last row moves into the hole, queued prompts are admitted as rows free up, the step width
+    goes 4 -> 2 -> 1 at the end.  Every request must produce exactly the tokens (and the token logprobs) it produces
+    alone; the reference's finish rules (ar.py:1313-1316) and response fields are checked on the way."""
+    from mlx_vlm_amd.batch import BatchGenerator
+
+    cfg, W, model = tiny
+    reqs = _mixed_requests(cfg, 11)
+    max_tokens = [4 + (5 * i) % 11 for i in range(11)]
+    singles = _single_runs(model, reqs, max_tokens)
+    free_before = len(model.language_model.pool._free_seqs)
+    gen = BatchGenerator(model, None, max_tokens=7, completion_batch_size=4, prefill_batch_size=2)
+    uids = _insert_all(gen, reqs, max_tokens)
+    assert uids == list(range(11)) and gen.has_pending_prompts and len(gen.unprocessed_prompts) == 11
+    got = {u: [] for u in uids}
+    finished, prompt_seen, widths = {}, {}, set()
+    rounds = 0
+    while gen.has_work:
+        prompts, out = gen.next()
+        rounds += 1
+        assert len(gen) <= 4 and rounds < 400
+        widths.add(gen._width)
+        for p in prompts:
+            prompt_seen[p.uid] = p.prompt_tokens
+        seen = set()
+        for r in out:
+            assert r.uid not in finished and r.uid not in seen          # one token per running request per round
+            seen.add(r.uid)
+            got[r.uid].append((r.token, r.token_logprob))
+            if r.finish_reason is not None:
+                finished[r.uid] = r.finish_reason
+    assert widths >= {1, 2, 4}
+    assert prompt_seen == {u: reqs[u][0].size for u in uids}
+    assert finished == {u: "length" for u in uids}
+    for u in uids:
+        assert [t for t, _ in got[u]] == [t for t, _ in singles[u]], (u, got[u], singles[u])
+        np.testing.assert_allclose([lp for _, lp in got[u]], [lp for _, lp in singles[u]], atol=2 ** -6, rtol=2 ** -7)
+    st = gen.stats()
+    assert st.generation_tokens == sum(max_tokens) and st.prompt_tokens == sum(r[0].size for r in reqs)
+    assert st.prompt_tps > 0 and st.generation_tps > 0
+    gen.close()
+    assert len(model.language_model.pool._free_seqs) == free_before      # every sequence and the scratch page returned
+
+
+def test_batch_generator_stop_token_and_remove(tiny):
+    """A stop token ends one request with finish_reason "stop" (the token is still reported, as in the reference);
+    remove(uid) drops a running request between rounds; the other rows are untouched by either."""
+    from mlx_vlm_amd.batch import BatchGenerator
+
+    cfg, W, model = tiny
+    reqs = _mixed_requests(cfg, 5, seed0=70)
+    singles = [[t for t, _ in s] for s in _single_runs(model, reqs, [12] * 5)]
+    stop_tok = singles[1][4]
+    want = []
+    for s in singles:                       # what each request emits with that stop token in force
+        want.append(s[:s.index(stop_tok) + 1] if stop_tok in s else s)
+    gen = BatchGenerator(model, None, max_tokens=12, stop_tokens={stop_tok}, completion_batch_size=8, compute_logprobs=False)
+    uids = _insert_all(gen, reqs, [12] * 5)
+    victim = next(u for u in uids if u != 1 and len(want[u]) >= 6)
+    got = {u: [] for u in uids}
+    reasons = {}
+    rounds = 0
+    while gen.has_work:
+        _, out = gen.next()
+        rounds += 1
+        for r in out:
+            got[r.uid].append(r.token)
+            assert r.token_logprob == 0.0
+            if r.finish_reason:
+                reasons[r.uid] = r.finish_reason
+        if rounds == 4:
+            assert gen.remove(victim) and not gen.remove(12345)
+    assert len(got[victim]) == 3 and victim not in reasons            # rounds 2..4 reported its first three tokens
+    assert got[victim] == want[victim][:3]
+    for u in uids:
+        if u == victim:
+            continue
+        assert got[u] == want[u], (u, got[u], want[u])
+        assert reasons[u] == ("stop" if want[u][-1] == stop_tok else "length")
+    assert reasons[uids[1]] == "stop"
+    gen.close()
+
+
+def test_generate_batch_continuous_more_requests_than_rows(tiny):
+    from mlx_vlm_amd.batch import generate_batch_continuous
+
+    cfg, W, model = tiny
+    reqs = _mixed_requests(cfg, 13, seed0=90)
+    singles = [[t for t, _ in s] for s in _single_runs(model, reqs, [9] * 13)]
+    toks, stats = generate_batch_continuous(model, [r[0].reshape(-1) for r in reqs],
+                                            [torch.from_numpy(r[1]) if r[1] is not None else None for r in reqs],
+                                            [r[2] for r in reqs], max_tokens=9)
+    assert toks == singles
+    assert stats.generation_tokens == 9 * 13 and stats.generation_tps > 0
