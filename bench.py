@@ -140,6 +140,49 @@ def batch_decode_throughput(model, cfg, B=8, max_tokens=64):
             "prompt_tps": stats.prompt_tps, "e2e_tokens_per_s": sum(len(t) for t in toks) / dt}
 
 
+def continuous_batch_throughput(model, cfg, n_requests=24, rows=8):
+    """Extra: a queue of requests with different lengths (336x336 image + 64-token prompt, 24..96 new tokens) through the
+    continuous `BatchGenerator` (8 decode rows; rows are refilled from the queue as requests finish) vs the same queue
+    as static batches of 8 that wait for their longest member."""
+    from mlx_vlm_amd.batch import generate_batch_continuous
+    from mlx_vlm_amd.generate import batch_generate_ids
+
+    reqs = [build_request(cfg, 336, 64, 700 + i) for i in range(n_requests)]
+    ids = [r[0].reshape(-1) for r in reqs]
+    pix = [r[1] for r in reqs]
+    thw = [r[2] for r in reqs]
+    lens = [24 + (37 * i) % 73 for i in range(n_requests)]
+    out = {"requests": n_requests, "rows": rows, "image": "336x336", "new_tokens": f"{min(lens)}..{max(lens)}"}
+
+    def run_continuous():
+        from mlx_vlm_amd.batch import BatchGenerator
+        gen = BatchGenerator(model, None, completion_batch_size=rows, prefill_batch_size=rows, compute_logprobs=False)
+        kw = [dict(pixel_values=p, image_grid_thw=g) for p, g in zip(pix, thw)]
+        gen.insert(ids, lens, prompt_kwargs=kw)
+        n = 0
+        while gen.has_work:
+            n += len(gen.next()[1])
+        gen.close()
+        return n
+
+    def run_static():
+        n = 0
+        for i in range(0, n_requests, rows):     # a static batch runs to its longest member
+            sl = slice(i, i + rows)
+            toks, _ = batch_generate_ids(model, ids[sl], pix[sl], thw[sl], max_tokens=max(lens[sl]))
+            n += sum(min(len(t), m) for t, m in zip(toks, lens[sl]))
+        return n
+
+    for name, fn in (("continuous", run_continuous), ("static", run_static)):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = fn()
+        torch.cuda.synchronize()
+        out[name + "_useful_tokens_per_s"] = n / (time.perf_counter() - t0)
+    return out
+
+
 def cpu_baseline(threads):
     """Reference-equivalent CPU path (the oracle: torch-CPU restatement of the reference; the reference itself needs
     `mlx`, which is not installable here).  Bounded sample, see the returned `sample` string."""
@@ -276,6 +319,10 @@ def main():
             extras["batch8"] = batch_decode_throughput(model, cfg, 8, 64)
         except Exception as e:   # an extra must never cost the headline line
             extras["batch8"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            extras["continuous"] = continuous_batch_throughput(model, cfg)
+        except Exception as e:
+            extras["continuous"] = {"error": f"{type(e).__name__}: {e}"}
     cpu = None
     if rank == 0 and ws == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(min(os.cpu_count() or 1, 32))
@@ -318,6 +365,7 @@ def main():
                                    "workload": f"{args.vit_batch} x 336x336 images per call ({args.vit_batch * 576} patches)",
                                    "ms_per_call": dt336 * 1e3}
             out["batch8_decode"] = extras["batch8"]
+            out["continuous_batching"] = extras["continuous"]
             out["vision_single_448_images_per_s"] = ips448
             out["vision_single_448_tflops"] = ips448 * VIT_TFLOP_448
         if cpu is not None:

@@ -19,6 +19,7 @@ _LAZY = {
     "generate_step": ("generate", "generate_step"),
     "GenerationResult": ("generate", "GenerationResult"),
     "BatchResponse": ("generate", "BatchResponse"),
+    "BatchGenerator": ("batch", "BatchGenerator"),
     "make_sampler": ("sample_utils", "make_sampler"),
 }
 

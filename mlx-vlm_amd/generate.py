@@ -382,8 +382,10 @@ def batch_generate_ids(model, input_ids_list: List[np.ndarray], pixel_values_lis
 
 def batch_generate(model, processor, images=None, audios=None, prompts: Optional[List[str]] = None, max_tokens: int = 128,
                    verbose: bool = False, group_by_shape: bool = True, track_image_sizes: bool = True, **kwargs) -> BatchResponse:
-    """reference ar.py:2890-3096: prompts (+ one image each) -> BatchResponse.  Requests are tokenised on the host,
-    then run through batch_generate_ids (static decode batches of up to 8)."""
+    """reference ar.py:2890-3096: prompts (+ one image each) -> BatchResponse.  Requests are tokenised on the host and
+    queued on a `BatchGenerator` (continuous batching, as the reference's `_generate_batch` does, ar.py:3199-3232);
+    `continuous=False` runs them as static decode batches of up to 8 (`batch_generate_ids`)."""
+    from .batch import generate_batch_continuous
     from .utils import prepare_inputs
 
     if audios:
@@ -401,7 +403,8 @@ def batch_generate(model, processor, images=None, audios=None, prompts: Optional
     stop_ids = tuple(getattr(stop, "eos_token_ids", ()) or ())
     smp = _resolve_sampler(kwargs.pop("sampler", None), kwargs.pop("temperature", 0.0), kwargs.pop("top_p", 1.0),
                            kwargs.pop("min_p", 0.0), kwargs.pop("top_k", 0), kwargs.pop("seed", None))
-    toks, stats = batch_generate_ids(model, ids_l, pix_l, grid_l, max_tokens=max_tokens, stop_ids=stop_ids, sampler=smp)
+    run = generate_batch_continuous if kwargs.pop("continuous", True) else batch_generate_ids
+    toks, stats = run(model, ids_l, pix_l, grid_l, max_tokens=max_tokens, stop_ids=stop_ids, sampler=smp)
     texts = [tokenizer.decode(t) if hasattr(tokenizer, "decode") else "" for t in toks]
     return BatchResponse(texts=texts, stats=stats, tokens=toks)
 

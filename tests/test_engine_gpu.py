@@ -427,6 +427,15 @@ def test_load_and_generate_user_api_end_to_end(tmp_path):
     segs = "".join(r.text for r in chunks)
     assert segs.split() == processor.tokenizer.decode(got).split() and out.text == segs
     assert out.finish_reason in ("stop", "length") and out.generation_tokens >= 1 and out.prompt_tps > 0
+    # batch_generate (continuous batching underneath): image + text-only + image requests, same tokens as the stream
+    from mlx_vlm_amd import BatchGenerator, batch_generate
+    resp = batch_generate(model, processor, images=[img, None, img], prompts=[prompt, words, prompt], max_tokens=6)
+    assert len(resp.texts) == 3 and resp.texts[0] == resp.texts[2] and resp.stats.generation_tokens >= 3
+    assert len(resp.tokens[0]) >= 1 and resp.tokens[0] == got[:len(resp.tokens[0])]
+    static = batch_generate(model, processor, images=[img, None, img], prompts=[prompt, words, prompt], max_tokens=6,
+                            continuous=False)
+    assert static.tokens == resp.tokens
+    assert callable(BatchGenerator)
 
 
 # ---- continuous batching: BatchGenerator over the paged pool
