@@ -140,3 +140,19 @@ def check(rc: int, what: str = ""):
     if rc != 0:
         kind = {1: "bad argument", 2: "unsupported shape"}.get(rc, f"HIP error {rc - 1000}" if rc >= 1000 else "error")
         raise VlmHipError(f"libvlm_hip {what} failed: rc={rc} ({kind})")
+
+
+def h2d(x, device):
+    """Host array / CPU tensor -> device, staged through pinned memory and enqueued asynchronously on the current stream.
+    A copy from pageable memory makes the host wait for the stream to drain first: with it, the host cannot enqueue the
+    LLM prefill while the ViT runs, and an admission on a side stream would stall the decode loop at every small index
+    upload.  The pinned staging block is recycled by torch's host allocator once the copy has executed."""
+    import numpy as np
+    import torch
+
+    t = torch.from_numpy(np.ascontiguousarray(x)) if isinstance(x, np.ndarray) else x
+    if t.device.type != "cpu":
+        return t.to(device)
+    if not torch.cuda.is_available() or torch.device(device).type == "cpu":
+        return t.to(device)
+    return t.contiguous().pin_memory().to(device, non_blocking=True)

@@ -10,7 +10,10 @@ per batch row, so
   * a finished request leaves by releasing its pages and, if it was not the last row, the last row takes its place:
     one table row and three 4-byte state words are copied - no KV bytes move and nothing is padded;
   * a new request joins after ONE varlen prefill launch over all admitted prompts (one ViT call over all their
-    images), by writing its first sampled token / position / context length into the next free row;
+    images), by writing its first sampled token / position / context length into the next free row.  That admission
+    (ViT + prefill + first sample) is enqueued on a SECOND HIP stream: the running rows keep decoding underneath it
+    and the new rows join at the first `next()` that finds its event complete (the reference alternates decode and
+    prefill on one stream, ar.py:2705-2887, so every admission stalls the running rows);
   * a decode step is one hipGraph replay over the first 1, 2, 4 or 8 rows (the widths the weight-streaming kernels
     are built for); rows past the live ones point at a scratch page.  The engine keeps one graph per width.
 
@@ -20,14 +23,16 @@ reference's `mx.async_eval` double buffering (ar.py:1044-1141), with the stop de
 """
 from __future__ import annotations
 
+import contextlib
 import time
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
 
 from . import ops
+from ._lib import h2d
 from .models.cache import PAGE, PagedSequence
 from .models.qwen2_vl.language import DecodeState
 from .sample_utils import Sampler, make_sampler
@@ -55,6 +60,20 @@ class _Row:
     num_tokens: int = 0
 
 
+@dataclass
+class _Admission:
+    """A prefill in flight on the side stream: everything the join needs, kept alive until then."""
+    batch: list
+    caches: list
+    lens: List[int]
+    tok0: torch.Tensor
+    lp0: Optional[torch.Tensor]
+    state: torch.Tensor            # int32 [2, n]: rope position, context length
+    event: torch.cuda.Event
+    tic: float
+    removed: set = field(default_factory=set)
+
+
 class BatchGenerator:
     """`insert(prompts)` queues token-id prompts (shortest first, ar.py:2620-2623); every `next()` reports one token
     per running request and advances the batch by one step.  `model` is the full `Model` (vision tower + language
@@ -72,7 +91,8 @@ class BatchGenerator:
 
     def __init__(self, model, processor=None, *, max_tokens: int = 128, stop_tokens=None,
                  sampler: Optional[Sampler] = None, completion_batch_size: int = MAX_ROWS,
-                 prefill_batch_size: int = MAX_ROWS, compute_logprobs: bool = True, use_graph: bool = True, **kwargs):
+                 prefill_batch_size: int = MAX_ROWS, compute_logprobs: bool = True, use_graph: bool = True,
+                 async_prefill: bool = True, **kwargs):
         unsupported = {k: v for k, v in kwargs.items() if v not in (None, False, 0, [], ())
                        and k not in ("prefill_step_size", "kv_group_size", "kv_quant_scheme", "quantized_kv_start",
                                      "greedy_sampling", "stream")}
@@ -85,6 +105,7 @@ class BatchGenerator:
         self.max_tokens = max_tokens
         self.compute_logprobs = compute_logprobs
         self.use_graph = use_graph
+        self.async_prefill = async_prefill
         self.completion_batch_size = max(1, min(int(completion_batch_size), MAX_ROWS))
         self.prefill_batch_size = max(1, int(prefill_batch_size))
         self.sampler = sampler or make_sampler()
@@ -110,7 +131,9 @@ class BatchGenerator:
         self._lp = torch.zeros(cap, dtype=torch.float32, device=dev)      # logprob of the token sitting in st.tok
         self._pin_tok = torch.empty(2, cap, dtype=torch.int32).pin_memory()
         self._pin_lp = torch.empty(2, cap, dtype=torch.float32).pin_memory()
-        self._inflight: Optional[Tuple[int, torch.cuda.Event, List[int]]] = None
+        self._inflight: Optional[Tuple[int, torch.cuda.Event, List[int], float]] = None
+        self._pending: Optional[_Admission] = None
+        self._side = torch.cuda.Stream(device=dev) if async_prefill else None
         self._calls = 0
         self._idle_steps = 0
         self._width = 0
@@ -167,6 +190,10 @@ class BatchGenerator:
             if row.uid == uid:
                 self._drop_rows([r])
                 return True
+        if self._pending is not None and any(b[0] == uid for b in self._pending.batch) \
+                and uid not in self._pending.removed:
+            self._pending.removed.add(uid)           # being prefilled: dropped when the admission joins
+            return True
         return False
 
     @property
@@ -175,11 +202,12 @@ class BatchGenerator:
 
     @property
     def has_pending_prompts(self) -> bool:
-        return len(self._unprocessed_sequences) > 0
+        return len(self._unprocessed_sequences) > 0 or self._pending is not None
 
     @property
     def has_work(self) -> bool:
-        return bool(self._rows) or bool(self._unprocessed_sequences) or self._inflight is not None
+        return (bool(self._rows) or bool(self._unprocessed_sequences) or self._inflight is not None
+                or self._pending is not None)
 
     def __len__(self):
         return len(self._rows)
@@ -202,6 +230,10 @@ class BatchGenerator:
             return
         self._closed = True
         torch.cuda.synchronize()
+        if self._pending is not None:
+            for c in self._pending.caches:
+                c[0]._seq.release()
+            self._pending = None
         for row in self._rows:
             row.seq.release()
         self._rows = []
@@ -244,56 +276,79 @@ class BatchGenerator:
             self._st.tok[n:].zero_()
         self._idle_steps = 0
 
-    def _admit(self) -> List[PromptProgress]:
-        """Prefill as many queued prompts as there are free rows (one ViT call, one varlen prefill launch)."""
+    def _admit_begin(self):
+        """Enqueue the prefill of as many queued prompts as there are free rows (one ViT call over all their images, one
+        varlen prefill launch, first tokens sampled on the device) - on the side stream when async_prefill."""
         from .generate import embed_requests
 
         free = self.completion_batch_size - len(self._rows)
         n = min(free, self.prefill_batch_size, len(self._unprocessed_sequences))
-        if n <= 0:
-            return []
-        lm, st = self.lm, self._st
+        if n <= 0 or self._pending is not None:
+            return
+        lm = self.lm
         batch, self._unprocessed_sequences = self._unprocessed_sequences[:n], self._unprocessed_sequences[n:]
         tic = time.perf_counter()
-        ids_l = [b[1] for b in batch]
-        pix_l = [b[3].get("pixel_values") for b in batch]
-        grid_l = [b[3].get("image_grid_thw") for b in batch]
-        emb, pos, lens, deltas = embed_requests(self.model, ids_l, pix_l, grid_l)
-        caches = [lm.make_cache() for _ in batch]
-        for c, L, b in zip(caches, lens, batch):
-            c[0]._seq.reserve(L + b[2] + 2)          # prompt + every token it may generate + the step in flight
-        logits = lm.prefill(emb, pos, caches, lens, "last")
-        step0 = torch.zeros(1, dtype=torch.int32, device=logits.device)
-        tok0, lp0 = ops.sample(logits, step=step0, want_logprobs=self.compute_logprobs, **self._sargs)
-        r0 = len(self._rows)
-        ctx = np.asarray(lens, dtype=np.int32)
-        posn = ctx + np.asarray(deltas, dtype=np.int32)
-        state = torch.from_numpy(np.stack([posn, ctx])).to(lm.device)
-        st.tok[r0:r0 + n].copy_(tok0)
-        st.pos[r0:r0 + n].copy_(state[0])
-        st.ctx[r0:r0 + n].copy_(state[1])
-        if self.compute_logprobs:
-            self._lp[r0:r0 + n].copy_(lp0.gather(1, tok0.long()[:, None]).reshape(-1).float())
-        for i, (c, b, L) in enumerate(zip(caches, batch, lens)):
+        where = contextlib.nullcontext()
+        if self._side is not None:
+            # pages released so far may still be written by steps already enqueued on the main stream
+            gate = torch.cuda.Event()
+            gate.record()
+            self._side.wait_event(gate)
+            where = torch.cuda.stream(self._side)
+        with where:
+            ids_l = [b[1] for b in batch]
+            pix_l = [b[3].get("pixel_values") for b in batch]
+            grid_l = [b[3].get("image_grid_thw") for b in batch]
+            emb, pos, lens, deltas = embed_requests(self.model, ids_l, pix_l, grid_l)
+            caches = [lm.make_cache() for _ in batch]
+            for c, L, b in zip(caches, lens, batch):
+                c[0]._seq.reserve(L + b[2] + 2)          # prompt + every token it may generate + the step in flight
+            logits = lm.prefill(emb, pos, caches, lens, "last")
+            step0 = torch.zeros(1, dtype=torch.int32, device=logits.device)
+            tok0, lp = ops.sample(logits, step=step0, want_logprobs=self.compute_logprobs, **self._sargs)
+            lp0 = lp.gather(1, tok0.long()[:, None]).reshape(-1).float() if self.compute_logprobs else None
+            ctx = np.asarray(lens, dtype=np.int32)
+            state = h2d(np.stack([ctx + np.asarray(deltas, dtype=np.int32), ctx]), lm.device)
+            ev = torch.cuda.Event()
+            ev.record()
+        self._pending = _Admission(batch, caches, list(lens), tok0, lp0, state, ev, tic)
+
+    def _admit_join(self) -> List[PromptProgress]:
+        """The admission has run (or the main stream is made to wait for it): its requests take the next free rows."""
+        p, self._pending = self._pending, None
+        torch.cuda.current_stream().wait_event(p.event)
+        if self._side is None:
+            p.event.synchronize()                     # synchronous mode: prompt time = wall time to the first token
+        st, lm = self._st, self.lm
+        out = []
+        dt = time.perf_counter() - p.tic              # wall time to the first token, as the reference reports it
+        for i, (c, b, L) in enumerate(zip(p.caches, p.batch, p.lens)):
             seq = c[0]._seq
-            self._table[r0 + i].copy_(lm.pool.block_table[seq.seq])
+            if b[0] in p.removed:
+                seq.release()
+                continue
+            r = len(self._rows)
+            st.tok[r:r + 1].copy_(p.tok0[i:i + 1])
+            st.pos[r:r + 1].copy_(p.state[0, i:i + 1])
+            st.ctx[r:r + 1].copy_(p.state[1, i:i + 1])
+            if p.lp0 is not None:
+                self._lp[r:r + 1].copy_(p.lp0[i:i + 1])
+            self._table[r].copy_(lm.pool.block_table[seq.seq])
             self._rows.append(_Row(uid=b[0], seq=seq, max_tokens=b[2], prompt_tokens=L))
-        torch.cuda.current_stream().synchronize()        # prompt time is wall time to the first token, as in the reference
-        dt = time.perf_counter() - tic
-        self._prompt_tokens_counter += int(sum(lens))
+            out.append(PromptProgress(uid=b[0], prompt_tokens=L, prompt_tps=L / dt if dt > 0 else 0.0, prompt_time=dt))
+        self._prompt_tokens_counter += int(sum(p.lens))
         self._prompt_time_counter += dt
-        return [PromptProgress(uid=b[0], prompt_tokens=L, prompt_tps=L / dt if dt > 0 else 0.0, prompt_time=dt)
-                for b, L in zip(batch, lens)]
+        return out
 
     # ------------------------------------------------------------------ one scheduling round
     def next(self):
         """-> (prompt_responses, generation_responses), reference ar.py:2705-2887."""
-        tic = time.perf_counter()
         responses: List[BatchGenerator.Response] = []
         if self._inflight is not None:
-            slot, ev, uids = self._inflight
+            slot, ev, uids, t_launch = self._inflight
             self._inflight = None
             ev.synchronize()
+            self._gen_time_counter += time.perf_counter() - t_launch
             toks, lps = self._pin_tok[slot].numpy(), self._pin_lp[slot].numpy()
             live = {row.uid: r for r, row in enumerate(self._rows)}
             gone = []
@@ -311,14 +366,18 @@ class BatchGenerator:
             self._gen_tokens_counter += len(responses)
             if gone:
                 self._drop_rows(gone)
-        decoding = bool(self._rows) or bool(responses)
-        t_admit = time.perf_counter()
-        prompt_responses = self._admit() if len(self._rows) < self.completion_batch_size else []
-        t_admit = time.perf_counter() - t_admit
+        prompt_responses: List[PromptProgress] = []
+        if self._side is None:
+            self._admit_begin()                      # synchronous mode: prefill, join, then decode (the reference's order)
+        if self._pending is not None:
+            if not self._rows:
+                self._pending.event.synchronize()    # nothing to decode meanwhile
+            if self._side is None or self._pending.event.query():
+                prompt_responses = self._admit_join()
         if self._rows:
             self._launch_step()
-        if decoding:
-            self._gen_time_counter += time.perf_counter() - tic - t_admit
+        if self._side is not None:
+            self._admit_begin()                      # under the step just enqueued
         return prompt_responses, responses
 
     def _launch_step(self):
@@ -334,7 +393,7 @@ class BatchGenerator:
             self._pin_lp[slot, :n].copy_(self._lp[:n], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self._inflight = (slot, ev, [row.uid for row in self._rows])
+        self._inflight = (slot, ev, [row.uid for row in self._rows], time.perf_counter())
         longest = max(row.prompt_tokens + row.max_tokens for row in self._rows) + 2
         st.nsplit = 1 if longest <= 2048 else max(2, min(32, (longest + 16 * PAGE - 1) // (16 * PAGE)))
         self.lm.decode_step_rows(st, width, self._table, self._sargs, use_graph=self.use_graph,

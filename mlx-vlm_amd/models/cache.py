@@ -20,6 +20,8 @@ from typing import List, Optional
 import numpy as np
 import torch
 
+from .._lib import h2d
+
 PAGE = 64
 # V key-slot order inside a page (csrc/common.cuh vlm_vslot): slot of token `w` of the page
 VSLOT = [(w & 32) + 8 * (((w & 31) & 15) >> 2) + 4 * ((w & 31) >> 4) + (w & 3) for w in range(PAGE)]
@@ -127,7 +129,7 @@ class KVPool:
             pages.append(p)
             grew = True
         if grew:
-            self.block_table[seq].copy_(torch.from_numpy(self.block_table_host[seq]), non_blocking=False)
+            self.block_table[seq].copy_(h2d(self.block_table_host[seq].copy(), self.block_table.device))
 
     @property
     def nbytes(self):

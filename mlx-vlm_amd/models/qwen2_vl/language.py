@@ -199,7 +199,7 @@ class LanguageModel:
 
     def embed_tokens(self, input_ids) -> torch.Tensor:
         """nn.Embedding (reference language.py:164,179).  input_ids [B, L] -> [B, L, D]"""
-        ids = torch.as_tensor(_to_np(input_ids), dtype=torch.int32).to(self.device)
+        ids = _lib.h2d(np.asarray(_to_np(input_ids), dtype=np.int32), self.device)
         B, Lq = ids.shape
         out = ops.embed_gather(ids.reshape(-1), self._w["embed"])
         return out.view(B, Lq, -1)
@@ -308,14 +308,14 @@ class LanguageModel:
         nqb = int(sum((n + 127) // 128 for n in lengths))
         pos = np.ascontiguousarray(position_ids, dtype=np.int32)
         i32 = torch.int32
-        pos_d = torch.from_numpy(pos).to(dev)
-        meta = torch.from_numpy(np.concatenate([kv_seq, kv_slot, cu])).to(dev)
+        pos_d = _lib.h2d(pos, dev)
+        meta = _lib.h2d(np.concatenate([kv_seq, kv_slot, cu]), dev)
         kv_seq_d, kv_slot_d, cu_d = meta[:T], meta[T:2 * T], meta[2 * T:]
         if logits_rows == "last":
             rows = (cu[1:] - 1).astype(np.int32)
         else:
             rows = np.arange(T, dtype=np.int32)
-        rows_d = torch.from_numpy(rows).to(dev)
+        rows_d = _lib.h2d(rows, dev)
         bf = torch.bfloat16
         h = inputs_embeds.contiguous()
         xn = torch.empty(T, D, dtype=bf, device=dev)
@@ -366,12 +366,12 @@ class LanguageModel:
         ctx = np.array([s.offset for s in seqs], dtype=np.int32)
         pos = ctx + np.asarray(rope_deltas, dtype=np.int64).reshape(-1).astype(np.int32)
         host = np.concatenate([pos, ctx, np.zeros(1, np.int32)])
-        dev = torch.from_numpy(host).to(self.device)
+        dev = _lib.h2d(host, self.device)
         st.pos.copy_(dev[:B]); st.ctx.copy_(dev[B:2 * B]); st.step.copy_(dev[2 * B:])
         if isinstance(first_tokens, torch.Tensor):
             st.tok.copy_(first_tokens.reshape(-1).to(torch.int32))
         else:
-            st.tok.copy_(torch.from_numpy(np.asarray(first_tokens, dtype=np.int32).reshape(-1)).to(self.device))
+            st.tok.copy_(_lib.h2d(np.asarray(first_tokens, dtype=np.int32).reshape(-1), self.device))
         st.seqs = seqs
         return st
 

@@ -8,7 +8,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-from ... import ops
+from ... import _lib, ops
 from ..base import InputEmbeddingsFeatures
 from .config import ModelConfig
 from .language import LanguageModel, _to_np
@@ -77,7 +77,7 @@ class Model:
                 f"Number of image token positions ({n}) does not match number of image features ({image_features.shape[0]})")
         B, Lq, D = inputs_embeds.shape
         rows = np.nonzero(pos.reshape(-1))[0].astype(np.int32)
-        rows_d = torch.from_numpy(rows).to(inputs_embeds.device)
+        rows_d = _lib.h2d(rows, inputs_embeds.device)
         flat = inputs_embeds.reshape(B * Lq, D)
         ops.scatter_rows_(image_features.contiguous(), rows_d, flat)
         return flat.view(B, Lq, D)

@@ -132,8 +132,8 @@ class VisionModel:
                 lens += [h * w] * t
             cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
             nqb = int(sum((l + 127) // 128 for l in lens))
-            hit = (torch.cos(freqs).to(self.device), torch.sin(freqs).to(self.device),
-                   torch.from_numpy(cu).to(self.device), len(lens), nqb, int(len(set(lens)) == 1))
+            hit = (_lib.h2d(torch.cos(freqs), self.device), _lib.h2d(torch.sin(freqs), self.device),
+                   _lib.h2d(cu, self.device), len(lens), nqb, int(len(set(lens)) == 1))
             if len(self._tab_cache) > 64:
                 self._tab_cache.clear()
             self._tab_cache[key] = hit
@@ -147,7 +147,7 @@ class VisionModel:
 
         c = self.config
         if not hidden_states.is_cuda:
-            hidden_states = hidden_states.to(self.device)
+            hidden_states = _lib.h2d(hidden_states, self.device)
         N = hidden_states.shape[0]
         # PatchEmbed (vision.py:93-101): astype(weight dtype) + zero pad of K (the channels-last move is folded
         # into the weight, see load_weights)
