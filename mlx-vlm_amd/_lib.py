@@ -142,11 +142,58 @@ def check(rc: int, what: str = ""):
         raise VlmHipError(f"libvlm_hip {what} failed: rc={rc} ({kind})")
 
 
+class _PinnedRing:
+    """One pinned staging buffer for every small host -> device upload of the process.  `Tensor.pin_memory()` per
+    upload goes through torch's pinned-memory allocator: a size class it has no idle block for costs a
+    hipHostMalloc (tens of ms for MB-sized blocks - measured as sporadic 60 ms stalls inside the prefill enqueue).
+    Regions are handed out in address order and wrap around; a region is reused only after the copy that read it
+    has executed (event per upload)."""
+
+    def __init__(self, nbytes: int = 64 << 20):
+        import collections
+
+        import torch
+
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        self.head = 0
+        self.inflight = collections.deque()           # (start, end, event), oldest first
+
+    def stage(self, t, device):
+        import torch
+
+        n = t.numel() * t.element_size()
+        if n == 0 or n > self.buf.numel() // 2:
+            return t.to(device)                       # rare and large: plain (synchronising) copy
+        start = (self.head + 255) & ~255
+        if start + n > self.buf.numel():
+            start = 0
+        end = start + n
+        while self.inflight:
+            s0, e0, ev = self.inflight[0]
+            if s0 < end and start < e0:
+                ev.synchronize()                      # the ring has come around to a region still being read
+            elif not ev.query():
+                break
+            self.inflight.popleft()
+        view = self.buf[start:end].view(t.dtype).view(t.shape)
+        view.copy_(t)
+        out = view.to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.inflight.append((start, end, ev))
+        self.head = end
+        return out
+
+
+_ring = None
+
+
 def h2d(x, device):
     """Host array / CPU tensor -> device, staged through pinned memory and enqueued asynchronously on the current stream.
     A copy from pageable memory makes the host wait for the stream to drain first: with it, the host cannot enqueue the
     LLM prefill while the ViT runs, and an admission on a side stream would stall the decode loop at every small index
-    upload.  The pinned staging block is recycled by torch's host allocator once the copy has executed."""
+    upload."""
+    global _ring
     import numpy as np
     import torch
 
@@ -155,4 +202,6 @@ def h2d(x, device):
         return t.to(device)
     if not torch.cuda.is_available() or torch.device(device).type == "cpu":
         return t.to(device)
-    return t.contiguous().pin_memory().to(device, non_blocking=True)
+    if _ring is None:
+        _ring = _PinnedRing()
+    return _ring.stage(t.contiguous(), device)

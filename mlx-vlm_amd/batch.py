@@ -13,7 +13,9 @@ per batch row, so
     images), by writing its first sampled token / position / context length into the next free row.  That admission
     (ViT + prefill + first sample) is enqueued on a SECOND HIP stream: the running rows keep decoding underneath it
     and the new rows join at the first `next()` that finds its event complete (the reference alternates decode and
-    prefill on one stream, ar.py:2705-2887, so every admission stalls the running rows);
+    prefill on one stream, ar.py:2705-2887, so every admission stalls the running rows).  Admissions run AHEAD of
+    the free rows: up to `prefill_ahead` prefilled requests wait with their pages, so a row that finishes is refilled
+    in the same `next()` call instead of idling for the length of a prefill;
   * a decode step is one hipGraph replay over the first 1, 2, 4 or 8 rows (the widths the weight-streaming kernels
     are built for); rows past the live ones point at a scratch page.  The engine keeps one graph per width.
 
@@ -72,6 +74,10 @@ class _Admission:
     event: torch.cuda.Event
     tic: float
     removed: set = field(default_factory=set)
+    joined: int = 0                # requests of `batch` already given a row (a join takes as many as there are free rows)
+
+    def waiting(self) -> int:
+        return sum(1 for b in self.batch[self.joined:] if b[0] not in self.removed)
 
 
 class BatchGenerator:
@@ -92,7 +98,7 @@ class BatchGenerator:
     def __init__(self, model, processor=None, *, max_tokens: int = 128, stop_tokens=None,
                  sampler: Optional[Sampler] = None, completion_batch_size: int = MAX_ROWS,
                  prefill_batch_size: int = MAX_ROWS, compute_logprobs: bool = True, use_graph: bool = True,
-                 async_prefill: bool = True, **kwargs):
+                 async_prefill: bool = True, prefill_ahead: int = 2, **kwargs):
         unsupported = {k: v for k, v in kwargs.items() if v not in (None, False, 0, [], ())
                        and k not in ("prefill_step_size", "kv_group_size", "kv_quant_scheme", "quantized_kv_start",
                                      "greedy_sampling", "stream")}
@@ -106,6 +112,7 @@ class BatchGenerator:
         self.compute_logprobs = compute_logprobs
         self.use_graph = use_graph
         self.async_prefill = async_prefill
+        self.prefill_ahead = max(0, int(prefill_ahead)) if async_prefill else 0
         self.completion_batch_size = max(1, min(int(completion_batch_size), MAX_ROWS))
         self.prefill_batch_size = max(1, int(prefill_batch_size))
         self.sampler = sampler or make_sampler()
@@ -132,7 +139,7 @@ class BatchGenerator:
         self._pin_tok = torch.empty(2, cap, dtype=torch.int32).pin_memory()
         self._pin_lp = torch.empty(2, cap, dtype=torch.float32).pin_memory()
         self._inflight: Optional[Tuple[int, torch.cuda.Event, List[int], float]] = None
-        self._pending: Optional[_Admission] = None
+        self._pending: List[_Admission] = []         # oldest first
         self._side = torch.cuda.Stream(device=dev) if async_prefill else None
         self._calls = 0
         self._idle_steps = 0
@@ -190,10 +197,10 @@ class BatchGenerator:
             if row.uid == uid:
                 self._drop_rows([r])
                 return True
-        if self._pending is not None and any(b[0] == uid for b in self._pending.batch) \
-                and uid not in self._pending.removed:
-            self._pending.removed.add(uid)           # being prefilled: dropped when the admission joins
-            return True
+        for p in self._pending:                      # being prefilled / waiting for a row: dropped at the join
+            if uid not in p.removed and any(b[0] == uid for b in p.batch[p.joined:]):
+                p.removed.add(uid)
+                return True
         return False
 
     @property
@@ -202,12 +209,12 @@ class BatchGenerator:
 
     @property
     def has_pending_prompts(self) -> bool:
-        return len(self._unprocessed_sequences) > 0 or self._pending is not None
+        return len(self._unprocessed_sequences) > 0 or bool(self._pending)
 
     @property
     def has_work(self) -> bool:
         return (bool(self._rows) or bool(self._unprocessed_sequences) or self._inflight is not None
-                or self._pending is not None)
+                or any(p.waiting() for p in self._pending))
 
     def __len__(self):
         return len(self._rows)
@@ -230,10 +237,10 @@ class BatchGenerator:
             return
         self._closed = True
         torch.cuda.synchronize()
-        if self._pending is not None:
-            for c in self._pending.caches:
+        for p in self._pending:
+            for c in p.caches[p.joined:]:
                 c[0]._seq.release()
-            self._pending = None
+        self._pending = []
         for row in self._rows:
             row.seq.release()
         self._rows = []
@@ -282,8 +289,9 @@ class BatchGenerator:
         from .generate import embed_requests
 
         free = self.completion_batch_size - len(self._rows)
-        n = min(free, self.prefill_batch_size, len(self._unprocessed_sequences))
-        if n <= 0 or self._pending is not None:
+        ahead = sum(p.waiting() for p in self._pending)
+        n = min(free + self.prefill_ahead - ahead, self.prefill_batch_size, len(self._unprocessed_sequences))
+        if n <= 0:
             return
         lm = self.lm
         batch, self._unprocessed_sequences = self._unprocessed_sequences[:n], self._unprocessed_sequences[n:]
@@ -311,33 +319,46 @@ class BatchGenerator:
             state = h2d(np.stack([ctx + np.asarray(deltas, dtype=np.int32), ctx]), lm.device)
             ev = torch.cuda.Event()
             ev.record()
-        self._pending = _Admission(batch, caches, list(lens), tok0, lp0, state, ev, tic)
+        self._pending.append(_Admission(batch, caches, list(lens), tok0, lp0, state, ev, tic))
 
     def _admit_join(self) -> List[PromptProgress]:
-        """The admission has run (or the main stream is made to wait for it): its requests take the next free rows."""
-        p, self._pending = self._pending, None
-        torch.cuda.current_stream().wait_event(p.event)
-        if self._side is None:
-            p.event.synchronize()                     # synchronous mode: prompt time = wall time to the first token
+        """Give free rows to prefilled requests, oldest admission first; an admission whose event has not fired is
+        waited for only when there is nothing to decode meanwhile."""
         st, lm = self._st, self.lm
-        out = []
-        dt = time.perf_counter() - p.tic              # wall time to the first token, as the reference reports it
-        for i, (c, b, L) in enumerate(zip(p.caches, p.batch, p.lens)):
-            seq = c[0]._seq
-            if b[0] in p.removed:
-                seq.release()
-                continue
-            r = len(self._rows)
-            st.tok[r:r + 1].copy_(p.tok0[i:i + 1])
-            st.pos[r:r + 1].copy_(p.state[0, i:i + 1])
-            st.ctx[r:r + 1].copy_(p.state[1, i:i + 1])
-            if p.lp0 is not None:
-                self._lp[r:r + 1].copy_(p.lp0[i:i + 1])
-            self._table[r].copy_(lm.pool.block_table[seq.seq])
-            self._rows.append(_Row(uid=b[0], seq=seq, max_tokens=b[2], prompt_tokens=L))
-            out.append(PromptProgress(uid=b[0], prompt_tokens=L, prompt_tps=L / dt if dt > 0 else 0.0, prompt_time=dt))
-        self._prompt_tokens_counter += int(sum(p.lens))
-        self._prompt_time_counter += dt
+        out: List[PromptProgress] = []
+        while self._pending and len(self._rows) < self.completion_batch_size:
+            p = self._pending[0]
+            if not p.event.query():
+                if self._side is not None and (self._rows or out):
+                    break                             # keep decoding; it joins at a later round
+                p.event.synchronize()                 # synchronous mode, or nothing to decode meanwhile
+            torch.cuda.current_stream().wait_event(p.event)
+            dt = time.perf_counter() - p.tic          # wall time to the first token, as the reference reports it
+            if p.joined == 0:
+                self._prompt_tokens_counter += int(sum(p.lens))
+                self._prompt_time_counter += dt
+            while p.joined < len(p.batch) and len(self._rows) < self.completion_batch_size:
+                i = p.joined
+                p.joined += 1
+                b, L, seq = p.batch[i], p.lens[i], p.caches[i][0]._seq
+                if b[0] in p.removed:
+                    seq.release()
+                    continue
+                r = len(self._rows)
+                st.tok[r:r + 1].copy_(p.tok0[i:i + 1])
+                st.pos[r:r + 1].copy_(p.state[0, i:i + 1])
+                st.ctx[r:r + 1].copy_(p.state[1, i:i + 1])
+                if p.lp0 is not None:
+                    self._lp[r:r + 1].copy_(p.lp0[i:i + 1])
+                self._table[r].copy_(lm.pool.block_table[seq.seq])
+                self._rows.append(_Row(uid=b[0], seq=seq, max_tokens=b[2], prompt_tokens=L))
+                out.append(PromptProgress(uid=b[0], prompt_tokens=L, prompt_tps=L / dt if dt > 0 else 0.0, prompt_time=dt))
+            if p.joined >= len(p.batch):
+                self._pending.pop(0)
+            elif not p.waiting():                     # only removed requests left
+                for c in p.caches[p.joined:]:
+                    c[0]._seq.release()
+                self._pending.pop(0)
         return out
 
     # ------------------------------------------------------------------ one scheduling round
@@ -366,14 +387,9 @@ class BatchGenerator:
             self._gen_tokens_counter += len(responses)
             if gone:
                 self._drop_rows(gone)
-        prompt_responses: List[PromptProgress] = []
         if self._side is None:
             self._admit_begin()                      # synchronous mode: prefill, join, then decode (the reference's order)
-        if self._pending is not None:
-            if not self._rows:
-                self._pending.event.synchronize()    # nothing to decode meanwhile
-            if self._side is None or self._pending.event.query():
-                prompt_responses = self._admit_join()
+        prompt_responses = self._admit_join()
         if self._rows:
             self._launch_step()
         if self._side is not None:

@@ -336,37 +336,58 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 // per-process fp32 workspace of the split-K path (grown on demand; never (re)allocated while the stream is capturing)
-float* g_splitk_ws = nullptr;
-size_t g_splitk_ws_bytes = 0;
+// Split-K partials: one workspace PER STREAM (a prefill on a side stream may run under another one), sized once for
+// everything the automatic policy can ask for: split-K is taken only when M*N < 256 tiles of 64x64 = 2^20 outputs and
+// splits <= 8, i.e. <= 32 MiB of fp32 partials.  No growth, hence no device-wide synchronisation in the launch path
+// (only the forced-split test hook can exceed the size and re-allocates).
+struct SplitkWs {
+  hipStream_t st;
+  float* p;
+  size_t bytes;
+};
+constexpr size_t SPLITK_WS_BYTES = 34u << 20;
+constexpr int MAX_SPLITK_WS = 8;
+SplitkWs g_splitk_ws[MAX_SPLITK_WS];
+int g_n_splitk_ws = 0;
 int g_splitk = 0;   // 0 = automatic, -1 = never (vlm_gemm_set_staging mode 8), n > 1 = forced split count (test hook, 9: 4)
 
-bool splitk_workspace(size_t bytes, hipStream_t st) {
-  if (bytes <= g_splitk_ws_bytes) return true;
+float* splitk_workspace(size_t bytes, hipStream_t st) {
+  SplitkWs* slot = nullptr;
+  for (int i = 0; i < g_n_splitk_ws; ++i)
+    if (g_splitk_ws[i].st == st) slot = &g_splitk_ws[i];
+  if (slot && bytes <= slot->bytes) return slot->p;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
-  if (hipDeviceSynchronize() != hipSuccess) return false;   // nobody may still read the old buffer
-  if (g_splitk_ws) (void)hipFree(g_splitk_ws);
-  g_splitk_ws = nullptr;
-  g_splitk_ws_bytes = 0;
-  const size_t want = bytes + (bytes >> 1);
-  if (hipMalloc(reinterpret_cast<void**>(&g_splitk_ws), want) != hipSuccess) return false;
-  g_splitk_ws_bytes = want;
-  return true;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+  if (!slot) {
+    if (g_n_splitk_ws == MAX_SPLITK_WS) return nullptr;      // caller falls back to the single-pass kernels
+    slot = &g_splitk_ws[g_n_splitk_ws];
+    *slot = SplitkWs{st, nullptr, 0};
+  } else {
+    if (hipStreamSynchronize(st) != hipSuccess) return nullptr;   // forced-split hook only: nobody may still read the old one
+    (void)hipFree(slot->p);
+    slot->p = nullptr;
+    slot->bytes = 0;
+  }
+  const size_t want = bytes > SPLITK_WS_BYTES ? bytes + (bytes >> 1) : SPLITK_WS_BYTES;
+  if (hipMalloc(reinterpret_cast<void**>(&slot->p), want) != hipSuccess) return nullptr;
+  slot->bytes = want;
+  if (slot == &g_splitk_ws[g_n_splitk_ws]) ++g_n_splitk_ws;
+  return slot->p;
 }
 
 template <int EPI>
 int launch_splitk(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
-                  int ldw, int ldc, int ldres, int splits, hipStream_t st) {
+                  int ldw, int ldc, int ldres, int splits, float* ws, hipStream_t st) {
   const int kchunk = vlm_cdiv(vlm_cdiv(K, splits), BK) * BK;
   splits = vlm_cdiv(K, kchunk);
   const int tiles_m = vlm_cdiv(M, 64), tiles_n = vlm_cdiv(N, 64), nwg = tiles_m * tiles_n;
   const size_t lds = 4 * (size_t)(64 + 64) * ROWB;   // four stages (see the 64x64 K loop)
   hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, VLM_EPI_NONE, true, true>), dim3(nwg, splits), dim3(256), lds, st,
                      (const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
-                     reinterpret_cast<bf16_t*>(g_splitk_ws), M, N, K, lda, ldw, N, 0, tiles_n, nwg, kchunk);
+                     reinterpret_cast<bf16_t*>(ws), M, N, K, lda, ldw, N, 0, tiles_n, nwg, kchunk);
   const long items = (long)M * (N >> 3);
   hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
-                     (const float*)g_splitk_ws, splits, (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, ldc, ldres);
+                     (const float*)ws, splits, (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, ldc, ldres);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
 }
@@ -395,8 +416,10 @@ int launch_epi(const void* A, const void* W, const void* bias, const void* res, 
     const long t64 = (long)vlm_cdiv(M, 64) * vlm_cdiv(N, 64);
     int splits = g_splitk > 1 ? g_splitk : 0;
     if (!splits && t64 < 256 && K >= 2048) splits = (int)std::min<long>(8, std::max<long>(2, (512 + t64 - 1) / t64));
-    if (splits > 1 && K / splits >= 4 * BK && splitk_workspace((size_t)splits * M * N * sizeof(float), st))
-      return launch_splitk<EPI>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, splits, st);
+    if (splits > 1 && K / splits >= 4 * BK) {
+      if (float* ws = splitk_workspace((size_t)splits * M * N * sizeof(float), st))
+        return launch_splitk<EPI>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, splits, ws, st);
+    }
   }
 #define CFG(BMV, BNV)                                                                                            \
   (glds ? launch_cfg<BMV, BNV, EPI, true>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st)                \
