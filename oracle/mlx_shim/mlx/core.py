@@ -953,7 +953,9 @@ class _Fast:
             else:
                 s = s + m.to(torch.float32)
         p = torch.softmax(s, dim=-1)
-        return array((p @ vf).to(tq.dtype))
+        # mlx/fast.cpp: q, k, v are cast to result_type(q, k, v), which is also the output type
+        out_t = torch.promote_types(torch.promote_types(tq.dtype, tk.dtype), tv.dtype)
+        return array((p @ vf).to(out_t))
 
     @staticmethod
     def rope(x, dims, *, traditional, base, scale, offset, freqs=None, stream=None):

@@ -41,13 +41,22 @@ F32 = torch.float32
 # --------------------------------------------------------------------------
 # dense ops
 # --------------------------------------------------------------------------
+def _result_type(*tensors):
+    """MLX type promotion of array operands (bf16 with f32 -> f32).  Same-dtype graphs are unaffected; it matters for
+    models that let float32 pixel values into a bf16 network without a cast (llava_bunny)."""
+    t = tensors[0].dtype
+    for x in tensors[1:]:
+        t = torch.promote_types(t, x.dtype)
+    return t
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None):
     """nn.Linear: y = x @ W.T + b (models/qwen2_vl/vision.py:129-130,168-169;
     language.py:52-55; mlp.py:9-11).  fp32 accumulate, one rounding."""
     y = x.to(F32) @ w.to(F32).T
     if b is not None:
         y = y + b.to(F32)
-    return y.to(x.dtype)
+    return y.to(_result_type(x, w))
 
 
 def layer_norm(x, w, b, eps: float = 1e-6):
@@ -70,7 +79,7 @@ def rms_norm(x, w, eps: float = 1e-6):
 
 def add(a, b):
     """residual add in T (vision.py:188-193; language.py:151-153)."""
-    return (a.to(F32) + b.to(F32)).to(a.dtype)
+    return (a.to(F32) + b.to(F32)).to(_result_type(a, b))
 
 
 def _c(v: float, T):
@@ -133,7 +142,7 @@ def sdpa(q, k, v, scale: float, causal: bool = False, q_offset: int = 0,
     if key_mask is not None:
         s = s.masked_fill(~key_mask[:, None, None, :], float("-inf"))
     p = torch.softmax(s, dim=-1)
-    return (p @ vf).to(q.dtype)
+    return (p @ vf).to(_result_type(q, k, v))
 
 
 # --------------------------------------------------------------------------
