@@ -157,6 +157,8 @@ typedef struct vlm_llm_config {
   int hidden, n_layers, inter, n_heads, n_kv_heads, head_dim, vocab;
   float rms_eps;
   int mrope_sec0, mrope_sec1; /* mrope_section[0], [1] */
+  float attn_scale;           /* softmax scale of the attention; 0 = head_dim ** -0.5.  Set when the engine's head_dim is a
+                                 zero-padded form of the model's (e.g. 64 -> 128, llava_bunny language.py:24-25) */
 } vlm_llm_config;
 
 typedef struct vlm_llm_layer {

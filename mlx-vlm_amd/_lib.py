@@ -17,7 +17,8 @@ c_void_p, c_int, c_float, c_uint, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c
 
 class LlmConfig(C.Structure):
     _fields_ = [("hidden", c_int), ("n_layers", c_int), ("inter", c_int), ("n_heads", c_int), ("n_kv_heads", c_int),
-                ("head_dim", c_int), ("vocab", c_int), ("rms_eps", c_float), ("mrope_sec0", c_int), ("mrope_sec1", c_int)]
+                ("head_dim", c_int), ("vocab", c_int), ("rms_eps", c_float), ("mrope_sec0", c_int), ("mrope_sec1", c_int),
+                ("attn_scale", c_float)]
 
 
 class LlmLayer(C.Structure):

@@ -124,7 +124,7 @@ extern "C" int vlm_llm_prefill(void* handle, const vlm_prefill_args* a, void* st
   const vlm_llm_config& c = m->cfg;
   const int D = c.hidden, hd = c.head_dim, Hq = c.n_heads, Hkv = c.n_kv_heads;
   const int QKV = (Hq + 2 * Hkv) * hd, T = a->T;
-  const float scale = 1.0f / sqrtf((float)hd);
+  const float scale = c.attn_scale > 0.f ? c.attn_scale : 1.0f / sqrtf((float)hd);
   for (int i = 0; i < c.n_layers; ++i) {
     const vlm_llm_layer& w = m->layers[i];
     // xn = RMSNorm(h)
@@ -162,7 +162,7 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
   const vlm_llm_config& c = m->cfg;
   const int D = c.hidden, hd = c.head_dim, Hq = c.n_heads, Hkv = c.n_kv_heads, B = a->B;
   const int QKV = (Hq + 2 * Hkv) * hd;
-  const float scale = 1.0f / sqrtf((float)hd);
+  const float scale = c.attn_scale > 0.f ? c.attn_scale : 1.0f / sqrtf((float)hd);
   int n = 0;
   // h = embed[tok]
   TRY(vlm_embed_gather(a->tok, m->g.embed, a->h, B, D, D, c.vocab, stream)); ++n;

@@ -104,7 +104,8 @@ class LanguageModel:
 
     @property
     def head_dim(self):
-        return self.args.hidden_size // self.args.num_attention_heads
+        """An explicit `args.head_dim` wins (a model whose heads are zero-padded to a width the kernels have)."""
+        return getattr(self.args, "head_dim", None) or self.args.hidden_size // self.args.num_attention_heads
 
     @property
     def n_kv_heads(self):
@@ -143,7 +144,8 @@ class LanguageModel:
 
         cfg = _lib.LlmConfig(t.hidden_size, t.num_hidden_layers, t.intermediate_size, t.num_attention_heads,
                              t.num_key_value_heads, self.head_dim, t.vocab_size, float(t.rms_norm_eps),
-                             int(self.mrope_section[0]), int(self.mrope_section[1]))
+                             int(self.mrope_section[0]), int(self.mrope_section[1]),
+                             float(getattr(t, "attn_scale", 0.0) or 0.0))
         h = C.c_void_p()
         check(L.vlm_llm_create(C.byref(cfg), C.byref(h)), "llm_create")
         self._handle = h
@@ -171,7 +173,11 @@ class LanguageModel:
         norm = self.arena.put(g("model.norm.weight"))
         hd = self.head_dim
         # compute_inv_freq (reference rope_utils.py:1042-1043), fp32 on the host
-        inv_freq = self.arena.put((1.0 / (t.rope_theta ** (torch.arange(0, hd, 2).to(torch.float32) / hd))).to(dev))
+        # `args.rope_dim` < head_dim: only the first rope_dim / 2 pairs rotate (the rest get angle 0 = identity)
+        rd = getattr(t, "rope_dim", None) or hd
+        inv = torch.zeros(hd // 2, dtype=torch.float32)
+        inv[: rd // 2] = 1.0 / (t.rope_theta ** (torch.arange(0, rd, 2).to(torch.float32) / rd))
+        inv_freq = self.arena.put(inv.to(dev))
         self._w.update(embed=embed, head=head, norm=norm, inv_freq=inv_freq)
         gl = _lib.LlmGlobals(embed.data_ptr(), norm.data_ptr(), head.data_ptr(), inv_freq.data_ptr())
         check(L.vlm_llm_set_globals(h, C.byref(gl)), "llm_set_globals")
