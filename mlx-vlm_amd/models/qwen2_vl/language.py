@@ -129,7 +129,7 @@ class LanguageModel:
         # ... and the big matrices live in ONE allocation too, in the order a decode step streams them, so the
         # driver can map the region with large page fragments (A/B knob: VLM_WEIGHT_ARENA=0 -> separate tensors)
         qkv_rows = (t.num_attention_heads + 2 * t.num_key_value_heads) * self.head_dim
-        per_layer = (qkv_rows + t.hidden_size + 3 * t.intermediate_size) * t.hidden_size * 2
+        per_layer = (qkv_rows + t.num_attention_heads * self.head_dim + 3 * t.intermediate_size) * t.hidden_size * 2
         n_big = t.num_hidden_layers * per_layer + (1 if t.tie_word_embeddings else 2) * t.vocab_size * t.hidden_size * 2
         use_wa = os.environ.get("VLM_WEIGHT_ARENA", "1") != "0"
         self.warena = Arena(n_big + (4 * t.num_hidden_layers + 4) * 4096, device=dev, zero=False) if use_wa else None

@@ -63,3 +63,25 @@ def bf16_close(a: torch.Tensor, b: torch.Tensor, ulps: float = 2.0, frac_exact: 
     rep = f"max_err={float(err.max()):.4g} rms={rms:.4g} bad={nbad}/{a.numel()} exact={exact:.3f}"
     ok = nbad == 0 and exact >= frac_exact and bool(torch.isfinite(a).all())
     return ok, rep
+
+
+def build_bunny_model(cfg, W, device="cuda", **kw):
+    """nanoLLaVA product model from oracle/llava_bunny.py's config + weights (already under the sanitized names)."""
+    from mlx_vlm_amd.models.llava_bunny import Model, ModelConfig
+
+    t, v = cfg.text, cfg.vision
+    mc = ModelConfig.from_dict(dict(
+        model_type="llava_bunny", auto_map={}, hidden_size=t.hidden_size, mm_hidden_size=v.hidden_size,
+        num_hidden_layers=t.num_hidden_layers, intermediate_size=t.intermediate_size,
+        num_attention_heads=t.num_attention_heads, num_key_value_heads=t.num_key_value_heads,
+        rms_norm_eps=t.rms_norm_eps, vocab_size=t.vocab_size, rope_theta=t.rope_theta,
+        attention_bias=t.attention_bias, tie_word_embeddings=t.tie_word_embeddings,
+        image_token_index=cfg.image_token_index,
+        vision_config=dict(num_hidden_layers=v.num_hidden_layers, hidden_size=v.hidden_size,
+                           intermediate_size=v.intermediate_size, num_attention_heads=v.num_attention_heads,
+                           image_size=v.image_size, patch_size=v.patch_size, num_channels=v.num_channels,
+                           layer_norm_eps=v.layer_norm_eps)))
+    m = Model(mc, device=device, **kw)
+    weights = m.language_model.sanitize(dict(W))
+    m.load_weights(weights)
+    return m

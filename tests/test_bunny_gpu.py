@@ -1,0 +1,129 @@
+"""GPU parity, nanoLLaVA (`llava_bunny`): the HIP path (SigLIP tower over the C-ABI ops, padded-head
+Qwen1.5 decoder on the decode engine) against oracle/llava_bunny.py on the same seeded bf16 weights, and against the
+vectors of the reference's own files (tests/golden/llava_bunny_tiny_ref.npz; only the .npz is read).
+
+Tolerances as in test_engine_gpu.py: activations are bf16 with ~1-ulp differences per op that compound over depth
+(stated per test against the tensor's rms); greedy tokens must be identical unless the oracle's own logit margin between
+the two candidates is below the stated fraction of the logit rms (tie-aware)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import llava_bunny as ob
+from tests.helpers import build_bunny_model
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "llava_bunny_tiny_ref.npz"))
+ROWS = slice(None, None, 7)
+
+
+@pytest.fixture(scope="module")
+def bunny():
+    cfg = ob.tiny_cfg()
+    W = {k: v.to(BF) for k, v in ob.random_weights(cfg, seed=4321, dtype=torch.float32, **ob.TEST_WEIGHT_SCALES).items()}
+    model = build_bunny_model(cfg, W, kv_pool_tokens=4096, max_seqs=8)
+    return cfg, W, model
+
+
+def _pixels(i):
+    return torch.from_numpy(ob.preprocess([G[f"img{i}.image_hwc"]]))
+
+
+def _rel_rms(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30))
+
+
+def _tie_aware(toks, ref_toks, ref_logits, tol):
+    for n, (a, b) in enumerate(zip(toks, ref_toks)):
+        if a != b:
+            row = ref_logits[n].float()
+            return abs(float(row[a]) - float(row[b])) <= tol * float(row.pow(2).mean().sqrt()), n
+    return True, None
+
+
+@pytest.mark.parametrize("i", [0, 1])
+def test_siglip_tower_and_projector_vs_oracle_and_reference(bunny, i):
+    cfg, W, model = bunny
+    pix = _pixels(i)
+    ref_last = ob.vision_tower(W, cfg, pix.to(BF))
+    last = model.vision_tower(pix)
+    assert last.shape == (729, cfg.vision.hidden_size)
+    assert _rel_rms(last, ref_last[0]) < 2e-2
+    assert _rel_rms(last[ROWS], torch.from_numpy(G[f"case{i}.bf16.ref_vision_last"])) < 2e-2
+    feats = model.encode_image(pix)
+    assert _rel_rms(feats, ob.mm_projector(W, ref_last)[0]) < 2e-2
+    assert _rel_rms(feats[ROWS], torch.from_numpy(G[f"case{i}.bf16.ref_image_features"])) < 2e-2
+    both = model.vision_tower(torch.cat([pix, _pixels(1 - i)]))       # two images per call: same rows for the first
+    assert torch.equal(both[:729], last)
+
+
+@pytest.mark.parametrize("i", [0, 1])
+def test_splice_and_prefill_logits_vs_oracle(bunny, i):
+    cfg, W, model = bunny
+    ids, pix = G[f"case{i}.input_ids"], _pixels(i)
+    f = model.get_input_embeddings(ids, pix)
+    ref = ob.get_input_embeddings(W, cfg, ids, pix)
+    assert f.inputs_embeds.shape == ref.shape == (1, ids.shape[1] + 728, cfg.text.hidden_size)
+    pos = int(np.argmax(ids[0] == cfg.image_token_index))
+    text_rows = list(range(pos)) + list(range(pos + 729, ref.shape[1]))
+    assert torch.equal(f.inputs_embeds[0, text_rows].cpu(), ref[0, text_rows])           # embedding rows: exact
+    assert _rel_rms(f.inputs_embeds[0, pos:pos + 729], ref[0, pos:pos + 729]) < 2e-2
+    assert np.array_equal(np.asarray(f.position_ids)[0, 0], np.arange(ref.shape[1]))
+    from mlx_vlm_amd.models import cache as cache_mod
+
+    lm = model.language_model
+    L = ref.shape[1]
+    cache = cache_mod.make_prompt_cache(lm)
+    logits = lm.prefill(f.inputs_embeds.reshape(L, -1), np.asarray(f.position_ids).reshape(3, L), [cache], [L], "last")
+    ref_logits = ob.language_model(W, cfg, ref)[0, -1]
+    err = (logits[0].float().cpu() - ref_logits.float()).abs().max() / ref_logits.float().pow(2).mean().sqrt()
+    assert float(err) < 6e-2, float(err)
+    gold = torch.from_numpy(G[f"case{i}.bf16.ref_prefill_logits_last"])
+    err = (logits[0].float().cpu() - gold).abs().max() / gold.pow(2).mean().sqrt()
+    assert float(err) < 6e-2, float(err)
+    cache[0]._seq.release()
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+@pytest.mark.parametrize("case", ["image0", "image1", "text"])
+def test_greedy_generate_step_vs_oracle(bunny, case, use_graph):
+    from mlx_vlm_amd.generate import generate_step
+
+    cfg, W, model = bunny
+    if case == "text":
+        ids, pix = G["generate_step.text.input_ids"], None
+    else:
+        i = int(case[-1])
+        ids, pix = G[f"case{i}.input_ids"], _pixels(i)
+    n_new = 12
+    ref_toks, ref_logits = ob.generate_greedy(W, cfg, ids, pix, max_tokens=n_new, return_logits=True)
+    got = [t for t, _ in generate_step(ids, model, pix, None, max_tokens=n_new, temperature=0.0, use_graph=use_graph)]
+    assert len(got) == n_new
+    ok, n = _tie_aware(got, ref_toks, ref_logits, tol=3e-2)
+    assert ok, (got, ref_toks, n)
+
+
+def test_greedy_vs_reference_goldens_both_numeric_paths(bunny):
+    """The reference's own runs: pixels pre-cast to bf16 (`case0.bf16`, the graph this engine computes) and float32
+    pixels as its pipeline ships them (`generate_step.image`: float32 activations by type promotion).  First tokens
+    identical; any later divergence must sit on a margin below 3 % of the logit rms of the respective run."""
+    from mlx_vlm_amd.generate import generate_step
+
+    cfg, W, model = bunny
+    ids, pix = G["case0.input_ids"], _pixels(0)
+    got = [t for t, _ in generate_step(ids, model, pix, None, max_tokens=6, temperature=0.0)]
+    gold = G["case0.bf16.ref_greedy"].tolist()
+    rows = torch.cat([torch.from_numpy(G["case0.bf16.ref_prefill_logits_last"])[None],
+                      torch.from_numpy(G["case0.bf16.ref_decode_logits"])])
+    ok, n = _tie_aware(got, gold, rows, tol=3e-2)
+    assert ok and got[0] == gold[0], (got, gold, n)
+    shipped = G["generate_step.image.tokens"].tolist()
+    ok, n = _tie_aware(got, shipped, torch.from_numpy(G["generate_step.image.logprobs"]), tol=3e-2)
+    assert ok and got[0] == shipped[0], (got, shipped, n)
+    text = [t for t, _ in generate_step(G["generate_step.text.input_ids"], model, None, None, max_tokens=6, temperature=0.0)]
+    ok, n = _tie_aware(text, G["generate_step.text.tokens"].tolist(), torch.from_numpy(G["generate_step.text.logprobs"]), tol=3e-2)
+    assert ok, (text, n)

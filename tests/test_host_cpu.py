@@ -265,3 +265,88 @@ def test_package_level_names_are_callable_in_any_import_order():
     from mlx_vlm_amd.generate import generate as fn
 
     assert fn.__name__ == "generate"
+
+
+# ---- nanoLLaVA (llava_bunny): the head-width mappings onto the engine's kernels are exact (no GPU needed)
+def test_bunny_llm_heads_spread_64_to_128_reproduce_rope_attention_exactly():
+    """language.py of models/llava_bunny lays 64-wide heads out in 128 columns (real dims [0,32) -> [0,32), [32,64) ->
+    [64,96)), gives the engine a frequency table with 32 real entries + zeros and attn_scale = 64 ** -0.5.  Emulated with
+    the oracle's primitives: q/k/v projections, rotate-half RoPE over 128 columns and attention on the spread layout
+    give bit-identical outputs (after o_proj) to the 64-wide computation - zeros stay zeros under rotation and add
+    exact zeros to every dot product."""
+    from mlx_vlm_amd.models.llava_bunny.language import ENGINE_HEAD_DIM, LanguageModel
+    from oracle import ops as O
+
+    torch.manual_seed(3)
+    B, L, D, H, hd = 1, 9, 128, 2, 64
+    bf = torch.bfloat16
+    x = torch.randn(B, L, D).to(bf)
+    wq, wk, wv = (torch.randn(H * hd, D).mul(0.1).to(bf) for _ in range(3))
+    bq, bk, bv = (torch.randn(H * hd).mul(0.1).to(bf) for _ in range(3))
+    wo = torch.randn(D, H * hd).mul(0.1).to(bf)
+    pos = torch.arange(5, 5 + L)[None]
+
+    def attend(wq, bq, wk, bk, wv, bv, wo, width, inv, scale):
+        q, k, v = (O.linear(x, w, b).reshape(B, L, H, width).permute(0, 2, 1, 3) for w, b in ((wq, bq), (wk, bk), (wv, bv)))
+        q, k = O.mrope_apply(q, pos, inv, None, "fused"), O.mrope_apply(k, pos, inv, None, "fused")
+        o = O.sdpa(q, k, v, scale=scale, causal=True)
+        return O.linear(o.permute(0, 2, 1, 3).reshape(B, L, -1), wo)
+
+    ref = attend(wq, bq, wk, bk, wv, bv, wo, hd, O.mrope_inv_freq(hd, 1e6), hd ** -0.5)
+    lm = object.__new__(LanguageModel)
+    lm.real_head_dim = hd
+    inv = torch.zeros(ENGINE_HEAD_DIM // 2)
+    inv[: hd // 2] = O.mrope_inv_freq(hd, 1e6)
+    got = attend(lm._spread(wq, H), lm._spread(bq, H), lm._spread(wk, H), lm._spread(bk, H), lm._spread(wv, H),
+                 lm._spread(bv, H), lm._spread(wo.t(), H).t().contiguous(), ENGINE_HEAD_DIM, inv, hd ** -0.5)
+    assert torch.equal(got, ref)
+
+
+def test_bunny_siglip_heads_padded_72_to_80_reproduce_attention_exactly():
+    """vision.py of models/llava_bunny zero-pads every 72-wide SigLIP head to the 80 the attention kernel has."""
+    from oracle import ops as O
+
+    torch.manual_seed(4)
+    N, E, H, hd, hp = 37, 144, 2, 72, 80
+    bf = torch.bfloat16
+    x = torch.randn(1, N, E).to(bf)
+    w = {n: torch.randn(E, E).mul(0.1).to(bf) for n in "qkvo"}
+    b = {n: torch.randn(E).mul(0.1).to(bf) for n in "qkvo"}
+
+    def heads(t, width):
+        return t.reshape(1, N, H, width).permute(0, 2, 1, 3)
+
+    q, k, v = (heads(O.linear(x, w[n], b[n]), hd) for n in "qkv")
+    ref = O.linear(O.sdpa(q, k, v, scale=hd ** -0.5).permute(0, 2, 1, 3).reshape(1, N, E), w["o"], b["o"])
+
+    def pad_rows(m):
+        out = torch.zeros(H, hp, m.shape[1], dtype=bf)
+        out[:, :hd] = m.reshape(H, hd, -1)
+        return out.reshape(H * hp, -1)
+
+    def pad_vec(vv):
+        out = torch.zeros(H, hp, dtype=bf)
+        out[:, :hd] = vv.reshape(H, hd)
+        return out.reshape(-1)
+
+    qp, kp, vp = (heads(O.linear(x, pad_rows(w[n]), pad_vec(b[n])), hp) for n in "qkv")
+    wo = torch.zeros(E, H, hp, dtype=bf)
+    wo[:, :, :hd] = w["o"].reshape(E, H, hd)
+    got = O.linear(O.sdpa(qp, kp, vp, scale=hd ** -0.5).permute(0, 2, 1, 3).reshape(1, N, H * hp), wo.reshape(E, H * hp), b["o"])
+    assert torch.equal(got, ref)
+
+
+def test_bunny_config_and_prompt_assembly_follow_the_reference():
+    from mlx_vlm_amd.models.llava_bunny import ModelConfig, assemble_input_ids
+
+    cfg = ModelConfig.from_dict(dict(model_type="llava_bunny", auto_map={}, hidden_size=128, mm_hidden_size=144,
+                                     num_hidden_layers=2, intermediate_size=256, num_attention_heads=2, rms_norm_eps=1e-6,
+                                     vocab_size=1024, vision_config=dict(hidden_size=144)))
+    assert cfg.text_config.num_key_value_heads == 2 and cfg.text_config.attention_bias and cfg.text_config.tie_word_embeddings
+    assert cfg.vision_config.model_type == "siglip_vision_model" and cfg.image_token_index == -200
+    with pytest.raises(ValueError):
+        ModelConfig.from_dict(dict(model_type="llava_bunny", auto_map={}, hidden_size=8, mm_hidden_size=8, num_hidden_layers=1,
+                                   intermediate_size=8, num_attention_heads=1, rms_norm_eps=1e-6, vocab_size=8,
+                                   rope_scaling={"type": "dynamic", "factor": 2.0}, vision_config={}))
+    ids, mask = assemble_input_ids(lambda s: [len(w) for w in s.split()], ["aa bbb <image> c", "<image> dddd ee f"], pad_token_id=0)
+    assert ids.tolist() == [[2, 3, -200, 1], [-200, 4, 2, 1]] and mask.tolist() == [[1, 1, 1, 1], [1, 1, 1, 1]]
