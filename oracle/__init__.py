@@ -27,6 +27,11 @@ remains unpinned.
     vision tower from the patch embeddings on, on the embedding merge, the rope-index tables (image, text-only,
     left-padded), the sampler filters and generate_step's tokens + bf16 logprobs on a text prompt; the patch-embed contraction agrees to 1 bf16 ulp (summation order).
     This pins the reference's GRAPH: op order, reshapes, dtype casts, rounding points, cache and position logic.
+    The same method pins the nanoLLaVA path (oracle/llava_bunny.py; make_golden_ref_bunny.py ->
+    llava_bunny_tiny_ref.npz; tests/test_oracle_ref_golden_bunny.py): models/llava_bunny/{config,vision,language,
+    llava_bunny}.py incl. its ImageProcessor - bit-exact in bf16 from the patch embeddings on, image processor
+    crc-exact, generate_step on a text prompt bit-exact, and the float32-promotion path the reference takes when
+    handed float32 pixels (tokens identical, float32 log-probs to 2e-4).
   * Pin 2 - an independent implementation (tests/golden/make_golden.py -> qwen2_vl_tiny_hf.npz): HuggingFace
     transformers 5.15 `Qwen2VLForConditionalGeneration` in fp32 (same checkpoint format).  The reference-over-
     shim vectors agree with it to 1.3e-5, which validates the stand-in.
