@@ -97,9 +97,22 @@ def load_processor(model_path: str, config):
     tok = AutoTokenizer.from_pretrained(model_path)
     ip_kwargs = {}
     pp = os.path.join(model_path, "preprocessor_config.json")
+    pc = {}
     if os.path.exists(pp):
         with open(pp) as f:
             pc = json.load(f)
+    if getattr(config, "model_type", None) == "llava_bunny":
+        # reference utils.py:1260-1270: models with a BaseImageProcessor get the bare tokenizer with the image
+        # processor attached; prepare_inputs splits the prompt at "<image>" (utils.py:2064-2095)
+        from .models.llava_bunny import ImageProcessor
+
+        tok.image_processor = ImageProcessor(**{k: pc[k] for k in ("image_mean", "image_std") if k in pc})
+        tok.image_token_index = getattr(config, "image_token_index", -200)
+        tok.tokenizer = tok
+        eos = config.eos_token_id if getattr(config, "eos_token_id", None) is not None else tok.eos_token_id
+        tok.stopping_criteria = StoppingCriteria(eos if isinstance(eos, list) else [eos], tok)
+        return tok
+    if pc:
         for k in ("image_mean", "image_std", "min_pixels", "max_pixels", "patch_size", "temporal_patch_size", "merge_size"):
             if k in pc:
                 ip_kwargs[k] = pc[k]
@@ -203,6 +216,22 @@ def prepare_inputs(processor, images=None, prompts=None, **kwargs) -> Dict[str, 
     pixel_values [N, C*T*ps*ps] f32, image_grid_thw [n_img, 3]."""
     if images is not None and not isinstance(images, (list, tuple)):
         images = [images]
+    if hasattr(processor, "image_processor") and hasattr(processor, "image_token_index"):
+        # BaseImageProcessor models (nanoLLaVA), reference utils.py:2064-2095
+        from .models.llava_bunny.processing import assemble_input_ids
+        from .models.qwen2_vl.processing_qwen2_vl import load_image
+
+        plist = [prompts] if isinstance(prompts, str) else list(prompts)
+        if processor.pad_token is None:
+            processor.pad_token = processor.eos_token
+        if not images:
+            enc = processor(plist, padding=True)
+            return {"input_ids": np.asarray(enc["input_ids"], dtype=np.int64),
+                    "attention_mask": np.asarray(enc["attention_mask"], dtype=np.int32)}
+        ids, mask = assemble_input_ids(lambda chunk: processor(chunk).input_ids, plist, processor.pad_token_id,
+                                       processor.image_token_index)
+        pix = processor.image_processor.preprocess([load_image(im) for im in images])
+        return {"input_ids": ids, "pixel_values": np.stack(pix), "attention_mask": mask}
     imgs = None
     if images:
         from .models.qwen2_vl.processing_qwen2_vl import load_image

@@ -350,3 +350,37 @@ def test_bunny_config_and_prompt_assembly_follow_the_reference():
                                    rope_scaling={"type": "dynamic", "factor": 2.0}, vision_config={}))
     ids, mask = assemble_input_ids(lambda s: [len(w) for w in s.split()], ["aa bbb <image> c", "<image> dddd ee f"], pad_token_id=0)
     assert ids.tolist() == [[2, 3, -200, 1], [-200, 4, 2, 1]] and mask.tolist() == [[1, 1, 1, 1], [1, 1, 1, 1]]
+
+
+def test_bunny_load_processor_and_prepare_inputs(tmp_path):
+    """load_processor for a llava_bunny checkpoint directory: tokenizer with the image processor attached (reference
+    utils.py:1260-1270) and the "<image>" branch of prepare_inputs (utils.py:2064-2095)."""
+    import json
+
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+
+    from mlx_vlm_amd.models.llava_bunny import ModelConfig
+    from mlx_vlm_amd.utils import load_config, load_processor, prepare_inputs
+
+    conf = dict(model_type="llava_bunny", auto_map={}, hidden_size=128, mm_hidden_size=144, num_hidden_layers=2,
+                intermediate_size=256, num_attention_heads=2, rms_norm_eps=1e-6, vocab_size=64, eos_token_id=[1],
+                vision_config=dict(hidden_size=144, num_hidden_layers=2, intermediate_size=288, num_attention_heads=2))
+    (tmp_path / "config.json").write_text(json.dumps(conf))
+    vocab = {"<unk>": 0, "<eos>": 1, "<pad>": 2, **{f"w{i}": i for i in range(3, 64)}}
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    PreTrainedTokenizerFast(tokenizer_object=tok, eos_token="<eos>", pad_token="<pad>", unk_token="<unk>").save_pretrained(str(tmp_path))
+    mc = ModelConfig.from_dict(load_config(str(tmp_path)))
+    proc = load_processor(str(tmp_path), mc)
+    assert proc.tokenizer is proc and proc.image_token_index == -200 and proc.stopping_criteria(1) and not proc.stopping_criteria(5)
+    img = np.random.default_rng(0).integers(0, 256, (40, 60, 3), dtype=np.uint8)
+    out = prepare_inputs(proc, images=img, prompts="w5 w6 <image> w7")
+    assert out["input_ids"].tolist() == [[5, 6, -200, 7]] and out["attention_mask"].tolist() == [[1, 1, 1, 1]]
+    assert out["pixel_values"].shape == (1, 3, 384, 384) and out["pixel_values"].dtype == np.float32
+    from oracle import llava_bunny as ob
+    assert np.array_equal(out["pixel_values"], ob.preprocess([img]))
+    text = prepare_inputs(proc, prompts="w9 w10 w11")
+    assert text["input_ids"].tolist() == [[9, 10, 11]] and "pixel_values" not in text
+    with pytest.raises(ValueError):
+        prepare_inputs(proc, images=img, prompts="no placeholder here")

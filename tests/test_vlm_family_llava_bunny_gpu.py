@@ -134,3 +134,66 @@ def test_greedy_vs_reference_goldens_both_numeric_paths(bunny):
     text = [t for t, _ in generate_step(G["generate_step.text.input_ids"], model, None, None, max_tokens=6, temperature=0.0)]
     ok, n = _tie_aware(text, G["generate_step.text.tokens"].tolist(), torch.from_numpy(G["generate_step.text.logprobs"]), tol=3e-2)
     assert ok, (text, n)
+
+
+def write_bunny_checkpoint(path, cfg, W):
+    """A nanoLLaVA checkpoint directory in the HF layout the reference loads (llava_bunny.py:180-222 renames it):
+    `model.vision_tower...` with the torch conv layout (O, C, kH, kW), `model.mm_projector.{0,2}`, `model.layers...`,
+    tied embeddings (no lm_head), config.json with the text parameters at the root, a WordLevel tokenizer."""
+    import json
+
+    from safetensors.torch import save_file
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+
+    t, v = cfg.text, cfg.vision
+    conf = dict(model_type="llava_bunny", auto_map={}, hidden_size=t.hidden_size, mm_hidden_size=v.hidden_size,
+                num_hidden_layers=t.num_hidden_layers, intermediate_size=t.intermediate_size,
+                num_attention_heads=t.num_attention_heads, num_key_value_heads=t.num_key_value_heads,
+                rms_norm_eps=t.rms_norm_eps, vocab_size=t.vocab_size, rope_theta=t.rope_theta, attention_bias=True,
+                tie_word_embeddings=True, eos_token_id=[1],
+                vision_config=dict(num_hidden_layers=v.num_hidden_layers, hidden_size=v.hidden_size,
+                                   intermediate_size=v.intermediate_size, num_attention_heads=v.num_attention_heads,
+                                   image_size=v.image_size, patch_size=v.patch_size))
+    (path / "config.json").write_text(json.dumps(conf))
+    hf = {}
+    for k, w in W.items():
+        w = w.contiguous()
+        if k.startswith("vision_tower."):
+            if k.endswith("patch_embedding.weight"):
+                w = w.permute(0, 3, 1, 2).contiguous()                   # (O, kH, kW, C) -> torch (O, C, kH, kW)
+            hf["model." + k] = w
+        elif k.startswith("mm_projector.linear_1."):
+            hf["model.mm_projector.0." + k.rsplit(".", 1)[1]] = w
+        elif k.startswith("mm_projector.linear_2."):
+            hf["model.mm_projector.2." + k.rsplit(".", 1)[1]] = w
+        else:
+            hf[k[len("language_model."):]] = w                           # language_model.model.X -> model.X
+    hf["model.layers.0.self_attn.rotary_emb.inv_freq"] = torch.zeros(32)  # dropped by sanitize (language.py:172-174)
+    save_file(hf, str(path / "model.safetensors"))
+    vocab = {"<unk>": 0, "<eos>": 1, "<pad>": 2, **{f"t{i}": i for i in range(3, t.vocab_size)}}
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    PreTrainedTokenizerFast(tokenizer_object=tok, eos_token="<eos>", pad_token="<pad>", unk_token="<unk>").save_pretrained(str(path))
+
+
+def test_load_and_generate_user_api_end_to_end(tmp_path):
+    """load(path) dispatches on model_type to models/llava_bunny; generate() with an "<image>" prompt goes through the
+    tokenizer split, the 384 x 384 image processor, the SigLIP tower, projector, splice, prefill and graph decode."""
+    from mlx_vlm_amd import generate, load
+
+    cfg = ob.tiny_cfg()
+    W = {k: v.to(BF) for k, v in ob.random_weights(cfg, seed=4321, dtype=torch.float32, **ob.TEST_WEIGHT_SCALES).items()}
+    write_bunny_checkpoint(tmp_path, cfg, W)
+    model, processor = load(str(tmp_path), kv_pool_tokens=4096, max_seqs=4)
+    assert type(model).__module__.endswith("llava_bunny.llava_bunny")
+    img = G["img0.image_hwc"]
+    ids = G["case0.input_ids"][0].tolist()
+    cut = ids.index(cfg.image_token_index)
+    prompt = " ".join(f"t{t}" for t in ids[:cut]) + " <image> " + " ".join(f"t{t}" for t in ids[cut + 1:])
+    out = generate(model, processor, prompt, image=img, max_tokens=6, temperature=0.0)
+    assert out.prompt_tokens == len(ids) and out.generation_tokens >= 1
+    toks = [int(w[1:]) for w in out.text.split() if w.startswith("t")]
+    ref_toks, ref_logits = ob.generate_greedy(W, cfg, np.array([ids]), _pixels(0), max_tokens=6, return_logits=True)
+    ok, n = _tie_aware(toks, ref_toks[:len(toks)], ref_logits, tol=3e-2)
+    assert ok and len(toks) >= 1, (toks, ref_toks, n)
