@@ -19,7 +19,7 @@ from typing import Any, Dict, List, Optional, Union
 import numpy as np
 import torch
 
-MODEL_REMAPPING = {"qwen2_5_vl": "qwen2_vl"} if False else {}   # only qwen2_vl is built this round
+MODEL_REMAPPING: Dict[str, str] = {}   # model_type aliases (reference utils.py:34-62); built: qwen2_vl, llava_bunny
 
 
 def get_model_and_args(config: dict):
