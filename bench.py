@@ -284,6 +284,8 @@ def main():
     del W
     torch.cuda.synchronize()
     load_s = time.perf_counter() - t0
+    from mlx_vlm_amd.utils import freeze_heap
+    freeze_heap()          # what load() does: no 100 ms cyclic-GC passes over the import heap inside timed loops
 
     req = build_request(cfg, 448, 128, seed=rank)
     req = (req[0], req[1].to(dev), req[2])

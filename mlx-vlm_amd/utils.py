@@ -77,6 +77,18 @@ def load_model(model_path: str, lazy: bool = False, device="cuda", **kwargs):
     return model
 
 
+def freeze_heap():
+    """Take everything allocated so far (torch, transformers, the model objects: ~4e5 GC-tracked containers) out of the
+    cyclic garbage collector's view.  A generation-2 pass over that heap costs 90-150 ms of host time wherever it
+    happens to trigger - in the middle of a prefill enqueue or a decode loop - and finds nothing: those objects live
+    as long as the process.  Reference-counted frees are unaffected.  VLM_GC_FREEZE=0 opts out."""
+    import gc
+
+    if os.environ.get("VLM_GC_FREEZE", "1") != "0":
+        gc.collect()
+        gc.freeze()
+
+
 def load(path_or_hf_repo: str, adapter_path=None, lazy: bool = False, revision=None, strict: bool = True, **kwargs):
     """reference utils.py:1065-1119 -> (model, processor).  Local paths only (no network in this build)."""
     if adapter_path is not None:
@@ -85,6 +97,7 @@ def load(path_or_hf_repo: str, adapter_path=None, lazy: bool = False, revision=N
         raise FileNotFoundError(f"{path_or_hf_repo} is not a local model directory")
     model = load_model(path_or_hf_repo, lazy=lazy, **kwargs)
     processor = load_processor(path_or_hf_repo, model.config)
+    freeze_heap()
     return model, processor
 
 

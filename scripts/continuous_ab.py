@@ -1,6 +1,6 @@
 """A/B of the BatchGenerator admission policies inside ONE process (box-to-box variance is 5-10 %):
 synchronous admission, asynchronous (side stream) without / with prefill-ahead, and static batches of 8.
-Usage: python scripts/continuous_ab.py [n_requests]"""
+Usage: python scripts/continuous_ab.py [n_requests] [--breakdown] [--gc-log] [--no-gc-freeze]"""
 import os
 import sys
 import time
@@ -15,13 +15,35 @@ from mlx_vlm_amd import synthetic  # noqa: E402
 from mlx_vlm_amd.models.qwen2_vl import Model, ModelConfig  # noqa: E402
 
 
+def watch_gc():
+    """Print every cyclic-GC pass of generation >= 1 with its duration: a 100 ms generation-2 pass over the torch /
+    transformers heap is the prime suspect for the sporadic host stalls inside prefill enqueues."""
+    import gc
+
+    t0 = {}
+
+    def cb(phase, info):
+        if phase == "start":
+            t0[info["generation"]] = time.perf_counter()
+        elif info["generation"] >= 1:
+            print(f"    [gc] generation {info['generation']} pass: {1e3 * (time.perf_counter() - t0.get(info['generation'], 0)):.1f} ms, "
+                  f"collected {info['collected']}")
+
+    gc.callbacks.append(cb)
+
+
 def main():
-    n_requests = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    if "--gc-log" in sys.argv:
+        watch_gc()
+    n_requests = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 24
     cfg = ModelConfig.from_dict(dict(synthetic.QWEN2_VL_2B))
     W = synthetic.random_weights(cfg, seed=0, device="cuda", fill=True)
     model = Model(cfg, device="cuda", kv_pool_tokens=16384, max_seqs=16)
     model.load_weights(W)
     del W
+    if "--no-gc-freeze" not in sys.argv:
+        from mlx_vlm_amd.utils import freeze_heap
+        freeze_heap()
     reqs = [bench.build_request(cfg, 336, 64, 700 + i) for i in range(n_requests)]
     ids = [r[0].reshape(-1) for r in reqs]
     pix = [r[1] for r in reqs]
