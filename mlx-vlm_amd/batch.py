@@ -43,6 +43,20 @@ MAX_ROWS = 8          # widest decode step of the engine's GEMV kernels
 WIDTHS = (1, 2, 4, 8)
 
 
+class _NullEvent:
+    """What the scheduler sees of a device event when no device is involved (the mock-engine tests on CPU, in the manner
+    of the reference's scheduler tests with mock models, tests/test_generate.py:50-166, 529-1170)."""
+
+    def record(self, *a):
+        pass
+
+    def query(self):
+        return True
+
+    def synchronize(self):
+        pass
+
+
 @dataclass
 class PromptProgress:
     """reference ar.py:906-913"""
@@ -127,8 +141,10 @@ class BatchGenerator:
         self._rows: List[_Row] = []
         self._closed = False
 
-        lm, dev, cap = self.lm, self.lm.device, self.completion_batch_size
-        self._st = self._borrow_state(lm, cap)
+        # buffers are sized for the widest step that can run: 3 live rows decode inside a 4-wide step
+        lm, dev, cap = self.lm, self.lm.device, next(w for w in WIDTHS if w >= self.completion_batch_size)
+        self._cuda = torch.device(dev).type == "cuda"
+        self._st = self._new_decode_state(cap)
         pool = lm.pool
         self._table = torch.zeros(cap, pool.max_pages, dtype=torch.int32, device=dev)
         self._scratch_seq = PagedSequence(pool)          # one page nobody reads: where idle rows write their k / v
@@ -136,11 +152,13 @@ class BatchGenerator:
         self._idle_row = torch.full((pool.max_pages,), self._scratch_seq.pages[0], dtype=torch.int32, device=dev)
         self._table[:] = self._idle_row
         self._lp = torch.zeros(cap, dtype=torch.float32, device=dev)      # logprob of the token sitting in st.tok
-        self._pin_tok = torch.empty(2, cap, dtype=torch.int32).pin_memory()
-        self._pin_lp = torch.empty(2, cap, dtype=torch.float32).pin_memory()
+        self._pin_tok = torch.empty(2, cap, dtype=torch.int32)
+        self._pin_lp = torch.empty(2, cap, dtype=torch.float32)
+        if self._cuda:
+            self._pin_tok, self._pin_lp = self._pin_tok.pin_memory(), self._pin_lp.pin_memory()
         self._inflight: Optional[Tuple[int, torch.cuda.Event, List[int], float]] = None
         self._pending: List[_Admission] = []         # oldest first
-        self._side = torch.cuda.Stream(device=dev) if async_prefill else None
+        self._side = torch.cuda.Stream(device=dev) if (async_prefill and self._cuda) else None
         self._calls = 0
         self._idle_steps = 0
         self._width = 0
@@ -150,6 +168,47 @@ class BatchGenerator:
         self._gen_tokens_counter = 0
         self._gen_time_counter = 0.0
         self._steps_counter = 0
+
+    # ------------------------------------------------------------------ engine hooks
+    # Everything that touches the device sits behind these five methods; the scheduler (queue, admission, joins,
+    # compaction, finish rules, stats) never looks past them, so it is driven by a mock engine in the CPU tests.
+    def _event(self):
+        return torch.cuda.Event() if self._cuda else _NullEvent()
+
+    def _new_decode_state(self, cap: int):
+        return self._borrow_state(self.lm, cap)
+
+    def _prefill_requests(self, batch):
+        """One ViT call over all images of `batch`, one varlen prefill launch, first tokens sampled on the device.
+        -> (caches, lengths, first tokens int32 [n], their log-probs f32 [n] or None, int32 [2, n] rope position /
+        context length of each request's first decode step)"""
+        from .generate import embed_requests
+
+        lm = self.lm
+        ids_l = [b[1] for b in batch]
+        pix_l = [b[3].get("pixel_values") for b in batch]
+        grid_l = [b[3].get("image_grid_thw") for b in batch]
+        emb, pos, lens, deltas = embed_requests(self.model, ids_l, pix_l, grid_l)
+        caches = [lm.make_cache() for _ in batch]
+        for c, L, b in zip(caches, lens, batch):
+            c[0]._seq.reserve(L + b[2] + 2)          # prompt + every token it may generate + the step in flight
+        logits = lm.prefill(emb, pos, caches, lens, "last")
+        step0 = torch.zeros(1, dtype=torch.int32, device=logits.device)
+        tok0, lp = ops.sample(logits, step=step0, want_logprobs=self.compute_logprobs, **self._sargs)
+        lp0 = lp.gather(1, tok0.long()[:, None]).reshape(-1).float() if self.compute_logprobs else None
+        ctx = np.asarray(lens, dtype=np.int32)
+        state = h2d(np.stack([ctx + np.asarray(deltas, dtype=np.int32), ctx]), lm.device)
+        return caches, list(lens), tok0, lp0, state
+
+    def _decode_rows(self, width: int):
+        """One decode step over rows 0..width-1 of the state: tok <- sampled token, pos and ctx advanced by one."""
+        self.lm.decode_step_rows(self._st, width, self._table, self._sargs, use_graph=self.use_graph,
+                                 with_logprobs=self.compute_logprobs)
+
+    def _row_logprobs(self, n: int) -> torch.Tensor:
+        """log-prob of the token each of the first n rows has just sampled (f32 [n])"""
+        st = self._st
+        return st.logprobs[:n].gather(1, st.tok[:n].long()[:, None]).reshape(-1).float()
 
     @staticmethod
     def _borrow_state(lm, cap: int) -> DecodeState:
@@ -236,7 +295,8 @@ class BatchGenerator:
         if self._closed:
             return
         self._closed = True
-        torch.cuda.synchronize()
+        if self._cuda:
+            torch.cuda.synchronize()
         for p in self._pending:
             for c in p.caches[p.joined:]:
                 c[0]._seq.release()
@@ -286,14 +346,11 @@ class BatchGenerator:
     def _admit_begin(self):
         """Enqueue the prefill of as many queued prompts as there are free rows (one ViT call over all their images, one
         varlen prefill launch, first tokens sampled on the device) - on the side stream when async_prefill."""
-        from .generate import embed_requests
-
         free = self.completion_batch_size - len(self._rows)
         ahead = sum(p.waiting() for p in self._pending)
         n = min(free + self.prefill_ahead - ahead, self.prefill_batch_size, len(self._unprocessed_sequences))
         if n <= 0:
             return
-        lm = self.lm
         batch, self._unprocessed_sequences = self._unprocessed_sequences[:n], self._unprocessed_sequences[n:]
         tic = time.perf_counter()
         where = contextlib.nullcontext()
@@ -304,22 +361,10 @@ class BatchGenerator:
             self._side.wait_event(gate)
             where = torch.cuda.stream(self._side)
         with where:
-            ids_l = [b[1] for b in batch]
-            pix_l = [b[3].get("pixel_values") for b in batch]
-            grid_l = [b[3].get("image_grid_thw") for b in batch]
-            emb, pos, lens, deltas = embed_requests(self.model, ids_l, pix_l, grid_l)
-            caches = [lm.make_cache() for _ in batch]
-            for c, L, b in zip(caches, lens, batch):
-                c[0]._seq.reserve(L + b[2] + 2)          # prompt + every token it may generate + the step in flight
-            logits = lm.prefill(emb, pos, caches, lens, "last")
-            step0 = torch.zeros(1, dtype=torch.int32, device=logits.device)
-            tok0, lp = ops.sample(logits, step=step0, want_logprobs=self.compute_logprobs, **self._sargs)
-            lp0 = lp.gather(1, tok0.long()[:, None]).reshape(-1).float() if self.compute_logprobs else None
-            ctx = np.asarray(lens, dtype=np.int32)
-            state = h2d(np.stack([ctx + np.asarray(deltas, dtype=np.int32), ctx]), lm.device)
-            ev = torch.cuda.Event()
+            caches, lens, tok0, lp0, state = self._prefill_requests(batch)
+            ev = self._event()
             ev.record()
-        self._pending.append(_Admission(batch, caches, list(lens), tok0, lp0, state, ev, tic))
+        self._pending.append(_Admission(batch, caches, lens, tok0, lp0, state, ev, tic))
 
     def _admit_join(self) -> List[PromptProgress]:
         """Give free rows to prefilled requests, oldest admission first; an admission whose event has not fired is
@@ -332,7 +377,8 @@ class BatchGenerator:
                 if self._side is not None and (self._rows or out):
                     break                             # keep decoding; it joins at a later round
                 p.event.synchronize()                 # synchronous mode, or nothing to decode meanwhile
-            torch.cuda.current_stream().wait_event(p.event)
+            if self._cuda:
+                torch.cuda.current_stream().wait_event(p.event)
             dt = time.perf_counter() - p.tic          # wall time to the first token, as the reference reports it
             if p.joined == 0:
                 self._prompt_tokens_counter += int(sum(p.lens))
@@ -407,15 +453,14 @@ class BatchGenerator:
         self._pin_tok[slot, :n].copy_(st.tok[:n], non_blocking=True)
         if self.compute_logprobs:
             self._pin_lp[slot, :n].copy_(self._lp[:n], non_blocking=True)
-        ev = torch.cuda.Event()
+        ev = self._event()
         ev.record()
         self._inflight = (slot, ev, [row.uid for row in self._rows], time.perf_counter())
         longest = max(row.prompt_tokens + row.max_tokens for row in self._rows) + 2
         st.nsplit = 1 if longest <= 2048 else max(2, min(32, (longest + 16 * PAGE - 1) // (16 * PAGE)))
-        self.lm.decode_step_rows(st, width, self._table, self._sargs, use_graph=self.use_graph,
-                                 with_logprobs=self.compute_logprobs)
+        self._decode_rows(width)
         if self.compute_logprobs:
-            self._lp[:n].copy_(st.logprobs[:n].gather(1, st.tok[:n].long()[:, None]).reshape(-1).float())
+            self._lp[:n].copy_(self._row_logprobs(n))
         for row in self._rows:
             row.seq.offset += 1
         self._idle_steps += 1

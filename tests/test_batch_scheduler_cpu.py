@@ -1,0 +1,215 @@
+"""The continuous-batching scheduler (mlx_vlm_amd/batch.py) driven by a mock engine on CPU - the way the reference
+tests its own `BatchGenerator` (tests/test_generate.py:50-166 mock model / processor, 529-1170 scheduling and stats).
+
+The mock engine is deterministic per request: the first token is a function of the prompt, every next token a function of
+(previous token, context length, rope position).  Whatever the scheduler does with the rows - admit in waves, keep
+prefilled requests waiting for a row, move the last row into a hole, run 1 / 2 / 4 / 8-wide steps with idle rows parked
+on the scratch page - every request must emit exactly the stream it emits alone, finish by the reference's rules
+(ar.py:1313-1316) and give its KV pages back."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from mlx_vlm_amd.batch import BatchGenerator
+from mlx_vlm_amd.models.cache import KVPool, PagedSequence
+
+V = 5003
+
+
+def first_token(ids):
+    return int((int(np.sum(ids)) * 31 + len(ids)) % V)
+
+
+def next_token(tok, ctx, pos):
+    return int((tok * 7 + ctx * 13 + pos * 3 + 1) % V)
+
+
+def stream_alone(ids, n, delta=0):
+    out, tok, ctx = [], first_token(ids), len(ids)
+    for _ in range(n):
+        out.append(tok)
+        tok, ctx = next_token(tok, ctx, ctx + delta), ctx + 1
+    return out
+
+
+class MockEngineGenerator(BatchGenerator):
+    """BatchGenerator with the five engine hooks replaced; everything else is the product code."""
+
+    def __init__(self, pool, **kw):
+        self.decode_widths = []
+        self.prefill_sizes = []
+        lm = SimpleNamespace(device="cpu", pool=pool)
+        super().__init__(SimpleNamespace(language_model=lm), None, **kw)
+
+    def _new_decode_state(self, cap):
+        z = lambda: torch.zeros(cap, dtype=torch.int32)  # noqa: E731
+        return SimpleNamespace(B=cap, tok=z(), pos=z(), ctx=z(), step=torch.zeros(1, dtype=torch.int32), nsplit=1,
+                               last_lp=torch.zeros(cap))
+
+    def _prefill_requests(self, batch):
+        self.prefill_sizes.append(len(batch))
+        caches, lens, toks = [], [], []
+        for uid, ids, max_tokens, kw in batch:
+            seq = PagedSequence(self.lm.pool)
+            seq.reserve(len(ids) + max_tokens + 2)
+            seq.offset = len(ids)
+            caches.append([SimpleNamespace(_seq=seq)])
+            lens.append(len(ids))
+            toks.append(first_token(ids))
+        tok0 = torch.tensor(toks, dtype=torch.int32)
+        lp0 = -tok0.float() / V if self.compute_logprobs else None
+        ctx = np.asarray(lens, dtype=np.int32)
+        delta = np.asarray([b[3].get("delta", 0) for b in batch], dtype=np.int32)
+        return caches, lens, tok0, lp0, torch.from_numpy(np.stack([ctx + delta, ctx]))
+
+    def _decode_rows(self, width):
+        st = self._st
+        self.decode_widths.append((width, len(self._rows)))
+        live = len(self._rows)
+        # rows past the live ones must sit on the scratch page with a bounded context (they run inside the step)
+        assert torch.all(self._table[live:] == self._scratch_seq.pages[0])
+        assert int(st.ctx[live:width].max() if width > live else 0) <= 4 * 64
+        for r in range(live):      # a live row's table row is its own sequence's pages
+            seq = self._rows[r].seq
+            assert self._table[r, : len(seq.pages)].tolist() == seq.pages
+            assert int(st.ctx[r]) == seq.offset
+        for r in range(width):
+            t, c, p = int(st.tok[r]), int(st.ctx[r]), int(st.pos[r])
+            st.tok[r] = next_token(t, c, p)
+            st.last_lp[r] = -float(st.tok[r]) / V
+        st.ctx[:width] += 1
+        st.pos[:width] += 1
+
+    def _row_logprobs(self, n):
+        return self._st.last_lp[:n].clone()
+
+
+def make_pool(paged=True, max_seqs=16):
+    return KVPool(n_layers=1, n_kv_heads=1, head_dim=128, max_tokens=64 * 64, max_seqs=max_seqs, device="cpu",
+                  layout="paged" if paged else "identity")
+
+
+def drain(gen, on_round=None):
+    got, reasons, prompts, rounds = {}, {}, {}, 0
+    while gen.has_work:
+        pr, out = gen.next()
+        rounds += 1
+        assert rounds < 2000 and len(gen) <= gen.completion_batch_size
+        for p in pr:
+            prompts[p.uid] = p.prompt_tokens
+        seen = set()
+        for r in out:
+            assert r.uid not in reasons and r.uid not in seen
+            seen.add(r.uid)
+            got.setdefault(r.uid, []).append((r.token, r.token_logprob))
+            if r.finish_reason:
+                reasons[r.uid] = r.finish_reason
+        if on_round:
+            on_round(rounds, got)
+    return got, reasons, prompts, rounds
+
+
+@pytest.mark.parametrize("cap,pbs,ahead", [(4, 2, 0), (4, 2, 2), (8, 8, 2), (1, 1, 0), (3, 5, 1)])
+def test_every_request_emits_its_own_stream(cap, pbs, ahead):
+    rng = np.random.default_rng(cap * 10 + ahead)
+    pool = make_pool()
+    free_pages, free_seqs = len(pool._free_pages), len(pool._free_seqs)
+    prompts = [rng.integers(1, 999, int(rng.integers(3, 40))) for _ in range(19)]
+    max_tokens = [int(rng.integers(1, 24)) for _ in prompts]
+    deltas = [int(rng.integers(-5, 3)) for _ in prompts]
+    gen = MockEngineGenerator(pool, completion_batch_size=cap, prefill_batch_size=pbs, prefill_ahead=ahead)
+    uids = gen.insert(prompts, max_tokens, prompt_kwargs=[{"delta": d} for d in deltas])
+    assert [len(x[1]) for x in gen.unprocessed_prompts] == sorted(len(p) for p in prompts)      # shortest first
+    got, reasons, seen_prompts, _ = drain(gen)
+    for u, p, m, d in zip(uids, prompts, max_tokens, deltas):
+        want = stream_alone(p, m, d)
+        assert [t for t, _ in got[u]] == want, u
+        np.testing.assert_allclose([lp for _, lp in got[u]], [-t / V for t in want], rtol=1e-6)
+        assert reasons[u] == "length" and seen_prompts[u] == len(p)
+    st = gen.stats()
+    assert st.generation_tokens == sum(max_tokens) and st.prompt_tokens == sum(len(p) for p in prompts)
+    assert all(w in (1, 2, 4, 8) and w >= n >= 1 and (w == 1 or w // 2 < n) for w, n in gen.decode_widths)
+    assert max(gen.prefill_sizes) <= pbs
+    gen.close()
+    assert len(pool._free_pages) == free_pages and len(pool._free_seqs) == free_seqs       # everything given back
+
+
+def test_stop_tokens_finish_with_stop_and_report_the_token():
+    pool = make_pool()
+    prompts = [np.arange(1, 6), np.arange(2, 12), np.arange(3, 9)]
+    alone = [stream_alone(p, 10) for p in prompts]
+    stop = alone[1][3]
+    gen = MockEngineGenerator(pool, max_tokens=10, stop_tokens={stop}, compute_logprobs=False)
+    uids = gen.insert(prompts)
+    got, reasons, _, _ = drain(gen)
+    for u, s in zip(uids, alone):
+        want = s[: s.index(stop) + 1] if stop in s else s
+        assert [t for t, _ in got[u]] == want and all(lp == 0.0 for _, lp in got[u])
+        assert reasons[u] == ("stop" if want[-1] == stop else "length")
+    assert reasons[uids[1]] == "stop"
+    gen.close()
+
+
+def test_remove_in_queue_while_prefilled_and_while_decoding():
+    pool = make_pool()
+    free_pages = len(pool._free_pages)
+    prompts = [np.arange(1, 4 + i) for i in range(8)]
+    gen = MockEngineGenerator(pool, max_tokens=12, completion_batch_size=2, prefill_batch_size=2, prefill_ahead=2)
+    uids = gen.insert(prompts)
+    assert gen.remove(uids[7]) and not gen.remove(uids[7])               # still queued
+    gen.next()                                                           # admits 2 (+2 ahead), rows 0, 1 run
+    gen.next()
+    waiting = [u for p in gen._pending for (u, *_rest) in p.batch[p.joined:]]
+    assert len(waiting) == 2 and gen.remove(waiting[0])                  # prefilled, waiting for a row
+    running = [row.uid for row in gen._rows]
+    assert gen.remove(running[0]) and not gen.remove(12345)              # decoding
+    removed = {uids[7], waiting[0], running[0]}
+    got, reasons, _, _ = drain(gen)
+    for u, p in zip(uids, prompts):
+        if u in removed:
+            assert u not in reasons                      # no finish for a removed request ...
+            assert [t for t, _ in got.get(u, [])] == stream_alone(p, 12)[: len(got.get(u, []))]   # ... only a prefix
+            continue
+        assert [t for t, _ in got[u]] == stream_alone(p, 12)
+    survivors = [u for u in uids if u not in removed]
+    assert sorted(reasons) == sorted(survivors)
+    gen.close()
+    assert len(pool._free_pages) == free_pages
+
+
+def test_insert_while_running_and_identity_layout_pool():
+    """Requests inserted between rounds join as rows free up; the pool layout (paged / identity) is invisible to the
+    scheduler because it addresses KV through its own table."""
+    pool = make_pool(paged=False, max_seqs=12)
+    gen = MockEngineGenerator(pool, max_tokens=9, completion_batch_size=4, prefill_batch_size=4, prefill_ahead=1)
+    first = [np.arange(1, 8), np.arange(1, 5)]
+    late = [np.arange(5, 30), np.arange(2, 4), np.arange(7, 19)]
+    uids = gen.insert(first)
+    state = {}
+
+    def on_round(n, got):
+        if n == 3:
+            state["late"] = gen.insert(late, [5, 9, 2])
+
+    got, reasons, _, _ = drain(gen, on_round)
+    for u, p, m in zip(uids + state["late"], first + late, [9, 9, 5, 9, 2]):
+        assert [t for t, _ in got[u]] == stream_alone(p, m) and reasons[u] == "length"
+    gen.close()
+
+
+def test_rejects_what_the_built_path_does_not_do():
+    pool = make_pool()
+    with pytest.raises(NotImplementedError):
+        MockEngineGenerator(pool, kv_bits=4)
+    with pytest.raises(TypeError):
+        MockEngineGenerator(pool, sampler=lambda x: x)
+    gen = MockEngineGenerator(pool)
+    with pytest.raises(ValueError):
+        gen.insert([np.array([], dtype=np.int64)])
+    with pytest.raises(NotImplementedError):
+        gen.insert([np.arange(3)], logits_processors=[[lambda t, l: l]])
+    with pytest.raises(ValueError):
+        gen.insert([np.arange(3)], max_tokens=[1, 2])
+    gen.close()
