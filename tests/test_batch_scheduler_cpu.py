@@ -159,14 +159,17 @@ def test_remove_in_queue_while_prefilled_and_while_decoding():
     gen = MockEngineGenerator(pool, max_tokens=12, completion_batch_size=2, prefill_batch_size=2, prefill_ahead=2)
     uids = gen.insert(prompts)
     assert gen.remove(uids[7]) and not gen.remove(uids[7])               # still queued
-    gen.next()                                                           # admits 2 (+2 ahead), rows 0, 1 run
-    gen.next()
+    early = {}
+    for _ in range(2):                                                   # admits 2 (+2 ahead), rows 0, 1 run
+        for r in gen.next()[1]:
+            early.setdefault(r.uid, []).append((r.token, r.token_logprob))
     waiting = [u for p in gen._pending for (u, *_rest) in p.batch[p.joined:]]
     assert len(waiting) == 2 and gen.remove(waiting[0])                  # prefilled, waiting for a row
     running = [row.uid for row in gen._rows]
     assert gen.remove(running[0]) and not gen.remove(12345)              # decoding
     removed = {uids[7], waiting[0], running[0]}
     got, reasons, _, _ = drain(gen)
+    got = {u: early.get(u, []) + got.get(u, []) for u in uids}
     for u, p in zip(uids, prompts):
         if u in removed:
             assert u not in reasons                      # no finish for a removed request ...
