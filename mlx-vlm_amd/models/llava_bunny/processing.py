@@ -21,8 +21,12 @@ class ImageProcessor:
 
         if not isinstance(images, (list, tuple)):
             images = [images]
+        # rescale (float64 product cast to float32, as transformers' `rescale`) and normalise are pure functions of
+        # (channel, byte): one 3 x 256 table built with exactly those operations, expanded per channel
         mean = np.asarray(self.image_mean, dtype=np.float32)
         std = np.asarray(self.image_std, dtype=np.float32)
+        levels = (np.arange(256, dtype=np.float64) * self.rescale_factor).astype(np.float32)
+        lut = (levels[None, :] - mean[:, None]) / std[:, None]                     # float32 [3, 256]
         out = []
         for img in images:
             if not isinstance(img, Image.Image):
@@ -31,9 +35,8 @@ class ImageProcessor:
                     arr = np.transpose(arr, (1, 2, 0))                 # channels first input
                 img = Image.fromarray(arr.astype(np.uint8))
             pil = img.convert("RGB").resize((self.size[1], self.size[0]), resample=Image.BICUBIC)
-            x = (np.asarray(pil).astype(np.float64) * self.rescale_factor).astype(np.float32)
-            x = (x - mean) / std
-            out.append(np.ascontiguousarray(np.transpose(x, (2, 0, 1))))
+            hwc = np.asarray(pil)
+            out.append(np.stack([lut[c].take(hwc[:, :, c]) for c in range(3)]))
         return out
 
     __call__ = preprocess
