@@ -317,14 +317,16 @@ def main():
         ips336, dt336 = vit_throughput(model, cfg, args.vit_batch, 336)
         ips448, dt448 = vit_throughput(model, cfg, 1, 448)
         extras = dict(kernels=kr, vit336=(ips336, dt336), vit448=(ips448, dt448))
-        try:
-            extras["batch8"] = batch_decode_throughput(model, cfg, 8, 64)
-        except Exception as e:   # an extra must never cost the headline line
-            extras["batch8"] = {"error": f"{type(e).__name__}: {e}"}
-        try:
-            extras["continuous"] = continuous_batch_throughput(model, cfg)
-        except Exception as e:
-            extras["continuous"] = {"error": f"{type(e).__name__}: {e}"}
+        # exploratory single-GPU extras: not part of the scaling runs (the other ranks would only wait for rank 0)
+        for key, fn in (("batch8", lambda: batch_decode_throughput(model, cfg, 8, 64)),
+                        ("continuous", lambda: continuous_batch_throughput(model, cfg))):
+            if ws > 1:
+                extras[key] = None
+                continue
+            try:
+                extras[key] = fn()
+            except Exception as e:   # an extra must never cost the headline line
+                extras[key] = {"error": f"{type(e).__name__}: {e}"}
     cpu = None
     if rank == 0 and ws == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(min(os.cpu_count() or 1, 32))
@@ -372,7 +374,9 @@ def main():
             out["vision_single_448_tflops"] = ips448 * VIT_TFLOP_448
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    parallel.barrier()             # ranks leave together (rank 0 was still measuring the per-kernel rooflines)
+    parallel.shutdown()
 
 
 if __name__ == "__main__":

@@ -109,3 +109,9 @@ def sum_over_ranks(x: float, device=None) -> float:
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def shutdown():
+    """Tear the process group down (no-op for a single process)."""
+    if dist.is_initialized():
+        dist.destroy_process_group()
