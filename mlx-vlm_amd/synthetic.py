@@ -23,8 +23,53 @@ QWEN2_VL_7B = dict(
 )
 
 
+# nanoLLaVA (qnguyen3/nanoLLaVA: Qwen1.5-0.5B + SigLIP-so400m/14-384), public HF config values - BASELINE configs[0]
+NANOLLAVA = dict(
+    model_type="llava_bunny", auto_map={}, hidden_size=1024, mm_hidden_size=1152, num_hidden_layers=24,
+    intermediate_size=2816, num_attention_heads=16, num_key_value_heads=16, rms_norm_eps=1e-6, vocab_size=151936,
+    rope_theta=1000000.0, attention_bias=True, tie_word_embeddings=True, image_token_index=-200,
+    vision_config=dict(model_type="siglip_vision_model", num_hidden_layers=27, hidden_size=1152, intermediate_size=4304,
+                       num_attention_heads=16, image_size=384, patch_size=14),
+)
+
+
+def bunny_weight_shapes(cfg) -> Dict[str, tuple]:
+    """name -> shape for a llava_bunny ModelConfig, sanitized names (reference llava_bunny.py:180-222; the unused
+    pooling head of the tower is left out)."""
+    t, v = cfg.text_config, cfg.vision_config
+    E, I, D = v.hidden_size, v.intermediate_size, t.hidden_size
+    hd = D // t.num_attention_heads
+    V = "vision_tower.vision_tower.vision_model."
+    s: Dict[str, tuple] = {V + "embeddings.patch_embedding.weight": (E, v.patch_size, v.patch_size, v.num_channels),
+                           V + "embeddings.patch_embedding.bias": (E,),
+                           V + "embeddings.position_embedding.weight": ((v.image_size // v.patch_size) ** 2, E)}
+    for i in range(v.num_hidden_layers):
+        p = f"{V}encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s[p + f"self_attn.{n}.weight"], s[p + f"self_attn.{n}.bias"] = (E, E), (E,)
+        s.update({p + "layer_norm1.weight": (E,), p + "layer_norm1.bias": (E,), p + "layer_norm2.weight": (E,),
+                  p + "layer_norm2.bias": (E,), p + "mlp.fc1.weight": (I, E), p + "mlp.fc1.bias": (I,),
+                  p + "mlp.fc2.weight": (E, I), p + "mlp.fc2.bias": (E,)})
+    s.update({"mm_projector.linear_1.weight": (D, E), "mm_projector.linear_1.bias": (D,),
+              "mm_projector.linear_2.weight": (D, D), "mm_projector.linear_2.bias": (D,),
+              "language_model.model.embed_tokens.weight": (t.vocab_size, D)})
+    for i in range(t.num_hidden_layers):
+        p = f"language_model.model.layers.{i}."
+        s.update({p + "input_layernorm.weight": (D,), p + "post_attention_layernorm.weight": (D,),
+                  p + "self_attn.q_proj.weight": (t.num_attention_heads * hd, D), p + "self_attn.q_proj.bias": (t.num_attention_heads * hd,),
+                  p + "self_attn.k_proj.weight": (t.num_key_value_heads * hd, D), p + "self_attn.k_proj.bias": (t.num_key_value_heads * hd,),
+                  p + "self_attn.v_proj.weight": (t.num_key_value_heads * hd, D), p + "self_attn.v_proj.bias": (t.num_key_value_heads * hd,),
+                  p + "self_attn.o_proj.weight": (D, t.num_attention_heads * hd),
+                  p + "mlp.gate_proj.weight": (t.intermediate_size, D), p + "mlp.up_proj.weight": (t.intermediate_size, D),
+                  p + "mlp.down_proj.weight": (D, t.intermediate_size)})
+    s["language_model.model.norm.weight"] = (D,)
+    return s
+
+
 def weight_shapes(cfg) -> Dict[str, tuple]:
     """name -> shape for a qwen2_vl ModelConfig, sanitized names (reference qwen2_vl.py:179-190)."""
+    if getattr(cfg, "model_type", None) == "llava_bunny":
+        return bunny_weight_shapes(cfg)
     t, v = cfg.text_config, cfg.vision_config
     E, D = v.embed_dim, t.hidden_size
     hd = D // t.num_attention_heads
@@ -64,8 +109,7 @@ def random_weights(cfg, seed: int = 0, device="cuda", dtype=torch.bfloat16, std:
     for name, shape in weight_shapes(cfg).items():
         if not fill:
             W[name] = torch.empty(shape, dtype=dtype, device=device)
-        elif name.endswith("norm1.weight") or name.endswith("norm2.weight") or name.endswith("ln_q.weight") \
-                or name.endswith("layernorm.weight") or name.endswith("model.norm.weight"):
+        elif name.endswith(("norm1.weight", "norm2.weight", "ln_q.weight", "layernorm.weight", "model.norm.weight")):
             W[name] = torch.ones(shape, dtype=dtype, device=device)
         elif name.endswith(".bias"):
             W[name] = torch.zeros(shape, dtype=dtype, device=device)
