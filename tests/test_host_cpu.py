@@ -384,3 +384,42 @@ def test_bunny_load_processor_and_prepare_inputs(tmp_path):
     assert text["input_ids"].tolist() == [[9, 10, 11]] and "pixel_values" not in text
     with pytest.raises(ValueError):
         prepare_inputs(proc, images=img, prompts="no placeholder here")
+
+
+@pytest.mark.parametrize("family", ["qwen2_vl", "llava_bunny"])
+def test_model_construction_and_weight_packing_run_without_a_device(family):
+    """Config -> model -> synthetic weights -> load_weights on the CPU: arena sizing, q|k|v packing, gate/up interleave,
+    head padding / spreading and the KV pool are host logic and must not need a GPU (no kernel is launched).  The decode
+    state of the widest batch must fit the small-tensor arena as well."""
+    from mlx_vlm_amd import synthetic
+    from mlx_vlm_amd.models.qwen2_vl.language import DecodeState
+
+    if family == "qwen2_vl":
+        from mlx_vlm_amd.models.qwen2_vl import Model, ModelConfig
+        conf = dict(synthetic.QWEN2_VL_2B, hidden_size=256, num_hidden_layers=2, intermediate_size=512, num_attention_heads=2,
+                    num_key_value_heads=1, vocab_size=1024,
+                    vision_config=dict(synthetic.QWEN2_VL_2B["vision_config"], depth=2, embed_dim=160, hidden_size=256, num_heads=2))
+    else:
+        from mlx_vlm_amd.models.llava_bunny import Model, ModelConfig
+        conf = dict(synthetic.NANOLLAVA, hidden_size=128, mm_hidden_size=144, num_hidden_layers=2, intermediate_size=256,
+                    num_attention_heads=2, num_key_value_heads=2, vocab_size=1024,
+                    vision_config=dict(synthetic.NANOLLAVA["vision_config"], num_hidden_layers=2, hidden_size=144,
+                                       intermediate_size=288, num_attention_heads=2))
+    cfg = ModelConfig.from_dict(conf)
+    W = synthetic.random_weights(cfg, seed=0, device="cpu")
+    model = Model(cfg, device="cpu", kv_pool_tokens=2048, max_seqs=4)
+    model.load_weights(W)
+    lm = model.language_model
+    t = cfg.text_config
+    hd = lm.head_dim
+    assert hd == 128 and lm.pool.head_dim == 128
+    assert lm._w["0.wqkv"].shape == ((t.num_attention_heads + 2 * t.num_key_value_heads) * hd, t.hidden_size)
+    assert lm._w["0.wo"].shape == (t.hidden_size, t.num_attention_heads * hd)
+    assert lm._w["0.wgu"].shape == (2 * t.intermediate_size, t.hidden_size)
+    gate = W["language_model.model.layers.0.mlp.gate_proj.weight"]
+    assert torch.equal(lm._w["0.wgu"][0::2], gate) and torch.equal(lm._w["0.wgu"][1], W["language_model.model.layers.0.mlp.up_proj.weight"][0])
+    st = DecodeState(lm, 8)
+    assert st.h.shape == (8, t.hidden_size) and st.attn.shape == (8, t.num_attention_heads * hd)
+    if family == "llava_bunny":
+        assert float(lm._w["inv_freq"][32:].abs().max()) == 0.0 and float(lm._w["inv_freq"][0]) == 1.0
+        assert model.vision_tower._w["0.wqkv"].shape == (3 * 2 * 80, 144)
