@@ -147,6 +147,14 @@ int vlm_sample(const void* logits, int ld, int B, int V, void* logprobs, void* s
                void* workspace, float temperature, float top_p, float min_p, int top_k, unsigned seed,
                const void* step_ptr, void* stream);
 
+/* The greedy tail of a decode step in two launches instead of five: vlm_sample at temperature 0 (ar.py:368 logprobs,
+ * sample_utils.py:63-64 argmax) + vlm_decode_advance (cache.py:362, language.py:476-509) + the NEXT step's
+ * vlm_embed_gather (language.py:164,179): h[b] = embed[tok[b]] (row stride ldh).  workspace: vlm_sample_workspace_bytes,
+ * zero-filled once at allocation (its first word is an arrival ticket the kernel re-arms). */
+int vlm_sample_greedy_advance(const void* logits, int ld, int B, int V, void* logprobs, int ldlp, void* tok,
+                              void* workspace, void* ctx, void* pos, void* out_ring, int ring_len, void* step,
+                              const void* embed, void* h, int D, int ldh, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Model-level engine: the layer loops of Qwen2Model / VisionModel run natively so that a decode
  * step is ~150 back-to-back launches with no host code in between and can be captured in a
@@ -207,7 +215,14 @@ typedef struct vlm_decode_args {
   float temperature, top_p, min_p;
   int top_k;
   unsigned seed;
+  int flags; /* VLM_DECODE_* */
 } vlm_decode_args;
+
+/* vlm_decode_args.flags */
+#define VLM_DECODE_FUSED_TAIL 1 /* greedy only: the step does not start with the embedding gather - h already holds
+                                   embed[tok] (the caller gathers it once after the prefill, vlm_embed_gather) and the
+                                   sampler tail (vlm_sample_greedy_advance) leaves the next step's h behind.  The host
+                                   must not rewrite tok between steps. */
 
 int vlm_llm_create(const vlm_llm_config* cfg, void** handle);          /* (host) */
 int vlm_llm_destroy(void* handle);
@@ -223,6 +238,25 @@ int vlm_llm_decode_graph_build(void* handle, const vlm_decode_args* a, void* str
 int vlm_llm_decode_graph_launch(void* handle, void* stream);
 /* number of kernel launches in one decode step (for reporting) */
 int vlm_llm_decode_launches(void* handle);
+
+/* Tuning of the captured decode step (no effect on results; measured defaults in DESIGN.md).  Changing a value drops
+ * the cached graphs of the handle.
+ *   VLM_TUNE_PREFETCH       0 = off; 1 = a side branch of the graph pulls the next layer's weights (and the K/V pages its
+ *                           attention reads) towards the 256 MB Infinity Cache while the current layer runs, one launch per
+ *                           layer started by a graph edge from the chain; 2 = the same from ONE persistent side kernel per
+ *                           step paced by a device word the chain publishes (no graph edge leaves the chain)
+ *   VLM_TUNE_PREFETCH_WGS   workgroups of the side kernel (default 256)
+ *   VLM_TUNE_PREFETCH_MASK  what is prefetched: bit 0 Wqkv, 1 Wo, 2 Wgate/up, 3 Wdown, 4 K/V pages, 5 the first
+ *                           lm_head rows during the last layer, 6 layer 0 of the next step during the sampler tail */
+#define VLM_TUNE_PREFETCH 0
+#define VLM_TUNE_PREFETCH_WGS 1
+#define VLM_TUNE_PREFETCH_MASK 2
+#define VLM_TUNE_PREFETCH_HEAD_MB 3 /* MiB of lm_head rows covered by mask bit 5 (default 96) */
+#define VLM_TUNE_DEBUG_SKIP 4       /* MEASUREMENT ONLY (results become meaningless): leave launches out of the captured step
+                                       to read their marginal cost off the wall clock - bit 0 qkv, 1 attention, 2 o_proj,
+                                       3 gate/up, 4 down, 5 lm_head, 6 sampler tail */
+int vlm_llm_set_tuning(void* handle, int key, int value);
+int vlm_llm_get_tuning(void* handle, int key);
 
 typedef struct vlm_vit_config {
   int depth, embed_dim, n_heads, mlp_hidden, patch_k /* padded K of the patch GEMM */, merge /* 2 */, out_dim;

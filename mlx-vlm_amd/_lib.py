@@ -46,7 +46,8 @@ class DecodeArgs(C.Structure):
                 ("h", c_void_p), ("qkv", c_void_p), ("attn", c_void_p), ("act", c_void_p), ("logits", c_void_p),
                 ("logprobs", c_void_p), ("scratch", c_void_p), ("part_o", c_void_p), ("part_ml", c_void_p),
                 ("sample_ws", c_void_p), ("out_ring", c_void_p), ("ring_len", c_int), ("nsplit", c_int),
-                ("temperature", c_float), ("top_p", c_float), ("min_p", c_float), ("top_k", c_int), ("seed", c_uint)]
+                ("temperature", c_float), ("top_p", c_float), ("min_p", c_float), ("top_k", c_int), ("seed", c_uint),
+                ("flags", c_int)]
 
 
 class VitConfig(C.Structure):
@@ -69,6 +70,9 @@ class VitArgs(C.Structure):
                 ("qkv", c_void_p), ("attn", c_void_p), ("mlp", c_void_p), ("mrg", c_void_p), ("out", c_void_p),
                 ("uniform_segments", c_int)]
 
+
+DECODE_FUSED_TAIL = 1                       # vlm_decode_args.flags
+TUNE_PREFETCH, TUNE_PREFETCH_WGS, TUNE_PREFETCH_MASK, TUNE_PREFETCH_HEAD_MB = 0, 1, 2, 3   # vlm_llm_set_tuning keys
 
 P = C.POINTER
 # name -> (restype, argtypes); every symbol include/vlm_hip.h declares
@@ -95,6 +99,10 @@ SIGNATURES = {
     "vlm_sample_workspace_bytes": (c_size_t, [c_int]),
     "vlm_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float,
                            c_float, c_float, c_int, c_uint, c_void_p, c_void_p]),
+    "vlm_sample_greedy_advance": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "vlm_llm_set_tuning": (c_int, [c_void_p, c_int, c_int]),
+    "vlm_llm_get_tuning": (c_int, [c_void_p, c_int]),
     "vlm_llm_create": (c_int, [P(LlmConfig), P(c_void_p)]),
     "vlm_llm_destroy": (c_int, [c_void_p]),
     "vlm_llm_set_layer": (c_int, [c_void_p, c_int, P(LlmLayer)]),
@@ -169,12 +177,19 @@ class _PinnedRing:
         if start + n > self.buf.numel():
             start = 0
         end = start + n
-        while self.inflight:
-            s0, e0, ev = self.inflight[0]
+        # the ring has come around: every upload still reading bytes of [start, end) must have executed.  Entries are in
+        # issue order and uploads of one stream complete in that order, so waiting for the NEWEST overlapping one covers
+        # the older ones; the whole deque is scanned (after a wrap the head may sit in the skipped tail of the buffer,
+        # not overlap and still be pending, with overlapping entries behind it)
+        newest = -1
+        for i, (s0, e0, _) in enumerate(self.inflight):
             if s0 < end and start < e0:
-                ev.synchronize()                      # the ring has come around to a region still being read
-            elif not ev.query():
-                break
+                newest = i
+        if newest >= 0:
+            self.inflight[newest][2].synchronize()
+            for _ in range(newest + 1):
+                self.inflight.popleft()
+        while self.inflight and self.inflight[0][2].query():
             self.inflight.popleft()
         view = self.buf[start:end].view(t.dtype).view(t.shape)
         view.copy_(t)

@@ -193,7 +193,11 @@ class BatchGenerator:
         for c, L, b in zip(caches, lens, batch):
             c[0]._seq.reserve(L + b[2] + 2)          # prompt + every token it may generate + the step in flight
         logits = lm.prefill(emb, pos, caches, lens, "last")
-        step0 = torch.zeros(1, dtype=torch.int32, device=logits.device)
+        # RNG stream of the first tokens: the sampler keys its noise on (seed, step, row, index).  Decode steps count up
+        # from 1 (see _borrow_state); every admission takes its own step value from a range they never reach, so no
+        # (step, row) pair is used twice - neither between an admission and a decode step nor between two admissions
+        self._admissions = getattr(self, "_admissions", 0) + 1
+        step0 = torch.full((1,), 0x40000000 + (self._admissions & 0x3FFFFFFF), dtype=torch.int32, device=logits.device)
         tok0, lp = ops.sample(logits, step=step0, want_logprobs=self.compute_logprobs, **self._sargs)
         lp0 = lp.gather(1, tok0.long()[:, None]).reshape(-1).float() if self.compute_logprobs else None
         ctx = np.asarray(lens, dtype=np.int32)
@@ -223,6 +227,7 @@ class BatchGenerator:
         st.in_use = True
         for buf in (st.tok, st.pos, st.ctx, st.step):
             buf.zero_()
+        st.step.fill_(1)          # sampling step counter of the decode steps (0 is never used: see _prefill_requests)
         return st
 
     # ------------------------------------------------------------------ queue (reference ar.py:2584-2670)

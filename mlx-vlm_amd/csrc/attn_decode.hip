@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include "common.cuh"
+#include "internal.h"
 #include "../../include/vlm_hip.h"
 
 namespace {
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ kpool, const bf16_t* __restrict__ vpool,
     const int* __restrict__ block_table, const int* __restrict__ kv_len, int ldq, int max_pages, int Hkv, int kv_len_add,
     int Hq, float scale_log2, int nsplit, int ldo, float* __restrict__ part_o, float* __restrict__ part_ml,
-    bf16_t* __restrict__ out) {
+    bf16_t* __restrict__ out, VlmProgress prog) {
   __shared__ __attribute__((aligned(16))) float red_o[NW][G][HD];
   __shared__ float red_m[NW][G], red_l[NW][G];
 
@@ -234,6 +235,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
     }
   }
   stamp(8);
+  // pacing word of the weight prefetcher (csrc/prefetch.hip): a hint, nothing is ordered by it
+  if (prog.word && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+    __hip_atomic_store(prog.word, prog.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ part_o,
@@ -254,10 +258,9 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* _
 
 }  // namespace
 
-extern "C" int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, const void* vpool,
-                                     const void* block_table, int max_pages, const void* kv_len, int kv_len_add, int B,
-                                     int Hq, int Hkv, int D, float scale, int nsplit, void* part_o, void* part_ml,
-                                     void* out, int ldo, void* stream) {
+int vlm_attn_decode_paged_ex(const void* q, int ldq, const void* kpool, const void* vpool, const void* block_table,
+                             int max_pages, const void* kv_len, int kv_len_add, int B, int Hq, int Hkv, int D, float scale,
+                             int nsplit, void* part_o, void* part_ml, void* out, int ldo, VlmProgress prog, void* stream) {
   if (!q || !kpool || !vpool || !kv_len || max_pages <= 0) return VLM_ERR_ARG;   // block_table == NULL: identity layout
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || nsplit <= 0 || Hq % Hkv != 0) return VLM_ERR_ARG;
   if (nsplit > 1 && (!part_o || !part_ml)) return VLM_ERR_ARG;
@@ -279,16 +282,16 @@ extern "C" int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, 
     hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, 8, true, false>), grid, dim3(8 * 64), 0, st, \
                        (const bf16_t*)q, (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)block_table,           \
                        (const int*)kv_len, ldq, max_pages, Hkv, kv_len_add, Hq, sl2, nsplit, ldo, (float*)part_o,       \
-                       (float*)part_ml, direct);                                                                        \
+                       (float*)part_ml, direct, prog);                                                                  \
   else                                                                                                                  \
   if (!block_table)                                                                                                     \
     hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, 8, false, true>), grid, dim3(8 * 64), 0, st, (const bf16_t*)q,      \
                        (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)nullptr, (const int*)kv_len, ldq,        \
-                       max_pages, Hkv, kv_len_add, Hq, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, direct);      \
+                       max_pages, Hkv, kv_len_add, Hq, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, direct, prog);\
   else                                                                                                                  \
     hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, 8, false, false>), grid, dim3(8 * 64), 0, st, (const bf16_t*)q,     \
                        (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)block_table, (const int*)kv_len, ldq,    \
-                       max_pages, Hkv, kv_len_add, Hq, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, direct)
+                       max_pages, Hkv, kv_len_add, Hq, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, direct, prog)
   switch (G) {
     case 1: GO(1); break;
     case 2: GO(2); break;
@@ -308,4 +311,12 @@ extern "C" int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, 
     VLM_CHECK_LAUNCH();
   }
   return VLM_OK;
+}
+
+extern "C" int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, const void* vpool,
+                                     const void* block_table, int max_pages, const void* kv_len, int kv_len_add, int B,
+                                     int Hq, int Hkv, int D, float scale, int nsplit, void* part_o, void* part_ml,
+                                     void* out, int ldo, void* stream) {
+  return vlm_attn_decode_paged_ex(q, ldq, kpool, vpool, block_table, max_pages, kv_len, kv_len_add, B, Hq, Hkv, D, scale,
+                                  nsplit, part_o, part_ml, out, ldo, VlmProgress{nullptr, 0}, stream);
 }

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/vlm_hip.h"
+#include "internal.h"
 
 #define TRY(expr)            \
   do {                       \
@@ -35,10 +36,27 @@ struct DecodeGraph {
   hipGraphExec_t exec;
   int launches;
   unsigned long long last_use;
+  VlmPfItem* pf_items = nullptr;          // device list of the persistent prefetcher (owned)
+  std::vector<hipEvent_t> events;         // fork / join events of the capture (owned)
 };
 constexpr size_t MAX_DECODE_GRAPHS = 16;
 
+// defaults: off until DESIGN.md's measurement picks them (vlm_llm_set_tuning)
+struct Tuning {
+  int prefetch = 0, wgs = 256, mask = 0x7f, head_mb = 96, debug_skip = 0;
+};
+
+// the second branch of a captured step (prefetch side chain)
+struct Fork {
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t>* events = nullptr;
+  const VlmPfItem* items_dev = nullptr;   // persistent form: the device list (built before the capture starts)
+  int n_items = 0;
+};
+
 struct Llm {
+  Tuning tune;
+  int* progress = nullptr;                // [0] pacing word, [1] exit counter of the persistent prefetcher (device)
   vlm_llm_config cfg;
   std::vector<vlm_llm_layer> layers;
   vlm_llm_globals g{};
@@ -55,7 +73,8 @@ inline bool same_key(const DecodeGraph& g, const vlm_decode_args& a, const vlm_k
          a.qkv == b.qkv && a.attn == b.attn && a.act == b.act && a.logits == b.logits && a.logprobs == b.logprobs &&
          a.scratch == b.scratch && a.part_o == b.part_o && a.part_ml == b.part_ml && a.sample_ws == b.sample_ws &&
          a.out_ring == b.out_ring && a.ring_len == b.ring_len && a.nsplit == b.nsplit && a.temperature == b.temperature &&
-         a.top_p == b.top_p && a.min_p == b.min_p && a.top_k == b.top_k && a.seed == b.seed && kv.kpool == g.kv.kpool &&
+         a.top_p == b.top_p && a.min_p == b.min_p && a.top_k == b.top_k && a.seed == b.seed && a.flags == b.flags &&
+         kv.kpool == g.kv.kpool &&
          kv.vpool == g.kv.vpool && kv.layer_stride == g.kv.layer_stride && kv.block_table == g.kv.block_table &&
          kv.max_pages == g.kv.max_pages;
 }
@@ -63,6 +82,8 @@ inline bool same_key(const DecodeGraph& g, const vlm_decode_args& a, const vlm_k
 inline void drop_graph(DecodeGraph& g) {
   if (g.exec) (void)hipGraphExecDestroy(g.exec);
   if (g.graph) (void)hipGraphDestroy(g.graph);
+  if (g.pf_items) (void)hipFree(g.pf_items);
+  for (hipEvent_t e : g.events) (void)hipEventDestroy(e);
 }
 
 struct Vit {
@@ -75,7 +96,7 @@ inline char* off(void* p, size_t bytes) { return static_cast<char*>(p) + bytes; 
 
 }  // namespace
 
-extern "C" int vlm_abi_version(void) { return 1; }
+extern "C" int vlm_abi_version(void) { return 2; }
 
 // ------------------------------------------------------------------ LLM
 extern "C" int vlm_llm_create(const vlm_llm_config* cfg, void** handle) {
@@ -93,8 +114,42 @@ extern "C" int vlm_llm_destroy(void* handle) {
   Llm* m = static_cast<Llm*>(handle);
   if (!m) return 1;
   for (DecodeGraph& g : m->graphs) drop_graph(g);
+  if (m->progress) (void)hipFree(m->progress);
   delete m;
   return 0;
+}
+
+extern "C" int vlm_llm_set_tuning(void* handle, int key, int value) {
+  Llm* m = static_cast<Llm*>(handle);
+  if (!m) return 1;
+  int* slot = nullptr;
+  switch (key) {
+    case VLM_TUNE_PREFETCH: if (value < 0 || value > 2) return 1; slot = &m->tune.prefetch; break;
+    case VLM_TUNE_PREFETCH_WGS: if (value <= 0 || value > 4096) return 1; slot = &m->tune.wgs; break;
+    case VLM_TUNE_PREFETCH_MASK: slot = &m->tune.mask; break;
+    case VLM_TUNE_PREFETCH_HEAD_MB: if (value < 0) return 1; slot = &m->tune.head_mb; break;
+    case VLM_TUNE_DEBUG_SKIP: slot = &m->tune.debug_skip; break;
+    default: return 1;
+  }
+  if (*slot == value) return 0;
+  *slot = value;
+  for (DecodeGraph& g : m->graphs) drop_graph(g);     // the captured steps bake the tuning in
+  m->graphs.clear();
+  m->exec = nullptr;
+  return 0;
+}
+
+extern "C" int vlm_llm_get_tuning(void* handle, int key) {
+  Llm* m = static_cast<Llm*>(handle);
+  if (!m) return -1;
+  switch (key) {
+    case VLM_TUNE_PREFETCH: return m->tune.prefetch;
+    case VLM_TUNE_PREFETCH_WGS: return m->tune.wgs;
+    case VLM_TUNE_PREFETCH_MASK: return m->tune.mask;
+    case VLM_TUNE_PREFETCH_HEAD_MB: return m->tune.head_mb;
+    case VLM_TUNE_DEBUG_SKIP: return m->tune.debug_skip;
+    default: return -1;
+  }
 }
 
 extern "C" int vlm_llm_set_layer(void* handle, int layer, const vlm_llm_layer* w) {
@@ -158,46 +213,154 @@ extern "C" int vlm_llm_prefill(void* handle, const vlm_prefill_args* a, void* st
   return 0;
 }
 
-static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* launches, bool sample) {
+// what layer i streams, as a prefetch item (mask: bit 0 Wqkv, 1 Wo, 2 Wgu, 3 Wdown, 4 K/V pages)
+static VlmPfItem layer_item(const Llm* m, int i, int mask, int need) {
   const vlm_llm_config& c = m->cfg;
-  const int D = c.hidden, hd = c.head_dim, Hq = c.n_heads, Hkv = c.n_kv_heads, B = a->B;
+  const vlm_llm_layer& w = m->layers[i];
+  const size_t D = (size_t)c.hidden, QKV = (size_t)(c.n_heads + 2 * c.n_kv_heads) * c.head_dim;
+  VlmPfItem it{};
+  if (mask & 1) it.seg[it.nseg++] = VlmPfSeg{w.wqkv, QKV * D * 2};
+  if (mask & 2) it.seg[it.nseg++] = VlmPfSeg{w.wo, D * (size_t)c.n_heads * c.head_dim * 2};
+  if (mask & 4) it.seg[it.nseg++] = VlmPfSeg{w.wgu, 2 * (size_t)c.inter * D * 2};
+  if (mask & 8) it.seg[it.nseg++] = VlmPfSeg{w.wdown, (size_t)c.inter * D * 2};
+  if (mask & 16) {
+    it.kbase = off(m->kv.kpool, (size_t)i * m->kv.layer_stride * 2);
+    it.vbase = off(m->kv.vpool, (size_t)i * m->kv.layer_stride * 2);
+  }
+  it.need = need;
+  return it;
+}
+
+static VlmPfItem head_item(const Llm* m, int need) {
+  const vlm_llm_config& c = m->cfg;
+  VlmPfItem it{};
+  size_t bytes = (size_t)c.vocab * c.hidden * 2, cap = (size_t)m->tune.head_mb << 20;
+  it.seg[it.nseg++] = VlmPfSeg{m->g.lm_head, bytes < cap ? bytes : cap};
+  it.need = need;
+  return it;
+}
+
+// the walk list of the persistent prefetcher: item for layer i >= 1 starts once layer i - 1's attention is done (pacing
+// word == i); then the first lm_head rows during the last layer; then layer 0 of the NEXT step once the sampler tail
+// has started (word == n_layers + 1)
+static std::vector<VlmPfItem> persistent_items(const Llm* m) {
+  const int NL = m->cfg.n_layers, mask = m->tune.mask;
+  std::vector<VlmPfItem> items;
+  for (int i = 1; i < NL; ++i) items.push_back(layer_item(m, i, mask, i));
+  if (mask & 32) items.push_back(head_item(m, NL));
+  if (mask & 64) items.push_back(layer_item(m, 0, mask, NL + 1));
+  return items;
+}
+
+static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* launches, bool sample, Fork* fork) {
+  const vlm_llm_config& c = m->cfg;
+  const int D = c.hidden, hd = c.head_dim, Hq = c.n_heads, Hkv = c.n_kv_heads, B = a->B, NL = c.n_layers;
   const int QKV = (Hq + 2 * Hkv) * hd;
   const float scale = c.attn_scale > 0.f ? c.attn_scale : 1.0f / sqrtf((float)hd);
+  const bool fused_tail = sample && (a->flags & VLM_DECODE_FUSED_TAIL) && a->temperature == 0.f;
+  if ((a->flags & VLM_DECODE_FUSED_TAIL) && !fused_tail) return 1;   // the flag promises h == embed[tok] at entry
+  const Tuning& tn = m->tune;
+  const int skip = tn.debug_skip;      // measurement only
+  const int pf = (fork && fork->side && m->progress && B <= 8) ? tn.prefetch : 0;
+  const VlmPfKv pfkv{(const int*)a->ctx, (const int*)m->kv.block_table, m->kv.max_pages, B,
+                     (size_t)Hkv * hd * 64 * 2};
+  hipStream_t main_s = (hipStream_t)stream;
   int n = 0;
+  auto new_event = [&](hipEvent_t* e) -> int {
+    hipError_t r = hipEventCreateWithFlags(e, hipEventDisableTiming);
+    if (r != hipSuccess) return 1000 + (int)r;
+    fork->events->push_back(*e);
+    return 0;
+  };
+  // edge chain -> side branch: everything enqueued on the chain so far precedes what the side stream does next
+  auto edge_to_side = [&]() -> int {
+    hipEvent_t e;
+    TRY(new_event(&e));
+    if (hipEventRecord(e, main_s) != hipSuccess) return 1001;
+    if (hipStreamWaitEvent(fork->side, e, 0) != hipSuccess) return 1002;
+    return 0;
+  };
+  if (pf) TRY(edge_to_side());          // fork: the side stream joins the capture
+  if (pf == 2 && fork->n_items > 0) {
+    TRY(vlm_prefetch_persistent_launch(fork->items_dev, fork->n_items, &pfkv, m->progress, (unsigned*)(m->progress + 1),
+                                       tn.wgs, fork->side)); ++n;
+  }
   // h = embed[tok]
-  TRY(vlm_embed_gather(a->tok, m->g.embed, a->h, B, D, D, c.vocab, stream)); ++n;
-  for (int i = 0; i < c.n_layers; ++i) {
+  if (!fused_tail) { TRY(vlm_embed_gather(a->tok, m->g.embed, a->h, B, D, D, c.vocab, stream)); ++n; }
+  for (int i = 0; i < NL; ++i) {
     const vlm_llm_layer& w = m->layers[i];
     void* kp = off(m->kv.kpool, (size_t)i * m->kv.layer_stride * 2);
     void* vp = off(m->kv.vpool, (size_t)i * m->kv.layer_stride * 2);
     // [RMSNorm + qkv GEMV + bias + M-RoPE at pos[b] + k/v write at slot ctx[b]] in one launch
+    if (!(skip & 1)) {
     TRY(vlm_gemv_qkv_rope_kvwrite(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos, a->ctx,
                                   m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, stream)); ++n;
+    }
     // attention over the pages (the new token is already in the cache: kv_len = ctx + 1)
-    if (a->nsplit == 1) {
+    const VlmProgress prog{pf == 2 ? m->progress : nullptr, i + 1};
+    if (skip & 2) {
+    } else if (a->nsplit == 1) {
       // short contexts: one workgroup per (sequence, kv head) -> final bf16 vector, plain o_proj GEMV + residual
-      TRY(vlm_attn_decode_paged(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale, 1,
-                                a->part_o, a->part_ml, a->attn, Hq * hd, stream)); ++n;
+      TRY(vlm_attn_decode_paged_ex(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale, 1,
+                                   a->part_o, a->part_ml, a->attn, Hq * hd, prog, stream)); ++n;
+    } else {
+      // long contexts: split-K partials, merged in the o_proj GEMV prologue
+      TRY(vlm_attn_decode_paged_ex(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale,
+                                   a->nsplit, a->part_o, a->part_ml, nullptr, 0, prog, stream)); ++n;
+    }
+    if (pf == 1) {
+      // the layer's weight stream (o_proj, gate/up, down: ~20 us) starts here; the side branch pulls the NEXT layer in
+      // the meantime.  Last layer: the first lm_head rows.
+      VlmPfItem it{};
+      if (i + 1 < NL) it = layer_item(m, i + 1, tn.mask, 0);
+      else if (tn.mask & 32) it = head_item(m, 0);
+      if (it.nseg > 0 || it.kbase) {
+        TRY(edge_to_side());
+        TRY(vlm_prefetch_launch(&it, &pfkv, tn.wgs, fork->side)); ++n;
+      }
+    }
+    if (skip & 4) {
+    } else if (a->nsplit == 1) {
       TRY(vlm_gemv_bf16(a->attn, w.wo, nullptr, a->h, nullptr, a->h, B, D, Hq * hd, Hq * hd, Hq * hd, D, D, 0.f,
                         VLM_EPI_RESIDUAL, stream)); ++n;
     } else {
-      // long contexts: split-K partials, merged in the o_proj GEMV prologue
-      TRY(vlm_attn_decode_paged(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale,
-                                a->nsplit, a->part_o, a->part_ml, nullptr, 0, stream)); ++n;
       TRY(vlm_gemv_attn_out(a->part_o, a->part_ml, a->nsplit, w.wo, a->h, D, B, D, Hq, hd, stream)); ++n;
     }
     // act = swiglu(RMSNorm(h) Wgu^T)
+    if (!(skip & 8))
     TRY(vlm_gemv_bf16(a->h, w.wgu, nullptr, nullptr, w.ln2_w, a->act, B, 2 * c.inter, D, D, D, c.inter, 0, c.rms_eps, VLM_EPI_SWIGLU, stream)); ++n;
     // h = h + act Wdown^T
+    if (!(skip & 16))
     TRY(vlm_gemv_bf16(a->act, w.wdown, nullptr, a->h, nullptr, a->h, B, D, c.inter, c.inter, c.inter, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
   }
   // logits = RMSNorm(h) lm_head^T
+  if (!(skip & 32))
   TRY(vlm_gemv_bf16(a->h, m->g.lm_head, nullptr, nullptr, m->g.final_norm_w, a->logits, B, c.vocab, D, D, D, c.vocab, 0,
                     c.rms_eps, VLM_EPI_NONE, stream)); ++n;
-  if (sample) {
-    TRY(vlm_sample(a->logits, c.vocab, B, c.vocab, a->logprobs, a->scratch, c.vocab, a->tok, a->sample_ws, a->temperature,
-                   a->top_p, a->min_p, a->top_k, a->seed, a->step, stream)); n += 3;
-    TRY(vlm_decode_advance(a->ctx, a->pos, a->tok, a->out_ring, a->ring_len, a->step, B, stream)); ++n;
+  if (sample && !(skip & 64)) {
+    if (pf == 1 && (tn.mask & 64)) {
+      // the sampler tail moves 0.3 MB: pull layer 0 for the next step while it runs
+      const VlmPfItem it = layer_item(m, 0, tn.mask, 0);
+      TRY(edge_to_side());
+      TRY(vlm_prefetch_launch(&it, &pfkv, tn.wgs, fork->side)); ++n;
+    }
+    const VlmProgress tail_prog{pf == 2 ? m->progress : nullptr, NL + 1};
+    if (fused_tail) {
+      TRY(vlm_sample_greedy_advance_ex(a->logits, c.vocab, B, c.vocab, a->logprobs, c.vocab, a->tok, a->sample_ws, a->ctx,
+                                       a->pos, a->out_ring, a->ring_len, a->step, m->g.embed, a->h, D, D, tail_prog,
+                                       stream)); n += 2;
+    } else {
+      TRY(vlm_sample_ex(a->logits, c.vocab, B, c.vocab, a->logprobs, a->scratch, c.vocab, a->tok, a->sample_ws, a->temperature,
+                        a->top_p, a->min_p, a->top_k, a->seed, a->step, tail_prog, stream)); n += 3;
+      TRY(vlm_decode_advance(a->ctx, a->pos, a->tok, a->out_ring, a->ring_len, a->step, B, stream)); ++n;
+    }
+  }
+  if (pf) {
+    // join: the capture ends on the chain's stream with the side branch folded back in
+    hipEvent_t e;
+    TRY(new_event(&e));
+    if (hipEventRecord(e, fork->side) != hipSuccess) return 1005;
+    if (hipStreamWaitEvent(main_s, e, 0) != hipSuccess) return 1006;
   }
   if (launches) *launches = n;
   return 0;
@@ -206,7 +369,7 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
 extern "C" int vlm_llm_decode_step(void* handle, const vlm_decode_args* a, void* stream) {
   Llm* m = static_cast<Llm*>(handle);
   if (!m || !a || a->B <= 0 || !m->kv.kpool) return 1;
-  return decode_impl(m, a, stream, &m->launches, true);
+  return decode_impl(m, a, stream, &m->launches, true, nullptr);
 }
 
 // embeddings -> logits only (the module-contract path: language_model(y, cache=...) at L == 1;
@@ -214,7 +377,7 @@ extern "C" int vlm_llm_decode_step(void* handle, const vlm_decode_args* a, void*
 extern "C" int vlm_llm_decode_forward(void* handle, const vlm_decode_args* a, void* stream) {
   Llm* m = static_cast<Llm*>(handle);
   if (!m || !a || a->B <= 0 || !m->kv.kpool) return 1;
-  return decode_impl(m, a, stream, nullptr, false);
+  return decode_impl(m, a, stream, nullptr, false, nullptr);
 }
 
 extern "C" int vlm_llm_decode_graph_build(void* handle, const vlm_decode_args* a, void* stream) {
@@ -236,12 +399,35 @@ extern "C" int vlm_llm_decode_graph_build(void* handle, const vlm_decode_args* a
   hipStream_t cap = nullptr;
   hipError_t e = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking);
   if (e != hipSuccess) return 1000 + (int)e;
-  e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
-  if (e != hipSuccess) { (void)hipStreamDestroy(cap); return 1000 + (int)e; }
   DecodeGraph ng{*a, m->kv, nullptr, nullptr, 0, ++m->tick};
-  int rc = decode_impl(m, a, (void*)cap, &ng.launches, true);
+  hipStream_t side = nullptr;
+  if (m->tune.prefetch) {
+    if (!m->progress) {
+      if (hipMalloc(&m->progress, 256) != hipSuccess || hipMemset(m->progress, 0, 256) != hipSuccess) return 1007;
+    }
+    e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+    if (e != hipSuccess) { (void)hipStreamDestroy(cap); return 1000 + (int)e; }
+  }
+  Fork fork{side, &ng.events, nullptr, 0};
+  if (m->tune.prefetch == 2) {
+    // device allocations are not allowed inside a capture: the list is built first
+    const std::vector<VlmPfItem> items = persistent_items(m);
+    if (!items.empty()) {
+      if (hipMalloc(&ng.pf_items, items.size() * sizeof(VlmPfItem)) != hipSuccess ||
+          hipMemcpy(ng.pf_items, items.data(), items.size() * sizeof(VlmPfItem), hipMemcpyHostToDevice) != hipSuccess) {
+        drop_graph(ng); (void)hipStreamDestroy(cap); (void)hipStreamDestroy(side);
+        return 1003;
+      }
+      fork.items_dev = ng.pf_items;
+      fork.n_items = (int)items.size();
+    }
+  }
+  e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) { drop_graph(ng); (void)hipStreamDestroy(cap); if (side) (void)hipStreamDestroy(side); return 1000 + (int)e; }
+  int rc = decode_impl(m, a, (void*)cap, &ng.launches, true, side ? &fork : nullptr);
   e = hipStreamEndCapture(cap, &ng.graph);
   (void)hipStreamDestroy(cap);
+  if (side) (void)hipStreamDestroy(side);
   if (rc != 0) { drop_graph(ng); return rc; }
   if (e != hipSuccess) { drop_graph(ng); return 1000 + (int)e; }
   e = hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0);

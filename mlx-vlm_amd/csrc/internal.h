@@ -1,0 +1,52 @@
+// Library-internal entry points (hidden visibility: not part of the C ABI of include/vlm_hip.h).
+// They are the exported operators plus the hooks the decode engine needs to keep the HBM busy
+// between the dependent kernels of a step (csrc/engine.hip, csrc/prefetch.hip).
+#pragma once
+#include <stddef.h>
+
+#define VLM_INTERNAL __attribute__((visibility("hidden")))
+
+// Pacing word of the weight prefetcher: the decode chain publishes "layer i's attention is done" (value i + 1) and
+// "the sampler tail has started" (n_layers + 1) with one relaxed agent-scope store; nothing is ordered by it - it
+// only tells the side kernel when to start pulling the next layer's weights towards the Infinity Cache.
+struct VlmProgress {
+  int* word;   // nullptr: no publication
+  int value;
+};
+
+VLM_INTERNAL int vlm_attn_decode_paged_ex(const void* q, int ldq, const void* kpool, const void* vpool,
+                                          const void* block_table, int max_pages, const void* kv_len, int kv_len_add, int B,
+                                          int Hq, int Hkv, int D, float scale, int nsplit, void* part_o, void* part_ml,
+                                          void* out, int ldo, VlmProgress prog, void* stream);
+
+VLM_INTERNAL int vlm_sample_ex(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
+                               void* workspace, float temperature, float top_p, float min_p, int top_k, unsigned seed,
+                               const void* step_ptr, VlmProgress prog, void* stream);
+
+VLM_INTERNAL int vlm_sample_greedy_advance_ex(const void* logits, int ld, int B, int V, void* logprobs, int ldlp, void* tok,
+                                              void* workspace, void* ctx, void* pos, void* out_ring, int ring_len, void* step,
+                                              const void* embed, void* h, int D, int ldh, VlmProgress prog, void* stream);
+
+// ---- weight / KV prefetch (csrc/prefetch.hip)
+struct VlmPfSeg {
+  const void* p;
+  size_t bytes;
+};
+// what one decoder layer (or the lm_head chunk) streams: weight segments + that layer's K / V pools
+struct VlmPfItem {
+  VlmPfSeg seg[4];
+  int nseg;
+  const void* kbase;   // layer's K pool (nullptr: no KV prefetch for this item)
+  const void* vbase;
+  int need;            // persistent form: start when *progress >= need; skip when *progress >= need + 2
+};
+struct VlmPfKv {
+  const int* ctx;           // [B] keys in the cache (device)
+  const int* block_table;   // [B][max_pages] or nullptr (identity layout)
+  int max_pages, B;
+  size_t page_bytes;        // bytes of one 64-token page of one pool (all kv heads)
+};
+
+VLM_INTERNAL int vlm_prefetch_launch(const VlmPfItem* item, const VlmPfKv* kv, int wgs, void* stream);
+VLM_INTERNAL int vlm_prefetch_persistent_launch(const VlmPfItem* items_dev, int n_items, const VlmPfKv* kv, int* progress,
+                                                unsigned* exit_count, int wgs, void* stream);

@@ -11,6 +11,7 @@
 // are done EXACTLY with a 64 Ki-bin histogram (count and probability mass per
 // key) instead of a sort - a radix-select that fits the LDS-less L2-resident row.
 #include "common.cuh"
+#include "internal.h"
 #include "../../include/vlm_hip.h"
 
 namespace {
@@ -22,9 +23,12 @@ __device__ __forceinline__ uint32_t bf_key(bf16_t b) { return (b & 0x8000u) ? (u
 __device__ __forceinline__ bf16_t key_bf(uint32_t k) { return (k & 0x8000u) ? (bf16_t)(k & 0x7fffu) : (bf16_t)(~k & 0xffffu); }
 
 __global__ __launch_bounds__(256) void lse_partial_kernel(const bf16_t* __restrict__ logits, int ld, int V,
-                                                          float* __restrict__ ws) {
+                                                          float* __restrict__ ws, VlmProgress prog) {
   __shared__ float red[16];
   const int b = blockIdx.y, blk = blockIdx.x;
+  // pacing word of the weight prefetcher: "the sampler tail has started" (the HBM is idle from here to the next step)
+  if (prog.word && blk == 0 && b == 0 && threadIdx.x == 0)
+    __hip_atomic_store(prog.word, prog.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int per = ((V + NBLK - 1) / NBLK + 7) & ~7;
   const int lo = blk * per, hi = min(V, lo + per);
   const bf16_t* row = logits + (size_t)b * ld;
@@ -94,6 +98,102 @@ __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restric
     if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
   }
   if (threadIdx.x == 0) tok[b] = besti;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Greedy tail of a decode step in ONE launch: logprobs + per-block argmax candidates as logprob_argmax_kernel, then the
+// LAST block to arrive (agent-scope ticket) reduces the candidates, writes the token and does what used to be three more
+// launches: the bookkeeping of vlm_decode_advance (cache.py:362 offset += 1, language.py:476-509 pos = offset + delta,
+// token ring, step counter) and the embedding gather of the NEXT step (nn.Embedding, language.py:164,179) into h.
+// Hand-off recipe (cdna_hip_programming.md, Guideline 16): plain candidate stores -> release fence (agent) -> asm
+// vmcnt(0) -> relaxed agent fetch_add; the last arriver: acquire fence (agent) -> barrier -> plain loads.
+// ------------------------------------------------------------------------------------------
+constexpr int TAIL_MAX_B = 64;
+
+__global__ __launch_bounds__(256) void logprob_argmax_tail_kernel(
+    const bf16_t* __restrict__ logits, int ld, int V, const float* __restrict__ ws, bf16_t* __restrict__ logprobs, int ldlp,
+    float* cand_v, int* cand_i, unsigned* ticket, int* __restrict__ tok, int* __restrict__ ctx, int* __restrict__ pos,
+    int* __restrict__ out_ring, int ring_len, int* __restrict__ step, const bf16_t* __restrict__ embed,
+    bf16_t* __restrict__ h, int D, int ldh, int B) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  __shared__ int s_last;
+  __shared__ int s_tok[TAIL_MAX_B];
+  const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+  const int li = tid & 63;
+  const float pm = ws[((size_t)b * NBLK + li) * 2], ps = ws[((size_t)b * NBLK + li) * 2 + 1];
+  const float m = wave_max(pm);
+  const float s = wave_sum(pm > -INFINITY ? ps * expf(pm - m) : 0.f);
+  const float lse = rbf(m + logf(s));          // logsumexp materialised in the logits dtype (ar.py:368)
+  const int per = ((V + NBLK - 1) / NBLK + 7) & ~7;
+  const int lo = blk * per, hi = min(V, lo + per);
+  const bf16_t* row = logits + (size_t)b * ld;
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int i = lo + tid; i < hi; i += 256) {
+    const bf16_t lpb = f2bf(bf2f(row[i]) - lse);
+    if (logprobs) logprobs[(size_t)b * ldlp + i] = lpb;
+    const float lp = bf2f(lpb);
+    if (lp > best || (lp == best && i < besti)) { best = lp; besti = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(besti, o, 64);
+    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+  }
+  if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = besti; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < besti)) { best = sv[w]; besti = si[w]; }
+    cand_v[(size_t)b * NBLK + blk] = best;
+    cand_i[(size_t)b * NBLK + blk] = besti;
+    // publish: release, then the ticket (this order; the asm wait restates the fence's own wait where the compiler
+    // cannot drop it)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = t == (unsigned)(gridDim.x * gridDim.y) - 1u;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // ---- last block: final argmax per row (64 candidates = one wavefront), lowest index on ties (sample_utils.py:63-64)
+  const int wave = tid >> 6;
+  for (int r = wave; r < B; r += 4) {
+    float bv = __hip_atomic_load(cand_v + (size_t)r * NBLK + li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int bi = __hip_atomic_load(cand_i + (size_t)r * NBLK + li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (li == 0) s_tok[r] = bi;
+  }
+  __syncthreads();
+  const int st = *step;
+  if (tid < B) {
+    const int t = s_tok[tid];
+    tok[tid] = t;
+    ctx[tid] += 1;
+    pos[tid] += 1;
+    if (out_ring) out_ring[(size_t)(st % ring_len) * B + tid] = t;
+  }
+  // next step's input embeddings
+  const int cpr = D >> 3;
+  for (int i = tid; i < B * cpr; i += 256) {
+    const int r = i / cpr, c = i % cpr;
+    reinterpret_cast<uint4*>(h + (size_t)r * ldh)[c] = reinterpret_cast<const uint4*>(embed + (size_t)s_tok[r] * D)[c];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    *step = st + 1;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every block has arrived: re-arm
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -290,21 +390,23 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
 
 }  // namespace
 
-extern "C" size_t vlm_sample_workspace_bytes(int B) { return (size_t)B * (NBLK * 4 * sizeof(float) + 65536 * sizeof(uint32_t)); }
+extern "C" size_t vlm_sample_workspace_bytes(int B) { return (size_t)B * (NBLK * 4 * sizeof(float) + 65536 * sizeof(uint32_t)) + 256; }
 
-// workspace layout: [B][NBLK][2] f32 lse partials | [B][NBLK] f32 cand_v | [B][NBLK] i32 cand_i | [B][65536] u32 hist
-extern "C" int vlm_sample(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
-                          void* workspace, float temperature, float top_p, float min_p, int top_k, unsigned seed,
-                          const void* step_ptr, void* stream) {
+// workspace layout: 256 B arrival ticket of the fused greedy tail (must be zero at allocation; the kernel re-arms it; at a
+// fixed offset so that a step over the first B' < B rows of a state finds the same word) |
+// [B][NBLK][2] f32 lse partials | [B][NBLK] f32 cand_v | [B][NBLK] i32 cand_i | [B][65536] u32 hist
+int vlm_sample_ex(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
+                  void* workspace, float temperature, float top_p, float min_p, int top_k, unsigned seed,
+                  const void* step_ptr, VlmProgress prog, void* stream) {
   if (!logits || !tok || !workspace || B <= 0 || V <= 0) return VLM_ERR_ARG;
   if (temperature < 0.f) return VLM_ERR_ARG;
   if (temperature > 0.f && (!logprobs || !scratch)) return VLM_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  float* ws = (float*)workspace;
+  float* ws = (float*)((char*)workspace + 256);
   float* cand_v = ws + (size_t)B * NBLK * 2;
   int* cand_i = (int*)(cand_v + (size_t)B * NBLK);
   uint32_t* hist = (uint32_t*)(cand_i + (size_t)B * NBLK);
-  hipLaunchKernelGGL(lse_partial_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws);
+  hipLaunchKernelGGL(lse_partial_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws, prog);
   VLM_CHECK_LAUNCH();
   hipLaunchKernelGGL(logprob_argmax_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws,
                      (bf16_t*)logprobs, ldlp, cand_v, cand_i);
@@ -317,4 +419,40 @@ extern "C" int vlm_sample(const void* logits, int ld, int B, int V, void* logpro
   }
   VLM_CHECK_LAUNCH();
   return VLM_OK;
+}
+
+extern "C" int vlm_sample(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
+                          void* workspace, float temperature, float top_p, float min_p, int top_k, unsigned seed,
+                          const void* step_ptr, void* stream) {
+  return vlm_sample_ex(logits, ld, B, V, logprobs, scratch, ldlp, tok, workspace, temperature, top_p, min_p, top_k, seed,
+                       step_ptr, VlmProgress{nullptr, 0}, stream);
+}
+
+int vlm_sample_greedy_advance_ex(const void* logits, int ld, int B, int V, void* logprobs, int ldlp, void* tok,
+                                 void* workspace, void* ctx, void* pos, void* out_ring, int ring_len, void* step,
+                                 const void* embed, void* h, int D, int ldh, VlmProgress prog, void* stream) {
+  if (!logits || !tok || !workspace || !ctx || !pos || !step || !embed || !h || B <= 0 || V <= 0) return VLM_ERR_ARG;
+  if (B > TAIL_MAX_B || D % 8 || ldh % 8) return VLM_ERR_SHAPE;
+  if (out_ring && ring_len <= 0) return VLM_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* ticket = (unsigned*)workspace;
+  float* ws = (float*)((char*)workspace + 256);
+  float* cand_v = ws + (size_t)B * NBLK * 2;
+  int* cand_i = (int*)(cand_v + (size_t)B * NBLK);
+  hipLaunchKernelGGL(lse_partial_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws, prog);
+  VLM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(logprob_argmax_tail_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws,
+                     (bf16_t*)logprobs, ldlp, cand_v, cand_i, ticket, (int*)tok, (int*)ctx, (int*)pos, (int*)out_ring, ring_len,
+                     (int*)step, (const bf16_t*)embed, (bf16_t*)h, D, ldh, B);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+/* greedy tail of the decode step in two launches: vlm_sample (temperature 0) + vlm_decode_advance + the next step's
+ * vlm_embed_gather (see logprob_argmax_tail_kernel) */
+extern "C" int vlm_sample_greedy_advance(const void* logits, int ld, int B, int V, void* logprobs, int ldlp, void* tok,
+                                         void* workspace, void* ctx, void* pos, void* out_ring, int ring_len, void* step,
+                                         const void* embed, void* h, int D, int ldh, void* stream) {
+  return vlm_sample_greedy_advance_ex(logits, ld, B, V, logprobs, ldlp, tok, workspace, ctx, pos, out_ring, ring_len, step,
+                                      embed, h, D, ldh, VlmProgress{nullptr, 0}, stream);
 }

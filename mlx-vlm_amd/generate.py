@@ -120,9 +120,13 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
     for k in ("repetition_penalty", "presence_penalty", "frequency_penalty", "logit_bias"):
         if kwargs.pop(k, None):
             raise NotImplementedError(f"{k} is outside the built hot path")
-    for k in ("repetition_context_size", "presence_context_size", "frequency_context_size", "max_kv_size", "kv_bits",
-              "kv_group_size", "quantized_kv_start", "draft_model", "verbose", "thinking_budget_criteria",
-              "kv_quant_scheme", "prompt_cache_checkpoint", "prompt_cache_checkpoint_len"):
+    for k in ("max_kv_size", "kv_bits", "draft_model", "thinking_budget_criteria"):
+        if kwargs.pop(k, None):
+            # the reference would switch cache class / decoding scheme (RotatingKVCache, QuantizedKVCache, speculative):
+            # dropping the request silently would change results without telling the caller
+            raise NotImplementedError(f"{k} is outside the built hot path (SURVEY section 8f.4)")
+    for k in ("repetition_context_size", "presence_context_size", "frequency_context_size", "kv_group_size",
+              "quantized_kv_start", "verbose", "kv_quant_scheme", "prompt_cache_checkpoint", "prompt_cache_checkpoint_len"):
         kwargs.pop(k, None)
     smp = _resolve_sampler(sampler, temperature, top_p, min_p, top_k, seed)
     sargs = smp.engine_args()
@@ -158,7 +162,8 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
     pipe.push(0, tok0)
     lps: List[Optional[torch.Tensor]] = [lp0[0] if lp0 is not None else None] + [None] * (lookahead + 1)
     issued = 0   # decode steps enqueued; step s (0-based) produces generated token s + 1
-    n = 0
+    n = 0        # tokens handed to the caller (counted BEFORE the yield: a consumer that closes the generator at the
+                 # yield - the stop-token path of stream_generate - has received that token)
     try:
         while n < max_tokens:
             while issued < min(n + lookahead, max_tokens - 1):
@@ -168,10 +173,11 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
                 if return_logprobs:
                     lps[issued % (lookahead + 2)] = st.logprobs[0].clone()
             tok = int(pipe.get(n)[0])
-            yield tok, lps[n % (lookahead + 2)]
             n += 1
+            yield tok, lps[(n - 1) % (lookahead + 2)]
     finally:
-        # the cache holds prompt + the tokens that were FED back (every yielded token except the last)
+        # the cache holds prompt + the tokens that were FED back: every yielded token except the last (steps enqueued
+        # ahead of the caller wrote further slots; they are overwritten when decoding continues from this offset)
         seq.offset = base_offset + max(0, min(n, issued + 1) - 1)
         if own_cache:
             seq.release()

@@ -66,15 +66,16 @@ class DecodeState:
         self.sample_ws = ops.sample_workspace(B, dev)
         self.graph_key = None
 
-    def args(self, temperature=0.0, top_p=1.0, min_p=0.0, top_k=0, seed=0, with_logprobs=True, B=None):
-        """B < self.B: the step runs over the first B rows (every buffer is row-major, a prefix is a valid state)."""
+    def args(self, temperature=0.0, top_p=1.0, min_p=0.0, top_k=0, seed=0, with_logprobs=True, B=None, flags=0):
+        """B < self.B: the step runs over the first B rows (every buffer is row-major, a prefix is a valid state).
+        flags: _lib.DECODE_FUSED_TAIL = the step starts from h == embed[tok] and leaves the next step's h behind."""
         p = lambda t: t.data_ptr()  # noqa: E731
         return _lib.DecodeArgs(self.B if B is None else int(B), p(self.tok), p(self.pos), p(self.ctx), p(self.step), p(self.h), p(self.qkv),
                                p(self.attn), p(self.act), p(self.logits),
                                p(self.logprobs) if (with_logprobs or temperature > 0) else None, p(self.scratch),
                                p(self.part_o), p(self.part_ml), p(self.sample_ws), p(self.out_ring), self.ring_len,
                                self.nsplit, float(temperature), float(top_p), float(min_p), int(top_k),
-                               int(seed) & 0xFFFFFFFF)
+                               int(seed) & 0xFFFFFFFF, int(flags))
 
 
 class LanguageModel:
@@ -149,6 +150,7 @@ class LanguageModel:
         h = C.c_void_p()
         check(L.vlm_llm_create(C.byref(cfg), C.byref(h)), "llm_create")
         self._handle = h
+        self.apply_tuning()
         for i in range(t.num_hidden_layers):
             p = f"model.layers.{i}."
             wqkv = big(torch.cat([g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"),
@@ -182,6 +184,26 @@ class LanguageModel:
         gl = _lib.LlmGlobals(embed.data_ptr(), norm.data_ptr(), head.data_ptr(), inv_freq.data_ptr())
         check(L.vlm_llm_set_globals(h, C.byref(gl)), "llm_set_globals")
         self._init_pool()
+
+    # decode-step tuning (results are identical under every setting; defaults from the measurements in DESIGN.md,
+    # environment overrides for A/B runs): VLM_DECODE_PREFETCH 0 / 1 (event-paced side branch) / 2 (persistent side
+    # kernel), VLM_DECODE_PREFETCH_MASK, VLM_DECODE_PREFETCH_WGS, VLM_DECODE_FUSED_TAIL 0 / 1
+    TUNING_DEFAULTS = {"prefetch": 0, "prefetch_wgs": 256, "prefetch_mask": 0x7f, "prefetch_head_mb": 96, "fused_tail": 1}
+
+    def apply_tuning(self, **over):
+        L = _lib.lib()
+        t = dict(self.TUNING_DEFAULTS)
+        for k in t:
+            env = os.environ.get("VLM_DECODE_" + k.upper())
+            if env is not None:
+                t[k] = int(env, 0)
+        t.update(over)
+        self.tuning = t
+        for key, name in ((_lib.TUNE_PREFETCH, "prefetch"), (_lib.TUNE_PREFETCH_WGS, "prefetch_wgs"),
+                          (_lib.TUNE_PREFETCH_MASK, "prefetch_mask"), (_lib.TUNE_PREFETCH_HEAD_MB, "prefetch_head_mb")):
+            check(L.vlm_llm_set_tuning(self._handle, key, int(t[name])), "llm_set_tuning")
+        for st in getattr(self, "_decode_states", {}).values():
+            st.graph_key = None          # the engine dropped its captured steps
 
     def _init_pool(self):
         t = self.args
@@ -379,6 +401,9 @@ class LanguageModel:
         else:
             st.tok.copy_(_lib.h2d(np.asarray(first_tokens, dtype=np.int32).reshape(-1), self.device))
         st.seqs = seqs
+        # a fused-tail step starts from h == embed[tok] (vlm_decode_args.flags); every later h is left behind by the
+        # previous step's sampler tail
+        ops.embed_gather(st.tok[:B], self._w["embed"], out=st.h[:B])
         return st
 
     def _kv_struct(self, row0: int, decode: bool = False):
@@ -399,9 +424,10 @@ class LanguageModel:
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         kv = self._kv_struct(st.seq_row0, decode=True)
         check(L.vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
-        args = st.args(**sampler_args)
+        fused = bool(self.tuning.get("fused_tail")) and float(sampler_args.get("temperature", 0.0)) == 0.0
+        args = st.args(flags=_lib.DECODE_FUSED_TAIL if fused else 0, **sampler_args)
         if use_graph:
-            key = (st.seq_row0, st.nsplit, tuple(sorted(sampler_args.items())))
+            key = (st.seq_row0, st.nsplit, fused, tuple(sorted(sampler_args.items())))
             if st.graph_key != key or getattr(self, "_graph_owner", None) is not st:
                 check(L.vlm_llm_decode_graph_build(self._handle, C.byref(args), stream), "decode_graph_build")
                 st.graph_key = key

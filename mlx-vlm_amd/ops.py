@@ -175,7 +175,8 @@ def cast_pad(src_f32, ld_dst):
 
 
 def sample_workspace(B, device):
-    return torch.empty(_lib.lib().vlm_sample_workspace_bytes(B), dtype=torch.uint8, device=device)
+    # zeroed: the first 256 bytes hold the arrival ticket of the fused greedy tail (csrc/sample.hip)
+    return torch.zeros(_lib.lib().vlm_sample_workspace_bytes(B), dtype=torch.uint8, device=device)
 
 
 def sample(logits, temperature=0.0, top_p=1.0, min_p=0.0, top_k=0, seed=0, step=None, want_logprobs=True, ws=None):
@@ -191,6 +192,21 @@ def sample(logits, temperature=0.0, top_p=1.0, min_p=0.0, top_k=0, seed=0, step=
                                 float(temperature), float(top_p), float(min_p), int(top_k), int(seed) & 0xFFFFFFFF,
                                 _p(step), _stream()), "sample")
     return tok, lp
+
+
+def sample_greedy_advance(logits, tok, ctx, pos, step, embed, h, out_ring=None, want_logprobs=True, ws=None):
+    """Greedy tail of a decode step (vlm_sample_greedy_advance): tok <- argmax, ctx += 1, pos += 1, ring, step += 1,
+    h <- embed[tok].  -> logprobs bf16 [B, V] or None"""
+    _dev(logits, tok, ctx, pos, step, embed, h, out_ring)
+    B, V = logits.shape
+    lp = torch.empty(B, V, dtype=torch.bfloat16, device=logits.device) if want_logprobs else None
+    if ws is None:
+        ws = sample_workspace(B, logits.device)
+    check(_lib.lib().vlm_sample_greedy_advance(_p(logits), logits.stride(0), B, V, _p(lp), V, _p(tok), _p(ws), _p(ctx), _p(pos),
+                                               _p(out_ring), out_ring.shape[0] if out_ring is not None else 0, _p(step),
+                                               _p(embed), _p(h), embed.shape[1], h.stride(0), _stream()),
+          "sample_greedy_advance")
+    return lp
 
 
 def gemm_set_staging(mode: int):

@@ -7,10 +7,16 @@ on a logprobs tensor too, for code written against the reference API.
 """
 from __future__ import annotations
 
+import itertools
+import os
 from dataclasses import dataclass
 from typing import Optional
 
 import torch
+
+# unseeded samplers: the reference draws from MLX's global RNG state (sample_utils.py:385-387 -> mx.random), so two
+# unseeded calls differ.  Here every unseeded sampler takes a fresh seed: process entropy + a counter.
+_unseeded = itertools.count(int.from_bytes(os.urandom(4), "little"))
 
 
 @dataclass
@@ -55,4 +61,5 @@ def make_sampler(temp: float = 0.0, top_p: float = 0.0, min_p: float = 0.0, min_
         raise NotImplementedError("min_tokens_to_keep > 1 is not built")
     if not (0 <= min_p <= 1.0):
         raise ValueError(f"`min_p` has to be a float in the [0, 1] interval, but is {min_p}")
-    return Sampler(temp=temp, top_p=top_p, min_p=min_p, top_k=top_k, seed=0 if seed is None else int(seed))
+    return Sampler(temp=temp, top_p=top_p, min_p=min_p, top_k=top_k,
+                   seed=(next(_unseeded) & 0xFFFFFFFF) if seed is None else int(seed))

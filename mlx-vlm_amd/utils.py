@@ -19,7 +19,20 @@ from typing import Any, Dict, List, Optional, Union
 import numpy as np
 import torch
 
-MODEL_REMAPPING: Dict[str, str] = {}   # model_type aliases (reference utils.py:34-62); built: qwen2_vl, llava_bunny
+# model_type aliases of the reference (utils.py:34-62): the checkpoint's `model_type` -> package under models/.  The
+# whole alias table is kept so that a lookup resolves exactly as it does there; families that are not built here then
+# fail in get_model_and_args with the reference's own "Model type ... not supported." (utils.py:633-635).
+# Built: qwen2_vl, llava_bunny (nanoLLaVA ships `model_type: "llava-qwen2"`, Bunny `"bunny-llama"`).
+MODEL_REMAPPING: Dict[str, str] = {
+    "llava-qwen2": "llava_bunny", "bunny-llama": "llava_bunny", "llava_qwen2": "fastvlm", "lfm2-vl": "lfm2_vl",
+    "cohere2_vision": "aya_vision", "jvlm": "jina_vlm", "phi4-siglip": "phi4_siglip", "sam3_video": "sam3",
+    "sam3.1_video": "sam3_1", "granite-vision": "granite_vision", "granite4-vision": "granite4_vision",
+    "granite4_vision": "granite4_vision", "rf-detr": "rfdetr", "falcon-perception": "falcon_perception",
+    "nemotronh_nano_omni_reasoning_v3": "nemotron_h_nano_omni", "cohere2moe": "cohere2_moe",
+    "unlimited-ocr": "unlimited_ocr", "mistral": "llama", "phi-msft": "phixtral", "falcon_mamba": "mamba",
+    "joyai_llm_flash": "deepseek_v3", "kimi_k2": "deepseek_v3", "minimax_m2": "minimax", "iquestcoder": "llama",
+    "nemotron-nas": "nemotron_nas", "inkling_mm_model": "inkling", "lille-130m": "lille_130m",
+}
 
 
 def get_model_and_args(config: dict):
@@ -114,7 +127,8 @@ def load_processor(model_path: str, config):
     if os.path.exists(pp):
         with open(pp) as f:
             pc = json.load(f)
-    if getattr(config, "model_type", None) == "llava_bunny":
+    mt = str(getattr(config, "model_type", "") or "").lower()
+    if MODEL_REMAPPING.get(mt, mt) == "llava_bunny":
         # reference utils.py:1260-1270: models with a BaseImageProcessor get the bare tokenizer with the image
         # processor attached; prepare_inputs splits the prompt at "<image>" (utils.py:2064-2095)
         from .models.llava_bunny import ImageProcessor

@@ -304,3 +304,26 @@ def generate_greedy(W, cfg: Cfg, input_ids, pixel_values: Optional[torch.Tensor]
             break
         logits = language_model(W, cfg, embed_tokens(W, np.array([[y]])), cache)[:, -1, :]
     return (toks, torch.stack(rows)) if return_logits else toks
+
+
+def decode_teacher_forced(W, cfg: Cfg, input_ids, pixel_values: Optional[torch.Tensor] = None, forced_tokens=(),
+                          cast_pixels: bool = True) -> torch.Tensor:
+    """Test construction (no reference counterpart): generate_step's device work (generate/ar.py:334-389) with the FED
+    tokens prescribed.  -> logits [1 + len(forced_tokens), V]: row 0 = last prompt row of the whole-prompt prefill, row
+    i = after feeding forced_tokens[i - 1] through the KVCache.  The head is applied to the last row only (the
+    reference computes every row and slices, ar.py:358 - same values, 700 x less work at V = 151,936)."""
+    ids = np.asarray(input_ids)
+    assert ids.shape[0] == 1
+    t = cfg.text
+    cache = [ops.KVCache() for _ in range(t.num_hidden_layers)]
+    head = W[LM + "embed_tokens.weight"] if t.tie_word_embeddings else W[LM + "lm_head.weight"]
+
+    def last_row_logits(h):
+        for i in range(t.num_hidden_layers):
+            h = decoder_layer(W, i, cfg, h, cache[i])
+        return ops.linear(ops.rms_norm(h[:, -1:, :], W[LM + "norm.weight"], t.rms_norm_eps), head)[0, 0]
+
+    rows = [last_row_logits(get_input_embeddings(W, cfg, ids, pixel_values, None, cast_pixels))]
+    for y in forced_tokens:
+        rows.append(last_row_logits(embed_tokens(W, np.array([[int(y)]]))))
+    return torch.stack(rows)

@@ -443,3 +443,45 @@ def generate_greedy(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_thw=No
     if return_logits:
         return toks, torch.stack(all_logits)
     return toks
+
+
+# --------------------------------------------------------------------------
+# test constructions on top of the restatement (no reference counterpart)
+# --------------------------------------------------------------------------
+def peak_head(W, cfg: Cfg, gamma: float = 1.0, stride: int = 389, n_cycle: Optional[int] = None):
+    """SURVEY.md par. 8d "peaked head": an UNTIED lm_head whose row succ(t) = (t + stride) mod n_cycle carries
+    gamma * E[t] / |E[t]| on top of the seeded noise.  The residual stream keeps the input embedding, so the next-token
+    logit of succ(t) stands several sigma above the rest: greedy decoding walks the cycle (no fixed point, no near-ties)
+    and token identity with the oracle can be demanded without a tie rule.  Returns a new weight dict."""
+    t = cfg.text
+    assert not t.tie_word_embeddings, "the peaked head needs an untied lm_head"
+    n = n_cycle or t.vocab_size
+    W = dict(W)
+    E = W["language_model.model.embed_tokens.weight"].float()
+    head = W["language_model.lm_head.weight"].float().clone()
+    src = torch.arange(n)
+    dst = (src + stride) % n
+    head[dst] += gamma * E[src] / E[src].norm(dim=-1, keepdim=True).clamp_min(1e-6)
+    W["language_model.lm_head.weight"] = head.to(W["language_model.model.embed_tokens.weight"].dtype)
+    return W
+
+
+def decode_teacher_forced(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_thw=None, forced_tokens=(),
+                          rope_mode: str = "fused", return_features: bool = False):
+    """generate_step's device work (generate/ar.py:334-389) with the FED tokens prescribed: full-prompt prefill, then one
+    decode forward per forced token at pos = cache offset + rope_delta (language.py:476-509).
+    -> logits [1 + len(forced_tokens), V]: row 0 = last prompt row, row i = after feeding forced_tokens[i-1]."""
+    input_ids = np.asarray(input_ids)
+    assert input_ids.shape[0] == 1
+    emb, pos, deltas = get_input_embeddings(W, cfg, input_ids, pixel_values, image_grid_thw)
+    cache = [ops.KVCache() for _ in range(cfg.text.num_hidden_layers)]
+    h = qwen2_model(W, cfg, emb, cache, torch.from_numpy(np.asarray(pos)), rope_mode)
+    rows = [lm_head(W, cfg, h[:, -1:, :])[0, 0]]
+    delta = int(deltas[0, 0])
+    for y in forced_tokens:
+        e = embed_tokens(W, np.array([[int(y)]]))
+        pid = torch.full((3, 1, 1), cache[0].offset + delta, dtype=torch.long)
+        h = qwen2_model(W, cfg, e, cache, pid, rope_mode)
+        rows.append(lm_head(W, cfg, h)[0, -1])
+    out = torch.stack(rows)
+    return (out, emb) if return_features else out

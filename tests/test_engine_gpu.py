@@ -215,6 +215,38 @@ def test_batch_generate_ids_matches_single(tiny, B):
     assert mism == 0, (toks, singles)
 
 
+@pytest.mark.parametrize("sizes", [[(56, 84)], []])
+def test_decode_step_tuning_variants_are_bit_identical(tiny, sizes):
+    """Weight prefetch on a side branch of the captured step (event-paced and persistent forms) and the fused greedy tail
+    change scheduling only: tokens AND every step's log-probs are bit-identical to the plain five-launch step."""
+    from mlx_vlm_amd.generate import generate_step
+
+    cfg, W, model = tiny
+    lm = model.language_model
+    ids, pix, thw = synth_request(cfg, sizes, n_text=14, seed=31) if sizes else \
+        (np.random.default_rng(32).integers(3, 1000, (1, 19)), None, None)
+    kw = dict(image_grid_thw=thw) if thw is not None else {}
+
+    def run():
+        toks, lps = [], []
+        for t, lp in generate_step(ids, model, torch.from_numpy(pix) if pix is not None else None, None, max_tokens=70,
+                                   temperature=0.0, lookahead=5, **kw):
+            toks.append(t)
+            lps.append(lp.clone())
+        return toks, torch.stack(lps)
+
+    try:
+        lm.apply_tuning(prefetch=0, fused_tail=0)
+        base_t, base_lp = run()
+        for prefetch, fused, mask in ((0, 1, 0x7f), (1, 0, 0x7f), (1, 1, 0x7f), (2, 0, 0x7f), (2, 1, 0x7f), (2, 1, 0x13), (1, 1, 0x2c)):
+            lm.apply_tuning(prefetch=prefetch, fused_tail=fused, prefetch_mask=mask)
+            t, lp = run()
+            assert t == base_t, (prefetch, fused, mask)
+            assert torch.equal(lp, base_lp), (prefetch, fused, mask)
+    finally:
+        lm.apply_tuning()
+
+
 def test_sampling_temperature_reproducible_and_varied(tiny):
     from mlx_vlm_amd.generate import generate_step
 

@@ -51,7 +51,7 @@ def vops():
 def test_library_loaded_is_in_tree():
     import mlx_vlm_amd._lib as L
 
-    assert L.lib().vlm_abi_version() == 1
+    assert L.lib().vlm_abi_version() == 2
     assert "mlx-vlm_amd/lib/libvlm_hip.so" in L.LIB_PATH
 
 
@@ -610,3 +610,45 @@ def test_gemm256_under_memory_pressure_race_screen(vops, variant):
             assert torch.equal(out, ref), f"iteration {it}"
     finally:
         vops.gemm_set_staging(0)
+
+
+@pytest.mark.parametrize("B,V", [(1, 151936), (3, 4099), (8, 32000)])
+def test_sample_greedy_advance_equals_sample_plus_advance_plus_gather(vops, B, V):
+    """The fused greedy tail (2 launches) against the unfused sequence it replaces: vlm_sample (temperature 0) +
+    vlm_decode_advance + the next step's vlm_embed_gather - every output bit-identical, repeatedly on the same
+    workspace (the arrival ticket re-arms itself)."""
+    from mlx_vlm_amd import _lib
+    from mlx_vlm_amd._lib import check
+    import ctypes as C
+
+    dev = "cuda"
+    D = 64
+    torch.manual_seed(B + V)
+    embed = torch.randn(V, D, device=dev).to(BF)
+    ws = vops.sample_workspace(B, dev)
+    ring_len = 4
+    state = lambda: dict(ctx=torch.arange(10, 10 + B, dtype=torch.int32, device=dev),   # noqa: E731
+                         pos=torch.arange(20, 20 + B, dtype=torch.int32, device=dev),
+                         step=torch.zeros(1, dtype=torch.int32, device=dev),
+                         ring=torch.full((ring_len, B), -1, dtype=torch.int32, device=dev))
+    a, b = state(), state()
+    tok_a = torch.zeros(B, dtype=torch.int32, device=dev)
+    h_a = torch.zeros(B, D, dtype=BF, device=dev)
+    for it in range(6):
+        logits = (torch.randn(B, V, device=dev) * 3).to(BF)
+        if it == 3:                                    # exact ties across blocks: the lowest index must win
+            logits[:, V // 3] = 50.0
+            logits[:, V - 5] = 50.0
+        lp_a = vops.sample_greedy_advance(logits, tok_a, a["ctx"], a["pos"], a["step"], embed, h_a, out_ring=a["ring"], ws=ws)
+        tok_b, lp_b = vops.sample(logits, step=b["step"])
+        check(_lib.lib().vlm_decode_advance(C.c_void_p(b["ctx"].data_ptr()), C.c_void_p(b["pos"].data_ptr()),
+                                            C.c_void_p(tok_b.data_ptr()), C.c_void_p(b["ring"].data_ptr()), ring_len,
+                                            C.c_void_p(b["step"].data_ptr()), B,
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "advance")
+        h_b = vops.embed_gather(tok_b, embed)
+        assert torch.equal(tok_a, tok_b), it
+        assert torch.equal(lp_a, lp_b)
+        assert torch.equal(h_a, h_b)
+        for k in ("ctx", "pos", "step", "ring"):
+            assert torch.equal(a[k], b[k]), (it, k)
+    assert int(a["step"][0]) == 6
