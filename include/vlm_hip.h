@@ -255,8 +255,14 @@ int vlm_llm_decode_launches(void* handle);
 #define VLM_TUNE_DEBUG_SKIP 4       /* MEASUREMENT ONLY (results become meaningless): leave launches out of the captured step
                                        to read their marginal cost off the wall clock - bit 0 qkv, 1 attention, 2 o_proj,
                                        3 gate/up, 4 down, 5 lm_head, 6 sampler tail */
+#define VLM_TUNE_FUSED_MLP 5        /* 1: batch-1 steps run o_proj + gate/up + down of a layer as ONE launch (csrc/mlp_fused.hip:
+                                       weight slices register-resident from entry, in-launch hand-offs); needs >= 256 CUs and
+                                       a supported shape, otherwise the step silently keeps the three launches */
 int vlm_llm_set_tuning(void* handle, int key, int value);
 int vlm_llm_get_tuning(void* handle, int key);
+/* diagnostic of the in-launch hand-offs (VLM_TUNE_FUSED_MLP): 0 = every bounded wait completed since the last call;
+ * non-zero = a wait gave up (results of that step are garbage).  Synchronises the device; clears the word. */
+int vlm_llm_fused_error(void* handle);
 
 typedef struct vlm_vit_config {
   int depth, embed_dim, n_heads, mlp_hidden, patch_k /* padded K of the patch GEMM */, merge /* 2 */, out_dim;

@@ -72,7 +72,7 @@ class VitArgs(C.Structure):
 
 
 DECODE_FUSED_TAIL = 1                       # vlm_decode_args.flags
-TUNE_PREFETCH, TUNE_PREFETCH_WGS, TUNE_PREFETCH_MASK, TUNE_PREFETCH_HEAD_MB = 0, 1, 2, 3   # vlm_llm_set_tuning keys
+TUNE_PREFETCH, TUNE_PREFETCH_WGS, TUNE_PREFETCH_MASK, TUNE_PREFETCH_HEAD_MB, TUNE_DEBUG_SKIP, TUNE_FUSED_MLP = 0, 1, 2, 3, 4, 5  # vlm_llm_set_tuning keys
 
 P = C.POINTER
 # name -> (restype, argtypes); every symbol include/vlm_hip.h declares
@@ -103,6 +103,7 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "vlm_llm_set_tuning": (c_int, [c_void_p, c_int, c_int]),
     "vlm_llm_get_tuning": (c_int, [c_void_p, c_int]),
+    "vlm_llm_fused_error": (c_int, [c_void_p]),
     "vlm_llm_create": (c_int, [P(LlmConfig), P(c_void_p)]),
     "vlm_llm_destroy": (c_int, [c_void_p]),
     "vlm_llm_set_layer": (c_int, [c_void_p, c_int, P(LlmLayer)]),

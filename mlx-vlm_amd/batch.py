@@ -477,7 +477,8 @@ def generate_batch_continuous(model, input_ids_list, pixel_values_list, grids, *
     """The reference's `_generate_batch` loop (ar.py:3212-3232) over the continuous generator: every request is queued
     at once, the generator keeps up to `batch_size` of them decoding and admits the next ones as rows free up.
     -> (tokens per request without the stop token, BatchStats)"""
-    gen = BatchGenerator(model, None, max_tokens=max_tokens, stop_tokens=set(stop_ids), sampler=sampler,
+    gen = BatchGenerator(model, None, max_tokens=max(max_tokens) if isinstance(max_tokens, (list, tuple)) else max_tokens,
+                         stop_tokens=set(stop_ids), sampler=sampler,
                          completion_batch_size=batch_size, prefill_batch_size=batch_size, compute_logprobs=False,
                          use_graph=use_graph)
     kw: List[Dict[str, Any]] = [dict(pixel_values=p, image_grid_thw=g) if p is not None else {}

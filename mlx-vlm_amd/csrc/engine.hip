@@ -12,6 +12,8 @@
 // enqueues the whole chain on a HIP stream with no host work in between.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <new>
 #include <vector>
 
@@ -43,7 +45,7 @@ constexpr size_t MAX_DECODE_GRAPHS = 16;
 
 // defaults: off until DESIGN.md's measurement picks them (vlm_llm_set_tuning)
 struct Tuning {
-  int prefetch = 0, wgs = 256, mask = 0x7f, head_mb = 96, debug_skip = 0;
+  int prefetch = 0, wgs = 256, mask = 0x7f, head_mb = 96, debug_skip = 0, fused_mlp = 0;
 };
 
 // the second branch of a captured step (prefetch side chain)
@@ -57,6 +59,8 @@ struct Fork {
 struct Llm {
   Tuning tune;
   int* progress = nullptr;                // [0] pacing word, [1] exit counter of the persistent prefetcher (device)
+  char* fm_buf = nullptr;                 // fused-MLP hand-off buffers: [256 B err] then per layer [256 B epoch | D granules | I granules]
+  size_t fm_stride = 0;
   vlm_llm_config cfg;
   std::vector<vlm_llm_layer> layers;
   vlm_llm_globals g{};
@@ -115,6 +119,7 @@ extern "C" int vlm_llm_destroy(void* handle) {
   if (!m) return 1;
   for (DecodeGraph& g : m->graphs) drop_graph(g);
   if (m->progress) (void)hipFree(m->progress);
+  if (m->fm_buf) (void)hipFree(m->fm_buf);
   delete m;
   return 0;
 }
@@ -129,6 +134,27 @@ extern "C" int vlm_llm_set_tuning(void* handle, int key, int value) {
     case VLM_TUNE_PREFETCH_MASK: slot = &m->tune.mask; break;
     case VLM_TUNE_PREFETCH_HEAD_MB: if (value < 0) return 1; slot = &m->tune.head_mb; break;
     case VLM_TUNE_DEBUG_SKIP: slot = &m->tune.debug_skip; break;
+    case VLM_TUNE_FUSED_MLP: {
+      if (value < 0 || value > 1) return 1;
+      slot = &m->tune.fused_mlp;
+      const vlm_llm_config& c = m->cfg;
+      if (value && !m->fm_buf) {
+        // one workgroup per CU, all resident: the in-launch hand-offs need the whole grid on the chip at once
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+          return 1000;
+        if (cus < 256 || !vlm_mlp_fused_supported(c.hidden, c.inter, c.n_heads * c.head_dim)) { value = 0; break; }
+        m->fm_stride = 256 + ((size_t)c.hidden + (size_t)c.inter) * 4;
+        m->fm_stride = (m->fm_stride + 255) & ~(size_t)255;
+        const size_t bytes = 256 + m->fm_stride * c.n_layers;
+        if (hipMalloc(&m->fm_buf, bytes) != hipSuccess) { m->fm_buf = nullptr; return 1008; }
+        if (hipMemset(m->fm_buf, 0, bytes) != hipSuccess) return 1009;
+        const unsigned one = 1;                      // launch epochs start at 1 (tag 0 = never written)
+        for (int i = 0; i < c.n_layers; ++i)
+          if (hipMemcpy(m->fm_buf + 256 + m->fm_stride * i, &one, 4, hipMemcpyHostToDevice) != hipSuccess) return 1010;
+      }
+      break;
+    }
     default: return 1;
   }
   if (*slot == value) return 0;
@@ -137,6 +163,25 @@ extern "C" int vlm_llm_set_tuning(void* handle, int key, int value) {
   m->graphs.clear();
   m->exec = nullptr;
   return 0;
+}
+
+extern "C" int vlm_llm_fused_error(void* handle) {
+  Llm* m = static_cast<Llm*>(handle);
+  if (!m) return -1;
+  if (!m->fm_buf) return 0;
+  unsigned e = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (hipMemcpy(&e, m->fm_buf, 4, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+  if (e) (void)hipMemset(m->fm_buf, 0, 4);
+  return (int)e;
+}
+
+// debug: the 16 phase stamps of the fused MLP launch (VLM_FUSED_STAMPS=1), microseconds; not part of the public header
+extern "C" int vlm_llm_debug_fused_stamps(void* handle, float* out16) {
+  Llm* m = static_cast<Llm*>(handle);
+  if (!m || !m->fm_buf || !out16) return 1;
+  if (hipDeviceSynchronize() != hipSuccess) return 2;
+  return hipMemcpy(out16, m->fm_buf + 64, 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
 }
 
 extern "C" int vlm_llm_get_tuning(void* handle, int key) {
@@ -148,6 +193,7 @@ extern "C" int vlm_llm_get_tuning(void* handle, int key) {
     case VLM_TUNE_PREFETCH_MASK: return m->tune.mask;
     case VLM_TUNE_PREFETCH_HEAD_MB: return m->tune.head_mb;
     case VLM_TUNE_DEBUG_SKIP: return m->tune.debug_skip;
+    case VLM_TUNE_FUSED_MLP: return m->tune.fused_mlp;
     default: return -1;
   }
 }
@@ -318,6 +364,19 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
         TRY(edge_to_side());
         TRY(vlm_prefetch_launch(&it, &pfkv, tn.wgs, fork->side)); ++n;
       }
+    }
+    const bool fused_mlp = tn.fused_mlp && m->fm_buf && B == 1 && a->nsplit == 1 && !(skip & (4 | 8 | 16));
+    if (fused_mlp) {
+      // o_proj + residual, RMSNorm + gate/up + SwiGLU, down + residual: one launch, two in-launch hand-offs
+      char* lb = m->fm_buf + 256 + m->fm_stride * (size_t)i;
+      // debug timeline (VLM_FUSED_STAMPS=1): workgroup 0 of the LAST layer's launch stamps its phases into fm_buf + 64
+      static const bool want_stamps = getenv("VLM_FUSED_STAMPS") != nullptr;
+      const char* fm = getenv("VLM_FUSED_MODE");     // measurement knobs of the fused launch (csrc/mlp_fused.hip)
+      const int fmode = fm ? (int)strtol(fm, nullptr, 0) : 0;
+      TRY(vlm_mlp_fused_launch(a->attn, a->h, w.wo, w.ln2_w, w.wgu, w.wdown, lb + 256, lb + 256 + (size_t)D * 4, lb, m->fm_buf,
+                               c.rms_eps, D, c.inter, Hq * hd, (want_stamps && i == NL - 1) ? m->fm_buf + 64 : nullptr,
+                               fmode, stream)); ++n;
+      continue;
     }
     if (skip & 4) {
     } else if (a->nsplit == 1) {

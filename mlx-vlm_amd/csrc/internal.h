@@ -50,3 +50,9 @@ struct VlmPfKv {
 VLM_INTERNAL int vlm_prefetch_launch(const VlmPfItem* item, const VlmPfKv* kv, int wgs, void* stream);
 VLM_INTERNAL int vlm_prefetch_persistent_launch(const VlmPfItem* items_dev, int n_items, const VlmPfKv* kv, int* progress,
                                                 unsigned* exit_count, int wgs, void* stream);
+
+// ---- fused o_proj + gate/up + down of a decoder layer at batch 1 (csrc/mlp_fused.hip)
+VLM_INTERNAL int vlm_mlp_fused_supported(int D, int I, int KO);
+VLM_INTERNAL int vlm_mlp_fused_launch(const void* attn, void* h, const void* wo, const void* ln2_w, const void* wgu,
+                                      const void* wdown, void* g_h, void* g_act, void* epoch, void* err, float eps, int D,
+                                      int I, int KO, void* stamps, int mode, void* stream);

@@ -81,6 +81,121 @@ def broadcast_weights(weights: Dict[str, torch.Tensor], src: int = 0, bucket_byt
     return weights
 
 
+def dp_load(model_path: str, device=None, src: int = 0, bucket_bytes: int = 1 << 30, **kwargs):
+    """`load()` for a data-parallel job (reference utils.py:1065-1119 on every rank would read the checkpoint W times):
+    rank `src` reads + sanitizes the safetensors, every other rank receives the replica over RCCL/xGMI in flat buckets
+    (`broadcast_weights`) and packs it for its own GPU.  -> (model, processor, stats) with stats = {"ranks", "backend",
+    "weight_bytes", "broadcast_s"} so that the first multi-GPU run explains itself."""
+    import time
+
+    from . import utils
+
+    rank, ws, local = world()
+    if device is None:
+        device = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
+    config = utils.load_config(model_path)
+    arch, _ = utils.get_model_and_args(config)
+    mc = arch.ModelConfig.from_dict(config)
+    model = arch.Model(mc, device=device, **kwargs)
+    weights = utils.read_sanitized_weights(model_path, model, config) if rank == src else None
+    stats = {"ranks": ws, "backend": dist.get_backend() if dist.is_initialized() else None, "weight_bytes": 0,
+             "broadcast_s": 0.0}
+    if ws > 1 and dist.is_initialized():
+        # the receiving side needs names / shapes / dtypes before it can post the bucket receives
+        meta = [[(k, tuple(v.shape), str(v.dtype).split(".")[-1]) for k, v in sorted(weights.items())]] if rank == src else [None]
+        dist.broadcast_object_list(meta, src=src)
+        comm_dev = device if dist.get_backend() == "nccl" else torch.device("cpu")
+        if rank == src:
+            weights = {k: v.to(comm_dev) for k, v in weights.items()}
+        else:
+            weights = {k: torch.empty(shape, dtype=getattr(torch, dt), device=comm_dev) for k, shape, dt in meta[0]}
+        if comm_dev.type == "cuda":
+            torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        broadcast_weights(weights, src=src, bucket_bytes=bucket_bytes)
+        if comm_dev.type == "cuda":
+            torch.cuda.synchronize()
+        stats["broadcast_s"] = max_over_ranks(time.perf_counter() - t0, comm_dev)
+    stats["weight_bytes"] = int(sum(v.numel() * v.element_size() for v in weights.values()))
+    model.load_weights(weights)
+    del weights
+    processor = utils.load_processor(model_path, model.config)
+    utils.freeze_heap()
+    if rank == 0 and ws > 1:
+        gbs = stats["weight_bytes"] / max(stats["broadcast_s"], 1e-9) / 1e9
+        print(f"[dp_load] {ws} ranks over {stats['backend']}: {stats['weight_bytes'] / 1e9:.2f} GB replica broadcast in "
+              f"{stats['broadcast_s']:.3f} s ({gbs:.1f} GB/s per receiving rank)", flush=True)
+    return model, processor, stats
+
+
+def dp_batch_generate(model, processor, prompts=None, images=None, *, requests=None, max_tokens=128, serve=None,
+                      dst: int = 0, **kwargs):
+    """Data-parallel `batch_generate` (reference ar.py:2890-3096 runs one device): every rank calls this with the SAME
+    request list; rank r serves the requests `shard_requests` deals it - the reference's own length sort
+    (ar.py:2620-2623) first, so the ranks see similar length mixes - on its own continuous `BatchGenerator`, with no
+    collective inside the prefill / decode steps; the token lists are gathered on `dst` at the end.
+
+    requests: pre-tokenised dicts {"input_ids", "pixel_values"?, "image_grid_thw"?, "max_tokens"?} (bypass, as
+    dispatch.py:759-762) - or prompts (+ one image each), tokenised on every rank.
+    serve(indices, requests, max_tokens) -> list of token lists: the per-rank engine (default: the continuous generator);
+    replaced by a mock in the CPU tests.
+    -> on `dst`: {"tokens": per request in the ORIGINAL order, "texts", "ranks", "per_rank_requests", "generation_tokens",
+    "wall_s", "tokens_per_s"}; on the other ranks: None."""
+    import time
+
+    import numpy as np
+
+    rank, ws, _ = world()
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        rank, ws = 0, 1
+    if requests is None:
+        from .utils import prepare_inputs
+
+        prompts = list(prompts or [])
+        images = list(images) if images is not None else [None] * len(prompts)
+        requests = []
+        for p, im in zip(prompts, images):
+            inp = prepare_inputs(processor, images=im, prompts=p)
+            requests.append({"input_ids": np.asarray(inp["input_ids"]).reshape(-1), "pixel_values": inp.get("pixel_values"),
+                             "image_grid_thw": inp.get("image_grid_thw")})
+    n = len(requests)
+    lengths = [int(np.asarray(r["input_ids"]).size) for r in requests]
+    mine = shard_requests(n, rank, ws, lengths)
+    mt = [int(r.get("max_tokens", max_tokens)) for r in requests]
+    if serve is None:
+        def serve(indices, reqs, max_toks):
+            from .batch import generate_batch_continuous
+
+            if not indices:
+                return []
+            tok = getattr(processor, "tokenizer", processor)
+            stop = getattr(getattr(tok, "stopping_criteria", None), "eos_token_ids", ()) or ()
+            toks, _ = generate_batch_continuous(model, [reqs[i]["input_ids"] for i in indices],
+                                                [reqs[i].get("pixel_values") for i in indices],
+                                                [reqs[i].get("image_grid_thw") for i in indices],
+                                                max_tokens=[max_toks[i] for i in indices], stop_ids=tuple(stop), **kwargs)
+            return toks
+    barrier()
+    t0 = time.perf_counter()
+    local = serve(mine, requests, mt)
+    if torch.cuda.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        torch.cuda.synchronize()
+    wall = max_over_ranks(time.perf_counter() - t0)
+    parts = gather_results(list(zip(mine, [list(map(int, t)) for t in local])), dst=dst)
+    if rank != dst:
+        return None
+    tokens: List = [None] * n
+    for part in parts:
+        for i, t in part:
+            tokens[i] = t
+    tok = getattr(processor, "tokenizer", processor) if processor is not None else None
+    texts = [tok.decode(t) if (tok is not None and hasattr(tok, "decode")) else "" for t in tokens]
+    total = sum(len(t) for t in tokens)
+    return {"tokens": tokens, "texts": texts, "ranks": ws, "per_rank_requests": [len(p) for p in parts],
+            "generation_tokens": total, "wall_s": wall, "tokens_per_s": total / max(wall, 1e-9)}
+
+
 def gather_results(local: List, dst: int = 0) -> List[List] | None:
     """Gather per-rank python result lists on `dst` (host side, small)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

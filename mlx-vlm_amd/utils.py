@@ -65,11 +65,11 @@ def load_config(model_path: str) -> dict:
     return config
 
 
-def load_model(model_path: str, lazy: bool = False, device="cuda", **kwargs):
-    """reference utils.py:736-987: config -> model class -> sanitize -> load_weights."""
+def read_sanitized_weights(model_path: str, model, config: dict) -> Dict[str, torch.Tensor]:
+    """The checkpoint of `model_path` as host tensors under the names `model.load_weights` takes (reference
+    utils.py:781-801 file discovery, 846-870 sanitize of the model and of its vision tower)."""
     from safetensors.torch import load_file
 
-    config = load_config(model_path)
     files = sorted(glob.glob(os.path.join(model_path, "*.safetensors")))
     if not files:
         raise FileNotFoundError(f"No safetensors found in {model_path}")
@@ -78,15 +78,22 @@ def load_model(model_path: str, lazy: bool = False, device="cuda", **kwargs):
         weights.update(load_file(f))
     if config.get("quantization"):
         raise NotImplementedError("MLX affine-quantized checkpoints are a 'next' row (SURVEY §8f.2)")
-    arch, _ = get_model_and_args(config)
-    mc = arch.ModelConfig.from_dict(config)
-    model = arch.Model(mc, device=device, **kwargs)
     weights = model.sanitize(weights)
     vt = {k: v for k, v in weights.items() if k.startswith("vision_tower.")}
     vt = {"vision_tower." + k: v for k, v in model.vision_tower.sanitize(
         {k[len("vision_tower."):]: v for k, v in vt.items()}).items()}
-    weights = {**{k: v for k, v in weights.items() if not k.startswith("vision_tower.")}, **vt}
-    model.load_weights(weights)
+    return {**{k: v for k, v in weights.items() if not k.startswith("vision_tower.")}, **vt}
+
+
+def load_model(model_path: str, lazy: bool = False, device="cuda", **kwargs):
+    """reference utils.py:736-987: config -> model class -> sanitize -> load_weights."""
+    config = load_config(model_path)
+    if not glob.glob(os.path.join(model_path, "*.safetensors")):
+        raise FileNotFoundError(f"No safetensors found in {model_path}")
+    arch, _ = get_model_and_args(config)
+    mc = arch.ModelConfig.from_dict(config)
+    model = arch.Model(mc, device=device, **kwargs)
+    model.load_weights(read_sanitized_weights(model_path, model, config))
     return model
 
 

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "vlm_hip.h"
+extern "C" int vlm_llm_debug_fused_stamps(void* handle, float* out16);
 
 #define CK(x)                                                                              \
   do {                                                                                     \
@@ -202,10 +203,10 @@ static void reset_state(const Model& m, State& s, int ctx0, hipStream_t st) {
 }
 
 struct Variant {
-  int pf = 0, wgs = 256, mask = 0x7f, flags = 0, headmb = 96, skip = 0;
+  int pf = 0, wgs = 256, mask = 0x7f, flags = 0, headmb = 96, skip = 0, fmlp = 0;
   std::string name() const {
     char b[128];
-    snprintf(b, sizeof b, "pf=%d wgs=%d mask=0x%02x flags=%d headmb=%d skip=0x%02x", pf, wgs, mask, flags, headmb, skip);
+    snprintf(b, sizeof b, "pf=%d wgs=%d mask=0x%02x flags=%d headmb=%d skip=0x%02x fmlp=%d", pf, wgs, mask, flags, headmb, skip, fmlp);
     return b;
   }
 };
@@ -218,6 +219,8 @@ static double run_variant(const Model& m, State& s, const Variant& v, int ctx0, 
   RC(vlm_llm_set_tuning(m.h, VLM_TUNE_PREFETCH_MASK, v.mask));
   RC(vlm_llm_set_tuning(m.h, VLM_TUNE_PREFETCH_HEAD_MB, v.headmb));
   RC(vlm_llm_set_tuning(m.h, VLM_TUNE_DEBUG_SKIP, v.skip));
+  RC(vlm_llm_set_tuning(m.h, VLM_TUNE_FUSED_MLP, v.fmlp));
+  if (v.fmlp && !vlm_llm_get_tuning(m.h, VLM_TUNE_FUSED_MLP)) printf("   (fused MLP not available on this device / shape)\n");
   s.a.flags = v.flags;
   RC(vlm_llm_set_kv(m.h, &m.kv));
   reset_state(m, s, ctx0, st);
@@ -314,7 +317,7 @@ int main(int argc, char** argv) {
     else if (a == "--block-table") use_table = true;
     else if (a == "--variant" && i + 1 < argc) {
       Variant v;
-      sscanf(argv[++i], "%d,%d,%i,%d,%d,%i", &v.pf, &v.wgs, &v.mask, &v.flags, &v.headmb, &v.skip);
+      sscanf(argv[++i], "%d,%d,%i,%d,%d,%i,%d", &v.pf, &v.wgs, &v.mask, &v.flags, &v.headmb, &v.skip, &v.fmlp);
       variants.push_back(v);
     }
   }
@@ -360,6 +363,21 @@ int main(int argc, char** argv) {
     const double us = run_variant(m, s, variants[vi], ctx0, warm, steps, &toks, st);
     if (vi == 0) base_toks = toks;
     const bool same = toks == base_toks;
+    int first_diff = -1;
+    for (size_t i = 0; i < toks.size() && i < base_toks.size(); ++i)
+      if (toks[i] != base_toks[i]) { first_diff = (int)i; break; }
+    if (variants[vi].fmlp && getenv("VLM_FUSED_STAMPS")) {
+      float st[16];
+      if (vlm_llm_debug_fused_stamps(m.h, st) == 0) {
+        printf("   fused launch, workgroup 0 (us): worker: o-published %.2f | past #1 %.2f | gu-published %.2f | past #2 %.2f | down-summed %.2f | end %.2f\n",
+               st[0], st[1], st[2], st[3], st[4], st[5]);
+        printf("                                    gatherer: h-gathered %.2f | past #1 %.2f | act-sentinels %.2f | act-gathered %.2f\n",
+               st[8], st[9], st[10], st[11]);
+      }
+    }
+    const int ferr = vlm_llm_fused_error(m.h);
+    if (ferr) printf("   FUSED HAND-OFF GAVE UP: code %d\n", ferr);
+    if (!same) printf("   first differing token at step %d of %zu\n", first_diff, toks.size());
     const double bytes = lm_bytes + 28672.0 * (ctx0 + steps / 2);
     if (getenv("VLM_ATTN_STAMPS")) {   // timeline of the LAST attention launch (library built with -DVLM_ATTN_TIMELINE)
       float st32[32];
@@ -371,7 +389,7 @@ int main(int argc, char** argv) {
         printf("\n");
       }
     }
-    printf("%-56s %8.1f us/step  %7.1f tok/s  %5.3f of 8 TB/s  launches %3d  tokens %s\n", variants[vi].name().c_str(), us,
+    printf("%-64s %8.1f us/step  %7.1f tok/s  %5.3f of 8 TB/s  launches %3d  tokens %s\n", variants[vi].name().c_str(), us,
            1e6 / us * B, bytes / us * 1e-6 / 8.0, vlm_llm_decode_launches(m.h), same ? "== baseline" : "DIFFER");
     fflush(stdout);
   }

@@ -232,6 +232,72 @@ def test_dp_path_gloo_world_size_2(tmp_path):
     assert r.returncode == 0 and "GLOO_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+DP_WORKER = r"""
+import os, sys, json, zlib
+import numpy as np, torch
+sys.path.insert(0, %r)
+from mlx_vlm_amd import parallel
+from oracle import qwen2_vl as oq
+from tests.test_engine_gpu import _write_tiny_checkpoint
+import pathlib
+rank, ws, local = parallel.init(backend="gloo")
+ckpt = pathlib.Path(os.environ["DP_CKPT"])
+cfg = oq.tiny_cfg()
+if rank == 0:
+    W = oq.random_weights(cfg, seed=1234, dtype=torch.bfloat16, std=0.05, embed_std=0.2)
+    _write_tiny_checkpoint(ckpt, cfg, W)
+parallel.barrier()
+if rank == 1:                       # rank 1 must not need the weight file: its directory holds config + tokenizer and a
+    import shutil                   # safetensors file the loader would choke on
+    mine = ckpt.parent / "ckpt_rank1"
+    shutil.copytree(ckpt, mine)
+    (mine / "model.safetensors").write_bytes(b"")
+    ckpt = mine
+parallel.barrier()
+model, processor, stats = parallel.dp_load(str(ckpt), device="cpu", bucket_bytes=1 << 16, kv_pool_tokens=1024, max_seqs=4)
+assert stats["ranks"] == 2 and stats["weight_bytes"] > 0 and stats["broadcast_s"] > 0
+# every rank holds the same packed replica
+lm = model.language_model
+crc = zlib.crc32(lm._w["0.wqkv"].view(torch.int16).numpy().tobytes()) ^ zlib.crc32(lm._w["embed"].view(torch.int16).numpy().tobytes())
+allc = parallel.gather_results([crc])
+# requests of different lengths; the mock engine "generates" a function of the prompt, so the gathered result can be
+# compared with the single-process answer
+rng = np.random.default_rng(0)
+reqs = [{"input_ids": rng.integers(3, 1000, int(n)), "max_tokens": 3 + i %% 4} for i, n in enumerate(rng.integers(4, 40, 11))]
+def mock(indices, rq, mt):
+    return [[int(rq[i]["input_ids"].sum() %% 997) + k for k in range(mt[i])] for i in indices]
+served = []
+def mock_logged(indices, rq, mt):
+    served.extend(indices)
+    return mock(indices, rq, mt)
+out = parallel.dp_batch_generate(model, None, requests=reqs, serve=mock_logged)
+lens = [len(r["input_ids"]) for r in reqs]
+assert served == parallel.shard_requests(len(reqs), rank, ws, lens)
+if rank == 0:
+    assert len(set(allc[0] + allc[1])) == 1, allc
+    assert out["tokens"] == mock(list(range(len(reqs))), reqs, [r["max_tokens"] for r in reqs])
+    assert out["ranks"] == 2 and sorted(out["per_rank_requests"]) == [5, 6]
+    print("DP_OK")
+else:
+    assert out is None
+parallel.shutdown()
+"""
+
+
+def test_dp_load_and_dp_batch_generate_gloo_world_size_2(tmp_path):
+    """The product entry points of the data-parallel path end to end on 2 gloo ranks: `dp_load` (rank 0 reads the
+    checkpoint, the replica is broadcast in buckets, rank 1 never opens the file) and `dp_batch_generate` (length-sorted
+    deal, per-rank serving, gather in the original order) against the single-process answer of a mock engine."""
+    script = tmp_path / "w.py"
+    script.write_text(DP_WORKER % ROOT)
+    (tmp_path / "ckpt").mkdir()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29614", DP_CKPT=str(tmp_path / "ckpt"))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29614", str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "DP_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_load_errors_match_reference_contract(tmp_path):
     """FileNotFoundError without a local directory / safetensors (reference utils.py:781-801,1209-1210), ValueError for an
     unknown model_type (utils.py:633-635)."""
