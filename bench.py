@@ -1,9 +1,13 @@
 #!/usr/bin/env python
 """Headline benchmark: decode tokens/sec + vision-prefill images/sec, Qwen2-VL-2B bf16 (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload qwen2vl-2b | nanollava | qwen2vl-7b-b32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+Workloads (BASELINE.json `configs`): the default is configs[1] (below); `nanollava` is configs[0] (nanoLLaVA dims, one
+336x336 image resized to 384x384, greedy 64 tokens); `qwen2vl-7b-b32` is configs[2] (Qwen2-VL-7B dims, 32 requests
+dealt data-parallel over the ranks through parallel.dp_batch_generate, every rank a continuous BatchGenerator).
 
 A "step" = one pass of the hot path over one request of BASELINE.json configs[1]:
 one synthetic 448x448 image (1024 patches -> 256 image tokens) + 128 text tokens,
@@ -183,53 +187,102 @@ def continuous_batch_throughput(model, cfg, n_requests=24, rows=8):
     return out
 
 
-def cpu_baseline(threads):
-    """Reference-equivalent CPU path (the oracle: torch-CPU restatement of the reference; the reference itself needs
-    `mlx`, which is not installable here).  Bounded sample, see the returned `sample` string."""
+def cpu_baseline(threads, with_hf=True):
+    """Reference-equivalent CPU path on the host cores, FULL model, nothing extrapolated: the oracle (torch-CPU
+    restatement of the reference's bf16 typed graph; the reference itself needs `mlx`, which is not installable here)
+    and, as the second opinion SURVEY section 8d asks for, HuggingFace `Qwen2VLForConditionalGeneration` in fp32 on
+    torch-CPU.  Bounded sample (see `sample`): 6 decode tokens at context 384 through all 28 layers + lm_head, one
+    448x448 and one 336x336 image through all 32 ViT blocks + merger."""
     from oracle import ops as O
     from oracle import qwen2_vl as oq
 
     torch.set_num_threads(threads)
-    LS, VS = 2, 2   # layers / blocks actually timed
-    cfg = oq.Cfg(text=oq.TextCfg(num_hidden_layers=LS), vision=oq.VisionCfg(depth=VS))
-    W = oq.random_weights(cfg, seed=0, dtype=torch.float32)
+    cfg = oq.Cfg()                                           # Qwen2-VL-2B dims
     t = cfg.text
-    # --- decode: per-layer time and lm_head time for ONE token at context 384
-    ctx = 384
-    cache = [O.KVCache() for _ in range(LS)]
-    emb = torch.randn(1, ctx, t.hidden_size) * 0.02
-    pos = torch.arange(ctx)[None, None].expand(3, 1, ctx)
-    oq.qwen2_model(W, cfg, emb, cache, pos)
-    e1 = torch.randn(1, 1, t.hidden_size) * 0.02
-    n_tok = 6
+    t0 = time.perf_counter()
+    W = oq.random_weights(cfg, seed=0, dtype=torch.bfloat16)
+    setup_s = time.perf_counter() - t0
+    ctx, n_tok = 384, 6
+    hd = t.hidden_size // t.num_attention_heads
+    cache = [O.KVCache() for _ in range(t.num_hidden_layers)]
+    g = torch.Generator().manual_seed(1)
+    for c in cache:     # a context of 384 tokens already in the cache (contents random: timing only)
+        c.update_and_fetch((torch.randn(1, t.num_key_value_heads, ctx, hd, generator=g) * 0.5).to(torch.bfloat16),
+                           (torch.randn(1, t.num_key_value_heads, ctx, hd, generator=g) * 0.5).to(torch.bfloat16))
+    e1 = (torch.randn(1, 1, t.hidden_size, generator=g) * 0.02).to(torch.bfloat16)
+    oq.lm_head(W, cfg, oq.qwen2_model(W, cfg, e1, cache, torch.full((3, 1, 1), ctx)))     # warm-up token
     t0 = time.perf_counter()
     for i in range(n_tok):
-        h = oq.qwen2_model(W, cfg, e1, cache, torch.full((3, 1, 1), ctx + i))
-    t_layers = (time.perf_counter() - t0) / n_tok
+        h = oq.qwen2_model(W, cfg, e1, cache, torch.full((3, 1, 1), ctx + 1 + i))
+        O.argmax_first(O.logprobs_from_logits(oq.lm_head(W, cfg, h)[:, -1, :]))
+    tok_s = n_tok / (time.perf_counter() - t0)
+    img_s = {}
+    for hw, n in ((448, 1024), (336, 576)):
+        grid = np.array([[1, hw // 14, hw // 14]])
+        pix = torch.randn(n, 1176, generator=g).to(torch.bfloat16)
+        t0 = time.perf_counter()
+        oq.vision_tower(W, cfg, pix, grid)
+        img_s[hw] = 1.0 / (time.perf_counter() - t0)
+    out = {"value": tok_s, "unit": "tokens/s", "cores": threads, "kind": "port",
+           "vision_images_per_s": img_s[336], "vision_images_per_s_448": img_s[448],
+           "sample": (f"oracle (torch-CPU restatement of the reference's bf16 graph), Qwen2-VL-2B at full size, {threads} threads: "
+                      f"decode = {n_tok} tokens at context {ctx} through all {t.num_hidden_layers} layers + lm_head + greedy "
+                      f"sampling; vision = one 336x336 image (576 patches) and one 448x448 image (1024 patches) through all "
+                      f"{cfg.vision.depth} ViT blocks + merger; nothing extrapolated"),
+           "setup_s": setup_s}
+    del W, cache
+    if with_hf:
+        try:
+            out["hf_fp32"] = _hf_cpu_baseline(cfg, threads, ctx, n_tok)
+        except Exception as e:                       # the second opinion must never cost the headline line
+            out["hf_fp32"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def _hf_cpu_baseline(cfg, threads, ctx, n_tok):
+    """HuggingFace transformers Qwen2VLForConditionalGeneration, fp32, torch-CPU, random init at the same dims: decode
+    tokens/s at the same context (greedy, KV cache) and the vision tower on one 336x336 image."""
+    import transformers
+    from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
+
+    t, v = cfg.text, cfg.vision
+    hcfg = Qwen2VLConfig(
+        text_config=dict(hidden_size=t.hidden_size, num_hidden_layers=t.num_hidden_layers,
+                         intermediate_size=t.intermediate_size, num_attention_heads=t.num_attention_heads,
+                         num_key_value_heads=t.num_key_value_heads, vocab_size=t.vocab_size, rms_norm_eps=t.rms_norm_eps,
+                         rope_theta=t.rope_theta, rope_scaling={"type": "mrope", "mrope_section": list(t.mrope_section)},
+                         tie_word_embeddings=t.tie_word_embeddings, max_position_embeddings=32768, bos_token_id=0,
+                         eos_token_id=1, pad_token_id=2),
+        vision_config=dict(depth=v.depth, embed_dim=v.embed_dim, hidden_size=v.hidden_size, num_heads=v.num_heads,
+                           mlp_ratio=int(v.mlp_ratio), patch_size=v.patch_size, spatial_merge_size=v.spatial_merge_size,
+                           temporal_patch_size=v.temporal_patch_size, in_channels=v.in_channels),
+        image_token_id=cfg.image_token_id, video_token_id=cfg.video_token_id,
+        vision_start_token_id=cfg.vision_start_token_id, tie_word_embeddings=t.tie_word_embeddings, bos_token_id=0,
+        eos_token_id=1, pad_token_id=2)
     t0 = time.perf_counter()
-    for i in range(3):
-        oq.lm_head(W, cfg, h)
-    t_head = (time.perf_counter() - t0) / 3
-    tok_s = 1.0 / (t_layers / LS * 28 + t_head)
-    # --- ViT: per-block time on one 448^2 image (1024 patches)
-    grid = np.array([[1, 32, 32]])
-    pix = torch.randn(1024, 1176)
-    x = oq.patch_embed(W, cfg, pix)
-    freqs = O.vision_rotary_freqs(grid, 80)
-    cu = oq.vision_cu_seqlens(grid)
-    t0 = time.perf_counter()
-    for i in range(VS):
-        x = oq.vision_block(W, i, cfg, x, cu, freqs)
-    t_block = (time.perf_counter() - t0) / VS
-    t0 = time.perf_counter()
-    oq.patch_merger(W, cfg, x)
-    t_merge = time.perf_counter() - t0
-    img_s = 1.0 / (t_block * 32 + t_merge)
-    return {"value": tok_s, "unit": "tokens/s", "cores": threads, "kind": "port",
-            "vision_images_per_s": img_s,
-            "sample": (f"oracle (torch-CPU fp32 restatement of the reference), Qwen2-VL-2B dims, {threads} threads: decode = "
-                       f"{n_tok} tokens through {LS} of 28 LLM layers at ctx {ctx} + lm_head, per-token time extrapolated "
-                       f"x28/{LS} layers; vision = {VS} of 32 ViT blocks + merger on one 448x448 image, extrapolated x32/{VS}")}
+    with torch.no_grad():
+        m = Qwen2VLForConditionalGeneration(hcfg).eval().to(torch.float32)
+        setup = time.perf_counter() - t0
+        ids = torch.randint(3, min(t.vocab_size, 151643) - 8, (1, ctx))
+        out = m(input_ids=ids, use_cache=True)
+        past = out.past_key_values
+        nxt = out.logits[:, -1].argmax(-1, keepdim=True)
+        out = m(input_ids=nxt, past_key_values=past, use_cache=True)          # warm-up token
+        past, nxt = out.past_key_values, out.logits[:, -1].argmax(-1, keepdim=True)
+        t0 = time.perf_counter()
+        for _ in range(n_tok):
+            out = m(input_ids=nxt, past_key_values=past, use_cache=True)
+            past, nxt = out.past_key_values, out.logits[:, -1].argmax(-1, keepdim=True)
+        tok_s = n_tok / (time.perf_counter() - t0)
+        pix = torch.randn(576, 1176)
+        grid = torch.tensor([[1, 24, 24]])
+        visual = m.model.visual if hasattr(m, "model") and hasattr(m.model, "visual") else m.visual
+        t0 = time.perf_counter()
+        visual(pix, grid_thw=grid)
+        img_s = 1.0 / (time.perf_counter() - t0)
+    return {"value": tok_s, "unit": "tokens/s", "vision_images_per_s": img_s, "cores": threads, "setup_s": setup,
+            "sample": f"transformers {transformers.__version__} Qwen2VLForConditionalGeneration fp32, random init, "
+                      f"{n_tok} greedy tokens at context {ctx} with its KV cache; vision tower on one 336x336 image"}
 
 
 DECODE_KERNELS = ("gemv_rowwave_kernel", "gemv_splitk_kernel", "attn_decode_mfma_kernel", "attn_decode_combine_kernel",
@@ -255,37 +308,237 @@ def pmc_traffic():
     return gu, per_tok
 
 
+def _load_synthetic(cfg_dict, model_pkg, rank, dev, **engine_kw):
+    """rank 0 materialises the synthetic replica, the others receive it over RCCL/xGMI (parallel.broadcast_weights)"""
+    from mlx_vlm_amd import parallel, synthetic
+    from mlx_vlm_amd.utils import freeze_heap
+
+    cfg = model_pkg.ModelConfig.from_dict(dict(cfg_dict))
+    t0 = time.perf_counter()
+    W = synthetic.random_weights(cfg, seed=0, device=dev, fill=(rank == 0))
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    parallel.broadcast_weights(W, src=0)
+    torch.cuda.synchronize()
+    bcast_s = parallel.max_over_ranks(time.perf_counter() - t1, dev)
+    nbytes = sum(v.numel() * v.element_size() for v in W.values())
+    model = model_pkg.Model(cfg, device=dev, **engine_kw)
+    model.load_weights(W)
+    del W
+    torch.cuda.synchronize()
+    freeze_heap()          # what load() does: no 100 ms cyclic-GC passes over the import heap inside timed loops
+    return cfg, model, {"load_s": time.perf_counter() - t0, "weight_bytes": nbytes, "broadcast_s": bcast_s}
+
+
+def _dist_info(ws):
+    import torch.distributed as dist
+
+    if ws > 1 and dist.is_initialized():
+        return {"backend": dist.get_backend(), "ranks": dist.get_world_size()}
+    return {"backend": None, "ranks": 1}
+
+
+def workload_nanollava(args, rank, ws, dev):
+    """BASELINE configs[0]: nanoLLaVA (SigLIP-so400m/14-384 + Qwen1.5-0.5B), one 336x336 image (resized to 384x384 -> 729
+    image tokens) + 128 text tokens, greedy 64 tokens, batch 1 per GPU (weak scaling)."""
+    from mlx_vlm_amd import parallel, synthetic
+    from mlx_vlm_amd.generate import generate_step
+    from mlx_vlm_amd.models import llava_bunny
+
+    cfg, model, load = _load_synthetic(synthetic.NANOLLAVA, llava_bunny, rank, dev, kv_pool_tokens=8192, max_seqs=8)
+    max_tokens = args.max_tokens or 64
+    rng = np.random.default_rng(rank)
+    img = rng.integers(0, 256, (336, 336, 3), dtype=np.uint8)
+    pix = torch.from_numpy(np.stack(llava_bunny.ImageProcessor().preprocess([img]))).to(dev)
+    text = np.random.default_rng(1000 + rank).integers(0, 151643, 128)
+    ids = np.concatenate([text[:64], [cfg.image_token_index], text[64:]]).astype(np.int64)[None]
+
+    def step():
+        t0 = time.perf_counter()
+        toks, t_first = [], None
+        for tok, _ in generate_step(ids, model, pix, None, max_tokens=max_tokens, temperature=0.0, return_logprobs=False,
+                                    lookahead=args.lookahead):
+            if t_first is None:
+                t_first = time.perf_counter()
+            toks.append(tok)
+        torch.cuda.synchronize()
+        return t_first - t0, time.perf_counter() - t_first, toks
+
+    for _ in range(args.warmup):
+        step()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pre = dec = 0.0
+    for _ in range(args.steps):
+        a, b, _ = step()
+        pre, dec = pre + a, dec + b
+    torch.cuda.synchronize()
+    parallel.barrier()
+    wall = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    dec_max, pre_max = parallel.max_over_ranks(dec, dev), parallel.max_over_ranks(pre, dev)
+    n_dec = args.steps * (max_tokens - 1)
+    tps = ws * n_dec / dec_max
+    t, v = cfg.text_config, cfg.vision_config
+    per_layer = 4 * t.hidden_size * t.hidden_size + 3 * t.hidden_size * t.intermediate_size
+    prompt_tokens = ids.shape[1] - 1 + model.vision_tower.num_patches
+    kv_per_tok = 2 * t.num_hidden_layers * t.num_key_value_heads * (t.hidden_size // t.num_attention_heads) * 2
+    bytes_per_token = 2 * (t.num_hidden_layers * per_layer + t.vocab_size * t.hidden_size) + kv_per_tok * (prompt_tokens + max_tokens // 2)
+    us_tok = dec_max / n_dec * 1e6
+    out = {"metric": "decode tokens/sec + vision-prefill images/sec, nanoLLaVA", "value": tps, "unit": "tokens/s", "n_gpus": ws,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "nanoLLaVA dims (Qwen1.5-0.5B + SigLIP-so400m/14-384, random-init bf16), batch=1 per GPU, one "
+                                  "336x336 image resized to 384x384 (729 image tokens) + 128 text tokens, greedy decode, EOS disabled",
+                      "prompt_tokens": int(prompt_tokens), "max_tokens": max_tokens, "parallelism": f"dp{ws}"},
+           "decode_us_per_token": us_tok, "prefill_ms_to_first_token": pre_max / args.steps * 1e3,
+           "prompt_tps": ws * prompt_tokens * args.steps / pre_max, "load": load, "distributed": _dist_info(ws),
+           "roofline": {"bound": "hbm", "kernel": "whole decode step", "achieved": bytes_per_token / us_tok * 1e-3,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_per_token / us_tok * 1e-3 / HBM_PEAK_GBS,
+                        "traffic": None, "algorithmic_bytes_per_token": bytes_per_token}}
+    if rank == 0 and not args.no_extras:
+        N, E, I = model.vision_tower.num_patches, v.hidden_size, v.intermediate_size
+        tflop = (v.num_hidden_layers * (2 * N * E * 3 * E + 2 * N * E * E + 4 * N * E * I + 4 * N * N * E)
+                 + 2 * N * model.vision_tower.patch_dim * E + 2 * N * (E * t.hidden_size + t.hidden_size ** 2)) / 1e12
+
+        def tower(n):
+            batch = pix.expand(n, -1, -1, -1).contiguous()
+            for _ in range(2):
+                model.encode_image(batch)
+            torch.cuda.synchronize()
+            dts = sorted(time_events(lambda: model.encode_image(batch), 1) for _ in range(5))
+            return n / dts[2]
+
+        ips1, ips8 = tower(1), tower(8)
+        out["vision_images_per_s"] = ips8
+        out["vision_images_per_s_single"] = ips1
+        out["roofline_vit"] = {"bound": "mfma", "achieved": ips8 * tflop, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": ips8 * tflop / MFMA_BF16_PEAK_TF, "tflop_per_image": tflop, "traffic": None,
+                               "workload": "8 x 384x384 images per call (SigLIP tower + projector)"}
+    if rank == 0 and ws == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_nanollava(min(os.cpu_count() or 1, 32))
+    return out
+
+
+def cpu_baseline_nanollava(threads):
+    """The oracle (torch-CPU restatement of the reference's llava_bunny files, bf16 typed graph) at full size on the host
+    cores: 6 decode tokens at context 857 through all 24 layers + lm_head, one image through the 27-layer tower."""
+    from oracle import llava_bunny as ob
+    from oracle import ops as O
+
+    torch.set_num_threads(threads)
+    cfg = ob.Cfg(text=ob.TextCfg(), vision=ob.VisionCfg())
+    W = ob.random_weights(cfg, seed=0, dtype=torch.bfloat16, std=0.02, embed_std=0.02)
+    t = cfg.text
+    ctx, n_tok, hd = 857, 6, t.hidden_size // t.num_attention_heads
+    g = torch.Generator().manual_seed(1)
+    cache = [O.KVCache() for _ in range(t.num_hidden_layers)]
+    for c in cache:
+        c.update_and_fetch((torch.randn(1, t.num_key_value_heads, ctx, hd, generator=g) * 0.5).to(torch.bfloat16),
+                           (torch.randn(1, t.num_key_value_heads, ctx, hd, generator=g) * 0.5).to(torch.bfloat16))
+    ob.decode_teacher_forced  # noqa: B018  (same code path, kept importable)
+    e1 = (torch.randn(1, 1, t.hidden_size, generator=g) * 0.02).to(torch.bfloat16)
+
+    def one(e):
+        h = e
+        for i in range(t.num_hidden_layers):
+            h = ob.decoder_layer(W, i, cfg, h, cache[i])
+        h = O.rms_norm(h, W[ob.LM + "norm.weight"], t.rms_norm_eps)
+        return O.argmax_first(O.logprobs_from_logits(O.linear(h, W[ob.LM + "embed_tokens.weight"])[:, -1, :]))
+
+    one(e1)
+    t0 = time.perf_counter()
+    for _ in range(n_tok):
+        one(e1)
+    tok_s = n_tok / (time.perf_counter() - t0)
+    pix = torch.randn(1, 3, 384, 384, generator=g).to(torch.bfloat16)
+    t0 = time.perf_counter()
+    ob.mm_projector(W, ob.vision_tower(W, cfg, pix))
+    img_s = 1.0 / (time.perf_counter() - t0)
+    return {"value": tok_s, "unit": "tokens/s", "cores": threads, "kind": "port", "vision_images_per_s": img_s,
+            "sample": f"oracle (torch-CPU restatement of the reference, bf16 graph), nanoLLaVA at full size, {threads} threads: "
+                      f"{n_tok} decode tokens at context {ctx} through all {t.num_hidden_layers} layers + lm_head; one 384x384 "
+                      f"image through the 27-layer SigLIP tower + projector; nothing extrapolated"}
+
+
+def workload_7b_b32(args, rank, ws, dev):
+    """BASELINE configs[2]: Qwen2-VL-7B dims, 32 requests (336x336 image + 128-token prompt each) dealt data-parallel over
+    the ranks by parallel.dp_batch_generate (length-sorted deal; every rank a continuous BatchGenerator of <= 8 rows; no
+    collective inside the steps).  Total work is fixed: strong scaling."""
+    from mlx_vlm_amd import parallel, synthetic
+    from mlx_vlm_amd.models import qwen2_vl
+
+    cfg, model, load = _load_synthetic(synthetic.QWEN2_VL_7B, qwen2_vl, rank, dev, kv_pool_tokens=32768, max_seqs=32)
+    n_req, max_tokens = 32, args.max_tokens or 64
+    reqs = []
+    for i in range(n_req):
+        ids, pix, thw = build_request(cfg, 336, 128, seed=i)
+        reqs.append({"input_ids": ids.reshape(-1), "pixel_values": pix, "image_grid_thw": thw, "max_tokens": max_tokens})
+    for _ in range(args.warmup):
+        parallel.dp_batch_generate(model, None, requests=reqs[: 2 * ws], max_tokens=8)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    total, res = 0, None
+    for _ in range(args.steps):
+        res = parallel.dp_batch_generate(model, None, requests=reqs, max_tokens=max_tokens)
+        if rank == 0:
+            total += res["generation_tokens"]
+    torch.cuda.synchronize()
+    parallel.barrier()
+    wall = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    t = cfg.text_config
+    lm_params = t.num_hidden_layers * (2 * t.hidden_size * (t.num_attention_heads + t.num_key_value_heads) * 128
+                                       + 3 * t.hidden_size * t.intermediate_size) + t.vocab_size * t.hidden_size
+    out = {"metric": "decode tokens/sec (end to end, prefill included), Qwen2-VL-7B batch=32", "value": total / wall if rank == 0 else 0.0,
+           "unit": "tokens/s", "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "Qwen2-VL-7B-Instruct dims (random-init bf16), 32 requests (one 336x336 image -> 144 image tokens + "
+                                  f"128 text tokens each, greedy {max_tokens} new tokens, EOS disabled) dealt data-parallel over the "
+                                  "ranks, continuous batching with 8 decode rows per GPU",
+                      "requests": n_req, "max_tokens": max_tokens, "parallelism": f"dp{ws}",
+                      "per_rank_requests": res["per_rank_requests"] if rank == 0 else None},
+           "load": load, "distributed": _dist_info(ws),
+           "roofline": {"bound": "hbm", "kernel": "whole job (weights streamed once per decode step for up to 8 rows)",
+                        "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                        "algorithmic_weight_bytes_per_step": 2 * lm_params}}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--max-tokens", type=int, default=256)
+    ap.add_argument("--max-tokens", type=int, default=0, help="0 = the workload's own (256 / 64 / 64)")
     ap.add_argument("--lookahead", type=int, default=8)
     ap.add_argument("--vit-batch", type=int, default=16)
+    ap.add_argument("--workload", default="qwen2vl-2b", choices=["qwen2vl-2b", "nanollava", "qwen2vl-7b-b32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-hf", action="store_true", help="skip the HuggingFace torch-CPU second opinion of cpu_baseline")
     ap.add_argument("--no-extras", action="store_true", help="skip kernel rooflines / ViT throughput (profiling runs)")
     args = ap.parse_args()
 
     from mlx_vlm_amd import parallel, synthetic
-    from mlx_vlm_amd.models.qwen2_vl import Model, ModelConfig
+    from mlx_vlm_amd.models import qwen2_vl
 
     rank, ws, local = parallel.init()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    cfg = ModelConfig.from_dict(dict(synthetic.QWEN2_VL_2B))
+    if rank == 0 and ws > 1:
+        print(f"[bench] {ws} ranks, backend {_dist_info(ws)['backend']} (RCCL over xGMI), one process per GPU", file=sys.stderr, flush=True)
+    if args.workload != "qwen2vl-2b":
+        out = (workload_nanollava if args.workload == "nanollava" else workload_7b_b32)(args, rank, ws, dev)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        parallel.barrier()
+        parallel.shutdown()
+        return
+    args.max_tokens = args.max_tokens or 256
 
-    # rank 0 materialises the replica; the others receive it over RCCL/xGMI
-    t0 = time.perf_counter()
-    W = synthetic.random_weights(cfg, seed=0, device=dev, fill=(rank == 0))
-    parallel.broadcast_weights(W, src=0)
-    model = Model(cfg, device=dev, kv_pool_tokens=16384, max_seqs=16)
-    model.load_weights(W)
-    del W
-    torch.cuda.synchronize()
-    load_s = time.perf_counter() - t0
-    from mlx_vlm_amd.utils import freeze_heap
-    freeze_heap()          # what load() does: no 100 ms cyclic-GC passes over the import heap inside timed loops
+    cfg, model, load = _load_synthetic(synthetic.QWEN2_VL_2B, qwen2_vl, rank, dev, kv_pool_tokens=16384, max_seqs=16)
+    if rank == 0 and ws > 1:
+        print(f"[bench] weights: {load['weight_bytes'] / 1e9:.2f} GB broadcast from rank 0 in {load['broadcast_s']:.3f} s", file=sys.stderr, flush=True)
 
     req = build_request(cfg, 448, 128, seed=rank)
     req = (req[0], req[1].to(dev), req[2])
@@ -329,10 +582,9 @@ def main():
                 extras[key] = {"error": f"{type(e).__name__}: {e}"}
     cpu = None
     if rank == 0 and ws == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(min(os.cpu_count() or 1, 32))
+        cpu = cpu_baseline(min(os.cpu_count() or 1, 32), with_hf=not args.no_cpu_hf)
 
     if rank == 0:
-        t = cfg.text_config
         lm_params = 28 * 46797824 + 1536 + 233373696
         ctx_mid = int(req[0].shape[1]) + args.max_tokens // 2
         bytes_per_token = 2 * lm_params + 28672 * ctx_mid + 28672
@@ -345,21 +597,23 @@ def main():
             "config": {"workload": "Qwen2-VL-2B-Instruct dims (random-init bf16), batch=1 per GPU, one 448x448 image "
                                    "(1024 patches -> 256 image tokens) + 128 text tokens, greedy 256-token decode, EOS disabled",
                        "prompt_tokens": int(req[0].shape[1]), "max_tokens": args.max_tokens, "parallelism": f"dp{ws}",
-                       "decode_lookahead": args.lookahead},
+                       "decode_lookahead": args.lookahead, "decode_tuning": dict(model.language_model.tuning)},
             "decode_us_per_token": us_per_token,
             "prefill_ms_to_first_token": pre_max / args.steps * 1e3,
             "prompt_tps": ws * args.steps * int(req[0].shape[1]) / pre_max,
             "e2e_tokens_per_s": ws * ntok / wall,
-            "load_s": load_s,
-            "roofline_decode_step": {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": step_gbs / HBM_PEAK_GBS, "traffic": traffic_tok,
-                                     "algorithmic_bytes_per_token": bytes_per_token},
+            "load_s": load["load_s"], "load": load, "distributed": _dist_info(ws),
+            # the number the north-star's 60 % target refers to: the WHOLE decode step against the HBM roofline
+            "roofline": {"bound": "hbm", "kernel": "whole decode step (all launches of one token)", "achieved": step_gbs,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS, "traffic": traffic_tok,
+                         "algorithmic_bytes_per_token": bytes_per_token},
         }
+        out["roofline_decode_step"] = dict(out["roofline"])
         if extras:
             k = extras["kernels"]["gemv_gate_up_swiglu"]
-            out["roofline"] = {"bound": "hbm", "kernel": GATE_UP_KERNEL + " (RMSNorm + gate/up GEMV + SwiGLU, 28 launches/token)",
-                               "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["GBps"] / HBM_PEAK_GBS,
-                               "traffic": traffic_gu, "bytes_per_launch": k["bytes_per_launch"], "us_per_launch": k["us_per_launch"]}
+            out["roofline_kernel"] = {"bound": "hbm", "kernel": GATE_UP_KERNEL + " (RMSNorm + gate/up GEMV + SwiGLU, 28 launches/token)",
+                                      "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["GBps"] / HBM_PEAK_GBS,
+                                      "traffic": traffic_gu, "bytes_per_launch": k["bytes_per_launch"], "us_per_launch": k["us_per_launch"]}
             out["kernel_rooflines"] = extras["kernels"]
             ips336, dt336 = extras["vit336"]
             ips448, dt448 = extras["vit448"]

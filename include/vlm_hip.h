@@ -147,6 +147,32 @@ int vlm_sample(const void* logits, int ld, int B, int V, void* logprobs, void* s
                void* workspace, float temperature, float top_p, float min_p, int top_k, unsigned seed,
                const void* step_ptr, void* stream);
 
+/* Logits processors of generate_step (make_logits_processors, sample_utils.py:92-146, applied at ar.py:360-364) as ONE
+ * device pass over the logits row(s), in the reference's order: logit_bias (129-134) -> repetition penalty (390-422:
+ * x < 0 ? x * p : x / p, once per distinct token of the last rep_ctx fed tokens) -> presence penalty (425-450: - p once
+ * per distinct token) -> frequency penalty (453-475: - p per occurrence).  Every step rounds to bf16 as the reference's
+ * typed graph does (python-float penalties are rounded to bf16 first).
+ * The history of fed tokens (prompt + every token fed back) lives on the device so the step stays graph-replayable:
+ * hist int32 [B][hist_cap] ring, hist_len int32 [B] tokens pushed so far.  push_tok != NULL: push_tok[b] is appended to
+ * row b's history FIRST (the decode step feeds tok[b]; the reference appends y before the processors run).
+ * A penalty of 0 / a context of 0 switches that processor off.  Contexts <= hist_cap <= 1024. */
+typedef struct vlm_penalty_args {
+  void* hist;
+  void* hist_len;
+  int hist_cap;
+  float rep_penalty;
+  int rep_ctx;
+  float pres_penalty;
+  int pres_ctx;
+  float freq_penalty;
+  int freq_ctx;
+  const void* bias_idx; /* int32 [n_bias] (distinct) */
+  const void* bias_val; /* fp32 [n_bias] */
+  int n_bias;
+} vlm_penalty_args;
+int vlm_apply_logit_penalties(void* logits, int ld, int B, int V, const void* push_tok, const vlm_penalty_args* p,
+                              void* stream);
+
 /* The greedy tail of a decode step in two launches instead of five: vlm_sample at temperature 0 (ar.py:368 logprobs,
  * sample_utils.py:63-64 argmax) + vlm_decode_advance (cache.py:362, language.py:476-509) + the NEXT step's
  * vlm_embed_gather (language.py:164,179): h[b] = embed[tok[b]] (row stride ldh).  workspace: vlm_sample_workspace_bytes,
@@ -216,6 +242,8 @@ typedef struct vlm_decode_args {
   int top_k;
   unsigned seed;
   int flags; /* VLM_DECODE_* */
+  const vlm_penalty_args* penalties; /* NULL: none.  Applied to the step's logits before sampling; the fed token is
+                                        pushed to the history first (vlm_apply_logit_penalties). (host pointer, copied) */
 } vlm_decode_args;
 
 /* vlm_decode_args.flags */

@@ -41,13 +41,19 @@ class PrefillArgs(C.Structure):
                 ("last_rows", c_void_p), ("n_last", c_int), ("xlast", c_void_p), ("logits", c_void_p)]
 
 
+class PenaltyArgs(C.Structure):
+    _fields_ = [("hist", c_void_p), ("hist_len", c_void_p), ("hist_cap", c_int), ("rep_penalty", c_float), ("rep_ctx", c_int),
+                ("pres_penalty", c_float), ("pres_ctx", c_int), ("freq_penalty", c_float), ("freq_ctx", c_int),
+                ("bias_idx", c_void_p), ("bias_val", c_void_p), ("n_bias", c_int)]
+
+
 class DecodeArgs(C.Structure):
     _fields_ = [("B", c_int), ("tok", c_void_p), ("pos", c_void_p), ("ctx", c_void_p), ("step", c_void_p),
                 ("h", c_void_p), ("qkv", c_void_p), ("attn", c_void_p), ("act", c_void_p), ("logits", c_void_p),
                 ("logprobs", c_void_p), ("scratch", c_void_p), ("part_o", c_void_p), ("part_ml", c_void_p),
                 ("sample_ws", c_void_p), ("out_ring", c_void_p), ("ring_len", c_int), ("nsplit", c_int),
                 ("temperature", c_float), ("top_p", c_float), ("min_p", c_float), ("top_k", c_int), ("seed", c_uint),
-                ("flags", c_int)]
+                ("flags", c_int), ("penalties", C.POINTER(PenaltyArgs))]
 
 
 class VitConfig(C.Structure):
@@ -99,6 +105,7 @@ SIGNATURES = {
     "vlm_sample_workspace_bytes": (c_size_t, [c_int]),
     "vlm_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float,
                            c_float, c_float, c_int, c_uint, c_void_p, c_void_p]),
+    "vlm_apply_logit_penalties": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, C.POINTER(PenaltyArgs), c_void_p]),
     "vlm_sample_greedy_advance": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "vlm_llm_set_tuning": (c_int, [c_void_p, c_int, c_int]),

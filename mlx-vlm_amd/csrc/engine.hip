@@ -32,6 +32,7 @@ namespace {
 // KV-pool view (both plain pointers / scalars).  A continuous batch changes width (1/2/4/8 rows) as requests come
 // and go, and a single-stream generate may interleave with it: each shape keeps its graph instead of re-capturing.
 struct DecodeGraph {
+  vlm_penalty_args pen;                   // copy of *args.penalties (zeroed when there are none)
   vlm_decode_args args;
   vlm_kv_pool kv;
   hipGraph_t graph;
@@ -71,9 +72,18 @@ struct Llm {
   int launches = 0;
 };
 
+inline bool same_pen(const vlm_penalty_args& x, const vlm_penalty_args* y) {
+  vlm_penalty_args z{};
+  if (!y) y = &z;
+  return x.hist == y->hist && x.hist_len == y->hist_len && x.hist_cap == y->hist_cap && x.rep_penalty == y->rep_penalty &&
+         x.rep_ctx == y->rep_ctx && x.pres_penalty == y->pres_penalty && x.pres_ctx == y->pres_ctx &&
+         x.freq_penalty == y->freq_penalty && x.freq_ctx == y->freq_ctx && x.bias_idx == y->bias_idx &&
+         x.bias_val == y->bias_val && x.n_bias == y->n_bias;
+}
+
 inline bool same_key(const DecodeGraph& g, const vlm_decode_args& a, const vlm_kv_pool& kv) {
   const vlm_decode_args& b = g.args;
-  return a.B == b.B && a.tok == b.tok && a.pos == b.pos && a.ctx == b.ctx && a.step == b.step && a.h == b.h &&
+  return same_pen(g.pen, a.penalties) && a.B == b.B && a.tok == b.tok && a.pos == b.pos && a.ctx == b.ctx && a.step == b.step && a.h == b.h &&
          a.qkv == b.qkv && a.attn == b.attn && a.act == b.act && a.logits == b.logits && a.logprobs == b.logprobs &&
          a.scratch == b.scratch && a.part_o == b.part_o && a.part_ml == b.part_ml && a.sample_ws == b.sample_ws &&
          a.out_ring == b.out_ring && a.ring_len == b.ring_len && a.nsplit == b.nsplit && a.temperature == b.temperature &&
@@ -396,6 +406,10 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
   if (!(skip & 32))
   TRY(vlm_gemv_bf16(a->h, m->g.lm_head, nullptr, nullptr, m->g.final_norm_w, a->logits, B, c.vocab, D, D, D, c.vocab, 0,
                     c.rms_eps, VLM_EPI_NONE, stream)); ++n;
+  if (sample && a->penalties) {
+    // logits processors (ar.py:360-364): the fed token joins the history, then bias / penalties on the step's logits
+    TRY(vlm_apply_logit_penalties(a->logits, c.vocab, B, c.vocab, a->tok, a->penalties, stream)); ++n;
+  }
   if (sample && !(skip & 64)) {
     if (pf == 1 && (tn.mask & 64)) {
       // the sampler tail moves 0.3 MB: pull layer 0 for the next step while it runs
@@ -458,7 +472,7 @@ extern "C" int vlm_llm_decode_graph_build(void* handle, const vlm_decode_args* a
   hipStream_t cap = nullptr;
   hipError_t e = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking);
   if (e != hipSuccess) return 1000 + (int)e;
-  DecodeGraph ng{*a, m->kv, nullptr, nullptr, 0, ++m->tick};
+  DecodeGraph ng{a->penalties ? *a->penalties : vlm_penalty_args{}, *a, m->kv, nullptr, nullptr, 0, ++m->tick};
   hipStream_t side = nullptr;
   if (m->tune.prefetch) {
     if (!m->progress) {

@@ -196,6 +196,81 @@ __global__ __launch_bounds__(256) void logprob_argmax_tail_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// logits processors (penalties / bias) - see include/vlm_hip.h::vlm_apply_logit_penalties
+// ------------------------------------------------------------------------------------------
+struct PenaltyK {
+  int* hist;
+  int* hist_len;
+  int hist_cap;
+  float rep_p;
+  int rep_ctx;
+  float pres_p;
+  int pres_ctx;
+  float freq_p;
+  int freq_ctx;
+  const int* bias_idx;
+  const float* bias_val;
+  int n_bias;
+};
+
+__global__ __launch_bounds__(1024) void logit_penalties_kernel(bf16_t* __restrict__ logits, int ld, int V,
+                                                                const int* __restrict__ push_tok, PenaltyK p) {
+  __shared__ int win[1024];
+  __shared__ int s_len;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  bf16_t* row = logits + (size_t)b * ld;
+  int* hist = p.hist + (size_t)b * p.hist_cap;
+  if (tid == 0) {
+    int len = p.hist_len[b];
+    if (push_tok) {
+      hist[len % p.hist_cap] = push_tok[b];
+      ++len;
+      p.hist_len[b] = len;
+    }
+    s_len = len;
+  }
+  __syncthreads();
+  const int len = s_len, n = min(len, p.hist_cap);
+  // logit_bias: x + bf16(v), distinct indices
+  for (int i = tid; i < p.n_bias; i += blockDim.x) {
+    const int t = p.bias_idx[i];
+    if (t >= 0 && t < V) row[t] = f2bf(bf2f(row[t]) + rbf(p.bias_val[i]));
+  }
+  __syncthreads();
+  // one pass per processor: thread i owns entry i of the window (chronological order); the FIRST occurrence of a token
+  // applies the update (once, or once per occurrence for the frequency penalty)
+  auto pass = [&](int ctx, float pen, int kind) {
+    const int w = min(ctx, n);
+    if (w <= 0 || pen == 0.f) return;
+    if (tid < w) win[tid] = hist[(len - w + tid) % p.hist_cap];
+    __syncthreads();
+    if (tid < w) {
+      const int t = win[tid];
+      bool first = true;
+      int count = 0;
+      for (int j = 0; j < w; ++j) {
+        const bool same = win[j] == t;
+        first = first && !(same && j < tid);
+        count += same;
+      }
+      if (first && t >= 0 && t < V) {
+        float x = bf2f(row[t]);
+        const float pb = rbf(pen);                       // weak-typed python scalar: rounded to the logits dtype first
+        if (kind == 0) x = x < 0.f ? rbf(x * pb) : rbf(x / pb);
+        else if (kind == 1) x = rbf(x - pb);
+        else for (int c = 0; c < count; ++c) x = rbf(x - pb);
+        row[t] = f2bf(x);
+      }
+    }
+    __syncthreads();
+  };
+  pass(p.rep_ctx, p.rep_p, 0);
+  pass(p.pres_ctx, p.pres_p, 1);
+  pass(p.freq_ctx, p.freq_p, 2);
+}
+
 // ------------------------------------------------------------------------------------------
 // General sampler: one 1024-thread workgroup per row (the row is L2 resident).
 // ------------------------------------------------------------------------------------------
@@ -455,4 +530,19 @@ extern "C" int vlm_sample_greedy_advance(const void* logits, int ld, int B, int 
                                          const void* embed, void* h, int D, int ldh, void* stream) {
   return vlm_sample_greedy_advance_ex(logits, ld, B, V, logprobs, ldlp, tok, workspace, ctx, pos, out_ring, ring_len, step,
                                       embed, h, D, ldh, VlmProgress{nullptr, 0}, stream);
+}
+
+extern "C" int vlm_apply_logit_penalties(void* logits, int ld, int B, int V, const void* push_tok, const vlm_penalty_args* p,
+                                         void* stream) {
+  if (!logits || !p || !p->hist || !p->hist_len || B <= 0 || V <= 0) return VLM_ERR_ARG;
+  if (p->hist_cap <= 0 || p->hist_cap > 1024 || p->rep_ctx > p->hist_cap || p->pres_ctx > p->hist_cap ||
+      p->freq_ctx > p->hist_cap)
+    return VLM_ERR_SHAPE;
+  if (p->n_bias > 0 && (!p->bias_idx || !p->bias_val)) return VLM_ERR_ARG;
+  PenaltyK k{(int*)p->hist, (int*)p->hist_len, p->hist_cap, p->rep_penalty, p->rep_ctx, p->pres_penalty, p->pres_ctx,
+             p->freq_penalty, p->freq_ctx, (const int*)p->bias_idx, (const float*)p->bias_val, p->n_bias};
+  hipLaunchKernelGGL(logit_penalties_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, (bf16_t*)logits, ld, V,
+                     (const int*)push_tok, k);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
 }

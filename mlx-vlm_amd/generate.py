@@ -116,17 +116,23 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
     (image_grid_thw, ...) are forwarded to model.get_input_embeddings.  logprobs is a device
     bf16 [V] tensor (None when return_logprobs=False)."""
     if logits_processors:
-        raise NotImplementedError("logits_processors are outside the built hot path (SURVEY §8a21)")
-    for k in ("repetition_penalty", "presence_penalty", "frequency_penalty", "logit_bias"):
-        if kwargs.pop(k, None):
-            raise NotImplementedError(f"{k} is outside the built hot path")
+        raise NotImplementedError("custom Python logits_processors cannot run inside the captured decode step; the "
+                                  "reference's own processors (logit_bias, repetition / presence / frequency penalty) are "
+                                  "built as a device pass: pass those keyword arguments instead")
+    from .sample_utils import make_logits_processors
+
+    # reference ar.py:290-302: the penalties / bias of generate_step as a device-side logits pass
+    procs = make_logits_processors(kwargs.pop("logit_bias", None), kwargs.pop("repetition_penalty", None),
+                                   kwargs.pop("repetition_context_size", 20), kwargs.pop("presence_penalty", None),
+                                   kwargs.pop("presence_context_size", 20), kwargs.pop("frequency_penalty", None),
+                                   kwargs.pop("frequency_context_size", 20))
     for k in ("max_kv_size", "kv_bits", "draft_model", "thinking_budget_criteria"):
         if kwargs.pop(k, None):
             # the reference would switch cache class / decoding scheme (RotatingKVCache, QuantizedKVCache, speculative):
             # dropping the request silently would change results without telling the caller
             raise NotImplementedError(f"{k} is outside the built hot path (SURVEY section 8f.4)")
-    for k in ("repetition_context_size", "presence_context_size", "frequency_context_size", "kv_group_size",
-              "quantized_kv_start", "verbose", "kv_quant_scheme", "prompt_cache_checkpoint", "prompt_cache_checkpoint_len"):
+    for k in ("kv_group_size", "quantized_kv_start", "verbose", "kv_quant_scheme", "prompt_cache_checkpoint",
+              "prompt_cache_checkpoint_len"):
         kwargs.pop(k, None)
     smp = _resolve_sampler(sampler, temperature, top_p, min_p, top_k, seed)
     sargs = smp.engine_args()
@@ -149,6 +155,12 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
         pos = np.broadcast_to(pos[None], (3,) + pos.shape)
     logits = lm.prefill(emb.reshape(L, -1), pos.reshape(3, L), [prompt_cache], [L], "last", reserve_extra=max_tokens + 2)
     step0 = torch.zeros(1, dtype=torch.int32, device=logits.device)
+    if procs:
+        # ar.py:360-364: at the first step `tokens` is the prompt; the history then grows by every token fed back (the
+        # decode step pushes its input token before it applies the processors)
+        pst = lm.decode_state(1)
+        pst.set_history([ids.reshape(-1)])
+        ops.apply_logit_penalties(logits, pst.penalty_args(procs))
     tok0, lp0 = ops.sample(logits, step=step0, want_logprobs=return_logprobs, **sargs)
 
     deltas = np.asarray(f.rope_deltas).reshape(-1)[:1]
@@ -167,7 +179,7 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
     try:
         while n < max_tokens:
             while issued < min(n + lookahead, max_tokens - 1):
-                lm.decode_run(st, 1, sargs, use_graph=use_graph)
+                lm.decode_run(st, 1, sargs, use_graph=use_graph, penalties=procs if procs else None)
                 issued += 1
                 pipe.push(issued, st.tok)
                 if return_logprobs:

@@ -64,9 +64,44 @@ class DecodeState:
         self.scratch = torch.empty(B, t.vocab_size, dtype=bf, device=dev)
         self.part_o = torch.empty(B, Hq, nsplit, hd, dtype=torch.float32, device=dev)
         self.sample_ws = ops.sample_workspace(B, dev)
+        # history of fed tokens for the logits processors (penalties): ring per row + count
+        from ...sample_utils import HIST_CAP
+        self.hist = A((B, HIST_CAP), i32, zero=True)
+        self.hist_len = A(B, i32, zero=True)
+        self._pen = None            # (key, PenaltyArgs, device bias tensors) kept alive while a graph may use them
         self.graph_key = None
 
-    def args(self, temperature=0.0, top_p=1.0, min_p=0.0, top_k=0, seed=0, with_logprobs=True, B=None, flags=0):
+    def penalty_args(self, spec):
+        """_lib.PenaltyArgs over this state's history for a sample_utils.LogitsProcessors spec (cached per spec)."""
+        if not spec:
+            return None
+        if self._pen is None or self._pen[0] != spec.key():
+            bias = spec.logit_bias or {}
+            idx = _lib.h2d(np.asarray(list(bias.keys()), dtype=np.int32), self.hist.device) if bias else None
+            val = _lib.h2d(np.asarray(list(bias.values()), dtype=np.float32), self.hist.device) if bias else None
+            pa = _lib.PenaltyArgs(self.hist.data_ptr(), self.hist_len.data_ptr(), self.hist.shape[1],
+                                  float(spec.repetition_penalty), int(spec.repetition_context_size),
+                                  float(spec.presence_penalty), int(spec.presence_context_size),
+                                  float(spec.frequency_penalty), int(spec.frequency_context_size),
+                                  idx.data_ptr() if idx is not None else None, val.data_ptr() if val is not None else None,
+                                  len(bias))
+            self._pen = (spec.key(), pa, idx, val)
+        return self._pen[1]
+
+    def set_history(self, rows_tokens):
+        """rows_tokens[b] = the tokens fed so far for row b (the prompt): the last HIST_CAP of them go into the ring"""
+        cap = self.hist.shape[1]
+        host = np.zeros((len(rows_tokens), cap), dtype=np.int32)
+        lens = np.zeros(len(rows_tokens), dtype=np.int32)
+        for b, t in enumerate(rows_tokens):
+            t = np.asarray(t, dtype=np.int64).reshape(-1)[-cap:]
+            host[b, :len(t)] = t
+            lens[b] = len(t)
+        self.hist[:len(rows_tokens)].copy_(_lib.h2d(host, self.hist.device))
+        self.hist_len[:len(rows_tokens)].copy_(_lib.h2d(lens, self.hist.device))
+
+    def args(self, temperature=0.0, top_p=1.0, min_p=0.0, top_k=0, seed=0, with_logprobs=True, B=None, flags=0,
+             penalties=None):
         """B < self.B: the step runs over the first B rows (every buffer is row-major, a prefix is a valid state).
         flags: _lib.DECODE_FUSED_TAIL = the step starts from h == embed[tok] and leaves the next step's h behind."""
         p = lambda t: t.data_ptr()  # noqa: E731
@@ -75,7 +110,8 @@ class DecodeState:
                                p(self.logprobs) if (with_logprobs or temperature > 0) else None, p(self.scratch),
                                p(self.part_o), p(self.part_ml), p(self.sample_ws), p(self.out_ring), self.ring_len,
                                self.nsplit, float(temperature), float(top_p), float(min_p), int(top_k),
-                               int(seed) & 0xFFFFFFFF, int(flags))
+                               int(seed) & 0xFFFFFFFF, int(flags),
+                               C.pointer(pa) if (pa := self.penalty_args(penalties)) is not None else None)
 
 
 class LanguageModel:
@@ -420,16 +456,16 @@ class LanguageModel:
         bt = pool.block_table[row0:]
         return _lib.KvPool(pool.kpool.data_ptr(), pool.vpool.data_ptr(), pool.layer_stride, bt.data_ptr(), pool.max_pages)
 
-    def decode_run(self, st: DecodeState, n_steps: int, sampler_args: dict, use_graph: bool = True):
-        """Enqueue n_steps decode steps (graph replays when use_graph)."""
+    def decode_run(self, st: DecodeState, n_steps: int, sampler_args: dict, use_graph: bool = True, penalties=None):
+        """Enqueue n_steps decode steps (graph replays when use_graph).  penalties: sample_utils.LogitsProcessors."""
         L = _lib.lib()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         kv = self._kv_struct(st.seq_row0, decode=True)
         check(L.vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
         fused = bool(self.tuning.get("fused_tail")) and float(sampler_args.get("temperature", 0.0)) == 0.0
-        args = st.args(flags=_lib.DECODE_FUSED_TAIL if fused else 0, **sampler_args)
+        args = st.args(flags=_lib.DECODE_FUSED_TAIL if fused else 0, penalties=penalties, **sampler_args)
         if use_graph:
-            key = (st.seq_row0, st.nsplit, fused, tuple(sorted(sampler_args.items())))
+            key = (st.seq_row0, st.nsplit, fused, penalties.key() if penalties else None, tuple(sorted(sampler_args.items())))
             if st.graph_key != key or getattr(self, "_graph_owner", None) is not st:
                 check(L.vlm_llm_decode_graph_build(self._handle, C.byref(args), stream), "decode_graph_build")
                 st.graph_key = key

@@ -209,6 +209,16 @@ def sample_greedy_advance(logits, tok, ctx, pos, step, embed, h, out_ring=None, 
     return lp
 
 
+def apply_logit_penalties(logits, pen_args, push_tok=None):
+    """In place on logits [B, V] (bf16): logit_bias / repetition / presence / frequency penalties over the device token
+    history (vlm_apply_logit_penalties).  pen_args: _lib.PenaltyArgs; push_tok int32 [B] is appended to the history first."""
+    _dev(logits, push_tok)
+    B, V = logits.shape
+    check(_lib.lib().vlm_apply_logit_penalties(_p(logits), logits.stride(0), B, V, _p(push_tok), C.byref(pen_args), _stream()),
+          "apply_logit_penalties")
+    return logits
+
+
 def gemm_set_staging(mode: int):
     """0 = automatic (LDS DMA when K % 64 == 0), 1 = always register staging (test / A-B knob)."""
     check(_lib.lib().vlm_gemm_set_staging(int(mode)), "gemm_set_staging")

@@ -63,3 +63,43 @@ def make_sampler(temp: float = 0.0, top_p: float = 0.0, min_p: float = 0.0, min_
         raise ValueError(f"`min_p` has to be a float in the [0, 1] interval, but is {min_p}")
     return Sampler(temp=temp, top_p=top_p, min_p=min_p, top_k=top_k,
                    seed=(next(_unseeded) & 0xFFFFFFFF) if seed is None else int(seed))
+
+
+HIST_CAP = 256      # device token history per decode row (csrc/sample.hip::logit_penalties_kernel)
+
+
+@dataclass
+class LogitsProcessors:
+    """What the reference's `make_logits_processors` (sample_utils.py:92-146) builds as a list of Python closures over mx
+    ops, as a SPEC for the device pass `vlm_apply_logit_penalties` (same processors, same order, same rounding points):
+    logit_bias -> repetition penalty -> presence penalty -> frequency penalty."""
+    logit_bias: Optional[dict] = None
+    repetition_penalty: float = 0.0
+    repetition_context_size: int = 20
+    presence_penalty: float = 0.0
+    presence_context_size: int = 20
+    frequency_penalty: float = 0.0
+    frequency_context_size: int = 20
+
+    def __bool__(self):
+        return bool(self.logit_bias) or any(p not in (None, 0, 0.0) for p in
+                                            (self.repetition_penalty, self.presence_penalty, self.frequency_penalty))
+
+    def key(self):
+        return (tuple(sorted((self.logit_bias or {}).items())), self.repetition_penalty, self.repetition_context_size,
+                self.presence_penalty, self.presence_context_size, self.frequency_penalty, self.frequency_context_size)
+
+
+def make_logits_processors(logit_bias=None, repetition_penalty=None, repetition_context_size=20, presence_penalty=None,
+                           presence_context_size=20, frequency_penalty=None, frequency_context_size=20) -> LogitsProcessors:
+    """reference sample_utils.py:92-146 (argument names, defaults and the repetition-penalty check of 405-406)."""
+    if repetition_penalty is not None and (not isinstance(repetition_penalty, (int, float)) or repetition_penalty < 0):
+        raise ValueError(f"penalty must be a non-negative float, got {repetition_penalty}")
+    for name, c in (("repetition", repetition_context_size), ("presence", presence_context_size),
+                    ("frequency", frequency_context_size)):
+        if c is not None and int(c) > HIST_CAP:
+            raise NotImplementedError(f"{name}_context_size > {HIST_CAP} is not built (device history ring)")
+    z = lambda v: 0.0 if v is None else float(v)      # noqa: E731
+    n = lambda v: 20 if v is None else max(0, int(v))  # noqa: E731
+    return LogitsProcessors(dict(logit_bias) if logit_bias else None, z(repetition_penalty), n(repetition_context_size),
+                            z(presence_penalty), n(presence_context_size), z(frequency_penalty), n(frequency_context_size))

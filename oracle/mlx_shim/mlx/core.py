@@ -105,6 +105,35 @@ def _axes(axis):
     return int(axis)
 
 
+class _At:
+    def __init__(self, arr):
+        self._a, self._i = arr, None
+
+    def __getitem__(self, i):
+        self._i = i
+        return self
+
+    def _apply(self, v, fn):
+        t = self._a._t.clone()
+        i = self._i if isinstance(self._i, tuple) else (self._i,)
+        lead, last = i[:-1], _u(i[-1])
+        for x in lead:
+            if not (isinstance(x, slice) and x == slice(None)):
+                raise NotImplementedError("shim .at[]: only [..., indices] forms are restated")
+        idx = torch.as_tensor(last).reshape(-1).tolist()
+        vt = _u(v)
+        vt = torch.as_tensor(vt).to(t.dtype).reshape(-1) if not isinstance(vt, (int, float)) else torch.tensor([vt], dtype=t.dtype)
+        for k, j in enumerate(idx):
+            t[..., j] = fn(t[..., j], vt[k % vt.numel()])
+        return array(t)
+
+    def add(self, v):
+        return self._apply(v, torch.add)
+
+    def subtract(self, v):
+        return self._apply(v, torch.sub)
+
+
 class array:
     __slots__ = ("_t",)
 
@@ -266,6 +295,13 @@ class array:
     # ---- indexing
     def __getitem__(self, i):
         return array(self._t[_idx(i)])
+
+    @property
+    def at(self):
+        """`a.at[idx].add(v)` / `.subtract(v)`: MLX's scatter-update forms.  Unlike `a[idx] += v`, EVERY update is applied,
+        duplicates in `idx` included (mlx.core.array.at docs); the updates are applied one after the other in the
+        array's dtype (scatter with a reduction = read-modify-write per update), i.e. k duplicates round k times."""
+        return _At(self)
 
     def __setitem__(self, i, v):
         v = _u(v)

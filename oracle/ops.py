@@ -341,6 +341,40 @@ def apply_min_p(logprobs, min_p: float, min_tokens_to_keep: int = 1):
     return torch.where(remove, torch.full_like(xf, float("-inf")), xf).to(logprobs.dtype)
 
 
+def apply_logits_processors(logits, tokens, logit_bias=None, repetition_penalty=None, repetition_context_size=20,
+                            presence_penalty=None, presence_context_size=20, frequency_penalty=None,
+                            frequency_context_size=20):
+    """make_logits_processors applied in its order (sample_utils.py:92-146): logit_bias (129-134), repetition penalty
+    (390-422: sign-aware, once per distinct token of the last `context` fed tokens), presence penalty (425-450: minus p
+    once per distinct token), frequency penalty (453-475: minus p per OCCURRENCE, `.at[].subtract`).  generate_step
+    feeds `tokens` = prompt + every token fed back so far (ar.py:360-364).  Typed graph: every step rounds to the logits
+    dtype; a python-float penalty is weak-typed (rounded to that dtype first); duplicate updates of `.at[]` apply one
+    after the other.  logits [B, V] -> new tensor."""
+    x = logits.clone()
+    T = x.dtype
+    toks = [int(t) for t in np.asarray(tokens).reshape(-1)]
+
+    def c(v):
+        return torch.tensor(v, dtype=T)
+
+    if logit_bias:
+        for k, v in logit_bias.items():
+            x[:, int(k)] = (x[:, int(k)] + c(float(v))).to(T)
+    if not toks:
+        return x
+    if repetition_penalty is not None and repetition_penalty != 0:
+        for t in dict.fromkeys(toks[-repetition_context_size:]):
+            col = x[:, t]
+            x[:, t] = torch.where(col < 0, (col * c(repetition_penalty)).to(T), (col / c(repetition_penalty)).to(T))
+    if presence_penalty is not None and presence_penalty != 0:
+        for t in dict.fromkeys(toks[-presence_context_size:]):
+            x[:, t] = (x[:, t] - c(presence_penalty)).to(T)
+    if frequency_penalty is not None and frequency_penalty != 0:
+        for t in toks[-frequency_context_size:]:
+            x[:, t] = (x[:, t] - c(frequency_penalty)).to(T)
+    return x
+
+
 def hash_uniform(seed: int, step: int, row: int, idx: np.ndarray) -> np.ndarray:
     """Counter-based uniform in (0,1) used by OUR categorical sampler (the MLX
     RNG stream, sample_utils.py:385-387 mx.random.categorical, is not

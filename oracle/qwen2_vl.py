@@ -415,7 +415,7 @@ def get_input_embeddings(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_t
 # generate_step, greedy (generate/ar.py:151-515)
 # --------------------------------------------------------------------------
 def generate_greedy(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_thw=None,
-                    max_tokens: int = 16, rope_mode: str = "fused", return_logits: bool = False):
+                    max_tokens: int = 16, rope_mode: str = "fused", return_logits: bool = False, processors=None):
     """generate_step with temperature 0: embeds -> full-prompt prefill ->
     logits[:, -1] -> logprobs = logits - logsumexp -> argmax -> decode loop with
     pos = cache offset + rope_delta (language.py:476-509)."""
@@ -428,7 +428,10 @@ def generate_greedy(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_thw=No
     logits = lm_head(W, cfg, h)[:, -1, :]
     toks, all_logits = [], []
     delta = int(deltas[0, 0])
+    fed = list(input_ids.reshape(-1))           # ar.py:360-364: `tokens` = the prompt, then every token fed back
     for n in range(max_tokens):
+        if processors:
+            logits = ops.apply_logits_processors(logits, fed, **processors)
         lp = ops.logprobs_from_logits(logits)
         y = int(ops.argmax_first(lp)[0])
         toks.append(y)
@@ -436,6 +439,7 @@ def generate_greedy(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_thw=No
         if n == max_tokens - 1:
             break
         e = embed_tokens(W, np.array([[y]]))
+        fed.append(y)
         p = cache[0].offset + delta
         pid = torch.full((3, 1, 1), p, dtype=torch.long)
         h = qwen2_model(W, cfg, e, cache, pid, rope_mode)

@@ -295,6 +295,30 @@ def test_fused_mlp_launch_matches_three_launch_layer_at_2b_widths():
     assert base_t == ref_toks
 
 
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_generate_step_with_penalties_matches_oracle(tiny, use_graph):
+    """repetition / presence / frequency penalties + logit_bias through generate_step (device-side logits pass inside the
+    captured step, history = prompt + fed tokens) against the oracle's restatement of ar.py:360-364 - the tiny model's
+    greedy fixed point is broken up by the penalties, so the token stream is not degenerate."""
+    from mlx_vlm_amd.generate import generate_step
+
+    cfg, W, model = tiny
+    ids = np.random.default_rng(61).integers(3, 1000, (1, 19))
+    kw = dict(repetition_penalty=1.4, repetition_context_size=16, presence_penalty=0.6, frequency_penalty=0.3,
+              logit_bias={7: 1.5, 11: -2.0})
+    n_new = 30
+    ref_toks, ref_logits = oq.generate_greedy(W, cfg, ids, max_tokens=n_new, return_logits=True,
+                                              processors=dict(logit_bias=kw["logit_bias"], repetition_penalty=1.4,
+                                                              repetition_context_size=16, presence_penalty=0.6,
+                                                              frequency_penalty=0.3))
+    toks = [t for t, _ in generate_step(ids, model, None, None, max_tokens=n_new, temperature=0.0, use_graph=use_graph, **kw)]
+    assert len(set(ref_toks)) > 5                      # the penalties do break the fixed point
+    ok, n, margin = _tie_aware_equal(toks, ref_toks, ref_logits, tol=3e-2)
+    assert ok, (toks, ref_toks, n, margin)
+    plain = [t for t, _ in generate_step(ids, model, None, None, max_tokens=n_new, temperature=0.0)]
+    assert plain != toks
+
+
 def test_sampling_temperature_reproducible_and_varied(tiny):
     from mlx_vlm_amd.generate import generate_step
 

@@ -652,3 +652,49 @@ def test_sample_greedy_advance_equals_sample_plus_advance_plus_gather(vops, B, V
         for k in ("ctx", "pos", "step", "ring"):
             assert torch.equal(a[k], b[k]), (it, k)
     assert int(a["step"][0]) == 6
+
+
+def test_logit_penalties_kernel_bit_exact_vs_oracle_and_reference_golden(vops):
+    """vlm_apply_logit_penalties (bias -> repetition -> presence -> frequency over the device token history) against the
+    oracle on the reference-generated cases (bit-exact bf16), then the push path: tokens appended one by one, ring
+    wrap-around included, equal to the oracle on the growing history."""
+    import os
+
+    from mlx_vlm_amd import _lib
+    from mlx_vlm_amd.sample_utils import HIST_CAP
+
+    P = np.load(os.path.join(os.path.dirname(__file__), "golden", "penalties_ref.npz"))
+    dev = "cuda"
+    for ci in range(int(P["n_cases"])):
+        g = lambda k: P[f"case{ci}.{k}"]                                      # noqa: E731
+        f = lambda k: 0.0 if np.isnan(g(k)) else float(g(k))                   # noqa: E731
+        toks = g("tokens")
+        x = torch.from_numpy(g("logits_bf16_as_f32")).to(BF).to(dev)
+        B = x.shape[0]
+        hist = torch.zeros(B, HIST_CAP, dtype=torch.int32, device=dev)
+        hist[:, :len(toks)] = torch.from_numpy(toks.astype(np.int32)).to(dev)
+        hlen = torch.full((B,), len(toks), dtype=torch.int32, device=dev)
+        bi = torch.from_numpy(g("bias_idx").astype(np.int32)).to(dev)
+        bv = torch.from_numpy(g("bias_val").astype(np.float32)).to(dev)
+        pa = _lib.PenaltyArgs(hist.data_ptr(), hlen.data_ptr(), HIST_CAP, f("rep"), int(g("rep_ctx")), f("pres"),
+                              int(g("pres_ctx")), f("freq"), int(g("freq_ctx")), bi.data_ptr() if len(bi) else None,
+                              bv.data_ptr() if len(bv) else None, len(bi))
+        vops.apply_logit_penalties(x, pa)
+        assert torch.equal(x.cpu(), torch.from_numpy(g("out_bf16_as_f32")).to(BF)), ci
+    # push path with wrap-around: cap 256, 300 pushes
+    rng = np.random.default_rng(3)
+    V = 500
+    hist = torch.zeros(1, HIST_CAP, dtype=torch.int32, device=dev)
+    hlen = torch.zeros(1, dtype=torch.int32, device=dev)
+    pa = _lib.PenaltyArgs(hist.data_ptr(), hlen.data_ptr(), HIST_CAP, 1.25, 40, 0.5, 256, 0.125, 7, None, None, 0)
+    fed = []
+    for step in range(300):
+        t = int(rng.integers(0, 30))
+        fed.append(t)
+        logits = (torch.randn(1, V) * 2).to(BF)
+        ref = O.apply_logits_processors(logits, fed, None, 1.25, 40, 0.5, 256, 0.125, 7)
+        x = logits.to(dev)
+        vops.apply_logit_penalties(x, pa, push_tok=torch.tensor([t], dtype=torch.int32, device=dev))
+        if step % 23 == 0 or step > 290:
+            assert torch.equal(x.cpu(), ref), step
+    assert int(hlen[0]) == 300

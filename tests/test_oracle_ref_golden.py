@@ -238,3 +238,18 @@ def test_streaming_detokenizer_matches_reference():
     segs.append(det.last_segment)
     assert segs == [str(x) for x in R["detok.ref_segments"]]
     assert det.text == str(R["detok.ref_text"][0])
+
+
+def test_logits_processors_match_reference_make_logits_processors():
+    """oracle/ops.py::apply_logits_processors against the reference's own make_logits_processors (sample_utils.py:92-146)
+    run over the shim (tests/golden/make_golden_penalties.py): logit_bias, repetition / presence / frequency penalties
+    with windows full of repeats, two rows - bit-exact bf16."""
+    P = np.load(os.path.join(os.path.dirname(__file__), "golden", "penalties_ref.npz"))
+    for ci in range(int(P["n_cases"])):
+        g = lambda k: P[f"case{ci}.{k}"]                                      # noqa: E731
+        f = lambda k: None if np.isnan(g(k)) else float(g(k))                  # noqa: E731
+        bias = dict(zip(g("bias_idx").tolist(), g("bias_val").tolist())) or None
+        x = torch.from_numpy(g("logits_bf16_as_f32")).to(torch.bfloat16)
+        y = ops.apply_logits_processors(x, g("tokens"), bias, f("rep"), int(g("rep_ctx")), f("pres"), int(g("pres_ctx")),
+                                      f("freq"), int(g("freq_ctx")))
+        assert torch.equal(y, torch.from_numpy(g("out_bf16_as_f32")).to(torch.bfloat16)), ci
