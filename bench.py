@@ -261,7 +261,7 @@ def _hf_cpu_baseline(cfg, threads, ctx, n_tok):
         eos_token_id=1, pad_token_id=2)
     t0 = time.perf_counter()
     with torch.no_grad():
-        m = Qwen2VLForConditionalGeneration(hcfg).eval().to(torch.float32)
+        m = Qwen2VLForConditionalGeneration(hcfg).eval().to(torch.float32)     # HF's own random initialisation
         setup = time.perf_counter() - t0
         ids = torch.randint(3, min(t.vocab_size, 151643) - 8, (1, ctx))
         out = m(input_ids=ids, use_cache=True)
