@@ -48,6 +48,15 @@ int vlm_abi_version(void);
 int vlm_gemm_bf16(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
                   int lda, int ldw, int ldc, int ldres, int epilogue, void* stream);
 
+/* The qkv projection of the vision attention with apply_rotary_pos_emb_vision (vision.py:35-50,141-142) as its epilogue:
+ * C = rope2d(A . W^T + bias) on the first rope_cols columns (the q and k heads, head_dim wide), plain bias on the rest.
+ * W's q / k rows must be INTERLEAVED per head - row (h, d) of the checkpoint at h * head_dim + 2 d, row (h, d + hd/2) at
+ * h * head_dim + 2 d + 1 (q.k is invariant under a common permutation of the head dimension) - so that a rotation pair
+ * is two adjacent outputs.  cos_sin: fp32 [2][M][head_dim / 2]: cos rows then sin rows of VisionModel.rot_pos_emb
+ * (vision.py:219-255).  Rounding as the reference: bf16(linear + bias), fp32 rotation, one rounding. */
+int vlm_gemm_bf16_rope2d(const void* A, const void* W, const void* bias, const void* cos_sin, void* C, int M, int N, int K,
+                         int lda, int ldw, int ldc, int head_dim, int rope_cols, void* stream);
+
 /* test / A-B knob for vlm_gemm_bf16 kernel selection: 0 = automatic (LDS-DMA staging when K % 64 == 0; the phased
  * 256x256 kernel from ~120 tiles up), 1 = 128x128 kernel with global -> VGPR -> LDS staging, 2 = 128x128 kernel with
  * LDS-DMA staging, 3 = 256x256 phased kernel whenever legal (K % 64 == 0, K >= 128, no SwiGLU), 4 = its 2-phase
@@ -101,6 +110,14 @@ int vlm_mrope_kvwrite(void* qkv, int ld, int T, int Hq, int Hkv, int D, const vo
                       const void* pos_w, const void* inv_freq, int sec0, int sec1, const void* kv_seq,
                       const void* kv_slot, const void* block_table, int max_pages, void* kpool, void* vpool,
                       void* stream);
+
+/* The fetch half of KVCache.update_and_fetch (cache.py:345-367 returns keys / values [..., :offset, :]) over the PAGED
+ * pools: the cached (rotated) k and v of token t - slot kv_slot[t] of sequence kv_seq[t] (NULL: seq = t) - are copied
+ * into the k / v columns of row t of a token-major qkv buffer [T][(Hq + 2 Hkv) * D] (the q columns are left alone).
+ * Used when a prompt chunk is prefilled onto a non-empty cache (ar.py:426-472 chunked prefill, dispatch.py:861-882
+ * prompt_cache continuation): the chunk attends to [cached tokens | its own]. */
+int vlm_kv_gather(void* qkv, int ld, int T, int Hq, int Hkv, int D, const void* kv_seq, const void* kv_slot,
+                  const void* block_table, int max_pages, const void* kpool, const void* vpool, void* stream);
 
 /* mx.fast.scaled_dot_product_attention on the prefill path: varlen segments (cu_seqlens int32
  * [nseg+1]), mask=None (vision.py:148-158) or mask="causal" (base.py:214-228,366-373), GQA.
@@ -295,6 +312,9 @@ int vlm_llm_fused_error(void* handle);
 typedef struct vlm_vit_config {
   int depth, embed_dim, n_heads, mlp_hidden, patch_k /* padded K of the patch GEMM */, merge /* 2 */, out_dim;
   float ln_eps;
+  int qk_interleaved; /* 1: the q / k rows of every wqkv / bqkv are interleaved per head (vlm_gemm_bf16_rope2d) and
+                         cos_tab / sin_tab of vlm_vit_args are ONE table (sin_tab == cos_tab + N * head_dim / 2): the 2-D
+                         rope runs in the qkv GEMM epilogue instead of a pass of its own */
 } vlm_vit_config;
 
 typedef struct vlm_vit_block {

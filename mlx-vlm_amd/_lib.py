@@ -58,7 +58,7 @@ class DecodeArgs(C.Structure):
 
 class VitConfig(C.Structure):
     _fields_ = [("depth", c_int), ("embed_dim", c_int), ("n_heads", c_int), ("mlp_hidden", c_int), ("patch_k", c_int),
-                ("merge", c_int), ("out_dim", c_int), ("ln_eps", c_float)]
+                ("merge", c_int), ("out_dim", c_int), ("ln_eps", c_float), ("qk_interleaved", c_int)]
 
 
 class VitBlock(C.Structure):
@@ -85,6 +85,7 @@ P = C.POINTER
 SIGNATURES = {
     "vlm_abi_version": (c_int, []),
     "vlm_gemm_bf16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    "vlm_gemm_bf16_rope2d": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     "vlm_gemm_set_staging": (c_int, [c_int]),
     "vlm_gemv_bf16": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_float, c_int, c_void_p]),
     "vlm_gemv_qkv_rope_kvwrite": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p] + [c_int] * 6
@@ -95,6 +96,7 @@ SIGNATURES = {
     "vlm_rope2d_vision": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "vlm_mrope_kvwrite": (c_int, [c_void_p] + [c_int] * 5 + [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 3 + [c_int]
                           + [c_void_p] * 3),
+    "vlm_kv_gather": (c_int, [c_void_p] + [c_int] * 5 + [c_void_p] * 3 + [c_int] + [c_void_p] * 3),
     "vlm_attn_prefill": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] + [c_int] * 5 + [c_float, c_int, c_void_p]),
     "vlm_attn_decode_paged": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 5
                               + [c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

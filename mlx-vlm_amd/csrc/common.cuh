@@ -107,4 +107,28 @@ __host__ __device__ __forceinline__ int vlm_vslot(int within) {
   return (within & 32) + 8 * ((kk & 15) >> 2) + 4 * (kk >> 4) + (kk & 3);
 }
 
+// Internal GEMM epilogue id: 2-D rotary embedding of the vision attention fused into the qkv projection
+// (apply_rotary_pos_emb_vision, reference mlx_vlm/models/qwen2_vl/vision.py:35-50,141-142).  The rotation pairs
+// element d with d + hd/2 of a head; the checkpoint's q / k rows are INTERLEAVED at load ((d, d + hd/2) -> columns
+// (2j, 2j + 1); q.k is invariant under a common permutation of the head dimension), so a pair sits in one 16-byte store
+// chunk of the epilogue.  Conventions inside the GEMM launch chain: `res` = fp32 table [2][M][hd/2] (cos rows, then sin
+// rows), `ldres` = hd | rope_cols << 12 (columns n < rope_cols are q / k heads).
+#define VLM_EPI_ROPE2D 32
+__device__ __forceinline__ uint4 vlm_rope2d_chunk(uint4 u, const void* table, int M, int m, int n, int packed) {
+  const int hd = packed & 0xfff, rope_cols = packed >> 12;
+  if (n >= rope_cols) return u;
+  const int half = hd >> 1, p0 = (n % hd) >> 1;
+  const float* t = static_cast<const float*>(table);
+  const float4 c = *reinterpret_cast<const float4*>(t + (size_t)m * half + p0);
+  const float4 s = *reinterpret_cast<const float4*>(t + ((size_t)M + m) * half + p0);
+  // x is the bf16-rounded linear output (bias included); fp32 rotation, one rounding (vision.py:46-50)
+  const float a0 = bf_lo(u.x), b0 = bf_hi(u.x), a1 = bf_lo(u.y), b1 = bf_hi(u.y);
+  const float a2 = bf_lo(u.z), b2 = bf_hi(u.z), a3 = bf_lo(u.w), b3 = bf_hi(u.w);
+  u.x = pack_bf2(a0 * c.x - b0 * s.x, b0 * c.x + a0 * s.x);
+  u.y = pack_bf2(a1 * c.y - b1 * s.y, b1 * c.y + a1 * s.y);
+  u.z = pack_bf2(a2 * c.z - b2 * s.z, b2 * c.z + a2 * s.z);
+  u.w = pack_bf2(a3 * c.w - b3 * s.w, b3 * c.w + a3 * s.w);
+  return u;
+}
+
 static inline int vlm_cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -575,8 +575,14 @@ extern "C" int vlm_vit_forward(void* handle, const vlm_vit_args* a, void* stream
   for (int i = 0; i < c.depth; ++i) {
     const vlm_vit_block& w = v->blocks[i];
     TRY(vlm_layernorm(a->x, w.ln1_w, w.ln1_b, a->xn, N, E, c.ln_eps, stream));
-    TRY(vlm_gemm_bf16(a->xn, w.wqkv, w.bqkv, nullptr, a->qkv, N, 3 * E, E, E, E, 3 * E, 0, VLM_EPI_BIAS, stream));
-    TRY(vlm_rope2d_vision(a->qkv, a->cos_tab, a->sin_tab, N, H, hd, 3 * E, stream));
+    if (c.qk_interleaved && a->sin_tab == off(const_cast<void*>(a->cos_tab), (size_t)N * (hd / 2) * sizeof(float))) {
+      // 2-D rope in the GEMM epilogue (one HBM pass less per block)
+      TRY(vlm_gemm_bf16_rope2d(a->xn, w.wqkv, w.bqkv, a->cos_tab, a->qkv, N, 3 * E, E, E, E, 3 * E, hd, 2 * E, stream));
+    } else {
+      if (c.qk_interleaved) return 1;     // interleaved weights need the fused form
+      TRY(vlm_gemm_bf16(a->xn, w.wqkv, w.bqkv, nullptr, a->qkv, N, 3 * E, E, E, E, 3 * E, 0, VLM_EPI_BIAS, stream));
+      TRY(vlm_rope2d_vision(a->qkv, a->cos_tab, a->sin_tab, N, H, hd, 3 * E, stream));
+    }
     TRY(vlm_attn_prefill(a->qkv, off(a->qkv, (size_t)E * 2), off(a->qkv, (size_t)2 * E * 2), a->attn, 3 * E, 3 * E, 3 * E, E,
                          a->cu_seqlens, a->nseg, a->total_qblocks, H, H, hd, scale, a->uniform_segments ? 2 : 0, stream));
     TRY(vlm_gemm_bf16(a->attn, w.wproj, w.bproj, a->x, a->x, N, E, E, E, E, E, E, VLM_EPI_BIAS | VLM_EPI_RESIDUAL, stream));

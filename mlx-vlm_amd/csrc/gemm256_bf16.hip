@@ -104,6 +104,7 @@ __device__ __forceinline__ void epilogue256(f32x4_t (&acc)[8][NF], char* smem, c
     const int m = m0 + row, n = n0o + cc * 8;
     if (m < M && n < n_out) {
       uint4 u = *reinterpret_cast<const uint4*>(cs + row * C_LDN + cc * 8);
+      if (EPI & VLM_EPI_ROPE2D) u = vlm_rope2d_chunk(u, res, M, m, n, ldres);
       if (EPI & VLM_EPI_RESIDUAL) {
         const uint4 r = *reinterpret_cast<const uint4*>(res + (size_t)m * ldres + n);
         u.x = pack_bf2(bf_lo(u.x) + bf_lo(r.x), bf_hi(u.x) + bf_hi(r.x));
@@ -765,6 +766,9 @@ int vlm_gemm256_try(const void* A, const void* W, const void* bias, const void* 
   switch (epilogue) {
     case VLM_EPI_NONE: return launch256<VLM_EPI_NONE>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
     case VLM_EPI_BIAS: return launch256<VLM_EPI_BIAS>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
+    case VLM_EPI_BIAS | VLM_EPI_ROPE2D:
+      if (g_persist) return -1;          // the persistent variant has its own chunked epilogue (no rope form)
+      return launch256<VLM_EPI_BIAS | VLM_EPI_ROPE2D>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
     case VLM_EPI_BIAS | VLM_EPI_GELU_FAST:
       return launch256<VLM_EPI_BIAS | VLM_EPI_GELU_FAST>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
     case VLM_EPI_BIAS | VLM_EPI_GELU_ERF:

@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
       const int m = m0 + row, n = n0o + cc * 8;
       if (m < M && n < n_out) {
         uint4 u = *reinterpret_cast<const uint4*>(cs + row * C_LD + cc * 8);
+        if (EPI & VLM_EPI_ROPE2D) u = vlm_rope2d_chunk(u, res, M, m, n, ldres);
         if (EPI & VLM_EPI_RESIDUAL) {
           const uint4 r = *reinterpret_cast<const uint4*>(res + (size_t)m * ldres + n);
           u.x = pack_bf2(bf_lo(u.x) + bf_lo(r.x), bf_hi(u.x) + bf_hi(r.x));
@@ -412,7 +413,7 @@ int launch_epi(const void* A, const void* W, const void* bias, const void* res, 
   const bool glds = (K % BK == 0) && !g_force_regstage;
   // split-K: few 64x64 tiles and a long K (LLM down projection at prompt length: 168 tiles x 140 K tiles, measured
   // 106 TF) -> enough (tile, K range) workgroups to fill the chip, fp32 partials summed by splitk_reduce_kernel
-  if (glds && !(EPI & VLM_EPI_SWIGLU) && g_splitk >= 0 && N % 8 == 0) {
+  if (glds && !(EPI & (VLM_EPI_SWIGLU | VLM_EPI_ROPE2D)) && g_splitk >= 0 && N % 8 == 0) {
     const long t64 = (long)vlm_cdiv(M, 64) * vlm_cdiv(N, 64);
     int splits = g_splitk > 1 ? g_splitk : 0;
     if (!splits && t64 < 256 && K >= 2048) splits = (int)std::min<long>(8, std::max<long>(2, (512 + t64 - 1) / t64));
@@ -454,8 +455,26 @@ extern "C" int vlm_gemm_set_staging(int mode) {
   return VLM_OK;
 }
 
+static int gemm_dispatch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
+                         int lda, int ldw, int ldc, int ldres, int epilogue, void* stream);
+
 extern "C" int vlm_gemm_bf16(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N,
                              int K, int lda, int ldw, int ldc, int ldres, int epilogue, void* stream) {
+  if (epilogue & ~(VLM_EPI_BIAS | VLM_EPI_GELU_FAST | VLM_EPI_GELU_ERF | VLM_EPI_RESIDUAL | VLM_EPI_SWIGLU)) return VLM_ERR_ARG;
+  return gemm_dispatch(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, epilogue, stream);
+}
+
+extern "C" int vlm_gemm_bf16_rope2d(const void* A, const void* W, const void* bias, const void* cos_sin, void* C, int M,
+                                    int N, int K, int lda, int ldw, int ldc, int head_dim, int rope_cols, void* stream) {
+  if (!cos_sin || !bias || head_dim <= 0 || head_dim > 4095 || head_dim % 16 != 0 || rope_cols < 0 || rope_cols > N ||
+      rope_cols % head_dim != 0)
+    return VLM_ERR_ARG;
+  return gemm_dispatch(A, W, bias, cos_sin, C, M, N, K, lda, ldw, ldc, head_dim | (rope_cols << 12),
+                       VLM_EPI_BIAS | VLM_EPI_ROPE2D, stream);
+}
+
+static int gemm_dispatch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
+                         int lda, int ldw, int ldc, int ldres, int epilogue, void* stream) {
   if (!A || !W || !C || M < 0 || N <= 0 || K <= 0) return VLM_ERR_ARG;
   if ((epilogue & VLM_EPI_BIAS) && !bias) return VLM_ERR_ARG;
   if ((epilogue & VLM_EPI_RESIDUAL) && !res) return VLM_ERR_ARG;
@@ -480,6 +499,7 @@ extern "C" int vlm_gemm_bf16(const void* A, const void* W, const void* bias, con
   switch (epilogue) {
     case VLM_EPI_NONE: GO(VLM_EPI_NONE);
     case VLM_EPI_BIAS: GO(VLM_EPI_BIAS);
+    case VLM_EPI_BIAS | VLM_EPI_ROPE2D: GO(VLM_EPI_BIAS | VLM_EPI_ROPE2D);
     case VLM_EPI_BIAS | VLM_EPI_GELU_FAST: GO(VLM_EPI_BIAS | VLM_EPI_GELU_FAST);
     case VLM_EPI_BIAS | VLM_EPI_GELU_ERF: GO(VLM_EPI_BIAS | VLM_EPI_GELU_ERF);
     case VLM_EPI_BIAS | VLM_EPI_RESIDUAL: GO(VLM_EPI_BIAS | VLM_EPI_RESIDUAL);

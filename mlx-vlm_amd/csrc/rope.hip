@@ -124,7 +124,52 @@ __global__ __launch_bounds__(256) void mrope_kvwrite_kernel(
   }
 }
 
+// the fetch half of KVCache.update_and_fetch (reference cache.py:345-367: `return self.keys[..., :offset, :], ...`) for a
+// PAGED cache: token t's cached (already rotated) k and v rows -> the k / v columns of row t of a token-major qkv buffer
+__global__ __launch_bounds__(256) void kv_gather_kernel(bf16_t* __restrict__ qkv, int ld, int T, int Hq, int Hkv, int D,
+                                                        const int* __restrict__ kv_seq, const int* __restrict__ kv_slot,
+                                                        const int* __restrict__ block_table, int max_pages,
+                                                        const bf16_t* __restrict__ kpool, const bf16_t* __restrict__ vpool) {
+  const int cpd = D >> 3, per_tok = 2 * Hkv * cpd;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)T * per_tok) return;
+  const int tok = (int)(idx / per_tok);
+  int it = (int)(idx % per_tok);
+  const bool is_v = it >= Hkv * cpd;
+  if (is_v) it -= Hkv * cpd;
+  const int g = it / cpd, c = it % cpd;
+  const int seq = kv_seq ? kv_seq[tok] : tok, slot = kv_slot[tok];
+  const size_t page = (size_t)block_table[(size_t)seq * max_pages + (slot >> 6)];
+  const int within = slot & 63;
+  bf16_t* row = qkv + (size_t)tok * ld;
+  if (!is_v) {
+    const uint4 k = *reinterpret_cast<const uint4*>(kpool + (((page * Hkv + g) * (size_t)cpd + c) * 64 + within) * 8);
+    *reinterpret_cast<uint4*>(row + (size_t)(Hq + g) * D + c * 8) = k;
+  } else {
+    const bf16_t* vb = vpool + ((page * Hkv + g) * (size_t)D + c * 8) * 64 + vlm_vslot(within);
+    uint4 v;
+    v.x = (uint32_t)vb[0 * 64] | ((uint32_t)vb[1 * 64] << 16);
+    v.y = (uint32_t)vb[2 * 64] | ((uint32_t)vb[3 * 64] << 16);
+    v.z = (uint32_t)vb[4 * 64] | ((uint32_t)vb[5 * 64] << 16);
+    v.w = (uint32_t)vb[6 * 64] | ((uint32_t)vb[7 * 64] << 16);
+    *reinterpret_cast<uint4*>(row + (size_t)(Hq + Hkv + g) * D + c * 8) = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int vlm_kv_gather(void* qkv, int ld, int T, int Hq, int Hkv, int D, const void* kv_seq, const void* kv_slot,
+                             const void* block_table, int max_pages, const void* kpool, const void* vpool, void* stream) {
+  if (!qkv || !kv_slot || !block_table || !kpool || !vpool || T < 0 || Hq < 0 || Hkv <= 0 || max_pages <= 0) return VLM_ERR_ARG;
+  if (D % 8 != 0 || ld % 8 != 0) return VLM_ERR_SHAPE;
+  if (T == 0) return VLM_OK;
+  const long total = (long)T * 2 * Hkv * (D / 8);
+  hipLaunchKernelGGL(kv_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv,
+                     ld, T, Hq, Hkv, D, (const int*)kv_seq, (const int*)kv_slot, (const int*)block_table, max_pages,
+                     (const bf16_t*)kpool, (const bf16_t*)vpool);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
 
 extern "C" int vlm_rope2d_vision(void* qkv, const void* cos_tab, const void* sin_tab, int N, int H, int D, int ld,
                                  void* stream) {

@@ -361,9 +361,8 @@ class LanguageModel:
         T, D = inputs_embeds.shape
         hd, Hq, Hkv = self.head_dim, t.num_attention_heads, t.num_key_value_heads
         seqs = [c[0]._seq for c in caches]
-        for s in seqs:
-            if s.offset != 0:
-                raise NotImplementedError("prefill onto a non-empty cache (prefix reuse / chunked prefill) is not built yet")
+        if any(s.offset != 0 for s in seqs):
+            return self._prefill_onto_cache(inputs_embeds, position_ids, caches, lengths, logits_rows, reserve_extra)
         cu = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
         kv_seq = np.concatenate([np.full(n, s.seq, dtype=np.int32) for n, s in zip(lengths, seqs)])
         kv_slot = np.concatenate([np.arange(n, dtype=np.int32) for n in lengths])
@@ -400,6 +399,95 @@ class LanguageModel:
             s.offset += n
         self._keep = (h, xn, qkv, attn, act, xlast, pos_d, meta, rows_d)  # keep alive until the stream has run
         return logits
+
+    def _prefill_onto_cache(self, inputs_embeds, position_ids, caches, lengths, logits_rows, reserve_extra):
+        """A prompt chunk appended to a NON-EMPTY cache: chunked prefill (reference ar.py:426-472) and `prompt_cache=`
+        continuation across calls, i.e. multi-turn (dispatch.py:861-882, common.py:243-263).  The chunk's queries attend
+        to [cached tokens | the chunk] (cache.py:345-367 + base.py:366-373 with the causal mask offset by the cache
+        length).  Rare path, kept simple: the layer loop runs here over the C-ABI operators; per layer the cached k / v
+        rows are fetched back into a full-length token-major buffer (vlm_kv_gather) and the varlen causal attention runs
+        over the whole sequence - the prefix rows carry zero queries and their outputs are dropped."""
+        t, dev = self.args, self.device
+        hd, Hq, Hkv = self.head_dim, t.num_attention_heads, t.num_key_value_heads
+        D, QKV = t.hidden_size, (Hq + 2 * Hkv) * self.head_dim
+        seqs = [c[0]._seq for c in caches]
+        offs = [int(s.offset) for s in seqs]
+        for n, s in zip(lengths, seqs):
+            s.reserve(s.offset + n + reserve_extra)
+        pool = self.pool
+        bt = pool.block_table
+        bf, i32 = torch.bfloat16, torch.int32
+        T = int(sum(lengths))
+        tot = [o + n for o, n in zip(offs, lengths)]
+        cu_full = np.concatenate([[0], np.cumsum(tot)]).astype(np.int32)
+        Tf = int(cu_full[-1])
+        # rows of the full-length buffer: per sequence [prefix | chunk]
+        new_rows = np.concatenate([np.arange(cu_full[i] + offs[i], cu_full[i + 1]) for i in range(len(seqs))]).astype(np.int64)
+        old_rows = np.concatenate([np.arange(cu_full[i], cu_full[i] + offs[i]) for i in range(len(seqs))]).astype(np.int64)
+        full_seq = np.concatenate([np.full(tot[i], seqs[i].seq, np.int32) for i in range(len(seqs))])
+        full_slot = np.concatenate([np.arange(tot[i], dtype=np.int32) for i in range(len(seqs))])
+        pos = np.ascontiguousarray(position_ids, dtype=np.int32)
+        pos_d = _lib.h2d(pos, dev)
+        new_rows_d, old_rows_d = _lib.h2d(new_rows, dev), _lib.h2d(old_rows, dev)
+        seq_d, slot_d, cu_d = _lib.h2d(full_seq, dev), _lib.h2d(full_slot, dev), _lib.h2d(cu_full, dev)
+        new_seq_d, new_slot_d = seq_d[new_rows_d], slot_d[new_rows_d]
+        old_seq_d, old_slot_d = seq_d[old_rows_d].contiguous(), slot_d[old_rows_d].contiguous()
+        nqb = int(sum((n + 127) // 128 for n in tot))
+        scale = float(getattr(t, "attn_scale", 0.0) or 0.0) or hd ** -0.5
+        h = inputs_embeds.contiguous().clone()
+        sec = self.mrope_section
+        for i in range(t.num_hidden_layers):
+            w = self._w
+            kp, vp = pool.layer_pools(i)
+            xn = ops.rmsnorm(h, w[f"{i}.ln1"], t.rms_norm_eps)
+            qkv = ops.gemm(xn, w[f"{i}.wqkv"], bias=w[f"{i}.bqkv"], epilogue=ops.EPI_BIAS)
+            ops.mrope_kvwrite_(qkv, Hq, Hkv, hd, pos_d[0], pos_d[1], pos_d[2], w["inv_freq"], int(sec[0]), int(sec[1]),
+                               kv_seq=new_seq_d.contiguous(), kv_slot=new_slot_d.contiguous(), block_table=bt, kpool=kp, vpool=vp)
+            full = torch.zeros(Tf, QKV, dtype=bf, device=dev)
+            full[new_rows_d] = qkv
+            if old_rows.size:
+                prefix = torch.zeros(old_rows.size, QKV, dtype=bf, device=dev)
+                ops.kv_gather_(prefix, Hq, Hkv, hd, old_slot_d, bt, kp, vp, kv_seq=old_seq_d)
+                full[old_rows_d] = prefix
+            attn = ops.attn_prefill(full, full[:, Hq * hd:], full[:, (Hq + Hkv) * hd:], cu_d, nqb, Hq, Hkv, hd, scale, True)
+            h = ops.gemm(attn[new_rows_d].contiguous(), w[f"{i}.wo"], res=h, epilogue=ops.EPI_RESIDUAL)
+            xn = ops.rmsnorm(h, w[f"{i}.ln2"], t.rms_norm_eps)
+            act = ops.gemm(xn, w[f"{i}.wgu"], epilogue=ops.EPI_SWIGLU)
+            h = ops.gemm(act, w[f"{i}.wdown"], res=h, epilogue=ops.EPI_RESIDUAL)
+        cu_new = np.concatenate([[0], np.cumsum(lengths)])
+        rows = (cu_new[1:] - 1) if logits_rows == "last" else np.arange(T)
+        xl = ops.rmsnorm(h[_lib.h2d(rows.astype(np.int64), dev)].contiguous(), w["norm"], t.rms_norm_eps)
+        logits = ops.gemm(xl, w["head"])
+        for n, s in zip(lengths, seqs):
+            s.offset += n
+        return logits
+
+    # ------------------------------------------------------------------ fused_greedy_decode (reference hook)
+    def supports_fused_greedy_logits_processors(self, processors) -> bool:
+        """reference ar.py:1023-1031: Python logits processors cannot run inside the captured step"""
+        return False
+
+    def fused_greedy_decode(self, inputs, cache=None, **kwargs):
+        """The reference's plug point for a native greedy decode step (generate/ar.py:1015-1042: GenerationBatch calls
+        `language_model.fused_greedy_decode(inputs[:, None], cache=prompt_cache, **fwd_kwargs)` and falls back to the
+        module call when it returns None): feed one token per row, run the whole step on the device - layers, lm_head,
+        log-softmax, argmax, cache / position advance - and return the sampled token ids [B] without a host round trip.
+        Returns None (= fall back) for anything the captured step does not cover."""
+        if cache is None or kwargs.get("logits_processors"):
+            return None
+        ids = _to_np(inputs).reshape(-1)
+        B = int(ids.size)
+        caches = [cache] if isinstance(cache[0], KVCache) else cache
+        if B not in (1, 2, 4, 8) or len(caches) != B or any(c[0].offset == 0 for c in caches):
+            return None
+        deltas = self._rope_deltas if self._rope_deltas is not None else np.zeros((B, 1), dtype=np.int64)
+        deltas = np.broadcast_to(np.asarray(deltas).reshape(-1, 1), (B, 1)) if np.asarray(deltas).size == 1 else np.asarray(deltas)
+        try:
+            st = self.decode_begin(caches, ids, deltas[:B], max_new_tokens=1)
+        except RuntimeError:          # rows not on consecutive block-table rows: let the caller use the module call
+            return None
+        self.decode_run(st, 1, dict(temperature=0.0, top_p=1.0, min_p=0.0, top_k=0, seed=0))
+        return st.tok[:B].clone()
 
     # ------------------------------------------------------------------ decode
     def decode_state(self, B: int) -> DecodeState:

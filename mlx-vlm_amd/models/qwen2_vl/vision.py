@@ -88,14 +88,28 @@ class VisionModel:
         wp[:, : self.patch_dim] = pw.to(device=dev, dtype=torch.bfloat16)
         self._w["patch"] = wp
 
+        # 2-D rope in the qkv GEMM epilogue (vlm_gemm_bf16_rope2d): the q / k rows of every block are interleaved per head
+        # at load, (d, d + hd/2) -> (2d, 2d + 1).  q.k does not change under a common permutation of the head dimension,
+        # v and everything downstream are untouched.  VLM_VIT_ROPE_FUSED=0: separate rope pass (A/B knob).
+        import os
+        self.rope_fused = os.environ.get("VLM_VIT_ROPE_FUSED", "1") != "0" and self.head_dim % 16 == 0
         cfg = _lib.VitConfig(c.depth, c.embed_dim, c.num_heads, self.mlp_hidden, self.patch_k, c.spatial_merge_size,
-                             c.hidden_size, float(c.layer_norm_eps) if hasattr(c, "layer_norm_eps") else 1e-6)
+                             c.hidden_size, float(c.layer_norm_eps) if hasattr(c, "layer_norm_eps") else 1e-6,
+                             int(self.rope_fused))
         cfg.ln_eps = 1e-6  # nn.LayerNorm(eps=1e-6) is hard-coded in the reference (vision.py:109,180-181)
+        E, hd, half = c.embed_dim, self.head_dim, self.head_dim // 2
+        inter = torch.stack([torch.arange(half), torch.arange(half) + half], dim=1).reshape(-1)          # 0, hd/2, 1, hd/2+1, ...
+        perm = (torch.arange(2 * c.num_heads)[:, None] * hd + inter[None, :]).reshape(-1)                   # q and k heads
+        self._qk_perm = torch.cat([perm, torch.arange(2 * E, 3 * E)])
         h = C.c_void_p()
         check(L.vlm_vit_create(C.byref(cfg), C.byref(h)), "vit_create")
         self._handle = h
         for i in range(c.depth):
             p = f"blocks.{i}."
+            if self.rope_fused:
+                W = dict(W)
+                for n in ("attn.qkv.weight", "attn.qkv.bias"):
+                    W[p + n] = W[p + n][self._qk_perm.to(W[p + n].device)]
             blk = _lib.VitBlock(*[g(p + n).data_ptr() for n in (
                 "norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
                 "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")])
@@ -132,8 +146,8 @@ class VisionModel:
                 lens += [h * w] * t
             cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
             nqb = int(sum((l + 127) // 128 for l in lens))
-            hit = (_lib.h2d(torch.cos(freqs), self.device), _lib.h2d(torch.sin(freqs), self.device),
-                   _lib.h2d(cu, self.device), len(lens), nqb, int(len(set(lens)) == 1))
+            cs = _lib.h2d(torch.stack([torch.cos(freqs), torch.sin(freqs)]).contiguous(), self.device)   # ONE table
+            hit = (cs[0], cs[1], _lib.h2d(cu, self.device), len(lens), nqb, int(len(set(lens)) == 1))
             if len(self._tab_cache) > 64:
                 self._tab_cache.clear()
             self._tab_cache[key] = hit

@@ -44,6 +44,19 @@ def gemm(a, w, bias=None, res=None, out=None, epilogue=EPI_NONE):
     return out
 
 
+def gemm_rope2d(a, w, bias, cos_sin, head_dim, rope_cols, out=None):
+    """out = rope2d(a @ w.T + bias) on the first rope_cols columns (q / k heads with interleaved pairs), bias only on the
+    rest (vlm_gemm_bf16_rope2d).  cos_sin fp32 [2, M, head_dim / 2]."""
+    _dev(a, w, bias, cos_sin, out)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    check(_lib.lib().vlm_gemm_bf16_rope2d(_p(a), _p(w), _p(bias), _p(cos_sin), _p(out), M, N, K, a.stride(0), w.stride(0),
+                                          out.stride(0), int(head_dim), int(rope_cols), _stream()), "gemm_rope2d")
+    return out
+
+
 def gemv(x, w, bias=None, res=None, norm_w=None, out=None, eps=1e-6, epilogue=EPI_NONE):
     _dev(x, w, bias, res, norm_w, out)
     M, K = x.shape
@@ -115,6 +128,14 @@ def mrope_kvwrite_(qkv, Hq, Hkv, D, pos_t, pos_h, pos_w, inv_freq, sec0, sec1, k
     check(_lib.lib().vlm_mrope_kvwrite(_p(qkv), qkv.stride(0), T, Hq, Hkv, D, _p(pos_t), _p(pos_h), _p(pos_w),
                                        _p(inv_freq), sec0, sec1, _p(kv_seq), _p(kv_slot), _p(block_table), max_pages,
                                        _p(kpool), _p(vpool), _stream()), "mrope_kvwrite")
+    return qkv
+
+
+def kv_gather_(qkv, Hq, Hkv, D, kv_slot, block_table, kpool, vpool, kv_seq=None):
+    """cached k / v of (kv_seq[t], kv_slot[t]) -> the k / v columns of row t of qkv [T, (Hq + 2 Hkv) * D] (in place)"""
+    _dev(qkv, kv_slot, block_table, kpool, vpool, kv_seq)
+    check(_lib.lib().vlm_kv_gather(_p(qkv), qkv.stride(0), qkv.shape[0], Hq, Hkv, D, _p(kv_seq), _p(kv_slot), _p(block_table),
+                                   block_table.shape[1], _p(kpool), _p(vpool), _stream()), "kv_gather")
     return qkv
 
 

@@ -319,6 +319,65 @@ def test_generate_step_with_penalties_matches_oracle(tiny, use_graph):
     assert plain != toks
 
 
+def test_prefill_onto_non_empty_cache_chunked_and_multi_turn(tiny):
+    """A prompt fed in two chunks (reference ar.py:426-472) and a follow-up turn appended to a `prompt_cache` that already
+    holds prompt + generated tokens (dispatch.py:861-882): the second prefill attends to [cached | new].  Against the
+    oracle's one-shot prefill of the concatenation (last-row logits, 3e-2 rel-rms; cache contents 2e-2) and then decoding
+    on: greedy tokens after the chunked prefill equal those after the one-shot prefill."""
+    cfg, W, model = tiny
+    lm = model.language_model
+    ids, pix, thw = synth_request(cfg, [(56, 84)], n_text=30, seed=70)
+    f = model.get_input_embeddings(ids, torch.from_numpy(pix), image_grid_thw=thw)
+    L = ids.shape[1]
+    cut = L - 17                                                    # the image block lies in the first chunk
+    ref_logits, ref_cache, _ = _oracle_prefill_logits(W, cfg, ids, pix, thw)
+    pos = np.asarray(f.position_ids)
+    cache = lm.make_cache()
+    emb = f.inputs_embeds.reshape(L, -1)
+    lm.prefill(emb[:cut].contiguous(), pos.reshape(3, L)[:, :cut], [cache], [cut], "last")
+    assert cache[0].offset == cut
+    logits = lm.prefill(emb[cut:].contiguous(), pos.reshape(3, L)[:, cut:], [cache], [L - cut], "last")
+    assert cache[0].offset == L
+    assert _rel_rms_err(logits[0], ref_logits[-1]) < 3e-2
+    for layer in (0, cfg.text.num_hidden_layers - 1):
+        k, v = cache[layer].state
+        rk, rv = ref_cache[layer].state
+        assert _rel_rms_err(k, rk) < 2e-2 and _rel_rms_err(v, rv) < 2e-2
+    # one-shot cache of the same prompt: the next decode step's logits agree (the caches are interchangeable)
+    one = lm.make_cache()
+    a = lm.prefill(emb.contiguous(), pos.reshape(3, L), [one], [L], "last")
+    assert _rel_rms_err(logits[0], a[0]) < 1e-2
+    lm._rope_deltas = np.asarray(f.rope_deltas)
+    x = lm(np.array([[77]]), cache=cache).logits[0, -1]
+    y = lm(np.array([[77]]), cache=one).logits[0, -1]
+    assert _rel_rms_err(x, y) < 1e-2
+    cache[0]._seq.release(); one[0]._seq.release()
+
+
+def test_fused_greedy_decode_hook_matches_module_call(tiny):
+    """`language_model.fused_greedy_decode(inputs, cache=)` (the reference's plug point, ar.py:1015-1042): same tokens as
+    the module call + host argmax, B = 1 and B = 2; returns None (= fall back) without a cache or with processors."""
+    cfg, W, model = tiny
+    lm = model.language_model
+    assert lm.fused_greedy_decode(np.array([[5]]), cache=None) is None
+    assert lm.supports_fused_greedy_logits_processors([lambda t, l: l]) is False
+    ids = np.random.default_rng(81).integers(3, 1000, (1, 21))
+    c1, c2 = lm.make_cache(), lm.make_cache()
+    o1 = lm(ids, cache=c1, logits_to_keep=1)
+    lm(ids, cache=c2, logits_to_keep=1)
+    tok = int(O.argmax_first(O.logprobs_from_logits(o1.logits[:, -1].cpu()))[0])
+    a, b = [tok], [tok]
+    for _ in range(6):
+        out = lm(np.array([[a[-1]]]), cache=c1)
+        a.append(int(O.argmax_first(O.logprobs_from_logits(out.logits[:, -1].cpu()))[0]))
+        t = lm.fused_greedy_decode(np.array([[b[-1]]]), cache=c2)
+        assert t is not None and t.shape == (1,)
+        b.append(int(t[0]))
+    assert a == b
+    assert lm.fused_greedy_decode(np.array([[1]]), cache=c2, logits_processors=[lambda t, l: l]) is None
+    c1[0]._seq.release(); c2[0]._seq.release()
+
+
 def test_sampling_temperature_reproducible_and_varied(tiny):
     from mlx_vlm_amd.generate import generate_step
 

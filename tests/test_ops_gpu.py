@@ -698,3 +698,40 @@ def test_logit_penalties_kernel_bit_exact_vs_oracle_and_reference_golden(vops):
         if step % 23 == 0 or step > 290:
             assert torch.equal(x.cpu(), ref), step
     assert int(hlen[0]) == 300
+
+
+@pytest.mark.parametrize("M,H,hd", [(9216, 16, 80), (1024, 16, 80), (200, 2, 80), (77, 3, 64)])
+def test_gemm_rope2d_epilogue_equals_gemm_then_rope_pass(vops, M, H, hd):
+    """vlm_gemm_bf16_rope2d (2-D rope of the vision attention in the qkv GEMM epilogue, q / k rows interleaved per head)
+    against the two-pass form it replaces - vlm_gemm_bf16 + bias, then vlm_rope2d_vision - on the original row order:
+    same contraction, same bias rounding, same rotation formula; the outputs are compared after undoing the
+    interleave.  Shapes cover the 256-tile kernel (16 x 336^2 images), the 128-tile kernel and ragged edges."""
+    import ctypes as C
+
+    from mlx_vlm_amd import _lib
+
+    dev = "cuda"
+    E = H * hd
+    K = 1280 if hd == 80 else 192
+    torch.manual_seed(M + H)
+    a = (torch.randn(M, K, device=dev) * 0.5).to(BF)
+    w = (torch.randn(3 * E, K, device=dev) * 0.05).to(BF)
+    b = (torch.randn(3 * E, device=dev) * 0.1).to(BF)
+    freqs = torch.rand(M, hd // 2, device=dev) * 6.0
+    cs = torch.stack([torch.cos(freqs), torch.sin(freqs)]).contiguous()
+    # reference form
+    ref = vops.gemm(a, w, bias=b, epilogue=vops.EPI_BIAS)
+    check = _lib.check
+    check(_lib.lib().vlm_rope2d_vision(C.c_void_p(ref.data_ptr()), C.c_void_p(cs[0].data_ptr()), C.c_void_p(cs[1].data_ptr()),
+                                       M, H, hd, 3 * E, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rope2d")
+    # fused form on interleaved rows
+    half = hd // 2
+    inter = torch.stack([torch.arange(half), torch.arange(half) + half], dim=1).reshape(-1)
+    perm = torch.cat([(torch.arange(2 * H)[:, None] * hd + inter[None, :]).reshape(-1), torch.arange(2 * E, 3 * E)]).to(dev)
+    out = vops.gemm_rope2d(a, w[perm].contiguous(), b[perm].contiguous(), cs, hd, 2 * E)
+    got = torch.empty_like(out)
+    got[:, perm] = out                                   # undo the interleave
+    assert torch.equal(got[:, 2 * E:], ref[:, 2 * E:])   # v: bias only, untouched
+    exact = float((got == ref).float().mean())
+    ok, rep = bf16_close(got, ref, ulps=1, atol_rms=0.0)
+    assert ok and exact > 0.999, (exact, rep)            # fp32 contraction of a*c - b*s may differ in the last place
