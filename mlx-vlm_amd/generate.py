@@ -72,6 +72,27 @@ class BatchResponse:
     image_sizes: Optional[List[Tuple[int, int]]] = None
 
 
+class PromptCacheState:
+    """KV cache + token history across conversation turns (reference generate/common.py:243-263)."""
+
+    def __init__(self):
+        self.cache: Optional[List[Any]] = None
+        self.token_ids: Optional[List[int]] = None
+
+    def find_prefix_length(self, new_ids) -> int:
+        if self.token_ids is None:
+            return 0
+        n = min(len(self.token_ids), len(new_ids))
+        for i in range(n):
+            if self.token_ids[i] != new_ids[i]:
+                return i
+        return n
+
+    def update(self, token_ids, kv_cache):
+        self.token_ids = [int(t) for t in token_ids]
+        self.cache = kv_cache
+
+
 def _peak_gb():
     return torch.cuda.max_memory_allocated() / 1e9 if torch.cuda.is_available() else 0.0
 
@@ -144,7 +165,14 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
     if ids.shape[0] != 1:
         raise ValueError("generate_step handles one sequence; use batch_generate for batches")
 
+    # continuation of a cached prefix (stream_generate's prompt_cache_state path): `ids` is the uncached suffix, its rope
+    # positions / delta come from the FULL prompt (reference dispatch.py:612-649 primes them on the model object)
+    pos_override, delta_override = kwargs.pop("position_ids", None), kwargs.pop("rope_deltas", None)
     f = model.get_input_embeddings(ids, pixel_values, mask=mask, **kwargs)
+    if pos_override is not None:
+        f.position_ids = np.asarray(pos_override)
+    if delta_override is not None:
+        f.rope_deltas = np.asarray(delta_override)
     own_cache = prompt_cache is None
     if own_cache:
         prompt_cache = cache_mod.make_prompt_cache(lm)
@@ -211,8 +239,10 @@ def stream_generate(model, processor, prompt: Optional[str] = None, image=None, 
     kwargs.pop("verbose", None)
     skip_special_tokens = kwargs.pop("skip_special_tokens", False)
     skip_ids = set(tokenizer.all_special_ids) if (skip_special_tokens and hasattr(tokenizer, "all_special_ids")) else set()
+    vision_cache = kwargs.pop("vision_cache", None)
+    prompt_cache_state = kwargs.pop("prompt_cache_state", None)
     for k in ("thinking_budget", "thinking_end_token", "thinking_start_token", "enable_thinking", "resize_shape",
-              "vision_cache", "prompt_cache_state", "apc_manager", "apc_tenant", "eos_tokens", "stopping_criteria"):
+              "apc_manager", "apc_tenant", "eos_tokens", "stopping_criteria"):
         kwargs.pop(k, None)
     if audio or video:
         raise NotImplementedError("audio / video inputs are outside the built hot path")
@@ -230,6 +260,45 @@ def stream_generate(model, processor, prompt: Optional[str] = None, image=None, 
 
     ids = np.asarray(input_ids if not isinstance(input_ids, torch.Tensor) else input_ids.cpu())
     total_prompt_tokens = int(ids.size)
+    full_ids = [int(t) for t in ids.reshape(-1)]
+
+    # vision feature cache (reference dispatch.py:800-809): the projected features of an image seen before are reused,
+    # the ViT prefill of this turn is skipped
+    if vision_cache is not None and image is not None and pixel_values is not None and hasattr(model, "encode_image"):
+        feats = vision_cache.get(image)
+        if feats is None:
+            feats = model.encode_image(pixel_values, **{k: v for k, v in kwargs.items() if k in ("image_grid_thw",)})
+            vision_cache.put(image, feats)
+        kwargs["cached_image_features"] = feats
+
+    # prompt cache reuse across turns (reference dispatch.py:861-882): the KV cache of the previous turn is trimmed to
+    # the shared token prefix and only the suffix is prefilled ONTO it (LanguageModel._prefill_onto_cache)
+    cached_tokens = 0
+    if prompt_cache_state is not None and prompt_cache_state.cache is not None and ids.ndim == 2 and ids.shape[0] == 1:
+        kv = prompt_cache_state.cache
+        have = int(kv[0].offset)
+        prefix = min(prompt_cache_state.find_prefix_length(full_ids), have)       # never beyond what the cache holds
+        cfgm = model.config
+        media = {getattr(cfgm, n, None) for n in ("image_token_id", "video_token_id", "image_token_index")} - {None}
+        suffix_text_only = not any(t in media for t in full_ids[prefix:])
+        lm = model.language_model
+        if 0 < prefix < len(full_ids) and suffix_text_only and hasattr(lm, "get_rope_index"):
+            pos, deltas = lm.get_rope_index(ids, kwargs.get("image_grid_thw"), kwargs.get("video_grid_thw"), None)
+            pos = np.asarray(pos)
+            if pos.ndim == 2:
+                pos = np.broadcast_to(pos[None], (3,) + pos.shape)
+            for c in kv:
+                c.trim(have - prefix)
+            kwargs.update(prompt_cache=kv, position_ids=pos[..., prefix:], rope_deltas=deltas)
+            ids, pixel_values, cached_tokens = ids[:, prefix:], None, prefix
+            kwargs.pop("cached_image_features", None)
+    if prompt_cache_state is not None and "prompt_cache" not in kwargs:
+        from .models import cache as _cm
+
+        if prompt_cache_state.cache is not None:
+            prompt_cache_state.cache[0]._seq.release()        # cold prefill: the old turn's pages go back to the pool
+            prompt_cache_state.cache = None
+        kwargs["prompt_cache"] = _cm.make_prompt_cache(model.language_model)
     detok = make_streaming_detokenizer(processor) if processor is not None else None
     stop = getattr(tokenizer, "stopping_criteria", None) if tokenizer is not None else None
 
@@ -238,7 +307,9 @@ def stream_generate(model, processor, prompt: Optional[str] = None, image=None, 
     finish_reason = None
     token, logprobs, n = None, None, -1
     prompt_tps = 0.0
+    fed: List[int] = []                 # tokens whose K/V the cache holds after the run (all yielded but the last)
     for n, (token, logprobs) in enumerate(gen):
+        fed.append(int(token))
         if n == 0:
             prompt_time = time.perf_counter() - tic
             prompt_tps = total_prompt_tokens / prompt_time
@@ -251,10 +322,15 @@ def stream_generate(model, processor, prompt: Optional[str] = None, image=None, 
         yield GenerationResult(text=detok.last_segment if detok else "", token=token, logprobs=logprobs,
                                prompt_tokens=total_prompt_tokens, generation_tokens=n + 1,
                                total_tokens=total_prompt_tokens + n + 1, prompt_tps=prompt_tps,
-                               generation_tps=(n + 1) / max(time.perf_counter() - tic, 1e-9), peak_memory=_peak_gb())
+                               generation_tps=(n + 1) / max(time.perf_counter() - tic, 1e-9), peak_memory=_peak_gb(),
+                               cached_tokens=cached_tokens)
     else:
         finish_reason = "length"
     gen.close()
+    if prompt_cache_state is not None:
+        kv = kwargs["prompt_cache"]
+        # the cache holds the prompt + every generated token that was fed back (generate_step leaves the offset there)
+        prompt_cache_state.update((full_ids + fed)[: int(kv[0].offset)], kv)
     if n < 0:
         yield GenerationResult(prompt_tokens=total_prompt_tokens, total_tokens=total_prompt_tokens,
                                peak_memory=_peak_gb(), finish_reason="length")
@@ -265,7 +341,7 @@ def stream_generate(model, processor, prompt: Optional[str] = None, image=None, 
                            prompt_tokens=total_prompt_tokens, generation_tokens=n + 1,
                            total_tokens=total_prompt_tokens + n + 1, prompt_tps=prompt_tps,
                            generation_tps=(n + 1) / max(time.perf_counter() - tic, 1e-9), peak_memory=_peak_gb(),
-                           finish_reason=finish_reason)
+                           cached_tokens=cached_tokens, finish_reason=finish_reason)
 
 
 def generate(model, processor, prompt: Optional[str] = None, image=None, audio=None, video=None, verbose: bool = False,

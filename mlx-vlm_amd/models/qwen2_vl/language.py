@@ -438,7 +438,7 @@ class LanguageModel:
         sec = self.mrope_section
         for i in range(t.num_hidden_layers):
             w = self._w
-            kp, vp = pool.layer_pools(i)
+            kp, vp = pool.kpool[i], pool.vpool[i]          # this layer's K / V pools (flat views)
             xn = ops.rmsnorm(h, w[f"{i}.ln1"], t.rms_norm_eps)
             qkv = ops.gemm(xn, w[f"{i}.wqkv"], bias=w[f"{i}.bqkv"], epilogue=ops.EPI_BIAS)
             ops.mrope_kvwrite_(qkv, Hq, Hkv, hd, pos_d[0], pos_d[1], pos_d[2], w["inv_freq"], int(sec[0]), int(sec[1]),

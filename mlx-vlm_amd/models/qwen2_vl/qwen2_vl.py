@@ -61,6 +61,11 @@ class Model:
         position_ids, rope_deltas = self.language_model.get_rope_index(ids, image_grid_thw, video_grid_thw, mask)
         return InputEmbeddingsFeatures(inputs_embeds=final, position_ids=position_ids, rope_deltas=rope_deltas)
 
+    def encode_image(self, pixel_values, image_grid_thw=None, **kwargs):
+        """Projected image features (vision tower + PatchMerger) - what `cached_image_features` carries (reference hook
+        `model.encode_image`, dispatch.py:805-809)."""
+        return self.vision_tower(torch.as_tensor(pixel_values), _to_np(image_grid_thw), output_hidden_states=False)
+
     @staticmethod
     def merge_input_ids_with_image_features(image_token_id, video_token_id, image_features, inputs_embeds, input_ids):
         """reference qwen2_vl.py:78-148: row-major over the batch, the i-th image-token position receives image

@@ -1,0 +1,74 @@
+"""MLX affine weight quantization restated on the CPU (test infrastructure - see oracle/__init__.py).
+
+The reference quantizes / loads 4-bit checkpoints through the un-vendored `mlx` runtime: `nn.quantize(model, group_size,
+bits, class_predicate)` in `load_model` (mlx_vlm/utils.py:918-967) swaps every Linear whose `<path>.scales` exists in the
+checkpoint for `nn.QuantizedLinear`, whose forward is `mx.quantized_matmul(x, weight, scales, biases, transpose=True,
+group_size, bits)` (+ bias), and `nn.Embedding` for `nn.QuantizedEmbedding` (`mx.dequantize` of the gathered rows; tied
+lm_head = `as_linear` = the same quantized matmul).  None of that arithmetic is in /root/reference; it is restated here
+from MLX 0.32's published semantics - "parity unpinned" applies (no reference golden can be produced without mlx):
+
+  layout    weight uint32 [out, in * bits / 32]: element k of a row sits in word k // (32 / bits), bit field
+            (k % (32 / bits)) * bits - little end first; scales / biases [out, in / group_size] in the model dtype
+  dequant   w[o, k] = scales[o, k // gs] * q[o, k] + biases[o, k // gs]
+  quantize  per group: w_max, w_min; scale = max((w_max - w_min) / (2^bits - 1), 1e-7), signed so that the edge of larger
+            magnitude lands exactly on an integer (edge = |w_min| > |w_max| ? w_min : w_max; q0 = round(edge / scale);
+            scale = edge / q0 if q0 != 0; bias = edge, or 0 when q0 == 0); q = clip(round((w - bias) / scale), 0, 2^bits-1)
+  matmul    y = x . dequant(w)^T accumulated in fp32, rounded once to x's dtype (policy of oracle/ops.py::linear)
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+F32 = torch.float32
+
+
+def quantize_affine(w: torch.Tensor, group_size: int = 64, bits: int = 4):
+    """mx.quantize(w, group_size, bits) -> (wq uint32 [N, K * bits / 32] as int64-safe torch.int32 bit pattern, scales,
+    biases) with scales / biases in w's dtype."""
+    assert w.dim() == 2 and w.shape[1] % group_size == 0 and 32 % bits == 0
+    N, K = w.shape
+    n_bins = (1 << bits) - 1
+    g = w.to(F32).reshape(N, K // group_size, group_size)
+    w_max, w_min = g.max(-1).values, g.min(-1).values
+    mask = w_min.abs() > w_max.abs()
+    scales = torch.clamp((w_max - w_min) / n_bins, min=1e-7)
+    scales = torch.where(mask, scales, -scales)
+    edge = torch.where(mask, w_min, w_max)
+    q0 = torch.round(edge / scales)
+    scales = torch.where(q0 != 0, edge / q0, scales)
+    biases = torch.where(q0 == 0, torch.zeros_like(edge), edge)
+    # scales / biases are materialised in the weight dtype; the integers are computed from the fp32 values
+    q = torch.clamp(torch.round((g - biases[..., None]) / scales[..., None]), 0, n_bins).to(torch.int64).reshape(N, K)
+    per = 32 // bits
+    q = q.reshape(N, K // per, per)
+    shifts = (torch.arange(per, dtype=torch.int64) * bits)
+    words = (q << shifts).sum(-1)                                   # < 2^32
+    wq = words.to(torch.int64).numpy().astype(np.uint32)
+    return torch.from_numpy(wq.view(np.int32)), scales.to(w.dtype), biases.to(w.dtype)
+
+
+def unpack(wq: torch.Tensor, bits: int = 4) -> torch.Tensor:
+    """uint32 words (int32 bit pattern) [N, W] -> integers [N, W * 32 / bits] (int64)"""
+    per = 32 // bits
+    u = torch.from_numpy(wq.numpy().view(np.uint32).astype(np.int64))
+    shifts = (torch.arange(per, dtype=torch.int64) * bits)
+    return ((u[..., None] >> shifts) & ((1 << bits) - 1)).reshape(wq.shape[0], -1)
+
+
+def dequantize(wq, scales, biases, group_size: int = 64, bits: int = 4, dtype=None) -> torch.Tensor:
+    """mx.dequantize: scales * q + biases per group, fp32 arithmetic, one rounding to the scales' dtype"""
+    q = unpack(wq, bits).to(F32)
+    N, K = q.shape
+    w = q.reshape(N, K // group_size, group_size) * scales.to(F32)[..., None] + biases.to(F32)[..., None]
+    return w.reshape(N, K).to(dtype or scales.dtype)
+
+
+def quantized_linear(x, wq, scales, biases, bias=None, group_size: int = 64, bits: int = 4):
+    """nn.QuantizedLinear: mx.quantized_matmul(x, w, scales, biases, transpose=True) (+ bias).  fp32 accumulation over
+    x (its dtype) times the fp32 dequantized weight, one rounding to x's dtype; the bias add is a second typed op."""
+    w = dequantize(wq, scales, biases, group_size, bits, dtype=F32)
+    y = (x.to(F32) @ w.T).to(x.dtype)
+    if bias is not None:
+        y = (y.to(F32) + bias.to(F32)).to(x.dtype)
+    return y

@@ -334,9 +334,10 @@ def test_prefill_onto_non_empty_cache_chunked_and_multi_turn(tiny):
     pos = np.asarray(f.position_ids)
     cache = lm.make_cache()
     emb = f.inputs_embeds.reshape(L, -1)
-    lm.prefill(emb[:cut].contiguous(), pos.reshape(3, L)[:, :cut], [cache], [cut], "last")
+    # (prefill uses its input as the residual stream: every call gets its own copy)
+    lm.prefill(emb[:cut].clone(), pos.reshape(3, L)[:, :cut], [cache], [cut], "last")
     assert cache[0].offset == cut
-    logits = lm.prefill(emb[cut:].contiguous(), pos.reshape(3, L)[:, cut:], [cache], [L - cut], "last")
+    logits = lm.prefill(emb[cut:].clone(), pos.reshape(3, L)[:, cut:], [cache], [L - cut], "last")
     assert cache[0].offset == L
     assert _rel_rms_err(logits[0], ref_logits[-1]) < 3e-2
     for layer in (0, cfg.text.num_hidden_layers - 1):
@@ -345,13 +346,53 @@ def test_prefill_onto_non_empty_cache_chunked_and_multi_turn(tiny):
         assert _rel_rms_err(k, rk) < 2e-2 and _rel_rms_err(v, rv) < 2e-2
     # one-shot cache of the same prompt: the next decode step's logits agree (the caches are interchangeable)
     one = lm.make_cache()
-    a = lm.prefill(emb.contiguous(), pos.reshape(3, L), [one], [L], "last")
+    a = lm.prefill(emb.clone(), pos.reshape(3, L), [one], [L], "last")
     assert _rel_rms_err(logits[0], a[0]) < 1e-2
     lm._rope_deltas = np.asarray(f.rope_deltas)
     x = lm(np.array([[77]]), cache=cache).logits[0, -1]
     y = lm(np.array([[77]]), cache=one).logits[0, -1]
     assert _rel_rms_err(x, y) < 1e-2
     cache[0]._seq.release(); one[0]._seq.release()
+
+
+def test_stream_generate_multi_turn_prompt_cache_state_and_vision_cache(tiny):
+    """Two conversation turns through stream_generate with a PromptCacheState and a VisionFeatureCache (reference
+    dispatch.py:800-809,861-882): turn 2's prompt = turn 1's prompt + its answer + new text; the cached KV prefix is reused
+    (cached_tokens > 0, only the suffix is prefilled onto the cache) and the image is not encoded again; the tokens equal
+    those of a cold run of the same turn-2 prompt."""
+    from mlx_vlm_amd.generate import PromptCacheState, stream_generate
+    from mlx_vlm_amd.vision_cache import VisionFeatureCache
+
+    cfg, W, model = tiny
+    ids1, pix, thw = synth_request(cfg, [(56, 56)], n_text=9, seed=90)
+    img_key = "turn-image"
+    state, vcache = PromptCacheState(), VisionFeatureCache(max_size=2)
+    kw = dict(pixel_values=torch.from_numpy(pix), mask=None, image_grid_thw=thw, max_tokens=6)
+    calls = {"n": 0}
+    tower = model.vision_tower.__class__.__call__
+
+    def counting(self, *a, **k):
+        calls["n"] += 1
+        return tower(self, *a, **k)
+
+    model.vision_tower.__class__.__call__ = counting
+    try:
+        r1 = list(stream_generate(model, None, image=img_key, input_ids=ids1, prompt_cache_state=state, vision_cache=vcache, **kw))
+        assert calls["n"] == 1 and len(vcache) == 1 and r1[-1].cached_tokens == 0
+        t1 = [r.token for r in r1[:-1]]
+        assert state.cache is not None and len(state.token_ids) == ids1.shape[1] + len(t1) - 1 == state.cache[0].offset
+        ids2 = np.concatenate([ids1[0], t1, np.random.default_rng(91).integers(3, 1000, 7)])[None]
+        r2 = list(stream_generate(model, None, image=img_key, input_ids=ids2, prompt_cache_state=state, vision_cache=vcache, **kw))
+        assert calls["n"] == 1                                   # the image was NOT encoded again
+        assert r2[-1].cached_tokens == ids1.shape[1] + len(t1) - 1
+        cold = list(stream_generate(model, None, input_ids=ids2, **kw))
+        assert calls["n"] == 2
+        assert [r.token for r in r2[:-1]] == [r.token for r in cold[:-1]]
+        assert r2[-1].prompt_tokens == cold[-1].prompt_tokens == ids2.shape[1]
+    finally:
+        model.vision_tower.__class__.__call__ = tower
+        if state.cache is not None:
+            state.cache[0]._seq.release()
 
 
 def test_fused_greedy_decode_hook_matches_module_call(tiny):
