@@ -86,6 +86,24 @@ int vlm_gemv_qkv_rope_kvwrite(const void* h, const void* norm_w, float eps, cons
 int vlm_gemv_attn_out(const void* part_o, const void* part_ml, int nsplit, const void* Wo, void* h, int ldh, int M,
                       int N, int Hq, int D, void* stream);
 
+/* MLX affine 4-bit weights (group 64): what load_model turns every Linear / Embedding of a 4-bit checkpoint into
+ * (utils.py:918-967: nn.quantize with the `<path>.scales in weights` predicate -> nn.QuantizedLinear = mx.quantized_matmul(x,
+ * weight, scales, biases, transpose=True, group_size=64, bits=4) (+ bias); nn.QuantizedEmbedding = mx.dequantize of the rows).
+ * Engine layout (repacked once at load): Wq uint32 [N][K/8], MLX's own words (element k of a row in word k / 8, bits
+ * 4 (k % 8) .. +3); Wsb uint32 [N][K/64] = scale bf16 (low half) | bias bf16 (high half) of each group.  K % 64 == 0.
+ * vlm_gemv_w4 / vlm_gemv_w4_qkv_rope_kvwrite: the decode GEMVs of vlm_gemv_bf16 / vlm_gemv_qkv_rope_kvwrite with the
+ *   dequantisation fused into the operand path (fp32 affine form per group, no weight is rounded); M in {1,2,4,8}.
+ * vlm_dequant_w4: rows of the matrix as bf16 (fp32 scale * q + bias, one rounding): rows == NULL -> rows 0..n_rows-1
+ *   (prefill: materialised once per projection, then vlm_gemm_bf16), rows != NULL -> gather (QuantizedEmbedding lookup). */
+int vlm_gemv_w4(const void* x, const void* Wq, const void* Wsb, const void* bias, const void* res, const void* norm_w, void* y,
+                int M, int N, int K, int ldx, int ldy, int ldres, float eps, int epilogue, void* stream);
+int vlm_gemv_w4_qkv_rope_kvwrite(const void* h, const void* norm_w, float eps, const void* Wq, const void* Wsb, const void* bqkv,
+                                 void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D, const void* pos, const void* slot,
+                                 const void* inv_freq, const void* block_table, int max_pages, void* kpool, void* vpool,
+                                 void* stream);
+int vlm_dequant_w4(const void* Wq, const void* Wsb, const void* rows, void* out, int n_rows, int K, int ldo, int n_table_rows,
+                   void* stream);
+
 /* nn.LayerNorm(eps) -> mx.fast.layer_norm (vision.py:109,180-181). dim % 8 == 0, dim <= 8192 */
 int vlm_layernorm(const void* x, const void* w, const void* b, void* y, int rows, int dim, float eps, void* stream);
 
@@ -214,10 +232,14 @@ typedef struct vlm_llm_config {
 
 typedef struct vlm_llm_layer {
   const void *ln1_w, *wqkv, *bqkv, *wo, *ln2_w, *wgu /* interleaved gate/up rows */, *wdown;
+  /* MLX affine 4-bit layers (vlm_gemv_w4): a non-NULL *_sb marks the matching w* as q words uint32 [N][K/8] with *_sb its
+   * (scale | bias << 16) words uint32 [N][K/64]; NULL = bf16 weight as before.  Rows packed / interleaved the same way. */
+  const void *wqkv_sb, *wo_sb, *wgu_sb, *wdown_sb;
 } vlm_llm_layer;
 
 typedef struct vlm_llm_globals {
   const void *embed, *final_norm_w, *lm_head /* == embed when tied */, *inv_freq /* fp32 [head_dim/2] */;
+  const void *embed_sb, *lm_head_sb; /* 4-bit embedding table / head (nn.QuantizedEmbedding, as_linear): see vlm_llm_layer */
 } vlm_llm_globals;
 
 typedef struct vlm_kv_pool {

@@ -22,11 +22,12 @@ class LlmConfig(C.Structure):
 
 
 class LlmLayer(C.Structure):
-    _fields_ = [(n, c_void_p) for n in ("ln1_w", "wqkv", "bqkv", "wo", "ln2_w", "wgu", "wdown")]
+    _fields_ = [(n, c_void_p) for n in ("ln1_w", "wqkv", "bqkv", "wo", "ln2_w", "wgu", "wdown",
+                                        "wqkv_sb", "wo_sb", "wgu_sb", "wdown_sb")]
 
 
 class LlmGlobals(C.Structure):
-    _fields_ = [(n, c_void_p) for n in ("embed", "final_norm_w", "lm_head", "inv_freq")]
+    _fields_ = [(n, c_void_p) for n in ("embed", "final_norm_w", "lm_head", "inv_freq", "embed_sb", "lm_head_sb")]
 
 
 class KvPool(C.Structure):
@@ -91,6 +92,10 @@ SIGNATURES = {
     "vlm_gemv_qkv_rope_kvwrite": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p] + [c_int] * 6
                                   + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p]),
     "vlm_gemv_attn_out": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "vlm_gemv_w4": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_int, c_void_p]),
+    "vlm_gemv_w4_qkv_rope_kvwrite": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6
+                                     + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p]),
+    "vlm_dequant_w4": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "vlm_layernorm": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p]),
     "vlm_rmsnorm_residual": (c_int, [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p]),
     "vlm_rope2d_vision": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),

@@ -60,6 +60,8 @@ struct Fork {
 struct Llm {
   Tuning tune;
   int* progress = nullptr;                // [0] pacing word, [1] exit counter of the persistent prefetcher (device)
+  void* wscratch = nullptr;               // bf16 scratch for the prefill GEMMs over 4-bit weights (largest matrix)
+  size_t wscratch_bytes = 0;
   char* fm_buf = nullptr;                 // fused-MLP hand-off buffers: [256 B err] then per layer [256 B epoch | D granules | I granules]
   size_t fm_stride = 0;
   vlm_llm_config cfg;
@@ -130,6 +132,7 @@ extern "C" int vlm_llm_destroy(void* handle) {
   for (DecodeGraph& g : m->graphs) drop_graph(g);
   if (m->progress) (void)hipFree(m->progress);
   if (m->fm_buf) (void)hipFree(m->fm_buf);
+  if (m->wscratch) (void)hipFree(m->wscratch);
   delete m;
   return 0;
 }
@@ -229,6 +232,29 @@ extern "C" int vlm_llm_set_kv(void* handle, const vlm_kv_pool* kv) {
   return 0;
 }
 
+// ---- one projection, bf16 or MLX 4-bit weights
+// prefill: C = epi(A . W^T): 4-bit weights are materialised as bf16 once per projection (vlm_dequant_w4 -> scratch)
+static int lin_gemm(Llm* m, const void* A, const void* W, const void* Wsb, const void* bias, const void* res, void* C, int M,
+                    int N, int K, int ldc, int ldres, int epi, void* stream) {
+  if (Wsb) {
+    const size_t need = (size_t)N * K * 2;
+    if (m->wscratch_bytes < need) {
+      if (m->wscratch) { (void)hipDeviceSynchronize(); (void)hipFree(m->wscratch); m->wscratch = nullptr; m->wscratch_bytes = 0; }
+      if (hipMalloc(&m->wscratch, need) != hipSuccess) return 1011;
+      m->wscratch_bytes = need;
+    }
+    TRY(vlm_dequant_w4(W, Wsb, nullptr, m->wscratch, N, K, K, N, stream));
+    W = m->wscratch;
+  }
+  return vlm_gemm_bf16(A, W, bias, res, C, M, N, K, K, K, ldc, ldres, epi, stream);
+}
+// decode: y = epi(x . W^T) for B rows
+static int lin_gemv(const void* x, const void* W, const void* Wsb, const void* bias, const void* res, const void* norm_w,
+                    void* y, int B, int N, int K, int ldy, int ldres, float eps, int epi, void* stream) {
+  if (Wsb) return vlm_gemv_w4(x, W, Wsb, bias, res, norm_w, y, B, N, K, K, ldy, ldres, eps, epi, stream);
+  return vlm_gemv_bf16(x, W, bias, res, norm_w, y, B, N, K, K, K, ldy, ldres, eps, epi, stream);
+}
+
 extern "C" int vlm_llm_prefill(void* handle, const vlm_prefill_args* a, void* stream) {
   Llm* m = static_cast<Llm*>(handle);
   if (!m || !a || !a->h || a->T <= 0) return 1;
@@ -241,7 +267,7 @@ extern "C" int vlm_llm_prefill(void* handle, const vlm_prefill_args* a, void* st
     // xn = RMSNorm(h)
     TRY(vlm_rmsnorm_residual(a->h, nullptr, w.ln1_w, a->xn, nullptr, T, D, c.rms_eps, stream));
     // qkv = xn Wqkv^T + b
-    TRY(vlm_gemm_bf16(a->xn, w.wqkv, w.bqkv, nullptr, a->qkv, T, QKV, D, D, D, QKV, 0, VLM_EPI_BIAS, stream));
+    TRY(lin_gemm(m, a->xn, w.wqkv, w.wqkv_sb, w.bqkv, nullptr, a->qkv, T, QKV, D, QKV, 0, VLM_EPI_BIAS, stream));
     // M-RoPE on q, k in place + paged KV write
     void* kp = m->kv.kpool ? off(m->kv.kpool, (size_t)i * m->kv.layer_stride * 2) : nullptr;
     void* vp = m->kv.vpool ? off(m->kv.vpool, (size_t)i * m->kv.layer_stride * 2) : nullptr;
@@ -251,11 +277,11 @@ extern "C" int vlm_llm_prefill(void* handle, const vlm_prefill_args* a, void* st
     TRY(vlm_attn_prefill(a->qkv, off(a->qkv, (size_t)Hq * hd * 2), off(a->qkv, (size_t)(Hq + Hkv) * hd * 2), a->attn, QKV,
                          QKV, QKV, Hq * hd, a->cu_seqlens, a->nseg, a->total_qblocks, Hq, Hkv, hd, scale, 1, stream));
     // h = h + attn Wo^T
-    TRY(vlm_gemm_bf16(a->attn, w.wo, nullptr, a->h, a->h, T, D, Hq * hd, Hq * hd, Hq * hd, D, D, VLM_EPI_RESIDUAL, stream));
+    TRY(lin_gemm(m, a->attn, w.wo, w.wo_sb, nullptr, a->h, a->h, T, D, Hq * hd, D, D, VLM_EPI_RESIDUAL, stream));
     // xn = RMSNorm(h); act = swiglu(xn Wgu^T); h = h + act Wdown^T
     TRY(vlm_rmsnorm_residual(a->h, nullptr, w.ln2_w, a->xn, nullptr, T, D, c.rms_eps, stream));
-    TRY(vlm_gemm_bf16(a->xn, w.wgu, nullptr, nullptr, a->act, T, 2 * c.inter, D, D, D, c.inter, 0, VLM_EPI_SWIGLU, stream));
-    TRY(vlm_gemm_bf16(a->act, w.wdown, nullptr, a->h, a->h, T, D, c.inter, c.inter, c.inter, D, D, VLM_EPI_RESIDUAL, stream));
+    TRY(lin_gemm(m, a->xn, w.wgu, w.wgu_sb, nullptr, nullptr, a->act, T, 2 * c.inter, D, c.inter, 0, VLM_EPI_SWIGLU, stream));
+    TRY(lin_gemm(m, a->act, w.wdown, w.wdown_sb, nullptr, a->h, a->h, T, D, c.inter, D, D, VLM_EPI_RESIDUAL, stream));
   }
   if (a->n_last > 0) {
     if (!a->last_rows || !a->xlast || !a->logits) return 1;
@@ -263,8 +289,8 @@ extern "C" int vlm_llm_prefill(void* handle, const vlm_prefill_args* a, void* st
     // gather = embed_gather over the residual stream viewed as a table of T rows
     TRY(vlm_embed_gather(a->last_rows, a->h, a->xlast, a->n_last, D, D, T, stream));
     TRY(vlm_rmsnorm_residual(a->xlast, nullptr, m->g.final_norm_w, a->xlast, nullptr, a->n_last, D, c.rms_eps, stream));
-    TRY(vlm_gemm_bf16(a->xlast, m->g.lm_head, nullptr, nullptr, a->logits, a->n_last, c.vocab, D, D, D, c.vocab, 0,
-                      VLM_EPI_NONE, stream));
+    TRY(lin_gemm(m, a->xlast, m->g.lm_head, m->g.lm_head_sb, nullptr, nullptr, a->logits, a->n_last, c.vocab, D, c.vocab, 0,
+                 VLM_EPI_NONE, stream));
   }
   return 0;
 }
@@ -342,15 +368,26 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
                                        tn.wgs, fork->side)); ++n;
   }
   // h = embed[tok]
-  if (!fused_tail) { TRY(vlm_embed_gather(a->tok, m->g.embed, a->h, B, D, D, c.vocab, stream)); ++n; }
+  if (!fused_tail) {
+    if (m->g.embed_sb) { TRY(vlm_dequant_w4(m->g.embed, m->g.embed_sb, a->tok, a->h, B, D, D, c.vocab, stream)); }
+    else { TRY(vlm_embed_gather(a->tok, m->g.embed, a->h, B, D, D, c.vocab, stream)); }
+    ++n;
+  } else if (m->g.embed_sb) {
+    return 1;      // the fused tail gathers bf16 embedding rows
+  }
   for (int i = 0; i < NL; ++i) {
     const vlm_llm_layer& w = m->layers[i];
     void* kp = off(m->kv.kpool, (size_t)i * m->kv.layer_stride * 2);
     void* vp = off(m->kv.vpool, (size_t)i * m->kv.layer_stride * 2);
     // [RMSNorm + qkv GEMV + bias + M-RoPE at pos[b] + k/v write at slot ctx[b]] in one launch
     if (!(skip & 1)) {
+    if (w.wqkv_sb) {
+      TRY(vlm_gemv_w4_qkv_rope_kvwrite(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.wqkv_sb, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos,
+                                       a->ctx, m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, stream)); ++n;
+    } else {
     TRY(vlm_gemv_qkv_rope_kvwrite(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos, a->ctx,
                                   m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, stream)); ++n;
+    }
     }
     // attention over the pages (the new token is already in the cache: kv_len = ctx + 1)
     const VlmProgress prog{pf == 2 ? m->progress : nullptr, i + 1};
@@ -360,9 +397,10 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
       TRY(vlm_attn_decode_paged_ex(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale, 1,
                                    a->part_o, a->part_ml, a->attn, Hq * hd, prog, stream)); ++n;
     } else {
-      // long contexts: split-K partials, merged in the o_proj GEMV prologue
+      // long contexts: split-K partials, merged in the o_proj GEMV prologue (bf16 Wo) or by the combine kernel (4-bit Wo)
       TRY(vlm_attn_decode_paged_ex(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale,
-                                   a->nsplit, a->part_o, a->part_ml, nullptr, 0, prog, stream)); ++n;
+                                   a->nsplit, a->part_o, a->part_ml, w.wo_sb ? a->attn : nullptr, w.wo_sb ? Hq * hd : 0, prog,
+                                   stream)); ++n;
     }
     if (pf == 1) {
       // the layer's weight stream (o_proj, gate/up, down: ~20 us) starts here; the side branch pulls the NEXT layer in
@@ -375,7 +413,8 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
         TRY(vlm_prefetch_launch(&it, &pfkv, tn.wgs, fork->side)); ++n;
       }
     }
-    const bool fused_mlp = tn.fused_mlp && m->fm_buf && B == 1 && a->nsplit == 1 && !(skip & (4 | 8 | 16));
+    const bool fused_mlp = tn.fused_mlp && m->fm_buf && B == 1 && a->nsplit == 1 && !(skip & (4 | 8 | 16)) && !w.wo_sb &&
+                           !w.wgu_sb && !w.wdown_sb;
     if (fused_mlp) {
       // o_proj + residual, RMSNorm + gate/up + SwiGLU, down + residual: one launch, two in-launch hand-offs
       char* lb = m->fm_buf + 256 + m->fm_stride * (size_t)i;
@@ -389,23 +428,22 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
       continue;
     }
     if (skip & 4) {
-    } else if (a->nsplit == 1) {
-      TRY(vlm_gemv_bf16(a->attn, w.wo, nullptr, a->h, nullptr, a->h, B, D, Hq * hd, Hq * hd, Hq * hd, D, D, 0.f,
-                        VLM_EPI_RESIDUAL, stream)); ++n;
+    } else if (a->nsplit == 1 || w.wo_sb) {
+      TRY(lin_gemv(a->attn, w.wo, w.wo_sb, nullptr, a->h, nullptr, a->h, B, D, Hq * hd, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
     } else {
       TRY(vlm_gemv_attn_out(a->part_o, a->part_ml, a->nsplit, w.wo, a->h, D, B, D, Hq, hd, stream)); ++n;
     }
     // act = swiglu(RMSNorm(h) Wgu^T)
     if (!(skip & 8))
-    TRY(vlm_gemv_bf16(a->h, w.wgu, nullptr, nullptr, w.ln2_w, a->act, B, 2 * c.inter, D, D, D, c.inter, 0, c.rms_eps, VLM_EPI_SWIGLU, stream)); ++n;
+    TRY(lin_gemv(a->h, w.wgu, w.wgu_sb, nullptr, nullptr, w.ln2_w, a->act, B, 2 * c.inter, D, c.inter, 0, c.rms_eps, VLM_EPI_SWIGLU, stream)); ++n;
     // h = h + act Wdown^T
     if (!(skip & 16))
-    TRY(vlm_gemv_bf16(a->act, w.wdown, nullptr, a->h, nullptr, a->h, B, D, c.inter, c.inter, c.inter, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
+    TRY(lin_gemv(a->act, w.wdown, w.wdown_sb, nullptr, a->h, nullptr, a->h, B, D, c.inter, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
   }
   // logits = RMSNorm(h) lm_head^T
   if (!(skip & 32))
-  TRY(vlm_gemv_bf16(a->h, m->g.lm_head, nullptr, nullptr, m->g.final_norm_w, a->logits, B, c.vocab, D, D, D, c.vocab, 0,
-                    c.rms_eps, VLM_EPI_NONE, stream)); ++n;
+  TRY(lin_gemv(a->h, m->g.lm_head, m->g.lm_head_sb, nullptr, nullptr, m->g.final_norm_w, a->logits, B, c.vocab, D, c.vocab, 0,
+               c.rms_eps, VLM_EPI_NONE, stream)); ++n;
   if (sample && a->penalties) {
     // logits processors (ar.py:360-364): the fed token joins the history, then bias / penalties on the step's logits
     TRY(vlm_apply_logit_penalties(a->logits, c.vocab, B, c.vocab, a->tok, a->penalties, stream)); ++n;

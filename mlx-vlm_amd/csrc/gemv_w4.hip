@@ -40,7 +40,7 @@ __device__ __forceinline__ float wdot2(unsigned w, unsigned x, float acc) {
 }
 
 // one q word (8 nibbles) against the 8 x values of its block, stored as pairs (x_j, x_{j+4}) in xp[0..3]
-__device__ __forceinline__ float w4_word(unsigned w, const unsigned* xp, float acc) {
+__device__ __forceinline__ float w4_word(unsigned w, const u32x4_t xp, float acc) {
   acc = wdot2((w & 0x000F000Fu) | 0x43004300u, xp[0], acc);
   acc = wdot2(((w >> 4) & 0x000F000Fu) | 0x43004300u, xp[1], acc);
   acc = wdot2(((w >> 8) & 0x000F000Fu) | 0x43004300u, xp[2], acc);
@@ -155,19 +155,21 @@ __global__ __launch_bounds__(256) void gemv_w4_kernel(const bf16_t* __restrict__
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
         const uint4* xs = reinterpret_cast<const uint4*>(smem + (size_t)m * K * 2) + (size_t)ch * 4;
-        unsigned xp[4][4];
+        // (ext_vector registers, constant indices only: plain arrays passed by pointer end up in scratch)
+        const u32x4_t* xv = reinterpret_cast<const u32x4_t*>(xs);
+        const u32x4_t xp0 = xv[0], xp1 = xv[1], xp2 = xv[2], xp3 = xv[3];
         float sx = 0.f;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const uint4 v = xs[b];
-          xp[b][0] = v.x; xp[b][1] = v.y; xp[b][2] = v.z; xp[b][3] = v.w;
-          sx += (bf_lo(v.x) + bf_hi(v.x)) + (bf_lo(v.y) + bf_hi(v.y)) + (bf_lo(v.z) + bf_hi(v.z)) + (bf_lo(v.w) + bf_hi(v.w));
-        }
+#define SX4(V) ((bf_lo(V[0]) + bf_hi(V[0])) + (bf_lo(V[1]) + bf_hi(V[1])) + (bf_lo(V[2]) + bf_hi(V[2])) + (bf_lo(V[3]) + bf_hi(V[3])))
+        sx = SX4(xp0) + SX4(xp1) + SX4(xp2) + SX4(xp3);
+#undef SX4
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           float d = 0.f;
-#pragma unroll
-          for (int b = 0; b < 4; ++b) d = w4_word(wq[r][c][b], xp[b], d);
+          const u32x4_t wv = wq[r][c];
+          d = w4_word(wv[0], xp0, d);
+          d = w4_word(wv[1], xp1, d);
+          d = w4_word(wv[2], xp2, d);
+          d = w4_word(wv[3], xp3, d);
           const float sc = bf_lo(sb[r][c]), bi = bf_hi(sb[r][c]);
           acc[r][m] += sc * (d - 128.f * sx) + bi * sx;
         }
@@ -190,7 +192,8 @@ __global__ __launch_bounds__(256) void gemv_w4_kernel(const bf16_t* __restrict__
     if (lane < MB) {
       const int m = lane;
       const int r0 = min(row[0], N - 1), r1 = min(row[R - 1], N - 1);
-      const float y0 = rbf(a0 + bf2f(bias[r0])), y1 = rbf(a1 + bf2f(bias[r1]));
+      // quantized_matmul rounds to bf16, the bias add is a second typed op
+      const float y0 = rbf(rbf(a0) + bf2f(bias[r0])), y1 = rbf(rbf(a1) + bf2f(bias[r1]));
       const int e_slot = rk.slot[m], e_pos = rk.pos[m];
       const size_t e_page = rk.block_table ? (size_t)rk.block_table[(size_t)m * rk.max_pages + (e_slot >> 6)]
                                            : (size_t)m * rk.max_pages + (e_slot >> 6);
@@ -236,6 +239,28 @@ __global__ __launch_bounds__(256) void gemv_w4_kernel(const bf16_t* __restrict__
         if (EPI & VLM_EPI_RESIDUAL) v = rbf(v) + bf2f(res[(size_t)m * ldres + row[r]]);
         y[(size_t)m * ldy + row[r]] = f2bf(v);
       }
+}
+
+// W4 -> bf16 rows (mx.dequantize: scale * q + bias, fp32 multiply then add - not contracted - one rounding).  rows ==
+// nullptr: rows 0..n_rows-1 of the matrix (prefill: the weight is materialised once per GEMM into a scratch matrix);
+// rows != nullptr: gather (nn.QuantizedEmbedding: dequantize of the looked-up rows).  One thread = one q word (8 weights).
+__global__ __launch_bounds__(256) void dequant_w4_kernel(const unsigned* __restrict__ Wq, const unsigned* __restrict__ Wsb,
+                                                         const int* __restrict__ rows, bf16_t* __restrict__ out, int n_rows,
+                                                         int K, int ldo, int n_table_rows) {
+  const int nch8 = K >> 3;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n_rows * nch8) return;
+  const int r = (int)(idx / nch8), c = (int)(idx % nch8);
+  int src = rows ? rows[r] : r;
+  src = src < 0 ? 0 : (src >= n_table_rows ? n_table_rows - 1 : src);
+  const unsigned w = Wq[(size_t)src * nch8 + c], sbw = Wsb[(size_t)src * (K >> 6) + (c >> 3)];
+  const float sc = bf_lo(sbw), bi = bf_hi(sbw);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = __fadd_rn(__fmul_rn(sc, (float)((w >> (4 * j)) & 0xFu)), bi);
+  uint4 o;
+  o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
+  *reinterpret_cast<uint4*>(out + (size_t)r * ldo + (size_t)c * 8) = o;
 }
 
 struct W4Args {
@@ -342,4 +367,15 @@ extern "C" int vlm_gemv_w4_qkv_rope_kvwrite(const void* h, const void* norm_w, f
                     (bf16_t*)kpool, (bf16_t*)vpool},
            (hipStream_t)stream};
   return w4_m<WPRO_RMSNORM, WEPI_ROPE_KV>(M, a);
+}
+
+extern "C" int vlm_dequant_w4(const void* Wq, const void* Wsb, const void* rows, void* out, int n_rows, int K, int ldo,
+                              int n_table_rows, void* stream) {
+  if (!Wq || !Wsb || !out || n_rows < 0 || K <= 0 || n_table_rows <= 0) return VLM_ERR_ARG;
+  if (K % 64 != 0 || ldo % 8 != 0) return VLM_ERR_SHAPE;
+  if (n_rows == 0) return VLM_OK;
+  const long total = (long)n_rows * (K / 8);
+  hipLaunchKernelGGL(dequant_w4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned*)Wq, (const unsigned*)Wsb, (const int*)rows, (bf16_t*)out, n_rows, K, ldo, n_table_rows);
+  return w4_err();
 }

@@ -157,8 +157,16 @@ class LanguageModel:
         L = _lib.lib()
         bf = torch.bfloat16
 
+        from .. import quantized as Qz
+
         def g(name):
             return W[name].to(device=dev, dtype=bf)
+
+        def lin(path):
+            """a projection weight: bf16 tensor, or QuantW when the checkpoint holds `<path>.scales` (utils.py:961)"""
+            if Qz.has_scales(W, path):
+                return Qz.take(W, path).to(dev)
+            return g(path + ".weight")
 
         # small tensors (norm weights, biases, rope table, decode state, block table) live in ONE arena
         small_bytes = t.num_hidden_layers * (2 * t.hidden_size + (t.num_attention_heads + 2 * t.num_key_value_heads) * self.head_dim) * 2
@@ -168,10 +176,12 @@ class LanguageModel:
         qkv_rows = (t.num_attention_heads + 2 * t.num_key_value_heads) * self.head_dim
         per_layer = (qkv_rows + t.num_attention_heads * self.head_dim + 3 * t.intermediate_size) * t.hidden_size * 2
         n_big = t.num_hidden_layers * per_layer + (1 if t.tie_word_embeddings else 2) * t.vocab_size * t.hidden_size * 2
-        use_wa = os.environ.get("VLM_WEIGHT_ARENA", "1") != "0"
+        use_wa = os.environ.get("VLM_WEIGHT_ARENA", "1") != "0" and not any(k.endswith(".scales") for k in W)
         self.warena = Arena(n_big + (4 * t.num_hidden_layers + 4) * 4096, device=dev, zero=False) if use_wa else None
 
         def big(x):
+            if isinstance(x, Qz.QuantW):
+                return x                       # 4-bit matrices keep their own (small) allocations
             x = x.contiguous()
             if self.warena is None:
                 return x
@@ -189,25 +199,42 @@ class LanguageModel:
         self.apply_tuning()
         for i in range(t.num_hidden_layers):
             p = f"model.layers.{i}."
-            wqkv = big(torch.cat([g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"),
-                                  g(p + "self_attn.v_proj.weight")], dim=0))
+            qkv_parts = [lin(p + "self_attn.q_proj"), lin(p + "self_attn.k_proj"), lin(p + "self_attn.v_proj")]
+            if any(isinstance(x, Qz.QuantW) for x in qkv_parts):
+                if not all(isinstance(x, Qz.QuantW) for x in qkv_parts):
+                    raise NotImplementedError("q / k / v projections of one layer must be all quantized or all bf16")
+                wqkv = Qz.cat_rows(qkv_parts)
+            else:
+                wqkv = big(torch.cat(qkv_parts, dim=0))
             bqkv = torch.cat([g(p + "self_attn.q_proj.bias"), g(p + "self_attn.k_proj.bias"),
                               g(p + "self_attn.v_proj.bias")], dim=0).contiguous()
-            gate, up = g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")
-            wo = big(g(p + "self_attn.o_proj.weight"))
-            wgu = big(torch.stack([gate, up], dim=1).reshape(2 * t.intermediate_size, t.hidden_size))
+            gate, up = lin(p + "mlp.gate_proj"), lin(p + "mlp.up_proj")
+            wo = big(lin(p + "self_attn.o_proj"))
+            if isinstance(gate, Qz.QuantW) != isinstance(up, Qz.QuantW):
+                raise NotImplementedError("gate / up projections of one layer must be both quantized or both bf16")
+            wgu = Qz.interleave_rows(gate, up) if isinstance(gate, Qz.QuantW) else \
+                big(torch.stack([gate, up], dim=1).reshape(2 * t.intermediate_size, t.hidden_size))
             del gate, up
             bqkv = self.arena.put(bqkv)
             ws = dict(ln1=self.arena.put(g(p + "input_layernorm.weight")), wqkv=wqkv, bqkv=bqkv, wo=wo,
                       ln2=self.arena.put(g(p + "post_attention_layernorm.weight")), wgu=wgu,
-                      wdown=big(g(p + "mlp.down_proj.weight")))
+                      wdown=big(lin(p + "mlp.down_proj")))
             for k, v in ws.items():
                 self._w[f"{i}.{k}"] = v
-            lay = _lib.LlmLayer(ws["ln1"].data_ptr(), wqkv.data_ptr(), bqkv.data_ptr(), ws["wo"].data_ptr(),
-                                ws["ln2"].data_ptr(), wgu.data_ptr(), ws["wdown"].data_ptr())
+
+            def wp(x):
+                return x.wq.data_ptr() if isinstance(x, Qz.QuantW) else x.data_ptr()
+
+            def sp(x):
+                return x.sb.data_ptr() if isinstance(x, Qz.QuantW) else None
+
+            lay = _lib.LlmLayer(ws["ln1"].data_ptr(), wp(wqkv), bqkv.data_ptr(), wp(ws["wo"]), ws["ln2"].data_ptr(), wp(wgu),
+                                wp(ws["wdown"]), sp(wqkv), sp(ws["wo"]), sp(wgu), sp(ws["wdown"]))
             check(L.vlm_llm_set_layer(h, i, C.byref(lay)), "llm_set_layer")
-        embed = big(g("model.embed_tokens.weight"))
-        head = embed if t.tie_word_embeddings else big(g("lm_head.weight"))
+        embed = big(lin("model.embed_tokens"))
+        head = embed if t.tie_word_embeddings else big(lin("lm_head"))
+        self.quantized = any(isinstance(v, Qz.QuantW) for v in self._w.values()) or isinstance(embed, Qz.QuantW) \
+            or isinstance(head, Qz.QuantW)
         norm = self.arena.put(g("model.norm.weight"))
         hd = self.head_dim
         # compute_inv_freq (reference rope_utils.py:1042-1043), fp32 on the host
@@ -217,7 +244,10 @@ class LanguageModel:
         inv[: rd // 2] = 1.0 / (t.rope_theta ** (torch.arange(0, rd, 2).to(torch.float32) / rd))
         inv_freq = self.arena.put(inv.to(dev))
         self._w.update(embed=embed, head=head, norm=norm, inv_freq=inv_freq)
-        gl = _lib.LlmGlobals(embed.data_ptr(), norm.data_ptr(), head.data_ptr(), inv_freq.data_ptr())
+        isq = lambda x: isinstance(x, Qz.QuantW)    # noqa: E731
+        gl = _lib.LlmGlobals(embed.wq.data_ptr() if isq(embed) else embed.data_ptr(), norm.data_ptr(),
+                             head.wq.data_ptr() if isq(head) else head.data_ptr(), inv_freq.data_ptr(),
+                             embed.sb.data_ptr() if isq(embed) else None, head.sb.data_ptr() if isq(head) else None)
         check(L.vlm_llm_set_globals(h, C.byref(gl)), "llm_set_globals")
         self._init_pool()
 
@@ -267,7 +297,11 @@ class LanguageModel:
         """nn.Embedding (reference language.py:164,179).  input_ids [B, L] -> [B, L, D]"""
         ids = _lib.h2d(np.asarray(_to_np(input_ids), dtype=np.int32), self.device)
         B, Lq = ids.shape
-        out = ops.embed_gather(ids.reshape(-1), self._w["embed"])
+        e = self._w["embed"]
+        if hasattr(e, "wq"):          # nn.QuantizedEmbedding: dequantize of the looked-up rows
+            out = ops.dequant_w4(e.wq, e.sb, rows=ids.reshape(-1).contiguous())
+        else:
+            out = ops.embed_gather(ids.reshape(-1), e)
         return out.view(B, Lq, -1)
 
     # ------------------------------------------------------------------ cache
@@ -436,8 +470,12 @@ class LanguageModel:
         scale = float(getattr(t, "attn_scale", 0.0) or 0.0) or hd ** -0.5
         h = inputs_embeds.contiguous().clone()
         sec = self.mrope_section
+        def dense(x):        # 4-bit matrices are materialised as bf16 for the GEMMs of this (rare) path
+            return ops.dequant_w4(x.wq, x.sb) if hasattr(x, "wq") else x
+
         for i in range(t.num_hidden_layers):
-            w = self._w
+            w = {k: (dense(v) if k.startswith(f"{i}.") or k in ("head",) else v) for k, v in self._w.items()
+                 if k.startswith(f"{i}.") or k in ("inv_freq", "norm", "head")} if self.quantized else self._w
             kp, vp = pool.kpool[i], pool.vpool[i]          # this layer's K / V pools (flat views)
             xn = ops.rmsnorm(h, w[f"{i}.ln1"], t.rms_norm_eps)
             qkv = ops.gemm(xn, w[f"{i}.wqkv"], bias=w[f"{i}.bqkv"], epilogue=ops.EPI_BIAS)
@@ -529,7 +567,8 @@ class LanguageModel:
         st.seqs = seqs
         # a fused-tail step starts from h == embed[tok] (vlm_decode_args.flags); every later h is left behind by the
         # previous step's sampler tail
-        ops.embed_gather(st.tok[:B], self._w["embed"], out=st.h[:B])
+        if not hasattr(self._w["embed"], "wq"):
+            ops.embed_gather(st.tok[:B], self._w["embed"], out=st.h[:B])
         return st
 
     def _kv_struct(self, row0: int, decode: bool = False):
@@ -550,7 +589,8 @@ class LanguageModel:
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         kv = self._kv_struct(st.seq_row0, decode=True)
         check(L.vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
-        fused = bool(self.tuning.get("fused_tail")) and float(sampler_args.get("temperature", 0.0)) == 0.0
+        fused = bool(self.tuning.get("fused_tail")) and float(sampler_args.get("temperature", 0.0)) == 0.0 \
+            and not hasattr(self._w["embed"], "wq")          # the fused tail gathers bf16 embedding rows
         args = st.args(flags=_lib.DECODE_FUSED_TAIL if fused else 0, penalties=penalties, **sampler_args)
         if use_graph:
             key = (st.seq_row0, st.nsplit, fused, penalties.key() if penalties else None, tuple(sorted(sampler_args.items())))

@@ -30,6 +30,12 @@ class Model:
         if strict and (len(vt) + len(lm) != len(weights)):
             extra = [k for k in weights if not k.startswith(("vision_tower.", "language_model."))]
             raise ValueError(f"unexpected weight names: {extra[:5]}")
+        # a 4-bit checkpoint may quantize the tower's Linears too (utils.py:961 predicate): the tower runs on the bf16 MFMA
+        # GEMMs, so those weights are materialised once, on the device (vlm_dequant_w4)
+        from .. import quantized as Qz
+        for path in [k[:-len(".scales")] for k in list(vt) if k.endswith(".scales")]:
+            vt[path + ".weight"] = Qz.dequantize_bf16(Qz.take(vt, path), self.device)
+            del vt[path + ".scales"], vt[path + ".biases"]
         self.vision_tower.load_weights(vt)
         self.language_model.load_weights(lm)
         return self

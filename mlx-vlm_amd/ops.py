@@ -240,6 +240,44 @@ def apply_logit_penalties(logits, pen_args, push_tok=None):
     return logits
 
 
+def gemv_w4(x, wq, sb, bias=None, res=None, norm_w=None, out=None, eps=1e-6, epilogue=EPI_NONE):
+    """decode GEMV over MLX 4-bit weights: wq int32 [N, K/8] (uint32 words), sb int32 [N, K/64] (scale | bias << 16)"""
+    _dev(x, wq, sb, bias, res, norm_w, out)
+    M, K = x.shape
+    N = wq.shape[0]
+    n_out = N // 2 if epilogue & EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().vlm_gemv_w4(_p(x), _p(wq), _p(sb), _p(bias), _p(res), _p(norm_w), _p(out), M, N, K, x.stride(0),
+                                 out.stride(0), res.stride(0) if res is not None else 0, eps, epilogue, _stream()), "gemv_w4")
+    return out
+
+
+def gemv_w4_qkv_rope_kvwrite(h, norm_w, wq, sb, bqkv, Hq, Hkv, D, pos, slot, inv_freq, block_table, kpool, vpool, eps=1e-6,
+                             out=None, max_pages=None):
+    """gemv_qkv_rope_kvwrite over 4-bit q/k/v rows (wq / sb as gemv_w4)"""
+    _dev(h, norm_w, wq, sb, bqkv, pos, slot, inv_freq, block_table, kpool, vpool)
+    M, K = h.shape
+    if out is None:
+        out = torch.zeros(M, (Hq + 2 * Hkv) * D, dtype=torch.bfloat16, device=h.device)
+    check(_lib.lib().vlm_gemv_w4_qkv_rope_kvwrite(_p(h), _p(norm_w), eps, _p(wq), _p(sb), _p(bqkv), _p(out), out.stride(0), M,
+                                                  K, Hq, Hkv, D, _p(pos), _p(slot), _p(inv_freq), _p(block_table),
+                                                  block_table.shape[1] if block_table is not None else int(max_pages),
+                                                  _p(kpool), _p(vpool), _stream()), "gemv_w4_qkv_rope_kvwrite")
+    return out
+
+
+def dequant_w4(wq, sb, rows=None, out=None):
+    """bf16 rows of a 4-bit matrix: all of them (rows None) or a gather (embedding lookup)"""
+    _dev(wq, sb, rows, out)
+    N, K = wq.shape[0], wq.shape[1] * 8
+    n = N if rows is None else rows.numel()
+    if out is None:
+        out = torch.empty(n, K, dtype=torch.bfloat16, device=wq.device)
+    check(_lib.lib().vlm_dequant_w4(_p(wq), _p(sb), _p(rows), _p(out), n, K, out.stride(0), N, _stream()), "dequant_w4")
+    return out
+
+
 def gemm_set_staging(mode: int):
     """0 = automatic (LDS DMA when K % 64 == 0), 1 = always register staging (test / A-B knob)."""
     check(_lib.lib().vlm_gemm_set_staging(int(mode)), "gemm_set_staging")

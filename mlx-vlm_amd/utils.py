@@ -76,8 +76,9 @@ def read_sanitized_weights(model_path: str, model, config: dict) -> Dict[str, to
     weights: Dict[str, torch.Tensor] = {}
     for f in files:
         weights.update(load_file(f))
-    if config.get("quantization"):
-        raise NotImplementedError("MLX affine-quantized checkpoints are a 'next' row (SURVEY §8f.2)")
+    from .models import quantized as Qz
+
+    Qz.check_quantization(config.get("quantization"))          # affine 4-bit / group 64 (utils.py:916-967)
     weights = model.sanitize(weights)
     vt = {k: v for k, v in weights.items() if k.startswith("vision_tower.")}
     vt = {"vision_tower." + k: v for k, v in model.vision_tower.sanitize(

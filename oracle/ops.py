@@ -52,7 +52,10 @@ def _result_type(*tensors):
 
 def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None):
     """nn.Linear: y = x @ W.T + b (models/qwen2_vl/vision.py:129-130,168-169;
-    language.py:52-55; mlp.py:9-11).  fp32 accumulate, one rounding."""
+    language.py:52-55; mlp.py:9-11).  fp32 accumulate, one rounding.  A quantized weight (oracle/quant.py::QW - what
+    load_model's nn.quantize swaps in for a 4-bit checkpoint, utils.py:918-967) goes through its quantized matmul."""
+    if hasattr(w, "wq"):
+        return w.linear(x, b)
     y = x.to(F32) @ w.to(F32).T
     if b is not None:
         y = y + b.to(F32)

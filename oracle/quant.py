@@ -72,3 +72,45 @@ def quantized_linear(x, wq, scales, biases, bias=None, group_size: int = 64, bit
     if bias is not None:
         y = (y.to(F32) + bias.to(F32)).to(x.dtype)
     return y
+
+
+class QW:
+    """An MLX-quantized weight as the oracle's weight dicts carry it (what nn.QuantizedLinear / nn.QuantizedEmbedding hold)."""
+
+    def __init__(self, wq, scales, biases, group_size: int = 64, bits: int = 4):
+        self.wq, self.scales, self.biases, self.group_size, self.bits = wq, scales, biases, group_size, bits
+
+    @property
+    def dtype(self):
+        return self.scales.dtype
+
+    @property
+    def shape(self):
+        return (self.wq.shape[0], self.wq.shape[1] * 32 // self.bits)
+
+    def linear(self, x, bias=None):
+        return quantized_linear(x, self.wq, self.scales, self.biases, bias, self.group_size, self.bits)
+
+    def rows(self, idx):
+        """nn.QuantizedEmbedding.__call__: mx.dequantize of the gathered rows"""
+        idx = torch.as_tensor(idx, dtype=torch.long)
+        flat = idx.reshape(-1)
+        w = dequantize(self.wq[flat], self.scales[flat], self.biases[flat], self.group_size, self.bits)
+        return w.reshape(*idx.shape, -1)
+
+
+def quantize_checkpoint(W, predicate=None, group_size: int = 64, bits: int = 4):
+    """What `mlx_vlm.convert` (nn.quantize on the model, then save) leaves in a 4-bit checkpoint: every 2-D `<path>.weight`
+    accepted by `predicate(path, tensor)` becomes `<path>.weight` (uint32 words) + `<path>.scales` + `<path>.biases`.
+    -> (checkpoint-style dict of tensors, oracle-style dict with QW objects under `<path>.weight`)"""
+    ck, ow = {}, {}
+    for k, v in W.items():
+        path = k[: -len(".weight")] if k.endswith(".weight") else None
+        if path is not None and v.dim() == 2 and v.shape[1] % group_size == 0 and (predicate is None or predicate(path, v)):
+            wq, s, b = quantize_affine(v, group_size, bits)
+            ck[path + ".weight"], ck[path + ".scales"], ck[path + ".biases"] = wq, s, b
+            ow[k] = QW(wq, s, b, group_size, bits)
+        else:
+            ck[k] = v
+            ow[k] = v
+    return ck, ow

@@ -373,8 +373,10 @@ def lm_head(W, cfg: Cfg, h):
 
 
 def embed_tokens(W, input_ids):
-    """nn.Embedding (language.py:164,179)."""
-    return W["language_model.model.embed_tokens.weight"][torch.as_tensor(np.asarray(input_ids), dtype=torch.long)]
+    """nn.Embedding (language.py:164,179); nn.QuantizedEmbedding for a 4-bit checkpoint (dequantize of the rows)."""
+    e = W["language_model.model.embed_tokens.weight"]
+    idx = torch.as_tensor(np.asarray(input_ids), dtype=torch.long)
+    return e.rows(idx) if hasattr(e, "wq") else e[idx]
 
 
 def merge_input_ids_with_image_features(cfg: Cfg, image_features, inputs_embeds, input_ids):

@@ -768,3 +768,84 @@ def test_generate_batch_continuous_more_requests_than_rows(tiny):
                                             [r[2] for r in reqs], max_tokens=9)
     assert toks == singles
     assert stats.generation_tokens == 9 * 13 and stats.generation_tps > 0
+
+
+# ------------------------------------------------------------------------------------------------ MLX 4-bit checkpoints
+def _quantized_tiny(seed=1234):
+    """tiny Qwen2-VL with the language model quantized the way `mlx_vlm.convert -q` leaves it (vision tower skipped):
+    -> (cfg, checkpoint-style dict with .weight/.scales/.biases, oracle dict with QW weights)"""
+    from oracle import quant as Q
+
+    cfg = oq.tiny_cfg()
+    W = oq.random_weights(cfg, seed=seed, dtype=BF, std=0.05, embed_std=0.2)
+    ck, ow = Q.quantize_checkpoint(W, predicate=lambda p, v: p.startswith("language_model."))
+    return cfg, ck, ow
+
+
+def test_quantized_4bit_teacher_forced_decode_vs_oracle():
+    """4-bit language model (embed_tokens, every Linear, the tied head): prefill through dequant + bf16 GEMM, decode through
+    the fused 4-bit GEMVs, every teacher-forced step's logits against the oracle running the SAME quantized weights through
+    nn.QuantizedLinear / nn.QuantizedEmbedding restated (oracle/quant.py).  Tolerance as the bf16 tiny test (2e-2 rel-rms
+    per row); prefill multiplies bf16-rounded dequantized weights (the qmm form), decode the fp32 affine form (qmv)."""
+    cfg, ck, ow = _quantized_tiny()
+    model = build_product_model(cfg, ck, kv_pool_tokens=4096, max_seqs=4)
+    lm = model.language_model
+    assert lm.quantized
+    ids, pix, thw = synth_request(cfg, [(56, 84)], n_text=14, seed=44)
+    forced = np.random.default_rng(45).integers(3, 1000, 70)
+    ref = oq.decode_teacher_forced(ow, cfg, ids, torch.from_numpy(pix).to(BF), thw, forced)
+    f = model.get_input_embeddings(ids, torch.from_numpy(pix), image_grid_thw=thw)
+    cache = lm.make_cache()
+    out = lm(ids, f.inputs_embeds, cache=cache, position_ids=f.position_ids, rope_deltas=f.rope_deltas, logits_to_keep=1)
+    rows = [out.logits[0, -1].clone()]
+    for y in forced:
+        rows.append(lm(np.array([[int(y)]]), cache=cache).logits[0, -1].clone())
+    cache[0]._seq.release()
+    got = torch.stack(rows)
+    worst = 0.0
+    for i in range(ref.shape[0]):
+        e = _rel_rms_err(got[i], ref[i])
+        worst = max(worst, e)
+        assert e < 2e-2, (i, e)
+    ok, rep = bf16_close(got, ref, ulps=4, atol_rms=8e-2)
+    assert ok, rep
+    # the quantization itself is visible: the bf16 model's logits are far from these (the test is not vacuous)
+    W = oq.random_weights(cfg, seed=1234, dtype=BF, std=0.05, embed_std=0.2)
+    ref_bf = oq.decode_teacher_forced(W, cfg, ids, torch.from_numpy(pix).to(BF), thw, forced[:4])
+    assert _rel_rms_err(ref[:5], ref_bf) > 0.1
+    print(f"4-bit teacher-forced: worst row rel-rms {worst:.4f}")
+
+
+def test_quantized_4bit_checkpoint_load_and_generate(tmp_path):
+    """An MLX-format 4-bit checkpoint on disk (uint32 `weight`, `scales`, `biases`, config["quantization"]) through load()
+    -> generate_step with the captured decode graph, B = 1 and a batch of 2, against the oracle on the same weights."""
+    import json
+
+    from mlx_vlm_amd import load
+    from mlx_vlm_amd.generate import generate_step
+
+    cfg, ck, ow = _quantized_tiny(seed=4321)
+    ck = {k: (v.view(torch.uint32) if v.dtype == torch.int32 else v) for k, v in ck.items()}
+    _write_tiny_checkpoint(tmp_path, cfg, ck)
+    conf = json.loads((tmp_path / "config.json").read_text())
+    conf["quantization"] = {"group_size": 64, "bits": 4}
+    (tmp_path / "config.json").write_text(json.dumps(conf))
+    model, _ = load(str(tmp_path), kv_pool_tokens=4096, max_seqs=4)
+    assert model.language_model.quantized
+    ids, pix, thw = synth_request(cfg, [(56, 56)], n_text=11, seed=46)
+    n_new = 12
+    ref_toks, ref_logits = oq.generate_greedy(ow, cfg, ids, torch.from_numpy(pix).to(BF), thw, max_tokens=n_new,
+                                              return_logits=True)
+    toks, lps = [], []
+    for t, lp in generate_step(ids, model, torch.from_numpy(pix), None, max_tokens=n_new, temperature=0.0, image_grid_thw=thw):
+        toks.append(t)
+        lps.append(lp.float().cpu())
+    ok, n, margin = _tie_aware_equal(toks, ref_toks, ref_logits, tol=3e-2)
+    assert ok, (toks, ref_toks, n, margin)
+    ok, rep = bf16_close(lps[0], O.logprobs_from_logits(ref_logits[0][None])[0], ulps=2, atol_rms=3e-2)
+    assert ok, rep
+    # unsupported modes fail loudly
+    conf["quantization"] = {"group_size": 32, "bits": 8}
+    (tmp_path / "config.json").write_text(json.dumps(conf))
+    with pytest.raises(NotImplementedError):
+        load(str(tmp_path))

@@ -735,3 +735,109 @@ def test_gemm_rope2d_epilogue_equals_gemm_then_rope_pass(vops, M, H, hd):
     exact = float((got == ref).float().mean())
     ok, rep = bf16_close(got, ref, ulps=1, atol_rms=0.0)
     assert ok and exact > 0.999, (exact, rep)            # fp32 contraction of a*c - b*s may differ in the last place
+
+
+# ------------------------------------------------------------------ MLX affine 4-bit weights (csrc/gemv_w4.hip)
+def _q4(N, K, seed, scale=0.05):
+    """-> (oracle QW, device QuantW) of one seeded matrix quantized the way mx.quantize does (oracle/quant.py)"""
+    from mlx_vlm_amd.models import quantized as Qz
+    from oracle import quant as Q
+
+    w = rnd(N, K, seed=seed, scale=scale)
+    wq, s, b = Q.quantize_affine(w)
+    dq = Qz.take({"p.weight": wq.view(torch.uint32), "p.scales": s, "p.biases": b}, "p")
+    return Q.QW(wq, s, b), dq.to("cuda")
+
+
+@pytest.mark.parametrize("N,K", [(96, 256), (33, 1536), (7, 8960)])
+def test_dequant_w4_bit_exact_and_row_gather(vops, N, K):
+    """vlm_dequant_w4 == mx.dequantize restated (fp32 scale * q + bias, one rounding): BIT-EXACT, whole matrix and a
+    gather with repeats (nn.QuantizedEmbedding lookup)."""
+    from oracle import quant as Q
+
+    ow, dw = _q4(N, K, seed=200 + N)
+    ref = Q.dequantize(ow.wq, ow.scales, ow.biases)
+    assert torch.equal(vops.dequant_w4(dw.wq, dw.sb).cpu(), ref)
+    idx = torch.tensor([N - 1, 0, 5 % N, N - 1, 2 % N], dtype=torch.int32)
+    assert torch.equal(vops.dequant_w4(dw.wq, dw.sb, rows=idx.cuda()).cpu(), ref[idx.long()])
+    assert torch.equal(ow.rows(idx), ref[idx.long()])
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 512, 256), (2, 1536, 1536), (8, 8192, 1536), (4, 1536, 8960), (1, 302, 4096),
+                                   (1, 1024, 18944)])
+def test_gemv_w4_plain_bias_residual_vs_oracle(vops, M, N, K):
+    """vlm_gemv_w4 vs nn.QuantizedLinear restated (oracle/quant.py::quantized_linear): every (R, KC) instantiation
+    (K <= 2048 / 4096 / 10240 / 20480 chunks per lane; 4 rows per wave at N >= 8192), ragged N.  2 ulps + 2e-3 rms:
+    both sides accumulate the exact fp32 affine form, in different orders."""
+    ow, dw = _q4(N, K, seed=210 + M)
+    x, b, r = rnd(M, K, seed=211), rnd(N, seed=212, scale=0.3), rnd(M, N, seed=213)
+    ok, rep = bf16_close(vops.gemv_w4(x.cuda(), dw.wq, dw.sb), ow.linear(x), ulps=2)
+    assert ok, rep
+    ok, rep = bf16_close(vops.gemv_w4(x.cuda(), dw.wq, dw.sb, bias=b.cuda(), epilogue=vops.EPI_BIAS), ow.linear(x, b), ulps=2)
+    assert ok, rep
+    rr = r.cuda().clone()
+    out = vops.gemv_w4(x.cuda(), dw.wq, dw.sb, res=rr, out=rr, epilogue=vops.EPI_RESIDUAL)          # in place
+    ok, rep = bf16_close(out, O.add(r, ow.linear(x)), ulps=2)
+    assert ok, rep
+
+
+@pytest.mark.parametrize("M", [1, 4])
+def test_gemv_w4_norm_prologue_swiglu_and_head(vops, M):
+    """the decode MLP half over 4-bit weights: [RMSNorm + gate/up + SwiGLU] on interleaved rows, then the norm + lm_head
+    form (N >= 8192: 4 rows per wave)."""
+    from mlx_vlm_amd.models import quantized as Qz
+
+    K, I = 1536, 2048
+    h, nw = rnd(M, K, seed=220), (1 + 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(221))).to(BF)
+    og, dg = _q4(I, K, seed=222)
+    ou, du = _q4(I, K, seed=223)
+    dgu = Qz.interleave_rows(dg, du)
+    xn = O.rms_norm(h, nw, 1e-6)
+    ref = O.swiglu(og.linear(xn), ou.linear(xn))
+    out = vops.gemv_w4(h.cuda(), dgu.wq, dgu.sb, norm_w=nw.cuda(), eps=1e-6, epilogue=vops.EPI_SWIGLU)
+    ok, rep = bf16_close(out, ref, ulps=3)
+    assert ok, rep
+    oh, dh = _q4(9000, K, seed=224)
+    ok, rep = bf16_close(vops.gemv_w4(h.cuda(), dh.wq, dh.sb, norm_w=nw.cuda(), eps=1e-6), oh.linear(xn), ulps=2)
+    assert ok, rep
+
+
+@pytest.mark.parametrize("M", [1, 2])
+def test_gemv_w4_qkv_rope_kvwrite_fused(vops, M):
+    """[RMSNorm + 4-bit qkv GEMV + bias + M-RoPE + paged KV write]: the bf16 test above with quantized q / k / v rows
+    concatenated the way the loader packs them; the bias add is a second typed op after the matmul's rounding."""
+    from mlx_vlm_amd.models import quantized as Qz
+
+    Hq, Hkv, D, K = 12, 2, 128, 1536
+    h = rnd(M, K, seed=60)
+    nw = (1 + 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(61))).to(BF)
+    parts = [_q4(Hq * D, K, seed=230), _q4(Hkv * D, K, seed=231), _q4(Hkv * D, K, seed=232)]
+    dq = Qz.cat_rows([p[1] for p in parts])
+    bqkv = rnd((Hq + 2 * Hkv) * D, seed=63, scale=0.3)
+    pos = torch.tensor([37, 1000], dtype=torch.int32)[:M]
+    slot = torch.tensor([70, 3], dtype=torch.int32)[:M]
+    inv = O.mrope_inv_freq(D, 1e6)
+    sel = O.chunked_position_selector([16, 24, 24], D // 2)
+    xn = O.rms_norm(h, nw, 1e-6)
+    bs = [bqkv[:Hq * D], bqkv[Hq * D:(Hq + Hkv) * D], bqkv[(Hq + Hkv) * D:]]
+    qkv = torch.cat([p[0].linear(xn, b) for p, b in zip(parts, bs)], -1).view(M, Hq + 2 * Hkv, D)
+    p3 = pos.long()[None, :, None].expand(3, M, 1)
+    qr = O.mrope_apply(qkv[:, :Hq][:, :, None], p3, inv, sel, "fused")[:, :, 0]
+    kr = O.mrope_apply(qkv[:, Hq:Hq + Hkv][:, :, None], p3, inv, sel, "fused")[:, :, 0]
+    n_pages, max_pages = 16, 4
+    bt = (torch.arange(M * max_pages, dtype=torch.int32).reshape(M, max_pages) * 3 + 1) % n_pages
+    kpool = torch.zeros(n_pages, Hkv, D // 8, 64, 8, dtype=BF, device="cuda")
+    vpool = torch.zeros(n_pages, Hkv, D, 64, dtype=BF, device="cuda")
+    out = vops.gemv_w4_qkv_rope_kvwrite(h.cuda(), nw.cuda(), dq.wq, dq.sb, bqkv.cuda(), Hq, Hkv, D, pos.cuda(), slot.cuda(),
+                                        inv.cuda(), bt.cuda(), kpool, vpool)
+    ok, rep = bf16_close(out.view(M, Hq + 2 * Hkv, D)[:, :Hq], qr, ulps=2)
+    assert ok, rep
+    kp = kpool.cpu().permute(0, 1, 3, 2, 4).reshape(n_pages, Hkv, 64, D)
+    vp = vpool.cpu()[..., VSLOT].permute(0, 1, 3, 2)
+    for m in range(M):
+        page, within = int(bt[m, int(slot[m]) // 64]), int(slot[m]) % 64
+        ok, rep = bf16_close(kp[page, :, within], kr[m], ulps=2)
+        assert ok, (m, rep)
+        ok, rep = bf16_close(vp[page, :, within], qkv[m, Hq + Hkv:], ulps=2)
+        assert ok, (m, rep)
+    assert int((kpool != 0).sum().cpu()) <= M * Hkv * D and int((vpool != 0).sum().cpu()) <= M * Hkv * D
