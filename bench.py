@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: decode tokens/sec + vision-prefill images/sec, Qwen2-VL-2B bf16 (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload qwen2vl-2b | nanollava | qwen2vl-7b-b32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload qwen2vl-2b | nanollava | qwen2vl-7b-b32 | qwen2vl-2b-w4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -308,14 +308,17 @@ def pmc_traffic():
     return gu, per_tok
 
 
-def _load_synthetic(cfg_dict, model_pkg, rank, dev, **engine_kw):
-    """rank 0 materialises the synthetic replica, the others receive it over RCCL/xGMI (parallel.broadcast_weights)"""
+def _load_synthetic(cfg_dict, model_pkg, rank, dev, w4=False, **engine_kw):
+    """rank 0 materialises the synthetic replica, the others receive it over RCCL/xGMI (parallel.broadcast_weights).
+    w4: the language model as an MLX affine 4-bit checkpoint (random nibbles / scales / biases of that layout)."""
     from mlx_vlm_amd import parallel, synthetic
     from mlx_vlm_amd.utils import freeze_heap
 
     cfg = model_pkg.ModelConfig.from_dict(dict(cfg_dict))
     t0 = time.perf_counter()
     W = synthetic.random_weights(cfg, seed=0, device=dev, fill=(rank == 0))
+    if w4:
+        synthetic.quantize_random_(W)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     parallel.broadcast_weights(W, src=0)
@@ -461,6 +464,49 @@ def cpu_baseline_nanollava(threads):
                       f"image through the 27-layer SigLIP tower + projector; nothing extrapolated"}
 
 
+def workload_2b_w4(args, rank, ws, dev):
+    """the headline workload over an MLX affine 4-bit language model (what the reference's README runs:
+    Qwen2-VL-2B-Instruct-4bit) - bf16 activations / KV / vision tower, 4-bit + group-64 scale / bias weights in the decoder,
+    embedding and head.  Decode through the dequant-fused GEMVs (csrc/gemv_w4.hip)."""
+    from mlx_vlm_amd import parallel, synthetic
+    from mlx_vlm_amd.models import qwen2_vl
+
+    cfg, model, load = _load_synthetic(synthetic.QWEN2_VL_2B, qwen2_vl, rank, dev, w4=True, kv_pool_tokens=16384, max_seqs=16)
+    max_tokens = args.max_tokens or 256
+    req = build_request(cfg, 448, 128, seed=rank)
+    req = (req[0], req[1].to(dev), req[2])
+    for _ in range(args.warmup):
+        run_step(model, req, max_tokens, args.lookahead)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pre = dec = 0.0
+    for _ in range(args.steps):
+        a, b, _ = run_step(model, req, max_tokens, args.lookahead)
+        pre, dec = pre + a, dec + b
+    torch.cuda.synchronize()
+    parallel.barrier()
+    wall = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    dec_max, pre_max = parallel.max_over_ranks(dec, dev), parallel.max_over_ranks(pre, dev)
+    n_dec = args.steps * (max_tokens - 1)
+    us_tok = dec_max / n_dec * 1e6
+    lm_params = 28 * 46797824 + 233373696                       # decoder Linears + the tied head, read once per token
+    ctx_mid = int(req[0].shape[1]) + max_tokens // 2
+    bytes_per_token = lm_params * 9 // 16 + 1536 * 2 + 28672 * ctx_mid + 28672     # 4 bits + 32 / 64 bits per weight
+    return {"metric": "decode tokens/sec, Qwen2-VL-2B 4-bit (MLX affine, group 64)", "value": ws * n_dec / dec_max, "unit": "tokens/s",
+            "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 activations, int4 affine weights (fp32 accumulate)",
+            "data": "synthetic",
+            "config": {"workload": "Qwen2-VL-2B-Instruct dims, language model as an MLX affine 4-bit checkpoint (random nibbles / "
+                                   "scales / biases), batch=1 per GPU, one 448x448 image + 128 text tokens, greedy "
+                                   f"{max_tokens}-token decode, EOS disabled",
+                       "prompt_tokens": int(req[0].shape[1]), "max_tokens": max_tokens, "parallelism": f"dp{ws}"},
+            "ttft_ms": pre_max / args.steps * 1e3, "us_per_token": us_tok, "load": load, "distributed": _dist_info(ws),
+            "roofline": {"bound": "hbm", "kernel": "whole decode step (4-bit weights + bf16 KV)", "achieved": bytes_per_token / us_tok / 1e3,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_per_token / us_tok / 1e3 / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_token": bytes_per_token}}
+
+
 def workload_7b_b32(args, rank, ws, dev):
     """BASELINE configs[2]: Qwen2-VL-7B dims, 32 requests (336x336 image + 128-token prompt each) dealt data-parallel over
     the ranks by parallel.dp_batch_generate (length-sorted deal; every rank a continuous BatchGenerator of <= 8 rows; no
@@ -513,7 +559,7 @@ def main():
     ap.add_argument("--max-tokens", type=int, default=0, help="0 = the workload's own (256 / 64 / 64)")
     ap.add_argument("--lookahead", type=int, default=8)
     ap.add_argument("--vit-batch", type=int, default=16)
-    ap.add_argument("--workload", default="qwen2vl-2b", choices=["qwen2vl-2b", "nanollava", "qwen2vl-7b-b32"])
+    ap.add_argument("--workload", default="qwen2vl-2b", choices=["qwen2vl-2b", "nanollava", "qwen2vl-7b-b32", "qwen2vl-2b-w4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-hf", action="store_true", help="skip the HuggingFace torch-CPU second opinion of cpu_baseline")
     ap.add_argument("--no-extras", action="store_true", help="skip kernel rooflines / ViT throughput (profiling runs)")
@@ -528,7 +574,8 @@ def main():
     if rank == 0 and ws > 1:
         print(f"[bench] {ws} ranks, backend {_dist_info(ws)['backend']} (RCCL over xGMI), one process per GPU", file=sys.stderr, flush=True)
     if args.workload != "qwen2vl-2b":
-        out = (workload_nanollava if args.workload == "nanollava" else workload_7b_b32)(args, rank, ws, dev)
+        out = {"nanollava": workload_nanollava, "qwen2vl-7b-b32": workload_7b_b32, "qwen2vl-2b-w4": workload_2b_w4}[args.workload](
+            args, rank, ws, dev)
         if rank == 0:
             print(json.dumps(out), flush=True)
         parallel.barrier()

@@ -5,6 +5,8 @@ from __future__ import annotations
 
 from typing import Dict
 
+import zlib
+
 import torch
 
 QWEN2_VL_2B = dict(
@@ -115,4 +117,22 @@ def random_weights(cfg, seed: int = 0, device="cuda", dtype=torch.bfloat16, std:
             W[name] = torch.zeros(shape, dtype=dtype, device=device)
         else:
             W[name] = (torch.randn(shape, generator=g, device=device, dtype=torch.float32) * std).to(dtype)
+    return W
+
+
+def quantize_random_(W: Dict[str, torch.Tensor], prefix: str = "language_model.", seed: int = 1, std: float = 0.02):
+    """Synthetic MLX affine 4-bit checkpoint IN PLACE (no quantizer is part of the product - the reference's lives in
+    convert.py, out of scope): every 2-D `<prefix>...weight` with in % 64 == 0 becomes random nibbles (uint32 words as
+    int32 bit patterns, [out, in / 8]) + `scales` / `biases` [out, in / 64] such that the dequantized weights are
+    ~uniform with standard deviation `std` (step = std * sqrt(12) / 15, bias = -7.5 steps)."""
+    for name in [k for k in W if k.startswith(prefix) and k.endswith(".weight") and W[k].dim() == 2 and W[k].shape[1] % 64 == 0]:
+        N, K = W[name].shape
+        dev = W[name].device
+        g = torch.Generator(device=dev).manual_seed(seed + (zlib.crc32(name.encode()) & 0xFFFF))
+        path = name[: -len(".weight")]
+        W[name] = torch.randint(-2 ** 31, 2 ** 31 - 1, (N, K // 8), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+        step = std * (12 ** 0.5) / 15
+        sc = (step * (0.75 + 0.5 * torch.rand(N, K // 64, generator=g, device=dev))).to(torch.bfloat16)
+        W[path + ".scales"] = sc
+        W[path + ".biases"] = (sc.float() * -7.5).to(torch.bfloat16)
     return W
