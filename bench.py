@@ -312,7 +312,7 @@ def _load_synthetic(cfg_dict, model_pkg, rank, dev, w4=False, **engine_kw):
     """rank 0 materialises the synthetic replica, the others receive it over RCCL/xGMI (parallel.broadcast_weights).
     w4: the language model as an MLX affine 4-bit checkpoint (random nibbles / scales / biases of that layout)."""
     from mlx_vlm_amd import parallel, synthetic
-    from mlx_vlm_amd.utils import freeze_heap
+    from mlx_vlm_amd.utils import fit_host_threads, freeze_heap
 
     cfg = model_pkg.ModelConfig.from_dict(dict(cfg_dict))
     t0 = time.perf_counter()
@@ -330,6 +330,7 @@ def _load_synthetic(cfg_dict, model_pkg, rank, dev, w4=False, **engine_kw):
     del W
     torch.cuda.synchronize()
     freeze_heap()          # what load() does: no 100 ms cyclic-GC passes over the import heap inside timed loops
+    fit_host_threads()     # what load() does: torch's CPU pool capped at the container's CPU quota
     return cfg, model, {"load_s": time.perf_counter() - t0, "weight_bytes": nbytes, "broadcast_s": bcast_s}
 
 
@@ -419,7 +420,8 @@ def workload_nanollava(args, rank, ws, dev):
                                "frac": ips8 * tflop / MFMA_BF16_PEAK_TF, "tflop_per_image": tflop, "traffic": None,
                                "workload": "8 x 384x384 images per call (SigLIP tower + projector)"}
     if rank == 0 and ws == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_nanollava(min(os.cpu_count() or 1, 32))
+        from mlx_vlm_amd.utils import cpu_quota
+        out["cpu_baseline"] = cpu_baseline_nanollava(min(cpu_quota(), 32))
     return out
 
 
@@ -629,7 +631,8 @@ def main():
                 extras[key] = {"error": f"{type(e).__name__}: {e}"}
     cpu = None
     if rank == 0 and ws == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(min(os.cpu_count() or 1, 32), with_hf=not args.no_cpu_hf)
+        from mlx_vlm_amd.utils import cpu_quota
+        cpu = cpu_baseline(min(cpu_quota(), 32), with_hf=not args.no_cpu_hf)          # the cores the container may use
 
     if rank == 0:
         lm_params = 28 * 46797824 + 1536 + 233373696

@@ -182,12 +182,13 @@ class _PinnedRing:
         self.head = 0
         self.inflight = collections.deque()           # (start, end, event), oldest first
 
-    def stage(self, t, device):
+    def stage(self, t, device, out=None):
+        """out: device tensor (or slice) of t's shape / dtype to fill instead of allocating"""
         import torch
 
         n = t.numel() * t.element_size()
-        if n == 0 or n > self.buf.numel() // 2:
-            return t.to(device)                       # rare and large: plain (synchronising) copy
+        if n == 0 or n > self.buf.numel() // 2:       # rare and large: plain (synchronising) copy
+            return t.to(device) if out is None else out.copy_(t)
         start = (self.head + 255) & ~255
         if start + n > self.buf.numel():
             start = 0
@@ -207,8 +208,14 @@ class _PinnedRing:
         while self.inflight and self.inflight[0][2].query():
             self.inflight.popleft()
         view = self.buf[start:end].view(t.dtype).view(t.shape)
-        view.copy_(t)
-        out = view.to(device, non_blocking=True)
+        # plain single-threaded memmove, NOT view.copy_(t): torch's CPU copy fans out over every core it sees (128 on the
+        # MI355X hosts) and the OpenMP workers keep spinning after the region; inside a CPU-quota'd container that burns
+        # the cgroup's budget and the whole process is throttled for the rest of the 100 ms scheduler period - measured
+        # as single 80-90 ms "memcpy" calls of 2.7 MB in the continuous-batching loop (profiles/r02_continuous_diag.txt)
+        if not t.is_contiguous():
+            t = t.contiguous()
+        C.memmove(self.buf.data_ptr() + start, t.data_ptr(), n)
+        out = view.to(device, non_blocking=True) if out is None else out.copy_(view, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.inflight.append((start, end, ev))
@@ -236,3 +243,27 @@ def h2d(x, device):
     if _ring is None:
         _ring = _PinnedRing()
     return _ring.stage(t.contiguous(), device)
+
+
+def h2d_cat(parts, device):
+    """dim-0 concatenation of host tensors assembled ON the device: each part is staged through the pinned ring into its
+    slice of one device tensor.  A host-side torch.cat of the pixel rows of an admission (2.7 MB of fp32 per 336 x 336
+    image) is a pass over freshly faulted pageable memory - measured 4 ms per call inside the continuous-batching loop."""
+    global _ring
+    import numpy as np
+    import torch
+
+    ts = [torch.from_numpy(np.ascontiguousarray(p)) if isinstance(p, np.ndarray) else torch.as_tensor(p) for p in parts]
+    if len(ts) == 1:
+        return h2d(ts[0], device)
+    if any(t.device.type != "cpu" for t in ts) or not torch.cuda.is_available() or torch.device(device).type == "cpu" \
+            or any(t.dtype != ts[0].dtype or t.shape[1:] != ts[0].shape[1:] for t in ts):
+        return torch.cat([t.to(device) for t in ts], dim=0)
+    if _ring is None:
+        _ring = _PinnedRing()
+    out = torch.empty((sum(t.shape[0] for t in ts),) + tuple(ts[0].shape[1:]), dtype=ts[0].dtype, device=device)
+    off = 0
+    for t in ts:
+        _ring.stage(t.contiguous(), device, out=out[off:off + t.shape[0]])
+        off += t.shape[0]
+    return out

@@ -94,6 +94,20 @@ class _Admission:
         return sum(1 for b in self.batch[self.joined:] if b[0] not in self.removed)
 
 
+_ADMISSION_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _admission_stream(dev) -> "torch.cuda.Stream":
+    """ONE side stream per device for the life of the process: the caching allocator keeps a pool per stream, so a fresh
+    stream per generator would find no cached blocks and pay ~13 hipMalloc calls (tens of ms each) in its first admissions
+    (profiles/r02_continuous_diag.txt)."""
+    idx = torch.device(dev).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx not in _ADMISSION_STREAMS:
+        _ADMISSION_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return _ADMISSION_STREAMS[idx]
+
+
 class BatchGenerator:
     """`insert(prompts)` queues token-id prompts (shortest first, ar.py:2620-2623); every `next()` reports one token
     per running request and advances the batch by one step.  `model` is the full `Model` (vision tower + language
@@ -158,7 +172,7 @@ class BatchGenerator:
             self._pin_tok, self._pin_lp = self._pin_tok.pin_memory(), self._pin_lp.pin_memory()
         self._inflight: Optional[Tuple[int, torch.cuda.Event, List[int], float]] = None
         self._pending: List[_Admission] = []         # oldest first
-        self._side = torch.cuda.Stream(device=dev) if (async_prefill and self._cuda) else None
+        self._side = _admission_stream(dev) if (async_prefill and self._cuda) else None
         self._calls = 0
         self._idle_steps = 0
         self._width = 0

@@ -24,7 +24,7 @@ from typing import Any, Callable, Generator, List, Optional, Tuple, Union
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from .models import cache as cache_mod
 from .sample_utils import Sampler, make_sampler
 
@@ -389,7 +389,7 @@ def embed_requests(model, input_ids_list, pixel_values_list, grids):
     feats_all = None
     if any(has_pix):
         grid_all = np.concatenate([np.asarray(g) for g, h in zip(grids, has_pix) if h], axis=0)
-        pv = torch.cat([torch.as_tensor(p) for p, h in zip(pixel_values_list, has_pix) if h], dim=0)
+        pv = _lib.h2d_cat([p for p, h in zip(pixel_values_list, has_pix) if h], lm.device)
         feats_all = model.vision_tower(pv, grid_all)
     foff = 0
     mm = model.config.vision_config.spatial_merge_size ** 2

@@ -110,6 +110,39 @@ def freeze_heap():
         gc.freeze()
 
 
+def cpu_quota() -> int:
+    """CPUs this process may actually use: the cgroup v2 / v1 CFS quota when there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(q) // int(period)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, period = int(f.read()), int(g.read())
+            if q > 0:
+                n = min(n, max(1, q // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def fit_host_threads():
+    """torch sizes its CPU thread pool from the cores it SEES (256 on an MI355X host); inside a container with a CFS quota
+    (16 cores on the boxes measured) any CPU tensor op then wakes ~128 OpenMP workers that keep spinning after the region,
+    the cgroup's budget is gone within milliseconds and the whole process - the decode loop included - is frozen for the
+    rest of the 100 ms period (profiles/r02_continuous_diag.txt: 80-90 ms stalls in a 2.7 MB copy).  The engine's own host
+    path uses no parallel CPU ops; this caps torch's pool at the quota for whatever else runs in the process.
+    VLM_FIT_HOST_THREADS=0 opts out."""
+    if os.environ.get("VLM_FIT_HOST_THREADS", "1") == "0":
+        return
+    q = cpu_quota()
+    if torch.get_num_threads() > q:
+        torch.set_num_threads(q)
+
+
 def load(path_or_hf_repo: str, adapter_path=None, lazy: bool = False, revision=None, strict: bool = True, **kwargs):
     """reference utils.py:1065-1119 -> (model, processor).  Local paths only (no network in this build)."""
     if adapter_path is not None:
@@ -119,6 +152,7 @@ def load(path_or_hf_repo: str, adapter_path=None, lazy: bool = False, revision=N
     model = load_model(path_or_hf_repo, lazy=lazy, **kwargs)
     processor = load_processor(path_or_hf_repo, model.config)
     freeze_heap()
+    fit_host_threads()
     return model, processor
 
 
