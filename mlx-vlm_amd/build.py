@@ -19,8 +19,13 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libvlm_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -amdgpu-mfma-vgpr-form: MFMA accumulators in architectural VGPRs instead of AGPRs.  hipcc's default put the flash
+# attention accumulators (O^T, S^T) in AGPRs and then copied all 48 O^T registers to VGPRs at the top of EVERY key tile
+# (v_accvgpr_read, for the rare rescale branch) - a full drain of the previous tile's P.V MFMAs; with the VGPR form the
+# D = 80 kernel needs 218 registers instead of 172 + 80, D = 128 fits two waves per SIMD (212 vs 292), and the 128-tile
+# GEMM loses its 5472 accumulator moves.  Results are bit-identical (profiles/r02_attn_prefill_probe.txt).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-variable", "-Wno-pass-failed"]
+         "-Wno-unused-variable", "-Wno-pass-failed", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def sources():

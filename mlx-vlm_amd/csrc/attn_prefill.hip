@@ -18,20 +18,36 @@
 // the keys), and the exponentiated S^T registers ARE the B operand of the second
 // MFMA with no cross-lane movement: the 8 k-slots a lane feeds to MFMA #m of a
 // 32-key block are its registers 8m..8m+7, i.e. keys 16m+4h+{0..3} and
-// 16m+8+4h+{0..3} (h = lane>>5), and V^T is read from LDS with exactly that key
-// permutation (two ds_read_b64 per fragment).  K rows are padded by 16 B and the
-// V^T rows by 8 B so the 16-lane ds_read_b128 / 32-lane ds_read_b64 groups are
-// bank-conflict free.  The next K/V tile's global loads are issued before the
+// 16m+8+4h+{0..3} (h = lane>>5).  V stays ROW-MAJOR in LDS (straight 16-byte copies of the
+// [key][d] rows, like K) and the V^T fragments come out of gfx950's transposing LDS read
+// (ds_read_b64_tr_b16: in a 16-lane group lane i passes the address of row i/4, columns
+// 4 (i%4)..+3 of a [4 keys][16 d] block and receives column i of its 4 rows - measured with
+// scripts/tr_probe.hip), two per fragment with exactly that key permutation.  K rows are padded by
+// 16 B; the V row pitch is 96 / 160 elements (pitch in dwords = 16 or 48 mod 64: the 4 rows a
+// 32-lane half reads fall on disjoint banks).  The next K/V tile's global loads are issued before the
 // MFMAs of the current one (register staging, T14-style) and written to LDS after
 // the barrier.  Output is stored as 8-byte bf16x4 pieces (4 consecutive d).
 #include "common.cuh"
 #include "../../include/vlm_hip.h"
 
+#ifdef ATTN_STAMPS
+// measurement build only (scripts/attn_probe.hip): per-phase cycle sums of one workgroup, kept in SGPRs inside the loop
+__device__ unsigned long long g_attn_stamps[4][8];
+#define ST_DECL unsigned long long st_prev = 0, st_sum[6] = {0, 0, 0, 0, 0, 0}; const bool st_on = blockIdx.x == ATTN_STAMPS && blockIdx.y == 0
+#define ST_BEGIN() do { if (st_on) { __builtin_amdgcn_sched_barrier(0); st_prev = __builtin_amdgcn_s_memtime(); } } while (0)
+#define ST_MARK(i) do { if (st_on) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_sum[i] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define ST_DECL
+#define ST_BEGIN()
+#define ST_MARK(i)
+#endif
+
 namespace {
 
 constexpr int BQ = 128;   // query rows per workgroup (4 waves x 32)
 constexpr int BKV = 64;   // keys per tile
-constexpr int VT_LD = BKV + 4;
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 
 template <int D, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(
@@ -42,14 +58,13 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
   constexpr int NKS = D / 16;              // k-steps of the S^T product
   constexpr int NDB = DP / 32;             // 32-wide d blocks of O^T
   constexpr int K_LD = D + 8;              // padded K row (elements)
-  constexpr int KCH = BKV * D / 8;         // 16-byte chunks in a K tile
+  constexpr int KCH = BKV * D / 8;         // 16-byte chunks in a K (or V) tile
   constexpr int K_PER = (KCH + 255) / 256;
-  constexpr int VIT = (BKV / 2) * (D / 8); // (key pair, d-chunk) items in a V tile
-  constexpr int V_PER = (VIT + 255) / 256;
+  constexpr int V_LD = (DP % 128 == 32 || DP % 128 == 96) ? DP : DP + 32;   // V row pitch: 96 (D 64, 80), 160 (D 128)
 
   // double-buffered: tile t+1 is written while the other waves may still read tile t -> ONE barrier per tile
   __shared__ __attribute__((aligned(16))) bf16_t Ks2[2][BKV * K_LD];
-  __shared__ __attribute__((aligned(16))) bf16_t Vt2[2][DP * VT_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs2[2][BKV * V_LD];
 
   // ---- locate (segment, head, q block) ----
   int seg = 0, qb = 0, head = blockIdx.y;
@@ -77,6 +92,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
   __builtin_assume(tid >= 0 && tid < 256);
   const int qrow = qb * BQ + wave * 32 + (lane & 31);          // row inside the segment
   const int qrow_c = min(qrow, seg_len - 1);
+  const bool wave_rows = qb * BQ + wave * 32 < seg_len;          // wave-uniform
 
   // ---- Q fragments (B operand of S^T): q = lane&31, d = ks*16 + 8h .. +8 ----
   bf16x8_t qf[NKS];
@@ -91,7 +107,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
   const bf16_t* kbase = kp + (size_t)seg_start * k_stride + (size_t)kvh * D;
   const bf16_t* vbase = vp + (size_t)seg_start * v_stride + (size_t)kvh * D;
 
-  u32x4_t rk[K_PER], rv0[V_PER], rv1[V_PER];
+  u32x4_t rk[K_PER], rv[K_PER];
   // (loads are unconditional - surplus lanes re-read the last chunk - so the staging
   //  registers are fully defined and stay in VGPRs; only the LDS store is guarded)
   auto gload = [&](int t) {
@@ -100,43 +116,21 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
     for (int i = 0; i < K_PER; ++i) {
       const int c = min(tid + 256 * i, KCH - 1);
       const int row = c / (D / 8), ch = c % (D / 8);
-      rk[i] = *reinterpret_cast<const u32x4_t*>(kbase + (size_t)min(j0 + row, seg_len - 1) * k_stride + ch * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < V_PER; ++i) {
-      const int c = min(tid + 256 * i, VIT - 1);
-      const int kpair = c % (BKV / 2), ch = c / (BKV / 2);
-      const bf16_t* v0 = vbase + (size_t)min(j0 + 2 * kpair, seg_len - 1) * v_stride + ch * 8;
-      const bf16_t* v1 = vbase + (size_t)min(j0 + 2 * kpair + 1, seg_len - 1) * v_stride + ch * 8;
-      rv0[i] = *reinterpret_cast<const u32x4_t*>(v0);
-      rv1[i] = *reinterpret_cast<const u32x4_t*>(v1);
+      const size_t r = (size_t)min(j0 + row, seg_len - 1);
+      rk[i] = *reinterpret_cast<const u32x4_t*>(kbase + r * k_stride + ch * 8);
+      rv[i] = *reinterpret_cast<const u32x4_t*>(vbase + r * v_stride + ch * 8);
     }
   };
   auto lstore = [&](int buf) {
     bf16_t* Ks = Ks2[buf];
-    bf16_t* Vt = Vt2[buf];
+    bf16_t* Vs = Vs2[buf];
 #pragma unroll
     for (int i = 0; i < K_PER; ++i) {
       const int c = tid + 256 * i;
       if ((KCH % 256 == 0) || c < KCH) {
         const int row = c / (D / 8), ch = c % (D / 8);
         *reinterpret_cast<u32x4_t*>(&Ks[row * K_LD + ch * 8]) = rk[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < V_PER; ++i) {
-      const int c = tid + 256 * i;
-      if ((VIT % 256 == 0) || c < VIT) {
-        const int kpair = c % (BKV / 2), ch = c / (BKV / 2);
-        // element 2e (low halves) and 2e+1 (high halves) of the two keys
-#define VT_PUT(E, AW, BW)                                                                                         \
-  *reinterpret_cast<uint32_t*>(&Vt[(ch * 8 + 2 * (E)) * VT_LD + 2 * kpair]) = ((AW) & 0xffffu) | ((BW) << 16);     \
-  *reinterpret_cast<uint32_t*>(&Vt[(ch * 8 + 2 * (E) + 1) * VT_LD + 2 * kpair]) = ((AW) >> 16) | ((BW) & 0xffff0000u);
-        VT_PUT(0, rv0[i].x, rv1[i].x)
-        VT_PUT(1, rv0[i].y, rv1[i].y)
-        VT_PUT(2, rv0[i].z, rv1[i].z)
-        VT_PUT(3, rv0[i].w, rv1[i].w)
-#undef VT_PUT
+        *reinterpret_cast<u32x4_t*>(&Vs[row * V_LD + ch * 8]) = rv[i];
       }
     }
   };
@@ -164,6 +158,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
   // next iteration find them in L2 instead of paying the HBM latency with a prefetch distance of a single tile
   // (register staging cannot run two tiles ahead: 28 more VGPRs do not exist here).  The value is only "used" to keep
   // the load alive.
+  ST_DECL;
+  ST_BEGIN();
   uint32_t pf_sink = 0;
   const int pf_row = tid >> 2;
   const bf16_t* pf_base = ((tid & 2) ? vbase : kbase) + (tid & 1) * 64;
@@ -176,23 +172,30 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
       pf_val = *reinterpret_cast<const uint32_t*>(pf_base + (size_t)r * ((tid & 2) ? v_stride : k_stride));
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the loads up here (hipcc otherwise sinks the prefetch next to its use)
+    ST_MARK(0);                          // global loads of tile t+1 issued
     const int j0 = t * BKV;
     const bf16_t* Ks = Ks2[t & 1];
-    const bf16_t* Vt = Vt2[t & 1];
+    const bf16_t* Vs = Vs2[t & 1];
 
+    // a wave whose 32 query rows all lie past the segment end (the last query block of a 576-patch image: rows 512..639)
+    // only helps with the staging: its MFMA / VALU slots go to the other workgroup on the SIMD
+    if (wave_rows) {
     // ---- S^T = K . Q^T for two 32-key blocks ----
+    // (ks outer, kb inner: consecutive MFMAs go to different accumulators - a dependent 32x32x16 pair issues 64 cycles
+    //  apart, an independent one 32; the accumulation order of each element is unchanged)
     f32x16_t st[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
-      const bf16_t* krow = &Ks[(kb * 32 + (lane & 31)) * K_LD + 8 * h];
+    const bf16_t* krow = &Ks[(lane & 31) * K_LD + 8 * h];
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(krow + ks * 16);
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(krow + kb * 32 * K_LD + ks * 16);
         st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
       }
-    }
 
     // ---- online softmax (q = lane&31 is lane-local; lane^32 holds the other keys) ----
     // The loop is VALU-bound (22 MFMAs per tile vs the element-wise work on 32 scores per lane), so the
@@ -203,6 +206,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
     //   * "deferred max": the reference max m_run only moves when some row's tile max exceeds it by more
     //     than 2^8 (log2 domain) - P stays <= 256, exact in the normalised result, and the O / l rescale
     //     (48 accumulator registers) runs on a few tiles per query block instead of every tile.
+    ST_MARK(1);                          // QK^T MFMAs issued
     const bool need_mask = (j0 + BKV > seg_len) || (CAUSAL && j0 + BKV - 1 > qb * BQ + wave * 32);
     if (need_mask) {
 #pragma unroll
@@ -253,31 +257,42 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
         pf[kb][mm] = __builtin_bit_cast(bf16x8_t, u);
       }
 
+    ST_MARK(2);                          // softmax + P pack (waits for the QK^T results)
     // ---- O^T += V^T . P^T ----
+    // lane (i = lane & 15, g = lane >> 4): d = db * 32 + 16 (g & 1) + i, keys K0 + {0..3} and K0 + 8 + {0..3} with
+    // K0 = kb * 32 + 16 mm + 4 h; it passes the address of row K0 + i / 4, columns (its group's 16 d) + 4 (i % 4)
+    const bf16_t* vlane = &Vs[(4 * h + ((lane & 15) >> 2)) * V_LD + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db) {
-      const bf16_t* vrow = &Vt[(db * 32 + (lane & 31)) * VT_LD + 4 * h];
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
-        for (int mm = 0; mm < 2; ++mm) {
-          const uint2 lo = *reinterpret_cast<const uint2*>(vrow + kb * 32 + 16 * mm);
-          const uint2 hi = *reinterpret_cast<const uint2*>(vrow + kb * 32 + 16 * mm + 8);
-          const u32x4_t u = {lo.x, lo.y, hi.x, hi.y};
-          const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, u);
+        for (int db = 0; db < NDB; ++db) {      // db innermost: NDB independent accumulator chains interleave
+          const bf16_t* p0 = vlane + (kb * 32 + 16 * mm) * V_LD + db * 32;
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0));
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 8 * V_LD));
+          const bf16x8_t vf = __builtin_shufflevector(__builtin_bit_cast(bf16x4_t, lo), __builtin_bit_cast(bf16x4_t, hi), 0, 1, 2, 3, 4,
+                                                      5, 6, 7);
           ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][mm], ot[db], 0, 0, 0);
         }
-    }
+    }   // wave_rows
 
     // hipcc otherwise hoists the register-only part of lstore (the V^T pair packing) up between the QK^T MFMAs - with
     // the s_waitcnt vmcnt it needs: the MFMAs then wait for the NEXT tile's global loads (found in the .s)
     __builtin_amdgcn_sched_barrier(0);
+    ST_MARK(3);                          // P.V MFMAs issued
     if (more) lstore((t + 1) & 1);   // the other buffer: last read in iteration t-1, one barrier ago
+    ST_MARK(4);                          // staging registers -> LDS (waits for tile t+1's global loads)
     __syncthreads();
+    ST_MARK(5);                          // barrier
     pf_sink += pf_val;   // consumed only here, behind the staging loads' own wait: the prefetch never stalls anything
   }
 
   asm volatile("" ::"v"(pf_sink));
+#ifdef ATTN_STAMPS
+  if (st_on && lane == 0)
+    for (int i = 0; i < 6; ++i) g_attn_stamps[wave][i] = st_sum[i];
+#endif
   // ---- normalise and store: lane holds O^T[d = db*32 + (r&3) + 8(r>>2) + 4h][q = lane&31] ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
