@@ -58,187 +58,244 @@ __device__ __forceinline__ uint4 pair_order(uint4 v) {
   return o;
 }
 
-// lane chunk = 32 elements (4 q words); KC chunks per lane cover K <= 2048 * KC; R rows per wave
+// lane chunk = 32 elements (4 q words); KC chunks per lane cover K <= 2048 * KC; R rows per wave and pass.
+// A workgroup stages the activation rows ONCE and then walks row groups gw = blockIdx.x * 4 + wave, + 4 * gridDim.x, ...
+// (the launcher caps the grid at 8 workgroups per CU): with one group per workgroup every one of the 1120 (gate/up) or
+// 9496 (head) workgroups repeated the x load + RMSNorm + LDS round trip before its first FMA - 8.7 us for 7.7 MB and
+// 3.4 TB/s on the head (profiles/r02_w4_kernel_stats.txt).  The next group's weights are in flight (second register
+// set, when R * KC <= 4) while the current one is reduced.
 template <int R, int KC, int MB, int PRO, int EPI>
 __global__ __launch_bounds__(256) void gemv_w4_kernel(const bf16_t* __restrict__ x, const unsigned* __restrict__ Wq,
                                                       const unsigned* __restrict__ Wsb, const bf16_t* __restrict__ bias,
                                                       const bf16_t* __restrict__ res, const bf16_t* __restrict__ norm_w,
                                                       bf16_t* __restrict__ y, int N, int K, int ldx, int ldy, int ldres,
-                                                      float eps, W4RopeKv rk) {
+                                                      float eps, W4RopeKv rk, int n_groups) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // xs[MB][K] bf16 in pair order | red[8] f32
+  constexpr bool DBUF = R * KC <= 4;        // long rows (KC >= 5) are the few-row projections: one pass, no second set
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nch32 = K >> 5, nch8 = K >> 3, ngrp = K >> 6;
-  const int gw = blockIdx.x * 4 + wave;
+  const int gstride = gridDim.x * 4;
 
-  // ---- rows of this wave (same maps as gemv_bf16.hip)
-  int row[R];
-  bool rope_pair = false;
-  int rope_head = 0, rope_j = 0;
-  if (EPI == WEPI_ROPE_KV) {
-    const int half = rk.D >> 1, n_pair = (rk.Hq + rk.Hkv) * half;
-    if (gw < n_pair) {
-      rope_pair = true;
-      rope_head = gw / half;
-      rope_j = gw % half;
-      row[0] = rope_head * rk.D + rope_j;
-      row[R - 1] = row[0] + half;
+  // ---- rows of a group (same maps as gemv_bf16.hip)
+  auto rows_of = [&](int gw, int (&row)[R]) {
+    if (EPI == WEPI_ROPE_KV) {
+      const int half = rk.D >> 1, n_pair = (rk.Hq + rk.Hkv) * half;
+      if (gw < n_pair) {
+        row[0] = (gw / half) * rk.D + gw % half;
+        row[R - 1] = row[0] + half;
+      } else {
+        row[0] = (rk.Hq + rk.Hkv) * rk.D + 2 * (gw - n_pair);
+        row[R - 1] = row[0] + 1;
+      }
     } else {
-      row[0] = (rk.Hq + rk.Hkv) * rk.D + 2 * (gw - n_pair);
-      row[R - 1] = row[0] + 1;
-    }
-  } else {
 #pragma unroll
-    for (int r = 0; r < R; ++r) row[r] = gw * R + r;
-  }
-  const bool active = row[0] < N;
+      for (int r = 0; r < R; ++r) row[r] = gw * R + r;
+    }
+  };
+  // ---- every q chunk and its (scale, bias) word of a group's rows
+  auto load_w = [&](const int (&row)[R], u32x4_t (&wq)[R][KC], unsigned (&sb)[R][KC]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const size_t rr = (size_t)min(row[r], N - 1);
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const int ch = min(lane + 64 * c, nch32 - 1);
+        wq[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(Wq + rr * nch8 + (size_t)ch * 4));
+        sb[r][c] = Wsb[rr * ngrp + (ch >> 1)];
+      }
+    }
+  };
 
-  // ---- the weight stream first: every q chunk and its (scale, bias) word of the wave's rows
+  int gw = blockIdx.x * 4 + wave;
+  int row[R];
   u32x4_t wq[R][KC];
   unsigned sb[R][KC];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const size_t rr = (size_t)min(row[r], N - 1);
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      const int ch = min(lane + 64 * c, nch32 - 1);
-      wq[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(Wq + rr * nch8 + (size_t)ch * 4));
-      sb[r][c] = Wsb[rr * ngrp + (ch >> 1)];
-    }
-  }
+  rows_of(min(gw, n_groups - 1), row);
+  load_w(row, wq, sb);                                   // the weight stream first
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---- activation rows -> LDS as bf16 in pair order (normalised when PRO_RMSNORM)
+  // ---- activation rows -> LDS as bf16 in pair order (normalised when PRO_RMSNORM): x and the norm weight are read ONCE
+  //      (one global round trip), the sum of squares comes from the registers
   float* red = reinterpret_cast<float*>(smem + (size_t)MB * K * 2);
-  for (int m = 0; m < MB; ++m) {
-    const bf16_t* xr = x + (size_t)m * ldx;
-    float inv = 1.f;
-    if (PRO == WPRO_RMSNORM) {
-      float s = 0.f;
-      for (int i = tid; i < nch8; i += 256) {
-        const uint4 v = reinterpret_cast<const uint4*>(xr)[i];
-        const float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
+  constexpr int XCH = KC >= 2 ? 2 : 1;       // norm prologue: K <= 4096 (checked by the launcher); KC == 1 <=> K <= 2048
+  if (PRO == WPRO_RMSNORM) {
+    uint4 xv[MB][XCH], wv[XCH];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += f[j] * f[j];
-      }
-      s = wave_sum(s);
-      __syncthreads();
-      if (lane == 0) red[wave] = s;
-      __syncthreads();
-      inv = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
+    for (int u = 0; u < XCH; ++u) {
+      const int i = min(tid + 256 * u, nch8 - 1);
+      wv[u] = reinterpret_cast<const uint4*>(norm_w)[i];
+#pragma unroll
+      for (int m = 0; m < MB; ++m) xv[m][u] = reinterpret_cast<const uint4*>(x + (size_t)m * ldx)[i];
     }
-    uint4* xs = reinterpret_cast<uint4*>(smem + (size_t)m * K * 2);
-    for (int i = tid; i < nch8; i += 256) {
-      uint4 v = reinterpret_cast<const uint4*>(xr)[i];
-      if (PRO == WPRO_RMSNORM) {
-        const uint4 wu = reinterpret_cast<const uint4*>(norm_w)[i];
-        // nn.RMSNorm typed graph: bf16(x * inv) then * weight -> bf16 (as gemv_bf16.hip)
-        v.x = pack_bf2(bf_lo(wu.x) * rbf(bf_lo(v.x) * inv), bf_hi(wu.x) * rbf(bf_hi(v.x) * inv));
-        v.y = pack_bf2(bf_lo(wu.y) * rbf(bf_lo(v.y) * inv), bf_hi(wu.y) * rbf(bf_hi(v.y) * inv));
-        v.z = pack_bf2(bf_lo(wu.z) * rbf(bf_lo(v.z) * inv), bf_hi(wu.z) * rbf(bf_hi(v.z) * inv));
-        v.w = pack_bf2(bf_lo(wu.w) * rbf(bf_lo(v.w) * inv), bf_hi(wu.w) * rbf(bf_hi(v.w) * inv));
-      }
-      xs[i] = pair_order(v);
+    float ssq[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      float s = 0.f;
+#pragma unroll
+      for (int u = 0; u < XCH; ++u)
+        if (tid + 256 * u < nch8) {
+          const uint4 v = xv[m][u];
+          const float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s += f[j] * f[j];
+        }
+      ssq[m] = wave_sum(s);
+    }
+    if (lane == 0)
+#pragma unroll
+      for (int m = 0; m < MB; ++m) red[wave * MB + m] = ssq[m];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const float inv = rsqrtf((red[m] + red[MB + m] + red[2 * MB + m] + red[3 * MB + m]) / (float)K + eps);
+      uint4* xs = reinterpret_cast<uint4*>(smem + (size_t)m * K * 2);
+#pragma unroll
+      for (int u = 0; u < XCH; ++u)
+        if (tid + 256 * u < nch8) {
+          uint4 v = xv[m][u];
+          const uint4 wu = wv[u];
+          // nn.RMSNorm typed graph: bf16(x * inv) then * weight -> bf16 (as gemv_bf16.hip)
+          v.x = pack_bf2(bf_lo(wu.x) * rbf(bf_lo(v.x) * inv), bf_hi(wu.x) * rbf(bf_hi(v.x) * inv));
+          v.y = pack_bf2(bf_lo(wu.y) * rbf(bf_lo(v.y) * inv), bf_hi(wu.y) * rbf(bf_hi(v.y) * inv));
+          v.z = pack_bf2(bf_lo(wu.z) * rbf(bf_lo(v.z) * inv), bf_hi(wu.z) * rbf(bf_hi(v.z) * inv));
+          v.w = pack_bf2(bf_lo(wu.w) * rbf(bf_lo(v.w) * inv), bf_hi(wu.w) * rbf(bf_hi(v.w) * inv));
+          xs[tid + 256 * u] = pair_order(v);
+        }
+    }
+  } else {
+    for (int m = 0; m < MB; ++m) {
+      const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)m * ldx);
+      uint4* xs = reinterpret_cast<uint4*>(smem + (size_t)m * K * 2);
+      for (int i = tid; i < nch8; i += 256) xs[i] = pair_order(xr[i]);
     }
   }
   __syncthreads();
-  if (!active) return;
 
-  float acc[R][MB];
+  for (; gw < n_groups; gw += gstride) {
+    // the next group's weights: in flight while this one is multiplied and reduced
+    int row_n[R];
+    u32x4_t wq_n[DBUF ? R : 1][DBUF ? KC : 1];
+    unsigned sb_n[DBUF ? R : 1][DBUF ? KC : 1];
+    const bool more = gw + gstride < n_groups;
+    if constexpr (DBUF) {
+      rows_of(min(gw + gstride, n_groups - 1), row_n);
+      if (more) load_w(row_n, reinterpret_cast<u32x4_t(&)[R][KC]>(wq_n), reinterpret_cast<unsigned(&)[R][KC]>(sb_n));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    float acc[R][MB];
 #pragma unroll
-  for (int r = 0; r < R; ++r)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
+      for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
 #pragma unroll
-  for (int c = 0; c < KC; ++c) {
-    const int ch = lane + 64 * c;
-    if (ch < nch32) {
+    for (int c = 0; c < KC; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch32) {
 #pragma unroll
-      for (int m = 0; m < MB; ++m) {
-        const uint4* xs = reinterpret_cast<const uint4*>(smem + (size_t)m * K * 2) + (size_t)ch * 4;
-        // (ext_vector registers, constant indices only: plain arrays passed by pointer end up in scratch)
-        const u32x4_t* xv = reinterpret_cast<const u32x4_t*>(xs);
-        const u32x4_t xp0 = xv[0], xp1 = xv[1], xp2 = xv[2], xp3 = xv[3];
-        float sx = 0.f;
+        for (int m = 0; m < MB; ++m) {
+          const uint4* xs = reinterpret_cast<const uint4*>(smem + (size_t)m * K * 2) + (size_t)ch * 4;
+          // (ext_vector registers, constant indices only: plain arrays passed by pointer end up in scratch)
+          const u32x4_t* xv = reinterpret_cast<const u32x4_t*>(xs);
+          const u32x4_t xp0 = xv[0], xp1 = xv[1], xp2 = xv[2], xp3 = xv[3];
+          float sx = 0.f;
 #define SX4(V) ((bf_lo(V[0]) + bf_hi(V[0])) + (bf_lo(V[1]) + bf_hi(V[1])) + (bf_lo(V[2]) + bf_hi(V[2])) + (bf_lo(V[3]) + bf_hi(V[3])))
-        sx = SX4(xp0) + SX4(xp1) + SX4(xp2) + SX4(xp3);
+          sx = SX4(xp0) + SX4(xp1) + SX4(xp2) + SX4(xp3);
 #undef SX4
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          float d = 0.f;
-          const u32x4_t wv = wq[r][c];
-          d = w4_word(wv[0], xp0, d);
-          d = w4_word(wv[1], xp1, d);
-          d = w4_word(wv[2], xp2, d);
-          d = w4_word(wv[3], xp3, d);
-          const float sc = bf_lo(sb[r][c]), bi = bf_hi(sb[r][c]);
-          acc[r][m] += sc * (d - 128.f * sx) + bi * sx;
+          for (int r = 0; r < R; ++r) {
+            float d = 0.f;
+            const u32x4_t wv = wq[r][c];
+            d = w4_word(wv[0], xp0, d);
+            d = w4_word(wv[1], xp1, d);
+            d = w4_word(wv[2], xp2, d);
+            d = w4_word(wv[3], xp3, d);
+            const float sc = bf_lo(sb[r][c]), bi = bf_hi(sb[r][c]);
+            acc[r][m] += sc * (d - 128.f * sx) + bi * sx;
+          }
         }
       }
     }
-  }
 #pragma unroll
-  for (int r = 0; r < R; ++r)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int m = 0; m < MB; ++m) acc[r][m] = wave_sum(acc[r][m]);
+      for (int m = 0; m < MB; ++m) acc[r][m] = wave_sum(acc[r][m]);
 
-  if (EPI == WEPI_ROPE_KV) {
-    // R == 2: (d, d + D/2) of one q / k head, or two consecutive v rows; lane m stores batch row m (as gemv_bf16.hip)
-    float a0 = 0.f, a1 = 0.f;
+    if (EPI == WEPI_ROPE_KV) {
+      // R == 2: (d, d + D/2) of one q / k head, or two consecutive v rows; lane m stores batch row m (as gemv_bf16.hip)
+      const int half = rk.D >> 1, n_pair = (rk.Hq + rk.Hkv) * half;
+      const bool rope_pair = gw < n_pair;
+      const int rope_head = gw / half, rope_j = gw % half;
+      float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-      a0 = (lane == m) ? acc[0][m] : a0;
-      a1 = (lane == m) ? acc[R - 1][m] : a1;
-    }
-    if (lane < MB) {
-      const int m = lane;
-      const int r0 = min(row[0], N - 1), r1 = min(row[R - 1], N - 1);
-      // quantized_matmul rounds to bf16, the bias add is a second typed op
-      const float y0 = rbf(rbf(a0) + bf2f(bias[r0])), y1 = rbf(rbf(a1) + bf2f(bias[r1]));
-      const int e_slot = rk.slot[m], e_pos = rk.pos[m];
-      const size_t e_page = rk.block_table ? (size_t)rk.block_table[(size_t)m * rk.max_pages + (e_slot >> 6)]
-                                           : (size_t)m * rk.max_pages + (e_slot >> 6);
-      const int e_within = e_slot & 63;
-      if (rope_pair) {
-        float sn, cs;
-        sincosf((float)e_pos * rk.inv_freq[rope_j], &sn, &cs);
-        const float o0 = y0 * cs - y1 * sn, o1 = y1 * cs + y0 * sn;
-        if (rope_head < rk.Hq) {
-          y[(size_t)m * ldy + row[0]] = f2bf(o0);
-          y[(size_t)m * ldy + row[R - 1]] = f2bf(o1);
+      for (int m = 0; m < MB; ++m) {
+        a0 = (lane == m) ? acc[0][m] : a0;
+        a1 = (lane == m) ? acc[R - 1][m] : a1;
+      }
+      if (lane < MB) {
+        const int m = lane;
+        const int r0 = min(row[0], N - 1), r1 = min(row[R - 1], N - 1);
+        // quantized_matmul rounds to bf16, the bias add is a second typed op
+        const float y0 = rbf(rbf(a0) + bf2f(bias[r0])), y1 = rbf(rbf(a1) + bf2f(bias[r1]));
+        const int e_slot = rk.slot[m], e_pos = rk.pos[m];
+        const size_t e_page = rk.block_table ? (size_t)rk.block_table[(size_t)m * rk.max_pages + (e_slot >> 6)]
+                                             : (size_t)m * rk.max_pages + (e_slot >> 6);
+        const int e_within = e_slot & 63;
+        if (rope_pair) {
+          float sn, cs;
+          sincosf((float)e_pos * rk.inv_freq[rope_j], &sn, &cs);
+          const float o0 = y0 * cs - y1 * sn, o1 = y1 * cs + y0 * sn;
+          if (rope_head < rk.Hq) {
+            y[(size_t)m * ldy + row[0]] = f2bf(o0);
+            y[(size_t)m * ldy + row[R - 1]] = f2bf(o1);
+          } else {
+            const int g = rope_head - rk.Hq, d0 = rope_j, d1 = rope_j + (rk.D >> 1);
+            bf16_t* kb = rk.kpool + (e_page * rk.Hkv + g) * (size_t)(rk.D >> 3) * 512;
+            kb[((size_t)(d0 >> 3) * 64 + e_within) * 8 + (d0 & 7)] = f2bf(o0);
+            kb[((size_t)(d1 >> 3) * 64 + e_within) * 8 + (d1 & 7)] = f2bf(o1);
+          }
         } else {
-          const int g = rope_head - rk.Hq, d0 = rope_j, d1 = rope_j + (rk.D >> 1);
-          bf16_t* kb = rk.kpool + (e_page * rk.Hkv + g) * (size_t)(rk.D >> 3) * 512;
-          kb[((size_t)(d0 >> 3) * 64 + e_within) * 8 + (d0 & 7)] = f2bf(o0);
-          kb[((size_t)(d1 >> 3) * 64 + e_within) * 8 + (d1 & 7)] = f2bf(o1);
+          const int vr = row[0] - (rk.Hq + rk.Hkv) * rk.D, g = vr / rk.D, d = vr % rk.D;
+          bf16_t* vb = rk.vpool + ((e_page * rk.Hkv + g) * (size_t)rk.D + d) * 64 + vlm_vslot(e_within);
+          vb[0] = f2bf(y0);
+          vb[64] = f2bf(y1);
         }
-      } else {
-        const int vr = row[0] - (rk.Hq + rk.Hkv) * rk.D, g = vr / rk.D, d = vr % rk.D;
-        bf16_t* vb = rk.vpool + ((e_page * rk.Hkv + g) * (size_t)rk.D + d) * 64 + vlm_vslot(e_within);
-        vb[0] = f2bf(y0);
-        vb[64] = f2bf(y1);
       }
+    } else if (EPI & VLM_EPI_SWIGLU) {
+#pragma unroll
+      for (int r = 0; r < R; r += 2)
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+          if (lane == (r >> 1) * MB + m && row[r] + 1 < N)
+            y[(size_t)m * ldy + (row[r] >> 1)] = f2bf(swiglu_(rbf(acc[r][m]), rbf(acc[r + 1][m])));
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+          if (lane == r * MB + m && row[r] < N) {
+            float v = acc[r][m];
+            if (EPI & VLM_EPI_BIAS) v = rbf(v) + bf2f(bias[row[r]]);          // quantized_matmul rounds, then + bias (typed op)
+            if (EPI & VLM_EPI_RESIDUAL) v = rbf(v) + bf2f(res[(size_t)m * ldres + row[r]]);
+            y[(size_t)m * ldy + row[r]] = f2bf(v);
+          }
     }
-    return;
-  }
-  if (EPI & VLM_EPI_SWIGLU) {
+
+    if constexpr (DBUF) {
 #pragma unroll
-    for (int r = 0; r < R; r += 2)
+      for (int r = 0; r < R; ++r) {
+        row[r] = row_n[r];
 #pragma unroll
-      for (int m = 0; m < MB; ++m)
-        if (lane == (r >> 1) * MB + m && row[r] + 1 < N)
-          y[(size_t)m * ldy + (row[r] >> 1)] = f2bf(swiglu_(rbf(acc[r][m]), rbf(acc[r + 1][m])));
-    return;
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-      if (lane == r * MB + m && row[r] < N) {
-        float v = acc[r][m];
-        if (EPI & VLM_EPI_BIAS) v = rbf(v) + bf2f(bias[row[r]]);          // quantized_matmul rounds, then + bias (typed op)
-        if (EPI & VLM_EPI_RESIDUAL) v = rbf(v) + bf2f(res[(size_t)m * ldres + row[r]]);
-        y[(size_t)m * ldy + row[r]] = f2bf(v);
+        for (int c = 0; c < KC; ++c) {
+          wq[r][c] = wq_n[r][c];
+          sb[r][c] = sb_n[r][c];
+        }
       }
+    } else if (more) {
+      rows_of(gw + gstride, row);
+      load_w(row, wq, sb);
+    }
+  }
 }
 
 // W4 -> bf16 rows (mx.dequantize: scale * q + bias, fp32 multiply then add - not contracted - one rounding).  rows ==
@@ -279,15 +336,22 @@ inline int w4_err() {
 
 template <int R, int KC, int MB, int PRO, int EPI>
 int w4_launch(const W4Args& a, int n_waves) {
-  const size_t lds = (size_t)MB * a.K * 2 + 64;
+  const size_t lds = (size_t)MB * a.K * 2 + 256;      // + red[4][MB] f32
   auto kern = gemv_w4_kernel<R, KC, MB, PRO, EPI>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return VLM_ERR_HIP + (int)e;
   }
-  hipLaunchKernelGGL(kern, dim3(vlm_cdiv(n_waves, 4)), dim3(256), lds, a.st, (const bf16_t*)a.x, (const unsigned*)a.Wq,
+  static int per_cu = 0;                                    // resident workgroups per CU of this instantiation
+  if (per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 2;
+    per_cu = nb > 8 ? 8 : nb;
+  }
+  const int grid = min(vlm_cdiv(n_waves, 4), 256 * per_cu);   // the resident workgroups walk the row groups
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, a.st, (const bf16_t*)a.x, (const unsigned*)a.Wq,
                      (const unsigned*)a.Wsb, (const bf16_t*)a.bias, (const bf16_t*)a.res, (const bf16_t*)a.norm_w,
-                     (bf16_t*)a.y, a.N, a.K, a.ldx, a.ldy, a.ldres, a.eps, a.rk);
+                     (bf16_t*)a.y, a.N, a.K, a.ldx, a.ldy, a.ldres, a.eps, a.rk, n_waves);
   return w4_err();
 }
 
@@ -332,7 +396,8 @@ extern "C" int vlm_gemv_w4(const void* x, const void* Wq, const void* Wsb, const
   if ((epilogue & VLM_EPI_RESIDUAL) && !res) return VLM_ERR_ARG;
   if (K % 64 != 0 || ldx % 8 != 0) return VLM_ERR_SHAPE;
   if ((epilogue & VLM_EPI_SWIGLU) && (N % 2 != 0)) return VLM_ERR_SHAPE;
-  if ((size_t)M * K * 2 + 64 > 160 * 1024) return VLM_ERR_SHAPE;
+  if ((size_t)M * K * 2 + 256 > 160 * 1024) return VLM_ERR_SHAPE;
+  if (norm_w && K > 4096) return VLM_ERR_SHAPE;      // the norm prologue keeps x in registers: 2 chunks per thread
   W4Args a{x, Wq, Wsb, bias, res, norm_w, y, N, K, ldx, ldy, ldres, eps, W4RopeKv{}, (hipStream_t)stream};
 #define GO(P, E) return w4_m<P, E>(M, a)
   if (norm_w) {
@@ -360,7 +425,7 @@ extern "C" int vlm_gemv_w4_qkv_rope_kvwrite(const void* h, const void* norm_w, f
                                             void* stream) {
   if (!h || !norm_w || !Wq || !Wsb || !bqkv || !qkv || !pos || !slot || !inv_freq || !kpool || !vpool || max_pages <= 0)
     return VLM_ERR_ARG;
-  if (hidden % 64 || D % 16 || (size_t)M * hidden * 2 > 64 * 1024) return VLM_ERR_SHAPE;
+  if (hidden % 64 || hidden > 4096 || D % 16 || (size_t)M * hidden * 2 > 64 * 1024) return VLM_ERR_SHAPE;
   const int N = (Hq + 2 * Hkv) * D;
   W4Args a{h, Wq, Wsb, bqkv, nullptr, norm_w, qkv, N, hidden, hidden, ldq, 0, eps,
            W4RopeKv{(const int*)pos, (const int*)slot, (const float*)inv_freq, (const int*)block_table, max_pages, Hq, Hkv, D,
