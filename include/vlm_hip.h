@@ -83,6 +83,20 @@ int vlm_gemv_qkv_rope_kvwrite(const void* h, const void* norm_w, float eps, cons
                               void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D, const void* pos,
                               const void* slot, const void* inv_freq, const void* block_table, int max_pages,
                               void* kpool, void* vpool, void* stream);
+
+/* The same projections for a batched decode step of up to 16 rows: from 5 rows on (9 for the qkv form) the batch rows
+ * become the N dimension of v_mfma_f32_16x16x32_bf16 (csrc/gemv_mfma.hip) - one weight stream for all rows instead of M dot
+ * products per weight chunk.  `workspace` (vlm_gemv_workspace_bytes() bytes, ZERO-INITIALISED once, owned by the caller;
+ * launches sharing it must be ordered by one stream) lets projections with few output rows and a long K (o_proj, down)
+ * split K over workgroups: fp32 partial tiles + an arrival ticket per tile, summed in a fixed order (deterministic).
+ * NULL = no split; shapes that then do not fit fall back to the kernels of vlm_gemv_bf16 (M in {1, 2, 4, 8}). */
+size_t vlm_gemv_workspace_bytes(void);
+int vlm_gemv_bf16_ws(const void* x, const void* W, const void* bias, const void* res, const void* norm_w, void* y, int M, int N,
+                     int K, int ldx, int ldw, int ldy, int ldres, float eps, int epilogue, void* workspace, void* stream);
+int vlm_gemv_qkv_rope_kvwrite_ws(const void* h, const void* norm_w, float eps, const void* Wqkv, const void* bqkv, void* qkv, int ldq,
+                                 int M, int hidden, int Hq, int Hkv, int D, const void* pos, const void* slot,
+                                 const void* inv_freq, const void* block_table, int max_pages, void* kpool, void* vpool,
+                                 void* workspace, void* stream);
 int vlm_gemv_attn_out(const void* part_o, const void* part_ml, int nsplit, const void* Wo, void* h, int ldh, int M,
                       int N, int Hq, int D, void* stream);
 
@@ -325,6 +339,8 @@ int vlm_llm_decode_launches(void* handle);
 #define VLM_TUNE_FUSED_MLP 5        /* 1: batch-1 steps run o_proj + gate/up + down of a layer as ONE launch (csrc/mlp_fused.hip:
                                        weight slices register-resident from entry, in-launch hand-offs); needs >= 256 CUs and
                                        a supported shape, otherwise the step silently keeps the three launches */
+#define VLM_TUNE_MFMA_GEMV 6        /* 1 (default): decode steps of 3..16 rows run their projections on the matrix cores
+                                       (csrc/gemv_mfma.hip); 0: the v_dot2c GEMVs (rows in {4, 8}) - A/B knob */
 int vlm_llm_set_tuning(void* handle, int key, int value);
 int vlm_llm_get_tuning(void* handle, int key);
 /* diagnostic of the in-launch hand-offs (VLM_TUNE_FUSED_MLP): 0 = every bounded wait completed since the last call;

@@ -79,7 +79,7 @@ class VitArgs(C.Structure):
 
 
 DECODE_FUSED_TAIL = 1                       # vlm_decode_args.flags
-TUNE_PREFETCH, TUNE_PREFETCH_WGS, TUNE_PREFETCH_MASK, TUNE_PREFETCH_HEAD_MB, TUNE_DEBUG_SKIP, TUNE_FUSED_MLP = 0, 1, 2, 3, 4, 5  # vlm_llm_set_tuning keys
+TUNE_PREFETCH, TUNE_PREFETCH_WGS, TUNE_PREFETCH_MASK, TUNE_PREFETCH_HEAD_MB, TUNE_DEBUG_SKIP, TUNE_FUSED_MLP, TUNE_MFMA_GEMV = 0, 1, 2, 3, 4, 5, 6  # vlm_llm_set_tuning keys
 
 P = C.POINTER
 # name -> (restype, argtypes); every symbol include/vlm_hip.h declares
@@ -91,6 +91,10 @@ SIGNATURES = {
     "vlm_gemv_bf16": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_float, c_int, c_void_p]),
     "vlm_gemv_qkv_rope_kvwrite": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p] + [c_int] * 6
                                   + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p]),
+    "vlm_gemv_workspace_bytes": (C.c_size_t, []),
+    "vlm_gemv_bf16_ws": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_float, c_int, c_void_p, c_void_p]),
+    "vlm_gemv_qkv_rope_kvwrite_ws": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p] + [c_int] * 6
+                                     + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlm_gemv_attn_out": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "vlm_gemv_w4": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_int, c_void_p]),
     "vlm_gemv_w4_qkv_rope_kvwrite": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6

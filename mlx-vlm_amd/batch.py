@@ -39,8 +39,8 @@ from .models.cache import PAGE, PagedSequence
 from .models.qwen2_vl.language import DecodeState
 from .sample_utils import Sampler, make_sampler
 
-MAX_ROWS = 8          # widest decode step of the engine's GEMV kernels
-WIDTHS = (1, 2, 4, 8)
+MAX_ROWS = 16         # widest decode step: one N tile of the skinny-M MFMA GEMM (csrc/gemv_mfma.hip); 8 over 4-bit weights
+WIDTHS = (1, 2, 4, 8, 16)
 
 
 class _NullEvent:
@@ -141,7 +141,11 @@ class BatchGenerator:
         self.use_graph = use_graph
         self.async_prefill = async_prefill
         self.prefill_ahead = max(0, int(prefill_ahead)) if async_prefill else 0
-        self.completion_batch_size = max(1, min(int(completion_batch_size), MAX_ROWS))
+        max_rows = 8 if getattr(self.lm, "quantized", False) else MAX_ROWS       # the 4-bit GEMVs take 1 / 2 / 4 / 8 rows
+        pool_seqs = getattr(getattr(self.lm, "pool", None), "max_seqs", 64)
+        if pool_seqs < 2 * MAX_ROWS + 2:      # rows + admissions prefilled ahead + the scratch page each hold a sequence slot
+            max_rows = min(max_rows, 8)
+        self.completion_batch_size = max(1, min(int(completion_batch_size), max_rows))
         self.prefill_batch_size = max(1, int(prefill_batch_size))
         self.sampler = sampler or make_sampler()
         if not isinstance(self.sampler, Sampler):
@@ -476,7 +480,8 @@ class BatchGenerator:
         ev.record()
         self._inflight = (slot, ev, [row.uid for row in self._rows], time.perf_counter())
         longest = max(row.prompt_tokens + row.max_tokens for row in self._rows) + 2
-        st.nsplit = 1 if longest <= 2048 else max(2, min(32, (longest + 16 * PAGE - 1) // (16 * PAGE)))
+        # (16-row steps keep the single-pass attention: the split merge lives in the o_proj prologue of the <= 8-row GEMV)
+        st.nsplit = 1 if longest <= 2048 or width > 8 else max(2, min(32, (longest + 16 * PAGE - 1) // (16 * PAGE)))
         self._decode_rows(width)
         if self.compute_logprobs:
             self._lp[:n].copy_(self._row_logprobs(n))

@@ -46,7 +46,7 @@ constexpr size_t MAX_DECODE_GRAPHS = 16;
 
 // defaults: off until DESIGN.md's measurement picks them (vlm_llm_set_tuning)
 struct Tuning {
-  int prefetch = 0, wgs = 256, mask = 0x7f, head_mb = 96, debug_skip = 0, fused_mlp = 0;
+  int prefetch = 0, wgs = 256, mask = 0x7f, head_mb = 96, debug_skip = 0, fused_mlp = 0, mfma_gemv = 1;
 };
 
 // the second branch of a captured step (prefetch side chain)
@@ -60,6 +60,7 @@ struct Fork {
 struct Llm {
   Tuning tune;
   int* progress = nullptr;                // [0] pacing word, [1] exit counter of the persistent prefetcher (device)
+  void* mfma_ws = nullptr;                // split-K partial tiles + tickets of the skinny-M decode GEMM (gemv_mfma.hip)
   void* wscratch = nullptr;               // bf16 scratch for the prefill GEMMs over 4-bit weights (largest matrix)
   size_t wscratch_bytes = 0;
   char* fm_buf = nullptr;                 // fused-MLP hand-off buffers: [256 B err] then per layer [256 B epoch | D granules | I granules]
@@ -122,6 +123,12 @@ extern "C" int vlm_llm_create(const vlm_llm_config* cfg, void** handle) {
   if (!m) return 1;
   m->cfg = *cfg;
   m->layers.resize(cfg->n_layers);
+  // (allocated here, not lazily: the first decode step may already run inside a stream capture)
+  if (hipMalloc(&m->mfma_ws, vlm_gemv_mfma_ws_bytes()) != hipSuccess || hipMemset(m->mfma_ws, 0, vlm_gemv_mfma_ws_bytes()) != hipSuccess) {
+    if (m->mfma_ws) (void)hipFree(m->mfma_ws);
+    delete m;
+    return 1012;
+  }
   *handle = m;
   return 0;
 }
@@ -133,6 +140,7 @@ extern "C" int vlm_llm_destroy(void* handle) {
   if (m->progress) (void)hipFree(m->progress);
   if (m->fm_buf) (void)hipFree(m->fm_buf);
   if (m->wscratch) (void)hipFree(m->wscratch);
+  if (m->mfma_ws) (void)hipFree(m->mfma_ws);
   delete m;
   return 0;
 }
@@ -147,6 +155,7 @@ extern "C" int vlm_llm_set_tuning(void* handle, int key, int value) {
     case VLM_TUNE_PREFETCH_MASK: slot = &m->tune.mask; break;
     case VLM_TUNE_PREFETCH_HEAD_MB: if (value < 0) return 1; slot = &m->tune.head_mb; break;
     case VLM_TUNE_DEBUG_SKIP: slot = &m->tune.debug_skip; break;
+    case VLM_TUNE_MFMA_GEMV: if (value < 0 || value > 1) return 1; slot = &m->tune.mfma_gemv; break;
     case VLM_TUNE_FUSED_MLP: {
       if (value < 0 || value > 1) return 1;
       slot = &m->tune.fused_mlp;
@@ -207,6 +216,7 @@ extern "C" int vlm_llm_get_tuning(void* handle, int key) {
     case VLM_TUNE_PREFETCH_HEAD_MB: return m->tune.head_mb;
     case VLM_TUNE_DEBUG_SKIP: return m->tune.debug_skip;
     case VLM_TUNE_FUSED_MLP: return m->tune.fused_mlp;
+    case VLM_TUNE_MFMA_GEMV: return m->tune.mfma_gemv;
     default: return -1;
   }
 }
@@ -249,10 +259,11 @@ static int lin_gemm(Llm* m, const void* A, const void* W, const void* Wsb, const
   return vlm_gemm_bf16(A, W, bias, res, C, M, N, K, K, K, ldc, ldres, epi, stream);
 }
 // decode: y = epi(x . W^T) for B rows
-static int lin_gemv(const void* x, const void* W, const void* Wsb, const void* bias, const void* res, const void* norm_w,
+static int lin_gemv(Llm* m, const void* x, const void* W, const void* Wsb, const void* bias, const void* res, const void* norm_w,
                     void* y, int B, int N, int K, int ldy, int ldres, float eps, int epi, void* stream) {
   if (Wsb) return vlm_gemv_w4(x, W, Wsb, bias, res, norm_w, y, B, N, K, K, ldy, ldres, eps, epi, stream);
-  return vlm_gemv_bf16(x, W, bias, res, norm_w, y, B, N, K, K, K, ldy, ldres, eps, epi, stream);
+  // B >= 3: batch rows on the matrix cores (gemv_mfma.hip), K split over workgroups through the engine's workspace
+  return vlm_gemv_bf16_ex(x, W, bias, res, norm_w, y, B, N, K, K, K, ldy, ldres, eps, epi, m->tune.mfma_gemv, m->mfma_ws, stream);
 }
 
 extern "C" int vlm_llm_prefill(void* handle, const vlm_prefill_args* a, void* stream) {
@@ -385,8 +396,9 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
       TRY(vlm_gemv_w4_qkv_rope_kvwrite(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.wqkv_sb, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos,
                                        a->ctx, m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, stream)); ++n;
     } else {
-    TRY(vlm_gemv_qkv_rope_kvwrite(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos, a->ctx,
-                                  m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, stream)); ++n;
+    TRY(vlm_gemv_qkv_rope_kvwrite_ex(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos, a->ctx,
+                                     m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, m->tune.mfma_gemv, m->mfma_ws,
+                                     stream)); ++n;
     }
     }
     // attention over the pages (the new token is already in the cache: kv_len = ctx + 1)
@@ -429,20 +441,20 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
     }
     if (skip & 4) {
     } else if (a->nsplit == 1 || w.wo_sb) {
-      TRY(lin_gemv(a->attn, w.wo, w.wo_sb, nullptr, a->h, nullptr, a->h, B, D, Hq * hd, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
+      TRY(lin_gemv(m, a->attn, w.wo, w.wo_sb, nullptr, a->h, nullptr, a->h, B, D, Hq * hd, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
     } else {
       TRY(vlm_gemv_attn_out(a->part_o, a->part_ml, a->nsplit, w.wo, a->h, D, B, D, Hq, hd, stream)); ++n;
     }
     // act = swiglu(RMSNorm(h) Wgu^T)
     if (!(skip & 8))
-    TRY(lin_gemv(a->h, w.wgu, w.wgu_sb, nullptr, nullptr, w.ln2_w, a->act, B, 2 * c.inter, D, c.inter, 0, c.rms_eps, VLM_EPI_SWIGLU, stream)); ++n;
+    TRY(lin_gemv(m, a->h, w.wgu, w.wgu_sb, nullptr, nullptr, w.ln2_w, a->act, B, 2 * c.inter, D, c.inter, 0, c.rms_eps, VLM_EPI_SWIGLU, stream)); ++n;
     // h = h + act Wdown^T
     if (!(skip & 16))
-    TRY(lin_gemv(a->act, w.wdown, w.wdown_sb, nullptr, a->h, nullptr, a->h, B, D, c.inter, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
+    TRY(lin_gemv(m, a->act, w.wdown, w.wdown_sb, nullptr, a->h, nullptr, a->h, B, D, c.inter, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
   }
   // logits = RMSNorm(h) lm_head^T
   if (!(skip & 32))
-  TRY(lin_gemv(a->h, m->g.lm_head, m->g.lm_head_sb, nullptr, nullptr, m->g.final_norm_w, a->logits, B, c.vocab, D, c.vocab, 0,
+  TRY(lin_gemv(m, a->h, m->g.lm_head, m->g.lm_head_sb, nullptr, nullptr, m->g.final_norm_w, a->logits, B, c.vocab, D, c.vocab, 0,
                c.rms_eps, VLM_EPI_NONE, stream)); ++n;
   if (sample && a->penalties) {
     // logits processors (ar.py:360-364): the fed token joins the history, then bias / penalties on the step's logits

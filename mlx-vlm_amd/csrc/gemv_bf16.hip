@@ -25,6 +25,7 @@
 //     a workgroup split K for RW rows (N / RW workgroups keep all 256 CUs busy),
 //     partial sums meet in LDS.
 #include "common.cuh"
+#include "internal.h"
 #include "../../include/vlm_hip.h"
 
 namespace {
@@ -529,11 +530,38 @@ int launch_sk_m(int M, const Args& a) {
 extern "C" int vlm_gemv_bf16(const void* x, const void* W, const void* bias, const void* res, const void* norm_w,
                              void* y, int M, int N, int K, int ldx, int ldw, int ldy, int ldres, float eps,
                              int epilogue, void* stream) {
+  return vlm_gemv_bf16_ex(x, W, bias, res, norm_w, y, M, N, K, ldx, ldw, ldy, ldres, eps, epilogue, 1, nullptr, stream);
+}
+
+extern "C" size_t vlm_gemv_workspace_bytes(void) { return vlm_gemv_mfma_ws_bytes(); }
+
+extern "C" int vlm_gemv_bf16_ws(const void* x, const void* W, const void* bias, const void* res, const void* norm_w, void* y,
+                                int M, int N, int K, int ldx, int ldw, int ldy, int ldres, float eps, int epilogue,
+                                void* workspace, void* stream) {
+  return vlm_gemv_bf16_ex(x, W, bias, res, norm_w, y, M, N, K, ldx, ldw, ldy, ldres, eps, epilogue, 1, workspace, stream);
+}
+
+extern "C" int vlm_gemv_qkv_rope_kvwrite_ws(const void* h, const void* norm_w, float eps, const void* Wqkv, const void* bqkv,
+                                            void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D, const void* pos,
+                                            const void* slot, const void* inv_freq, const void* block_table, int max_pages,
+                                            void* kpool, void* vpool, void* workspace, void* stream) {
+  return vlm_gemv_qkv_rope_kvwrite_ex(h, norm_w, eps, Wqkv, bqkv, qkv, ldq, M, hidden, Hq, Hkv, D, pos, slot, inv_freq, block_table,
+                                      max_pages, kpool, vpool, 1, workspace, stream);
+}
+
+// mfma: 0 = v_dot2c kernels only; ws: the engine's workspace for vlm_gemv_mfma_try (nullptr: no K split over workgroups)
+VLM_INTERNAL int vlm_gemv_bf16_ex(const void* x, const void* W, const void* bias, const void* res, const void* norm_w,
+                                  void* y, int M, int N, int K, int ldx, int ldw, int ldy, int ldres, float eps,
+                                  int epilogue, int mfma, void* ws, void* stream) {
   if (!x || !W || !y || N <= 0 || K <= 0) return VLM_ERR_ARG;
   if ((epilogue & VLM_EPI_BIAS) && !bias) return VLM_ERR_ARG;
   if ((epilogue & VLM_EPI_RESIDUAL) && !res) return VLM_ERR_ARG;
   if (K % 8 != 0 || ldx % 8 != 0 || ldw % 8 != 0) return VLM_ERR_SHAPE;
   if ((epilogue & VLM_EPI_SWIGLU) && (N % 2 != 0)) return VLM_ERR_SHAPE;
+  if (mfma) {   // (M >= 3 by default) batch rows as the N dimension of the matrix cores (gemv_mfma.hip); -1: shape not handled there
+    const int rc = vlm_gemv_mfma_try(x, W, bias, res, norm_w, y, M, N, K, ldx, ldw, ldy, ldres, eps, epilogue, nullptr, ws, stream);
+    if (rc >= 0) return rc;
+  }
   if ((size_t)M * K * 2 > 64 * 1024 && (norm_w || K <= 3584)) return VLM_ERR_SHAPE;
   Args a{x, W, bias, res, norm_w, y, N, K, ldx, ldw, ldy, ldres, eps, RopeKvArgs{}, AttnProArgs{}, (hipStream_t)stream};
   if (K <= 3584) {
@@ -569,10 +597,26 @@ extern "C" int vlm_gemv_qkv_rope_kvwrite(const void* h, const void* norm_w, floa
                                          const void* pos, const void* slot, const void* inv_freq,
                                          const void* block_table, int max_pages, void* kpool, void* vpool,
                                          void* stream) {
+  return vlm_gemv_qkv_rope_kvwrite_ex(h, norm_w, eps, Wqkv, bqkv, qkv, ldq, M, hidden, Hq, Hkv, D, pos, slot, inv_freq, block_table,
+                                      max_pages, kpool, vpool, 1, nullptr, stream);
+}
+
+VLM_INTERNAL int vlm_gemv_qkv_rope_kvwrite_ex(const void* h, const void* norm_w, float eps, const void* Wqkv,
+                                              const void* bqkv, void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D,
+                                              const void* pos, const void* slot, const void* inv_freq,
+                                              const void* block_table, int max_pages, void* kpool, void* vpool, int mfma,
+                                              void* ws, void* stream) {
   if (!h || !norm_w || !Wqkv || !bqkv || !qkv || !pos || !slot || !inv_freq || !kpool || !vpool || max_pages <= 0)
     return VLM_ERR_ARG;
-  if (hidden % 8 || D % 16 || hidden > 3584 || (size_t)M * hidden * 2 > 64 * 1024) return VLM_ERR_SHAPE;
   const int N = (Hq + 2 * Hkv) * D;
+  if (mfma) {
+    const VlmRopeKv rk{(const int*)pos, (const int*)slot, (const float*)inv_freq, (const int*)block_table, max_pages, Hq, Hkv, D,
+                       (unsigned short*)kpool, (unsigned short*)vpool};
+    const int rc = vlm_gemv_mfma_try(h, Wqkv, bqkv, nullptr, norm_w, qkv, M, N, hidden, hidden, hidden, ldq, 0, eps, VLM_EPI_BIAS, &rk,
+                                     ws, stream);
+    if (rc >= 0) return rc;
+  }
+  if (hidden % 8 || D % 16 || hidden > 3584 || (size_t)M * hidden * 2 > 64 * 1024) return VLM_ERR_SHAPE;
   Args a{h, Wqkv, bqkv, nullptr, norm_w, qkv, N, hidden, hidden, hidden, ldq, 0, eps,
          RopeKvArgs{(const int*)pos, (const int*)slot, (const float*)inv_freq, (const int*)block_table, max_pages, Hq, Hkv,
                     D, (bf16_t*)kpool, (bf16_t*)vpool},

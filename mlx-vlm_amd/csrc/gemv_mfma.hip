@@ -1,0 +1,416 @@
+// Skinny-M decode GEMM for gfx950: the weight-streaming GEMV family of gemv_bf16.hip for 3 <= M <= 16 batch rows
+//     y[m][n] = epilogue( sum_k prologue(x)[m][k] * W[n][k] )
+// on the matrix cores.  Same call sites (the nn.Linear calls of a decoder layer at L = 1, mlx_vlm/models/qwen2_vl/
+// language.py:52-55,76,120, mlp.py:9-14, language.py:514-517 as_linear; RMSNorm 130-133,149-153,200; M-RoPE rope_utils.py:
+// 567-651; KVCache.update_and_fetch cache.py:345-367), used by a batched decode step (generate/ar.py:2584-2887).
+//
+// Why: the v_dot2c kernels re-read every activation chunk from LDS and issue M dot products per weight chunk and row: at
+// M = 8 the VALU, not HBM, sets their pace (gate/up 22 us vs 10.6 us at M = 1).  Here the batch rows are the N dimension
+// of v_mfma_f32_16x16x32_bf16: one instruction multiplies a 16-row x 32-k weight fragment with all (<= 16) batch rows, so
+// the kernel stays a weight stream for every M it accepts.
+//
+// Mapping.  A = W tile (16 output rows x 32 k), B = x^T (32 k x 16 batch rows; rows past M alias row M - 1 and their
+// columns of D are dropped), D[n][m] fp32.  An A fragment wants lane l to hold row l & 15 - ADJACENT lanes on DIFFERENT rows,
+// i.e. 16-byte pieces 3 KB apart when loaded straight from the weight matrix: the first version did that and ran 2.5 x
+// SLOWER than the v_dot2c kernels (27 us for the 4.7 MB o_proj: every wave instruction is 64 uncoalesced accesses,
+// profiles/r02_mfma_gemv.txt).  So the weights are loaded COALESCED (one instruction = 4 rows x 256 contiguous bytes),
+// all of a wave's chunks in flight before the first use, and each wave transposes chunk by chunk through a PRIVATE 4 KiB
+// LDS region (row pitch 272 B: conflict-free ds_read_b128 fragments; same-wave LDS operations execute in order, so the
+// region needs no barrier).  x^T fragments come from the workgroup's staged activations.
+//   unit   = (16-row tile, K segment ks of KS); the 4 waves of a workgroup interleave the unit's 128-wide K chunks (<= 6
+//            each, 24 loads of a lane in flight), their partial tiles meet in LDS
+//   KS > 1 (few row tiles x long K: o_proj, down): fp32 partial tiles go to a workspace, the LAST workgroup of a tile
+//            to arrive (agent-scope ticket) sums them in the fixed order ks = 0..KS-1 - deterministic - and runs the epilogue
+//   the activations (normalised when the RMSNorm prologue is on) are staged ONCE per workgroup, which then walks units
+//            blockIdx.x, + gridDim.x, ...: all of K (FULLX), or - long K, no norm: the down projection - only the K
+//            segment ks = blockIdx.x % KS that all its units share (the grid is a multiple of KS)
+// Epilogues as gemv_bf16.hip, one thread per (n, m) of the tile: bias, residual, SwiGLU on interleaved gate / up rows, and
+// M-RoPE + paged KV write, for which a tile's 16 rows are (d0 .. d0 + 7, d0 + D/2 .. d0 + D/2 + 7) of one q / k head so
+// that both elements of a rotation pair sit in the tile.
+#include <stdlib.h>
+
+#include "common.cuh"
+#include "internal.h"
+#include "../../include/vlm_hip.h"
+
+namespace {
+
+enum { MPRO_NONE = 0, MPRO_RMSNORM = 1 };
+constexpr int MEPI_ROPE_KV = 1 << 10;
+constexpr int NCW = 6;             // 128-wide K chunks per wave and unit
+constexpr int WREG = 16 * 272;      // bytes of a wave's private transposition region
+
+struct MfmaArgs {
+  const bf16_t *x, *W, *bias, *res, *norm_w;
+  bf16_t* y;
+  int M, N, K, ldx, ldw, ldy, ldres;
+  float eps;
+  VlmRopeKv rk;
+  float* ws;            // [n_tiles * KS][256] fp32 partial tiles (KS > 1)
+  unsigned* tickets;    // [n_tiles] arrivals of the current launch (zero between launches)
+  int n_tiles, KS, nblk, bpk;   // row tiles, K segments, 128-wide chunks of K, chunks per segment
+};
+
+template <int EPI>
+__device__ __forceinline__ int tile_row(const MfmaArgs& a, int tile, int r) {
+  if (EPI == MEPI_ROPE_KV) {
+    const int half = a.rk.D >> 1, tph = half >> 3, n_rot = (a.rk.Hq + a.rk.Hkv) * tph;
+    if (tile < n_rot) return (tile / tph) * a.rk.D + (tile % tph) * 8 + (r & 7) + (r >> 3) * half;
+    return (a.rk.Hq + a.rk.Hkv) * a.rk.D + (tile - n_rot) * 16 + r;
+  }
+  return tile * 16 + r;
+}
+
+// NCW: 128-wide K chunks per wave and unit (3: two register sets, the next unit's weights are in flight while this one
+// is multiplied; 6: one set).  XS > 0: the activations fit the prologue's registers (rows_per_wave * chunks_per_lane <= XS):
+// x and the norm weight are loaded ONCE, ahead of the weight stream (vector loads return in issue order), and the RMS
+// statistics come from the registers; otherwise the activations are staged before any weight load is issued.
+template <int PRO, int EPI, bool FULLX, int NCW, int XS>
+__global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // xs[M][P] | wreg[4][WREG] | part[4][256] f32 | red | flag
+  constexpr bool DBUF = NCW == 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+  const int kx = FULLX ? a.K : a.bpk * 128;                // staged elements per batch row
+  const int P = kx * 2 + 16;                               // row pitch (bytes): P / 16 odd -> conflict-free ds_read_b128
+  char* wreg = smem + (size_t)a.M * P + (size_t)wave * WREG;
+  float* part = reinterpret_cast<float*>(smem + (size_t)a.M * P + 4 * WREG);
+  float* red = part + 1024;
+  int* s_flag = reinterpret_cast<int*>(red + 64);
+  const int n_units = a.n_tiles * a.KS, G = gridDim.x;
+  const int mrow = min(r16, a.M - 1);
+
+  // chunk c of the unit (128 k): instruction j covers rows 4 j .. 4 j + 3, lane -> row 4 j + (lane >> 4), 16 bytes at
+  // k offset 8 (lane & 15): 256 contiguous bytes per row
+  auto load_w = [&](int u, u32x4_t (&wv)[NCW][4]) {
+    const int tile = u / a.KS, ks = u % a.KS;
+    const int kb0 = ks * a.bpk, kb1 = min(a.nblk, kb0 + a.bpk);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16_t* wr = a.W + (size_t)min(tile_row<EPI>(a, tile, 4 * j + g), a.N - 1) * a.ldw + r16 * 8;
+#pragma unroll
+      for (int i = 0; i < NCW; ++i) {
+        const int b = max(min(kb0 + wave + 4 * i, kb1 - 1), 0);   // clamped: surplus slots re-read the last chunk, unused
+        wv[i][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr + (size_t)b * 128));
+      }
+    }
+  };
+
+  // ---- activations -> LDS (bf16, rows at pitch P), loop form: before any weight load when it is the FULLX prologue
+  auto stage_x = [&](int kb0) {
+    const int nch = kx >> 3, k0 = FULLX ? 0 : kb0 * 128;
+    if (PRO == MPRO_RMSNORM) {
+      for (int m = wave; m < a.M; m += 4) {                  // sum of squares per batch row: wave w takes rows w, w + 4, ...
+        const uint4* xr = reinterpret_cast<const uint4*>(a.x + (size_t)m * a.ldx);
+        float ss = 0.f;
+        for (int i = lane; i < nch; i += 64) {
+          const uint4 v = xr[i];
+          const float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) red[m] = rsqrtf(ss / (float)a.K + a.eps);
+      }
+      __syncthreads();
+    }
+    for (int i = tid; i < a.M * nch; i += 256) {
+      const int m = i / nch, c = i % nch;
+      const int kc = min(k0 + c * 8, a.K - 8);               // segment tail past K: re-read, never multiplied
+      uint4 v = *reinterpret_cast<const uint4*>(a.x + (size_t)m * a.ldx + kc);
+      if (PRO == MPRO_RMSNORM) {
+        const float inv = red[m];
+        const uint4 wu = *reinterpret_cast<const uint4*>(a.norm_w + kc);
+        // nn.RMSNorm typed graph: bf16(x * inv) then * weight -> bf16 (as gemv_bf16.hip)
+        v.x = pack_bf2(bf_lo(wu.x) * rbf(bf_lo(v.x) * inv), bf_hi(wu.x) * rbf(bf_hi(v.x) * inv));
+        v.y = pack_bf2(bf_lo(wu.y) * rbf(bf_lo(v.y) * inv), bf_hi(wu.y) * rbf(bf_hi(v.y) * inv));
+        v.z = pack_bf2(bf_lo(wu.z) * rbf(bf_lo(v.z) * inv), bf_hi(wu.z) * rbf(bf_hi(v.z) * inv));
+        v.w = pack_bf2(bf_lo(wu.w) * rbf(bf_lo(v.w) * inv), bf_hi(wu.w) * rbf(bf_hi(v.w) * inv));
+      }
+      *reinterpret_cast<uint4*>(smem + (size_t)m * P + (size_t)c * 16) = v;
+    }
+  };
+
+  int u = blockIdx.x;
+  u32x4_t wvA[NCW][4], wvB[DBUF ? NCW : 1][DBUF ? 4 : 1];
+  const int kb_fix = FULLX ? 0 : (blockIdx.x % a.KS) * a.bpk;      // !FULLX: this workgroup's K segment (G % KS == 0)
+  if (XS > 0) {
+    // wave w owns batch rows w, w + 4, ..; slot s = (row index rw, chunk column cl): chunk lane + 64 cl of row w + 4 rw
+    constexpr int XA = XS > 0 ? XS : 1, NWC = XS > 6 ? 7 : 3;   // chunks per lane <= 3 (K <= 1536) in the 6-slot form
+    const int nch = kx >> 3, cpl = (nch + 63) >> 6, k0 = kb_fix * 128;
+    u32x4_t xr[XA], nw[NWC];     // (ext_vector arrays: HIP's uint4 struct arrays end up in scratch)
+#pragma unroll
+    for (int s_ = 0; s_ < XA; ++s_) {
+      const int rw = s_ / cpl, cl = s_ % cpl;
+      const int m = min(wave + 4 * rw, a.M - 1), c = min(lane + 64 * cl, nch - 1);
+      xr[s_] = *reinterpret_cast<const u32x4_t*>(a.x + (size_t)m * a.ldx + min(k0 + c * 8, a.K - 8));
+    }
+    if (PRO == MPRO_RMSNORM) {
+#pragma unroll
+      for (int cl = 0; cl < NWC; ++cl) nw[cl] = reinterpret_cast<const u32x4_t*>(a.norm_w)[min(lane + 64 * min(cl, cpl - 1), nch - 1)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    load_w(min(u, n_units - 1), wvA);                        // behind the small loads: they return first
+    __builtin_amdgcn_sched_barrier(0);
+    const int rpw = (a.M + 3) >> 2;
+    for (int rw = 0; rw < rpw; ++rw) {
+      const int m = wave + 4 * rw;
+      float inv = 1.f;
+      if (PRO == MPRO_RMSNORM) {
+        float ss = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < XA; ++s_)
+          if (s_ / cpl == rw && lane + 64 * (s_ % cpl) < nch) {
+            const u32x4_t v = xr[s_];
+            const float f[8] = {bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1]), bf_lo(v[2]), bf_hi(v[2]), bf_lo(v[3]), bf_hi(v[3])};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+          }
+        inv = rsqrtf(wave_sum(ss) / (float)a.K + a.eps);
+      }
+#pragma unroll
+      for (int s_ = 0; s_ < XA; ++s_)
+        if (s_ / cpl == rw) {
+          const int cl = s_ % cpl, c = lane + 64 * cl;
+          u32x4_t v = xr[s_];
+          if (PRO == MPRO_RMSNORM) {
+            u32x4_t wu = nw[0];
+#pragma unroll
+            for (int q = 1; q < NWC; ++q) wu = (cl == q) ? nw[q] : wu;
+            u32x4_t o;
+            o[0] = pack_bf2(bf_lo(wu[0]) * rbf(bf_lo(v[0]) * inv), bf_hi(wu[0]) * rbf(bf_hi(v[0]) * inv));
+            o[1] = pack_bf2(bf_lo(wu[1]) * rbf(bf_lo(v[1]) * inv), bf_hi(wu[1]) * rbf(bf_hi(v[1]) * inv));
+            o[2] = pack_bf2(bf_lo(wu[2]) * rbf(bf_lo(v[2]) * inv), bf_hi(wu[2]) * rbf(bf_hi(v[2]) * inv));
+            o[3] = pack_bf2(bf_lo(wu[3]) * rbf(bf_lo(v[3]) * inv), bf_hi(wu[3]) * rbf(bf_hi(v[3]) * inv));
+            v = o;
+          }
+          if (m < a.M && c < nch) *reinterpret_cast<u32x4_t*>(smem + (size_t)m * P + (size_t)c * 16) = v;
+        }
+    }
+    __syncthreads();
+  } else {
+    stage_x(kb_fix);
+    load_w(min(u, n_units - 1), wvA);
+    __syncthreads();
+  }
+
+  // one unit: transposition + MFMAs of this wave's chunks, cross-wave / cross-workgroup reduction, epilogue
+  auto unit = [&](int u, u32x4_t (&wv)[NCW][4]) __attribute__((always_inline)) {
+    const int tile = u / a.KS, ks = u % a.KS;
+    const int kb0 = ks * a.bpk, kb1 = min(a.nblk, kb0 + a.bpk);
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const char* xrow = smem + (size_t)mrow * P + g * 16 - (FULLX ? 0 : (size_t)kb0 * 256);
+#pragma unroll
+    for (int i = 0; i < NCW; ++i) {
+      const int b = kb0 + wave + 4 * i;
+      if (b < kb1) {                                          // wave-uniform
+        // chunk -> the wave's region [16 rows][272 B] (as loaded: row 4 j + g, byte 16 r16), then the fragments
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4_t*>(wreg + (4 * j + g) * 272 + r16 * 16) = wv[i][j];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          const u32x4_t af = *reinterpret_cast<const u32x4_t*>(wreg + r16 * 272 + kb * 64 + g * 16);
+          const u32x4_t bf = *reinterpret_cast<const u32x4_t*>(xrow + (size_t)b * 256 + kb * 64);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bf), acc, 0, 0,
+                                                        0);
+        }
+      }
+    }
+    if (!DBUF && u + G < n_units) load_w(u + G, wv);          // one register set: the next unit's weights go out now
+
+    // D[n = 4 g + i][m = r16]  ->  part[wave][n * 16 + m]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part[wave * 256 + (4 * g + i) * 16 + r16] = acc[i];
+    __syncthreads();
+    const int n_l = tid >> 4, m = tid & 15;
+    float v = (part[tid] + part[256 + tid]) + (part[512 + tid] + part[768 + tid]);
+    bool mine = true;
+    if (a.KS > 1) {
+      // partial tile -> workspace with agent-scope (L2-write-through) stores, complete before the ticket; the reader uses
+      // agent-scope loads.  (An agent-scope release FENCE here writes back the whole XCD L2 - 20 us per launch, measured.)
+      __hip_atomic_store(a.ws + (size_t)u * 256 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_flag = t == (unsigned)a.KS - 1u;
+      }
+      __syncthreads();
+      mine = *s_flag != 0;
+      if (mine) {
+        v = 0.f;
+        for (int k = 0; k < a.KS; ++k)
+          v += __hip_atomic_load(a.ws + ((size_t)tile * a.KS + k) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // every segment of this tile has arrived: re-arm (launches that share the array are ordered by their stream)
+        if (tid == 0) __hip_atomic_store(a.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (mine) {
+      const int n = tile_row<EPI>(a, tile, n_l);
+      if (EPI == MEPI_ROPE_KV || (EPI & VLM_EPI_SWIGLU)) {
+        __syncthreads();                  // (uniform: `mine` is per workgroup) every thread has read its part[] sums
+        part[tid] = v;
+        __syncthreads();
+      }
+      if (EPI == MEPI_ROPE_KV) {
+        const int half = a.rk.D >> 1, tph = half >> 3, n_rot = (a.rk.Hq + a.rk.Hkv) * tph;
+        if (m < a.M) {
+          const int e_slot = a.rk.slot[m];
+          const size_t e_page = a.rk.block_table ? (size_t)a.rk.block_table[(size_t)m * a.rk.max_pages + (e_slot >> 6)]
+                                                 : (size_t)m * a.rk.max_pages + (e_slot >> 6);
+          const int e_within = e_slot & 63;
+          if (tile < n_rot) {
+            if (n_l < 8) {
+              const int head = tile / tph, j = (tile % tph) * 8 + n_l, n1 = n + half;
+              const float y0 = rbf(v + bf2f(a.bias[n])), y1 = rbf(part[tid + 128] + bf2f(a.bias[n1]));
+              float sn, cs;
+              sincosf((float)a.rk.pos[m] * a.rk.inv_freq[j], &sn, &cs);
+              const float o0 = y0 * cs - y1 * sn, o1 = y1 * cs + y0 * sn;
+              if (head < a.rk.Hq) {
+                a.y[(size_t)m * a.ldy + n] = f2bf(o0);
+                a.y[(size_t)m * a.ldy + n1] = f2bf(o1);
+              } else {
+                const int gq = head - a.rk.Hq, d0 = j, d1 = j + half;
+                bf16_t* kb = a.rk.kpool + (e_page * a.rk.Hkv + gq) * (size_t)(a.rk.D >> 3) * 512;
+                kb[((size_t)(d0 >> 3) * 64 + e_within) * 8 + (d0 & 7)] = f2bf(o0);
+                kb[((size_t)(d1 >> 3) * 64 + e_within) * 8 + (d1 & 7)] = f2bf(o1);
+              }
+            }
+          } else if (n < a.N) {
+            const int vr = n - (a.rk.Hq + a.rk.Hkv) * a.rk.D, gq = vr / a.rk.D, d = vr % a.rk.D;
+            bf16_t* vb = a.rk.vpool + ((e_page * a.rk.Hkv + gq) * (size_t)a.rk.D + d) * 64 + vlm_vslot(e_within);
+            vb[0] = f2bf(rbf(v + bf2f(a.bias[n])));
+          }
+        }
+      } else if (EPI & VLM_EPI_SWIGLU) {
+        if (m < a.M && !(n_l & 1) && n + 1 < a.N)
+          a.y[(size_t)m * a.ldy + (n >> 1)] = f2bf(swiglu_(rbf(v), rbf(part[tid + 16])));
+      } else if (m < a.M && n < a.N) {
+        if (EPI & VLM_EPI_BIAS) v += bf2f(a.bias[n]);
+        if (EPI & VLM_EPI_RESIDUAL) v = rbf(v) + bf2f(a.res[(size_t)m * a.ldres + n]);
+        a.y[(size_t)m * a.ldy + n] = f2bf(v);
+      }
+    }
+    __syncthreads();                      // part[] is rewritten by the next unit
+  };
+
+  if constexpr (DBUF) {
+    auto& wvB_ = reinterpret_cast<u32x4_t(&)[NCW][4]>(wvB);
+    while (u < n_units) {
+      if (u + G < n_units) load_w(u + G, wvB_);
+      unit(u, wvA);
+      u += G;
+      if (u >= n_units) break;
+      if (u + G < n_units) load_w(u + G, wvA);
+      unit(u, wvB_);
+      u += G;
+    }
+  } else {
+    for (; u < n_units; u += G) unit(u, wvA);
+  }
+}
+
+template <int PRO, int EPI, bool FULLX, int NCW, int XS>
+int mfma_launch2(const MfmaArgs& a, size_t lds, int n_units, hipStream_t st) {
+  auto kern = gemv_mfma_kernel<PRO, EPI, FULLX, NCW, XS>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return VLM_ERR_HIP + (int)e;
+  }
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 1;
+  int grid = min(n_units, 256 * min(nb, 2));       // few resident workgroups: the activation staging is paid per workgroup
+  grid -= grid % a.KS;                             // a workgroup keeps its K segment (unit id = tile * KS + ks)
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
+}
+
+template <int PRO, int EPI, bool FULLX>
+int mfma_launch(const MfmaArgs& a, size_t lds, int n_units, hipStream_t st) {
+  const bool ncw3 = a.bpk <= 12;
+  const int kx = FULLX ? a.K : a.bpk * 128;
+  const int cpl = ((kx >> 3) + 63) / 64, slots = ((a.M + 3) / 4) * cpl;
+  constexpr int S6 = 6, S14 = 14;
+  if (ncw3) {
+    if (cpl <= 3 && slots <= 6) return mfma_launch2<PRO, EPI, FULLX, 3, S6>(a, lds, n_units, st);
+    if constexpr (PRO == MPRO_NONE)
+      if (slots <= 14) return mfma_launch2<PRO, EPI, FULLX, 3, S14>(a, lds, n_units, st);
+    return mfma_launch2<PRO, EPI, FULLX, 3, 0>(a, lds, n_units, st);
+  }
+  if (cpl <= 3 && slots <= 6) return mfma_launch2<PRO, EPI, FULLX, 6, S6>(a, lds, n_units, st);
+  return mfma_launch2<PRO, EPI, FULLX, 6, 0>(a, lds, n_units, st);
+}
+
+}  // namespace
+
+VLM_INTERNAL size_t vlm_gemv_mfma_ws_bytes(void) { return (size_t)4096 * 256 * 4 + 8192 * 4; }   // 4096 units of partials + tickets
+
+// -> VLM_OK, an error, or -1: shape not handled here (the caller takes the v_dot2c kernels)
+VLM_INTERNAL int vlm_gemv_mfma_try(const void* x, const void* W, const void* bias, const void* res, const void* norm_w, void* y, int M, int N,
+                                   int K, int ldx, int ldw, int ldy, int ldres, float eps, int epilogue, const VlmRopeKv* rk,
+                                   void* ws, void* stream) {
+  // A/B knobs: VLM_GEMV_MFMA=0 turns the path off, VLM_GEMV_MFMA_MIN_M moves the row count it starts at.  Default 5: a
+  // step costs the same here for 4, 8 or 16 rows (1.45 ms at 2B dims) while the v_dot2c step grows with the rows (1.25 ms at
+  // 4, 1.8 ms at 8): profiles/r02_mfma_gemv.txt.  The qkv + RoPE + KV-write form starts at 9 rows (6.2 vs 7.2 us at 8).
+  static const bool enabled = [] { const char* e = getenv("VLM_GEMV_MFMA"); return !e || atoi(e) != 0; }();
+  static const int min_m = [] { const char* e = getenv("VLM_GEMV_MFMA_MIN_M"); return e ? atoi(e) : 5; }();
+  if (!enabled || M < (rk ? max(min_m, 9) : min_m) || M > 16 || K % 128 || ldx % 8 || ldw % 8) return -1;
+  const bool rope = rk != nullptr;
+  if (rope && (rk->D % 16 || !norm_w || !bias)) return -1;
+  if (!rope && epilogue != VLM_EPI_NONE && epilogue != VLM_EPI_BIAS && epilogue != VLM_EPI_RESIDUAL && epilogue != VLM_EPI_SWIGLU &&
+      epilogue != (VLM_EPI_BIAS | VLM_EPI_RESIDUAL))
+    return -1;
+  if (norm_w && (epilogue & VLM_EPI_RESIDUAL)) return -1;
+  if ((epilogue & VLM_EPI_SWIGLU) && (N % 16)) return -1;
+  MfmaArgs a{};
+  a.x = (const bf16_t*)x; a.W = (const bf16_t*)W; a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res;
+  a.norm_w = (const bf16_t*)norm_w; a.y = (bf16_t*)y;
+  a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldres = ldres; a.eps = eps;
+  if (rope) {
+    a.rk = *rk;
+    if (N != (rk->Hq + 2 * rk->Hkv) * rk->D) return -1;
+    a.n_tiles = (rk->Hq + rk->Hkv) * (rk->D / 16) + rk->Hkv * rk->D / 16;
+  } else {
+    a.n_tiles = vlm_cdiv(N, 16);
+  }
+  a.nblk = K / 128;
+  // K segments.  A workgroup streams its 16-row x segment slice at a few tens of bytes per clock, so a unit of <= ~48 KB
+  // (12 chunks: the double-buffered form) is the target and splitting further only adds the cross-workgroup hand-off
+  // (qkv at KS = 3: 10 us, one dependent chain of partial store -> ticket -> partial loads -> epilogue)
+  int KS = vlm_cdiv(a.nblk, 4 * NCW);
+  if (ws)
+    while (vlm_cdiv(a.nblk, KS) > 12 && KS < 16 && (size_t)a.n_tiles * (KS + 1) <= 4096) ++KS;
+  if (KS > 1 && (!ws || a.n_tiles > 8192 || (size_t)a.n_tiles * KS > 4096)) return -1;
+  a.KS = KS;
+  a.bpk = vlm_cdiv(a.nblk, KS);
+  if (a.bpk > 4 * NCW) return -1;
+  a.ws = (float*)ws;
+  a.tickets = ws ? (unsigned*)((char*)ws + (size_t)4096 * 256 * 4) : nullptr;
+  const int n_units = a.n_tiles * KS;
+  const size_t tail = 4 * WREG + 4096 + 256 + 64;
+  const size_t lds_full = (size_t)M * ((size_t)K * 2 + 16) + tail, lds_seg = (size_t)M * ((size_t)a.bpk * 256 + 16) + tail;
+  const bool fullx = lds_full <= (norm_w ? 152 : 100) * 1024;      // (one workgroup per CU above 80 KB: only when the norm needs it)
+  if (!fullx && (norm_w || lds_seg > 100 * 1024)) return -1;
+  hipStream_t st = (hipStream_t)stream;
+#define GO(P, E) return fullx ? mfma_launch<P, E, true>(a, lds_full, n_units, st) : mfma_launch<P, E, false>(a, lds_seg, n_units, st)
+#define GOF(P, E) return mfma_launch<P, E, true>(a, lds_full, n_units, st)
+  if (rope) GOF(MPRO_RMSNORM, MEPI_ROPE_KV);
+  if (norm_w) {
+    switch (epilogue) {
+      case VLM_EPI_NONE: GOF(MPRO_RMSNORM, VLM_EPI_NONE);
+      case VLM_EPI_BIAS: GOF(MPRO_RMSNORM, VLM_EPI_BIAS);
+      case VLM_EPI_SWIGLU: GOF(MPRO_RMSNORM, VLM_EPI_SWIGLU);
+      default: return -1;
+    }
+  }
+  switch (epilogue) {
+    case VLM_EPI_NONE: GO(MPRO_NONE, VLM_EPI_NONE);
+    case VLM_EPI_BIAS: GO(MPRO_NONE, VLM_EPI_BIAS);
+    case VLM_EPI_RESIDUAL: GO(MPRO_NONE, VLM_EPI_RESIDUAL);
+    case VLM_EPI_BIAS | VLM_EPI_RESIDUAL: GO(MPRO_NONE, VLM_EPI_BIAS | VLM_EPI_RESIDUAL);
+    case VLM_EPI_SWIGLU: GO(MPRO_NONE, VLM_EPI_SWIGLU);
+    default: return -1;
+  }
+#undef GO
+#undef GOF
+}

@@ -56,3 +56,28 @@ VLM_INTERNAL int vlm_mlp_fused_supported(int D, int I, int KO);
 VLM_INTERNAL int vlm_mlp_fused_launch(const void* attn, void* h, const void* wo, const void* ln2_w, const void* wgu,
                                       const void* wdown, void* g_h, void* g_act, void* epoch, void* err, float eps, int D,
                                       int I, int KO, void* stamps, int mode, void* stream);
+
+// ---- skinny-M decode GEMM on the matrix cores (csrc/gemv_mfma.hip): 3 <= M <= 16 batch rows
+struct VlmRopeKv {
+  const int* pos;            // [M] rope position (all three M-RoPE axes are equal for a decoded text token)
+  const int* slot;           // [M] KV slot (= tokens already in the cache)
+  const float* inv_freq;     // [D/2]
+  const int* block_table;    // [M][max_pages] or nullptr (identity layout)
+  int max_pages, Hq, Hkv, D;
+  unsigned short* kpool;     // [page][Hkv][D/8][64][8]
+  unsigned short* vpool;     // [page][Hkv][D][64 key slots]
+};
+VLM_INTERNAL size_t vlm_gemv_mfma_ws_bytes(void);
+// -> 0 done, > 0 error, -1 shape not handled (take the v_dot2c kernels).  ws: zero-initialised workspace of
+// vlm_gemv_mfma_ws_bytes() owned by the caller (one per engine: launches that share it must be stream-ordered), or nullptr
+// (no K split across workgroups).  rk != nullptr: the qkv projection with M-RoPE + paged KV write.
+VLM_INTERNAL int vlm_gemv_mfma_try(const void* x, const void* W, const void* bias, const void* res, const void* norm_w, void* y,
+                                   int M, int N, int K, int ldx, int ldw, int ldy, int ldres, float eps, int epilogue,
+                                   const VlmRopeKv* rk, void* ws, void* stream);
+VLM_INTERNAL int vlm_gemv_bf16_ex(const void* x, const void* W, const void* bias, const void* res, const void* norm_w, void* y,
+                                  int M, int N, int K, int ldx, int ldw, int ldy, int ldres, float eps, int epilogue, int mfma,
+                                  void* ws, void* stream);
+VLM_INTERNAL int vlm_gemv_qkv_rope_kvwrite_ex(const void* h, const void* norm_w, float eps, const void* Wqkv, const void* bqkv,
+                                              void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D, const void* pos,
+                                              const void* slot, const void* inv_freq, const void* block_table, int max_pages,
+                                              void* kpool, void* vpool, int mfma, void* ws, void* stream);

@@ -254,7 +254,7 @@ class LanguageModel:
     # decode-step tuning (results are identical under every setting; defaults from the measurements in DESIGN.md,
     # environment overrides for A/B runs): VLM_DECODE_PREFETCH 0 / 1 (event-paced side branch) / 2 (persistent side
     # kernel), VLM_DECODE_PREFETCH_MASK, VLM_DECODE_PREFETCH_WGS, VLM_DECODE_FUSED_TAIL 0 / 1
-    TUNING_DEFAULTS = {"prefetch": 0, "prefetch_wgs": 256, "prefetch_mask": 0x7f, "prefetch_head_mb": 96, "fused_tail": 1,
+    TUNING_DEFAULTS = {"prefetch": 0, "prefetch_wgs": 256, "prefetch_mask": 0x7f, "prefetch_head_mb": 96, "fused_tail": 1, "mfma_gemv": 1,
                        "fused_mlp": 0}
 
     def apply_tuning(self, **over):
@@ -268,7 +268,7 @@ class LanguageModel:
         self.tuning = t
         for key, name in ((_lib.TUNE_PREFETCH, "prefetch"), (_lib.TUNE_PREFETCH_WGS, "prefetch_wgs"),
                           (_lib.TUNE_PREFETCH_MASK, "prefetch_mask"), (_lib.TUNE_PREFETCH_HEAD_MB, "prefetch_head_mb"),
-                          (_lib.TUNE_FUSED_MLP, "fused_mlp")):
+                          (_lib.TUNE_FUSED_MLP, "fused_mlp"), (_lib.TUNE_MFMA_GEMV, "mfma_gemv")):
             check(L.vlm_llm_set_tuning(self._handle, key, int(t[name])), "llm_set_tuning")
         for st in getattr(self, "_decode_states", {}).values():
             st.graph_key = None          # the engine dropped its captured steps

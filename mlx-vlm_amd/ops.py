@@ -70,6 +70,46 @@ def gemv(x, w, bias=None, res=None, norm_w=None, out=None, eps=1e-6, epilogue=EP
     return out
 
 
+_gemv_ws = {}
+
+
+def gemv_workspace(device):
+    """zero-initialised split-K workspace of the batched (5..16 row) decode projections, one per device for callers of the
+    operator layer (the engine owns its own)"""
+    key = torch.device(device).index or 0
+    if key not in _gemv_ws:
+        _gemv_ws[key] = torch.zeros(_lib.lib().vlm_gemv_workspace_bytes(), dtype=torch.uint8, device=device)
+    return _gemv_ws[key]
+
+
+def gemv_ws(x, w, bias=None, res=None, norm_w=None, out=None, eps=1e-6, epilogue=EPI_NONE):
+    """gemv for a batched decode step (up to 16 rows), K split over workgroups through the workspace where it pays"""
+    _dev(x, w, bias, res, norm_w, out)
+    M, K = x.shape
+    N = w.shape[0]
+    n_out = N // 2 if epilogue & EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().vlm_gemv_bf16_ws(_p(x), _p(w), _p(bias), _p(res), _p(norm_w), _p(out), M, N, K, x.stride(0),
+                                      w.stride(0), out.stride(0), res.stride(0) if res is not None else 0, eps, epilogue,
+                                      _p(gemv_workspace(x.device)), _stream()), "gemv_ws")
+    return out
+
+
+def gemv_qkv_rope_kvwrite_ws(h, norm_w, wqkv, bqkv, Hq, Hkv, D, pos, slot, inv_freq, block_table, kpool, vpool, eps=1e-6,
+                             out=None, max_pages=None):
+    _dev(h, norm_w, wqkv, bqkv, pos, slot, inv_freq, block_table, kpool, vpool)
+    M, K = h.shape
+    if out is None:
+        out = torch.zeros(M, (Hq + 2 * Hkv) * D, dtype=torch.bfloat16, device=h.device)
+    check(_lib.lib().vlm_gemv_qkv_rope_kvwrite_ws(_p(h), _p(norm_w), eps, _p(wqkv), _p(bqkv), _p(out), out.stride(0), M, K,
+                                                  Hq, Hkv, D, _p(pos), _p(slot), _p(inv_freq), _p(block_table),
+                                                  block_table.shape[1] if block_table is not None else int(max_pages),
+                                                  _p(kpool), _p(vpool), _p(gemv_workspace(h.device)), _stream()),
+          "gemv_qkv_rope_kvwrite_ws")
+    return out
+
+
 def gemv_qkv_rope_kvwrite(h, norm_w, wqkv, bqkv, Hq, Hkv, D, pos, slot, inv_freq, block_table, kpool, vpool, eps=1e-6,
                           out=None, max_pages=None):
     """decode-step fusion: RMSNorm + qkv GEMV + bias + M-RoPE + paged KV write.  -> qkv [M, (Hq+2Hkv)*D] (q part valid)

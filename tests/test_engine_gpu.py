@@ -718,6 +718,40 @@ def test_batch_generator_continuous_equals_single_requests(tiny, async_prefill):
     assert len(model.language_model.pool._free_seqs) == free_before      # every sequence and the scratch page returned
 
 
+def test_batch_generator_16_rows_matrix_core_steps_equal_single_requests(tiny):
+    """20 requests through 16 decode rows: steps of 16 and 8 rows run their projections on the matrix cores
+    (csrc/gemv_mfma.hip), narrower ones on the v_dot2c GEMVs, single requests on the latter only.  The two kernel families
+    sum in different orders, so a request's tokens must equal the ones it produces alone except where its own top-2
+    log-prob gap is inside bf16 noise, and the token log-probs agree to 2 bf16 ulps."""
+    from mlx_vlm_amd.batch import BatchGenerator
+
+    cfg, W, _ = tiny
+    model = build_product_model(cfg, W, kv_pool_tokens=16384, max_seqs=40)       # 16 rows + admissions ahead + scratch
+    reqs = _mixed_requests(cfg, 20, seed0=140)
+    max_tokens = [6 + (7 * i) % 9 for i in range(20)]
+    singles = _single_runs(model, reqs, max_tokens)
+    gen = BatchGenerator(model, None, max_tokens=8, completion_batch_size=16, prefill_batch_size=8)
+    assert gen.completion_batch_size == 16
+    uids = _insert_all(gen, reqs, max_tokens)
+    got = {u: [] for u in uids}
+    widths = set()
+    while gen.has_work:
+        _, out = gen.next()
+        widths.add(gen._width)
+        for r in out:
+            got[r.uid].append((r.token, r.token_logprob))
+    gen.close()
+    assert 16 in widths and 8 in widths
+    for u in uids:
+        a, b = got[u], singles[u]
+        assert len(a) == len(b) == max_tokens[u]
+        for i, ((ta, la), (tb, lb)) in enumerate(zip(a, b)):
+            if ta != tb:      # a tie inside bf16 noise: both runs rate the two candidates within 2 ulps of each other
+                assert abs(la - lb) <= 2 ** -6 * max(1.0, abs(lb)), (u, i, a, b)
+                break
+            assert abs(la - lb) <= 2 ** -6 * max(1.0, abs(lb)), (u, i, la, lb)
+
+
 def test_batch_generator_stop_token_and_remove(tiny):
     """A stop token ends one request with finish_reason "stop" (the token is still reported, as in the reference);
     remove(uid) drops a running request between rounds; the other rows are untouched by either."""

@@ -841,3 +841,82 @@ def test_gemv_w4_qkv_rope_kvwrite_fused(vops, M):
         ok, rep = bf16_close(vp[page, :, within], qkv[m, Hq + Hkv:], ulps=2)
         assert ok, (m, rep)
     assert int((kpool != 0).sum().cpu()) <= M * Hkv * D and int((vpool != 0).sum().cpu()) <= M * Hkv * D
+
+
+# ------------------------------------------------------------------ batched decode rows on the matrix cores (csrc/gemv_mfma.hip)
+@pytest.mark.parametrize("M", [5, 8, 13, 16])
+@pytest.mark.parametrize("N,K", [(2048, 1536), (1536, 8960), (1000, 3584), (152, 256), (3584, 18944)])
+def test_gemv_mfma_rows_plain_bias_residual(vops, M, N, K):
+    """5..16 batch rows as the N dimension of the MFMA (vlm_gemv_bf16_ws): every K-split form (one segment; 6 segments of
+    the 8960-wide down projection through the workspace + tickets; 13 of the 7B one), ragged N, bias, residual in place,
+    bias + residual - vs the oracle (2 ulps: fp32 accumulation in another order), and bit-identical when repeated (the
+    partial tiles are summed in a fixed order)."""
+    x, w, b = rnd(M, K, seed=7), rnd(N, K, seed=8, scale=0.05), rnd(N, seed=9, scale=0.3)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    ref = O.linear(x, w)
+    out = vops.gemv_ws(xd, wd)
+    ok, rep = bf16_close(out, ref, ulps=2)
+    assert ok, rep
+    for _ in range(3):
+        assert torch.equal(vops.gemv_ws(xd, wd), out)
+    ok, rep = bf16_close(vops.gemv_ws(xd, wd, bias=bd, epilogue=vops.EPI_BIAS), O.linear(x, w, b), ulps=2)
+    assert ok, rep
+    r = rnd(M, N, seed=10)
+    rr = r.cuda().clone()
+    out2 = vops.gemv_ws(xd, wd, res=rr, out=rr, epilogue=vops.EPI_RESIDUAL)
+    ok, rep = bf16_close(out2, O.add(r, ref), ulps=2)
+    assert ok, rep
+
+
+@pytest.mark.parametrize("M", [6, 8, 16])
+@pytest.mark.parametrize("K,I", [(1536, 2048), (3584, 1024)])
+def test_gemv_mfma_rows_norm_prologue_swiglu_and_head(vops, M, K, I):
+    h, nw = rnd(M, K, seed=10), (1 + 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(11))).to(BF)
+    wgu = rnd(2 * I, K, seed=12, scale=0.05)
+    xn = O.rms_norm(h, nw, 1e-6)
+    ref = O.swiglu(O.linear(xn, wgu[0::2]), O.linear(xn, wgu[1::2]))
+    out = vops.gemv_ws(h.cuda(), wgu.cuda(), norm_w=nw.cuda(), eps=1e-6, epilogue=vops.EPI_SWIGLU)
+    ok, rep = bf16_close(out, ref, ulps=3)
+    assert ok, rep
+    wh = rnd(9000, K, seed=13, scale=0.05)
+    ok, rep = bf16_close(vops.gemv_ws(h.cuda(), wh.cuda(), norm_w=nw.cuda(), eps=1e-6), O.linear(xn, wh), ulps=2)
+    assert ok, rep
+
+
+@pytest.mark.parametrize("M", [9, 16])
+@pytest.mark.parametrize("paged", [True, False])
+def test_gemv_mfma_rows_qkv_rope_kvwrite(vops, M, paged):
+    """[RMSNorm + qkv + bias + M-RoPE + paged KV write] for 9..16 rows: a tile's 16 rows are (d0..d0+7, d0+64..d0+71) of one
+    head so both halves of a rotation pair meet in one workgroup; block-table and identity layouts."""
+    Hq, Hkv, D, K = 12, 2, 128, 1536
+    h = rnd(M, K, seed=60)
+    nw = (1 + 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(61))).to(BF)
+    wqkv, bqkv = rnd((Hq + 2 * Hkv) * D, K, seed=62, scale=0.05), rnd((Hq + 2 * Hkv) * D, seed=63, scale=0.3)
+    g = torch.Generator().manual_seed(64)
+    pos = torch.randint(0, 3000, (M,), generator=g, dtype=torch.int32)
+    max_pages = 4
+    slot = torch.randint(0, 64 * max_pages, (M,), generator=g, dtype=torch.int32)
+    inv = O.mrope_inv_freq(D, 1e6)
+    sel = O.chunked_position_selector([16, 24, 24], D // 2)
+    qkv = O.linear(O.rms_norm(h, nw, 1e-6), wqkv, bqkv).view(M, Hq + 2 * Hkv, D)
+    p3 = pos.long()[None, :, None].expand(3, M, 1)
+    qr = O.mrope_apply(qkv[:, :Hq][:, :, None], p3, inv, sel, "fused")[:, :, 0]
+    kr = O.mrope_apply(qkv[:, Hq:Hq + Hkv][:, :, None], p3, inv, sel, "fused")[:, :, 0]
+    n_pages = M * max_pages
+    bt = torch.randperm(n_pages, generator=g).to(torch.int32).reshape(M, max_pages) if paged else \
+        torch.arange(n_pages, dtype=torch.int32).reshape(M, max_pages)
+    kpool = torch.zeros(n_pages, Hkv, D // 8, 64, 8, dtype=BF, device="cuda")
+    vpool = torch.zeros(n_pages, Hkv, D, 64, dtype=BF, device="cuda")
+    out = vops.gemv_qkv_rope_kvwrite_ws(h.cuda(), nw.cuda(), wqkv.cuda(), bqkv.cuda(), Hq, Hkv, D, pos.cuda(), slot.cuda(),
+                                        inv.cuda(), bt.cuda() if paged else None, kpool, vpool, max_pages=max_pages)
+    ok, rep = bf16_close(out.view(M, Hq + 2 * Hkv, D)[:, :Hq], qr, ulps=2)
+    assert ok, rep
+    kp = kpool.cpu().permute(0, 1, 3, 2, 4).reshape(n_pages, Hkv, 64, D)
+    vp = vpool.cpu()[..., VSLOT].permute(0, 1, 3, 2)
+    for m in range(M):
+        page, within = int(bt[m, int(slot[m]) // 64]), int(slot[m]) % 64
+        ok, rep = bf16_close(kp[page, :, within], kr[m], ulps=2)
+        assert ok, (m, rep)
+        ok, rep = bf16_close(vp[page, :, within], qkv[m, Hq + Hkv:], ulps=2)
+        assert ok, (m, rep)
+    assert int((kpool != 0).sum().cpu()) <= M * Hkv * D and int((vpool != 0).sum().cpu()) <= M * Hkv * D
