@@ -123,9 +123,13 @@ extern "C" int vlm_llm_create(const vlm_llm_config* cfg, void** handle) {
   if (!m) return 1;
   m->cfg = *cfg;
   m->layers.resize(cfg->n_layers);
-  // (allocated here, not lazily: the first decode step may already run inside a stream capture)
-  if (hipMalloc(&m->mfma_ws, vlm_gemv_mfma_ws_bytes()) != hipSuccess || hipMemset(m->mfma_ws, 0, vlm_gemv_mfma_ws_bytes()) != hipSuccess) {
-    if (m->mfma_ws) (void)hipFree(m->mfma_ws);
+  // (allocated here, not lazily: the first decode step may already run inside a stream capture.  No device - host-side
+  //  construction in the CPU tests - leaves it null: the split-K forms are then simply not taken)
+  if (hipMalloc(&m->mfma_ws, vlm_gemv_mfma_ws_bytes()) != hipSuccess) {
+    m->mfma_ws = nullptr;
+    (void)hipGetLastError();
+  } else if (hipMemset(m->mfma_ws, 0, vlm_gemv_mfma_ws_bytes()) != hipSuccess) {
+    (void)hipFree(m->mfma_ws);
     delete m;
     return 1012;
   }
