@@ -516,7 +516,7 @@ def workload_7b_b32(args, rank, ws, dev):
     from mlx_vlm_amd import parallel, synthetic
     from mlx_vlm_amd.models import qwen2_vl
 
-    cfg, model, load = _load_synthetic(synthetic.QWEN2_VL_7B, qwen2_vl, rank, dev, kv_pool_tokens=32768, max_seqs=32)
+    cfg, model, load = _load_synthetic(synthetic.QWEN2_VL_7B, qwen2_vl, rank, dev, kv_pool_tokens=32768, max_seqs=40)
     n_req, max_tokens = 32, args.max_tokens or 64
     reqs = []
     for i in range(n_req):
@@ -543,7 +543,7 @@ def workload_7b_b32(args, rank, ws, dev):
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "Qwen2-VL-7B-Instruct dims (random-init bf16), 32 requests (one 336x336 image -> 144 image tokens + "
                                   f"128 text tokens each, greedy {max_tokens} new tokens, EOS disabled) dealt data-parallel over the "
-                                  "ranks, continuous batching with 8 decode rows per GPU",
+                                  "ranks, continuous batching with up to 16 decode rows per GPU (projections of 8 / 16-row steps on the matrix cores)",
                       "requests": n_req, "max_tokens": max_tokens, "parallelism": f"dp{ws}",
                       "per_rank_requests": res["per_rank_requests"] if rank == 0 else None},
            "load": load, "distributed": _dist_info(ws),
@@ -585,7 +585,7 @@ def main():
         return
     args.max_tokens = args.max_tokens or 256
 
-    cfg, model, load = _load_synthetic(synthetic.QWEN2_VL_2B, qwen2_vl, rank, dev, kv_pool_tokens=16384, max_seqs=16)
+    cfg, model, load = _load_synthetic(synthetic.QWEN2_VL_2B, qwen2_vl, rank, dev, kv_pool_tokens=32768, max_seqs=40)
     if rank == 0 and ws > 1:
         print(f"[bench] weights: {load['weight_bytes'] / 1e9:.2f} GB broadcast from rank 0 in {load['broadcast_s']:.3f} s", file=sys.stderr, flush=True)
 
@@ -621,6 +621,7 @@ def main():
         extras = dict(kernels=kr, vit336=(ips336, dt336), vit448=(ips448, dt448))
         # exploratory single-GPU extras: not part of the scaling runs (the other ranks would only wait for rank 0)
         for key, fn in (("batch8", lambda: batch_decode_throughput(model, cfg, 8, 64)),
+                        ("batch16", lambda: batch_decode_throughput(model, cfg, 16, 64)),
                         ("continuous", lambda: continuous_batch_throughput(model, cfg))):
             if ws > 1:
                 extras[key] = None
@@ -673,6 +674,7 @@ def main():
                                    "workload": f"{args.vit_batch} x 336x336 images per call ({args.vit_batch * 576} patches)",
                                    "ms_per_call": dt336 * 1e3}
             out["batch8_decode"] = extras["batch8"]
+            out["batch16_decode"] = extras.get("batch16")
             out["continuous_batching"] = extras["continuous"]
             out["vision_single_448_images_per_s"] = ips448
             out["vision_single_448_tflops"] = ips448 * VIT_TFLOP_448

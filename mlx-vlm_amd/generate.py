@@ -415,7 +415,7 @@ def embed_requests(model, input_ids_list, pixel_values_list, grids):
 def batch_generate_ids(model, input_ids_list: List[np.ndarray], pixel_values_list: List[Any], grids: List[Any], *,
                        max_tokens: int = 128, stop_ids=(), sampler: Optional[Sampler] = None, lookahead: int = 4,
                        use_graph: bool = True) -> Tuple[List[List[int]], BatchStats]:
-    """Pre-tokenised batched generation: the requests are processed in decode batches of up to 8 sequences.
+    """Pre-tokenised batched generation: the requests are processed in decode batches of up to 16 sequences.
     One ViT call over the concatenated patches of the batch (as the reference does per shape group,
     ar.py:3165-3167), one varlen LLM prefill, then batched graph decode.  -> (tokens per request, stats)."""
     lm = model.language_model
@@ -428,7 +428,8 @@ def batch_generate_ids(model, input_ids_list: List[np.ndarray], pixel_values_lis
     i = 0
     while i < len(order):
         rem = len(order) - i
-        B = 8 if rem >= 8 else 4 if rem >= 4 else 2 if rem >= 2 else 1
+        wide = rem >= 16 and not getattr(lm, "quantized", False) and len(lm.pool._free_seqs) >= 16      # 16-row steps: gemv_mfma.hip
+        B = 16 if wide else 8 if rem >= 8 else 4 if rem >= 4 else 2 if rem >= 2 else 1
         idxs = order[i:i + B]
         i += B
         t0 = time.perf_counter()
