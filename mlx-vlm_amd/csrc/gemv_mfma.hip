@@ -17,8 +17,8 @@
 // all of a wave's chunks in flight before the first use, and each wave transposes chunk by chunk through a PRIVATE 4 KiB
 // LDS region (row pitch 272 B: conflict-free ds_read_b128 fragments; same-wave LDS operations execute in order, so the
 // region needs no barrier).  x^T fragments come from the workgroup's staged activations.
-//   unit   = (16-row tile, K segment ks of KS); the 4 waves of a workgroup interleave the unit's 128-wide K chunks (<= 6
-//            each, 24 loads of a lane in flight), their partial tiles meet in LDS
+//   unit   = (16-row tile, K segment ks of KS); the 4 waves of a workgroup interleave the unit's 128-wide K chunks (<= 7
+//            each, up to 28 loads of a lane in flight), their partial tiles meet in LDS
 //   KS > 1 (few row tiles x long K: o_proj, down): fp32 partial tiles go to a workspace, the LAST workgroup of a tile
 //            to arrive (agent-scope ticket) sums them in the fixed order ks = 0..KS-1 - deterministic - and runs the epilogue
 //   the activations (normalised when the RMSNorm prologue is on) are staged ONCE per workgroup, which then walks units
@@ -37,7 +37,7 @@ namespace {
 
 enum { MPRO_NONE = 0, MPRO_RMSNORM = 1 };
 constexpr int MEPI_ROPE_KV = 1 << 10;
-constexpr int NCW = 6;             // 128-wide K chunks per wave and unit
+constexpr int NCW = 7;             // 128-wide K chunks per wave and unit (28 per unit: K = 3584, the 7B hidden size, in one segment)
 constexpr int WREG = 16 * 272;      // bytes of a wave's private transposition region
 
 struct MfmaArgs {
@@ -62,7 +62,7 @@ __device__ __forceinline__ int tile_row(const MfmaArgs& a, int tile, int r) {
 }
 
 // NCW: 128-wide K chunks per wave and unit (3: two register sets, the next unit's weights are in flight while this one
-// is multiplied; 6: one set).  XS > 0: the activations fit the prologue's registers (rows_per_wave * chunks_per_lane <= XS):
+// is multiplied; 7: one set).  XS > 0: the activations fit the prologue's registers (rows_per_wave * chunks_per_lane <= XS):
 // x and the norm weight are loaded ONCE, ahead of the weight stream (vector loads return in issue order), and the RMS
 // statistics come from the registers; otherwise the activations are staged before any weight load is issued.
 template <int PRO, int EPI, bool FULLX, int NCW, int XS>
@@ -337,8 +337,8 @@ int mfma_launch(const MfmaArgs& a, size_t lds, int n_units, hipStream_t st) {
       if (slots <= 14) return mfma_launch2<PRO, EPI, FULLX, 3, S14>(a, lds, n_units, st);
     return mfma_launch2<PRO, EPI, FULLX, 3, 0>(a, lds, n_units, st);
   }
-  if (cpl <= 3 && slots <= 6) return mfma_launch2<PRO, EPI, FULLX, 6, S6>(a, lds, n_units, st);
-  return mfma_launch2<PRO, EPI, FULLX, 6, 0>(a, lds, n_units, st);
+  if (cpl <= 3 && slots <= 6) return mfma_launch2<PRO, EPI, FULLX, 7, S6>(a, lds, n_units, st);
+  return mfma_launch2<PRO, EPI, FULLX, 7, 0>(a, lds, n_units, st);
 }
 
 }  // namespace
