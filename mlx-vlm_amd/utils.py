@@ -180,6 +180,7 @@ def load_processor(model_path: str, config):
         tok.tokenizer = tok
         eos = config.eos_token_id if getattr(config, "eos_token_id", None) is not None else tok.eos_token_id
         tok.stopping_criteria = StoppingCriteria(eos if isinstance(eos, list) else [eos], tok)
+        tok.detokenizer = _pick_detokenizer(model_path, tok)
         return tok
     if pc:
         for k in ("image_mean", "image_std", "min_pixels", "max_pixels", "patch_size", "temporal_patch_size", "merge_size"):
@@ -188,7 +189,15 @@ def load_processor(model_path: str, config):
     proc = Qwen2VLProcessor(Qwen2VLImageProcessor(**ip_kwargs), tok)
     eos = config.eos_token_id if getattr(config, "eos_token_id", None) is not None else tok.eos_token_id
     tok.stopping_criteria = StoppingCriteria(eos if isinstance(eos, list) else [eos], tok)
+    proc.detokenizer = _pick_detokenizer(model_path, tok)
     return proc
+
+
+def _pick_detokenizer(model_path, tok):
+    """reference tokenizer_utils.py:453-480: the streaming detokenizer that fits tokenizer.json's decoder"""
+    from .tokenizer_utils import detokenizer_class_for
+
+    return detokenizer_class_for(model_path)(tok)
 
 
 class StoppingCriteria:
@@ -274,6 +283,15 @@ class NaiveStreamingDetokenizer:
 
 
 def make_streaming_detokenizer(processor):
+    """An isolated, reset detokenizer for one generation (reference tokenizer_utils.py:406-410): a copy of the one
+    `load_processor` picked for the tokenizer (SPM / byte-level BPE / naive), or a naive one for a bare tokenizer."""
+    import copy
+
+    det = getattr(processor, "detokenizer", None)
+    if det is not None:
+        det = copy.copy(det)
+        det.reset()
+        return det
     tok = processor.tokenizer if hasattr(processor, "tokenizer") else processor
     if not hasattr(tok, "decode"):
         return None
