@@ -479,7 +479,11 @@ def batch_generate(model, processor, images=None, audios=None, prompts: Optional
                    verbose: bool = False, group_by_shape: bool = True, track_image_sizes: bool = True, **kwargs) -> BatchResponse:
     """reference ar.py:2890-3096: prompts (+ one image each) -> BatchResponse.  Requests are tokenised on the host and
     queued on a `BatchGenerator` (continuous batching, as the reference's `_generate_batch` does, ar.py:3199-3232);
-    `continuous=False` runs them as static decode batches of up to 8 (`batch_generate_ids`)."""
+    `continuous=False` runs them as static decode batches of up to 16 (`batch_generate_ids`).
+    `group_by_shape` (ar.py:2972-2986, utils.py:2139-2188) is accepted and has nothing to do here: the reference groups
+    images of equal size because its vision tower takes one shape per call; this engine's ViT attention is varlen
+    (`cu_seqlens`), so images of ANY sizes share one launch and no padding or regrouping exists.  `track_image_sizes`
+    fills `BatchResponse.image_sizes` with each image's original (height, width), (0, 0) for text-only prompts."""
     from .batch import generate_batch_continuous
     from .utils import prepare_inputs
 
@@ -488,8 +492,9 @@ def batch_generate(model, processor, images=None, audios=None, prompts: Optional
     prompts = list(prompts or [])
     images = list(images) if images is not None else [None] * len(prompts)
     tokenizer = _tokenizer_of(processor)
-    ids_l, pix_l, grid_l = [], [], []
+    ids_l, pix_l, grid_l, sizes = [], [], [], []
     for p, im in zip(prompts, images):
+        sizes.append(_image_hw(im))
         inp = prepare_inputs(processor, images=im, prompts=p)
         ids_l.append(np.asarray(inp["input_ids"]).reshape(-1))
         pix_l.append(inp.get("pixel_values"))
@@ -501,7 +506,28 @@ def batch_generate(model, processor, images=None, audios=None, prompts: Optional
     run = generate_batch_continuous if kwargs.pop("continuous", True) else batch_generate_ids
     toks, stats = run(model, ids_l, pix_l, grid_l, max_tokens=max_tokens, stop_ids=stop_ids, sampler=smp)
     texts = [tokenizer.decode(t) if hasattr(tokenizer, "decode") else "" for t in toks]
-    return BatchResponse(texts=texts, stats=stats, tokens=toks)
+    return BatchResponse(texts=texts, stats=stats, tokens=toks, image_sizes=sizes if track_image_sizes else None)
+
+
+def _image_hw(im) -> Tuple[int, int]:
+    """original (height, width) of one request's image (reference ar.py:2957-2970): PIL image, array (H, W, C) or path"""
+    if im is None:
+        return (0, 0)
+    if isinstance(im, (list, tuple)):
+        return _image_hw(im[0]) if im else (0, 0)
+    if hasattr(im, "height") and hasattr(im, "width"):
+        return (int(im.height), int(im.width))
+    if hasattr(im, "shape") and len(im.shape) >= 2:
+        return (int(im.shape[0]), int(im.shape[1]))
+    if isinstance(im, (str, bytes)) or hasattr(im, "__fspath__"):
+        try:
+            from PIL import Image
+
+            with Image.open(im) as f:
+                return (int(f.height), int(f.width))
+        except Exception:
+            return (0, 0)
+    return (0, 0)
 
 
 # `mlx_vlm_amd.generate` names both this module and the function (as in the reference, where the package's eager

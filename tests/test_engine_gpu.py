@@ -639,6 +639,9 @@ def test_load_and_generate_user_api_end_to_end(tmp_path):
     static = batch_generate(model, processor, images=[img, None, img], prompts=[prompt, words, prompt], max_tokens=6,
                             continuous=False)
     assert static.tokens == resp.tokens
+    assert resp.image_sizes == [(100, 150), (0, 0), (100, 150)]          # original (height, width), (0, 0) without an image
+    assert batch_generate(model, processor, images=[img], prompts=[prompt], max_tokens=2, group_by_shape=False,
+                          track_image_sizes=False).image_sizes is None
     assert callable(BatchGenerator)
 
 
