@@ -165,12 +165,18 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
   const bf16_t* pf_base = ((tid & 2) ? vbase : kbase) + (tid & 1) * 64;
   for (int t = 0; t < ntiles; ++t) {
     const bool more = (t + 1) < ntiles;
+#ifndef ATTN_ABL_NO_GLOAD          // ablation builds of scripts/attn_probe.hip only (results are then meaningless)
     if (more) gload(t + 1);
+#endif
     uint32_t pf_val = 0;
-    if (t + 2 < ntiles) {
+#ifndef ATTN_ABL_NO_PF
+    // (D = 128 only - the long causal LLM prompt.  For the ViT's 576-key segments K / V of a head are L2-resident after the
+    //  first query block and the extra load only costs issue slots: 55.4 -> 54.3 us per block without it)
+    if (D == 128 && t + 2 < ntiles) {
       const int r = min((t + 2) * BKV + pf_row, seg_len - 1);
       pf_val = *reinterpret_cast<const uint32_t*>(pf_base + (size_t)r * ((tid & 2) ? v_stride : k_stride));
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);   // keep the loads up here (hipcc otherwise sinks the prefetch next to its use)
     ST_MARK(0);                          // global loads of tile t+1 issued
     const int j0 = t * BKV;
@@ -281,7 +287,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
     // the s_waitcnt vmcnt it needs: the MFMAs then wait for the NEXT tile's global loads (found in the .s)
     __builtin_amdgcn_sched_barrier(0);
     ST_MARK(3);                          // P.V MFMAs issued
+#ifndef ATTN_ABL_NO_LSTORE
     if (more) lstore((t + 1) & 1);   // the other buffer: last read in iteration t-1, one barrier ago
+#endif
     ST_MARK(4);                          // staging registers -> LDS (waits for tile t+1's global loads)
     __syncthreads();
     ST_MARK(5);                          // barrier
