@@ -115,6 +115,15 @@ int vlm_gemv_w4_qkv_rope_kvwrite(const void* h, const void* norm_w, float eps, c
                                  void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D, const void* pos, const void* slot,
                                  const void* inv_freq, const void* block_table, int max_pages, void* kpool, void* vpool,
                                  void* stream);
+/* batched decode rows (5..16; 9..16 for the qkv form) over 4-bit weights: the dequant-fused MFMA form of csrc/gemv_mfma.hip -
+ * nibbles become bf16 128 + q in the A fragments, every 64-wide group enters the sum as scale * (D - 128 sum_x) + bias * sum_x in
+ * fp32 (no weight is rounded); `workspace` as vlm_gemv_bf16_ws.  Other row counts: the kernels of vlm_gemv_w4. */
+int vlm_gemv_w4_ws(const void* x, const void* Wq, const void* Wsb, const void* bias, const void* res, const void* norm_w, void* y,
+                   int M, int N, int K, int ldx, int ldy, int ldres, float eps, int epilogue, void* workspace, void* stream);
+int vlm_gemv_w4_qkv_rope_kvwrite_ws(const void* h, const void* norm_w, float eps, const void* Wq, const void* Wsb, const void* bqkv,
+                                    void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D, const void* pos, const void* slot,
+                                    const void* inv_freq, const void* block_table, int max_pages, void* kpool, void* vpool,
+                                    void* workspace, void* stream);
 int vlm_dequant_w4(const void* Wq, const void* Wsb, const void* rows, void* out, int n_rows, int K, int ldo, int n_table_rows,
                    void* stream);
 

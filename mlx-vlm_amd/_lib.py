@@ -99,6 +99,9 @@ SIGNATURES = {
     "vlm_gemv_w4": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_int, c_void_p]),
     "vlm_gemv_w4_qkv_rope_kvwrite": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6
                                      + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p]),
+    "vlm_gemv_w4_ws": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_float, c_int, c_void_p, c_void_p]),
+    "vlm_gemv_w4_qkv_rope_kvwrite_ws": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6
+                                        + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlm_dequant_w4": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "vlm_layernorm": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float, c_void_p]),
     "vlm_rmsnorm_residual": (c_int, [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p]),

@@ -39,7 +39,7 @@ from .models.cache import PAGE, PagedSequence
 from .models.qwen2_vl.language import DecodeState
 from .sample_utils import Sampler, make_sampler
 
-MAX_ROWS = 16         # widest decode step: one N tile of the skinny-M MFMA GEMM (csrc/gemv_mfma.hip); 8 over 4-bit weights
+MAX_ROWS = 16         # widest decode step: one N tile of the skinny-M MFMA GEMM (csrc/gemv_mfma.hip), bf16 or 4-bit weights
 WIDTHS = (1, 2, 4, 8, 16)
 
 
@@ -141,7 +141,7 @@ class BatchGenerator:
         self.use_graph = use_graph
         self.async_prefill = async_prefill
         self.prefill_ahead = max(0, int(prefill_ahead)) if async_prefill else 0
-        max_rows = 8 if getattr(self.lm, "quantized", False) else MAX_ROWS       # the 4-bit GEMVs take 1 / 2 / 4 / 8 rows
+        max_rows = MAX_ROWS
         pool_seqs = getattr(getattr(self.lm, "pool", None), "max_seqs", 64)
         if pool_seqs < 2 * MAX_ROWS + 2:      # rows + admissions prefilled ahead + the scratch page each hold a sequence slot
             max_rows = min(max_rows, 8)

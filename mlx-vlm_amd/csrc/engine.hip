@@ -265,7 +265,7 @@ static int lin_gemm(Llm* m, const void* A, const void* W, const void* Wsb, const
 // decode: y = epi(x . W^T) for B rows
 static int lin_gemv(Llm* m, const void* x, const void* W, const void* Wsb, const void* bias, const void* res, const void* norm_w,
                     void* y, int B, int N, int K, int ldy, int ldres, float eps, int epi, void* stream) {
-  if (Wsb) return vlm_gemv_w4(x, W, Wsb, bias, res, norm_w, y, B, N, K, K, ldy, ldres, eps, epi, stream);
+  if (Wsb) return vlm_gemv_w4_ex(x, W, Wsb, bias, res, norm_w, y, B, N, K, K, ldy, ldres, eps, epi, m->tune.mfma_gemv, m->mfma_ws, stream);
   // B >= 3: batch rows on the matrix cores (gemv_mfma.hip), K split over workgroups through the engine's workspace
   return vlm_gemv_bf16_ex(x, W, bias, res, norm_w, y, B, N, K, K, K, ldy, ldres, eps, epi, m->tune.mfma_gemv, m->mfma_ws, stream);
 }
@@ -397,8 +397,9 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
     // [RMSNorm + qkv GEMV + bias + M-RoPE at pos[b] + k/v write at slot ctx[b]] in one launch
     if (!(skip & 1)) {
     if (w.wqkv_sb) {
-      TRY(vlm_gemv_w4_qkv_rope_kvwrite(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.wqkv_sb, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos,
-                                       a->ctx, m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, stream)); ++n;
+      TRY(vlm_gemv_w4_qkv_rope_kvwrite_ex(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.wqkv_sb, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos,
+                                          a->ctx, m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, m->tune.mfma_gemv,
+                                          m->mfma_ws, stream)); ++n;
     } else {
     TRY(vlm_gemv_qkv_rope_kvwrite_ex(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos, a->ctx,
                                      m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, m->tune.mfma_gemv, m->mfma_ws,

@@ -42,6 +42,7 @@ constexpr int WREG = 16 * 272;      // bytes of a wave's private transposition r
 
 struct MfmaArgs {
   const bf16_t *x, *W, *bias, *res, *norm_w;
+  const unsigned* Wsb;  // MLX affine 4-bit weights: W = q words uint32 [N][K/8], Wsb = (scale | bias << 16) [N][K/64]; else null
   bf16_t* y;
   int M, N, K, ldx, ldw, ldy, ldres;
   float eps;
@@ -65,9 +66,17 @@ __device__ __forceinline__ int tile_row(const MfmaArgs& a, int tile, int r) {
 // is multiplied; 7: one set).  XS > 0: the activations fit the prologue's registers (rows_per_wave * chunks_per_lane <= XS):
 // x and the norm weight are loaded ONCE, ahead of the weight stream (vector loads return in issue order), and the RMS
 // statistics come from the registers; otherwise the activations are staged before any weight load is issued.
-template <int PRO, int EPI, bool FULLX, int NCW, int XS>
+//
+// W4 (MLX affine 4-bit weights, group 64 - nn.QuantizedLinear at a batched decode step, reference utils.py:918-967): a
+// chunk is 64 bytes of nibbles per row, ONE 16-byte load per lane (row lane >> 2, 32 weights) + one (scale | bias) word;
+// a nibble q becomes the bf16 number 128 + q by OR-ing it into the mantissa of 0x4300, two per instruction, which leaves
+// the 8 weights of a word in the order (0,4,1,5,2,6,3,7) - the activations are staged in the same order, the contraction
+// does not care.  Each 64-wide group is multiplied on its own (2 MFMAs from a zero accumulator) and enters the sum as
+// scale * (D - 128 * sum_x) + bias * sum_x in fp32 (sum_x per batch row and group, once per workgroup): the exact affine
+// form, no weight is rounded - the numerics of csrc/gemv_w4.hip.
+template <int PRO, int EPI, bool FULLX, int NCW, int XS, bool W4>
 __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // xs[M][P] | wreg[4][WREG] | part[4][256] f32 | red | flag
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // xs[M][P] | wreg[4][WREG] | part[4][256] f32 | red | flag | sbr | xsum
   constexpr bool DBUF = NCW == 3;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
   const int kx = FULLX ? a.K : a.bpk * 128;                // staged elements per batch row
@@ -76,14 +85,29 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
   float* part = reinterpret_cast<float*>(smem + (size_t)a.M * P + 4 * WREG);
   float* red = part + 1024;
   int* s_flag = reinterpret_cast<int*>(red + 64);
+  unsigned* sbr = reinterpret_cast<unsigned*>(red + 80) + wave * 32;      // W4: the wave's 16 rows x 2 groups of (scale | bias)
+  float* xsum = red + 80 + 128;                                           // W4: [M][kx / 64] sums of the staged activations
   const int n_units = a.n_tiles * a.KS, G = gridDim.x;
   const int mrow = min(r16, a.M - 1);
 
   // chunk c of the unit (128 k): instruction j covers rows 4 j .. 4 j + 3, lane -> row 4 j + (lane >> 4), 16 bytes at
-  // k offset 8 (lane & 15): 256 contiguous bytes per row
+  // k offset 8 (lane & 15): 256 contiguous bytes per row.  W4: one instruction covers all 16 rows (lane -> row lane >> 2,
+  // 16 bytes = 32 nibbles at k offset 32 (lane & 3)); slot [1] carries the row's (scale | bias) word of group (lane & 1)
   auto load_w = [&](int u, u32x4_t (&wv)[NCW][4]) {
     const int tile = u / a.KS, ks = u % a.KS;
     const int kb0 = ks * a.bpk, kb1 = min(a.nblk, kb0 + a.bpk);
+    if (W4) {
+      const size_t row = (size_t)min(tile_row<EPI>(a, tile, lane >> 2), a.N - 1);
+      const unsigned* wq = reinterpret_cast<const unsigned*>(a.W) + row * (a.K >> 3) + (lane & 3) * 4;
+      const unsigned* sb = a.Wsb + row * (a.K >> 6) + (lane & 1);
+#pragma unroll
+      for (int i = 0; i < NCW; ++i) {
+        const int b = max(min(kb0 + wave + 4 * i, kb1 - 1), 0);
+        wv[i][0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wq + (size_t)b * 16));
+        wv[i][1][0] = sb[(size_t)b * 2];
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bf16_t* wr = a.W + (size_t)min(tile_row<EPI>(a, tile, 4 * j + g), a.N - 1) * a.ldw + r16 * 8;
@@ -93,6 +117,34 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
         wv[i][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr + (size_t)b * 128));
       }
     }
+  };
+
+  // W4: 8 consecutive bf16 -> the order (0,4,1,5,2,6,3,7) of an expanded q word
+  auto x_order = [&](u32x4_t v) {
+    if (!W4) return v;
+    u32x4_t o;
+    o[0] = (v[0] & 0xffffu) | (v[2] << 16);
+    o[1] = (v[0] >> 16) | (v[2] & 0xffff0000u);
+    o[2] = (v[1] & 0xffffu) | (v[3] << 16);
+    o[3] = (v[1] >> 16) | (v[3] & 0xffff0000u);
+    return o;
+  };
+  // W4: per batch row and 64-wide group, the sum of the staged (bf16) activations; after the staging barrier
+  auto group_sums = [&]() {
+    if (!W4) return;
+    const int ng = kx >> 6;
+    for (int i = tid; i < a.M * ng; i += 256) {
+      const int m = i / ng, q = i % ng;
+      const u32x4_t* p = reinterpret_cast<const u32x4_t*>(smem + (size_t)m * P + (size_t)q * 128);
+      float sx = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const u32x4_t v = p[c];
+        sx += ((bf_lo(v[0]) + bf_hi(v[0])) + (bf_lo(v[1]) + bf_hi(v[1]))) + ((bf_lo(v[2]) + bf_hi(v[2])) + (bf_lo(v[3]) + bf_hi(v[3])));
+      }
+      xsum[i] = sx;
+    }
+    __syncthreads();
   };
 
   // ---- activations -> LDS (bf16, rows at pitch P), loop form: before any weight load when it is the FULLX prologue
@@ -126,7 +178,8 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
         v.z = pack_bf2(bf_lo(wu.z) * rbf(bf_lo(v.z) * inv), bf_hi(wu.z) * rbf(bf_hi(v.z) * inv));
         v.w = pack_bf2(bf_lo(wu.w) * rbf(bf_lo(v.w) * inv), bf_hi(wu.w) * rbf(bf_hi(v.w) * inv));
       }
-      *reinterpret_cast<uint4*>(smem + (size_t)m * P + (size_t)c * 16) = v;
+      const u32x4_t o = x_order(u32x4_t{v.x, v.y, v.z, v.w});
+      *reinterpret_cast<u32x4_t*>(smem + (size_t)m * P + (size_t)c * 16) = o;
     }
   };
 
@@ -183,7 +236,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
             o[3] = pack_bf2(bf_lo(wu[3]) * rbf(bf_lo(v[3]) * inv), bf_hi(wu[3]) * rbf(bf_hi(v[3]) * inv));
             v = o;
           }
-          if (m < a.M && c < nch) *reinterpret_cast<u32x4_t*>(smem + (size_t)m * P + (size_t)c * 16) = v;
+          if (m < a.M && c < nch) *reinterpret_cast<u32x4_t*>(smem + (size_t)m * P + (size_t)c * 16) = x_order(v);
         }
     }
     __syncthreads();
@@ -192,6 +245,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
     load_w(min(u, n_units - 1), wvA);
     __syncthreads();
   }
+  group_sums();
 
   // one unit: transposition + MFMAs of this wave's chunks, cross-wave / cross-workgroup reduction, epilogue
   auto unit = [&](int u, u32x4_t (&wv)[NCW][4]) __attribute__((always_inline)) {
@@ -203,6 +257,36 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
     for (int i = 0; i < NCW; ++i) {
       const int b = kb0 + wave + 4 * i;
       if (b < kb1) {                                          // wave-uniform
+        if (W4) {
+          // 32 nibbles -> 32 bf16 (128 + q) at row lane >> 2, bytes 64 (lane & 3) .. +64 of the wave's region
+          char* dst = wreg + (lane >> 2) * 272 + (lane & 3) * 64;
+#pragma unroll
+          for (int w4 = 0; w4 < 4; ++w4) {
+            const unsigned w = wv[i][0][w4];
+            const u32x4_t e = {(w & 0x000F000Fu) | 0x43004300u, ((w >> 4) & 0x000F000Fu) | 0x43004300u,
+                               ((w >> 8) & 0x000F000Fu) | 0x43004300u, ((w >> 12) & 0x000F000Fu) | 0x43004300u};
+            *reinterpret_cast<u32x4_t*>(dst + w4 * 16) = e;
+          }
+          if ((lane & 3) < 2) sbr[(lane >> 2) * 2 + (lane & 1)] = wv[i][1][0];
+          const float* xs_m = xsum + (size_t)mrow * (kx >> 6) + (size_t)(b - (FULLX ? 0 : kb0)) * 2;
+#pragma unroll
+          for (int gq = 0; gq < 2; ++gq) {
+            f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+              const int kb = 2 * gq + k2;
+              const u32x4_t af = *reinterpret_cast<const u32x4_t*>(wreg + r16 * 272 + kb * 64 + g * 16);
+              const u32x4_t bf = *reinterpret_cast<const u32x4_t*>(xrow + (size_t)b * 256 + kb * 64);
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bf), d, 0, 0, 0);
+            }
+            const float sx = xs_m[gq];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const unsigned sbw = sbr[(4 * g + q) * 2 + gq];
+              acc[q] += bf_lo(sbw) * (d[q] - 128.f * sx) + bf_hi(sbw) * sx;
+            }
+          }
+        } else {
         // chunk -> the wave's region [16 rows][272 B] (as loaded: row 4 j + g, byte 16 r16), then the fragments
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4_t*>(wreg + (4 * j + g) * 272 + r16 * 16) = wv[i][j];
@@ -212,6 +296,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
           const u32x4_t bf = *reinterpret_cast<const u32x4_t*>(xrow + (size_t)b * 256 + kb * 64);
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bf), acc, 0, 0,
                                                         0);
+        }
         }
       }
     }
@@ -261,7 +346,8 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
           if (tile < n_rot) {
             if (n_l < 8) {
               const int head = tile / tph, j = (tile % tph) * 8 + n_l, n1 = n + half;
-              const float y0 = rbf(v + bf2f(a.bias[n])), y1 = rbf(part[tid + 128] + bf2f(a.bias[n1]));
+              // (4-bit: quantized_matmul rounds to bf16, the bias add is a second typed op)
+              const float y0 = rbf((W4 ? rbf(v) : v) + bf2f(a.bias[n])), y1 = rbf((W4 ? rbf(part[tid + 128]) : part[tid + 128]) + bf2f(a.bias[n1]));
               float sn, cs;
               sincosf((float)a.rk.pos[m] * a.rk.inv_freq[j], &sn, &cs);
               const float o0 = y0 * cs - y1 * sn, o1 = y1 * cs + y0 * sn;
@@ -278,14 +364,14 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
           } else if (n < a.N) {
             const int vr = n - (a.rk.Hq + a.rk.Hkv) * a.rk.D, gq = vr / a.rk.D, d = vr % a.rk.D;
             bf16_t* vb = a.rk.vpool + ((e_page * a.rk.Hkv + gq) * (size_t)a.rk.D + d) * 64 + vlm_vslot(e_within);
-            vb[0] = f2bf(rbf(v + bf2f(a.bias[n])));
+            vb[0] = f2bf(rbf((W4 ? rbf(v) : v) + bf2f(a.bias[n])));
           }
         }
       } else if (EPI & VLM_EPI_SWIGLU) {
         if (m < a.M && !(n_l & 1) && n + 1 < a.N)
           a.y[(size_t)m * a.ldy + (n >> 1)] = f2bf(swiglu_(rbf(v), rbf(part[tid + 16])));
       } else if (m < a.M && n < a.N) {
-        if (EPI & VLM_EPI_BIAS) v += bf2f(a.bias[n]);
+        if (EPI & VLM_EPI_BIAS) v = (W4 ? rbf(v) : v) + bf2f(a.bias[n]);
         if (EPI & VLM_EPI_RESIDUAL) v = rbf(v) + bf2f(a.res[(size_t)m * a.ldres + n]);
         a.y[(size_t)m * a.ldy + n] = f2bf(v);
       }
@@ -309,9 +395,9 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
   }
 }
 
-template <int PRO, int EPI, bool FULLX, int NCW, int XS>
+template <int PRO, int EPI, bool FULLX, int NCW, int XS, bool W4>
 int mfma_launch2(const MfmaArgs& a, size_t lds, int n_units, hipStream_t st) {
-  auto kern = gemv_mfma_kernel<PRO, EPI, FULLX, NCW, XS>;
+  auto kern = gemv_mfma_kernel<PRO, EPI, FULLX, NCW, XS, W4>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return VLM_ERR_HIP + (int)e;
@@ -325,20 +411,25 @@ int mfma_launch2(const MfmaArgs& a, size_t lds, int n_units, hipStream_t st) {
   return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
 }
 
-template <int PRO, int EPI, bool FULLX>
-int mfma_launch(const MfmaArgs& a, size_t lds, int n_units, hipStream_t st) {
+template <int PRO, int EPI, bool FULLX, bool W4>
+int mfma_launch1(const MfmaArgs& a, size_t lds, int n_units, hipStream_t st) {
   const bool ncw3 = a.bpk <= 12;
   const int kx = FULLX ? a.K : a.bpk * 128;
   const int cpl = ((kx >> 3) + 63) / 64, slots = ((a.M + 3) / 4) * cpl;
   constexpr int S6 = 6, S14 = 14;
   if (ncw3) {
-    if (cpl <= 3 && slots <= 6) return mfma_launch2<PRO, EPI, FULLX, 3, S6>(a, lds, n_units, st);
+    if (cpl <= 3 && slots <= 6) return mfma_launch2<PRO, EPI, FULLX, 3, S6, W4>(a, lds, n_units, st);
     if constexpr (PRO == MPRO_NONE)
-      if (slots <= 14) return mfma_launch2<PRO, EPI, FULLX, 3, S14>(a, lds, n_units, st);
-    return mfma_launch2<PRO, EPI, FULLX, 3, 0>(a, lds, n_units, st);
+      if (slots <= 14) return mfma_launch2<PRO, EPI, FULLX, 3, S14, W4>(a, lds, n_units, st);
+    return mfma_launch2<PRO, EPI, FULLX, 3, 0, W4>(a, lds, n_units, st);
   }
-  if (cpl <= 3 && slots <= 6) return mfma_launch2<PRO, EPI, FULLX, 7, S6>(a, lds, n_units, st);
-  return mfma_launch2<PRO, EPI, FULLX, 7, 0>(a, lds, n_units, st);
+  if (cpl <= 3 && slots <= 6) return mfma_launch2<PRO, EPI, FULLX, 7, S6, W4>(a, lds, n_units, st);
+  return mfma_launch2<PRO, EPI, FULLX, 7, 0, W4>(a, lds, n_units, st);
+}
+
+template <int PRO, int EPI, bool FULLX>
+int mfma_launch(const MfmaArgs& a, size_t lds, int n_units, hipStream_t st) {
+  return a.Wsb ? mfma_launch1<PRO, EPI, FULLX, true>(a, lds, n_units, st) : mfma_launch1<PRO, EPI, FULLX, false>(a, lds, n_units, st);
 }
 
 }  // namespace
@@ -346,9 +437,28 @@ int mfma_launch(const MfmaArgs& a, size_t lds, int n_units, hipStream_t st) {
 VLM_INTERNAL size_t vlm_gemv_mfma_ws_bytes(void) { return (size_t)4096 * 256 * 4 + 8192 * 4; }   // 4096 units of partials + tickets
 
 // -> VLM_OK, an error, or -1: shape not handled here (the caller takes the v_dot2c kernels)
+static int mfma_try(const void* x, const void* W, const void* Wsb, const void* bias, const void* res, const void* norm_w, void* y,
+                    int M, int N, int K, int ldx, int ldw, int ldy, int ldres, float eps, int epilogue, const VlmRopeKv* rk,
+                    void* ws, void* stream);
+
 VLM_INTERNAL int vlm_gemv_mfma_try(const void* x, const void* W, const void* bias, const void* res, const void* norm_w, void* y, int M, int N,
                                    int K, int ldx, int ldw, int ldy, int ldres, float eps, int epilogue, const VlmRopeKv* rk,
                                    void* ws, void* stream) {
+  return mfma_try(x, W, nullptr, bias, res, norm_w, y, M, N, K, ldx, ldw, ldy, ldres, eps, epilogue, rk, ws, stream);
+}
+
+// the same over MLX affine 4-bit weights (Wq words [N][K/8], Wsb (scale | bias << 16) [N][K/64]): all supported row counts
+// (the v_dot2c 4-bit GEMVs stop at 8 rows)
+VLM_INTERNAL int vlm_gemv_mfma_try_w4(const void* x, const void* Wq, const void* Wsb, const void* bias, const void* res,
+                                      const void* norm_w, void* y, int M, int N, int K, int ldx, int ldy, int ldres, float eps,
+                                      int epilogue, const VlmRopeKv* rk, void* ws, void* stream) {
+  if (!Wsb) return -1;
+  return mfma_try(x, Wq, Wsb, bias, res, norm_w, y, M, N, K, ldx, 8, ldy, ldres, eps, epilogue, rk, ws, stream);
+}
+
+static int mfma_try(const void* x, const void* W, const void* Wsb, const void* bias, const void* res, const void* norm_w, void* y,
+                    int M, int N, int K, int ldx, int ldw, int ldy, int ldres, float eps, int epilogue, const VlmRopeKv* rk,
+                    void* ws, void* stream) {
   // A/B knobs: VLM_GEMV_MFMA=0 turns the path off, VLM_GEMV_MFMA_MIN_M moves the row count it starts at.  Default 5: a
   // step costs the same here for 4, 8 or 16 rows (1.45 ms at 2B dims) while the v_dot2c step grows with the rows (1.25 ms at
   // 4, 1.8 ms at 8): profiles/r02_mfma_gemv.txt.  The qkv + RoPE + KV-write form starts at 9 rows (6.2 vs 7.2 us at 8).
@@ -364,7 +474,7 @@ VLM_INTERNAL int vlm_gemv_mfma_try(const void* x, const void* W, const void* bia
   if ((epilogue & VLM_EPI_SWIGLU) && (N % 16)) return -1;
   MfmaArgs a{};
   a.x = (const bf16_t*)x; a.W = (const bf16_t*)W; a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res;
-  a.norm_w = (const bf16_t*)norm_w; a.y = (bf16_t*)y;
+  a.norm_w = (const bf16_t*)norm_w; a.y = (bf16_t*)y; a.Wsb = (const unsigned*)Wsb;
   a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldres = ldres; a.eps = eps;
   if (rope) {
     a.rk = *rk;
@@ -387,7 +497,7 @@ VLM_INTERNAL int vlm_gemv_mfma_try(const void* x, const void* W, const void* bia
   a.ws = (float*)ws;
   a.tickets = ws ? (unsigned*)((char*)ws + (size_t)4096 * 256 * 4) : nullptr;
   const int n_units = a.n_tiles * KS;
-  const size_t tail = 4 * WREG + 4096 + 256 + 64;
+  const size_t tail = 4 * WREG + 4096 + 256 + 64 + 512 + (Wsb ? (size_t)M * (K / 64) * 4 : 0);      // + sbr, xsum (4-bit)
   const size_t lds_full = (size_t)M * ((size_t)K * 2 + 16) + tail, lds_seg = (size_t)M * ((size_t)a.bpk * 256 + 16) + tail;
   const bool fullx = lds_full <= (norm_w ? 152 : 100) * 1024;      // (one workgroup per CU above 80 KB: only when the norm needs it)
   if (!fullx && (norm_w || lds_seg > 100 * 1024)) return -1;

@@ -18,6 +18,7 @@
 // chunk   scale * (dot - 128 * sum x) + bias * sum x   is the group's exact affine form (fp32; sum x is computed once per
 // lane and chunk, shared by all rows).  No weight is ever rounded to bf16.
 #include "common.cuh"
+#include "internal.h"
 #include "../../include/vlm_hip.h"
 
 namespace {
@@ -391,7 +392,32 @@ int w4_m(int M, const W4Args& a) {
 extern "C" int vlm_gemv_w4(const void* x, const void* Wq, const void* Wsb, const void* bias, const void* res,
                            const void* norm_w, void* y, int M, int N, int K, int ldx, int ldy, int ldres, float eps,
                            int epilogue, void* stream) {
+  return vlm_gemv_w4_ex(x, Wq, Wsb, bias, res, norm_w, y, M, N, K, ldx, ldy, ldres, eps, epilogue, 1, nullptr, stream);
+}
+
+extern "C" int vlm_gemv_w4_ws(const void* x, const void* Wq, const void* Wsb, const void* bias, const void* res, const void* norm_w,
+                              void* y, int M, int N, int K, int ldx, int ldy, int ldres, float eps, int epilogue, void* workspace,
+                              void* stream) {
+  return vlm_gemv_w4_ex(x, Wq, Wsb, bias, res, norm_w, y, M, N, K, ldx, ldy, ldres, eps, epilogue, 1, workspace, stream);
+}
+
+extern "C" int vlm_gemv_w4_qkv_rope_kvwrite_ws(const void* h, const void* norm_w, float eps, const void* Wq, const void* Wsb,
+                                               const void* bqkv, void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D,
+                                               const void* pos, const void* slot, const void* inv_freq, const void* block_table,
+                                               int max_pages, void* kpool, void* vpool, void* workspace, void* stream) {
+  return vlm_gemv_w4_qkv_rope_kvwrite_ex(h, norm_w, eps, Wq, Wsb, bqkv, qkv, ldq, M, hidden, Hq, Hkv, D, pos, slot, inv_freq,
+                                         block_table, max_pages, kpool, vpool, 1, workspace, stream);
+}
+
+// mfma / ws as vlm_gemv_bf16_ex: batched steps (5..16 rows) go to the dequant-fused MFMA form of csrc/gemv_mfma.hip
+VLM_INTERNAL int vlm_gemv_w4_ex(const void* x, const void* Wq, const void* Wsb, const void* bias, const void* res,
+                                const void* norm_w, void* y, int M, int N, int K, int ldx, int ldy, int ldres, float eps,
+                                int epilogue, int mfma, void* ws, void* stream) {
   if (!x || !Wq || !Wsb || !y || N <= 0 || K <= 0) return VLM_ERR_ARG;
+  if (mfma) {
+    const int rc = vlm_gemv_mfma_try_w4(x, Wq, Wsb, bias, res, norm_w, y, M, N, K, ldx, ldy, ldres, eps, epilogue, nullptr, ws, stream);
+    if (rc >= 0) return rc;
+  }
   if ((epilogue & VLM_EPI_BIAS) && !bias) return VLM_ERR_ARG;
   if ((epilogue & VLM_EPI_RESIDUAL) && !res) return VLM_ERR_ARG;
   if (K % 64 != 0 || ldx % 8 != 0) return VLM_ERR_SHAPE;
@@ -423,8 +449,24 @@ extern "C" int vlm_gemv_w4_qkv_rope_kvwrite(const void* h, const void* norm_w, f
                                             const void* pos, const void* slot, const void* inv_freq,
                                             const void* block_table, int max_pages, void* kpool, void* vpool,
                                             void* stream) {
+  return vlm_gemv_w4_qkv_rope_kvwrite_ex(h, norm_w, eps, Wq, Wsb, bqkv, qkv, ldq, M, hidden, Hq, Hkv, D, pos, slot, inv_freq,
+                                         block_table, max_pages, kpool, vpool, 1, nullptr, stream);
+}
+
+VLM_INTERNAL int vlm_gemv_w4_qkv_rope_kvwrite_ex(const void* h, const void* norm_w, float eps, const void* Wq, const void* Wsb,
+                                                 const void* bqkv, void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D,
+                                                 const void* pos, const void* slot, const void* inv_freq,
+                                                 const void* block_table, int max_pages, void* kpool, void* vpool, int mfma,
+                                                 void* ws, void* stream) {
   if (!h || !norm_w || !Wq || !Wsb || !bqkv || !qkv || !pos || !slot || !inv_freq || !kpool || !vpool || max_pages <= 0)
     return VLM_ERR_ARG;
+  if (mfma) {
+    const VlmRopeKv rk{(const int*)pos, (const int*)slot, (const float*)inv_freq, (const int*)block_table, max_pages, Hq, Hkv, D,
+                       (unsigned short*)kpool, (unsigned short*)vpool};
+    const int rc = vlm_gemv_mfma_try_w4(h, Wq, Wsb, bqkv, nullptr, norm_w, qkv, M, (Hq + 2 * Hkv) * D, hidden, hidden, ldq, 0, eps,
+                                        VLM_EPI_BIAS, &rk, ws, stream);
+    if (rc >= 0) return rc;
+  }
   if (hidden % 64 || hidden > 4096 || D % 16 || (size_t)M * hidden * 2 > 64 * 1024) return VLM_ERR_SHAPE;
   const int N = (Hq + 2 * Hkv) * D;
   W4Args a{h, Wq, Wsb, bqkv, nullptr, norm_w, qkv, N, hidden, hidden, ldq, 0, eps,

@@ -74,6 +74,9 @@ VLM_INTERNAL size_t vlm_gemv_mfma_ws_bytes(void);
 VLM_INTERNAL int vlm_gemv_mfma_try(const void* x, const void* W, const void* bias, const void* res, const void* norm_w, void* y,
                                    int M, int N, int K, int ldx, int ldw, int ldy, int ldres, float eps, int epilogue,
                                    const VlmRopeKv* rk, void* ws, void* stream);
+VLM_INTERNAL int vlm_gemv_mfma_try_w4(const void* x, const void* Wq, const void* Wsb, const void* bias, const void* res,
+                                      const void* norm_w, void* y, int M, int N, int K, int ldx, int ldy, int ldres, float eps,
+                                      int epilogue, const VlmRopeKv* rk, void* ws, void* stream);
 VLM_INTERNAL int vlm_gemv_bf16_ex(const void* x, const void* W, const void* bias, const void* res, const void* norm_w, void* y,
                                   int M, int N, int K, int ldx, int ldw, int ldy, int ldres, float eps, int epilogue, int mfma,
                                   void* ws, void* stream);
@@ -81,3 +84,10 @@ VLM_INTERNAL int vlm_gemv_qkv_rope_kvwrite_ex(const void* h, const void* norm_w,
                                               void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D, const void* pos,
                                               const void* slot, const void* inv_freq, const void* block_table, int max_pages,
                                               void* kpool, void* vpool, int mfma, void* ws, void* stream);
+VLM_INTERNAL int vlm_gemv_w4_ex(const void* x, const void* Wq, const void* Wsb, const void* bias, const void* res, const void* norm_w,
+                                void* y, int M, int N, int K, int ldx, int ldy, int ldres, float eps, int epilogue, int mfma, void* ws,
+                                void* stream);
+VLM_INTERNAL int vlm_gemv_w4_qkv_rope_kvwrite_ex(const void* h, const void* norm_w, float eps, const void* Wq, const void* Wsb,
+                                                 const void* bqkv, void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D,
+                                                 const void* pos, const void* slot, const void* inv_freq, const void* block_table,
+                                                 int max_pages, void* kpool, void* vpool, int mfma, void* ws, void* stream);

@@ -428,7 +428,7 @@ def batch_generate_ids(model, input_ids_list: List[np.ndarray], pixel_values_lis
     i = 0
     while i < len(order):
         rem = len(order) - i
-        wide = rem >= 16 and not getattr(lm, "quantized", False) and len(lm.pool._free_seqs) >= 16      # 16-row steps: gemv_mfma.hip
+        wide = rem >= 16 and len(lm.pool._free_seqs) >= 16      # 16-row steps: gemv_mfma.hip
         B = 16 if wide else 8 if rem >= 8 else 4 if rem >= 4 else 2 if rem >= 2 else 1
         idxs = order[i:i + B]
         i += B

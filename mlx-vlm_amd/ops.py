@@ -307,6 +307,34 @@ def gemv_w4_qkv_rope_kvwrite(h, norm_w, wq, sb, bqkv, Hq, Hkv, D, pos, slot, inv
     return out
 
 
+def gemv_w4_ws(x, wq, sb, bias=None, res=None, norm_w=None, out=None, eps=1e-6, epilogue=EPI_NONE):
+    """gemv_w4 for a batched decode step (up to 16 rows), split-K through the workspace where it pays"""
+    _dev(x, wq, sb, bias, res, norm_w, out)
+    M, K = x.shape
+    N = wq.shape[0]
+    n_out = N // 2 if epilogue & EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().vlm_gemv_w4_ws(_p(x), _p(wq), _p(sb), _p(bias), _p(res), _p(norm_w), _p(out), M, N, K, x.stride(0),
+                                    out.stride(0), res.stride(0) if res is not None else 0, eps, epilogue,
+                                    _p(gemv_workspace(x.device)), _stream()), "gemv_w4_ws")
+    return out
+
+
+def gemv_w4_qkv_rope_kvwrite_ws(h, norm_w, wq, sb, bqkv, Hq, Hkv, D, pos, slot, inv_freq, block_table, kpool, vpool, eps=1e-6,
+                                out=None, max_pages=None):
+    _dev(h, norm_w, wq, sb, bqkv, pos, slot, inv_freq, block_table, kpool, vpool)
+    M, K = h.shape
+    if out is None:
+        out = torch.zeros(M, (Hq + 2 * Hkv) * D, dtype=torch.bfloat16, device=h.device)
+    check(_lib.lib().vlm_gemv_w4_qkv_rope_kvwrite_ws(_p(h), _p(norm_w), eps, _p(wq), _p(sb), _p(bqkv), _p(out), out.stride(0), M,
+                                                     K, Hq, Hkv, D, _p(pos), _p(slot), _p(inv_freq), _p(block_table),
+                                                     block_table.shape[1] if block_table is not None else int(max_pages),
+                                                     _p(kpool), _p(vpool), _p(gemv_workspace(h.device)), _stream()),
+          "gemv_w4_qkv_rope_kvwrite_ws")
+    return out
+
+
 def dequant_w4(wq, sb, rows=None, out=None):
     """bf16 rows of a 4-bit matrix: all of them (rows None) or a gather (embedding lookup)"""
     _dev(wq, sb, rows, out)

@@ -886,3 +886,43 @@ def test_quantized_4bit_checkpoint_load_and_generate(tmp_path):
     (tmp_path / "config.json").write_text(json.dumps(conf))
     with pytest.raises(NotImplementedError):
         load(str(tmp_path))
+
+
+def test_quantized_4bit_16_row_batch_equals_single_requests():
+    """A 4-bit language model through 16 decode rows (dequant-fused MFMA projections) vs the same requests alone (4-bit
+    v_dot2c GEMVs): tokens equal except at ties inside bf16 noise; a token's log-prob is bf16(logit - bf16(lse)), so the two
+    summation orders may differ by an ulp of the LOGIT: the bound is 2 ulps of the step's log-prob span (max |lp| over the
+    vocabulary, the logit scale), not of the log-prob itself."""
+    from mlx_vlm_amd.batch import BatchGenerator
+    from mlx_vlm_amd.generate import generate_step
+
+    cfg, ck, ow = _quantized_tiny()
+    model = build_product_model(cfg, ck, kv_pool_tokens=16384, max_seqs=40)
+    reqs = _mixed_requests(cfg, 18, seed0=240)
+    max_tokens = [5 + (3 * i) % 7 for i in range(18)]
+    singles = []
+    for (ids, pix, thw), m in zip(reqs, max_tokens):
+        kw = dict(image_grid_thw=thw) if thw is not None else {}
+        singles.append([(t, float(lp[t]), float(lp.float().abs().max())) for t, lp in
+                        generate_step(ids, model, torch.from_numpy(pix) if pix is not None else None, None, max_tokens=m, **kw)])
+    gen = BatchGenerator(model, None, max_tokens=8, completion_batch_size=16, prefill_batch_size=8)
+    assert gen.completion_batch_size == 16
+    uids = _insert_all(gen, reqs, max_tokens)
+    got = {u: [] for u in uids}
+    widths = set()
+    while gen.has_work:
+        _, out = gen.next()
+        widths.add(gen._width)
+        for r in out:
+            got[r.uid].append((r.token, r.token_logprob))
+    gen.close()
+    assert 16 in widths
+    n_equal = 0
+    for u in uids:
+        for i, ((ta, la), (tb, lb, span)) in enumerate(zip(got[u], singles[u])):
+            assert abs(la - lb) <= 2 * 2 ** -7 * span, (u, i, span, got[u], singles[u])
+            if ta != tb:
+                break
+            n_equal += 1
+        assert len(got[u]) == len(singles[u]) == max_tokens[u]
+    assert n_equal >= 0.8 * sum(max_tokens), (n_equal, sum(max_tokens))       # ties are the exception, not the rule

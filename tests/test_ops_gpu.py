@@ -920,3 +920,81 @@ def test_gemv_mfma_rows_qkv_rope_kvwrite(vops, M, paged):
         ok, rep = bf16_close(vp[page, :, within], qkv[m, Hq + Hkv:], ulps=2)
         assert ok, (m, rep)
     assert int((kpool != 0).sum().cpu()) <= M * Hkv * D and int((vpool != 0).sum().cpu()) <= M * Hkv * D
+
+
+# ------------------------------------------------------------------ batched decode rows over 4-bit weights (gemv_mfma.hip, W4 form)
+@pytest.mark.parametrize("M", [5, 8, 16])
+@pytest.mark.parametrize("N,K", [(2048, 1536), (1536, 8960), (302, 256), (1024, 3584)])
+def test_gemv_w4_mfma_rows_plain_bias_residual(vops, M, N, K):
+    """vlm_gemv_w4_ws for 5..16 rows vs nn.QuantizedLinear restated: nibbles as bf16 128 + q in the MFMA A fragments, every
+    64-wide group scaled in fp32 (exact affine form), bias as a second typed op; split-K forms through the workspace;
+    repeatable bit for bit."""
+    ow, dw = _q4(N, K, seed=310 + M)
+    x, b, r = rnd(M, K, seed=311), rnd(N, seed=312, scale=0.3), rnd(M, N, seed=313)
+    out = vops.gemv_w4_ws(x.cuda(), dw.wq, dw.sb)
+    ok, rep = bf16_close(out, ow.linear(x), ulps=2)
+    assert ok, rep
+    assert torch.equal(vops.gemv_w4_ws(x.cuda(), dw.wq, dw.sb), out)
+    ok, rep = bf16_close(vops.gemv_w4_ws(x.cuda(), dw.wq, dw.sb, bias=b.cuda(), epilogue=vops.EPI_BIAS), ow.linear(x, b), ulps=2)
+    assert ok, rep
+    rr = r.cuda().clone()
+    out2 = vops.gemv_w4_ws(x.cuda(), dw.wq, dw.sb, res=rr, out=rr, epilogue=vops.EPI_RESIDUAL)
+    # r + lin cancels: the error of the sum is one rounding step of the INTERMEDIATE lin (rms 2.2 here: an ulp of 2^-6 where
+    # the sum can be near 0) plus the sum's own rounding, so the bound is stated on |lin| + |sum|
+    lin = ow.linear(x).float()
+    ref2 = O.add(r, ow.linear(x)).float()
+    err = (out2.float().cpu() - ref2).abs()
+    tol = 2.0 ** -7 * lin.abs() + 2 * 2.0 ** -7 * ref2.abs() + 2e-3 * float(ref2.pow(2).mean().sqrt())
+    assert bool((err <= tol).all()), (float(err.max()), int((err > tol).sum()))
+
+
+@pytest.mark.parametrize("M", [8, 16])
+def test_gemv_w4_mfma_rows_norm_swiglu_head_and_qkv(vops, M):
+    from mlx_vlm_amd.models import quantized as Qz
+
+    K, I = 1536, 2048
+    h, nw = rnd(M, K, seed=320), (1 + 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(321))).to(BF)
+    og, dg = _q4(I, K, seed=322)
+    ou, du = _q4(I, K, seed=323)
+    dgu = Qz.interleave_rows(dg, du)
+    xn = O.rms_norm(h, nw, 1e-6)
+    out = vops.gemv_w4_ws(h.cuda(), dgu.wq, dgu.sb, norm_w=nw.cuda(), eps=1e-6, epilogue=vops.EPI_SWIGLU)
+    ok, rep = bf16_close(out, O.swiglu(og.linear(xn), ou.linear(xn)), ulps=3)
+    assert ok, rep
+    oh, dh = _q4(9000, K, seed=324)
+    ok, rep = bf16_close(vops.gemv_w4_ws(h.cuda(), dh.wq, dh.sb, norm_w=nw.cuda(), eps=1e-6), oh.linear(xn), ulps=2)
+    assert ok, rep
+    if M < 9:
+        return
+    # qkv + M-RoPE + paged KV write over 4-bit q / k / v rows
+    Hq, Hkv, D = 12, 2, 128
+    parts = [_q4(Hq * D, K, seed=330), _q4(Hkv * D, K, seed=331), _q4(Hkv * D, K, seed=332)]
+    dq = Qz.cat_rows([p[1] for p in parts])
+    bqkv = rnd((Hq + 2 * Hkv) * D, seed=333, scale=0.3)
+    g = torch.Generator().manual_seed(334)
+    pos = torch.randint(0, 3000, (M,), generator=g, dtype=torch.int32)
+    max_pages = 4
+    slot = torch.randint(0, 64 * max_pages, (M,), generator=g, dtype=torch.int32)
+    inv = O.mrope_inv_freq(D, 1e6)
+    sel = O.chunked_position_selector([16, 24, 24], D // 2)
+    bs = [bqkv[:Hq * D], bqkv[Hq * D:(Hq + Hkv) * D], bqkv[(Hq + Hkv) * D:]]
+    qkv = torch.cat([p[0].linear(xn, b) for p, b in zip(parts, bs)], -1).view(M, Hq + 2 * Hkv, D)
+    p3 = pos.long()[None, :, None].expand(3, M, 1)
+    qr = O.mrope_apply(qkv[:, :Hq][:, :, None], p3, inv, sel, "fused")[:, :, 0]
+    kr = O.mrope_apply(qkv[:, Hq:Hq + Hkv][:, :, None], p3, inv, sel, "fused")[:, :, 0]
+    n_pages = M * max_pages
+    bt = torch.randperm(n_pages, generator=g).to(torch.int32).reshape(M, max_pages)
+    kpool = torch.zeros(n_pages, Hkv, D // 8, 64, 8, dtype=BF, device="cuda")
+    vpool = torch.zeros(n_pages, Hkv, D, 64, dtype=BF, device="cuda")
+    out = vops.gemv_w4_qkv_rope_kvwrite_ws(h.cuda(), nw.cuda(), dq.wq, dq.sb, bqkv.cuda(), Hq, Hkv, D, pos.cuda(), slot.cuda(),
+                                           inv.cuda(), bt.cuda(), kpool, vpool)
+    ok, rep = bf16_close(out.view(M, Hq + 2 * Hkv, D)[:, :Hq], qr, ulps=2)
+    assert ok, rep
+    kp = kpool.cpu().permute(0, 1, 3, 2, 4).reshape(n_pages, Hkv, 64, D)
+    vp = vpool.cpu()[..., VSLOT].permute(0, 1, 3, 2)
+    for m in range(M):
+        page, within = int(bt[m, int(slot[m]) // 64]), int(slot[m]) % 64
+        ok, rep = bf16_close(kp[page, :, within], kr[m], ulps=2)
+        assert ok, (m, rep)
+        ok, rep = bf16_close(vp[page, :, within], qkv[m, Hq + Hkv:], ulps=2)
+        assert ok, (m, rep)
