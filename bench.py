@@ -317,7 +317,9 @@ def _load_synthetic(cfg_dict, model_pkg, rank, dev, w4=False, **engine_kw):
     cfg = model_pkg.ModelConfig.from_dict(dict(cfg_dict))
     t0 = time.perf_counter()
     W = synthetic.random_weights(cfg, seed=0, device=dev, fill=(rank == 0))
-    if w4:
+    if w4 and getattr(cfg, "model_type", "") == "phi3_v":
+        synthetic.quantize_random_(W, prefix="", skip=("model.vision_embed_tokens.",))
+    elif w4:
         synthetic.quantize_random_(W)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -556,6 +558,69 @@ def workload_7b_b32(args, rank, ws, dev):
     return out
 
 
+def workload_phi35v_w4_b16(args, rank, ws, dev):
+    """BASELINE configs[4]: Phi-3.5-vision-instruct with an MLX affine 4-bit language model (the dequant-fused kernels:
+    csrc/gemv_w4.hip at 1-4 rows, the W4 form of csrc/gemv_mfma.hip at 5-16 rows; prefill = dequantise + bf16 GEMM), batch
+    16 PER GPU: 16 requests of one 336 x 336 image (HD transform at num_crops 4: 5 CLIP views -> 757 image tokens) + 128
+    text tokens, greedy 64 new tokens, through the continuous generator at 16 decode rows (weak scaling: every rank
+    serves its own 16)."""
+    from mlx_vlm_amd import parallel, synthetic
+    from mlx_vlm_amd.batch import generate_batch_continuous
+    from mlx_vlm_amd.models import phi3_v
+
+    cfg, model, load = _load_synthetic(synthetic.PHI35_VISION, phi3_v, rank, dev, w4=True, kv_pool_tokens=32768, max_seqs=40)
+    n_req, max_tokens = 16, args.max_tokens or 64
+    ip = phi3_v.Phi3VImageProcessor()
+    ids_l, pix_l, ex_l = [], [], []
+    for i in range(n_req):
+        rng = np.random.default_rng(1000 * rank + i)
+        out = ip([rng.integers(0, 256, (336, 336, 3), dtype=np.uint8)])
+        n_img = ip.calc_num_image_tokens(np.zeros((336, 336, 3), np.uint8))
+        text = rng.integers(3, 32000, 128)
+        ids_l.append(np.concatenate([text[:64], np.full(n_img, -1), text[64:]]).astype(np.int64))
+        pix_l.append(torch.from_numpy(out["pixel_values"]).to(dev))
+        ex_l.append({"image_sizes": out["image_sizes"]})
+    run = lambda n, mt: generate_batch_continuous(model, ids_l[:n], pix_l[:n], [None] * n, max_tokens=mt, extras=ex_l[:n])  # noqa: E731
+    for _ in range(args.warmup):
+        run(n_req, 8)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gen_tok = gen_t = pre_tok = pre_t = 0.0
+    for _ in range(args.steps):
+        toks, st = run(n_req, max_tokens)
+        gen_tok, gen_t = gen_tok + st.generation_tokens, gen_t + st.generation_time
+        pre_tok, pre_t = pre_tok + st.prompt_tokens, pre_t + st.prompt_time
+    torch.cuda.synchronize()
+    parallel.barrier()
+    wall = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    gen_t_max = parallel.max_over_ranks(gen_t, dev)
+    D, I, H = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
+    lm_params = cfg.num_hidden_layers * (3 * H * 128 * D + D * H * 128 + 3 * D * I) + 2 * cfg.vocab_size * D   # engine layout (96 -> 128)
+    step_bytes = lm_params * 9 // 16          # weights streamed once per 16-row step (4 bits + 32 / 64 bits per weight)
+    steps_per_s = gen_tok / n_req / gen_t_max
+    v = cfg.vision_config
+    N = 577
+    clip_tflop = 5 * ((v.num_hidden_layers - 1) * (8 * N * v.hidden_size ** 2 + 4 * N * v.hidden_size * v.intermediate_size
+                                                   + 4 * N * N * v.hidden_size) + 2 * 576 * 588 * v.hidden_size) / 1e12
+    out = {"metric": "decode tokens/sec, Phi-3.5-vision int4 (MLX affine, group 64), batch=16 per GPU", "value": ws * gen_tok / gen_t_max,
+           "unit": "tokens/s", "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16 activations, int4 affine weights (fp32 accumulate)", "data": "synthetic",
+           "config": {"workload": "Phi-3.5-vision-instruct dims (Phi-3-mini 3.8B decoder as an MLX affine 4-bit checkpoint: random "
+                                  "nibbles / scales / biases; CLIP ViT-L/14-336 bf16), 16 requests per GPU: one 336x336 image (5 views -> "
+                                  f"757 image tokens) + 128 text tokens, greedy {max_tokens} new tokens, EOS disabled, 16 decode rows",
+                      "requests_per_gpu": n_req, "prompt_tokens": int(ids_l[0].size), "max_tokens": max_tokens, "parallelism": f"dp{ws}"},
+           "e2e_tokens_per_s": ws * gen_tok / wall, "prompt_tps": ws * pre_tok / max(pre_t, 1e-9),
+           "images_per_s_prefill": ws * n_req * args.steps / max(pre_t, 1e-9), "clip_tflop_per_image": clip_tflop,
+           "load": load, "distributed": _dist_info(ws),
+           "roofline": {"bound": "hbm", "kernel": "whole 16-row decode step (4-bit weights streamed once per step)",
+                        "achieved": step_bytes * steps_per_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": step_bytes * steps_per_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_weight_bytes_per_step": step_bytes}}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -564,7 +629,7 @@ def main():
     ap.add_argument("--max-tokens", type=int, default=0, help="0 = the workload's own (256 / 64 / 64)")
     ap.add_argument("--lookahead", type=int, default=8)
     ap.add_argument("--vit-batch", type=int, default=16)
-    ap.add_argument("--workload", default="qwen2vl-2b", choices=["qwen2vl-2b", "nanollava", "qwen2vl-7b-b32", "qwen2vl-2b-w4"])
+    ap.add_argument("--workload", default="qwen2vl-2b", choices=["qwen2vl-2b", "nanollava", "qwen2vl-7b-b32", "qwen2vl-2b-w4", "phi35v-w4-b16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-hf", action="store_true", help="skip the HuggingFace torch-CPU second opinion of cpu_baseline")
     ap.add_argument("--no-extras", action="store_true", help="skip kernel rooflines / ViT throughput (profiling runs)")
@@ -579,7 +644,8 @@ def main():
     if rank == 0 and ws > 1:
         print(f"[bench] {ws} ranks, backend {_dist_info(ws)['backend']} (RCCL over xGMI), one process per GPU", file=sys.stderr, flush=True)
     if args.workload != "qwen2vl-2b":
-        out = {"nanollava": workload_nanollava, "qwen2vl-7b-b32": workload_7b_b32, "qwen2vl-2b-w4": workload_2b_w4}[args.workload](
+        out = {"nanollava": workload_nanollava, "qwen2vl-7b-b32": workload_7b_b32, "qwen2vl-2b-w4": workload_2b_w4,
+               "phi35v-w4-b16": workload_phi35v_w4_b16}[args.workload](
             args, rank, ws, dev)
         if rank == 0:
             print(json.dumps(out), flush=True)

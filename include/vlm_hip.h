@@ -151,6 +151,13 @@ int vlm_mrope_kvwrite(void* qkv, int ld, int T, int Hq, int Hkv, int D, const vo
                       const void* pos_w, const void* inv_freq, int sec0, int sec1, const void* kv_seq,
                       const void* kv_slot, const void* block_table, int max_pages, void* kpool, void* vpool,
                       void* stream);
+/* the same with SuScaledRoPE's input scale (rope_utils.py:174-176, Phi-3.5 phi3_v.py:41-48): q and k are multiplied by
+ * qk_scale and rounded to bf16 (the reference's typed `scale.astype(x.dtype) * x`) before the rotation; v is not scaled.
+ * qk_scale = 1 is vlm_mrope_kvwrite bit for bit. */
+int vlm_mrope_kvwrite_scaled(void* qkv, int ld, int T, int Hq, int Hkv, int D, const void* pos_t, const void* pos_h,
+                             const void* pos_w, const void* inv_freq, int sec0, int sec1, const void* kv_seq,
+                             const void* kv_slot, const void* block_table, int max_pages, void* kpool, void* vpool,
+                             float qk_scale, void* stream);
 
 /* The fetch half of KVCache.update_and_fetch (cache.py:345-367 returns keys / values [..., :offset, :]) over the PAGED
  * pools: the cached (rotated) k and v of token t - slot kv_slot[t] of sequence kv_seq[t] (NULL: seq = t) - are copied
@@ -251,6 +258,8 @@ typedef struct vlm_llm_config {
   int mrope_sec0, mrope_sec1; /* mrope_section[0], [1] */
   float attn_scale;           /* softmax scale of the attention; 0 = head_dim ** -0.5.  Set when the engine's head_dim is a
                                  zero-padded form of the model's (e.g. 64 -> 128, llava_bunny language.py:24-25) */
+  float rope_qk_scale;        /* ABI v3.  SuScaledRoPE (rope_utils.py:96-189): q and k are multiplied by this and rounded to
+                                 bf16 before the rotation, in the prefill pass and in every decode qkv epilogue; 0 = 1 = none */
 } vlm_llm_config;
 
 typedef struct vlm_llm_layer {

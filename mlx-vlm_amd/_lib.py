@@ -18,7 +18,7 @@ c_void_p, c_int, c_float, c_uint, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c
 class LlmConfig(C.Structure):
     _fields_ = [("hidden", c_int), ("n_layers", c_int), ("inter", c_int), ("n_heads", c_int), ("n_kv_heads", c_int),
                 ("head_dim", c_int), ("vocab", c_int), ("rms_eps", c_float), ("mrope_sec0", c_int), ("mrope_sec1", c_int),
-                ("attn_scale", c_float)]
+                ("attn_scale", c_float), ("rope_qk_scale", c_float)]
 
 
 class LlmLayer(C.Structure):
@@ -108,6 +108,8 @@ SIGNATURES = {
     "vlm_rope2d_vision": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "vlm_mrope_kvwrite": (c_int, [c_void_p] + [c_int] * 5 + [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 3 + [c_int]
                           + [c_void_p] * 3),
+    "vlm_mrope_kvwrite_scaled": (c_int, [c_void_p] + [c_int] * 5 + [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 3 + [c_int]
+                                 + [c_void_p] * 2 + [c_float, c_void_p]),
     "vlm_kv_gather": (c_int, [c_void_p] + [c_int] * 5 + [c_void_p] * 3 + [c_int] + [c_void_p] * 3),
     "vlm_attn_prefill": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] + [c_int] * 5 + [c_float, c_int, c_void_p]),
     "vlm_attn_decode_paged": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 5

@@ -206,7 +206,8 @@ class BatchGenerator:
         ids_l = [b[1] for b in batch]
         pix_l = [b[3].get("pixel_values") for b in batch]
         grid_l = [b[3].get("image_grid_thw") for b in batch]
-        emb, pos, lens, deltas = embed_requests(self.model, ids_l, pix_l, grid_l)
+        extras = [{k: v for k, v in b[3].items() if k not in ("pixel_values", "image_grid_thw")} for b in batch]
+        emb, pos, lens, deltas = embed_requests(self.model, ids_l, pix_l, grid_l, extras)
         caches = [lm.make_cache() for _ in batch]
         for c, L, b in zip(caches, lens, batch):
             c[0]._seq.reserve(L + b[2] + 2)          # prompt + every token it may generate + the step in flight
@@ -492,9 +493,11 @@ class BatchGenerator:
 
 
 def generate_batch_continuous(model, input_ids_list, pixel_values_list, grids, *, max_tokens=128, stop_ids=(),
-                              sampler: Optional[Sampler] = None, batch_size: int = MAX_ROWS, use_graph: bool = True):
+                              sampler: Optional[Sampler] = None, batch_size: int = MAX_ROWS, use_graph: bool = True,
+                              extras: Optional[List[Optional[dict]]] = None):
     """The reference's `_generate_batch` loop (ar.py:3212-3232) over the continuous generator: every request is queued
     at once, the generator keeps up to `batch_size` of them decoding and admits the next ones as rows free up.
+    extras: per-request keyword arguments of the model's `get_input_embeddings` besides pixels / grid (phi3_v: image_sizes).
     -> (tokens per request without the stop token, BatchStats)"""
     gen = BatchGenerator(model, None, max_tokens=max(max_tokens) if isinstance(max_tokens, (list, tuple)) else max_tokens,
                          stop_tokens=set(stop_ids), sampler=sampler,
@@ -502,6 +505,11 @@ def generate_batch_continuous(model, input_ids_list, pixel_values_list, grids, *
                          use_graph=use_graph)
     kw: List[Dict[str, Any]] = [dict(pixel_values=p, image_grid_thw=g) if p is not None else {}
                                 for p, g in zip(pixel_values_list, grids)]
+    for k, e in zip(kw, extras or []):
+        if e and "pixel_values" in k:
+            k.update(e)
+            if k.get("image_grid_thw") is None:
+                del k["image_grid_thw"]
     uids = gen.insert([np.asarray(i).reshape(-1) for i in input_ids_list], max_tokens, prompt_kwargs=kw)
     results = {u: [] for u in uids}
     tic = time.perf_counter()

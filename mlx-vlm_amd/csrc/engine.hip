@@ -113,7 +113,7 @@ inline char* off(void* p, size_t bytes) { return static_cast<char*>(p) + bytes; 
 
 }  // namespace
 
-extern "C" int vlm_abi_version(void) { return 2; }
+extern "C" int vlm_abi_version(void) { return 3; }
 
 // ------------------------------------------------------------------ LLM
 extern "C" int vlm_llm_create(const vlm_llm_config* cfg, void** handle) {
@@ -277,6 +277,7 @@ extern "C" int vlm_llm_prefill(void* handle, const vlm_prefill_args* a, void* st
   const int D = c.hidden, hd = c.head_dim, Hq = c.n_heads, Hkv = c.n_kv_heads;
   const int QKV = (Hq + 2 * Hkv) * hd, T = a->T;
   const float scale = c.attn_scale > 0.f ? c.attn_scale : 1.0f / sqrtf((float)hd);
+  const float qk_scale = c.rope_qk_scale > 0.f ? c.rope_qk_scale : 1.f;
   for (int i = 0; i < c.n_layers; ++i) {
     const vlm_llm_layer& w = m->layers[i];
     // xn = RMSNorm(h)
@@ -286,8 +287,9 @@ extern "C" int vlm_llm_prefill(void* handle, const vlm_prefill_args* a, void* st
     // M-RoPE on q, k in place + paged KV write
     void* kp = m->kv.kpool ? off(m->kv.kpool, (size_t)i * m->kv.layer_stride * 2) : nullptr;
     void* vp = m->kv.vpool ? off(m->kv.vpool, (size_t)i * m->kv.layer_stride * 2) : nullptr;
-    TRY(vlm_mrope_kvwrite(a->qkv, QKV, T, Hq, Hkv, hd, a->pos_t, a->pos_h, a->pos_w, m->g.inv_freq, c.mrope_sec0,
-                          c.mrope_sec1, a->kv_seq, a->kv_slot, m->kv.block_table, m->kv.max_pages, kp, vp, stream));
+    TRY(vlm_mrope_kvwrite_scaled(a->qkv, QKV, T, Hq, Hkv, hd, a->pos_t, a->pos_h, a->pos_w, m->g.inv_freq, c.mrope_sec0,
+                                 c.mrope_sec1, a->kv_seq, a->kv_slot, m->kv.block_table, m->kv.max_pages, kp, vp, qk_scale,
+                                 stream));
     // causal flash attention over each sequence
     TRY(vlm_attn_prefill(a->qkv, off(a->qkv, (size_t)Hq * hd * 2), off(a->qkv, (size_t)(Hq + Hkv) * hd * 2), a->attn, QKV,
                          QKV, QKV, Hq * hd, a->cu_seqlens, a->nseg, a->total_qblocks, Hq, Hkv, hd, scale, 1, stream));
@@ -354,6 +356,7 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
   const int D = c.hidden, hd = c.head_dim, Hq = c.n_heads, Hkv = c.n_kv_heads, B = a->B, NL = c.n_layers;
   const int QKV = (Hq + 2 * Hkv) * hd;
   const float scale = c.attn_scale > 0.f ? c.attn_scale : 1.0f / sqrtf((float)hd);
+  const float qk_scale = c.rope_qk_scale > 0.f ? c.rope_qk_scale : 1.f;
   const bool fused_tail = sample && (a->flags & VLM_DECODE_FUSED_TAIL) && a->temperature == 0.f;
   if ((a->flags & VLM_DECODE_FUSED_TAIL) && !fused_tail) return 1;   // the flag promises h == embed[tok] at entry
   const Tuning& tn = m->tune;
@@ -399,14 +402,15 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
     if (w.wqkv_sb) {
       TRY(vlm_gemv_w4_qkv_rope_kvwrite_ex(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.wqkv_sb, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos,
                                           a->ctx, m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, m->tune.mfma_gemv,
-                                          m->mfma_ws, stream)); ++n;
+                                          m->mfma_ws, qk_scale, stream)); ++n;
     } else {
     TRY(vlm_gemv_qkv_rope_kvwrite_ex(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos, a->ctx,
                                      m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, m->tune.mfma_gemv, m->mfma_ws,
-                                     stream)); ++n;
+                                     qk_scale, stream)); ++n;
     }
     }
     // attention over the pages (the new token is already in the cache: kv_len = ctx + 1)
+    const bool combine = w.wo_sb != nullptr || Hq * hd > 3584;
     const VlmProgress prog{pf == 2 ? m->progress : nullptr, i + 1};
     if (skip & 2) {
     } else if (a->nsplit == 1) {
@@ -414,9 +418,10 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
       TRY(vlm_attn_decode_paged_ex(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale, 1,
                                    a->part_o, a->part_ml, a->attn, Hq * hd, prog, stream)); ++n;
     } else {
-      // long contexts: split-K partials, merged in the o_proj GEMV prologue (bf16 Wo) or by the combine kernel (4-bit Wo)
+      // long contexts: split-K partials, merged in the o_proj GEMV prologue (bf16 Wo up to 3584 columns: the row-wave
+      // kernel) or by the combine kernel (4-bit Wo; wider bf16 Wo, e.g. 32 heads x 128)
       TRY(vlm_attn_decode_paged_ex(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale,
-                                   a->nsplit, a->part_o, a->part_ml, w.wo_sb ? a->attn : nullptr, w.wo_sb ? Hq * hd : 0, prog,
+                                   a->nsplit, a->part_o, a->part_ml, combine ? a->attn : nullptr, combine ? Hq * hd : 0, prog,
                                    stream)); ++n;
     }
     if (pf == 1) {
@@ -445,7 +450,7 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
       continue;
     }
     if (skip & 4) {
-    } else if (a->nsplit == 1 || w.wo_sb) {
+    } else if (a->nsplit == 1 || combine) {
       TRY(lin_gemv(m, a->attn, w.wo, w.wo_sb, nullptr, a->h, nullptr, a->h, B, D, Hq * hd, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
     } else {
       TRY(vlm_gemv_attn_out(a->part_o, a->part_ml, a->nsplit, w.wo, a->h, D, B, D, Hq, hd, stream)); ++n;

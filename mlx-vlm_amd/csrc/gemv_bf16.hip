@@ -41,6 +41,7 @@ struct RopeKvArgs {
   int max_pages, Hq, Hkv, D;
   bf16_t* kpool;             // [page][Hkv][D/8][64][8]
   bf16_t* vpool;             // [page][Hkv][D][64 key slots]
+  float qk_scale = 1.f;      // q and k are multiplied by this (a typed op: rounded to bf16) before the rotation - SuScaledRoPE
 };
 
 struct AttnProArgs {
@@ -327,7 +328,8 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
       if (rope_pair) {
         float sn, cs;
         sincosf((float)e_pos * e_if, &sn, &cs);
-        const float o0 = y0 * cs - y1 * sn, o1 = y1 * cs + y0 * sn;
+        const float z0 = rbf(y0 * rk.qk_scale), z1 = rbf(y1 * rk.qk_scale);      // (exact no-op at scale 1)
+        const float o0 = z0 * cs - z1 * sn, o1 = z1 * cs + z0 * sn;
         if (rope_head < rk.Hq) {
           y[(size_t)m * ldy + row[0]] = f2bf(o0);
           y[(size_t)m * ldy + row[R - 1]] = f2bf(o1);
@@ -546,7 +548,7 @@ extern "C" int vlm_gemv_qkv_rope_kvwrite_ws(const void* h, const void* norm_w, f
                                             const void* slot, const void* inv_freq, const void* block_table, int max_pages,
                                             void* kpool, void* vpool, void* workspace, void* stream) {
   return vlm_gemv_qkv_rope_kvwrite_ex(h, norm_w, eps, Wqkv, bqkv, qkv, ldq, M, hidden, Hq, Hkv, D, pos, slot, inv_freq, block_table,
-                                      max_pages, kpool, vpool, 1, workspace, stream);
+                                      max_pages, kpool, vpool, 1, workspace, 1.f, stream);
 }
 
 // mfma: 0 = v_dot2c kernels only; ws: the engine's workspace for vlm_gemv_mfma_try (nullptr: no K split over workgroups)
@@ -598,20 +600,20 @@ extern "C" int vlm_gemv_qkv_rope_kvwrite(const void* h, const void* norm_w, floa
                                          const void* block_table, int max_pages, void* kpool, void* vpool,
                                          void* stream) {
   return vlm_gemv_qkv_rope_kvwrite_ex(h, norm_w, eps, Wqkv, bqkv, qkv, ldq, M, hidden, Hq, Hkv, D, pos, slot, inv_freq, block_table,
-                                      max_pages, kpool, vpool, 1, nullptr, stream);
+                                      max_pages, kpool, vpool, 1, nullptr, 1.f, stream);
 }
 
 VLM_INTERNAL int vlm_gemv_qkv_rope_kvwrite_ex(const void* h, const void* norm_w, float eps, const void* Wqkv,
                                               const void* bqkv, void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D,
                                               const void* pos, const void* slot, const void* inv_freq,
                                               const void* block_table, int max_pages, void* kpool, void* vpool, int mfma,
-                                              void* ws, void* stream) {
+                                              void* ws, float qk_scale, void* stream) {
   if (!h || !norm_w || !Wqkv || !bqkv || !qkv || !pos || !slot || !inv_freq || !kpool || !vpool || max_pages <= 0)
     return VLM_ERR_ARG;
   const int N = (Hq + 2 * Hkv) * D;
   if (mfma) {
     const VlmRopeKv rk{(const int*)pos, (const int*)slot, (const float*)inv_freq, (const int*)block_table, max_pages, Hq, Hkv, D,
-                       (unsigned short*)kpool, (unsigned short*)vpool};
+                       (unsigned short*)kpool, (unsigned short*)vpool, qk_scale};
     const int rc = vlm_gemv_mfma_try(h, Wqkv, bqkv, nullptr, norm_w, qkv, M, N, hidden, hidden, hidden, ldq, 0, eps, VLM_EPI_BIAS, &rk,
                                      ws, stream);
     if (rc >= 0) return rc;
@@ -619,7 +621,7 @@ VLM_INTERNAL int vlm_gemv_qkv_rope_kvwrite_ex(const void* h, const void* norm_w,
   if (hidden % 8 || D % 16 || hidden > 3584 || (size_t)M * hidden * 2 > 64 * 1024) return VLM_ERR_SHAPE;
   Args a{h, Wqkv, bqkv, nullptr, norm_w, qkv, N, hidden, hidden, hidden, ldq, 0, eps,
          RopeKvArgs{(const int*)pos, (const int*)slot, (const float*)inv_freq, (const int*)block_table, max_pages, Hq, Hkv,
-                    D, (bf16_t*)kpool, (bf16_t*)vpool},
+                    D, (bf16_t*)kpool, (bf16_t*)vpool, qk_scale},
          AttnProArgs{}, (hipStream_t)stream};
   return launch_rw_m<PRO_RMSNORM, EPI_ROPE_KV>(M, a);
 }

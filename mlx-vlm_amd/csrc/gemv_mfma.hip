@@ -350,7 +350,8 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
               const float y0 = rbf((W4 ? rbf(v) : v) + bf2f(a.bias[n])), y1 = rbf((W4 ? rbf(part[tid + 128]) : part[tid + 128]) + bf2f(a.bias[n1]));
               float sn, cs;
               sincosf((float)a.rk.pos[m] * a.rk.inv_freq[j], &sn, &cs);
-              const float o0 = y0 * cs - y1 * sn, o1 = y1 * cs + y0 * sn;
+              const float z0 = rbf(y0 * a.rk.qk_scale), z1 = rbf(y1 * a.rk.qk_scale);      // SuScaledRoPE's typed x * scale
+              const float o0 = z0 * cs - z1 * sn, o1 = z1 * cs + z0 * sn;
               if (head < a.rk.Hq) {
                 a.y[(size_t)m * a.ldy + n] = f2bf(o0);
                 a.y[(size_t)m * a.ldy + n1] = f2bf(o1);

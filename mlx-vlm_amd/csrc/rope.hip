@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void mrope_kvwrite_kernel(
     bf16_t* __restrict__ qkv, int ld, int T, int Hq, int Hkv, int D, const int* __restrict__ pos_t,
     const int* __restrict__ pos_h, const int* __restrict__ pos_w, const float* __restrict__ inv_freq, int sec0, int sec1,
     const int* __restrict__ kv_seq, const int* __restrict__ kv_slot, const int* __restrict__ block_table, int max_pages,
-    bf16_t* __restrict__ kpool, bf16_t* __restrict__ vpool) {
+    bf16_t* __restrict__ kpool, bf16_t* __restrict__ vpool, float qk_scale) {
   const int half = D >> 1, cph = half >> 3;
   const int rot_items = (Hq + Hkv) * cph;      // rotary chunks per token
   const int v_items = Hkv * (D >> 3);          // v copy chunks per token
@@ -100,8 +100,10 @@ __global__ __launch_bounds__(256) void mrope_kvwrite_kernel(
       const float ang = p * inv_freq[f];
       float s, co;
       sincosf(ang, &s, &co);
-      oa[j] = a[j] * co - b[j] * s;
-      ob[j] = b[j] * co + a[j] * s;
+      // SuScaledRoPE multiplies q / k by T(scale) first (a typed op: one rounding; exact no-op at scale 1)
+      const float za = rbf(a[j] * qk_scale), zb = rbf(b[j] * qk_scale);
+      oa[j] = za * co - zb * s;
+      ob[j] = zb * co + za * s;
     }
     const uint4 lo = pack8(oa), hi = pack8(ob);
     *reinterpret_cast<uint4*>(base) = lo;
@@ -187,6 +189,14 @@ extern "C" int vlm_mrope_kvwrite(void* qkv, int ld, int T, int Hq, int Hkv, int 
                                  const void* pos_w, const void* inv_freq, int sec0, int sec1, const void* kv_seq,
                                  const void* kv_slot, const void* block_table, int max_pages, void* kpool, void* vpool,
                                  void* stream) {
+  return vlm_mrope_kvwrite_scaled(qkv, ld, T, Hq, Hkv, D, pos_t, pos_h, pos_w, inv_freq, sec0, sec1, kv_seq, kv_slot, block_table,
+                              max_pages, kpool, vpool, 1.f, stream);
+}
+
+extern "C" int vlm_mrope_kvwrite_scaled(void* qkv, int ld, int T, int Hq, int Hkv, int D, const void* pos_t, const void* pos_h,
+                                        const void* pos_w, const void* inv_freq, int sec0, int sec1, const void* kv_seq,
+                                        const void* kv_slot, const void* block_table, int max_pages, void* kpool, void* vpool,
+                                        float qk_scale, void* stream) {
   if (!qkv || !pos_t || !pos_h || !pos_w || !inv_freq || T < 0 || Hq <= 0 || Hkv <= 0) return VLM_ERR_ARG;
   if ((kpool != nullptr) != (vpool != nullptr)) return VLM_ERR_ARG;
   if (kpool && (!kv_slot || !block_table || max_pages <= 0)) return VLM_ERR_ARG;
@@ -196,7 +206,7 @@ extern "C" int vlm_mrope_kvwrite(void* qkv, int ld, int T, int Hq, int Hkv, int 
   hipLaunchKernelGGL(mrope_kvwrite_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (bf16_t*)qkv, ld, T, Hq, Hkv, D, (const int*)pos_t, (const int*)pos_h, (const int*)pos_w,
                      (const float*)inv_freq, sec0, sec1, (const int*)kv_seq, (const int*)kv_slot,
-                     (const int*)block_table, max_pages, (bf16_t*)kpool, (bf16_t*)vpool);
+                     (const int*)block_table, max_pages, (bf16_t*)kpool, (bf16_t*)vpool, qk_scale);
   VLM_CHECK_LAUNCH();
   return VLM_OK;
 }

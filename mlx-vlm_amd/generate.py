@@ -379,10 +379,31 @@ def generate(model, processor, prompt: Optional[str] = None, image=None, audio=N
 
 
 # ---------------------------------------------------------------------------------------------
-def embed_requests(model, input_ids_list, pixel_values_list, grids):
+def _embed_requests_per_model(model, input_ids_list, pixel_values_list, extras):
+    """Model families other than Qwen2-VL (llava_bunny, phi3_v): every request through the model's own
+    `get_input_embeddings` (its tower, projector and splice rule), the results concatenated for one varlen prefill."""
+    embs, poss, lens, deltas = [], [], [], []
+    for ids, pix, kw in zip(input_ids_list, pixel_values_list, extras):
+        ids = np.asarray(ids).reshape(1, -1)
+        f = model.get_input_embeddings(ids, torch.as_tensor(pix) if pix is not None else None, **(kw or {}))
+        L = f.inputs_embeds.shape[1]
+        p = np.asarray(f.position_ids)
+        if p.ndim == 2:
+            p = np.broadcast_to(p[None], (3,) + p.shape)
+        embs.append(f.inputs_embeds.reshape(L, -1))
+        poss.append(p.reshape(3, L))
+        lens.append(L)
+        deltas.append(int(np.asarray(f.rope_deltas).reshape(-1)[0]) if f.rope_deltas is not None else 0)
+    return torch.cat(embs, dim=0), np.concatenate(poss, axis=1), lens, deltas
+
+
+def embed_requests(model, input_ids_list, pixel_values_list, grids, extras=None):
     """Input embeddings of several requests for ONE varlen prefill: one ViT call over the concatenated patches of all
     images (as the reference does per shape group, ar.py:3165-3167), features scattered into each request's
-    placeholder rows, per-request M-RoPE positions.  -> (embeds [sum L, D], position_ids [3, sum L], lengths, rope deltas)"""
+    placeholder rows, per-request M-RoPE positions.  -> (embeds [sum L, D], position_ids [3, sum L], lengths, rope deltas)
+    `extras`: per-request keyword arguments of `get_input_embeddings` besides the pixels (phi3_v: image_sizes)."""
+    if not hasattr(model, "merge_input_ids_with_image_features"):
+        return _embed_requests_per_model(model, input_ids_list, pixel_values_list, extras or [None] * len(input_ids_list))
     lm = model.language_model
     embs, poss, lens, deltas = [], [], [], []
     has_pix = [p is not None for p in pixel_values_list]

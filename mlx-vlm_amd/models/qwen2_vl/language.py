@@ -164,6 +164,8 @@ class LanguageModel:
 
         def lin(path):
             """a projection weight: bf16 tensor, or QuantW when the checkpoint holds `<path>.scales` (utils.py:961)"""
+            if isinstance(W.get(path + ".weight"), Qz.QuantW):      # already packed by a model-specific loader (phi3_v)
+                return W[path + ".weight"].to(dev)
             if Qz.has_scales(W, path):
                 return Qz.take(W, path).to(dev)
             return g(path + ".weight")
@@ -176,7 +178,7 @@ class LanguageModel:
         qkv_rows = (t.num_attention_heads + 2 * t.num_key_value_heads) * self.head_dim
         per_layer = (qkv_rows + t.num_attention_heads * self.head_dim + 3 * t.intermediate_size) * t.hidden_size * 2
         n_big = t.num_hidden_layers * per_layer + (1 if t.tie_word_embeddings else 2) * t.vocab_size * t.hidden_size * 2
-        use_wa = os.environ.get("VLM_WEIGHT_ARENA", "1") != "0" and not any(k.endswith(".scales") for k in W)
+        use_wa = os.environ.get("VLM_WEIGHT_ARENA", "1") != "0" and not any(k.endswith(".scales") or isinstance(v, Qz.QuantW) for k, v in W.items())
         self.warena = Arena(n_big + (4 * t.num_hidden_layers + 4) * 4096, device=dev, zero=False) if use_wa else None
 
         def big(x):
@@ -192,7 +194,7 @@ class LanguageModel:
         cfg = _lib.LlmConfig(t.hidden_size, t.num_hidden_layers, t.intermediate_size, t.num_attention_heads,
                              t.num_key_value_heads, self.head_dim, t.vocab_size, float(t.rms_norm_eps),
                              int(self.mrope_section[0]), int(self.mrope_section[1]),
-                             float(getattr(t, "attn_scale", 0.0) or 0.0))
+                             float(getattr(t, "attn_scale", 0.0) or 0.0), float(getattr(t, "rope_qk_scale", 0.0) or 0.0))
         h = C.c_void_p()
         check(L.vlm_llm_create(C.byref(cfg), C.byref(h)), "llm_create")
         self._handle = h
@@ -242,6 +244,10 @@ class LanguageModel:
         rd = getattr(t, "rope_dim", None) or hd
         inv = torch.zeros(hd // 2, dtype=torch.float32)
         inv[: rd // 2] = 1.0 / (t.rope_theta ** (torch.arange(0, rd, 2).to(torch.float32) / rd))
+        if getattr(t, "inv_freq", None) is not None:      # a model's own table (SuScaledRoPE: 1 / (factor * theta ** (2 i / d)))
+            own = torch.as_tensor(t.inv_freq, dtype=torch.float32).reshape(-1)
+            inv.zero_()
+            inv[: own.numel()] = own
         inv_freq = self.arena.put(inv.to(dev))
         self._w.update(embed=embed, head=head, norm=norm, inv_freq=inv_freq)
         isq = lambda x: isinstance(x, Qz.QuantW)    # noqa: E731
@@ -480,7 +486,8 @@ class LanguageModel:
             xn = ops.rmsnorm(h, w[f"{i}.ln1"], t.rms_norm_eps)
             qkv = ops.gemm(xn, w[f"{i}.wqkv"], bias=w[f"{i}.bqkv"], epilogue=ops.EPI_BIAS)
             ops.mrope_kvwrite_(qkv, Hq, Hkv, hd, pos_d[0], pos_d[1], pos_d[2], w["inv_freq"], int(sec[0]), int(sec[1]),
-                               kv_seq=new_seq_d.contiguous(), kv_slot=new_slot_d.contiguous(), block_table=bt, kpool=kp, vpool=vp)
+                               kv_seq=new_seq_d.contiguous(), kv_slot=new_slot_d.contiguous(), block_table=bt, kpool=kp, vpool=vp,
+                               qk_scale=getattr(t, "rope_qk_scale", None))
             full = torch.zeros(Tf, QKV, dtype=bf, device=dev)
             full[new_rows_d] = qkv
             if old_rows.size:

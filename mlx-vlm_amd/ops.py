@@ -161,10 +161,17 @@ def rope2d_vision_(qkv, cos_tab, sin_tab, n_heads):
 
 
 def mrope_kvwrite_(qkv, Hq, Hkv, D, pos_t, pos_h, pos_w, inv_freq, sec0, sec1, kv_seq=None, kv_slot=None,
-                   block_table=None, kpool=None, vpool=None):
+                   block_table=None, kpool=None, vpool=None, qk_scale=None):
+    """qk_scale: SuScaledRoPE's typed input scale of q and k (vlm_mrope_kvwrite_scaled); None = plain"""
     _dev(qkv, pos_t, inv_freq)
     T = qkv.shape[0]
     max_pages = block_table.shape[1] if block_table is not None else 0
+    if qk_scale is not None and float(qk_scale) != 1.0:
+        check(_lib.lib().vlm_mrope_kvwrite_scaled(_p(qkv), qkv.stride(0), T, Hq, Hkv, D, _p(pos_t), _p(pos_h), _p(pos_w),
+                                                  _p(inv_freq), sec0, sec1, _p(kv_seq), _p(kv_slot), _p(block_table),
+                                                  max_pages, _p(kpool), _p(vpool), float(qk_scale), _stream()),
+              "mrope_kvwrite_scaled")
+        return qkv
     check(_lib.lib().vlm_mrope_kvwrite(_p(qkv), qkv.stride(0), T, Hq, Hkv, D, _p(pos_t), _p(pos_h), _p(pos_w),
                                        _p(inv_freq), sec0, sec1, _p(kv_seq), _p(kv_slot), _p(block_table), max_pages,
                                        _p(kpool), _p(vpool), _stream()), "mrope_kvwrite")

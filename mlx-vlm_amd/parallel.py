@@ -129,6 +129,10 @@ def dp_load(model_path: str, device=None, src: int = 0, bucket_bytes: int = 1 <<
     return model, processor, stats
 
 
+_REQUEST_KEYS = ("input_ids", "pixel_values", "image_grid_thw", "max_tokens")     # the rest of a request: model-specific
+                                                                                  # get_input_embeddings arguments (phi3_v: image_sizes)
+
+
 def dp_batch_generate(model, processor, prompts=None, images=None, *, requests=None, max_tokens=128, serve=None,
                       dst: int = 0, **kwargs):
     """Data-parallel `batch_generate` (reference ar.py:2890-3096 runs one device): every rank calls this with the SAME
@@ -158,7 +162,8 @@ def dp_batch_generate(model, processor, prompts=None, images=None, *, requests=N
         for p, im in zip(prompts, images):
             inp = prepare_inputs(processor, images=im, prompts=p)
             requests.append({"input_ids": np.asarray(inp["input_ids"]).reshape(-1), "pixel_values": inp.get("pixel_values"),
-                             "image_grid_thw": inp.get("image_grid_thw")})
+                             "image_grid_thw": inp.get("image_grid_thw"),
+                             **{k: v for k, v in inp.items() if k not in _REQUEST_KEYS and k != "attention_mask"}})
     n = len(requests)
     lengths = [int(np.asarray(r["input_ids"]).size) for r in requests]
     mine = shard_requests(n, rank, ws, lengths)
@@ -174,7 +179,9 @@ def dp_batch_generate(model, processor, prompts=None, images=None, *, requests=N
             toks, _ = generate_batch_continuous(model, [reqs[i]["input_ids"] for i in indices],
                                                 [reqs[i].get("pixel_values") for i in indices],
                                                 [reqs[i].get("image_grid_thw") for i in indices],
-                                                max_tokens=[max_toks[i] for i in indices], stop_ids=tuple(stop), **kwargs)
+                                                max_tokens=[max_toks[i] for i in indices], stop_ids=tuple(stop),
+                                                extras=[{k: v for k, v in reqs[i].items() if k not in _REQUEST_KEYS} for i in indices],
+                                                **kwargs)
             return toks
     barrier()
     t0 = time.perf_counter()

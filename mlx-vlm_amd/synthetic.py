@@ -35,6 +35,53 @@ NANOLLAVA = dict(
 )
 
 
+# Phi-3.5-vision-instruct (microsoft/Phi-3.5-vision-instruct: Phi-3-mini decoder + CLIP ViT-L/14-336), public HF config values -
+# BASELINE configs[4].  The checkpoint's 48 short / long RoPE factors are not reproduced here (no network): stand-ins of the
+# same range and shape (ascending, [1, 1.3] and [1, 64])
+PHI35_VISION = dict(
+    model_type="phi3_v", hidden_size=3072, num_hidden_layers=32, intermediate_size=8192, num_attention_heads=32,
+    num_key_value_heads=32, rms_norm_eps=1e-5, vocab_size=32064, rope_theta=10000.0, max_position_embeddings=131072,
+    original_max_position_embeddings=4096, tie_word_embeddings=False,
+    rope_scaling={"type": "su", "short_factor": [round(1.0 + 0.3 * i / 47, 4) for i in range(48)],
+                  "long_factor": [round(1.0 + 63.0 * (i / 47) ** 2, 4) for i in range(48)]},
+    vision_config=dict(num_hidden_layers=24, hidden_size=1024, intermediate_size=4096, num_attention_heads=16, image_size=336,
+                       patch_size=14, layer_norm_eps=1e-5),
+)
+
+
+def phi3v_weight_shapes(cfg) -> Dict[str, tuple]:
+    """name -> shape for a phi3_v ModelConfig under the reference's (= HF) names (phi3_v.py:136-177, vision.py:113-206)"""
+    v = cfg.vision_config
+    E, I, D = v.hidden_size, v.intermediate_size, cfg.hidden_size
+    hd = D // cfg.num_attention_heads
+    C = "model.vision_embed_tokens.img_processor.vision_model."
+    s: Dict[str, tuple] = {C + "embeddings.class_embedding": (E,),
+                           C + "embeddings.patch_embedding.weight": (E, v.patch_size, v.patch_size, v.num_channels),
+                           C + "embeddings.position_embedding.weight": ((v.image_size // v.patch_size) ** 2 + 1, E),
+                           C + "pre_layrnorm.weight": (E,), C + "pre_layrnorm.bias": (E,),
+                           C + "post_layernorm.weight": (E,), C + "post_layernorm.bias": (E,)}
+    for i in range(v.num_hidden_layers):
+        p = f"{C}encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s[p + f"self_attn.{n}.weight"], s[p + f"self_attn.{n}.bias"] = (E, E), (E,)
+        s.update({p + "layer_norm1.weight": (E,), p + "layer_norm1.bias": (E,), p + "layer_norm2.weight": (E,),
+                  p + "layer_norm2.bias": (E,), p + "mlp.fc1.weight": (I, E), p + "mlp.fc1.bias": (I,),
+                  p + "mlp.fc2.weight": (E, I), p + "mlp.fc2.bias": (E,)})
+    T = "model.vision_embed_tokens."
+    s.update({T + "glb_GN": (1, 1, 4 * E), T + "sub_GN": (1, 1, 1, 4 * E), T + "img_projection.0.weight": (D, 4 * E),
+              T + "img_projection.0.bias": (D,), T + "img_projection.2.weight": (D, D), T + "img_projection.2.bias": (D,),
+              "model.embed_tokens.weight": (cfg.vocab_size, D)})
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        s.update({p + "input_layernorm.weight": (D,), p + "post_attention_layernorm.weight": (D,),
+                  p + "self_attn.qkv_proj.weight": ((cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * hd, D),
+                  p + "self_attn.o_proj.weight": (D, cfg.num_attention_heads * hd),
+                  p + "mlp.gate_up_proj.weight": (2 * cfg.intermediate_size, D), p + "mlp.down_proj.weight": (D, cfg.intermediate_size)})
+    s["model.norm.weight"] = (D,)
+    s["lm_head.weight"] = (cfg.vocab_size, D)
+    return s
+
+
 def bunny_weight_shapes(cfg) -> Dict[str, tuple]:
     """name -> shape for a llava_bunny ModelConfig, sanitized names (reference llava_bunny.py:180-222; the unused
     pooling head of the tower is left out)."""
@@ -72,6 +119,8 @@ def weight_shapes(cfg) -> Dict[str, tuple]:
     """name -> shape for a qwen2_vl ModelConfig, sanitized names (reference qwen2_vl.py:179-190)."""
     if getattr(cfg, "model_type", None) == "llava_bunny":
         return bunny_weight_shapes(cfg)
+    if getattr(cfg, "model_type", None) == "phi3_v":
+        return phi3v_weight_shapes(cfg)
     t, v = cfg.text_config, cfg.vision_config
     E, D = v.embed_dim, t.hidden_size
     hd = D // t.num_attention_heads
@@ -111,7 +160,8 @@ def random_weights(cfg, seed: int = 0, device="cuda", dtype=torch.bfloat16, std:
     for name, shape in weight_shapes(cfg).items():
         if not fill:
             W[name] = torch.empty(shape, dtype=dtype, device=device)
-        elif name.endswith(("norm1.weight", "norm2.weight", "ln_q.weight", "layernorm.weight", "model.norm.weight")):
+        elif name.endswith(("norm1.weight", "norm2.weight", "ln_q.weight", "layernorm.weight", "model.norm.weight",
+                            "layrnorm.weight")):
             W[name] = torch.ones(shape, dtype=dtype, device=device)
         elif name.endswith(".bias"):
             W[name] = torch.zeros(shape, dtype=dtype, device=device)
@@ -120,12 +170,14 @@ def random_weights(cfg, seed: int = 0, device="cuda", dtype=torch.bfloat16, std:
     return W
 
 
-def quantize_random_(W: Dict[str, torch.Tensor], prefix: str = "language_model.", seed: int = 1, std: float = 0.02):
+def quantize_random_(W: Dict[str, torch.Tensor], prefix: str = "language_model.", seed: int = 1, std: float = 0.02,
+                     skip: tuple = ()):
     """Synthetic MLX affine 4-bit checkpoint IN PLACE (no quantizer is part of the product - the reference's lives in
     convert.py, out of scope): every 2-D `<prefix>...weight` with in % 64 == 0 becomes random nibbles (uint32 words as
     int32 bit patterns, [out, in / 8]) + `scales` / `biases` [out, in / 64] such that the dequantized weights are
     ~uniform with standard deviation `std` (step = std * sqrt(12) / 15, bias = -7.5 steps)."""
-    for name in [k for k in W if k.startswith(prefix) and k.endswith(".weight") and W[k].dim() == 2 and W[k].shape[1] % 64 == 0]:
+    for name in [k for k in W if k.startswith(prefix) and not k.startswith(skip or ("\0",)) and k.endswith(".weight")
+                 and W[k].dim() == 2 and W[k].shape[1] % 64 == 0]:
         N, K = W[name].shape
         dev = W[name].device
         g = torch.Generator(device=dev).manual_seed(seed + (zlib.crc32(name.encode()) & 0xFFFF))

@@ -182,6 +182,17 @@ def load_processor(model_path: str, config):
         tok.stopping_criteria = StoppingCriteria(eos if isinstance(eos, list) else [eos], tok)
         tok.detokenizer = _pick_detokenizer(model_path, tok)
         return tok
+    if MODEL_REMAPPING.get(mt, mt) == "phi3_v":
+        # reference phi3_v/processing_phi3_v.py:596-660 (Phi3VProcessor.from_pretrained): tokenizer + the HD image processor
+        # with num_crops / num_img_tokens / mean / std of preprocessor_config.json, chat template from the tokenizer
+        from .models.phi3_v import Phi3VImageProcessor, Phi3VProcessor
+
+        ipk = {k: pc[k] for k in ("num_crops", "num_img_tokens", "image_mean", "image_std") if k in pc}
+        proc = Phi3VProcessor(Phi3VImageProcessor(**ipk), tok, chat_template=getattr(tok, "chat_template", None))
+        eos = config.eos_token_id if getattr(config, "eos_token_id", None) is not None else tok.eos_token_id
+        tok.stopping_criteria = StoppingCriteria(eos if isinstance(eos, list) else [eos], tok)
+        proc.detokenizer = _pick_detokenizer(model_path, tok)
+        return proc
     if pc:
         for k in ("image_mean", "image_std", "min_pixels", "max_pixels", "patch_size", "temporal_patch_size", "merge_size"):
             if k in pc:

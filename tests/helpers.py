@@ -85,3 +85,32 @@ def build_bunny_model(cfg, W, device="cuda", **kw):
     weights = m.language_model.sanitize(dict(W))
     m.load_weights(weights)
     return m
+
+
+def phi3v_config_from_oracle(cfg, quantization=None):
+    """ModelConfig of models/phi3_v from oracle/phi3_v.py's Cfg (HF layout: text parameters at the root)"""
+    from mlx_vlm_amd.models.phi3_v import ModelConfig
+
+    t, v = cfg.text, cfg.vision
+    d = dict(model_type="phi3_v", vocab_size=t.vocab_size, num_hidden_layers=t.num_hidden_layers,
+             intermediate_size=t.intermediate_size, num_attention_heads=t.num_attention_heads,
+             num_key_value_heads=t.num_key_value_heads, rms_norm_eps=t.rms_norm_eps, hidden_size=t.hidden_size,
+             rope_theta=t.rope_theta, max_position_embeddings=t.max_position_embeddings,
+             original_max_position_embeddings=t.original_max_position_embeddings,
+             vision_config=dict(num_hidden_layers=v.num_hidden_layers, hidden_size=v.hidden_size,
+                                intermediate_size=v.intermediate_size, num_attention_heads=v.num_attention_heads,
+                                image_size=v.image_size, patch_size=v.patch_size, layer_norm_eps=v.layer_norm_eps))
+    if t.short_factor is not None:
+        d["rope_scaling"] = {"type": "su", "short_factor": list(t.short_factor), "long_factor": list(t.long_factor)}
+    if quantization:
+        d["quantization"] = quantization
+    return ModelConfig.from_dict(d)
+
+
+def build_phi3v_model(cfg, W, device="cuda", **kw):
+    """Phi-3.5-vision product model from oracle/phi3_v.py's config + (checkpoint-style) weights"""
+    from mlx_vlm_amd.models.phi3_v import Model
+
+    m = Model(phi3v_config_from_oracle(cfg), device=device, **kw)
+    m.load_weights(W)
+    return m

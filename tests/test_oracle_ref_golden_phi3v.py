@@ -1,0 +1,202 @@
+"""Phi-3.5-vision (`phi3_v`): the oracle against vectors produced by the REFERENCE'S OWN files
+(tests/golden/make_golden_ref_phi3v.py ran mlx_vlm/models/phi3_v/*.py, models/base.py, models/cache.py, models/rope_utils.py
+and generate/ar.py unmodified over oracle/mlx_shim; only the .npz is read here).  CPU only."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops
+from oracle import phi3_v as op
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "phi3_v_tiny_ref.npz"))
+ROWS = slice(None, None, 11)
+CR, CC = slice(None, None, 37), slice(None, None, 4)
+DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+
+
+def _weights(dt):
+    W = op.random_weights(op.tiny_cfg(), seed=4321, dtype=torch.float32, **op.TEST_WEIGHT_SCALES)
+    return {k: v.to(dt) for k, v in W.items()}
+
+
+def _from_bits(a):
+    return torch.from_numpy((a.astype(np.uint32) << 16).view(np.float32).copy()).to(torch.bfloat16)
+
+
+def _case_inputs(ci):
+    pv, sz = op.preprocess([G[f"img{int(i)}.image_hwc"] for i in G[f"case{ci}.which"]])
+    assert np.array_equal(sz, G[f"case{ci}.image_sizes"])
+    return torch.from_numpy(pv.astype(np.float32)), sz          # the pipeline hands float32 over (mx.array of float64 data)
+
+
+def _close(name, got, ref, dt, rtol=2e-4, atol=2e-5):
+    got = got.detach().to(torch.float32).numpy()
+    if dt == "f32":
+        np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol, err_msg=name)
+    else:
+        assert np.array_equal(got, ref), (name, int((got != ref).sum()), float(np.abs(got - ref).max()))
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_image_processor_bit_exact_vs_reference(i):
+    """Phi3VImageProcessor (processing_phi3_v.py:78-236): HD size rule, bicubic resize, global view + tiles, CLIP
+    normalisation in float64; token count rule."""
+    im = G[f"img{i}.image_hwc"]
+    pv, sz = op.preprocess([im])
+    assert list(pv.shape) == G[f"img{i}.ref_pixel_shape"].tolist() and str(pv.dtype) == str(G[f"img{i}.ref_pixel_dtype"][0])
+    assert np.array_equal(sz, G[f"img{i}.ref_image_sizes"])
+    np.testing.assert_allclose(pv.astype(np.float64).sum(axis=(2, 3, 4)), G[f"img{i}.ref_pixel_sum"], rtol=0, atol=1e-7)
+    assert zlib.crc32(np.ascontiguousarray(pv).astype(np.float32).tobytes()) == int(G[f"img{i}.ref_pixel_crc32"][0])
+    assert op.num_image_tokens(im.shape[1], im.shape[0]) == int(G[f"img{i}.ref_num_tokens"][0])
+
+
+def test_image_processor_batch_pads_views_to_the_maximum():
+    pv, sz = op.preprocess([G["img0.image_hwc"], G["img2.image_hwc"]])
+    assert pv.shape[1] == max(int(G["img0.ref_pixel_shape"][1]), int(G["img2.ref_pixel_shape"][1]))
+    n2 = int(G["img2.ref_pixel_shape"][1])
+    assert n2 < pv.shape[1] and not pv[1, n2:].any()
+    pv01, sz01 = op.preprocess([G["img0.image_hwc"], G["img1.image_hwc"]])
+    assert list(pv01.shape) == G["batch01.ref_pixel_shape"].tolist() and np.array_equal(sz01, G["batch01.ref_image_sizes"])
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("ci", [0, 1])
+def test_clip_tower_hd_transform_and_splice_vs_reference(ci, dt):
+    """CLIP states, HD row assembly + separators + projection, write-back at the negative ids.  f32: everything to 2e-4
+    (an arrangement error of the HD transform would be a gross mismatch).  bf16: view 0's encoder states bit-exact from
+    the reference's own embeddings (Conv2d vs GEMM summation order differs by an ulp in a few elements, which then
+    spreads); the spliced prompt at bf16 noise level (1e-2 rel-rms: two bf16 roundings) for the same reason."""
+    cfg, W = op.tiny_cfg(), _weights(DT[dt])
+    pix, sz = _case_inputs(ci)
+    pix = pix.to(DT[dt])
+    p = f"case{ci}.{dt}."
+    B, T = pix.shape[:2]
+    feat, states = op.clip_features(W, cfg, pix.reshape(B * T, *pix.shape[2:]), return_states=True)
+    if dt == "f32":
+        _close("clip state1", states[1][:, CR, CC], G[p + "ref_clip_state1"], dt, rtol=1e-3, atol=1e-4)
+        _close("clip feature state", states[-1][:, CR, CC], G[p + "ref_clip_feature_state"], dt, rtol=1e-3, atol=1e-4)
+    elif ci == 0:
+        ref0 = _from_bits(G[p + "ref_clip_embeddings_view0_bits"])[None]
+        own0 = states[0][:1]
+        d = (own0.float() - ref0.float()).abs()
+        assert float(d.max()) <= 2.0 ** -6 * float(ref0.float().abs().max()) and float((d > 0).float().mean()) < 5e-3
+        _, st = op.clip_features(W, cfg, pix.reshape(B * T, *pix.shape[2:])[:1], embeddings=None, return_states=True)
+        # restart from the reference's pre_layrnorm output: encoder layers bit for bit
+        x = ref0
+        chain = [x]
+        for i in range(cfg.vision.num_hidden_layers - 1):
+            x = op.encoder_layer(W, i, cfg, x)
+            chain.append(x)
+        _close("clip state1 (view 0)", chain[1][0, CR, CC], G[p + "ref_clip_state1"][0], dt)
+        _close("clip feature state (view 0)", chain[-1][0, CR, CC], G[p + "ref_clip_feature_state"][0], dt)
+    emb = op.get_input_embeddings(W, cfg, G[f"case{ci}.input_ids"], pix, sz)
+    assert emb.shape[1] == int(G[p + "ref_inputs_embeds_len"][0]) == G[f"case{ci}.input_ids"].shape[1]
+    if dt == "f32":
+        _close("inputs_embeds", emb[0, ROWS], G[p + "ref_inputs_embeds"], dt, rtol=2e-3, atol=2e-4)
+    else:
+        ref = _from_bits(G[p + "ref_inputs_embeds_bits"]).float()
+        own = emb[0].float()
+        neg = torch.from_numpy(G[f"case{ci}.input_ids"][0] < 0)
+        assert torch.equal(own[~neg], ref[~neg])                                   # text rows: the embedding table, exact
+        err = (own[neg] - ref[neg]).abs()
+        assert float(err.max()) <= 4 * 2.0 ** -8 * float(ref[neg].abs().max()), float(err.max())
+        rel = float(err.pow(2).mean().sqrt() / ref[neg].pow(2).mean().sqrt())
+        assert rel < 1e-2, rel                                                       # bf16 noise level; the f32 case pins the arrangement
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("ci", [0, 1])
+def test_prefill_and_kvcache_decode_vs_reference(ci, dt):
+    """Phi-3 decoder from the reference's own spliced prompt: fused qkv split, SuScaledRoPE (short factors, the typed
+    x * scale), KVCache growth, silu(gate) * up, lm_head; 6 greedy steps - bf16 bit for bit."""
+    cfg, W = op.tiny_cfg(), _weights(DT[dt])
+    p = f"case{ci}.{dt}."
+    if dt == "bf16":
+        emb = _from_bits(G[p + "ref_inputs_embeds_bits"])[None]
+    else:
+        pix, sz = _case_inputs(ci)
+        emb = op.get_input_embeddings(W, cfg, G[f"case{ci}.input_ids"], pix, sz)
+    cache = [ops.KVCache() for _ in range(cfg.text.num_hidden_layers)]
+    logits = op.language_model(W, cfg, emb, cache, last_only=True)[:, -1, :]
+    tol = dict(rtol=5e-3, atol=5e-4)
+    _close("prefill last", logits[0], G[p + "ref_prefill_logits_last"], dt, **tol)
+    toks, rows = [], []
+    for n in range(7):
+        y = int(ops.argmax_first(ops.logprobs_from_logits(logits))[0])
+        toks.append(y)
+        rows.append(logits[0].clone())
+        logits = op.language_model(W, cfg, op.embed_tokens(W, np.array([[y]])), cache)[:, -1, :]
+    if dt == "bf16":
+        assert toks[:6] == G[p + "ref_greedy"].tolist()
+        _close("decode logits", torch.stack(rows[1:7]), G[p + "ref_decode_logits"], dt)
+    else:
+        ref_t = G[p + "ref_greedy"].tolist()
+        n_same = next((i for i in range(6) if toks[i] != ref_t[i]), 6)
+        assert n_same >= 1
+        _close("decode logits", torch.stack(rows[1:1 + n_same]), G[p + "ref_decode_logits"][:n_same], dt, **tol)
+    assert cache[0].offset == G[f"case{ci}.input_ids"].shape[1] + 7
+
+
+def test_generate_step_text_prompt_vs_reference():
+    """The reference's generate_step (ar.py:151-515) on a text prompt, bf16: tokens and bf16 logprobs bit for bit."""
+    cfg, W = op.tiny_cfg(), _weights(torch.bfloat16)
+    toks, rows = op.generate_greedy(W, cfg, G["generate_step.text.input_ids"], None, max_tokens=6, return_logits=True)
+    assert toks == G["generate_step.text.tokens"].tolist()
+    lp = torch.stack([ops.logprobs_from_logits(r[None])[0] for r in rows]).to(torch.float32).numpy()
+    assert np.array_equal(lp, G["generate_step.text.logprobs"])
+
+
+def test_generate_step_image_prompt_vs_reference():
+    """generate_step on the image prompt of case 0 (bf16; phi3_v casts the pixels to the embedding dtype, phi3_v.py:222-223):
+    the oracle end to end from pixels; tokens equal, log-probs within the tower's summation-order noise."""
+    cfg, W = op.tiny_cfg(), _weights(torch.bfloat16)
+    pix, sz = _case_inputs(0)
+    toks, rows = op.generate_greedy(W, cfg, G["case0.input_ids"], pix, sz, max_tokens=6, return_logits=True)
+    assert toks == G["generate_step.image.tokens"].tolist()
+    lp = torch.stack([ops.logprobs_from_logits(r[None])[0] for r in rows]).to(torch.float32).numpy()
+    ref = G["generate_step.image.logprobs"]
+    assert np.abs(lp - ref).max() <= 4 * 2.0 ** -8 * np.abs(ref).max()
+
+
+def test_su_scaled_rope_short_and_long_factors_vs_reference():
+    """SuScaledRoPE (rope_utils.py:96-189) on its own: short factors below original_max_position_embeddings, long
+    factors once offset + L exceeds it, the bf16-rounded scale."""
+    t = op.tiny_cfg().text
+    x = torch.from_numpy(G["su_rope.x"]).to(torch.bfloat16)
+    assert np.array_equal(op.su_rope(x, 100, t).float().numpy(), G["su_rope.short_at_100"])
+    assert np.array_equal(op.su_rope(x, 4095, t).float().numpy(), G["su_rope.long_at_4095"])
+    _, _, s = op.su_rope_tables(t, torch.float32)
+    assert abs(s - float(G["su_rope.scale"][0])) < 1e-6
+
+
+def test_prompt_assembly_vs_reference():
+    """Phi3VProcessor._convert_images_texts_to_inputs (processing_phi3_v.py:322-425): <|image_N|> -> num_tokens copies of
+    -N between the tokenised text chunks (the product's processor, with the same stand-in tokenizer)."""
+    from mlx_vlm_amd.models.phi3_v.processing_phi3_v import Phi3VProcessor
+
+    class WordTokenizer:
+        bos_token_id = 1
+        pad_token_id = 0
+
+        def encode(self, text, add_special_tokens=True):
+            ids = [3 + (zlib.crc32(w.encode()) % 900) for w in text.split()]
+            return ([self.bos_token_id] if add_special_tokens else []) + ids
+
+    proc = Phi3VProcessor(tokenizer=WordTokenizer())
+    out = proc(images=[G["img0.image_hwc"], G["img1.image_hwc"]], text=str(G["prompt.text"][0]))
+    assert np.array_equal(np.asarray(out["input_ids"]), G["prompt.ref_input_ids"])
+    assert list(out["pixel_values"].shape) == G["batch01.ref_pixel_shape"].tolist()
+    assert np.array_equal(np.asarray(out["image_sizes"]), G["batch01.ref_image_sizes"])
+
+
+def test_sanitize_and_config_vs_reference():
+    from mlx_vlm_amd.models.phi3_v import ModelConfig, sanitize_keys
+
+    assert sorted(sanitize_keys(list(G["sanitize.keys_in"]))) == list(G["sanitize.keys_out"])
+    t = op.tiny_cfg().text
+    mc = ModelConfig.from_dict(dict(model_type="phi3_v", vocab_size=t.vocab_size, hidden_size=t.hidden_size,
+                                    num_hidden_layers=2, intermediate_size=256, num_attention_heads=2, num_key_value_heads=2))
+    assert list(mc.eos_token_id or []) == G["config.eos_token_id"].tolist()
