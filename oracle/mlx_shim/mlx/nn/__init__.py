@@ -17,6 +17,22 @@ class Module:
     def __init__(self):
         self._training = False
 
+    # mlx.nn.Module is a dict: arrays / containers / sub-modules assigned as attributes are stored as ITEMS, bypassing any
+    # class-level property of the same name, and `__getattr__` serves them when normal lookup fails.  The reference relies
+    # on that (models/idefics2/language.py: a `layers` property whose getter raises sits next to `self.layers = [...]`).
+    def __setattr__(self, key, val):
+        desc = getattr(type(self), key, None)
+        if isinstance(desc, property) and desc.fset is None:
+            self.__dict__[key] = val
+        else:
+            object.__setattr__(self, key, val)
+
+    def __getattr__(self, key):
+        d = object.__getattribute__(self, "__dict__")
+        if key in d:
+            return d[key]
+        raise AttributeError(f"{type(self).__name__!r} object has no attribute {key!r}")
+
     # ---- parameter tree
     def _items(self):
         for k, v in self.__dict__.items():
