@@ -306,7 +306,10 @@ extern "C" int vlm_llm_prefill(void* handle, const vlm_prefill_args* a, void* st
     // gather = embed_gather over the residual stream viewed as a table of T rows
     TRY(vlm_embed_gather(a->last_rows, a->h, a->xlast, a->n_last, D, D, T, stream));
     TRY(vlm_rmsnorm_residual(a->xlast, nullptr, m->g.final_norm_w, a->xlast, nullptr, a->n_last, D, c.rms_eps, stream));
-    TRY(lin_gemm(m, a->xlast, m->g.lm_head, m->g.lm_head_sb, nullptr, nullptr, a->logits, a->n_last, c.vocab, D, c.vocab, 0,
+    // a vocabulary that is not a multiple of 8 (Idefics2: 32003): logits rows have pitch VL = vocab rounded up, the head
+    // matrix VL rows (the loader pads it with zero rows); the samplers read the first `vocab` columns only
+    const int VL = (c.vocab + 7) & ~7;
+    TRY(lin_gemm(m, a->xlast, m->g.lm_head, m->g.lm_head_sb, nullptr, nullptr, a->logits, a->n_last, VL, D, VL, 0,
                  VLM_EPI_NONE, stream));
   }
   return 0;
@@ -463,12 +466,13 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
     TRY(lin_gemv(m, a->act, w.wdown, w.wdown_sb, nullptr, a->h, nullptr, a->h, B, D, c.inter, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
   }
   // logits = RMSNorm(h) lm_head^T
+  const int VL = (c.vocab + 7) & ~7;      // row pitch of logits / logprobs / scratch (see vlm_llm_prefill)
   if (!(skip & 32))
-  TRY(lin_gemv(m, a->h, m->g.lm_head, m->g.lm_head_sb, nullptr, nullptr, m->g.final_norm_w, a->logits, B, c.vocab, D, c.vocab, 0,
+  TRY(lin_gemv(m, a->h, m->g.lm_head, m->g.lm_head_sb, nullptr, nullptr, m->g.final_norm_w, a->logits, B, c.vocab, D, VL, 0,
                c.rms_eps, VLM_EPI_NONE, stream)); ++n;
   if (sample && a->penalties) {
     // logits processors (ar.py:360-364): the fed token joins the history, then bias / penalties on the step's logits
-    TRY(vlm_apply_logit_penalties(a->logits, c.vocab, B, c.vocab, a->tok, a->penalties, stream)); ++n;
+    TRY(vlm_apply_logit_penalties(a->logits, VL, B, c.vocab, a->tok, a->penalties, stream)); ++n;
   }
   if (sample && !(skip & 64)) {
     if (pf == 1 && (tn.mask & 64)) {
@@ -479,11 +483,11 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
     }
     const VlmProgress tail_prog{pf == 2 ? m->progress : nullptr, NL + 1};
     if (fused_tail) {
-      TRY(vlm_sample_greedy_advance_ex(a->logits, c.vocab, B, c.vocab, a->logprobs, c.vocab, a->tok, a->sample_ws, a->ctx,
+      TRY(vlm_sample_greedy_advance_ex(a->logits, VL, B, c.vocab, a->logprobs, VL, a->tok, a->sample_ws, a->ctx,
                                        a->pos, a->out_ring, a->ring_len, a->step, m->g.embed, a->h, D, D, tail_prog,
                                        stream)); n += 2;
     } else {
-      TRY(vlm_sample_ex(a->logits, c.vocab, B, c.vocab, a->logprobs, a->scratch, c.vocab, a->tok, a->sample_ws, a->temperature,
+      TRY(vlm_sample_ex(a->logits, VL, B, c.vocab, a->logprobs, a->scratch, VL, a->tok, a->sample_ws, a->temperature,
                         a->top_p, a->min_p, a->top_k, a->seed, a->step, tail_prog, stream)); n += 3;
       TRY(vlm_decode_advance(a->ctx, a->pos, a->tok, a->out_ring, a->ring_len, a->step, B, stream)); ++n;
     }

@@ -481,6 +481,8 @@ template <int MB, int PRO, int EPI>
 int launch_rw_k(const Args& a) {
   if (a.K <= 512 * 3) return launch_rw_r<3, MB, PRO, EPI>(a);
   if (a.K <= 512 * 7) return launch_rw_r<7, MB, PRO, EPI>(a);
+  if constexpr (PRO == PRO_RMSNORM)      // hidden 4096 (Mistral-7B / Idefics2-8B): the norm-prologue forms only
+    if (a.K <= 512 * 8) return launch_rw_r<8, MB, PRO, EPI>(a);
   return VLM_ERR_SHAPE;
 }
 
@@ -566,7 +568,7 @@ VLM_INTERNAL int vlm_gemv_bf16_ex(const void* x, const void* W, const void* bias
   }
   if ((size_t)M * K * 2 > 64 * 1024 && (norm_w || K <= 3584)) return VLM_ERR_SHAPE;
   Args a{x, W, bias, res, norm_w, y, N, K, ldx, ldw, ldy, ldres, eps, RopeKvArgs{}, AttnProArgs{}, (hipStream_t)stream};
-  if (K <= 3584) {
+  if (K <= 3584 || (norm_w && K <= 4096)) {
 #define GO(P, E) return launch_rw_m<P, E>(M, a)
     if (norm_w) {
       switch (epilogue) {
@@ -618,7 +620,7 @@ VLM_INTERNAL int vlm_gemv_qkv_rope_kvwrite_ex(const void* h, const void* norm_w,
                                      ws, stream);
     if (rc >= 0) return rc;
   }
-  if (hidden % 8 || D % 16 || hidden > 3584 || (size_t)M * hidden * 2 > 64 * 1024) return VLM_ERR_SHAPE;
+  if (hidden % 8 || D % 16 || hidden > 4096 || (size_t)M * hidden * 2 > 64 * 1024) return VLM_ERR_SHAPE;
   Args a{h, Wqkv, bqkv, nullptr, norm_w, qkv, N, hidden, hidden, hidden, ldq, 0, eps,
          RopeKvArgs{(const int*)pos, (const int*)slot, (const float*)inv_freq, (const int*)block_table, max_pages, Hq, Hkv,
                     D, (bf16_t*)kpool, (bf16_t*)vpool, qk_scale},

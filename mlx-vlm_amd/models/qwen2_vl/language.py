@@ -59,9 +59,11 @@ class DecodeState:
         self.act = A((B, t.intermediate_size), bf)
         self.part_ml = A((B, Hq, nsplit, 2), torch.float32)
         self.out_ring = A((ring_len, B), i32, zero=True)
-        self.logits = torch.empty(B, t.vocab_size, dtype=bf, device=dev)
-        self.logprobs = torch.empty(B, t.vocab_size, dtype=bf, device=dev)
-        self.scratch = torch.empty(B, t.vocab_size, dtype=bf, device=dev)
+        # rows at pitch VL = vocab rounded up to 8 (the engine's pitch: 16-byte aligned rows for any vocabulary, e.g. 32003)
+        VL = (t.vocab_size + 7) & ~7
+        self.logits = torch.empty(B, VL, dtype=bf, device=dev)[:, : t.vocab_size]
+        self.logprobs = torch.empty(B, VL, dtype=bf, device=dev)[:, : t.vocab_size]
+        self.scratch = torch.empty(B, VL, dtype=bf, device=dev)[:, : t.vocab_size]
         self.part_o = torch.empty(B, Hq, nsplit, hd, dtype=torch.float32, device=dev)
         self.sample_ws = ops.sample_workspace(B, dev)
         # history of fed tokens for the logits processors (penalties): ring per row + count
@@ -177,7 +179,7 @@ class LanguageModel:
         # driver can map the region with large page fragments (A/B knob: VLM_WEIGHT_ARENA=0 -> separate tensors)
         qkv_rows = (t.num_attention_heads + 2 * t.num_key_value_heads) * self.head_dim
         per_layer = (qkv_rows + t.num_attention_heads * self.head_dim + 3 * t.intermediate_size) * t.hidden_size * 2
-        n_big = t.num_hidden_layers * per_layer + (1 if t.tie_word_embeddings else 2) * t.vocab_size * t.hidden_size * 2
+        n_big = t.num_hidden_layers * per_layer + (1 if t.tie_word_embeddings else 2) * (t.vocab_size + 8) * t.hidden_size * 2
         use_wa = os.environ.get("VLM_WEIGHT_ARENA", "1") != "0" and not any(k.endswith(".scales") or isinstance(v, Qz.QuantW) for k, v in W.items())
         self.warena = Arena(n_big + (4 * t.num_hidden_layers + 4) * 4096, device=dev, zero=False) if use_wa else None
 
@@ -233,8 +235,18 @@ class LanguageModel:
             lay = _lib.LlmLayer(ws["ln1"].data_ptr(), wp(wqkv), bqkv.data_ptr(), wp(ws["wo"]), ws["ln2"].data_ptr(), wp(wgu),
                                 wp(ws["wdown"]), sp(wqkv), sp(ws["wo"]), sp(wgu), sp(ws["wdown"]))
             check(L.vlm_llm_set_layer(h, i, C.byref(lay)), "llm_set_layer")
-        embed = big(lin("model.embed_tokens"))
-        head = embed if t.tie_word_embeddings else big(lin("lm_head"))
+        def pad_rows8(x):
+            """the head (and a tied embedding) gets zero rows up to a multiple of 8: the prefill logits GEMM runs over them"""
+            n = (-x.shape[0]) % 8
+            if n == 0:
+                return x
+            if isinstance(x, Qz.QuantW):
+                return Qz.QuantW(torch.cat([x.wq, torch.zeros(n, x.wq.shape[1], dtype=x.wq.dtype, device=x.wq.device)]).contiguous(),
+                                 torch.cat([x.sb, torch.zeros(n, x.sb.shape[1], dtype=x.sb.dtype, device=x.sb.device)]).contiguous())
+            return torch.cat([x, torch.zeros(n, x.shape[1], dtype=x.dtype, device=x.device)])
+
+        embed = big(pad_rows8(lin("model.embed_tokens")) if t.tie_word_embeddings else lin("model.embed_tokens"))
+        head = embed if t.tie_word_embeddings else big(pad_rows8(lin("lm_head")))
         self.quantized = any(isinstance(v, Qz.QuantW) for v in self._w.values()) or isinstance(embed, Qz.QuantW) \
             or isinstance(head, Qz.QuantW)
         norm = self.arena.put(g("model.norm.weight"))
@@ -428,7 +440,7 @@ class LanguageModel:
         attn = torch.empty(T, Hq * hd, dtype=bf, device=dev)
         act = torch.empty(T, t.intermediate_size, dtype=bf, device=dev)
         xlast = torch.empty(len(rows), D, dtype=bf, device=dev)
-        logits = torch.empty(len(rows), t.vocab_size, dtype=bf, device=dev)
+        logits = torch.empty(len(rows), (t.vocab_size + 7) & ~7, dtype=bf, device=dev)[:, : t.vocab_size]      # pitch: see DecodeState
         a = _lib.PrefillArgs(h.data_ptr(), T, pos_d[0].data_ptr(), pos_d[1].data_ptr(), pos_d[2].data_ptr(),
                              kv_seq_d.data_ptr(), kv_slot_d.data_ptr(), cu_d.data_ptr(), len(lengths), nqb,
                              xn.data_ptr(), qkv.data_ptr(), attn.data_ptr(), act.data_ptr(), rows_d.data_ptr(),
@@ -502,7 +514,7 @@ class LanguageModel:
         cu_new = np.concatenate([[0], np.cumsum(lengths)])
         rows = (cu_new[1:] - 1) if logits_rows == "last" else np.arange(T)
         xl = ops.rmsnorm(h[_lib.h2d(rows.astype(np.int64), dev)].contiguous(), w["norm"], t.rms_norm_eps)
-        logits = ops.gemm(xl, w["head"])
+        logits = ops.gemm(xl, w["head"])[:, : t.vocab_size]
         for n, s in zip(lengths, seqs):
             s.offset += n
         return logits

@@ -182,6 +182,25 @@ def load_processor(model_path: str, config):
         tok.stopping_criteria = StoppingCriteria(eos if isinstance(eos, list) else [eos], tok)
         tok.detokenizer = _pick_detokenizer(model_path, tok)
         return tok
+    if MODEL_REMAPPING.get(mt, mt) == "idefics2":
+        # reference idefics2/processing_idefics2.py:165-214 (Idefics2Processor.from_pretrained): tokenizer + transformers' image
+        # processor configuration (size / mean / std / do_image_splitting) + image_seq_len of processor_config.json
+        from .models.idefics2 import Idefics2ImageProcessor, Idefics2Processor
+
+        ipk = {k: pc[k] for k in ("size", "image_mean", "image_std", "rescale_factor", "do_image_splitting") if k in pc}
+        pk = {}
+        ppath = os.path.join(model_path, "processor_config.json")
+        if os.path.exists(ppath):
+            with open(ppath) as f:
+                pcfg = json.load(f)
+            if "image_seq_len" in pcfg:
+                pk["image_seq_len"] = pcfg["image_seq_len"]
+            ipk.update({k: v for k, v in (pcfg.get("image_processor") or {}).items() if k in ("size",)})
+        proc = Idefics2Processor(Idefics2ImageProcessor(**ipk), tok, chat_template=getattr(tok, "chat_template", None), **pk)
+        eos = config.eos_token_id if getattr(config, "eos_token_id", None) is not None else tok.eos_token_id
+        tok.stopping_criteria = StoppingCriteria(eos if isinstance(eos, list) else [eos], tok)
+        proc.detokenizer = _pick_detokenizer(model_path, tok)
+        return proc
     if MODEL_REMAPPING.get(mt, mt) == "phi3_v":
         # reference phi3_v/processing_phi3_v.py:596-660 (Phi3VProcessor.from_pretrained): tokenizer + the HD image processor
         # with num_crops / num_img_tokens / mean / std of preprocessor_config.json, chat template from the tokenizer

@@ -114,3 +114,31 @@ def build_phi3v_model(cfg, W, device="cuda", **kw):
     m = Model(phi3v_config_from_oracle(cfg), device=device, **kw)
     m.load_weights(W)
     return m
+
+
+def idefics2_config_from_oracle(cfg):
+    from mlx_vlm_amd.models.idefics2 import ModelConfig
+
+    t, v, p = cfg.text, cfg.vision, cfg.perceiver
+    return ModelConfig.from_dict(dict(
+        model_type="idefics2", image_token_id=cfg.image_token_id, vocab_size=t.vocab_size,
+        text_config=dict(model_type="mistral", hidden_size=t.hidden_size, intermediate_size=t.intermediate_size,
+                         num_hidden_layers=t.num_hidden_layers, num_attention_heads=t.num_attention_heads,
+                         num_key_value_heads=t.num_key_value_heads, rms_norm_eps=t.rms_norm_eps, vocab_size=t.vocab_size,
+                         rope_theta=t.rope_theta),
+        vision_config=dict(model_type="idefics2", hidden_size=v.hidden_size, intermediate_size=v.intermediate_size,
+                           num_hidden_layers=v.num_hidden_layers, num_attention_heads=v.num_attention_heads,
+                           num_channels=v.num_channels, image_size=v.image_size, patch_size=v.patch_size,
+                           layer_norm_eps=v.layer_norm_eps),
+        perceiver_config=dict(model_type="idefics2", num_key_value_heads=p.num_key_value_heads, resampler_depth=p.resampler_depth,
+                              resampler_head_dim=p.resampler_head_dim, resampler_n_heads=p.resampler_n_heads,
+                              resampler_n_latents=p.resampler_n_latents)))
+
+
+def build_idefics2_model(cfg, W, device="cuda", **kw):
+    """Idefics2 product model from oracle/idefics2.py's config + weights (sanitized names)"""
+    from mlx_vlm_amd.models.idefics2 import Model
+
+    m = Model(idefics2_config_from_oracle(cfg), device=device, **kw)
+    m.load_weights(W)
+    return m
