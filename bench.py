@@ -558,6 +558,67 @@ def workload_7b_b32(args, rank, ws, dev):
     return out
 
 
+def workload_idefics2_b8(args, rank, ws, dev):
+    """BASELINE configs[3]: Idefics2-8B (SigLIP-so400m tower + perceiver resampler + Mistral-7B, bf16), multi-image prompts -
+    4 x 336 x 336 images per prompt (378 x 378 after the processor's resize rule: 729 patches each -> 4 x 64 image tokens
+    interleaved with the text) + 128 text tokens, batch 8 PER GPU through the continuous generator, greedy 64 new tokens."""
+    from mlx_vlm_amd import parallel, synthetic
+    from mlx_vlm_amd.batch import generate_batch_continuous
+    from mlx_vlm_amd.models import idefics2
+
+    cfg, model, load = _load_synthetic(synthetic.IDEFICS2_8B, idefics2, rank, dev, kv_pool_tokens=32768, max_seqs=40)
+    n_req, max_tokens, n_img = 8, args.max_tokens or 64, 4
+    ip = idefics2.Idefics2ImageProcessor()
+    nl = cfg.perceiver_config.resampler_n_latents
+    ids_l, pix_l, ex_l = [], [], []
+    for i in range(n_req):
+        rng = np.random.default_rng(1000 * rank + i)
+        out = ip([[rng.integers(1, 256, (336, 336, 3), dtype=np.uint8) for _ in range(n_img)]])
+        text = rng.integers(3, 32000, 128)
+        parts = []
+        for j in range(n_img):
+            parts += [text[32 * j: 32 * (j + 1)], np.full(nl, cfg.image_token_id)]
+        ids_l.append(np.concatenate(parts).astype(np.int64))
+        pix_l.append(torch.from_numpy(out["pixel_values"]).to(dev))
+        ex_l.append({"pixel_attention_mask": out["pixel_attention_mask"]})
+    run = lambda n, mt: generate_batch_continuous(model, ids_l[:n], pix_l[:n], [None] * n, max_tokens=mt, extras=ex_l[:n],  # noqa: E731
+                                                  batch_size=8)
+    for _ in range(args.warmup):
+        run(n_req, 8)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gen_tok = gen_t = pre_tok = pre_t = 0.0
+    for _ in range(args.steps):
+        toks, st = run(n_req, max_tokens)
+        gen_tok, gen_t = gen_tok + st.generation_tokens, gen_t + st.generation_time
+        pre_tok, pre_t = pre_tok + st.prompt_tokens, pre_t + st.prompt_time
+    torch.cuda.synchronize()
+    parallel.barrier()
+    wall = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    gen_t_max = parallel.max_over_ranks(gen_t, dev)
+    t = cfg.text_config
+    D, TI = t.hidden_size, t.intermediate_size
+    lm_params = t.num_hidden_layers * (D * (t.num_attention_heads + 2 * t.num_key_value_heads) * 128 + D * D + 3 * D * TI) + t.vocab_size * D
+    kv_tok = 2 * t.num_hidden_layers * t.num_key_value_heads * 128 * 2
+    ctx_mid = int(ids_l[0].size) + max_tokens // 2
+    step_bytes = 2 * lm_params + n_req * ctx_mid * kv_tok
+    steps_per_s = gen_tok / n_req / gen_t_max
+    return {"metric": "decode tokens/sec, Idefics2-8B multi-image (4 x 336x336 per prompt), batch=8 per GPU", "value": ws * gen_tok / gen_t_max,
+            "unit": "tokens/s", "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Idefics2-8B dims (SigLIP-so400m/14 tower 27 layers + perceiver resampler + Mistral-7B, random-init bf16), "
+                                   "8 requests per GPU: 4 x 336x336 images (378x378 after resize, 729 patches -> 64 latents each) interleaved "
+                                   f"with 128 text tokens, greedy {max_tokens} new tokens, EOS disabled, 8 decode rows",
+                       "requests_per_gpu": n_req, "images_per_prompt": n_img, "prompt_tokens": int(ids_l[0].size),
+                       "max_tokens": max_tokens, "parallelism": f"dp{ws}"},
+            "e2e_tokens_per_s": ws * gen_tok / wall, "prompt_tps": ws * pre_tok / max(pre_t, 1e-9),
+            "images_per_s_prefill": ws * n_req * n_img * args.steps / max(pre_t, 1e-9), "load": load, "distributed": _dist_info(ws),
+            "roofline": {"bound": "hbm", "kernel": "whole 8-row decode step (bf16 weights once + 8 rows of K / V)",
+                         "achieved": step_bytes * steps_per_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": step_bytes * steps_per_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_step": step_bytes}}
+
+
 def workload_phi35v_w4_b16(args, rank, ws, dev):
     """BASELINE configs[4]: Phi-3.5-vision-instruct with an MLX affine 4-bit language model (the dequant-fused kernels:
     csrc/gemv_w4.hip at 1-4 rows, the W4 form of csrc/gemv_mfma.hip at 5-16 rows; prefill = dequantise + bf16 GEMM), batch
@@ -634,7 +695,7 @@ def main():
     ap.add_argument("--max-tokens", type=int, default=0, help="0 = the workload's own (256 / 64 / 64)")
     ap.add_argument("--lookahead", type=int, default=8)
     ap.add_argument("--vit-batch", type=int, default=16)
-    ap.add_argument("--workload", default="qwen2vl-2b", choices=["qwen2vl-2b", "nanollava", "qwen2vl-7b-b32", "qwen2vl-2b-w4", "phi35v-w4-b16"])
+    ap.add_argument("--workload", default="qwen2vl-2b", choices=["qwen2vl-2b", "nanollava", "qwen2vl-7b-b32", "qwen2vl-2b-w4", "phi35v-w4-b16", "idefics2-b8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-hf", action="store_true", help="skip the HuggingFace torch-CPU second opinion of cpu_baseline")
     ap.add_argument("--no-extras", action="store_true", help="skip kernel rooflines / ViT throughput (profiling runs)")
@@ -650,7 +711,7 @@ def main():
         print(f"[bench] {ws} ranks, backend {_dist_info(ws)['backend']} (RCCL over xGMI), one process per GPU", file=sys.stderr, flush=True)
     if args.workload != "qwen2vl-2b":
         out = {"nanollava": workload_nanollava, "qwen2vl-7b-b32": workload_7b_b32, "qwen2vl-2b-w4": workload_2b_w4,
-               "phi35v-w4-b16": workload_phi35v_w4_b16}[args.workload](
+               "phi35v-w4-b16": workload_phi35v_w4_b16, "idefics2-b8": workload_idefics2_b8}[args.workload](
             args, rank, ws, dev)
         if rank == 0:
             print(json.dumps(out), flush=True)

@@ -49,6 +49,57 @@ PHI35_VISION = dict(
 )
 
 
+# Idefics2-8B (HuggingFaceM4/idefics2-8b: SigLIP-so400m/14-980 tower + perceiver resampler + Mistral-7B), public HF config values -
+# BASELINE configs[3]
+IDEFICS2_8B = dict(
+    model_type="idefics2", image_token_id=32001, vocab_size=32003,
+    text_config=dict(model_type="mistral", hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32,
+                     num_key_value_heads=8, rms_norm_eps=1e-5, vocab_size=32003, rope_theta=10000.0),
+    vision_config=dict(model_type="idefics2", hidden_size=1152, intermediate_size=4304, num_hidden_layers=27, num_attention_heads=16,
+                       num_channels=3, image_size=980, patch_size=14, layer_norm_eps=1e-6),
+    perceiver_config=dict(model_type="idefics2", num_key_value_heads=4, resampler_depth=3, resampler_head_dim=96,
+                          resampler_n_heads=16, resampler_n_latents=64),
+)
+
+
+def idefics2_weight_shapes(cfg) -> Dict[str, tuple]:
+    """name -> shape for an idefics2 ModelConfig, sanitized names (reference idefics2.py:294-321)"""
+    t, v, p = cfg.text_config, cfg.vision_config, cfg.perceiver_config
+    E, I, D, TI = v.hidden_size, v.intermediate_size, t.hidden_size, t.intermediate_size
+    hd = D // t.num_attention_heads
+    s: Dict[str, tuple] = {"vision_model.embeddings.patch_embedding.weight": (E, v.patch_size, v.patch_size, v.num_channels),
+                           "vision_model.embeddings.patch_embedding.bias": (E,),
+                           "vision_model.embeddings.position_embedding.weight": ((v.image_size // v.patch_size) ** 2, E),
+                           "vision_model.post_layernorm.weight": (E,), "vision_model.post_layernorm.bias": (E,)}
+    for i in range(v.num_hidden_layers):
+        q = f"vision_model.encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s[q + f"self_attn.{n}.weight"], s[q + f"self_attn.{n}.bias"] = (E, E), (E,)
+        s.update({q + "layer_norm1.weight": (E,), q + "layer_norm1.bias": (E,), q + "layer_norm2.weight": (E,),
+                  q + "layer_norm2.bias": (E,), q + "mlp.fc1.weight": (I, E), q + "mlp.fc1.bias": (I,),
+                  q + "mlp.fc2.weight": (E, I), q + "mlp.fc2.bias": (E,)})
+    s.update({"connector.modality_projection.gate_proj.weight": (TI, E), "connector.modality_projection.up_proj.weight": (TI, E),
+              "connector.modality_projection.down_proj.weight": (D, TI), "connector.perceiver_resampler.latents": (p.resampler_n_latents, D),
+              "connector.perceiver_resampler.norm.weight": (D,)})
+    ph = p.resampler_head_dim
+    for i in range(p.resampler_depth):
+        q = f"connector.perceiver_resampler.layers.{i}."
+        s.update({q + "input_latents_norm.weight": (D,), q + "input_context_norm.weight": (D,), q + "post_attention_layernorm.weight": (D,),
+                  q + "self_attn.q_proj.weight": (p.resampler_n_heads * ph, D), q + "self_attn.k_proj.weight": (p.num_key_value_heads * ph, D),
+                  q + "self_attn.v_proj.weight": (p.num_key_value_heads * ph, D), q + "self_attn.o_proj.weight": (D, p.resampler_n_heads * ph),
+                  q + "mlp.gate_proj.weight": (4 * D, D), q + "mlp.up_proj.weight": (4 * D, D), q + "mlp.down_proj.weight": (D, 4 * D)})
+    s["language_model.embed_tokens.weight"] = (t.vocab_size, D)
+    for i in range(t.num_hidden_layers):
+        q = f"language_model.layers.{i}."
+        s.update({q + "input_layernorm.weight": (D,), q + "post_attention_layernorm.weight": (D,),
+                  q + "self_attn.q_proj.weight": (t.num_attention_heads * hd, D), q + "self_attn.k_proj.weight": (t.num_key_value_heads * hd, D),
+                  q + "self_attn.v_proj.weight": (t.num_key_value_heads * hd, D), q + "self_attn.o_proj.weight": (D, t.num_attention_heads * hd),
+                  q + "mlp.gate_proj.weight": (TI, D), q + "mlp.up_proj.weight": (TI, D), q + "mlp.down_proj.weight": (D, TI)})
+    s["language_model.norm.weight"] = (D,)
+    s["language_model.lm_head.weight"] = (t.vocab_size, D)
+    return s
+
+
 def phi3v_weight_shapes(cfg) -> Dict[str, tuple]:
     """name -> shape for a phi3_v ModelConfig under the reference's (= HF) names (phi3_v.py:136-177, vision.py:113-206)"""
     v = cfg.vision_config
@@ -121,6 +172,8 @@ def weight_shapes(cfg) -> Dict[str, tuple]:
         return bunny_weight_shapes(cfg)
     if getattr(cfg, "model_type", None) == "phi3_v":
         return phi3v_weight_shapes(cfg)
+    if getattr(cfg, "model_type", None) == "idefics2":
+        return idefics2_weight_shapes(cfg)
     t, v = cfg.text_config, cfg.vision_config
     E, D = v.embed_dim, t.hidden_size
     hd = D // t.num_attention_heads
@@ -161,7 +214,7 @@ def random_weights(cfg, seed: int = 0, device="cuda", dtype=torch.bfloat16, std:
         if not fill:
             W[name] = torch.empty(shape, dtype=dtype, device=device)
         elif name.endswith(("norm1.weight", "norm2.weight", "ln_q.weight", "layernorm.weight", "model.norm.weight",
-                            "layrnorm.weight")):
+                            "layrnorm.weight", "_norm.weight", ".norm.weight")):
             W[name] = torch.ones(shape, dtype=dtype, device=device)
         elif name.endswith(".bias"):
             W[name] = torch.zeros(shape, dtype=dtype, device=device)
