@@ -267,7 +267,8 @@ def stream_generate(model, processor, prompt: Optional[str] = None, image=None, 
     if vision_cache is not None and image is not None and pixel_values is not None and hasattr(model, "encode_image"):
         feats = vision_cache.get(image)
         if feats is None:
-            feats = model.encode_image(pixel_values, **{k: v for k, v in kwargs.items() if k in ("image_grid_thw",)})
+            feats = model.encode_image(pixel_values, **{k: v for k, v in kwargs.items()
+                                                        if k in ("image_grid_thw", "image_sizes", "pixel_attention_mask")})
             vision_cache.put(image, feats)
         kwargs["cached_image_features"] = feats
 
