@@ -29,6 +29,8 @@
 // that both elements of a rotation pair sit in the tile.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.cuh"
 #include "internal.h"
 #include "../../include/vlm_hip.h"
@@ -68,12 +70,20 @@ __device__ __forceinline__ int tile_row(const MfmaArgs& a, int tile, int r) {
 // statistics come from the registers; otherwise the activations are staged before any weight load is issued.
 //
 // W4 (MLX affine 4-bit weights, group 64 - nn.QuantizedLinear at a batched decode step, reference utils.py:918-967): a
-// chunk is 64 bytes of nibbles per row, ONE 16-byte load per lane (row lane >> 2, 32 weights) + one (scale | bias) word;
-// a nibble q becomes the bf16 number 128 + q by OR-ing it into the mantissa of 0x4300, two per instruction, which leaves
-// the 8 weights of a word in the order (0,4,1,5,2,6,3,7) - the activations are staged in the same order, the contraction
-// does not care.  Each 64-wide group is multiplied on its own (2 MFMAs from a zero accumulator) and enters the sum as
-// scale * (D - 128 * sum_x) + bias * sum_x in fp32 (sum_x per batch row and group, once per workgroup): the exact affine
-// form, no weight is rounded - the numerics of csrc/gemv_w4.hip.
+// chunk is 64 bytes of nibbles per row, ONE 16-byte load per lane + the row's (scale | bias) pair.  A q word IS 8
+// consecutive k of one row, i.e. an A fragment of the MFMA: lane (row l & 15, quarter l >> 4) loads the 4 words of its
+// row's quarter - the weights go from global memory to the matrix cores through registers only, no LDS transposition (the
+// bf16 form needs one because a 16-byte piece of a bf16 row is only a quarter of a fragment's k range).  The contraction
+// index is free, so the 4 MFMAs of a chunk take one word each; for the affine form every MFMA must stay inside one 64-wide
+// group, while a lane's 16 bytes lie in one group only: the lower and upper 32 lanes trade two words (lanes l and l ^ 32,
+// one cross-lane move per pair of words), after which words 0 / 1 of every lane belong to group 0 and words 2 / 3 to group
+// 1; the x^T fragments are read at the matching k offsets.  A nibble q becomes the bf16 number 128 + q by OR-ing it into the
+// mantissa of 0x4300, two per instruction, which leaves the 8 weights of a word in the order (0,4,1,5,2,6,3,7) - the
+// activations are staged in the same order.  Each group is multiplied on its own (2 MFMAs from a zero accumulator) and
+// enters the sum as scale * (D - 128 * sum_x) + bias * sum_x in fp32 (sum_x per batch row and group, once per workgroup):
+// the exact affine form, no weight is rounded - the numerics of csrc/gemv_w4.hip.  A wave's chunks are independent
+// straight-line code when the unit is full (no per-chunk branch): MFMAs, dequantisation and LDS reads of neighbouring
+// chunks overlap.
 template <int PRO, int EPI, bool FULLX, int NCW, int XS, bool W4>
 __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // xs[M][P] | wreg[4][WREG] | part[4][256] f32 | red | flag | sbr | xsum
@@ -85,8 +95,8 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
   float* part = reinterpret_cast<float*>(smem + (size_t)a.M * P + 4 * WREG);
   float* red = part + 1024;
   int* s_flag = reinterpret_cast<int*>(red + 64);
-  unsigned* sbr = reinterpret_cast<unsigned*>(red + 80) + wave * 32;      // W4: the wave's 16 rows x 2 groups of (scale | bias)
-  float* xsum = red + 80 + 128;                                           // W4: [M][kx / 64] sums of the staged activations
+  unsigned* sbr = reinterpret_cast<unsigned*>(red + 80) + wave * (7 * 32);   // W4: per chunk slot, the wave's 16 rows x 2 groups of (scale | bias)
+  float* xsum = red + 80 + 4 * 7 * 32;                                      // W4: [M][kx / 64] sums of the staged activations
   const int n_units = a.n_tiles * a.KS, G = gridDim.x;
   const int mrow = min(r16, a.M - 1);
 
@@ -97,14 +107,18 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
     const int tile = u / a.KS, ks = u % a.KS;
     const int kb0 = ks * a.bpk, kb1 = min(a.nblk, kb0 + a.bpk);
     if (W4) {
-      const size_t row = (size_t)min(tile_row<EPI>(a, tile, lane >> 2), a.N - 1);
-      const unsigned* wq = reinterpret_cast<const unsigned*>(a.W) + row * (a.K >> 3) + (lane & 3) * 4;
-      const unsigned* sb = a.Wsb + row * (a.K >> 6) + (lane & 1);
+      // lane (r16, g): row r16 of the tile, the 4 words (32 k) of quarter g of the chunk; slot [1] = the row's (scale | bias)
+      // words of the chunk's two groups
+      const size_t row = (size_t)min(tile_row<EPI>(a, tile, r16), a.N - 1);
+      const unsigned* wq = reinterpret_cast<const unsigned*>(a.W) + row * (a.K >> 3) + g * 4;
+      const unsigned* sb = a.Wsb + row * (a.K >> 6);
 #pragma unroll
       for (int i = 0; i < NCW; ++i) {
         const int b = max(min(kb0 + wave + 4 * i, kb1 - 1), 0);
         wv[i][0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wq + (size_t)b * 16));
-        wv[i][1][0] = sb[(size_t)b * 2];
+        const uint2 s2 = *reinterpret_cast<const uint2*>(sb + (size_t)b * 2);
+        wv[i][1][0] = s2.x;
+        wv[i][1][1] = s2.y;
       }
       return;
     }
@@ -252,41 +266,42 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
     const int tile = u / a.KS, ks = u % a.KS;
     const int kb0 = ks * a.bpk, kb1 = min(a.nblk, kb0 + a.bpk);
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    const char* xrow = smem + (size_t)mrow * P + g * 16 - (FULLX ? 0 : (size_t)kb0 * 256);
+    const char* xrow0 = smem + (size_t)mrow * P - (FULLX ? 0 : (size_t)kb0 * 256);
+    const char* xrow = xrow0 + g * 16;
+    // one chunk of this wave: W4 - registers only; bf16 - through the wave's transposition region
+    auto chunk = [&](int i, int b) __attribute__((always_inline)) {
+      if (W4) {
+        const u32x4_t w = wv[i][0];
+        const bool lo = lane < 32;
+        // lanes l and l ^ 32 (same row, quarters g and g ^ 2) trade words so that words 0 / 1 of every lane come from the
+        // chunk's first 64-wide group and words 2 / 3 from the second: the lower half sends its words 2 / 3, the upper 0 / 1
+        const unsigned s0 = __shfl_xor(lo ? w[2] : w[0], 32), s1 = __shfl_xor(lo ? w[3] : w[1], 32);
+        const unsigned v4[4] = {lo ? w[0] : s0, lo ? w[1] : s1, lo ? s0 : w[2], lo ? s1 : w[3]};
+        unsigned* sb_i = sbr + i * 32;
+        if (g == 0) *reinterpret_cast<uint2*>(sb_i + r16 * 2) = uint2{wv[i][1][0], wv[i][1][1]};
+        const float* xs_m = xsum + (size_t)mrow * (kx >> 6) + (size_t)(b - (FULLX ? 0 : kb0)) * 2;
+        // k offsets (bytes into the chunk's 256 B of x) of the lane's words: own quarter 32 g, the partner's 32 (g ^ 2)
+        const char* xb = xrow0 + (size_t)b * 256;
+        const int off[2] = {lo ? 64 * g : 64 * (g - 2) + 32, lo ? 64 * (g + 2) : 64 * g + 32};
 #pragma unroll
-    for (int i = 0; i < NCW; ++i) {
-      const int b = kb0 + wave + 4 * i;
-      if (b < kb1) {                                          // wave-uniform
-        if (W4) {
-          // 32 nibbles -> 32 bf16 (128 + q) at row lane >> 2, bytes 64 (lane & 3) .. +64 of the wave's region
-          char* dst = wreg + (lane >> 2) * 272 + (lane & 3) * 64;
+        for (int gq = 0; gq < 2; ++gq) {
+          f32x4_t d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int w4 = 0; w4 < 4; ++w4) {
-            const unsigned w = wv[i][0][w4];
-            const u32x4_t e = {(w & 0x000F000Fu) | 0x43004300u, ((w >> 4) & 0x000F000Fu) | 0x43004300u,
-                               ((w >> 8) & 0x000F000Fu) | 0x43004300u, ((w >> 12) & 0x000F000Fu) | 0x43004300u};
-            *reinterpret_cast<u32x4_t*>(dst + w4 * 16) = e;
+          for (int k2 = 0; k2 < 2; ++k2) {
+            const unsigned wd = v4[2 * gq + k2];
+            const u32x4_t af = {(wd & 0x000F000Fu) | 0x43004300u, ((wd >> 4) & 0x000F000Fu) | 0x43004300u,
+                                ((wd >> 8) & 0x000F000Fu) | 0x43004300u, ((wd >> 12) & 0x000F000Fu) | 0x43004300u};
+            const u32x4_t bf = *reinterpret_cast<const u32x4_t*>(xb + off[gq] + 16 * k2);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bf), d, 0, 0, 0);
           }
-          if ((lane & 3) < 2) sbr[(lane >> 2) * 2 + (lane & 1)] = wv[i][1][0];
-          const float* xs_m = xsum + (size_t)mrow * (kx >> 6) + (size_t)(b - (FULLX ? 0 : kb0)) * 2;
+          const float sx = xs_m[gq];
 #pragma unroll
-          for (int gq = 0; gq < 2; ++gq) {
-            f32x4_t d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-              const int kb = 2 * gq + k2;
-              const u32x4_t af = *reinterpret_cast<const u32x4_t*>(wreg + r16 * 272 + kb * 64 + g * 16);
-              const u32x4_t bf = *reinterpret_cast<const u32x4_t*>(xrow + (size_t)b * 256 + kb * 64);
-              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bf), d, 0, 0, 0);
-            }
-            const float sx = xs_m[gq];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const unsigned sbw = sbr[(4 * g + q) * 2 + gq];
-              acc[q] += bf_lo(sbw) * (d[q] - 128.f * sx) + bf_hi(sbw) * sx;
-            }
+          for (int q = 0; q < 4; ++q) {
+            const unsigned sbw = sb_i[(4 * g + q) * 2 + gq];
+            acc[q] += bf_lo(sbw) * (d[q] - 128.f * sx) + bf_hi(sbw) * sx;
           }
-        } else {
+        }
+      } else {
         // chunk -> the wave's region [16 rows][272 B] (as loaded: row 4 j + g, byte 16 r16), then the fragments
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4_t*>(wreg + (4 * j + g) * 272 + r16 * 16) = wv[i][j];
@@ -297,7 +312,26 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bf), acc, 0, 0,
                                                         0);
         }
-        }
+      }
+    };
+    // W4: the wave's valid chunks (wave-uniform count) as straight-line code - no per-chunk branch, so the MFMAs,
+    // dequantisation and LDS reads of neighbouring chunks overlap; the common counts NCW, NCW - 1, NCW - 2 get a copy each
+    const int n_valid = max(0, min(NCW, (kb1 - kb0 - wave + 3) >> 2));
+    auto straight = [&](auto nc) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < decltype(nc)::value; ++i) chunk(i, kb0 + wave + 4 * i);
+    };
+    if (W4 && n_valid == NCW) {
+      straight(std::integral_constant<int, NCW>{});
+    } else if (W4 && NCW > 1 && n_valid == NCW - 1) {
+      straight(std::integral_constant<int, (NCW > 1 ? NCW - 1 : 1)>{});
+    } else if (W4 && NCW > 2 && n_valid == NCW - 2) {
+      straight(std::integral_constant<int, (NCW > 2 ? NCW - 2 : 1)>{});
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCW; ++i) {
+        const int b = kb0 + wave + 4 * i;
+        if (b < kb1) chunk(i, b);                             // wave-uniform
       }
     }
     if (!DBUF && u + G < n_units) load_w(u + G, wv);          // one register set: the next unit's weights go out now
@@ -489,8 +523,14 @@ static int mfma_try(const void* x, const void* W, const void* Wsb, const void* b
   // (12 chunks: the double-buffered form) is the target and splitting further only adds the cross-workgroup hand-off
   // (qkv at KS = 3: 10 us, one dependent chain of partial store -> ticket -> partial loads -> epilogue)
   int KS = vlm_cdiv(a.nblk, 4 * NCW);
+  // ... and only while the row tiles alone do not fill the chip: every unit of a split tile ends in the hand-off chain
+  // (partial store -> vmcnt(0), which also drains the next unit's weight loads -> ticket -> partial loads), ~5-10 us per
+  // unit with one workgroup per CU.  Measured at Phi-3.5 dims (K = 3072, 1024 / 768 row tiles, 16 rows): gate/up and qkv
+  // 48 us at KS = 2 (profiles/r02_phi35v_kernel_stats.txt)
   if (ws)
-    while (vlm_cdiv(a.nblk, KS) > 12 && KS < 16 && (size_t)a.n_tiles * (KS + 1) <= 4096) ++KS;
+    while (vlm_cdiv(a.nblk, KS) > 12 && KS < 16 && (size_t)a.n_tiles * (KS + 1) <= 4096 &&
+           (!norm_w || a.n_tiles * KS < 640))      // (the segment forms without a norm also split to fit their x segment in LDS)
+      ++KS;
   if (KS > 1 && (!ws || a.n_tiles > 8192 || (size_t)a.n_tiles * KS > 4096)) return -1;
   a.KS = KS;
   a.bpk = vlm_cdiv(a.nblk, KS);
@@ -498,7 +538,7 @@ static int mfma_try(const void* x, const void* W, const void* Wsb, const void* b
   a.ws = (float*)ws;
   a.tickets = ws ? (unsigned*)((char*)ws + (size_t)4096 * 256 * 4) : nullptr;
   const int n_units = a.n_tiles * KS;
-  const size_t tail = 4 * WREG + 4096 + 256 + 64 + 512 + (Wsb ? (size_t)M * (K / 64) * 4 : 0);      // + sbr, xsum (4-bit)
+  const size_t tail = 4 * WREG + 4096 + 256 + 64 + 4 * 7 * 128 + (Wsb ? (size_t)M * (K / 64) * 4 : 0);      // + sbr, xsum (4-bit)
   const size_t lds_full = (size_t)M * ((size_t)K * 2 + 16) + tail, lds_seg = (size_t)M * ((size_t)a.bpk * 256 + 16) + tail;
   const bool fullx = lds_full <= (norm_w ? 152 : 100) * 1024;      // (one workgroup per CU above 80 KB: only when the norm needs it)
   if (!fullx && (norm_w || lds_seg > 100 * 1024)) return -1;
