@@ -287,20 +287,23 @@ def _hf_cpu_baseline(cfg, threads, ctx, n_tok):
 
 DECODE_KERNELS = ("gemv_rowwave_kernel", "gemv_splitk_kernel", "attn_decode_mfma_kernel", "attn_decode_combine_kernel",
                   "lse_partial_kernel", "logprob_argmax_kernel", "argmax_final_kernel", "embed_gather_kernel",
-                  "decode_advance_kernel", "sample_filter_kernel")
+                  "decode_advance_kernel", "sample_filter_kernel", "logprob_argmax_tail_kernel")
+HEAD_KERNEL = "gemv_rowwave_kernel<4, 3, 1, 1, 0>"         # RMSNorm + lm_head GEMV: exactly one launch per decoded token
 GATE_UP_KERNEL = "gemv_rowwave_kernel<4, 3, 1, 1, 16>"     # name as rocprofv3 prints it (R=4 rows/wave, RMSNorm prologue, SwiGLU)
 
 
 def pmc_traffic():
-    """HBM bytes per launch from the committed --pmc pass (scripts/final_round.sh -> profiles/r01_pmc_traffic.json:
-    (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of MI355X_MICROARCH.md).  bench.py cannot collect
-    hardware counters itself; None when the file is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
+    """HBM bytes per launch from the committed --pmc passes (scripts/r02_final_prof.sh -> profiles/r02_pmc_traffic.json, taken
+    on the kernels of this tree at the end of round 2; the round-1 file as a fallback): (2 * FETCH_SIZE + WRITE_SIZE) * 1024,
+    the gfx950 correction of MI355X_MICROARCH.md.  bench.py cannot collect hardware counters itself (they need rocprofv3 around
+    the process); None when no file is there."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    path = next((p for p in (os.path.join(here, "r02_pmc_traffic.json"), os.path.join(here, "r01_pmc_traffic.json")) if os.path.exists(p)), None)
+    if path is None:
         return None, None
     d = json.load(open(path))
     gu = d.get(GATE_UP_KERNEL, {}).get("hbm_bytes_per_launch")
-    steps = d.get("decode_advance_kernel", {}).get("launches", 0)
+    steps = d.get(HEAD_KERNEL, {}).get("launches", 0) or d.get("decode_advance_kernel", {}).get("launches", 0)
     per_tok = None
     if steps:
         per_tok = sum(v.get("hbm_bytes_per_launch", 0.0) * v["launches"] for k, v in d.items()
