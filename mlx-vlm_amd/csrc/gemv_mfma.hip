@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
 #pragma unroll
       for (int i = 0; i < decltype(nc)::value; ++i) chunk(i, kb0 + wave + 4 * i);
     };
-    if (W4 && n_valid == NCW) {
+    if (n_valid == NCW) {
       straight(std::integral_constant<int, NCW>{});
     } else if (W4 && NCW > 1 && n_valid == NCW - 1) {
       straight(std::integral_constant<int, (NCW > 1 ? NCW - 1 : 1)>{});
