@@ -384,9 +384,17 @@ def _embed_requests_per_model(model, input_ids_list, pixel_values_list, extras):
     """Model families other than Qwen2-VL (llava_bunny, phi3_v): every request through the model's own
     `get_input_embeddings` (its tower, projector and splice rule), the results concatenated for one varlen prefill."""
     embs, poss, lens, deltas = [], [], [], []
-    for ids, pix, kw in zip(input_ids_list, pixel_values_list, extras):
+    # one tower pass for the images of ALL requests where the model offers it (`encode_images_batched`: per-request features,
+    # computed together - the GEMMs of 4 x 729 rows of one request run at a fraction of the rate of 32 x 729)
+    feats = None
+    if hasattr(model, "encode_images_batched") and sum(p is not None for p in pixel_values_list) > 1:
+        feats = model.encode_images_batched(pixel_values_list, extras)
+    for j, (ids, pix, kw) in enumerate(zip(input_ids_list, pixel_values_list, extras)):
         ids = np.asarray(ids).reshape(1, -1)
-        f = model.get_input_embeddings(ids, torch.as_tensor(pix) if pix is not None else None, **(kw or {}))
+        kw = dict(kw or {})
+        if feats is not None and feats[j] is not None:
+            kw["cached_image_features"] = feats[j]
+        f = model.get_input_embeddings(ids, torch.as_tensor(pix) if pix is not None else None, **kw)
         L = f.inputs_embeds.shape[1]
         p = np.asarray(f.position_ids)
         if p.ndim == 2:

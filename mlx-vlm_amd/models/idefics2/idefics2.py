@@ -74,12 +74,20 @@ class Model:
 
     # ------------------------------------------------------------------ reference idefics2.py:184-250
     def _real_images(self, pixel_values, pixel_attention_mask):
-        """-> (real images [n, C, H, W] host float32, patch mask bool [n, gh, gw])"""
-        pv = pixel_values.detach().cpu().float().numpy() if isinstance(pixel_values, torch.Tensor) else np.asarray(pixel_values, dtype=np.float32)
-        B, N, C, H, W = pv.shape
-        pv = pv.reshape(B * N, C, H, W)
-        real = np.where((pv == 0.0).reshape(B * N, -1).sum(axis=1) != C * H * W)[0]
-        pv = pv[real]
+        """-> (real images [n, C, H, W] float32 - a device tensor when the pixels already live there, else a host array -,
+        patch mask bool [n, gh, gw])"""
+        if isinstance(pixel_values, torch.Tensor) and pixel_values.is_cuda:
+            B, N, C, H, W = pixel_values.shape
+            pv = pixel_values.reshape(B * N, C, H, W)
+            real = np.where((pv != 0).reshape(B * N, -1).any(dim=1).cpu().numpy())[0]      # bookkeeping: B * N flags come back
+            if len(real) != B * N:
+                pv = pv[torch.as_tensor(real, device=pv.device)]
+        else:
+            pv = pixel_values.detach().float().numpy() if isinstance(pixel_values, torch.Tensor) else np.asarray(pixel_values, dtype=np.float32)
+            B, N, C, H, W = pv.shape
+            pv = pv.reshape(B * N, C, H, W)
+            real = np.where((pv == 0.0).reshape(B * N, -1).sum(axis=1) != C * H * W)[0]
+            pv = pv[real]
         if pixel_attention_mask is None:
             pam = np.ones((len(real), H, W), dtype=bool)
         else:
@@ -92,8 +100,32 @@ class Model:
     def encode_image(self, pixel_values, pixel_attention_mask=None, **kwargs) -> torch.Tensor:
         """-> resampler outputs of every real image, bf16 [n * n_latents, hidden]"""
         pv, pmask = self._real_images(pixel_values, pixel_attention_mask)
-        pooled = self.vision_model(torch.from_numpy(np.ascontiguousarray(pv)), pmask)
+        pooled = self.vision_model(pv if isinstance(pv, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(pv)), pmask)
         return self.connector(pooled, pv.shape[0])
+
+    def encode_images_batched(self, pixel_values_list, extras):
+        """The images of several requests through ONE tower + connector pass per padded image size (requests whose images
+        were padded to different sizes cannot share a pass: padding patches take part in the unmasked encoder attention,
+        as in the reference).  -> per request: resampler rows [n_i * n_latents, hidden] or None"""
+        groups, out = {}, [None] * len(pixel_values_list)
+        for j, (pv, kw) in enumerate(zip(pixel_values_list, extras)):
+            if pv is None:
+                continue
+            real, pmask = self._real_images(pv, (kw or {}).get("pixel_attention_mask", None))
+            groups.setdefault(tuple(real.shape[1:]), []).append((j, real, pmask))
+        nl = self.config.perceiver_config.resampler_n_latents
+        for items in groups.values():
+            reals = [r if isinstance(r, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(r)) for _, r, _ in items]
+            if any(r.is_cuda for r in reals):
+                reals = [r if r.is_cuda else r.to(self.device) for r in reals]
+            real = torch.cat(reals, dim=0) if len(reals) > 1 else reals[0]
+            pmask = np.concatenate([m for _, _, m in items], axis=0)
+            feats = self.connector(self.vision_model(real, pmask), real.shape[0])
+            at = 0
+            for j, r, _ in items:
+                out[j] = feats[at * nl: (at + r.shape[0]) * nl]
+                at += r.shape[0]
+        return out
 
     def get_input_embeddings(self, input_ids=None, pixel_values=None, **kwargs):
         lm = self.language_model

@@ -67,6 +67,27 @@ class Model:
         """-> the projected rows of every image, concatenated (what a vision-feature cache stores for this model)"""
         return torch.cat(self.vision_model.image_features(pixel_values, image_sizes), dim=0)
 
+    def encode_images_batched(self, pixel_values_list, extras):
+        """The views of several requests through ONE CLIP pass (every view is 336 x 336) and one projection GEMM pair.
+        -> per request: projected rows of its images, concatenated, or None"""
+        idx = [j for j, pv in enumerate(pixel_values_list) if pv is not None]
+        out = [None] * len(pixel_values_list)
+        if not idx:
+            return out
+        pvs = [torch.as_tensor(pixel_values_list[j]) for j in idx]
+        sizes = [np.asarray((extras[j] or {})["image_sizes"]).reshape(-1, 2) for j in idx]
+        T = max(p.shape[1] for p in pvs)
+        dev_any = any(p.is_cuda for p in pvs)
+        pvs = [p if p.shape[1] == T else torch.cat([p, p.new_zeros(p.shape[0], T - p.shape[1], *p.shape[2:])], dim=1) for p in pvs]
+        if dev_any:
+            pvs = [p if p.is_cuda else p.to(self.device) for p in pvs]
+        rows = self.vision_model.image_features(torch.cat(pvs, dim=0), np.concatenate(sizes, axis=0))
+        at = 0
+        for j, sz in zip(idx, sizes):
+            out[j] = torch.cat(rows[at: at + len(sz)], dim=0) if len(sz) > 1 else rows[at]
+            at += len(sz)
+        return out
+
     # ------------------------------------------------------------------ reference phi3_v.py:199-233
     def get_input_embeddings(self, input_ids=None, pixel_values=None, **kwargs):
         lm = self.language_model
@@ -76,23 +97,22 @@ class Model:
         emb = lm.embed_tokens(np.where(ids < 0, 0, ids))               # the rows at negative ids are overwritten below
         pos, deltas = lm.get_rope_index(ids)
         if pixel_values is not None:
-            positions = np.argwhere(ids < 0).tolist()
+            where = np.argwhere(ids < 0)
             cached = kwargs.get("cached_image_features", None)
             if cached is not None:
-                rows = [cached]
+                rows = cached
             else:
                 image_sizes = kwargs.get("image_sizes", None)
                 if image_sizes is None:
                     raise ValueError("phi3_v needs `image_sizes` next to `pixel_values` (the processor returns both)")
                 rows = self.vision_model.image_features(pixel_values, image_sizes)
-            idx = 0
-            for r in rows:
-                if idx >= len(positions):
-                    break
-                b, start = positions[idx]
-                cnt = min(r.shape[0], len(positions) - idx)
-                emb[b, start:start + cnt] = r[:cnt]
-                idx += cnt
+                rows = torch.cat(rows, dim=0) if len(rows) > 1 else rows[0]
+            # image i's rows go to its run of negative ids (the processor emits exactly cnt_i of them, contiguous): the
+            # reference writes cnt_i rows from the run's first position on (vision.py:257-262) - the same rows
+            n = min(rows.shape[0], len(where))
+            from ... import _lib
+            flat = _lib.h2d((where[:n, 0] * ids.shape[1] + where[:n, 1]).astype(np.int64), self.device)
+            emb.view(-1, emb.shape[-1]).index_copy_(0, flat, rows[:n].to(emb.dtype))
         return InputEmbeddingsFeatures(inputs_embeds=emb, position_ids=pos, rope_deltas=deltas)
 
     def __call__(self, input_ids, pixel_values=None, mask=None, cache=None, **kwargs):
