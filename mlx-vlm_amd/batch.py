@@ -134,6 +134,7 @@ class BatchGenerator:
             raise NotImplementedError(f"BatchGenerator: outside the built path: {sorted(unsupported)}")
         self.model = model
         self.lm = model.language_model
+        self.lm._batch_users = getattr(self.lm, "_batch_users", 0) + 1      # models with per-call global state (phi3_v's RoPE regime)
         self.processor = processor
         self.tokenizer = getattr(processor, "tokenizer", processor)
         self.max_tokens = max_tokens
@@ -319,6 +320,7 @@ class BatchGenerator:
         if self._closed:
             return
         self._closed = True
+        self.lm._batch_users = max(0, getattr(self.lm, "_batch_users", 1) - 1)
         if self._cuda:
             torch.cuda.synchronize()
         for p in self._pending:

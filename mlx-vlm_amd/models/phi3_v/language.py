@@ -18,9 +18,14 @@ and interleaved gate / up rows.  Phi-3.5 has 96-wide heads; everything maps onto
     x * T(scale) on q and k before the rotation - a typed multiply, i.e. one more bf16 rounding of q and k, which attention
     amplifies to ~1 % of an output (measured in tests/test_phi3v_cpu.py), so it is kept: `rope_qk_scale` of
     `vlm_llm_config` applies it with the reference's rounding in the prefill rope pass and in every decode qkv epilogue.
-    Only the short-factor regime is built: the reference switches to the long factors for the rows of any call whose
-    offset + length exceeds `original_max_position_embeddings` (keys cached earlier keep the short ones); prompts +
-    generations beyond that limit raise NotImplementedError instead of silently using other frequencies.
+    The reference decides short vs long factors PER CALL: long iff (largest cache offset of the call) + (tokens of the
+    call) exceeds `original_max_position_embeddings`, for the rows of that call only - a prompt of 5000 tokens is rotated
+    with the long factors, a generation that crosses position 4096 switches at that step while the keys cached before keep
+    the short-factor rotation.  Here the engine reads ONE frequency table whose CONTENTS are switched in stream order
+    between the calls (the pointer never changes, so captured decode graphs stay valid): `prefill` picks the regime of its
+    call, `decode_run` splits a run of steps at the crossing.  Built for one sequence at a time (generate / stream_generate,
+    one stream); a continuous batch whose rows would need the long table raises NotImplementedError (its admissions run on a
+    second stream and would race with the table).
   * plain RoPE = M-RoPE with equal axes: positions arange(L), rope_deltas 0.
 """
 from __future__ import annotations
@@ -58,11 +63,16 @@ class LanguageModel(_Engine):
         su = rs.get("type") in ("su", "longrope") or ("short_factor" in rs and "long_factor" in rs)
         if rs and not su:
             raise NotImplementedError(f"rope_scaling {rs.get('type')}: only Su-scaled RoPE (short / long factors) is built")
-        freqs = float(c.rope_theta) ** (np.arange(0, hd, 2, dtype=np.float32) / np.float32(hd))
-        scale = 1.0
+        base = float(c.rope_theta) ** (np.arange(0, hd, 2, dtype=np.float32) / np.float32(hd))
+        freqs, scale = base, 1.0
+        self._inv_tables = None
         if su:
-            freqs = np.asarray(rs["short_factor"], dtype=np.float32) * freqs
+            freqs = np.asarray(rs["short_factor"], dtype=np.float32) * base
             scale = su_scale(c.max_position_embeddings, c.original_max_position_embeddings)
+            pad = np.zeros(ENGINE_HEAD_DIM // 2 - hd // 2, dtype=np.float32)
+            self._inv_tables = (np.concatenate([np.float32(1.0) / freqs, pad]),
+                                np.concatenate([np.float32(1.0) / (np.asarray(rs["long_factor"], dtype=np.float32) * base), pad]))
+        self._long_regime = False
         self.real_head_dim = hd
         self.model_config = c
         self.max_context = int(c.original_max_position_embeddings) if su else None
@@ -176,19 +186,60 @@ class LanguageModel(_Engine):
         pos = np.broadcast_to(np.arange(L, dtype=np.int64)[None, None], (3, B, L)).copy()
         return pos, np.zeros((B, 1), dtype=np.int64)
 
-    # ------------------------------------------------------------------ the short-factor regime only
+    # ------------------------------------------------------------------ short / long factor regimes (rope_utils.py:168-172)
+    def _set_regime(self, long: bool):
+        """Switch the CONTENTS of the engine's frequency table (stream-ordered copy; pointer and graphs unchanged)."""
+        if self._inv_tables is None or bool(long) == self._long_regime:
+            return
+        if not hasattr(self, "_inv_dev"):
+            self._inv_dev = tuple(torch.from_numpy(t).to(self.device) for t in self._inv_tables)
+        self._w["inv_freq"].copy_(self._inv_dev[1 if long else 0])
+        self._long_regime = bool(long)
+
     def _check_context(self, total: int):
+        """Batched paths (several sequences share the table, admissions run on a second stream): short regime only."""
         if self.max_context is not None and total > self.max_context:
             raise NotImplementedError(
-                f"{total} positions exceed original_max_position_embeddings = {self.max_context}: the reference switches to "
-                "the long RoPE factors there (rope_utils.py:168-172); that regime is not built")
+                f"{total} positions exceed original_max_position_embeddings = {self.max_context} in a batch: the long-factor "
+                "regime of SuScaledRoPE is built for one sequence at a time (generate / stream_generate)")
 
     def prefill(self, inputs_embeds, position_ids, caches, lengths, logits_rows="last", reserve_extra=0):
-        for cch, n in zip(caches, lengths):
-            self._check_context(int(cch[0]._seq.offset) + int(n))
+        from ..cache import PAGE
+
+        ends = [int(cch[0]._seq.offset) + int(n) for cch, n in zip(caches, lengths)]
+        if len(caches) == 1 and not getattr(self, "_batch_users", 0):
+            self._set_regime(self.max_context is not None and ends[0] > self.max_context)     # the regime of THIS call
+        else:
+            # a BatchGenerator is alive (it registers itself in `_batch_users`) or several sequences share the call: every
+            # sequence must stay in the short regime for its whole life - its page reservation (made by the generator
+            # before the admission prefill: prompt + max_tokens) tells how far it may grow
+            for cch, e in zip(caches, ends):
+                self._check_context(max(e, (len(cch[0]._seq.pages) - 1) * PAGE))
+            self._set_regime(False)
         return super().prefill(inputs_embeds, position_ids, caches, lengths, logits_rows, reserve_extra)
 
     def decode_begin(self, caches, first_tokens, rope_deltas, max_new_tokens):
-        for cch in caches:
-            self._check_context(int(cch[0]._seq.offset) + int(max_new_tokens))
+        if len(caches) > 1 or getattr(self, "_batch_users", 0):
+            for cch in caches:
+                self._check_context(int(cch[0]._seq.offset) + int(max_new_tokens))
+        elif self.max_context is not None:
+            self._set_regime(int(caches[0][0]._seq.offset) >= self.max_context)       # the regime of the first step
         return super().decode_begin(caches, first_tokens, rope_deltas, max_new_tokens)
+
+    def decode_run(self, st, n_steps, sampler_args, use_graph=True, penalties=None):
+        """A decode step is a call of one token at cache offset o: long factors iff o + 1 > original_max, i.e. from o =
+        original_max on.  A run that crosses is split there, the table switched between the two halves."""
+        if self.max_context is None or n_steps <= 0:
+            return super().decode_run(st, n_steps, sampler_args, use_graph, penalties)
+        o0 = max(int(s.offset) for s in st.seqs)
+        n_short = max(0, min(n_steps, self.max_context - o0))
+        if n_short < n_steps and len(st.seqs) > 1:
+            self._check_context(o0 + n_steps)
+        if n_short > 0:
+            self._set_regime(False)
+            super().decode_run(st, n_short, sampler_args, use_graph, penalties)
+        if n_short < n_steps:
+            self._set_regime(True)
+            super().decode_run(st, n_steps - n_short, sampler_args, use_graph, penalties)
+
+

@@ -303,3 +303,37 @@ def test_real_widths_4bit_two_layers_vs_oracle():
     assert n == ids.shape[1] + 6
     worst = _check_rows(got, ref, 2e-2, "phi3.5 widths 4-bit")
     print(f"phi3.5 real widths, 4-bit: worst row rel-rms {worst:.4f}")
+
+
+@pytest.mark.parametrize("prompt_len", [4090, 4200])
+def test_su_rope_long_factor_regime_switches_per_call(tiny, prompt_len):
+    """SuScaledRoPE picks its factors per call (rope_utils.py:168-172): long iff cache offset + tokens of the call exceed
+    original_max_position_embeddings (4096).  4090-token prompt: short-factor prefill, then teacher-forced decode steps whose
+    cache offset runs 4090 .. 4101 - the steps from offset 4096 on use the long factors over keys cached with the short
+    ones; 4200-token prompt: long from the prefill on.  Every row vs the oracle (which restates that rule and is pinned to the
+    reference's rope on both sides of the limit); through the module contract and through generate_step's graph replay."""
+    from mlx_vlm_amd.generate import generate_step
+
+    cfg, W, model = tiny
+    ids = np.random.default_rng(300 + prompt_len).integers(3, 1000, (1, prompt_len))
+    forced = np.random.default_rng(301).integers(3, 1000, 12)
+    ref = op.decode_teacher_forced(W, cfg, ids, None, None, forced)
+    got, _, n = _engine_teacher_forced(model, ids, None, None, forced)
+    assert n == prompt_len + 12
+    worst = _check_rows(got, ref, 2.5e-2, f"phi3v long regime {prompt_len}")
+    # the same through generate_step (lookahead batches of graph replays split at the crossing): greedy tokens vs the oracle
+    ref_toks, ref_logits = op.generate_greedy(W, cfg, ids, None, None, max_tokens=12, return_logits=True)
+    toks = [t for t, _ in generate_step(ids, model, None, None, max_tokens=12, temperature=0.0, lookahead=4)]
+    for i in range(12):
+        if toks[i] != ref_toks[i]:
+            r = ref_logits[i].float()
+            top2 = r.topk(2).values
+            assert float(top2[0] - top2[1]) < 0.06 * float(r.pow(2).mean().sqrt()), (i, toks, ref_toks)
+            break
+    assert toks[0] == ref_toks[0]
+    # back to a short prompt afterwards: the table must have been switched back
+    ids2, _, _ = _request(cfg, [], seed=77)
+    f2 = np.random.default_rng(78).integers(3, 1000, 4)
+    _check_rows(_engine_teacher_forced(model, ids2, None, None, f2)[0], op.decode_teacher_forced(W, cfg, ids2, None, None, f2), 2e-2,
+                "phi3v short again")
+    print(f"phi3v long-factor regime, prompt {prompt_len}: worst row rel-rms {worst:.4f}")
