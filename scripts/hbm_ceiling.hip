@@ -1,0 +1,143 @@
+// Achievable HBM bandwidth on this part, next to the 8 TB/s vendor figure the rooflines divide by (SURVEY section 8d asks for a
+// measured stream ceiling beside the peak): a read-only streaming reduction and a copy over buffers far larger than the
+// 256 MB Infinity Cache, non-temporal 16-byte loads, several grid sizes.
+//   hipcc --offload-arch=gfx950 -O3 -o scripts/bin/hbm_ceiling scripts/hbm_ceiling.hip && scripts/bin/hbm_ceiling
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+template <int UNROLL>
+__global__ __launch_bounds__(256) void read_kernel(const u32x4_t* __restrict__ src, size_t n16, unsigned* out) {
+  // workgroup w streams the contiguous slice [w * per, (w + 1) * per): every wave instruction is 1 KiB contiguous
+  const size_t per = n16 / gridDim.x;
+  const u32x4_t* p = src + (size_t)blockIdx.x * per + threadIdx.x;
+  unsigned acc = 0;
+  size_t i = 0;
+  for (; i + (size_t)UNROLL * 256 <= per; i += (size_t)UNROLL * 256) {
+    u32x4_t v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(p + i + (size_t)u * 256);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc ^= v[u][0] ^ v[u][1] ^ v[u][2] ^ v[u][3];
+  }
+  for (; i + threadIdx.x < per; i += 256) {          // tail of the slice
+    const u32x4_t v = __builtin_nontemporal_load(p + i);
+    acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+  }
+  if (acc == 0x12345678u) out[0] = acc;      // keeps the loads alive
+}
+
+template <int UNROLL>
+__global__ __launch_bounds__(256) void copy_kernel(const u32x4_t* __restrict__ src, u32x4_t* __restrict__ dst, size_t n16) {
+  const size_t per = n16 / gridDim.x;
+  const size_t base = (size_t)blockIdx.x * per + threadIdx.x;
+  for (size_t i = 0; i + (size_t)UNROLL * 256 <= per; i += (size_t)UNROLL * 256) {
+    u32x4_t v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(src + base + i + (size_t)u * 256);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) __builtin_nontemporal_store(v[u], dst + base + i + (size_t)u * 256);
+  }
+}
+
+int main() {
+  const size_t bytes = (size_t)4 << 30;            // 4 GiB per buffer
+  u32x4_t *a, *b;
+  unsigned* out;
+  if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess || hipMalloc(&out, 64) != hipSuccess) return 1;
+  hipMemset(a, 1, bytes);
+  hipMemset(b, 2, bytes);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const size_t n16 = bytes / 16;
+  printf("buffer %.1f GiB; GB/s = 1e9 bytes/s; read = bytes read, copy = bytes read + bytes written\n", bytes / 1073741824.0);
+  for (int grid : {256, 512, 1024, 2048, 4096, 8192}) {
+    float best_r = 0.f, best_c = 0.f;
+    for (int rep = 0; rep < 4; ++rep) {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(read_kernel<8>, dim3(grid), dim3(256), 0, 0, a, n16, out);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      best_r = fmaxf(best_r, bytes / ms / 1e6f);
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(copy_kernel<4>, dim3(grid), dim3(256), 0, 0, a, b, n16);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms, e0, e1);
+      best_c = fmaxf(best_c, 2.f * bytes / ms / 1e6f);
+    }
+    printf("grid %5d x 256 threads: read %7.0f GB/s   copy %7.0f GB/s\n", grid, best_r, best_c);
+  }
+  // a decode-sized read: 55 MB (one gate/up matrix) per launch, cycling through 28 distinct regions (1.5 GB > Infinity Cache)
+  const size_t piece = 55050240 / 16;
+  for (int grid : {256, 512, 1024, 2048}) {
+    hipEventRecord(e0);
+    for (int it = 0; it < 56; ++it)
+      hipLaunchKernelGGL(read_kernel<8>, dim3(grid), dim3(256), 0, 0, a + (size_t)(it % 28) * piece, piece, out);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("55 MB reads back to back, grid %4d: %.2f us per launch = %.0f GB/s (launch gaps included)\n", grid, ms * 1e3f / 56,
+           55050240.0 * 56 / ms / 1e6);
+  }
+  // the launch structure of one Qwen2-VL-2B decode step as PLAIN READ kernels of the same sizes (no arithmetic, no dependent
+  // prologue loads): per layer qkv 6.29 MB, attention ~0.46 MB by 2 workgroups, o_proj 4.72 MB, gate/up 55.05 MB, down 27.53 MB;
+  // then the 466.7 MB head - 141 launches in one stream, distinct regions (3.1 GB)
+  {
+    const size_t sz[5] = {6291456, 458752, 4718592, 55050240, 27525120};
+    const int gr[5] = {512, 2, 512, 2048, 1024};
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+      size_t off = 0;
+      hipEventRecord(e0);
+      for (int l = 0; l < 28; ++l)
+        for (int k = 0; k < 5; ++k) {
+          hipLaunchKernelGGL(read_kernel<8>, dim3(gr[k]), dim3(256), 0, 0, a + off / 16, sz[k] / 16, out);
+          off += sz[k];
+        }
+      hipLaunchKernelGGL(read_kernel<8>, dim3(2048), dim3(256), 0, 0, a + off / 16, (size_t)466747392 / 16, out);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      best = fminf(best, ms);
+    }
+    printf("decode-step skeleton (141 plain read launches, 3.10 GB), eager launches: %.1f us per step = %.0f GB/s = %.1f %% of 8 TB/s\n",
+           best * 1e3f, 3.102e9 / best / 1e6, 3.102e9 / best / 1e6 / 80.0);
+    // the same captured into a hipGraph and replayed (what the engine does with its step): no host launch cost in the way
+    hipStream_t st;
+    hipStreamCreate(&st);
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    hipStreamBeginCapture(st, hipStreamCaptureModeGlobal);
+    size_t off = 0;
+    for (int l = 0; l < 28; ++l)
+      for (int k = 0; k < 5; ++k) {
+        hipLaunchKernelGGL(read_kernel<8>, dim3(gr[k]), dim3(256), 0, st, a + off / 16, sz[k] / 16, out);
+        off += sz[k];
+      }
+    hipLaunchKernelGGL(read_kernel<8>, dim3(2048), dim3(256), 0, st, a + off / 16, (size_t)466747392 / 16, out);
+    hipStreamEndCapture(st, &graph);
+    hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    best = 1e30f;
+    for (int rep = 0; rep < 6; ++rep) {
+      hipEventRecord(e0, st);
+      for (int r = 0; r < 4; ++r) hipGraphLaunch(exec, st);
+      hipEventRecord(e1, st);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      best = fminf(best, ms / 4);
+    }
+    printf("decode-step skeleton, hipGraph replay: %.1f us per step = %.0f GB/s = %.1f %% of 8 TB/s\n", best * 1e3f,
+           3.102e9 / best / 1e6, 3.102e9 / best / 1e6 / 80.0);
+  }
+  return 0;
+}
