@@ -21,6 +21,11 @@ _LAZY = {
     "BatchResponse": ("generate", "BatchResponse"),
     "BatchGenerator": ("batch", "BatchGenerator"),
     "make_sampler": ("sample_utils", "make_sampler"),
+    "apply_chat_template": ("prompt_utils", "apply_chat_template"),
+    "get_message_json": ("prompt_utils", "get_message_json"),
+    "BatchStats": ("generate", "BatchStats"),
+    "PromptCacheState": ("generate", "PromptCacheState"),
+    "VisionFeatureCache": ("vision_cache", "VisionFeatureCache"),
 }
 
 

@@ -33,7 +33,13 @@ class Connector:
         if hd > HEAD_PAD:
             raise NotImplementedError(f"resampler_head_dim {hd}")
 
+        from .. import quantized as Qz
+
         def g(name):
+            """a tensor, or - for a Linear the checkpoint holds in MLX 4 bits (`<path>.scales`, utils.py:961) - its bf16
+            dequantisation: the connector runs on the bf16 GEMMs"""
+            if name.endswith(".weight") and Qz.has_scales(W, name[: -len(".weight")]):
+                return Qz.dequantize_bf16(Qz.take(W, name[: -len(".weight")]), dev).contiguous()
             return W[name].to(device=dev, dtype=bf).contiguous()
 
         def gated(prefix):

@@ -55,7 +55,11 @@ class VisionModel:
         c, dev, bf = self.config, self.device, torch.bfloat16
         E, H, hd, hp = c.hidden_size, c.num_attention_heads, self.head_dim, self.head_pad
 
+        from .. import quantized as Qz
+
         def g(name):
+            if name.endswith(".weight") and Qz.has_scales(W, name[: -len(".weight")]):      # a 4-bit Linear: dequantised once
+                return Qz.dequantize_bf16(Qz.take(W, name[: -len(".weight")]), dev)
             return W[name].to(device=dev, dtype=bf)
 
         wp = torch.zeros(E, self.patch_k, dtype=bf, device=dev)

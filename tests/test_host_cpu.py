@@ -502,3 +502,26 @@ def test_generate_step_rejects_unbuilt_options():
                dict(logits_processors=[lambda t, l: l])):
         with pytest.raises(NotImplementedError):
             next(generate_step(ids, None, None, None, max_tokens=2, **kw))
+
+
+def test_dp_batch_generate_carries_model_specific_request_fields(monkeypatch):
+    """A request's fields besides input_ids / pixel_values / image_grid_thw / max_tokens (phi3_v: image_sizes, idefics2:
+    pixel_attention_mask) travel to the per-rank generator as `extras`, in the order the rank serves its requests."""
+    from mlx_vlm_amd import batch, parallel
+
+    seen = {}
+
+    def fake(model, ids, pix, grids, *, max_tokens, stop_ids=(), extras=None, **kw):
+        seen.update(ids=ids, pix=pix, grids=grids, max_tokens=max_tokens, extras=extras)
+        return [[7] * m for m in max_tokens], None
+
+    monkeypatch.setattr(batch, "generate_batch_continuous", fake)
+    reqs = [{"input_ids": np.arange(5), "pixel_values": "pv0", "image_sizes": [[336, 336]], "max_tokens": 2},
+            {"input_ids": np.arange(9)},
+            {"input_ids": np.arange(7), "pixel_values": "pv2", "pixel_attention_mask": "pm2", "image_grid_thw": "g2"}]
+    out = parallel.dp_batch_generate(object(), None, requests=reqs, max_tokens=3)
+    order = parallel.shard_requests(3, 0, 1, [5, 9, 7])
+    assert [len(t) for t in out["tokens"]] == [2, 3, 3]
+    assert seen["extras"] == [{k: v for k, v in reqs[i].items() if k not in parallel._REQUEST_KEYS} for i in order]
+    assert seen["pix"] == [reqs[i].get("pixel_values") for i in order] and seen["grids"] == [reqs[i].get("image_grid_thw") for i in order]
+    assert seen["extras"][order.index(0)] == {"image_sizes": [[336, 336]]} and seen["extras"][order.index(2)] == {"pixel_attention_mask": "pm2"}
