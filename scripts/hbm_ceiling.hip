@@ -138,6 +138,40 @@ int main() {
     }
     printf("decode-step skeleton, hipGraph replay: %.1f us per step = %.0f GB/s = %.1f %% of 8 TB/s\n", best * 1e3f,
            3.102e9 / best / 1e6, 3.102e9 / best / 1e6 / 80.0);
+    // what a coarser launch structure could reach AT BEST (same bytes, plain reads, graph replay): the layer's bytes in 4, 3,
+    // 2 launches and in 1 - upper bounds for designs that merge phases, before any cost of the in-kernel hand-offs they need
+    const size_t L4[4] = {6291456, 458752 + 4718592, 55050240, 27525120};
+    const size_t L3[3] = {6291456 + 458752 + 4718592, 55050240, 27525120};
+    const size_t L2[2] = {6291456 + 458752 + 4718592, 55050240 + 27525120};
+    const size_t L1[1] = {6291456 + 458752 + 4718592 + 55050240 + 27525120};
+    const size_t* variants[4] = {L4, L3, L2, L1};
+    const int counts[4] = {4, 3, 2, 1};
+    for (int v = 0; v < 4; ++v) {
+      hipGraph_t g2;
+      hipGraphExec_t e2;
+      hipStreamBeginCapture(st, hipStreamCaptureModeGlobal);
+      size_t o2 = 0;
+      for (int l = 0; l < 28; ++l)
+        for (int k = 0; k < counts[v]; ++k) {
+          const size_t b = variants[v][k];
+          hipLaunchKernelGGL(read_kernel<8>, dim3(b > 20000000 ? 2048 : 512), dim3(256), 0, st, a + o2 / 16, b / 16, out);
+          o2 += b;
+        }
+      hipLaunchKernelGGL(read_kernel<8>, dim3(2048), dim3(256), 0, st, a + o2 / 16, (size_t)466747392 / 16, out);
+      hipStreamEndCapture(st, &g2);
+      hipGraphInstantiate(&e2, g2, nullptr, nullptr, 0);
+      float b2 = 1e30f;
+      for (int rep = 0; rep < 6; ++rep) {
+        hipEventRecord(e0, st);
+        for (int r = 0; r < 4; ++r) hipGraphLaunch(e2, st);
+        hipEventRecord(e1, st);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        b2 = fminf(b2, ms / 4);
+      }
+      printf("  %d launch(es) per layer: %.1f us per step = %.1f %% of 8 TB/s\n", counts[v], b2 * 1e3f, 3.102e9 / b2 / 1e6 / 80.0);
+    }
   }
   return 0;
 }
