@@ -187,6 +187,19 @@ int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, const void*
                           int max_pages, const void* kv_len, int kv_len_add, int B, int Hq, int Hkv, int D,
                           float scale, int nsplit, void* part_o, void* part_ml, void* out, int ldo, void* stream);
 
+/* The same op (base.py:366-373 at L == 1) in its page-split form, the one the decode engine uses for up to 64
+ * (sequence, kv head) pairs: nsplit one-wave workgroups per (sequence, kv head), workgroup s walks pages s, s + nsplit,
+ * ... - one 64-token page (32 KB of K + V) is the whole load of a compute unit, so a context is pulled through
+ * min(pages, nsplit) CUs per kv head instead of one - and the LAST workgroup to arrive (one agent-scope ticket per
+ * (sequence, kv head)) merges the partials and writes out [B][Hq*D] (bf16): one launch, no merge pass, no merge in the
+ * o_proj prologue.  part_o fp32 [B*Hkv][nsplit][Hq/Hkv][D] and part_ml fp32 [B*Hkv][nsplit][Hq/Hkv][2] are scratch
+ * (same sizes as vlm_attn_decode_paged's); tickets: uint32 [B*Hkv], ZERO before the first launch - every launch leaves
+ * it zero again.  Launches that share part_o / part_ml / tickets must be stream-ordered. */
+int vlm_attn_decode_paged_split(const void* q, int ldq, const void* kpool, const void* vpool, const void* block_table,
+                                int max_pages, const void* kv_len, int kv_len_add, int B, int Hq, int Hkv, int D,
+                                float scale, int nsplit, void* part_o, void* part_ml, void* tickets, void* out, int ldo,
+                                void* stream);
+
 /* nn.Embedding (language.py:164,179): out[t] = table[ids[t]] */
 int vlm_embed_gather(const void* ids, const void* table, void* out, int T, int D, int ldo, int vocab, void* stream);
 
@@ -359,6 +372,12 @@ int vlm_llm_decode_launches(void* handle);
                                        a supported shape, otherwise the step silently keeps the three launches */
 #define VLM_TUNE_MFMA_GEMV 6        /* 1 (default): decode steps of 3..16 rows run their projections on the matrix cores
                                        (csrc/gemv_mfma.hip); 0: the v_dot2c GEMVs (rows in {4, 8}) - A/B knob */
+#define VLM_TUNE_ATTN_PAGESPLIT 7   /* decode attention of steps with at most 64 (row, kv head) pairs: N > 0 (default 16) = the
+                                       page-split form (vlm_attn_decode_paged_split) with up to N workgroups per pair (32 when
+                                       the caller asked for a split, i.e. a long context); 0 = the round-2 forms (one workgroup
+                                       per pair, or split-K partials merged in the o_proj prologue) - A/B knob */
+#define VLM_TUNE_GEMV_VARIANT 8     /* A/B knob of the batch-1 GEMV launch shapes (bit 0: down projection with 6 rows per
+                                       workgroup = one workgroup per CU at N = 1536) */
 int vlm_llm_set_tuning(void* handle, int key, int value);
 int vlm_llm_get_tuning(void* handle, int key);
 /* diagnostic of the in-launch hand-offs (VLM_TUNE_FUSED_MLP): 0 = every bounded wait completed since the last call;

@@ -240,6 +240,215 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
     __hip_atomic_store(prog.word, prog.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Page-split form: ONE wave (= one workgroup) per (sequence, kv head, page stride), S workgroups per (sequence, kv head),
+// the LAST workgroup to arrive merges the partials and writes the final bf16 vector - no second launch, no merge in the
+// o_proj prologue.
+//
+// Why (round-2 profile, profiles/r02_attn_decode_timeline.txt): the one-workgroup-per-kv-head form pulls a kv head's
+// whole context (0.3 MB at 600 tokens) through ONE compute unit's vector-memory path - "kv-issued" grew with the bytes,
+// 2.9 us at ctx 300, 5.8 us at ctx 600 - and ran on 2 of 256 CUs.  Here a page's 32 KB is the whole load of a CU, so
+// the K/V arrival time is one memory round trip whatever the context, and the pages of a context are spread over
+// S * Hkv CUs.  A workgroup walks pages s, s + S, s + 2S, ... (interleaved, so a short context still uses every
+// workgroup that has a page).
+// Hand-off (cdna_hip_programming.md Guideline 16, R1 form): partials (O^T registers -> [bh][s][head][d] fp32, m / l)
+// leave with write-through (sc1) stores, every storing wave drains them (s_waitcnt vmcnt(0)), then ONE returning
+// agent-scope atomic takes a ticket; the workgroup that draws S - 1 reads the partials back with sc1 loads (the
+// producers stored sc1: no acquire fence needed), merges in fp32, stores bf16 and re-arms the ticket word (every
+// workgroup has arrived by then).  Workgroups whose first page lies beyond the context store nothing and only arrive.
+// tickets: one zero-initialised word per (sequence, kv head), owned by the caller, zero again after every launch.
+template <int G, bool IDENT>
+__global__ __launch_bounds__(64) void attn_decode_pagesplit_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ kpool, const bf16_t* __restrict__ vpool,
+    const int* __restrict__ block_table, const int* __restrict__ kv_len, int ldq, int max_pages, int Hkv, int kv_len_add,
+    float scale_log2, int S, int ldo, float* part_o, float* part_ml, unsigned* tickets, bf16_t* __restrict__ out) {
+  const int bh = blockIdx.x, b = bh / Hkv, g = bh % Hkv, s = blockIdx.y;
+  const int lane = threadIdx.x, head = lane & 15, gq = lane >> 4;
+  // every kernel argument in ONE scalar-load batch at entry (the tail's arguments would otherwise be fetched lazily,
+  // one more round trip on the path to the ticket)
+  asm volatile("" ::"s"(part_o), "s"(part_ml), "s"(tickets), "s"(out), "s"(S), "s"(ldo));
+  int pi = s;
+  const int* trow = IDENT ? nullptr : block_table + (size_t)b * max_pages;
+  size_t page = IDENT ? (size_t)b * max_pages + min(pi, max_pages - 1) : (size_t)trow[min(pi, max_pages - 1)];
+  int len_raw;
+  asm volatile("global_load_dword %0, %1, off" : "=v"(len_raw) : "v"(kv_len + b) : "memory");
+  bf16x8_t qf[4];
+  {
+    const bf16_t* qr = q + (size_t)b * ldq + (size_t)(g * G + min(head, G - 1)) * HD + 8 * gq;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) qf[ds] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(qr + 32 * ds));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4_t ot[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ot[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  int len = 0, npages = 0;
+  do {
+    if (!IDENT) asm volatile("s_waitcnt vmcnt(0)" : "+v"(len_raw), "+v"(page)::"memory");
+    const bf16_t* kp = kpool + (page * Hkv + g) * (size_t)(HD / 8) * PAGE * 8 + ((size_t)gq * PAGE + head) * 8;
+    const bf16_t* vp = vpool + (page * Hkv + g) * (size_t)HD * PAGE + (size_t)head * PAGE + 8 * gq;
+    u32x4_t kf[4][4], vf[8][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds)
+        kf[t][ds] = *reinterpret_cast<const u32x4_t*>(kp + ((size_t)(4 * ds) * PAGE + 16 * t) * 8);
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        vf[dt][u] = *reinterpret_cast<const u32x4_t*>(vp + (size_t)(16 * dt) * PAGE + 32 * u);
+    const int pc = pi;     // the page being processed
+    pi += S;
+    const size_t next_page = IDENT ? (size_t)b * max_pages + min(pi, max_pages - 1) : (size_t)trow[min(pi, max_pages - 1)];
+    __builtin_amdgcn_sched_barrier(0);
+    if (!IDENT) {
+      len = __builtin_amdgcn_readfirstlane(len_raw) + kv_len_add;
+      npages = (len + PAGE - 1) / PAGE;
+    }
+    f32x4_t st[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      st[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds)
+        st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[t][ds]), qf[ds], st[t], 0, 0, 0);
+    }
+    if (IDENT) {
+      asm volatile("s_waitcnt vmcnt(16)" : "+v"(len_raw)::"memory");
+      len = __builtin_amdgcn_readfirstlane(len_raw) + kv_len_add;
+      npages = (len + PAGE - 1) / PAGE;
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = pc * PAGE + 16 * t + 4 * gq + r;
+        const float sv = key < len ? st[t][r] * scale_log2 : -INFINITY;
+        st[t][r] = sv;
+        mt = fmaxf(mt, sv);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = exp2f(m_run - m_use);
+    float ls = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = exp2f(st[t][r] - m_use);
+        st[t][r] = p;
+        ls += p;
+      }
+    l_run = l_run * alpha + ls;
+    m_run = m_new;
+    bf16x8_t pb[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const u32x4_t pk = {pack_bf2(st[2 * u][0], st[2 * u][1]), pack_bf2(st[2 * u][2], st[2 * u][3]),
+                          pack_bf2(st[2 * u + 1][0], st[2 * u + 1][1]), pack_bf2(st[2 * u + 1][2], st[2 * u + 1][3])};
+      pb[u] = __builtin_bit_cast(bf16x8_t, pk);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        u32x4_t vv = vf[dt][u];
+        const int k0 = pc * PAGE + 32 * u + 4 * gq, k1 = k0 + 16;
+        vv[0] = (k0 + 1 < len) ? vv[0] : ((k0 < len) ? (vv[0] & 0xffffu) : 0u);
+        vv[1] = (k0 + 3 < len) ? vv[1] : ((k0 + 2 < len) ? (vv[1] & 0xffffu) : 0u);
+        vv[2] = (k1 + 1 < len) ? vv[2] : ((k1 < len) ? (vv[2] & 0xffffu) : 0u);
+        vv[3] = (k1 + 3 < len) ? vv[3] : ((k1 + 2 < len) ? (vv[3] & 0xffffu) : 0u);
+        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pb[u], ot[dt], 0, 0, 0);
+      }
+    }
+    if (pi >= npages) break;
+    page = next_page;
+  } while (true);
+
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  const int n_act = min(S, npages);                // splits that own at least one page of this context
+  const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(part_o, 0, 0x7fffffff, 0x00020000);   // (offsets checked by the launcher)
+  typedef unsigned long long u64;
+  if (s < n_act && head < G) {
+    const int o0 = (((bh * S + s) * G + head) * HD + 4 * gq) * 4;                       // byte offset of d = 4 gq
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ot[dt]), rs_o, o0 + 64 * dt, 0, 16);   // aux 16 = sc1
+    if (gq == 0)
+      __hip_atomic_store(reinterpret_cast<u64*>(part_ml) + ((size_t)bh * S + s) * G + head,
+                         ((u64)__float_as_uint(l_run) << 32) | __float_as_uint(m_run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      // every storing wave drains (R1)
+  unsigned tk = 0;
+  if (lane == 0) tk = __hip_atomic_fetch_add(tickets + bh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tk = __builtin_amdgcn_readfirstlane(tk);
+  if (tk != (unsigned)S - 1u) return;
+
+  // ---- last arriver: out[head][d] = sum_s f_s O_s[head][d] / sum_s f_s l_s,  f_s = 2^(m_s - M)
+  constexpr int NJ = (G + 1) / 2;                  // float4 items per lane: G * 32 items over 64 lanes
+  constexpr int CH = 8;                            // splits per pass (all loads of a pass in flight together)
+  float M[NJ], L[NJ];
+  f32x4_t acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) { M[j] = -INFINITY; L[j] = 0.f; acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  for (int c0 = 0; c0 < n_act; c0 += CH) {
+    u64 ml[CH][NJ];
+    u32x4_t o[CH][NJ];
+#pragma unroll
+    for (int sp = 0; sp < CH; ++sp) {
+      const int spc = min(c0 + sp, n_act - 1);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int item = min(lane + 64 * j, G * 32 - 1);
+        ml[sp][j] = __hip_atomic_load(reinterpret_cast<const u64*>(part_ml) + ((size_t)bh * S + spc) * G + (item >> 5),
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        o[sp][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_o, ((bh * S + spc) * G * HD + item * 4) * 4, 0, 16);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);             // every load of the pass is issued before the first use waits
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      float mc = -INFINITY;
+#pragma unroll
+      for (int sp = 0; sp < CH; ++sp) mc = fmaxf(mc, (c0 + sp < n_act) ? __uint_as_float((unsigned)ml[sp][j]) : -INFINITY);
+      const float mn = fmaxf(M[j], mc);             // finite: every split < n_act holds at least one valid key
+      const float a = exp2f(M[j] - mn);
+      L[j] *= a;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[j][r] *= a;
+#pragma unroll
+      for (int sp = 0; sp < CH; ++sp) {
+        const float f = (c0 + sp < n_act) ? exp2f(__uint_as_float((unsigned)ml[sp][j]) - mn) : 0.f;
+        L[j] += f * __uint_as_float((unsigned)(ml[sp][j] >> 32));
+        const f32x4_t ov = __builtin_bit_cast(f32x4_t, o[sp][j]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r] += f * ov[r];
+      }
+      M[j] = mn;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int item = lane + 64 * j;
+    if (item < G * 32) {
+      const float il = 1.0f / L[j];
+      uint2 w;
+      w.x = pack_bf2(acc[j][0] * il, acc[j][1] * il);
+      w.y = pack_bf2(acc[j][2] * il, acc[j][3] * il);
+      *reinterpret_cast<uint2*>(out + (size_t)b * ldo + (size_t)(g * G + (item >> 5)) * HD + 4 * (item & 31)) = w;
+    }
+  }
+  if (lane == 0) __hip_atomic_store(tickets + bh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+}
+
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ part_o,
                                                                   const float* __restrict__ part_ml, int nsplit,
                                                                   bf16_t* __restrict__ out, int ldo, int Hq) {
@@ -319,4 +528,42 @@ extern "C" int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, 
                                      void* out, int ldo, void* stream) {
   return vlm_attn_decode_paged_ex(q, ldq, kpool, vpool, block_table, max_pages, kv_len, kv_len_add, B, Hq, Hkv, D, scale,
                                   nsplit, part_o, part_ml, out, ldo, VlmProgress{nullptr, 0}, stream);
+}
+
+extern "C" int vlm_attn_decode_paged_split(const void* q, int ldq, const void* kpool, const void* vpool,
+                                           const void* block_table, int max_pages, const void* kv_len, int kv_len_add, int B,
+                                           int Hq, int Hkv, int D, float scale, int nsplit, void* part_o, void* part_ml,
+                                           void* tickets, void* out, int ldo, void* stream) {
+  if (!q || !kpool || !vpool || !kv_len || !part_o || !part_ml || !tickets || !out || max_pages <= 0) return VLM_ERR_ARG;
+  if (B <= 0 || Hq <= 0 || Hkv <= 0 || nsplit <= 0 || nsplit > 65535 || Hq % Hkv != 0) return VLM_ERR_ARG;
+  if (D != HD || ldq % 8 != 0 || ldo % 4 != 0) return VLM_ERR_SHAPE;
+  if ((size_t)B * Hq * nsplit * HD * 4 >= ((size_t)1 << 31)) return VLM_ERR_SHAPE;   // 32-bit buffer offsets
+  const int G = Hq / Hkv;
+  hipStream_t st = (hipStream_t)stream;
+  const float sl2 = scale * 1.44269504088896340736f;
+  dim3 grid(B * Hkv, nsplit);
+#define GO(GV)                                                                                                           \
+  if (!block_table)                                                                                                      \
+    hipLaunchKernelGGL((attn_decode_pagesplit_kernel<GV, true>), grid, dim3(64), 0, st, (const bf16_t*)q,                \
+                       (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)nullptr, (const int*)kv_len, ldq, max_pages, \
+                       Hkv, kv_len_add, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, (unsigned*)tickets, (bf16_t*)out); \
+  else                                                                                                                   \
+    hipLaunchKernelGGL((attn_decode_pagesplit_kernel<GV, false>), grid, dim3(64), 0, st, (const bf16_t*)q,               \
+                       (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)block_table, (const int*)kv_len, ldq,       \
+                       max_pages, Hkv, kv_len_add, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, (unsigned*)tickets,  \
+                       (bf16_t*)out)
+  switch (G) {
+    case 1: GO(1); break;
+    case 2: GO(2); break;
+    case 3: GO(3); break;
+    case 4: GO(4); break;
+    case 5: GO(5); break;
+    case 6: GO(6); break;
+    case 7: GO(7); break;
+    case 8: GO(8); break;
+    default: return VLM_ERR_SHAPE;
+  }
+#undef GO
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
 }

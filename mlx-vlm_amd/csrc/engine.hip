@@ -47,6 +47,8 @@ constexpr size_t MAX_DECODE_GRAPHS = 16;
 // defaults: off until DESIGN.md's measurement picks them (vlm_llm_set_tuning)
 struct Tuning {
   int prefetch = 0, wgs = 256, mask = 0x7f, head_mb = 96, debug_skip = 0, fused_mlp = 0, mfma_gemv = 1;
+  int attn_pagesplit = 16;                // vlm_attn_decode_paged_split with up to this many workgroups per (row, kv head)
+  int gemv_variant = 0;                   // A/B bits of the batch-1 GEMV launch shapes (VLM_TUNE_GEMV_VARIANT)
 };
 
 // the second branch of a captured step (prefetch side chain)
@@ -61,6 +63,7 @@ struct Llm {
   Tuning tune;
   int* progress = nullptr;                // [0] pacing word, [1] exit counter of the persistent prefetcher (device)
   void* mfma_ws = nullptr;                // split-K partial tiles + tickets of the skinny-M decode GEMM (gemv_mfma.hip)
+  unsigned* attn_tickets = nullptr;       // [64] arrival words of the page-split decode attention (zero between launches)
   void* wscratch = nullptr;               // bf16 scratch for the prefill GEMMs over 4-bit weights (largest matrix)
   size_t wscratch_bytes = 0;
   char* fm_buf = nullptr;                 // fused-MLP hand-off buffers: [256 B err] then per layer [256 B epoch | D granules | I granules]
@@ -113,7 +116,7 @@ inline char* off(void* p, size_t bytes) { return static_cast<char*>(p) + bytes; 
 
 }  // namespace
 
-extern "C" int vlm_abi_version(void) { return 3; }
+extern "C" int vlm_abi_version(void) { return 4; }
 
 // ------------------------------------------------------------------ LLM
 extern "C" int vlm_llm_create(const vlm_llm_config* cfg, void** handle) {
@@ -133,6 +136,12 @@ extern "C" int vlm_llm_create(const vlm_llm_config* cfg, void** handle) {
     delete m;
     return 1012;
   }
+  if (hipMalloc((void**)&m->attn_tickets, 64 * sizeof(unsigned)) != hipSuccess) {
+    m->attn_tickets = nullptr;            // (no device: the page-split form is then not taken)
+    (void)hipGetLastError();
+  } else if (hipMemset(m->attn_tickets, 0, 64 * sizeof(unsigned)) != hipSuccess) {
+    return 1013;
+  }
   *handle = m;
   return 0;
 }
@@ -145,6 +154,7 @@ extern "C" int vlm_llm_destroy(void* handle) {
   if (m->fm_buf) (void)hipFree(m->fm_buf);
   if (m->wscratch) (void)hipFree(m->wscratch);
   if (m->mfma_ws) (void)hipFree(m->mfma_ws);
+  if (m->attn_tickets) (void)hipFree(m->attn_tickets);
   delete m;
   return 0;
 }
@@ -160,6 +170,8 @@ extern "C" int vlm_llm_set_tuning(void* handle, int key, int value) {
     case VLM_TUNE_PREFETCH_HEAD_MB: if (value < 0) return 1; slot = &m->tune.head_mb; break;
     case VLM_TUNE_DEBUG_SKIP: slot = &m->tune.debug_skip; break;
     case VLM_TUNE_MFMA_GEMV: if (value < 0 || value > 1) return 1; slot = &m->tune.mfma_gemv; break;
+    case VLM_TUNE_ATTN_PAGESPLIT: if (value < 0 || value > 32) return 1; slot = &m->tune.attn_pagesplit; break;
+    case VLM_TUNE_GEMV_VARIANT: if (value < 0) return 1; slot = &m->tune.gemv_variant; break;
     case VLM_TUNE_FUSED_MLP: {
       if (value < 0 || value > 1) return 1;
       slot = &m->tune.fused_mlp;
@@ -183,6 +195,7 @@ extern "C" int vlm_llm_set_tuning(void* handle, int key, int value) {
     }
     default: return 1;
   }
+  if (key == VLM_TUNE_GEMV_VARIANT) vlm_gemv_set_variant(value);
   if (*slot == value) return 0;
   *slot = value;
   for (DecodeGraph& g : m->graphs) drop_graph(g);     // the captured steps bake the tuning in
@@ -221,6 +234,8 @@ extern "C" int vlm_llm_get_tuning(void* handle, int key) {
     case VLM_TUNE_DEBUG_SKIP: return m->tune.debug_skip;
     case VLM_TUNE_FUSED_MLP: return m->tune.fused_mlp;
     case VLM_TUNE_MFMA_GEMV: return m->tune.mfma_gemv;
+    case VLM_TUNE_ATTN_PAGESPLIT: return m->tune.attn_pagesplit;
+    case VLM_TUNE_GEMV_VARIANT: return m->tune.gemv_variant;
     default: return -1;
   }
 }
@@ -415,7 +430,18 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
     // attention over the pages (the new token is already in the cache: kv_len = ctx + 1)
     const bool combine = w.wo_sb != nullptr || Hq * hd > 3584;
     const VlmProgress prog{pf == 2 ? m->progress : nullptr, i + 1};
+    // few (row, kv head) pairs: the page-split form - one wave per page stride over up to 256 CUs, the last arriver
+    // writes the final vector (part_o / part_ml are sized for 32 splits by the caller)
+    int psplit = 0;
+    if (tn.attn_pagesplit > 0 && m->attn_tickets && B * Hkv <= 64 && pf != 2) {
+      psplit = a->nsplit > 1 ? 32 : tn.attn_pagesplit;
+      if (psplit > 256 / (B * Hkv)) psplit = 256 / (B * Hkv);
+      if (psplit < 2) psplit = 0;
+    }
     if (skip & 2) {
+    } else if (psplit) {
+      TRY(vlm_attn_decode_paged_split(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale,
+                                      psplit, a->part_o, a->part_ml, m->attn_tickets, a->attn, Hq * hd, stream)); ++n;
     } else if (a->nsplit == 1) {
       // short contexts: one workgroup per (sequence, kv head) -> final bf16 vector, plain o_proj GEMV + residual
       TRY(vlm_attn_decode_paged_ex(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale, 1,
@@ -438,7 +464,7 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
         TRY(vlm_prefetch_launch(&it, &pfkv, tn.wgs, fork->side)); ++n;
       }
     }
-    const bool fused_mlp = tn.fused_mlp && m->fm_buf && B == 1 && a->nsplit == 1 && !(skip & (4 | 8 | 16)) && !w.wo_sb &&
+    const bool fused_mlp = tn.fused_mlp && m->fm_buf && B == 1 && (psplit || a->nsplit == 1) && !(skip & (4 | 8 | 16)) && !w.wo_sb &&
                            !w.wgu_sb && !w.wdown_sb;
     if (fused_mlp) {
       // o_proj + residual, RMSNorm + gate/up + SwiGLU, down + residual: one launch, two in-launch hand-offs
@@ -453,7 +479,7 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
       continue;
     }
     if (skip & 4) {
-    } else if (a->nsplit == 1 || combine) {
+    } else if (psplit || a->nsplit == 1 || combine) {
       TRY(lin_gemv(m, a->attn, w.wo, w.wo_sb, nullptr, a->h, nullptr, a->h, B, D, Hq * hd, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
     } else {
       TRY(vlm_gemv_attn_out(a->part_o, a->part_ml, a->nsplit, w.wo, a->h, D, B, D, Hq, hd, stream)); ++n;

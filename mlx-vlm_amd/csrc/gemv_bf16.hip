@@ -505,10 +505,18 @@ int launch_sk(const Args& a) {
   return launch_err();
 }
 
+int g_gemv_variant = 0;   // A/B bits (VLM_TUNE_GEMV_VARIANT)
+
 template <int MB, int EPI>
 int launch_sk_k(const Args& a) {
   const int ni = vlm_cdiv(a.K, 2048);
   if (MB <= 2) {
+    // N = 1536 rows over 256 CUs: 4 rows per workgroup = 384 workgroups = 1.5 per CU (half the CUs stream 143 KB, half
+    // 72 KB: the launch ends with the loaded half); 6 rows = ONE 107 KB workgroup per CU, 3 rows = two per CU
+    if constexpr (MB == 1) {
+      if (ni <= 5 && (g_gemv_variant & 1) && a.N % 6 == 0) return launch_sk<6, 5, MB, EPI>(a);
+      if (ni <= 5 && (g_gemv_variant & 2) && a.N % 3 == 0) return launch_sk<3, 5, MB, EPI>(a);
+    }
     if (ni <= 5) return launch_sk<4, 5, MB, EPI>(a);
     if (ni <= 10) return launch_sk<2, 10, MB, EPI>(a);
   } else {
@@ -530,6 +538,8 @@ int launch_sk_m(int M, const Args& a) {
 }
 
 }  // namespace
+
+VLM_INTERNAL void vlm_gemv_set_variant(int bits) { g_gemv_variant = bits; }
 
 extern "C" int vlm_gemv_bf16(const void* x, const void* W, const void* bias, const void* res, const void* norm_w,
                              void* y, int M, int N, int K, int ldx, int ldw, int ldy, int ldres, float eps,

@@ -273,7 +273,7 @@ class LanguageModel:
     # environment overrides for A/B runs): VLM_DECODE_PREFETCH 0 / 1 (event-paced side branch) / 2 (persistent side
     # kernel), VLM_DECODE_PREFETCH_MASK, VLM_DECODE_PREFETCH_WGS, VLM_DECODE_FUSED_TAIL 0 / 1
     TUNING_DEFAULTS = {"prefetch": 0, "prefetch_wgs": 256, "prefetch_mask": 0x7f, "prefetch_head_mb": 96, "fused_tail": 1, "mfma_gemv": 1,
-                       "fused_mlp": 0}
+                       "fused_mlp": 0, "attn_pagesplit": 16, "gemv_variant": 0}
 
     def apply_tuning(self, **over):
         L = _lib.lib()
@@ -286,7 +286,8 @@ class LanguageModel:
         self.tuning = t
         for key, name in ((_lib.TUNE_PREFETCH, "prefetch"), (_lib.TUNE_PREFETCH_WGS, "prefetch_wgs"),
                           (_lib.TUNE_PREFETCH_MASK, "prefetch_mask"), (_lib.TUNE_PREFETCH_HEAD_MB, "prefetch_head_mb"),
-                          (_lib.TUNE_FUSED_MLP, "fused_mlp"), (_lib.TUNE_MFMA_GEMV, "mfma_gemv")):
+                          (_lib.TUNE_FUSED_MLP, "fused_mlp"), (_lib.TUNE_MFMA_GEMV, "mfma_gemv"),
+                          (_lib.TUNE_ATTN_PAGESPLIT, "attn_pagesplit"), (_lib.TUNE_GEMV_VARIANT, "gemv_variant")):
             check(L.vlm_llm_set_tuning(self._handle, key, int(t[name])), "llm_set_tuning")
         for st in getattr(self, "_decode_states", {}).values():
             st.graph_key = None          # the engine dropped its captured steps
@@ -672,7 +673,8 @@ class LanguageModel:
         caches = [cache] if isinstance(cache[0], KVCache) else cache
         cache_offset = caches[0][0].offset
 
-        if Lq == 1 and cache_offset > 0 and inputs_embeds is None and B in (1, 2, 4, 8):
+        # decode widths of the engine: 1 / 2 / 4 / 8 rows on the v_dot2c GEMVs, 9..16 rows on the skinny-M MFMA GEMM
+        if Lq == 1 and cache_offset > 0 and inputs_embeds is None and (B in (1, 2, 4, 8) or 9 <= B <= 16):
             # decode: pos = cache offset + rope delta (language.py:476-509); logits only
             deltas = self._rope_deltas if self._rope_deltas is not None else np.zeros((B, 1), dtype=np.int64)
             deltas = np.broadcast_to(np.asarray(deltas).reshape(-1, 1), (B, 1)) if np.asarray(deltas).size == 1 else deltas

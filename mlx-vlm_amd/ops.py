@@ -217,6 +217,25 @@ def attn_decode_paged(q, kpool, vpool, block_table, kv_len, kv_len_add, Hq, Hkv,
     return out if merge else (part_o, part_ml)
 
 
+def attn_decode_paged_split(q, kpool, vpool, block_table, kv_len, kv_len_add, Hq, Hkv, D, scale, nsplit, out=None,
+                            max_pages=None, tickets=None):
+    """page-split decode attention (one wave per page stride, last arriver merges) -> bf16 [B, Hq*D]"""
+    _dev(q, kpool, vpool, block_table, kv_len)
+    B = q.shape[0]
+    part_o = torch.empty(B, Hq, nsplit, D, dtype=torch.float32, device=q.device)
+    part_ml = torch.empty(B, Hq, nsplit, 2, dtype=torch.float32, device=q.device)
+    if tickets is None:
+        tickets = torch.zeros(B * Hkv, dtype=torch.int32, device=q.device)
+    if out is None:
+        out = torch.empty(B, Hq * D, dtype=torch.bfloat16, device=q.device)
+    check(_lib.lib().vlm_attn_decode_paged_split(_p(q), q.stride(0), _p(kpool), _p(vpool), _p(block_table),
+                                                 block_table.shape[1] if block_table is not None else int(max_pages),
+                                                 _p(kv_len), kv_len_add, B, Hq, Hkv, D, scale, nsplit, _p(part_o),
+                                                 _p(part_ml), _p(tickets), _p(out), out.stride(0), _stream()),
+          "attn_decode_split")
+    return out
+
+
 def embed_gather(ids, table, out=None):
     _dev(ids, table)
     T = ids.numel()

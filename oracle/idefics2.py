@@ -22,6 +22,7 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
 
+import math
 import numpy as np
 import torch
 
@@ -97,12 +98,18 @@ PR = "connector.perceiver_resampler."
 LM = "language_model."
 
 
-def random_weights(cfg: Cfg, seed: int = 0, dtype=torch.bfloat16, std: float = 0.05, embed_std: float = 0.2) -> Dict[str, torch.Tensor]:
+def random_weights(cfg: Cfg, seed: int = 0, dtype=torch.bfloat16, std: float = 0.05, embed_std: float = 0.2,
+                   fast: bool = False) -> Dict[str, torch.Tensor]:
     """Seeded weights under the reference's (sanitized) names; patch weight (O, kH, kW, C)."""
     g = torch.Generator().manual_seed(seed)
     v, t, p = cfg.vision, cfg.text, cfg.perceiver
 
+    n_fast = [0]
+
     def rn(*shape, s=std):
+        if fast and math.prod(shape) >= (1 << 20):      # big matrices: threaded Philox streams (ops.fast_normal)
+            n_fast[0] += 1
+            return ops.fast_normal(shape, (seed, n_fast[0]), s, dtype)
         return (torch.randn(*shape, generator=g) * s).to(dtype)
 
     def nw(dim):

@@ -405,3 +405,66 @@ def categorical_gumbel(logprobs, temp: float, seed: int, step: int, row: int = 0
     g = -np.log(-np.log(u.astype(np.float32))).astype(np.float32)
     z = (x + g).astype(np.float32)
     return int(np.argmax(z))
+
+
+# ---------------------------------------------------------------------------------------------- synthetic weights
+_NORMAL_POOL = []
+_SCALED_POOLS = {}
+
+
+def _normal_pool() -> torch.Tensor:
+    """2^26 N(0, 1) floats, drawn once per process from numpy SFC64 streams (one per 4 Mi block, thread pool)."""
+    if _NORMAL_POOL:
+        return _NORMAL_POOL[0]
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    import numpy as np
+
+    n, BLK = 1 << 26, 1 << 22
+    buf = np.empty(n, dtype=np.float32)
+
+    def fill(i):                                    # pure numpy: the GIL is released while drawing
+        rng = np.random.Generator(np.random.SFC64(np.random.SeedSequence([0xC0FFEE, i])))
+        rng.standard_normal(BLK, dtype=np.float32, out=buf[i * BLK:(i + 1) * BLK])
+
+    try:
+        workers = len(os.sched_getaffinity(0))
+    except AttributeError:
+        workers = os.cpu_count() or 1
+    with ThreadPoolExecutor(max_workers=max(1, min(16, workers))) as ex:
+        list(ex.map(fill, range(n // BLK)))
+    _NORMAL_POOL.append(torch.from_numpy(buf))
+    return _NORMAL_POOL[0]
+
+
+def fast_normal(shape, seed, std: float, dtype=torch.bfloat16) -> torch.Tensor:
+    """N(0, std^2) values for the BIG tensors of a full-size synthetic checkpoint (test infrastructure: 7-8 B parameters
+    through torch.randn's single-threaded generator take two minutes per model on the GPU box's clock).  Every tensor is
+    a run of windows of ONE 2^26-element normal pool, starting at an offset hashed from `seed` (an int or a tuple of
+    ints) and jumping by a prime at every wrap, scaled and rounded per tensor - deterministic, seconds per model.
+    Tensors therefore share values at different alignments; rows, layers and matrices still all differ, which is what
+    a parity test needs (the oracle and the engine read the same checkpoint)."""
+    pool = _normal_pool()
+    P = pool.numel()
+    n = 1
+    for d in shape:
+        n *= int(d)
+    key = list(seed) if isinstance(seed, (tuple, list)) else [int(seed)]
+    h = 0x9E3779B97F4A7C15
+    for k in key:
+        h = ((h ^ (int(k) & 0xFFFFFFFFFFFFFFFF)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        h ^= h >> 31
+    off = h % P
+    sk = (float(std), dtype)
+    if sk not in _SCALED_POOLS:                    # the pool at this scale and dtype, once: tensors are then plain copies
+        _SCALED_POOLS[sk] = (pool * float(std)).to(dtype)
+    sp = _SCALED_POOLS[sk]
+    out = torch.empty(n, dtype=dtype)
+    pos = 0
+    while pos < n:
+        take = min(n - pos, P - off)
+        out[pos:pos + take].copy_(sp[off:off + take])
+        pos += take
+        off = (off + take + 1000003) % P
+    return out.reshape(*shape)

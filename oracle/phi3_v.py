@@ -108,12 +108,18 @@ VT = "model.vision_embed_tokens."
 CLIP = VT + "img_processor.vision_model."
 
 
-def random_weights(cfg: Cfg, seed: int = 0, dtype=torch.bfloat16, std: float = 0.05, embed_std: float = 0.2) -> Dict[str, torch.Tensor]:
+def random_weights(cfg: Cfg, seed: int = 0, dtype=torch.bfloat16, std: float = 0.05, embed_std: float = 0.2,
+                   fast: bool = False) -> Dict[str, torch.Tensor]:
     """Seeded weights under the reference's names (patch weight (O, kH, kW, C), as `VisionModel.sanitize` leaves it)."""
     g = torch.Generator().manual_seed(seed)
     v, t = cfg.vision, cfg.text
 
+    n_fast = [0]
+
     def rn(*shape, s=std):
+        if fast and math.prod(shape) >= (1 << 20):      # big matrices: threaded Philox streams (ops.fast_normal)
+            n_fast[0] += 1
+            return ops.fast_normal(shape, (seed, n_fast[0]), s, dtype)
         return (torch.randn(*shape, generator=g) * s).to(dtype)
 
     def ln(prefix, dim):

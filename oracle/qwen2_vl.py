@@ -10,6 +10,7 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
+import math
 import numpy as np
 import torch
 
@@ -74,13 +75,18 @@ def tiny_cfg(**over) -> Cfg:
 
 
 def random_weights(cfg: Cfg, seed: int = 0, dtype=torch.bfloat16, std: float = 0.02,
-                   embed_std: Optional[float] = None) -> Dict[str, torch.Tensor]:
+                   embed_std: Optional[float] = None, fast: bool = False) -> Dict[str, torch.Tensor]:
     """Synthetic checkpoint: Linear/Embedding ~ N(0, std^2),
     norm weights 1 (+small noise so they are exercised), biases small noise."""
     g = torch.Generator().manual_seed(seed)
     W: Dict[str, torch.Tensor] = {}
 
+    n_fast = [0]
+
     def rn(*shape, s=std):
+        if fast and math.prod(shape) >= (1 << 20):      # big matrices: threaded Philox streams (ops.fast_normal)
+            n_fast[0] += 1
+            return ops.fast_normal(shape, (seed, n_fast[0]), s, dtype)
         return (torch.randn(*shape, generator=g) * s).to(dtype)
 
     v, t = cfg.vision, cfg.text

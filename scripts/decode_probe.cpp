@@ -203,10 +203,10 @@ static void reset_state(const Model& m, State& s, int ctx0, hipStream_t st) {
 }
 
 struct Variant {
-  int pf = 0, wgs = 256, mask = 0x7f, flags = 0, headmb = 96, skip = 0, fmlp = 0;
+  int pf = 0, wgs = 256, mask = 0x7f, flags = 0, headmb = 96, skip = 0, fmlp = 0, psplit = 16, gv = 0;
   std::string name() const {
-    char b[128];
-    snprintf(b, sizeof b, "pf=%d wgs=%d mask=0x%02x flags=%d headmb=%d skip=0x%02x fmlp=%d", pf, wgs, mask, flags, headmb, skip, fmlp);
+    char b[160];
+    snprintf(b, sizeof b, "pf=%d flags=%d skip=0x%02x fmlp=%d psplit=%d gv=%d", pf, flags, skip, fmlp, psplit, gv);
     return b;
   }
 };
@@ -220,6 +220,8 @@ static double run_variant(const Model& m, State& s, const Variant& v, int ctx0, 
   RC(vlm_llm_set_tuning(m.h, VLM_TUNE_PREFETCH_HEAD_MB, v.headmb));
   RC(vlm_llm_set_tuning(m.h, VLM_TUNE_DEBUG_SKIP, v.skip));
   RC(vlm_llm_set_tuning(m.h, VLM_TUNE_FUSED_MLP, v.fmlp));
+  RC(vlm_llm_set_tuning(m.h, VLM_TUNE_ATTN_PAGESPLIT, v.psplit));
+  RC(vlm_llm_set_tuning(m.h, VLM_TUNE_GEMV_VARIANT, v.gv));
   if (v.fmlp && !vlm_llm_get_tuning(m.h, VLM_TUNE_FUSED_MLP)) printf("   (fused MLP not available on this device / shape)\n");
   s.a.flags = v.flags;
   RC(vlm_llm_set_kv(m.h, &m.kv));
@@ -317,7 +319,7 @@ int main(int argc, char** argv) {
     else if (a == "--block-table") use_table = true;
     else if (a == "--variant" && i + 1 < argc) {
       Variant v;
-      sscanf(argv[++i], "%d,%d,%i,%d,%d,%i,%d", &v.pf, &v.wgs, &v.mask, &v.flags, &v.headmb, &v.skip, &v.fmlp);
+      sscanf(argv[++i], "%d,%d,%i,%d,%d,%i,%d,%d,%i", &v.pf, &v.wgs, &v.mask, &v.flags, &v.headmb, &v.skip, &v.fmlp, &v.psplit, &v.gv);
       variants.push_back(v);
     }
   }
@@ -389,7 +391,7 @@ int main(int argc, char** argv) {
         printf("\n");
       }
     }
-    printf("%-64s %8.1f us/step  %7.1f tok/s  %5.3f of 8 TB/s  launches %3d  tokens %s\n", variants[vi].name().c_str(), us,
+    printf("%-56s %8.1f us/step  %7.1f tok/s  %5.3f of 8 TB/s  launches %3d  tokens %s\n", variants[vi].name().c_str(), us,
            1e6 / us * B, bytes / us * 1e-6 / 8.0, vlm_llm_decode_launches(m.h), same ? "== baseline" : "DIFFER");
     fflush(stdout);
   }

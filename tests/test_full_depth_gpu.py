@@ -1,0 +1,212 @@
+"""GPU parity at the sizes the benchmarks run ("next" item 1): BASELINE configs[2], [3] and [4] at FULL
+depth, and the 16-row decode step against the oracle.
+
+  * configs[2]  Qwen2-VL-7B: 32 ViT blocks of 1280 (merger out 3584), 28 decoder layers of 3584 / 18944, GQA 28:4,
+                untied lm_head, V = 152,064; one 336 x 336 image (144 image tokens) + 128 text tokens;
+  * configs[3]  Idefics2-8B: SigLIP-so400m (27 layers of 1152 / 4304), perceiver resampler (3 layers, 64 latents),
+                Mistral-7B (32 layers of 4096 / 14336, GQA 32:8), V = 32,003; one prompt with 4 x 336 x 336 images;
+  * configs[4]  Phi-3.5-vision: CLIP ViT-L/14-336 (24 layers, 23 run), HD transform, Phi-3 decoder (32 layers of
+                3072 / 8192, 32 heads of 96) with an MLX 4-bit language model, V = 32,064; one 336 x 336 image;
+each: image features, last-row prefill logits and 8 teacher-forced decode steps (a seeded random token stream, every
+step's logits) against the oracle on the same synthetic checkpoint - the form of
+tests/test_parity_decode_gpu.py::test_full_depth_qwen2_vl_2b_image_prefill_and_teacher_forced_decode;
+  * 16 rows (and 9) through vlm_llm_decode_forward - every projection on the skinny-M MFMA GEMM, qkv + rope + KV write
+    in its epilogue - with EVERY row's logits compared with the oracle's (not with single-request runs of the engine),
+    bf16 (Qwen2-VL) and MLX 4-bit (Phi-3).
+
+Tolerances per depth (rel-rms of a logit row against the oracle; stated at each assert): the engine and the oracle
+round at the same points but accumulate in different orders, a 1-ulp flip of a bf16 activation is amplified by the
+layers after it; measured distances grow as ~sqrt(depth): 2 layers 0.3-1.2 %, 28 layers 2-3 %, 32 layers + a 4-bit
+language model 3-4 %.
+
+The synthetic checkpoints use oracle.ops.fast_normal for their big matrices (windows of one normal pool: seconds instead
+of minutes per 8 B-parameter model on the GPU box's clock); the oracle and the engine read the same tensors.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import build_idefics2_model, build_phi3v_model, build_product_model
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+N_FORCED = 8
+
+
+def _rel_rms(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30))
+
+
+def _check_rows(got, ref, tol_rms, tag):
+    """every row within tol_rms (rel-rms); argmax identical wherever the oracle's top-2 margin exceeds 0.25 rms (far
+    above the per-element error at every tolerance used here)"""
+    worst = 0.0
+    for i in range(ref.shape[0]):
+        e = _rel_rms(got[i], ref[i])
+        worst = max(worst, e)
+        assert e < tol_rms, (tag, i, e)
+        r = ref[i].float()
+        top2 = r.topk(2).values
+        if float(top2[0] - top2[1]) > 0.25 * float(r.pow(2).mean().sqrt()):
+            assert int(got[i].float().argmax()) == int(r.argmax()), (tag, i)
+    return worst
+
+
+def _teacher_forced(model, ids, pixels, forced, **kw):
+    lm = model.language_model
+    f = model.get_input_embeddings(ids, pixels, **kw)
+    cache = lm.make_cache()
+    out = lm(ids, f.inputs_embeds, cache=cache, position_ids=f.position_ids, rope_deltas=f.rope_deltas, logits_to_keep=1)
+    rows = [out.logits[0, -1].clone()]
+    for y in forced:
+        rows.append(lm(np.array([[int(y)]]), cache=cache).logits[0, -1].clone())
+    n = cache[0].offset
+    cache[0]._seq.release()
+    return torch.stack(rows), n
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[2]
+def test_full_depth_qwen2_vl_7b_image_prefill_and_teacher_forced_decode():
+    from oracle import image_processor as oip
+    from oracle import qwen2_vl as oq
+
+    text = oq.TextCfg(hidden_size=3584, num_hidden_layers=28, intermediate_size=18944, num_attention_heads=28,
+                      num_key_value_heads=4, vocab_size=152064, tie_word_embeddings=False)
+    cfg = oq.Cfg(text=text, vision=oq.VisionCfg(depth=32, embed_dim=1280, hidden_size=3584, num_heads=16))
+    W = oq.random_weights(cfg, seed=70, dtype=BF, std=0.02, fast=True)
+    model = build_product_model(cfg, W, kv_pool_tokens=4096, max_seqs=4)
+    img = np.random.default_rng(31).integers(0, 256, (3, 336, 336), dtype=np.uint8)
+    pix, thw = oip.process([img])
+    n_img = int(thw.prod()) // 4
+    assert (pix.shape[0], n_img) == (576, 144)
+    text_ids = np.random.default_rng(1031).integers(0, 151643, 128)
+    ids = np.concatenate([[cfg.vision_start_token_id], np.full(n_img, cfg.image_token_id), [cfg.vision_start_token_id + 1],
+                          text_ids]).astype(np.int64)[None]
+    forced = np.random.default_rng(1032).integers(0, 151643, N_FORCED)
+    pix_t = torch.from_numpy(pix).to(BF)
+    ref_feats = oq.vision_tower(W, cfg, pix_t, thw)
+    ref = oq.decode_teacher_forced(W, cfg, ids, pix_t, thw, forced)
+    feats = model.vision_tower(torch.from_numpy(pix), thw)
+    e_feat = _rel_rms(feats, ref_feats)
+    assert e_feat < 3e-2, e_feat                                    # 32 blocks + merger in bf16
+    got, n = _teacher_forced(model, ids, torch.from_numpy(pix), forced, image_grid_thw=thw)
+    assert n == ids.shape[1] + N_FORCED == 274 + N_FORCED and got.shape == ref.shape == (1 + N_FORCED, 152064)
+    worst = _check_rows(got, ref, 4e-2, "7B")                       # 28 layers of bf16 after a 32-block tower
+    print(f"full-depth 7B: feature rel-rms {e_feat:.4f}, worst logit-row rel-rms {worst:.4f}")
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[3]
+def test_full_depth_idefics2_8b_four_images_prefill_and_teacher_forced_decode():
+    from oracle import idefics2 as oi
+    from tests.test_vlm_family_idefics2_gpu import _images, _request
+
+    cfg = oi.Cfg(text=oi.TextCfg(), vision=oi.VisionCfg(), perceiver=oi.PerceiverCfg())
+    assert (cfg.text.num_hidden_layers, cfg.vision.num_hidden_layers, cfg.text.vocab_size) == (32, 27, 32003)
+    W = oi.random_weights(cfg, seed=71, dtype=BF, std=0.02, embed_std=0.02, fast=True)
+    model = build_idefics2_model(cfg, W, kv_pool_tokens=4096, max_seqs=4)
+    imgs = _images(90, [(336, 336)] * 4)
+    ids, pv, pm = _request(cfg, imgs, seed=91, n_text=(20, 30, 30), vocab_hi=32000)
+    assert pv.shape == (1, 4, 3, 378, 378) and int((ids == cfg.image_token_id).sum()) == 256
+    ref_feats = oi.image_features(W, cfg, torch.from_numpy(pv).to(BF), pm)
+    got_feats = model.encode_image(torch.from_numpy(pv), pm)
+    e_feat = _rel_rms(got_feats, ref_feats.reshape(-1, ref_feats.shape[-1]))
+    assert e_feat < 3e-2, e_feat                                    # 27 SigLIP layers + 3 perceiver layers in bf16
+    forced = np.random.default_rng(92).integers(3, 32000, N_FORCED)
+    ref = oi.decode_teacher_forced(W, cfg, ids, torch.from_numpy(pv), pm, forced)
+    got, n = _teacher_forced(model, ids, torch.from_numpy(pv), forced, pixel_attention_mask=pm)
+    assert n == ids.shape[1] + N_FORCED and got.shape == ref.shape == (1 + N_FORCED, 32003)
+    worst = _check_rows(got, ref, 4e-2, "idefics2-8b")              # 32 layers of bf16 behind tower + resampler
+    print(f"full-depth Idefics2-8B: feature rel-rms {e_feat:.4f}, worst logit-row rel-rms {worst:.4f}")
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[4]
+def test_full_depth_phi35_vision_4bit_prefill_and_teacher_forced_decode():
+    from oracle import phi3_v as op
+    from oracle import quant as Q
+    from tests.test_vlm_family_phi3v_gpu import _images, _request
+
+    short, long = op.su_factors(96, seed=9)
+    cfg = op.Cfg(text=op.TextCfg(short_factor=short, long_factor=long), vision=op.VisionCfg())
+    assert (cfg.text.num_hidden_layers, cfg.vision.num_hidden_layers, cfg.text.vocab_size) == (32, 24, 32064)
+    W = op.random_weights(cfg, seed=72, dtype=BF, std=0.02, embed_std=0.02, fast=True)
+    # MLX affine 4-bit language model (group 64), bf16 tower / projection: ck = the packed checkpoint the engine loads,
+    # ow = the oracle's view of the same quantized weights
+    ck, ow = Q.quantize_checkpoint(W, predicate=lambda p, v: not p.startswith("model.vision_embed_tokens."))
+    del W
+    model = build_phi3v_model(cfg, ck, kv_pool_tokens=4096, max_seqs=4)
+    imgs = _images(93, [(336, 336)])
+    ids, pv, sz = _request(cfg, imgs, n_text=(20, 40, 40), seed=94, vocab_hi=32000)
+    assert int((ids < 0).sum()) == 757
+    forced = np.random.default_rng(95).integers(3, 32000, N_FORCED)
+    ref_rows = op.image_features(ow, cfg, torch.from_numpy(pv).to(BF), sz)[0]
+    got_rows = model.vision_model.image_features(torch.from_numpy(pv), sz)[0]
+    e_feat = _rel_rms(got_rows, ref_rows)
+    assert e_feat < 3e-2, e_feat                                    # 23 CLIP layers + HD projection in bf16
+    ref = op.decode_teacher_forced(ow, cfg, ids, torch.from_numpy(pv), sz, forced)
+    got, n = _teacher_forced(model, ids, torch.from_numpy(pv), forced, image_sizes=sz)
+    assert n == ids.shape[1] + N_FORCED and got.shape == ref.shape == (1 + N_FORCED, 32064)
+    worst = _check_rows(got, ref, 5e-2, "phi3.5-vision 4-bit")      # 32 layers, 4-bit weights amplify activation flips
+    print(f"full-depth Phi-3.5-vision (4-bit LM): feature rel-rms {e_feat:.4f}, worst logit-row rel-rms {worst:.4f}")
+
+
+# ------------------------------------------------------------------------------------------------ 16 decode rows vs oracle
+def _rows_vs_oracle(model, lm_decode_ref, prompts, forced, tol, tag):
+    """prompts: B token arrays; forced: [steps][B].  Prefill each prompt into its own cache (consecutive KV slots), then
+    every step feeds one token per row through ONE B-row vlm_llm_decode_forward; every row of every step vs the
+    oracle's teacher-forced logits of that sequence."""
+    lm = model.language_model
+    B = len(prompts)
+    caches = []
+    for p in prompts:
+        c = lm.make_cache()
+        lm(p[None], cache=c, logits_to_keep=1)
+        caches.append(c)
+    got = []
+    for step in forced:
+        got.append(lm(np.asarray(step, dtype=np.int64).reshape(B, 1), cache=caches).logits[:, 0].clone())
+    got = torch.stack(got)                                          # [steps, B, V]
+    for c in caches:
+        c[0]._seq.release()
+    worst = 0.0
+    for b in range(B):
+        ref = lm_decode_ref(prompts[b], [int(s[b]) for s in forced])[1:]      # drop the prefill row
+        worst = max(worst, _check_rows(got[:, b], ref, tol, f"{tag} row {b}"))
+    return worst
+
+
+@pytest.mark.parametrize("B", [16, 9])
+def test_decode_forward_16_rows_every_row_vs_oracle_bf16(B):
+    """Qwen2-VL tiny dims, B rows of different context lengths (3 .. 140 tokens: rows on their first page, rows past a page
+    boundary) through the B-row decode forward (B = 9 runs as its own width: rows as the MFMA N dimension, 7 idle
+    columns): 4 steps, every row's logits vs the oracle; 2 layers of bf16: 2e-2."""
+    from oracle import qwen2_vl as oq
+
+    cfg = oq.tiny_cfg()
+    W = oq.random_weights(cfg, seed=1234, dtype=BF, std=0.05, embed_std=0.2)
+    model = build_product_model(cfg, W, kv_pool_tokens=16384, max_seqs=32)
+    rng = np.random.default_rng(500 + B)
+    prompts = [rng.integers(3, 1000, 3 + (b * 37) % 138).astype(np.int64) for b in range(B)]
+    forced = rng.integers(3, 1000, (4, B))
+    worst = _rows_vs_oracle(model, lambda p, f: oq.decode_teacher_forced(W, cfg, p[None], None, None, np.asarray(f)),
+                            prompts, forced, 2e-2, f"bf16 B={B}")
+    print(f"{B}-row decode forward vs oracle (bf16): worst row rel-rms {worst:.4f}")
+
+
+def test_decode_forward_16_rows_every_row_vs_oracle_4bit():
+    """the same over an MLX 4-bit Phi-3 tiny model (dequant-fused MFMA form of the skinny-M GEMM, Su-RoPE in the qkv
+    epilogue): 16 rows, 4 steps, every row vs the oracle's 4-bit graph; 2e-2."""
+    from oracle import phi3_v as op
+    from oracle import quant as Q
+
+    cfg = op.tiny_cfg()
+    W = op.random_weights(cfg, seed=4321, dtype=BF, std=0.04, embed_std=0.2)
+    ck, ow = Q.quantize_checkpoint(W, predicate=lambda p, v: not p.startswith("model.vision_embed_tokens."))
+    model = build_phi3v_model(cfg, ck, kv_pool_tokens=16384, max_seqs=32)
+    rng = np.random.default_rng(516)
+    B = 16
+    prompts = [rng.integers(3, 1000, 3 + (b * 37) % 138).astype(np.int64) for b in range(B)]
+    forced = rng.integers(3, 1000, (4, B))
+    worst = _rows_vs_oracle(model, lambda p, f: op.decode_teacher_forced(ow, cfg, p[None], None, None, np.asarray(f)),
+                            prompts, forced, 2e-2, "4-bit B=16")
+    print(f"16-row decode forward vs oracle (4-bit): worst row rel-rms {worst:.4f}")

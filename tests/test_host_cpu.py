@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES)
     for s in declared:
         assert hasattr(L, s), s
-    assert L.vlm_abi_version() == 3
+    assert L.vlm_abi_version() == 4
 
 
 def test_no_cpu_fallback_ops_raise_on_cpu_tensors():

@@ -287,6 +287,51 @@ def test_attn_decode_paged(vops, lens, nsplit):
     assert ok, rep
 
 
+@pytest.mark.parametrize("lens,nsplit,heads", [([1, 130], 8, (12, 2)), ([700, 64], 4, (12, 2)), ([65], 16, (12, 2)),
+                                               ([2000, 1, 63, 64], 8, (28, 4)), ([640], 16, (12, 2)), ([513, 1100], 32, (8, 8)),
+                                               ([1, 64, 65, 2047], 2, (16, 2)), ([4100], 32, (32, 8)), ([386], 16, (14, 2))])
+@pytest.mark.parametrize("identity", [False, True])
+def test_attn_decode_paged_split_vs_oracle(vops, lens, nsplit, heads, identity):
+    """vlm_attn_decode_paged_split (one wave per page stride, the last arriver merges): every (length, split count, GQA
+    group) against the oracle's SDPA - lengths of 1 token, exact page multiples, more pages than splits (a workgroup
+    walks several pages), more splits than pages (workgroups that only arrive), G = 1 / 4 / 6 / 7 / 8.  The launch is
+    repeated on the same ticket words: a ticket that was not re-armed would make the second launch merge early or
+    never.  Same bar as the one-workgroup form: 2 ulps + 2 % of the output rms (P is rounded to bf16 for P.V)."""
+    Hq, Hkv = heads
+    B, D = len(lens), 128
+    scale = D ** -0.5
+    g = torch.Generator().manual_seed(27)
+    max_pages = max((n + 63) // 64 for n in lens) + 1
+    n_pages = B * max_pages if identity else sum((n + 63) // 64 for n in lens) + 3
+    perm = torch.randperm(n_pages, generator=g).tolist()
+    bt = torch.zeros(B, max_pages, dtype=torch.int32)
+    kpool = torch.full((n_pages, Hkv, D // 8, 64, 8), float("nan"), dtype=BF)   # unwritten slots hold NaN on purpose
+    vpool = torch.full((n_pages, Hkv, D, 64), float("nan"), dtype=BF)
+    q = rnd(B, Hq * D, seed=28)
+    refs = []
+    for b, n in enumerate(lens):
+        k, v = rnd(n, Hkv, D, seed=30 + b), rnd(n, Hkv, D, seed=40 + b)
+        for p in range((n + 63) // 64):
+            page = b * max_pages + p if identity else perm.pop()
+            bt[b, p] = page
+            m = min(64, n - p * 64)
+            kk = k[p * 64:p * 64 + m]
+            kpool[page, :, :, :m, :] = kk.permute(1, 0, 2).reshape(Hkv, m, D // 8, 8).permute(0, 2, 1, 3)
+            vpool[page][:, :, VSLOT[:m]] = v[p * 64:p * 64 + m].permute(1, 2, 0)
+        qb = q[b].view(1, Hq, 1, D)
+        refs.append(O.sdpa(qb, k.permute(1, 0, 2)[None], v.permute(1, 0, 2)[None], scale)[0, :, 0])
+    ref = torch.stack(refs).reshape(B, Hq * D)
+    kv_len = torch.tensor(lens, dtype=torch.int32).cuda()
+    tickets = torch.zeros(B * Hkv, dtype=torch.int32, device="cuda")
+    qd, kd, vd, btd = q.cuda(), kpool.cuda(), vpool.cuda(), (None if identity else bt.cuda())
+    for rep_i in range(3):
+        out = vops.attn_decode_paged_split(qd, kd, vd, btd, kv_len, 0, Hq, Hkv, D, scale, nsplit, max_pages=max_pages,
+                                           tickets=tickets)
+        ok, rep = bf16_close(out, ref, ulps=2, atol_rms=2e-2)
+        assert ok, (rep_i, rep)
+        assert int(tickets.abs().sum()) == 0                      # re-armed
+
+
 # ------------------------------------------------------------------ gather / scatter / cast (bit-exact)
 def test_embed_scatter_cast_exact(vops):
     table = rnd(1000, 256, seed=50)
