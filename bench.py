@@ -285,30 +285,48 @@ def _hf_cpu_baseline(cfg, threads, ctx, n_tok):
                       f"{n_tok} greedy tokens at context {ctx} with its KV cache; vision tower on one 336x336 image"}
 
 
-DECODE_KERNELS = ("gemv_rowwave_kernel", "gemv_splitk_kernel", "attn_decode_mfma_kernel", "attn_decode_combine_kernel",
-                  "lse_partial_kernel", "logprob_argmax_kernel", "argmax_final_kernel", "embed_gather_kernel",
-                  "decode_advance_kernel", "sample_filter_kernel", "logprob_argmax_tail_kernel")
+DECODE_KERNELS = ("gemv_rowwave_kernel", "gemv_splitk_kernel", "attn_decode_mfma_kernel", "attn_decode_pagesplit_kernel",
+                  "attn_decode_combine_kernel", "lse_partial_kernel", "logprob_argmax_kernel", "argmax_final_kernel",
+                  "embed_gather_kernel", "decode_advance_kernel", "sample_filter_kernel", "logprob_argmax_tail_kernel")
 HEAD_KERNEL = "gemv_rowwave_kernel<4, 3, 1, 1, 0>"         # RMSNorm + lm_head GEMV: exactly one launch per decoded token
 GATE_UP_KERNEL = "gemv_rowwave_kernel<4, 3, 1, 1, 16>"     # name as rocprofv3 prints it (R=4 rows/wave, RMSNorm prologue, SwiGLU)
+DECODE_CSRC = ("gemv_bf16.hip", "attn_decode.hip", "sample.hip", "embed.hip", "engine.hip", "common.cuh", "internal.h")
+
+
+def decode_csrc_sha16():
+    """hash of the sources of every kernel in the decode step + the engine that sequences them: what a PMC pass was taken on"""
+    import hashlib
+
+    h = hashlib.sha256()
+    base = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mlx-vlm_amd", "csrc")
+    for f in DECODE_CSRC:
+        h.update(open(os.path.join(base, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic():
-    """HBM bytes per launch from the committed --pmc passes (scripts/r02_final_prof.sh -> profiles/r02_pmc_traffic.json, taken
-    on the kernels of this tree at the end of round 2; the round-1 file as a fallback): (2 * FETCH_SIZE + WRITE_SIZE) * 1024,
-    the gfx950 correction of MI355X_MICROARCH.md.  bench.py cannot collect hardware counters itself (they need rocprofv3 around
-    the process); None when no file is there."""
+    """HBM bytes per launch from the committed --pmc passes (scripts/r03_final_prof.sh -> profiles/r03_pmc_traffic.json):
+    (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of MI355X_MICROARCH.md.  bench.py cannot collect hardware
+    counters itself (they need rocprofv3 around the process).  The file records the hash of the decode step's kernel sources
+    it was taken on (`_meta.decode_csrc_sha16`, scripts/pmc_summary.py); a file without it or with another hash is STALE and
+    refused: -> (None, None, reason)."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((p for p in (os.path.join(here, "r02_pmc_traffic.json"), os.path.join(here, "r01_pmc_traffic.json")) if os.path.exists(p)), None)
-    if path is None:
-        return None, None
+    cands = sorted((f for f in os.listdir(here) if f.endswith("_pmc_traffic.json")), reverse=True) if os.path.isdir(here) else []
+    if not cands:
+        return None, None, "no profiles/*_pmc_traffic.json"
+    path = os.path.join(here, cands[0])
     d = json.load(open(path))
+    sha = d.get("_meta", {}).get("decode_csrc_sha16")
+    if sha != decode_csrc_sha16():
+        return None, None, (f"{cands[0]} is stale: taken on decode sources {sha}, this tree is {decode_csrc_sha16()} "
+                            "(re-run scripts/r03_final_prof.sh)")
     gu = d.get(GATE_UP_KERNEL, {}).get("hbm_bytes_per_launch")
     steps = d.get(HEAD_KERNEL, {}).get("launches", 0) or d.get("decode_advance_kernel", {}).get("launches", 0)
     per_tok = None
     if steps:
         per_tok = sum(v.get("hbm_bytes_per_launch", 0.0) * v["launches"] for k, v in d.items()
                       if k.startswith(DECODE_KERNELS)) / steps
-    return gu, per_tok
+    return gu, per_tok, cands[0]
 
 
 def _load_synthetic(cfg_dict, model_pkg, rank, dev, w4=False, **engine_kw):
@@ -339,12 +357,15 @@ def _load_synthetic(cfg_dict, model_pkg, rank, dev, w4=False, **engine_kw):
     return cfg, model, {"load_s": time.perf_counter() - t0, "weight_bytes": nbytes, "broadcast_s": bcast_s}
 
 
-def _dist_info(ws):
+def _dist_info(ws, load=None):
     import torch.distributed as dist
 
+    out = {"backend": None, "ranks": 1}
     if ws > 1 and dist.is_initialized():
-        return {"backend": dist.get_backend(), "ranks": dist.get_world_size()}
-    return {"backend": None, "ranks": 1}
+        out = {"backend": dist.get_backend(), "ranks": dist.get_world_size()}
+        if load and load.get("broadcast_s"):
+            out["weight_broadcast_GBps"] = load["weight_bytes"] / load["broadcast_s"] / 1e9
+    return out
 
 
 def workload_nanollava(args, rank, ws, dev):
@@ -401,7 +422,7 @@ def workload_nanollava(args, rank, ws, dev):
                                   "336x336 image resized to 384x384 (729 image tokens) + 128 text tokens, greedy decode, EOS disabled",
                       "prompt_tokens": int(prompt_tokens), "max_tokens": max_tokens, "parallelism": f"dp{ws}"},
            "decode_us_per_token": us_tok, "prefill_ms_to_first_token": pre_max / args.steps * 1e3,
-           "prompt_tps": ws * prompt_tokens * args.steps / pre_max, "load": load, "distributed": _dist_info(ws),
+           "prompt_tps": ws * prompt_tokens * args.steps / pre_max, "load": load, "distributed": _dist_info(ws, load),
            "roofline": {"bound": "hbm", "kernel": "whole decode step", "achieved": bytes_per_token / us_tok * 1e-3,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_per_token / us_tok * 1e-3 / HBM_PEAK_GBS,
                         "traffic": None, "algorithmic_bytes_per_token": bytes_per_token}}
@@ -471,6 +492,82 @@ def cpu_baseline_nanollava(threads):
                       f"image through the 27-layer SigLIP tower + projector; nothing extrapolated"}
 
 
+def cpu_baseline_lm(kind, threads):
+    """cpu_baseline of the non-headline workloads: the oracle (torch-CPU restatement of the reference's graph for that model
+    family) at FULL size on the host cores, single-stream decode - a bounded sample (3 or 6 tokens at the workload's context,
+    all layers + lm_head + greedy sampling; K / V of the context pre-filled with random values: timing only).  The big
+    matrices of the synthetic checkpoint come from oracle.ops.fast_normal (seconds instead of minutes of setup)."""
+    from oracle import ops as O
+
+    torch.set_num_threads(threads)
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(1)
+    t0 = time.perf_counter()
+    if kind in ("qwen2vl-7b", "qwen2vl-2b-w4"):
+        from oracle import qwen2_vl as oq
+        if kind == "qwen2vl-7b":
+            cfg = oq.Cfg(text=oq.TextCfg(hidden_size=3584, num_hidden_layers=28, intermediate_size=18944, num_attention_heads=28,
+                                         num_key_value_heads=4, vocab_size=152064, tie_word_embeddings=False),
+                         vision=oq.VisionCfg(depth=1, embed_dim=1280, hidden_size=3584, num_heads=16))
+            ctx, n_tok, label = 274, 3, "Qwen2-VL-7B language model (28 layers of 3584 / 18944, untied head)"
+        else:
+            cfg = oq.Cfg(vision=oq.VisionCfg(depth=1))
+            ctx, n_tok, label = 386, 6, "Qwen2-VL-2B language model as an MLX affine 4-bit checkpoint (oracle/quant.py)"
+        W = oq.random_weights(cfg, seed=0, dtype=BF, fast=True)
+        if kind == "qwen2vl-2b-w4":
+            from oracle import quant as Q
+            W = Q.quantize_checkpoint(W, predicate=lambda p, v: p.startswith("language_model."))[1]
+        t = cfg.text
+        hd, nkv, nl = t.hidden_size // t.num_attention_heads, t.num_key_value_heads, t.num_hidden_layers
+        step = lambda e, cache, i: O.argmax_first(O.logprobs_from_logits(  # noqa: E731
+            oq.lm_head(W, cfg, oq.qwen2_model(W, cfg, e, cache, torch.full((3, 1, 1), ctx + i)))[:, -1, :]))
+    elif kind == "idefics2-8b":
+        from oracle import idefics2 as om
+        cfg = om.Cfg(text=om.TextCfg(), vision=om.VisionCfg(num_hidden_layers=1), perceiver=om.PerceiverCfg())
+        W = om.random_weights(cfg, seed=0, dtype=BF, std=0.02, embed_std=0.02, fast=True)
+        t = cfg.text
+        hd, nkv, nl = 128, t.num_key_value_heads, t.num_hidden_layers
+        ctx, n_tok, label = 384, 3, "Idefics2-8B language model (Mistral-7B: 32 layers of 4096 / 14336)"
+        step = lambda e, cache, i: O.argmax_first(O.logprobs_from_logits(om.language_model(W, cfg, e, cache, last_only=True)[:, -1, :]))  # noqa: E731
+    elif kind == "phi35v-w4":
+        from oracle import phi3_v as om
+        from oracle import quant as Q
+        short, long = om.su_factors(96, seed=9)
+        cfg = om.Cfg(text=om.TextCfg(short_factor=short, long_factor=long), vision=om.VisionCfg(num_hidden_layers=1))
+        W = om.random_weights(cfg, seed=0, dtype=BF, std=0.02, embed_std=0.02, fast=True)
+        W = Q.quantize_checkpoint(W, predicate=lambda p, v: not p.startswith("model.vision_embed_tokens."))[1]
+        t = cfg.text
+        hd, nkv, nl = t.hidden_size // t.num_attention_heads, t.num_key_value_heads, t.num_hidden_layers
+        ctx, n_tok, label = 885, 6, "Phi-3.5-vision language model (32 layers of 3072 / 8192) as an MLX affine 4-bit checkpoint"
+        step = lambda e, cache, i: O.argmax_first(O.logprobs_from_logits(om.language_model(W, cfg, e, cache, last_only=True)[:, -1, :]))  # noqa: E731
+    else:
+        raise ValueError(kind)
+    setup_s = time.perf_counter() - t0
+    cache = [O.KVCache() for _ in range(nl)]
+    for c in cache:
+        c.update_and_fetch((torch.randn(1, nkv, ctx, hd, generator=g) * 0.5).to(BF), (torch.randn(1, nkv, ctx, hd, generator=g) * 0.5).to(BF))
+    e1 = (torch.randn(1, 1, t.hidden_size, generator=g) * 0.02).to(BF)
+    step(e1, cache, 0)                                        # warm-up token
+    t0 = time.perf_counter()
+    for i in range(n_tok):
+        step(e1, cache, 1 + i)
+    tok_s = n_tok / (time.perf_counter() - t0)
+    return {"value": tok_s, "unit": "tokens/s", "cores": threads, "kind": "port", "setup_s": setup_s,
+            "sample": f"oracle (torch-CPU restatement of the reference's typed graph), {label} at full size, {threads} threads: "
+                      f"{n_tok} single-stream decode tokens at context {ctx} through all {nl} layers + lm_head + greedy sampling; "
+                      "nothing extrapolated (the CPU path has no batched step: one sequence)"}
+
+
+def _with_cpu_baseline(out, kind, args, rank, ws):
+    if rank == 0 and ws == 1 and not args.no_cpu_baseline:
+        from mlx_vlm_amd.utils import cpu_quota
+        try:
+            out["cpu_baseline"] = cpu_baseline_lm(kind, min(cpu_quota(), 32))
+        except Exception as e:                                # the baseline leg must never cost the measured line
+            out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
 def workload_2b_w4(args, rank, ws, dev):
     """the headline workload over an MLX affine 4-bit language model (what the reference's README runs:
     Qwen2-VL-2B-Instruct-4bit) - bf16 activations / KV / vision tower, 4-bit + group-64 scale / bias weights in the decoder,
@@ -511,7 +608,7 @@ def workload_2b_w4(args, rank, ws, dev):
                                    "scales / biases), batch=1 per GPU, one 448x448 image + 128 text tokens, greedy "
                                    f"{max_tokens}-token decode, EOS disabled",
                        "prompt_tokens": int(req[0].shape[1]), "max_tokens": max_tokens, "parallelism": f"dp{ws}"},
-            "ttft_ms": pre_max / args.steps * 1e3, "us_per_token": us_tok, "load": load, "distributed": _dist_info(ws),
+            "ttft_ms": pre_max / args.steps * 1e3, "us_per_token": us_tok, "load": load, "distributed": _dist_info(ws, load),
             "roofline": {"bound": "hbm", "kernel": "whole decode step (4-bit weights + bf16 KV)", "achieved": bytes_per_token / us_tok / 1e3,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_per_token / us_tok / 1e3 / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_token": bytes_per_token}}
@@ -536,10 +633,13 @@ def workload_7b_b32(args, rank, ws, dev):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     total, res = 0, None
+    dec_tok = dec_steps = 0
+    dec_t = 0.0
     for _ in range(args.steps):
         res = parallel.dp_batch_generate(model, None, requests=reqs, max_tokens=max_tokens)
         if rank == 0:
             total += res["generation_tokens"]
+            dec_tok, dec_steps, dec_t = dec_tok + res["decode_tokens"], dec_steps + res["decode_steps"], dec_t + res["decode_time_s"]
     torch.cuda.synchronize()
     parallel.barrier()
     wall = parallel.max_over_ranks(time.perf_counter() - t0, dev)
@@ -554,10 +654,20 @@ def workload_7b_b32(args, rank, ws, dev):
                                   "ranks, continuous batching with up to 16 decode rows per GPU (projections of 8 / 16-row steps on the matrix cores)",
                       "requests": n_req, "max_tokens": max_tokens, "parallelism": f"dp{ws}",
                       "per_rank_requests": res["per_rank_requests"] if rank == 0 else None},
-           "load": load, "distributed": _dist_info(ws),
-           "roofline": {"bound": "hbm", "kernel": "whole job (weights streamed once per decode step for up to 8 rows)",
-                        "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                        "algorithmic_weight_bytes_per_step": 2 * lm_params}}
+           "load": load, "distributed": _dist_info(ws, load),
+           }
+    if rank == 0:
+        # decode steps of the job (graph replays summed over the ranks; decode time = the slowest rank's): a step streams the
+        # weights once and, per row it serves, that row's K / V (57,344 B per cached token at 7B) at the mean context
+        kv_tok = 2 * t.num_hidden_layers * t.num_key_value_heads * 128 * 2
+        ctx_mid = int(reqs[0]["input_ids"].size) + max_tokens // 2
+        job_bytes = dec_steps * 2 * lm_params + dec_tok * ctx_mid * kv_tok
+        gbs = job_bytes / max(dec_t, 1e-9) / 1e9 / ws            # per GPU: the ranks' steps run concurrently
+        out["decode_tokens_per_s"] = dec_tok / max(dec_t, 1e-9)
+        out["roofline"] = {"bound": "hbm", "kernel": "decode steps of the job (bf16 weights once per step + K / V of the rows it serves), per GPU",
+                           "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_weight_bytes_per_step": 2 * lm_params, "decode_steps": dec_steps,
+                           "decode_tokens": dec_tok, "decode_time_s": dec_t, "kv_bytes_per_cached_token": kv_tok}
     return out
 
 
@@ -616,7 +726,7 @@ def workload_idefics2_b8(args, rank, ws, dev):
                        "requests_per_gpu": n_req, "images_per_prompt": n_img, "prompt_tokens": int(ids_l[0].size),
                        "max_tokens": max_tokens, "parallelism": f"dp{ws}"},
             "e2e_tokens_per_s": ws * gen_tok / wall, "prompt_tps": ws * pre_tok / max(pre_t, 1e-9),
-            "images_per_s_prefill": ws * n_req * n_img * args.steps / max(pre_t, 1e-9), "load": load, "distributed": _dist_info(ws),
+            "images_per_s_prefill": ws * n_req * n_img * args.steps / max(pre_t, 1e-9), "load": load, "distributed": _dist_info(ws, load),
             "roofline": {"bound": "hbm", "kernel": "whole 8-row decode step (bf16 weights once + 8 rows of K / V)",
                          "achieved": step_bytes * steps_per_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": step_bytes * steps_per_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_step": step_bytes}}
@@ -681,7 +791,7 @@ def workload_phi35v_w4_b16(args, rank, ws, dev):
                       "requests_per_gpu": n_req, "prompt_tokens": int(ids_l[0].size), "max_tokens": max_tokens, "parallelism": f"dp{ws}"},
            "e2e_tokens_per_s": ws * gen_tok / wall, "prompt_tps": ws * pre_tok / max(pre_t, 1e-9),
            "images_per_s_prefill": ws * n_req * args.steps / max(pre_t, 1e-9), "clip_tflop_per_image": clip_tflop,
-           "load": load, "distributed": _dist_info(ws),
+           "load": load, "distributed": _dist_info(ws, load),
            "roofline": {"bound": "hbm", "kernel": "whole 16-row decode step (4-bit weights once + 16 rows of bf16 K / V)",
                         "achieved": step_bytes * steps_per_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": step_bytes * steps_per_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
@@ -704,6 +814,27 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip kernel rooflines / ViT throughput (profiling runs)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` outside torchrun: launch the N ranks ourselves (one process per GPU over RCCL, the form
+        # the driver uses: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        print(f"[bench] --gpus {args.gpus} outside torchrun: launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+        sys.exit(subprocess.call(cmd, env=env))
+    ws_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws_env != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ws_env}: the rank count of the launcher and --gpus must agree "
+                 "(run `python bench.py --gpus N`, or torchrun --nproc-per-node N bench.py --gpus N)")
+
     from mlx_vlm_amd import parallel, synthetic
     from mlx_vlm_amd.models import qwen2_vl
 
@@ -716,6 +847,10 @@ def main():
         out = {"nanollava": workload_nanollava, "qwen2vl-7b-b32": workload_7b_b32, "qwen2vl-2b-w4": workload_2b_w4,
                "phi35v-w4-b16": workload_phi35v_w4_b16, "idefics2-b8": workload_idefics2_b8}[args.workload](
             args, rank, ws, dev)
+        kind = {"qwen2vl-7b-b32": "qwen2vl-7b", "qwen2vl-2b-w4": "qwen2vl-2b-w4", "phi35v-w4-b16": "phi35v-w4",
+                "idefics2-b8": "idefics2-8b"}.get(args.workload)
+        if kind:
+            out = _with_cpu_baseline(out, kind, args, rank, ws)
         if rank == 0:
             print(json.dumps(out), flush=True)
         parallel.barrier()
@@ -778,7 +913,7 @@ def main():
         ctx_mid = int(req[0].shape[1]) + args.max_tokens // 2
         bytes_per_token = 2 * lm_params + 28672 * ctx_mid + 28672
         step_gbs = bytes_per_token / (us_per_token * 1e-6) / 1e9
-        traffic_gu, traffic_tok = pmc_traffic()
+        traffic_gu, traffic_tok, traffic_src = pmc_traffic()
         out = {
             "metric": "decode tokens/sec + vision-prefill images/sec, Qwen2-VL-2B", "value": decode_tps, "unit": "tokens/s",
             "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -791,11 +926,11 @@ def main():
             "prefill_ms_to_first_token": pre_max / args.steps * 1e3,
             "prompt_tps": ws * args.steps * int(req[0].shape[1]) / pre_max,
             "e2e_tokens_per_s": ws * ntok / wall,
-            "load_s": load["load_s"], "load": load, "distributed": _dist_info(ws),
+            "load_s": load["load_s"], "load": load, "distributed": _dist_info(ws, load),
             # the number the north-star's 60 % target refers to: the WHOLE decode step against the HBM roofline
             "roofline": {"bound": "hbm", "kernel": "whole decode step (all launches of one token)", "achieved": step_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS, "traffic": traffic_tok,
-                         "algorithmic_bytes_per_token": bytes_per_token},
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_token": bytes_per_token},
         }
         out["roofline_decode_step"] = dict(out["roofline"])
         if extras:

@@ -195,10 +195,20 @@ int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, const void*
  * o_proj prologue.  part_o fp32 [B*Hkv][nsplit][Hq/Hkv][D] and part_ml fp32 [B*Hkv][nsplit][Hq/Hkv][2] are scratch
  * (same sizes as vlm_attn_decode_paged's); tickets: uint32 [B*Hkv], ZERO before the first launch - every launch leaves
  * it zero again.  Launches that share part_o / part_ml / tickets must be stream-ordered. */
+/* out == NULL: the partial-only form.  Nothing is merged and no ticket is taken (tickets may be NULL): every split s
+ * of every head writes (m, l) - m in the log2 domain, (-inf, 0) for a split with no page - to part_ml fp32
+ * [B][Hq][nsplit][2] and, when it has pages, its unnormalised O as bf16 to part_o [B][Hq][nsplit][D]; the launch ends
+ * at those (plain) stores and vlm_gemv_attn_out_bf16 merges them in the o_proj prologue. */
 int vlm_attn_decode_paged_split(const void* q, int ldq, const void* kpool, const void* vpool, const void* block_table,
                                 int max_pages, const void* kv_len, int kv_len_add, int B, int Hq, int Hkv, int D,
                                 float scale, int nsplit, void* part_o, void* part_ml, void* tickets, void* out, int ldo,
                                 void* stream);
+
+/* h[0][0:N] += merge(partials of vlm_attn_decode_paged_split's partial-only form) Wo^T for ONE decode row
+ * (language.py:115-120,151): every thread of the o_proj GEMV loads one 8-element chunk of all nsplit <= 16 bf16 partials
+ * and their (m, l) ahead of its weight stream and merges them in registers.  Hq * D <= 2048. */
+int vlm_gemv_attn_out_bf16(const void* part_o, const void* part_ml, int nsplit, const void* Wo, void* h, int ldh, int N,
+                           int Hq, int D, void* stream);
 
 /* nn.Embedding (language.py:164,179): out[t] = table[ids[t]] */
 int vlm_embed_gather(const void* ids, const void* table, void* out, int T, int D, int ldo, int vocab, void* stream);
@@ -377,7 +387,10 @@ int vlm_llm_decode_launches(void* handle);
                                        the caller asked for a split, i.e. a long context); 0 = the round-2 forms (one workgroup
                                        per pair, or split-K partials merged in the o_proj prologue) - A/B knob */
 #define VLM_TUNE_GEMV_VARIANT 8     /* A/B knob of the batch-1 GEMV launch shapes (bit 0: down projection with 6 rows per
-                                       workgroup = one workgroup per CU at N = 1536) */
+                                       workgroup = one workgroup per CU at N = 1536; bit 1: 3 rows) */
+#define VLM_TUNE_ATTN_MERGE 9       /* where the page-split attention of a ONE-row step is merged: 1 (default) = in the o_proj
+                                       GEMV's prologue (partial-only attention launch, vlm_gemv_attn_out_bf16; needs bf16 Wo,
+                                       Hq * D <= 2048, <= 16 splits), 0 = by the attention launch's last-arriving workgroup */
 int vlm_llm_set_tuning(void* handle, int key, int value);
 int vlm_llm_get_tuning(void* handle, int key);
 /* diagnostic of the in-launch hand-offs (VLM_TUNE_FUSED_MLP): 0 = every bounded wait completed since the last call;

@@ -80,7 +80,7 @@ class VitArgs(C.Structure):
 
 DECODE_FUSED_TAIL = 1                       # vlm_decode_args.flags
 TUNE_PREFETCH, TUNE_PREFETCH_WGS, TUNE_PREFETCH_MASK, TUNE_PREFETCH_HEAD_MB, TUNE_DEBUG_SKIP, TUNE_FUSED_MLP, TUNE_MFMA_GEMV = 0, 1, 2, 3, 4, 5, 6  # vlm_llm_set_tuning keys
-TUNE_ATTN_PAGESPLIT, TUNE_GEMV_VARIANT = 7, 8
+TUNE_ATTN_PAGESPLIT, TUNE_GEMV_VARIANT, TUNE_ATTN_MERGE = 7, 8, 9
 
 P = C.POINTER
 # name -> (restype, argtypes); every symbol include/vlm_hip.h declares
@@ -117,6 +117,7 @@ SIGNATURES = {
                               + [c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vlm_attn_decode_paged_split": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 5
                                     + [c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "vlm_gemv_attn_out_bf16": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "vlm_embed_gather": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "vlm_scatter_image_rows": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "vlm_cast_f32_bf16_pad": (c_int, [c_void_p] * 2 + [c_int] * 4 + [c_void_p]),

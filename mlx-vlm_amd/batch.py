@@ -314,6 +314,7 @@ class BatchGenerator:
         s.generation_time = self._gen_time_counter
         s.generation_tps = self._gen_tokens_counter / self._gen_time_counter if self._gen_time_counter > 0 else 0
         s.peak_memory = _peak_gb()
+        s.decode_steps = self._steps_counter       # (not a reference field: graph replays so far, for the roofline of a job)
         return s
 
     def close(self):

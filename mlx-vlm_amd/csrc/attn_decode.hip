@@ -154,8 +154,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
         st[t][r] = sv;
         mt = fmaxf(mt, sv);
       }
-    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    mt = col4_max(mt);
     const float m_new = fmaxf(m_run, mt);
     const float m_use = m_new == -INFINITY ? 0.f : m_new;    // a wave with no valid key yet: p = exp2(-inf - 0) = 0
     const float alpha = exp2f(m_run - m_use);
@@ -202,8 +201,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
 
   if (STAMPS) { asm volatile("" :: "v"(ot[7][3])); stamp(5); }
   // ---- merge the waves of the workgroup: ot[dt][r] = O^T[d = 16dt + 4gq + r][head]
-  l_run += __shfl_xor(l_run, 16, 64);
-  l_run += __shfl_xor(l_run, 32, 64);
+  l_run = col4_sum(l_run);
   if (head < G) {
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt)
@@ -257,7 +255,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
 // producers stored sc1: no acquire fence needed), merges in fp32, stores bf16 and re-arms the ticket word (every
 // workgroup has arrived by then).  Workgroups whose first page lies beyond the context store nothing and only arrive.
 // tickets: one zero-initialised word per (sequence, kv head), owned by the caller, zero again after every launch.
-template <int G, bool IDENT>
+template <int G, bool IDENT, bool MERGE>
 __global__ __launch_bounds__(64) void attn_decode_pagesplit_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ kpool, const bf16_t* __restrict__ vpool,
     const int* __restrict__ block_table, const int* __restrict__ kv_len, int ldq, int max_pages, int Hkv, int kv_len_add,
@@ -330,8 +328,7 @@ __global__ __launch_bounds__(64) void attn_decode_pagesplit_kernel(
         st[t][r] = sv;
         mt = fmaxf(mt, sv);
       }
-    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    mt = col4_max(mt);
     const float m_new = fmaxf(m_run, mt);
     const float m_use = m_new == -INFINITY ? 0.f : m_new;
     const float alpha = exp2f(m_run - m_use);
@@ -372,8 +369,23 @@ __global__ __launch_bounds__(64) void attn_decode_pagesplit_kernel(
     page = next_page;
   } while (true);
 
-  l_run += __shfl_xor(l_run, 16, 64);
-  l_run += __shfl_xor(l_run, 32, 64);
+  l_run = col4_sum(l_run);
+  if (!MERGE) {
+    // partials for the o_proj prologue (vlm_gemv_attn_out_bf16): EVERY split writes (m, l) - a split with no page writes
+    // (-inf, 0) and is skipped there - and the splits with pages their O^T as bf16 [b][head][s][d] (plain stores: the
+    // kernel boundary publishes them).  m stays in the log2 domain of this kernel.
+    if (head < G) {
+      const size_t e = ((size_t)b * (Hkv * G) + (g * G + head)) * S + s;
+      if (gq == 0) *reinterpret_cast<float2*>(part_ml + e * 2) = make_float2(m_run, l_run);
+      if (m_run != -INFINITY) {
+        bf16_t* po = reinterpret_cast<bf16_t*>(part_o) + e * HD + 4 * gq;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt)
+          *reinterpret_cast<uint2*>(po + 16 * dt) = make_uint2(pack_bf2(ot[dt][0], ot[dt][1]), pack_bf2(ot[dt][2], ot[dt][3]));
+      }
+    }
+    return;
+  }
   const int n_act = min(S, npages);                // splits that own at least one page of this context
   const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(part_o, 0, 0x7fffffff, 0x00020000);   // (offsets checked by the launcher)
   typedef unsigned long long u64;
@@ -534,7 +546,8 @@ extern "C" int vlm_attn_decode_paged_split(const void* q, int ldq, const void* k
                                            const void* block_table, int max_pages, const void* kv_len, int kv_len_add, int B,
                                            int Hq, int Hkv, int D, float scale, int nsplit, void* part_o, void* part_ml,
                                            void* tickets, void* out, int ldo, void* stream) {
-  if (!q || !kpool || !vpool || !kv_len || !part_o || !part_ml || !tickets || !out || max_pages <= 0) return VLM_ERR_ARG;
+  if (!q || !kpool || !vpool || !kv_len || !part_o || !part_ml || max_pages <= 0) return VLM_ERR_ARG;
+  if (out && !tickets) return VLM_ERR_ARG;
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || nsplit <= 0 || nsplit > 65535 || Hq % Hkv != 0) return VLM_ERR_ARG;
   if (D != HD || ldq % 8 != 0 || ldo % 4 != 0) return VLM_ERR_SHAPE;
   if ((size_t)B * Hq * nsplit * HD * 4 >= ((size_t)1 << 31)) return VLM_ERR_SHAPE;   // 32-bit buffer offsets
@@ -542,16 +555,15 @@ extern "C" int vlm_attn_decode_paged_split(const void* q, int ldq, const void* k
   hipStream_t st = (hipStream_t)stream;
   const float sl2 = scale * 1.44269504088896340736f;
   dim3 grid(B * Hkv, nsplit);
+#define GO1(GV, ID, MG)                                                                                                  \
+  hipLaunchKernelGGL((attn_decode_pagesplit_kernel<GV, ID, MG>), grid, dim3(64), 0, st, (const bf16_t*)q,                 \
+                     (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)block_table, (const int*)kv_len, ldq, max_pages, \
+                     Hkv, kv_len_add, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, (unsigned*)tickets, (bf16_t*)out)
 #define GO(GV)                                                                                                           \
-  if (!block_table)                                                                                                      \
-    hipLaunchKernelGGL((attn_decode_pagesplit_kernel<GV, true>), grid, dim3(64), 0, st, (const bf16_t*)q,                \
-                       (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)nullptr, (const int*)kv_len, ldq, max_pages, \
-                       Hkv, kv_len_add, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, (unsigned*)tickets, (bf16_t*)out); \
-  else                                                                                                                   \
-    hipLaunchKernelGGL((attn_decode_pagesplit_kernel<GV, false>), grid, dim3(64), 0, st, (const bf16_t*)q,               \
-                       (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)block_table, (const int*)kv_len, ldq,       \
-                       max_pages, Hkv, kv_len_add, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, (unsigned*)tickets,  \
-                       (bf16_t*)out)
+  do {                                                                                                                   \
+    if (!block_table) { if (out) GO1(GV, true, true); else GO1(GV, true, false); }                                       \
+    else { if (out) GO1(GV, false, true); else GO1(GV, false, false); }                                                  \
+  } while (0)
   switch (G) {
     case 1: GO(1); break;
     case 2: GO(2); break;
@@ -564,6 +576,7 @@ extern "C" int vlm_attn_decode_paged_split(const void* q, int ldq, const void* k
     default: return VLM_ERR_SHAPE;
   }
 #undef GO
+#undef GO1
   VLM_CHECK_LAUNCH();
   return VLM_OK;
 }

@@ -229,7 +229,11 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[kb][r]);
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * scale_log2;         // scale_log2 > 0
+    {
+      float ma, mb;
+      vlm_xor32_pair(mt, ma, mb);                                 // lanes l / l ^ 32 in one v_permlane32_swap (no LDS round trip)
+      mt = fmaxf(ma, mb) * scale_log2;                            // scale_log2 > 0
+    }
     if (__any(mt > m_run + 8.0f)) {                                // wave-uniform: move the reference max
       const float m_new = fmaxf(m_run, mt);
       const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);   // m_run = -inf -> 0
@@ -302,7 +306,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
     for (int i = 0; i < 6; ++i) g_attn_stamps[wave][i] = st_sum[i];
 #endif
   // ---- normalise and store: lane holds O^T[d = db*32 + (r&3) + 8(r>>2) + 4h][q = lane&31] ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  float l_a, l_b;
+  vlm_xor32_pair(l_run, l_a, l_b);
+  const float l_tot = l_a + l_b;
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   if (qrow < seg_len) {
     bf16_t* orow = op + (size_t)(seg_start + qrow) * o_stride + (size_t)head * D;

@@ -49,15 +49,63 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 // round a float through bf16 (typed-graph emulation of a materialised T tensor)
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
+// Wave-wide reductions on the DPP data path.  __shfl_xor compiles to ds_bpermute_b32 on gfx950 - an LDS-crossbar round
+// trip of ~100 cycles per step, six dependent steps per reduction, on the critical tail of every GEMV launch (found in the
+// .s of gemv_rowwave_kernel).  DPP operands ride inside the VALU instruction (v_add_f32_dpp): quad swaps, row_half_mirror
+// and row_mirror leave every 16-lane row with its row sum; row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3) carry
+// the row sums up so that lane 63 holds the total, which v_readlane_b32 broadcasts through an SGPR.  Result in EVERY lane
+// (as the xor butterfly gave); fp32 summation order differs from the butterfly's.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float vlm_dpp(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                               ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += vlm_dpp<0xB1, 0xf>(0.f, v);     // quad_perm [1,0,3,2]
+  v += vlm_dpp<0x4E, 0xf>(0.f, v);     // quad_perm [2,3,0,1]
+  v += vlm_dpp<0x141, 0xf>(0.f, v);    // row_half_mirror
+  v += vlm_dpp<0x140, 0xf>(0.f, v);    // row_mirror
+  v += vlm_dpp<0x142, 0xa>(0.f, v);    // row_bcast:15 into rows 1 and 3
+  v += vlm_dpp<0x143, 0xc>(0.f, v);    // row_bcast:31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, vlm_dpp<0xB1, 0xf>(v, v));
+  v = fmaxf(v, vlm_dpp<0x4E, 0xf>(v, v));
+  v = fmaxf(v, vlm_dpp<0x141, 0xf>(v, v));
+  v = fmaxf(v, vlm_dpp<0x140, 0xf>(v, v));
+  v = fmaxf(v, vlm_dpp<0x142, 0xa>(v, v));
+  v = fmaxf(v, vlm_dpp<0x143, 0xc>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// lane l <-> lane l ^ 16 / l ^ 32 exchanges as ONE gfx950 instruction each (v_permlane16_swap_b32 / v_permlane32_swap_b32:
+// with both operands = v, the results are [r0 r0 r2 r2] | [r1 r1 r3 r3] resp. [lo lo] | [hi hi]) instead of a ds_bpermute
+__device__ __forceinline__ void vlm_xor16_pair(float v, float& a, float& b) {
+  typedef unsigned int u32x2_t_ __attribute__((ext_vector_type(2)));
+  const u32x2_t_ r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  a = __builtin_bit_cast(float, r[0]);
+  b = __builtin_bit_cast(float, r[1]);
+}
+__device__ __forceinline__ void vlm_xor32_pair(float v, float& a, float& b) {
+  typedef unsigned int u32x2_t_ __attribute__((ext_vector_type(2)));
+  const u32x2_t_ r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  a = __builtin_bit_cast(float, r[0]);
+  b = __builtin_bit_cast(float, r[1]);
+}
+// reductions over the 4 lanes {l & 15, + 16, + 32, + 48} (one MFMA column held by the four 16-lane rows)
+__device__ __forceinline__ float col4_max(float v) {
+  float a, b;
+  vlm_xor16_pair(v, a, b);
+  v = fmaxf(a, b);
+  vlm_xor32_pair(v, a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float col4_sum(float v) {
+  float a, b;
+  vlm_xor16_pair(v, a, b);
+  v = a + b;
+  vlm_xor32_pair(v, a, b);
+  return a + b;
 }
 
 // block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` = >=16 floats of LDS

@@ -49,6 +49,7 @@ struct Tuning {
   int prefetch = 0, wgs = 256, mask = 0x7f, head_mb = 96, debug_skip = 0, fused_mlp = 0, mfma_gemv = 1;
   int attn_pagesplit = 16;                // vlm_attn_decode_paged_split with up to this many workgroups per (row, kv head)
   int gemv_variant = 0;                   // A/B bits of the batch-1 GEMV launch shapes (VLM_TUNE_GEMV_VARIANT)
+  int attn_merge = 1;                     // 1: one-row steps merge the page-split partials in the o_proj prologue
 };
 
 // the second branch of a captured step (prefetch side chain)
@@ -172,6 +173,7 @@ extern "C" int vlm_llm_set_tuning(void* handle, int key, int value) {
     case VLM_TUNE_MFMA_GEMV: if (value < 0 || value > 1) return 1; slot = &m->tune.mfma_gemv; break;
     case VLM_TUNE_ATTN_PAGESPLIT: if (value < 0 || value > 32) return 1; slot = &m->tune.attn_pagesplit; break;
     case VLM_TUNE_GEMV_VARIANT: if (value < 0) return 1; slot = &m->tune.gemv_variant; break;
+    case VLM_TUNE_ATTN_MERGE: if (value < 0 || value > 1) return 1; slot = &m->tune.attn_merge; break;
     case VLM_TUNE_FUSED_MLP: {
       if (value < 0 || value > 1) return 1;
       slot = &m->tune.fused_mlp;
@@ -236,6 +238,7 @@ extern "C" int vlm_llm_get_tuning(void* handle, int key) {
     case VLM_TUNE_MFMA_GEMV: return m->tune.mfma_gemv;
     case VLM_TUNE_ATTN_PAGESPLIT: return m->tune.attn_pagesplit;
     case VLM_TUNE_GEMV_VARIANT: return m->tune.gemv_variant;
+    case VLM_TUNE_ATTN_MERGE: return m->tune.attn_merge;
     default: return -1;
   }
 }
@@ -438,10 +441,15 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
       if (psplit > 256 / (B * Hkv)) psplit = 256 / (B * Hkv);
       if (psplit < 2) psplit = 0;
     }
+    // ... and for ONE row over bf16 Wo the merge moves into the o_proj prologue: the attention launch ends at its partial
+    // stores (no ticket, no last-arriver pass)
+    const bool merge_in_oproj = psplit && tn.attn_merge && B == 1 && !w.wo_sb && Hq * hd <= 2048 && psplit <= 16 &&
+                                !(tn.fused_mlp && m->fm_buf);
     if (skip & 2) {
     } else if (psplit) {
       TRY(vlm_attn_decode_paged_split(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale,
-                                      psplit, a->part_o, a->part_ml, m->attn_tickets, a->attn, Hq * hd, stream)); ++n;
+                                      psplit, a->part_o, a->part_ml, m->attn_tickets, merge_in_oproj ? nullptr : a->attn, Hq * hd,
+                                      stream)); ++n;
     } else if (a->nsplit == 1) {
       // short contexts: one workgroup per (sequence, kv head) -> final bf16 vector, plain o_proj GEMV + residual
       TRY(vlm_attn_decode_paged_ex(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale, 1,
@@ -479,6 +487,8 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
       continue;
     }
     if (skip & 4) {
+    } else if (merge_in_oproj) {
+      TRY(vlm_gemv_attn_out_bf16(a->part_o, a->part_ml, psplit, w.wo, a->h, D, D, Hq, hd, stream)); ++n;
     } else if (psplit || a->nsplit == 1 || combine) {
       TRY(lin_gemv(m, a->attn, w.wo, w.wo_sb, nullptr, a->h, nullptr, a->h, B, D, Hq * hd, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
     } else {

@@ -30,7 +30,7 @@
 
 namespace {
 
-enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_ATTN = 2 };
+enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_ATTN = 2, PRO_ATTN_BF16 = 3 };
 constexpr int EPI_ROPE_KV = 1 << 10;   // internal epilogue id (qkv projection)
 
 struct RopeKvArgs {
@@ -45,10 +45,11 @@ struct RopeKvArgs {
 };
 
 struct AttnProArgs {
-  const float* part_o;       // [M][Hq][S][D]
-  const float* part_ml;      // [M][Hq][S][2]
+  const float* part_o;       // [M][Hq][S][D]  (PRO_ATTN_BF16: bf16 elements, the page-split attention's partials)
+  const float* part_ml;      // [M][Hq][S][2]  (PRO_ATTN: m in the natural-log domain; PRO_ATTN_BF16: log2 domain, -inf = no page)
   int S, Hq, D;
 };
+constexpr int AT2_S = 16;    // splits the PRO_ATTN_BF16 prologue reads (all of them, unconditionally)
 
 __device__ __forceinline__ u32x4_t ntl(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)); }
 
@@ -143,6 +144,24 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
           at_o[it][sp][1] = po[1];
         }
       }
+    }
+  }
+  // PRO_ATTN_BF16 (M == 1, K <= 2048, S <= 16): the merge of the page-split decode attention (attn_decode.hip, MERGE =
+  // false) - one 8-element chunk of x per thread, EVERY split's (m, l) and bf16 O chunk loaded unconditionally (a split
+  // without a page carries m = -inf and is dropped by a select; its O bytes may be anything), all of it issued here, ahead
+  // of the weight stream: the attention launch ends at its partial stores (no ticket, no last-arriver pass), and this
+  // kernel pays S * 24 B per thread of L2 reads in front of its weights
+  float2 a2_ml[PRO == PRO_ATTN_BF16 ? AT2_S : 1];
+  u32x4_t a2_o[PRO == PRO_ATTN_BF16 ? AT2_S : 1];
+  if (PRO == PRO_ATTN_BF16) {
+    const int ch = min(tid, nchunk - 1), hd0 = ch * 8;
+    const size_t base = (size_t)(hd0 / ap.D) * ap.S;
+    const bf16_t* po = reinterpret_cast<const bf16_t*>(ap.part_o);
+#pragma unroll
+    for (int sp = 0; sp < AT2_S; ++sp) {
+      const size_t e = base + min(sp, ap.S - 1);
+      a2_ml[sp] = *reinterpret_cast<const float2*>(ap.part_ml + e * 2);
+      a2_o[sp] = *reinterpret_cast<const u32x4_t*>(po + e * ap.D + hd0 % ap.D);
     }
   }
   // epilogue operands (bias / residual / rope position, slot, page) for the lane that will store
@@ -250,6 +269,32 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
         o.z = pack_bf2(acc8[4], acc8[5]); o.w = pack_bf2(acc8[6], acc8[7]);
         reinterpret_cast<uint4*>(xs)[item] = o;     // item = m * nchunk + chunk: xs is [MB][K]
       }
+    }
+  } else if (PRO == PRO_ATTN_BF16) {
+    // x[h*D + d] = sum_s f_s O_s[d] / sum_s f_s l_s,  f_s = 2^(m_s - M)
+    float mm = -INFINITY;
+#pragma unroll
+    for (int sp = 0; sp < AT2_S; ++sp) mm = fmaxf(mm, sp < ap.S ? a2_ml[sp].x : -INFINITY);
+    float ll = 0.f, acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sp = 0; sp < AT2_S; ++sp) {
+      const bool on = sp < ap.S && a2_ml[sp].x != -INFINITY;
+      const float f = on ? exp2f(a2_ml[sp].x - mm) : 0.f;
+      ll += on ? f * a2_ml[sp].y : 0.f;
+      const u32x4_t o = a2_o[sp];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned w = o[j];
+        acc8[2 * j] += on ? f * bf_lo(w) : 0.f;
+        acc8[2 * j + 1] += on ? f * bf_hi(w) : 0.f;
+      }
+    }
+    const float il = 1.0f / ll;
+    if (tid < nchunk) {
+      uint4 o;
+      o.x = pack_bf2(acc8[0] * il, acc8[1] * il); o.y = pack_bf2(acc8[2] * il, acc8[3] * il);
+      o.z = pack_bf2(acc8[4] * il, acc8[5] * il); o.w = pack_bf2(acc8[6] * il, acc8[7] * il);
+      reinterpret_cast<uint4*>(smem)[tid] = o;
     }
   } else if (PRO == PRO_ATTN) {
     // general form (more splits / rows): three short phases so that every global load of a phase is independent
@@ -636,6 +681,16 @@ VLM_INTERNAL int vlm_gemv_qkv_rope_kvwrite_ex(const void* h, const void* norm_w,
                     D, (bf16_t*)kpool, (bf16_t*)vpool, qk_scale},
          AttnProArgs{}, (hipStream_t)stream};
   return launch_rw_m<PRO_RMSNORM, EPI_ROPE_KV>(M, a);
+}
+
+extern "C" int vlm_gemv_attn_out_bf16(const void* part_o, const void* part_ml, int nsplit, const void* Wo, void* h, int ldh,
+                                      int N, int Hq, int D, void* stream) {
+  if (!part_o || !part_ml || !Wo || !h || nsplit <= 0 || nsplit > AT2_S) return VLM_ERR_ARG;
+  const int K = Hq * D;
+  if (K % 8 || K > 2048 || D % 8) return VLM_ERR_SHAPE;     // one x chunk per thread
+  Args a{nullptr, Wo, nullptr, h, nullptr, h, N, K, K, K, ldh, ldh, 0.f, RopeKvArgs{},
+         AttnProArgs{(const float*)part_o, (const float*)part_ml, nsplit, Hq, D}, (hipStream_t)stream};
+  return launch_rw_k<1, PRO_ATTN_BF16, VLM_EPI_RESIDUAL>(a);
 }
 
 extern "C" int vlm_gemv_attn_out(const void* part_o, const void* part_ml, int nsplit, const void* Wo, void* h, int ldh,

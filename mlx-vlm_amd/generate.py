@@ -444,10 +444,12 @@ def embed_requests(model, input_ids_list, pixel_values_list, grids, extras=None)
 
 def batch_generate_ids(model, input_ids_list: List[np.ndarray], pixel_values_list: List[Any], grids: List[Any], *,
                        max_tokens: int = 128, stop_ids=(), sampler: Optional[Sampler] = None, lookahead: int = 4,
-                       use_graph: bool = True) -> Tuple[List[List[int]], BatchStats]:
+                       use_graph: bool = True, extras: Optional[List[Optional[dict]]] = None) -> Tuple[List[List[int]], BatchStats]:
     """Pre-tokenised batched generation: the requests are processed in decode batches of up to 16 sequences.
     One ViT call over the concatenated patches of the batch (as the reference does per shape group,
-    ar.py:3165-3167), one varlen LLM prefill, then batched graph decode.  -> (tokens per request, stats)."""
+    ar.py:3165-3167), one varlen LLM prefill, then batched graph decode.  -> (tokens per request, stats).
+    `extras`: per-request keyword arguments of the family's `get_input_embeddings` (phi3_v: image_sizes; idefics2:
+    pixel_attention_mask), as `generate_batch_continuous` takes them."""
     lm = model.language_model
     smp = sampler or make_sampler()
     sargs = smp.engine_args()
@@ -464,7 +466,8 @@ def batch_generate_ids(model, input_ids_list: List[np.ndarray], pixel_values_lis
         i += B
         t0 = time.perf_counter()
         emb_cat, pos_cat, lens, deltas = embed_requests(model, [input_ids_list[j] for j in idxs],
-                                                        [pixel_values_list[j] for j in idxs], [grids[j] for j in idxs])
+                                                        [pixel_values_list[j] for j in idxs], [grids[j] for j in idxs],
+                                                        extras=[extras[j] for j in idxs] if extras else None)
         caches = lm.make_cache_batch(len(idxs))
         logits = lm.prefill(emb_cat, pos_cat, caches, lens, "last", reserve_extra=max_tokens + 2)
         step0 = torch.zeros(1, dtype=torch.int32, device=logits.device)
@@ -522,19 +525,21 @@ def batch_generate(model, processor, images=None, audios=None, prompts: Optional
     prompts = list(prompts or [])
     images = list(images) if images is not None else [None] * len(prompts)
     tokenizer = _tokenizer_of(processor)
-    ids_l, pix_l, grid_l, sizes = [], [], [], []
+    ids_l, pix_l, grid_l, sizes, extras = [], [], [], [], []
     for p, im in zip(prompts, images):
         sizes.append(_image_hw(im))
         inp = prepare_inputs(processor, images=im, prompts=p)
         ids_l.append(np.asarray(inp["input_ids"]).reshape(-1))
         pix_l.append(inp.get("pixel_values"))
         grid_l.append(inp.get("image_grid_thw"))
+        # the model family's own get_input_embeddings arguments (phi3_v: image_sizes, idefics2: pixel_attention_mask)
+        extras.append({k: v for k, v in inp.items() if k not in ("input_ids", "pixel_values", "image_grid_thw", "attention_mask")})
     stop = getattr(tokenizer, "stopping_criteria", None)
     stop_ids = tuple(getattr(stop, "eos_token_ids", ()) or ())
     smp = _resolve_sampler(kwargs.pop("sampler", None), kwargs.pop("temperature", 0.0), kwargs.pop("top_p", 1.0),
                            kwargs.pop("min_p", 0.0), kwargs.pop("top_k", 0), kwargs.pop("seed", None))
     run = generate_batch_continuous if kwargs.pop("continuous", True) else batch_generate_ids
-    toks, stats = run(model, ids_l, pix_l, grid_l, max_tokens=max_tokens, stop_ids=stop_ids, sampler=smp)
+    toks, stats = run(model, ids_l, pix_l, grid_l, max_tokens=max_tokens, stop_ids=stop_ids, sampler=smp, extras=extras)
     texts = [tokenizer.decode(t) if hasattr(tokenizer, "decode") else "" for t in toks]
     return BatchResponse(texts=texts, stats=stats, tokens=toks, image_sizes=sizes if track_image_sizes else None)
 

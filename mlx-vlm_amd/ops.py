@@ -217,11 +217,29 @@ def attn_decode_paged(q, kpool, vpool, block_table, kv_len, kv_len_add, Hq, Hkv,
     return out if merge else (part_o, part_ml)
 
 
+def gemv_attn_out_bf16_(part_o, part_ml, wo, h, Hq, D):
+    """h[0] += merge(page-split partials) @ wo.T in place (one decode row)"""
+    _dev(part_o, part_ml, wo, h)
+    check(_lib.lib().vlm_gemv_attn_out_bf16(_p(part_o), _p(part_ml), part_o.shape[2], _p(wo), _p(h), h.stride(0), wo.shape[0],
+                                            Hq, D, _stream()), "gemv_attn_out_bf16")
+    return h
+
+
 def attn_decode_paged_split(q, kpool, vpool, block_table, kv_len, kv_len_add, Hq, Hkv, D, scale, nsplit, out=None,
-                            max_pages=None, tickets=None):
-    """page-split decode attention (one wave per page stride, last arriver merges) -> bf16 [B, Hq*D]"""
+                            max_pages=None, tickets=None, merge=True):
+    """page-split decode attention (one wave per page stride).  merge=True: the last arriver merges -> bf16 [B, Hq*D];
+    merge=False: the partial-only form -> (part_o bf16 [B, Hq, nsplit, D], part_ml fp32 [B, Hq, nsplit, 2]) for
+    gemv_attn_out_bf16_."""
     _dev(q, kpool, vpool, block_table, kv_len)
     B = q.shape[0]
+    if not merge:
+        part_o = torch.full((B, Hq, nsplit, D), float("nan"), dtype=torch.bfloat16, device=q.device)   # unwritten = NaN on purpose
+        part_ml = torch.empty(B, Hq, nsplit, 2, dtype=torch.float32, device=q.device)
+        check(_lib.lib().vlm_attn_decode_paged_split(_p(q), q.stride(0), _p(kpool), _p(vpool), _p(block_table),
+                                                     block_table.shape[1] if block_table is not None else int(max_pages),
+                                                     _p(kv_len), kv_len_add, B, Hq, Hkv, D, scale, nsplit, _p(part_o),
+                                                     _p(part_ml), None, None, 0, _stream()), "attn_decode_split")
+        return part_o, part_ml
     part_o = torch.empty(B, Hq, nsplit, D, dtype=torch.float32, device=q.device)
     part_ml = torch.empty(B, Hq, nsplit, 2, dtype=torch.float32, device=q.device)
     if tickets is None:

@@ -141,7 +141,8 @@ def dp_batch_generate(model, processor, prompts=None, images=None, *, requests=N
     collective inside the prefill / decode steps; the token lists are gathered on `dst` at the end.
 
     requests: pre-tokenised dicts {"input_ids", "pixel_values"?, "image_grid_thw"?, "max_tokens"?} (bypass, as
-    dispatch.py:759-762) - or prompts (+ one image each), tokenised on every rank.
+    dispatch.py:759-762) - or prompts (+ one image each): every rank tokenises / image-processes ONLY the requests it is
+    dealt (the deal then sorts by a tokeniser-free length proxy).
     serve(indices, requests, max_tokens) -> list of token lists: the per-rank engine (default: the continuous generator);
     replaced by a mock in the CPU tests.
     -> on `dst`: {"tokens": per request in the ORIGINAL order, "texts", "ranks", "per_rank_requests", "generation_tokens",
@@ -153,21 +154,31 @@ def dp_batch_generate(model, processor, prompts=None, images=None, *, requests=N
     rank, ws, _ = world()
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         rank, ws = 0, 1
+    mt_default = max_tokens
     if requests is None:
+        # prompts: the deal needs a length BEFORE anything is tokenised - the host-side tokeniser + image processor is the
+        # resource that scales worst with the rank count, so every rank prepares ONLY its own requests.
+        # Proxy of the reference's token-length sort key: characters of the prompt, an image counts as 1024 characters
+        # (identical on every rank, no tokeniser involved).
         from .utils import prepare_inputs
 
         prompts = list(prompts or [])
         images = list(images) if images is not None else [None] * len(prompts)
-        requests = []
-        for p, im in zip(prompts, images):
-            inp = prepare_inputs(processor, images=im, prompts=p)
-            requests.append({"input_ids": np.asarray(inp["input_ids"]).reshape(-1), "pixel_values": inp.get("pixel_values"),
-                             "image_grid_thw": inp.get("image_grid_thw"),
-                             **{k: v for k, v in inp.items() if k not in _REQUEST_KEYS and k != "attention_mask"}})
-    n = len(requests)
-    lengths = [int(np.asarray(r["input_ids"]).size) for r in requests]
-    mine = shard_requests(n, rank, ws, lengths)
-    mt = [int(r.get("max_tokens", max_tokens)) for r in requests]
+        n = len(prompts)
+        lengths = [len(p) + (1024 if im is not None else 0) for p, im in zip(prompts, images)]
+        mine = shard_requests(n, rank, ws, lengths)
+        requests = [None] * n
+        for i in mine:
+            inp = prepare_inputs(processor, images=images[i], prompts=prompts[i])
+            requests[i] = {"input_ids": np.asarray(inp["input_ids"]).reshape(-1), "pixel_values": inp.get("pixel_values"),
+                           "image_grid_thw": inp.get("image_grid_thw"),
+                           **{k: v for k, v in inp.items() if k not in _REQUEST_KEYS and k != "attention_mask"}}
+        mt = [int(mt_default)] * n
+    else:
+        n = len(requests)
+        lengths = [int(np.asarray(r["input_ids"]).size) for r in requests]
+        mine = shard_requests(n, rank, ws, lengths)
+        mt = [int(r.get("max_tokens", max_tokens)) for r in requests]
     if serve is None:
         def serve(indices, reqs, max_toks):
             from .batch import generate_batch_continuous
@@ -176,19 +187,28 @@ def dp_batch_generate(model, processor, prompts=None, images=None, *, requests=N
                 return []
             tok = getattr(processor, "tokenizer", processor)
             stop = getattr(getattr(tok, "stopping_criteria", None), "eos_token_ids", ()) or ()
-            toks, _ = generate_batch_continuous(model, [reqs[i]["input_ids"] for i in indices],
-                                                [reqs[i].get("pixel_values") for i in indices],
-                                                [reqs[i].get("image_grid_thw") for i in indices],
-                                                max_tokens=[max_toks[i] for i in indices], stop_ids=tuple(stop),
-                                                extras=[{k: v for k, v in reqs[i].items() if k not in _REQUEST_KEYS} for i in indices],
-                                                **kwargs)
-            return toks
+            toks, st = generate_batch_continuous(model, [reqs[i]["input_ids"] for i in indices],
+                                                 [reqs[i].get("pixel_values") for i in indices],
+                                                 [reqs[i].get("image_grid_thw") for i in indices],
+                                                 max_tokens=[max_toks[i] for i in indices], stop_ids=tuple(stop),
+                                                 extras=[{k: v for k, v in reqs[i].items() if k not in _REQUEST_KEYS} for i in indices],
+                                                 **kwargs)
+            return toks, st
     barrier()
     t0 = time.perf_counter()
     local = serve(mine, requests, mt)
+    st = None
+    if isinstance(local, tuple):            # the default engine also hands back its BatchStats (a mock may return tokens only)
+        local, st = local
     if torch.cuda.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
         torch.cuda.synchronize()
     wall = max_over_ranks(time.perf_counter() - t0)
+    # decode / prefill split of the job: tokens summed, times maximised over the ranks (what a whole-job rate divides by)
+    gen_time = max_over_ranks(float(getattr(st, "generation_time", 0.0) or 0.0))
+    pre_time = max_over_ranks(float(getattr(st, "prompt_time", 0.0) or 0.0))
+    gen_tok = sum_over_ranks(float(getattr(st, "generation_tokens", 0) or 0))
+    pre_tok = sum_over_ranks(float(getattr(st, "prompt_tokens", 0) or 0))
+    dec_steps = sum_over_ranks(float(getattr(st, "decode_steps", 0) or 0))
     parts = gather_results(list(zip(mine, [list(map(int, t)) for t in local])), dst=dst)
     if rank != dst:
         return None
@@ -200,7 +220,9 @@ def dp_batch_generate(model, processor, prompts=None, images=None, *, requests=N
     texts = [tok.decode(t) if (tok is not None and hasattr(tok, "decode")) else "" for t in tokens]
     total = sum(len(t) for t in tokens)
     return {"tokens": tokens, "texts": texts, "ranks": ws, "per_rank_requests": [len(p) for p in parts],
-            "generation_tokens": total, "wall_s": wall, "tokens_per_s": total / max(wall, 1e-9)}
+            "generation_tokens": total, "wall_s": wall, "tokens_per_s": total / max(wall, 1e-9),
+            "decode_tokens": int(gen_tok), "decode_time_s": gen_time, "prompt_tokens": int(pre_tok), "prompt_time_s": pre_time,
+            "decode_steps": int(dec_steps)}
 
 
 def gather_results(local: List, dst: int = 0) -> List[List] | None:

@@ -61,8 +61,11 @@ def make_sampler(temp: float = 0.0, top_p: float = 0.0, min_p: float = 0.0, min_
         raise NotImplementedError("min_tokens_to_keep > 1 is not built")
     if not (0 <= min_p <= 1.0):
         raise ValueError(f"`min_p` has to be a float in the [0, 1] interval, but is {min_p}")
-    return Sampler(temp=temp, top_p=top_p, min_p=min_p, top_k=top_k,
-                   seed=(next(_unseeded) & 0xFFFFFFFF) if seed is None else int(seed))
+    # greedy: the seed is never read, and it is part of the captured step's key - a fresh seed per call would make every
+    # default generate() re-capture its decode graph; unseeded SAMPLING draws a fresh stream per sampler
+    if seed is None:
+        seed = 0 if temp == 0 else next(_unseeded) & 0xFFFFFFFF
+    return Sampler(temp=temp, top_p=top_p, min_p=min_p, top_k=top_k, seed=int(seed))
 
 
 HIST_CAP = 256      # device token history per decode row (csrc/sample.hip::logit_penalties_kernel)

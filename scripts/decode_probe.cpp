@@ -203,10 +203,10 @@ static void reset_state(const Model& m, State& s, int ctx0, hipStream_t st) {
 }
 
 struct Variant {
-  int pf = 0, wgs = 256, mask = 0x7f, flags = 0, headmb = 96, skip = 0, fmlp = 0, psplit = 16, gv = 0;
+  int pf = 0, wgs = 256, mask = 0x7f, flags = 0, headmb = 96, skip = 0, fmlp = 0, psplit = 16, gv = 0, am = 1;
   std::string name() const {
     char b[160];
-    snprintf(b, sizeof b, "pf=%d flags=%d skip=0x%02x fmlp=%d psplit=%d gv=%d", pf, flags, skip, fmlp, psplit, gv);
+    snprintf(b, sizeof b, "pf=%d flags=%d skip=0x%02x fmlp=%d psplit=%d gv=%d am=%d", pf, flags, skip, fmlp, psplit, gv, am);
     return b;
   }
 };
@@ -222,6 +222,7 @@ static double run_variant(const Model& m, State& s, const Variant& v, int ctx0, 
   RC(vlm_llm_set_tuning(m.h, VLM_TUNE_FUSED_MLP, v.fmlp));
   RC(vlm_llm_set_tuning(m.h, VLM_TUNE_ATTN_PAGESPLIT, v.psplit));
   RC(vlm_llm_set_tuning(m.h, VLM_TUNE_GEMV_VARIANT, v.gv));
+  RC(vlm_llm_set_tuning(m.h, VLM_TUNE_ATTN_MERGE, v.am));
   if (v.fmlp && !vlm_llm_get_tuning(m.h, VLM_TUNE_FUSED_MLP)) printf("   (fused MLP not available on this device / shape)\n");
   s.a.flags = v.flags;
   RC(vlm_llm_set_kv(m.h, &m.kv));
@@ -319,7 +320,7 @@ int main(int argc, char** argv) {
     else if (a == "--block-table") use_table = true;
     else if (a == "--variant" && i + 1 < argc) {
       Variant v;
-      sscanf(argv[++i], "%d,%d,%i,%d,%d,%i,%d,%d,%i", &v.pf, &v.wgs, &v.mask, &v.flags, &v.headmb, &v.skip, &v.fmlp, &v.psplit, &v.gv);
+      sscanf(argv[++i], "%d,%d,%i,%d,%d,%i,%d,%d,%i,%d", &v.pf, &v.wgs, &v.mask, &v.flags, &v.headmb, &v.skip, &v.fmlp, &v.psplit, &v.gv, &v.am);
       variants.push_back(v);
     }
   }

@@ -5,6 +5,8 @@ hbm_bytes = (k * FETCH_SIZE + WRITE_SIZE) * 1024 with k = 2: on gfx950 this rocp
 bytes of a wide coalesced streaming read in FETCH_SIZE (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported.
 FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950 ("exceeds the capabilities of the hardware"), so they come
 from two runs of the same command; pass both databases.
+The output carries `_meta.decode_csrc_sha16` = the hash bench.py computes over the decode step's kernel sources
+(bench.decode_csrc_sha16): bench.py refuses the file as stale when the sources have changed since the passes.
 usage: pmc_summary.py <out.json> <db> [<db> ...]"""
 import json
 import re
@@ -32,10 +34,14 @@ def main(out, *dbs):
         if f is not None and w is not None:
             d["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
             d["fetch_kb_raw"], d["write_kb_raw"] = f, w
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bench import decode_csrc_sha16
+    res["_meta"] = {"decode_csrc_sha16": decode_csrc_sha16(), "kernels": sorted(k for k in res if not k.startswith(("at::", "__amd")))}
     txt = json.dumps(res, indent=1, sort_keys=True)
     if out:
         open(out, "w").write(txt + "\n")
-    for k, d in sorted(res.items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch", 0) * kv[1]["launches"])[:16]:
+    for k, d in sorted(((k, d) for k, d in res.items() if k != "_meta"), key=lambda kv: -kv[1].get("hbm_bytes_per_launch", 0) * kv[1]["launches"])[:16]:
         print(f"{k[:70]:70s} n={d['launches']:6d} hbm/launch {d.get('hbm_bytes_per_launch', 0) / 1e6:10.3f} MB")
 
 

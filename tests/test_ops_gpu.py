@@ -51,7 +51,7 @@ def vops():
 def test_library_loaded_is_in_tree():
     import mlx_vlm_amd._lib as L
 
-    assert L.lib().vlm_abi_version() == 3
+    assert L.lib().vlm_abi_version() == 4
     assert "mlx-vlm_amd/lib/libvlm_hip.so" in L.LIB_PATH
 
 
@@ -330,6 +330,40 @@ def test_attn_decode_paged_split_vs_oracle(vops, lens, nsplit, heads, identity):
         ok, rep = bf16_close(out, ref, ulps=2, atol_rms=2e-2)
         assert ok, (rep_i, rep)
         assert int(tickets.abs().sum()) == 0                      # re-armed
+
+
+@pytest.mark.parametrize("n,nsplit,heads", [(386, 16, (12, 2)), (1, 16, (12, 2)), (64, 8, (12, 2)), (1024, 16, (12, 2)),
+                                            (1500, 16, (16, 8)), (700, 4, (8, 1)), (130, 16, (14, 2))])
+def test_attn_decode_partial_only_plus_oproj_prologue_merge(vops, n, nsplit, heads):
+    """the one-row decode path of the engine: vlm_attn_decode_paged_split without merge (bf16 partials + (m, l), splits
+    without a page flagged (-inf, 0); unwritten partial slots hold NaN on purpose) -> vlm_gemv_attn_out_bf16 (merge in
+    the o_proj prologue + residual) against the oracle's SDPA -> Linear -> residual.  The partials are rounded to bf16
+    before the merge (the one-launch forms merge fp32 partials): 3 ulps + 2 % of the rms of the o_proj output."""
+    Hq, Hkv = heads
+    D = 128
+    scale = D ** -0.5
+    max_pages = (n + 63) // 64 + 2
+    kpool = torch.full((max_pages, Hkv, D // 8, 64, 8), float("nan"), dtype=BF)
+    vpool = torch.full((max_pages, Hkv, D, 64), float("nan"), dtype=BF)
+    q = rnd(1, Hq * D, seed=61)
+    k, v = rnd(n, Hkv, D, seed=62), rnd(n, Hkv, D, seed=63)
+    for p in range((n + 63) // 64):
+        m = min(64, n - p * 64)
+        kpool[p, :, :, :m, :] = k[p * 64:p * 64 + m].permute(1, 0, 2).reshape(Hkv, m, D // 8, 8).permute(0, 2, 1, 3)
+        vpool[p][:, :, VSLOT[:m]] = v[p * 64:p * 64 + m].permute(1, 2, 0)
+    att = O.sdpa(q.view(1, Hq, 1, D), k.permute(1, 0, 2)[None], v.permute(1, 0, 2)[None], scale)[0, :, 0].reshape(1, Hq * D)
+    N = 1536
+    wo = rnd(N, Hq * D, seed=64, scale=0.03)
+    h = rnd(1, N, seed=65)
+    ref = (O.linear(att, wo).float() + h.float()).to(BF)
+    po, pml = vops.attn_decode_paged_split(q.cuda(), kpool.cuda(), vpool.cuda(), None, torch.tensor([n], dtype=torch.int32).cuda(), 0,
+                                           Hq, Hkv, D, scale, nsplit, max_pages=max_pages, merge=False)
+    n_act = min(nsplit, (n + 63) // 64)
+    ml = pml.cpu()
+    assert bool(torch.isfinite(ml[0, :, :n_act, 0]).all()) and bool((ml[0, :, n_act:, 0] == float("-inf")).all())
+    out = vops.gemv_attn_out_bf16_(po, pml, wo.cuda(), h.cuda().clone(), Hq, D)
+    ok, rep = bf16_close(out, ref, ulps=3, atol_rms=2e-2)
+    assert ok, rep
 
 
 # ------------------------------------------------------------------ gather / scatter / cast (bit-exact)
