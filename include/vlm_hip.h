@@ -257,6 +257,12 @@ typedef struct vlm_penalty_args {
   const void* bias_idx; /* int32 [n_bias] (distinct) */
   const void* bias_val; /* fp32 [n_bias] */
   int n_bias;
+  /* per-request processors of a continuous batch (BatchGenerator.insert(..., logits_processors=), ar.py:2584-2606):
+   * row_params != NULL: fp32 [B][8] on the device = {rep_penalty, rep_ctx, pres_penalty, pres_ctx, freq_penalty, freq_ctx,
+   * n_bias, 0} of row b - the scalar fields above are then ignored - and row b's bias list sits at bias_idx / bias_val +
+   * b * bias_stride.  The host rewrites the table as requests join and leave; a captured step keeps its arguments. */
+  const void* row_params;
+  int bias_stride;
 } vlm_penalty_args;
 int vlm_apply_logit_penalties(void* logits, int ld, int B, int V, const void* push_tok, const vlm_penalty_args* p,
                               void* stream);
@@ -283,6 +289,13 @@ typedef struct vlm_llm_config {
                                  zero-padded form of the model's (e.g. 64 -> 128, llava_bunny language.py:24-25) */
   float rope_qk_scale;        /* ABI v3.  SuScaledRoPE (rope_utils.py:96-189): q and k are multiplied by this and rounded to
                                  bf16 before the rotation, in the prefill pass and in every decode qkv epilogue; 0 = 1 = none */
+  int rope_long_from;         /* ABI v4.  SuScaledRoPE's short / long factor regimes: > 0 = original_max_position_embeddings and
+                                 vlm_llm_globals.inv_freq holds TWO tables [2][head_dim / 2] (short factors, then long).  A decode
+                                 step picks the long table for every row when ANY row's cache offset >= this value - the
+                                 reference's per-call rule position_end = max(offset) + 1 > original_max (rope_utils.py:168-172)
+                                 evaluated inside the qkv epilogue, so captured steps cross the limit without host help and a
+                                 continuous batch behaves as the reference's batched call; a prefill call names its regime in
+                                 vlm_prefill_args.rope_long.  0 = one table */
 } vlm_llm_config;
 
 typedef struct vlm_llm_layer {
@@ -320,6 +333,8 @@ typedef struct vlm_prefill_args {
   const void* last_rows;
   int n_last;
   void *xlast, *logits;
+  int rope_long; /* models with rope_long_from > 0: 1 = this call uses the LONG frequency table (the caller applies
+                    SuScaledRoPE's per-call rule: max cache offset + tokens of the call > original_max) */
 } vlm_prefill_args;
 
 /* one decode step for B sequences (B in {1,2,4,8}); every buffer is device resident so the

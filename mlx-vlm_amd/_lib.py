@@ -18,7 +18,7 @@ c_void_p, c_int, c_float, c_uint, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c
 class LlmConfig(C.Structure):
     _fields_ = [("hidden", c_int), ("n_layers", c_int), ("inter", c_int), ("n_heads", c_int), ("n_kv_heads", c_int),
                 ("head_dim", c_int), ("vocab", c_int), ("rms_eps", c_float), ("mrope_sec0", c_int), ("mrope_sec1", c_int),
-                ("attn_scale", c_float), ("rope_qk_scale", c_float)]
+                ("attn_scale", c_float), ("rope_qk_scale", c_float), ("rope_long_from", c_int)]
 
 
 class LlmLayer(C.Structure):
@@ -39,13 +39,14 @@ class PrefillArgs(C.Structure):
     _fields_ = [("h", c_void_p), ("T", c_int), ("pos_t", c_void_p), ("pos_h", c_void_p), ("pos_w", c_void_p),
                 ("kv_seq", c_void_p), ("kv_slot", c_void_p), ("cu_seqlens", c_void_p), ("nseg", c_int),
                 ("total_qblocks", c_int), ("xn", c_void_p), ("qkv", c_void_p), ("attn", c_void_p), ("act", c_void_p),
-                ("last_rows", c_void_p), ("n_last", c_int), ("xlast", c_void_p), ("logits", c_void_p)]
+                ("last_rows", c_void_p), ("n_last", c_int), ("xlast", c_void_p), ("logits", c_void_p), ("rope_long", c_int)]
 
 
 class PenaltyArgs(C.Structure):
     _fields_ = [("hist", c_void_p), ("hist_len", c_void_p), ("hist_cap", c_int), ("rep_penalty", c_float), ("rep_ctx", c_int),
                 ("pres_penalty", c_float), ("pres_ctx", c_int), ("freq_penalty", c_float), ("freq_ctx", c_int),
-                ("bias_idx", c_void_p), ("bias_val", c_void_p), ("n_bias", c_int)]
+                ("bias_idx", c_void_p), ("bias_val", c_void_p), ("n_bias", c_int), ("row_params", c_void_p),
+                ("bias_stride", c_int)]
 
 
 class DecodeArgs(C.Structure):

@@ -39,6 +39,7 @@ from .models.cache import PAGE, PagedSequence
 from .models.qwen2_vl.language import DecodeState
 from .sample_utils import Sampler, make_sampler
 
+_PROCS_KEY = "__logits_processors__"     # a request's LogitsProcessors spec inside its keyword arguments
 MAX_ROWS = 16         # widest decode step: one N tile of the skinny-M MFMA GEMM (csrc/gemv_mfma.hip), bf16 or 4-bit weights
 WIDTHS = (1, 2, 4, 8, 16)
 
@@ -74,6 +75,7 @@ class _Row:
     max_tokens: int
     prompt_tokens: int
     num_tokens: int = 0
+    procs: Any = None              # this request's sample_utils.LogitsProcessors (None: none)
 
 
 @dataclass
@@ -89,6 +91,7 @@ class _Admission:
     tic: float
     removed: set = field(default_factory=set)
     joined: int = 0                # requests of `batch` already given a row (a join takes as many as there are free rows)
+    pen: Any = None                # device (hist, hist_len, params, bias_idx, bias_val) of the admitted requests, or None
 
     def waiting(self) -> int:
         return sum(1 for b in self.batch[self.joined:] if b[0] not in self.removed)
@@ -112,8 +115,10 @@ class BatchGenerator:
     """`insert(prompts)` queues token-id prompts (shortest first, ar.py:2620-2623); every `next()` reports one token
     per running request and advances the batch by one step.  `model` is the full `Model` (vision tower + language
     model): per-request `prompt_kwargs` carry `pixel_values` / `image_grid_thw` and the ViT runs inside the admission
-    prefill.  Quantised KV, APC, speculative drafts and logits processors are outside the built path and are
-    rejected, not ignored."""
+    prefill.  Per-request logits processors (`insert(..., logits_processors=)`, ar.py:2584-2606) are the reference's own
+    four - logit_bias, repetition / presence / frequency penalty, as `make_logits_processors` specs - applied by the device
+    pass inside the step from per-row parameter tables; arbitrary Python callables cannot run inside a captured step.
+    Quantised KV, APC and speculative drafts are outside the built path and are rejected, not ignored."""
 
     @dataclass
     class Response:
@@ -207,12 +212,32 @@ class BatchGenerator:
         ids_l = [b[1] for b in batch]
         pix_l = [b[3].get("pixel_values") for b in batch]
         grid_l = [b[3].get("image_grid_thw") for b in batch]
-        extras = [{k: v for k, v in b[3].items() if k not in ("pixel_values", "image_grid_thw")} for b in batch]
+        extras = [{k: v for k, v in b[3].items() if k not in ("pixel_values", "image_grid_thw", _PROCS_KEY)} for b in batch]
         emb, pos, lens, deltas = embed_requests(self.model, ids_l, pix_l, grid_l, extras)
         caches = [lm.make_cache() for _ in batch]
         for c, L, b in zip(caches, lens, batch):
             c[0]._seq.reserve(L + b[2] + 2)          # prompt + every token it may generate + the step in flight
         logits = lm.prefill(emb, pos, caches, lens, "last")
+        # per-request logits processors on the FIRST token (ar.py:360-364: `tokens` is the prompt there): a history of each
+        # admitted prompt + its parameter rows, applied by the device pass; the same rows move into the decode state at the join
+        self._last_pen = None
+        specs = [b[3].get(_PROCS_KEY) for b in batch]
+        if any(specs):
+            cap = self._st.hist.shape[1]
+            host_h = np.zeros((len(batch), cap), dtype=np.int32)
+            host_n = np.zeros(len(batch), dtype=np.int32)
+            for r, b in enumerate(batch):
+                t = np.asarray(b[1], dtype=np.int64).reshape(-1)[-cap:]
+                host_h[r, :len(t)] = t
+                host_n[r] = len(t)
+            params, bidx, bval = DecodeState.pack_row_penalties(specs, cap)
+            dev = lm.device
+            pen = tuple(h2d(x, dev) for x in (host_h, host_n, params, bidx, bval))
+            from . import _lib
+            pa = _lib.PenaltyArgs(pen[0].data_ptr(), pen[1].data_ptr(), cap, 0.0, 0, 0.0, 0, 0.0, 0, pen[3].data_ptr(),
+                                  pen[4].data_ptr(), 0, pen[2].data_ptr(), DecodeState.MAX_ROW_BIAS)
+            ops.apply_logit_penalties(logits, pa)
+            self._last_pen = pen
         # RNG stream of the first tokens: the sampler keys its noise on (seed, step, row, index).  Decode steps count up
         # from 1 (see _borrow_state); every admission takes its own step value from a range they never reach, so no
         # (step, row) pair is used twice - neither between an admission and a decode step nor between two admissions
@@ -227,7 +252,7 @@ class BatchGenerator:
     def _decode_rows(self, width: int):
         """One decode step over rows 0..width-1 of the state: tok <- sampled token, pos and ctx advanced by one."""
         self.lm.decode_step_rows(self._st, width, self._table, self._sargs, use_graph=self.use_graph,
-                                 with_logprobs=self.compute_logprobs)
+                                 with_logprobs=self.compute_logprobs, row_penalties=any(row.procs for row in self._rows))
 
     def _row_logprobs(self, n: int) -> torch.Tensor:
         """log-prob of the token each of the first n rows has just sampled (f32 [n])"""
@@ -253,20 +278,43 @@ class BatchGenerator:
     # ------------------------------------------------------------------ queue (reference ar.py:2584-2670)
     def insert(self, prompts, max_tokens=None, prompt_kwargs: Optional[List[dict]] = None, logits_processors=None,
                thinking_budget_criteria=None) -> List[int]:
-        if logits_processors or thinking_budget_criteria:
-            raise NotImplementedError("logits processors / thinking budgets are outside the built path")
+        """logits_processors: one entry per prompt (reference ar.py:2584-2606) - None, a `sample_utils.LogitsProcessors`
+        (what `make_logits_processors` returns here) or a list holding one; they run on the device inside the step, each
+        row with its own parameters and token history."""
+        if thinking_budget_criteria:
+            raise NotImplementedError("thinking budgets are outside the built path")
         if max_tokens is None or isinstance(max_tokens, int):
             max_tokens = [max_tokens or self.max_tokens] * len(prompts)
         if prompt_kwargs is None:
             prompt_kwargs = [{}] * len(prompts)
-        if len(max_tokens) != len(prompts) or len(prompt_kwargs) != len(prompts):
-            raise ValueError("max_tokens / prompt_kwargs must have one entry per prompt")
+        if logits_processors is None:
+            logits_processors = [None] * len(prompts)
+        if len(max_tokens) != len(prompts) or len(prompt_kwargs) != len(prompts) or len(logits_processors) != len(prompts):
+            raise ValueError("max_tokens / prompt_kwargs / logits_processors must have one entry per prompt")
+        from .sample_utils import LogitsProcessors
+        specs = []
+        for lp in logits_processors:
+            if isinstance(lp, (list, tuple)):
+                lp = [x for x in lp if x] or None
+                if lp is not None and len(lp) == 1:
+                    lp = lp[0]
+            if lp is not None and not isinstance(lp, LogitsProcessors):
+                raise NotImplementedError("BatchGenerator runs logits processors on the device: pass the spec returned by "
+                                          "mlx_vlm_amd.sample_utils.make_logits_processors (logit_bias, repetition / presence / "
+                                          "frequency penalty); Python callables cannot run inside the captured step")
+            if lp:
+                from .sample_utils import HIST_CAP
+                DecodeState.pack_row_penalties([lp], HIST_CAP)                    # validates (bias list length) before queueing
+            specs.append(lp if lp else None)
         uids = []
-        for p, m, kw in zip(prompts, max_tokens, prompt_kwargs):
+        for p, m, kw, sp in zip(prompts, max_tokens, prompt_kwargs, specs):
             ids = np.asarray(p, dtype=np.int64).reshape(-1)
             if ids.size == 0:
                 raise ValueError("empty prompt")
-            self._unprocessed_sequences.append((self.uid_count, ids, int(m), dict(kw or {})))
+            kw = dict(kw or {})
+            if sp:
+                kw[_PROCS_KEY] = sp               # travels with the request's keyword arguments (the queue item keeps its shape)
+            self._unprocessed_sequences.append((self.uid_count, ids, int(m), kw))
             uids.append(self.uid_count)
             self.uid_count += 1
         self._unprocessed_sequences.sort(key=lambda x: len(x[1]))
@@ -341,6 +389,28 @@ class BatchGenerator:
         except Exception:
             pass
 
+    # ------------------------------------------------------------------ per-row logits processors (device tables of the state)
+    def _set_row_penalties(self, r: int, pen, i: int, spec):
+        """row r of the decode state <- request i of an admission (history of its prompt + its parameters), or cleared"""
+        st = self._st
+        if spec and pen is not None:
+            st.row_penalty_tables()
+            st.hist[r].copy_(pen[0][i])
+            st.hist_len[r:r + 1].copy_(pen[1][i:i + 1])
+            st.row_params[r].copy_(pen[2][i])
+            st.row_bias_idx[r].copy_(pen[3][i])
+            st.row_bias_val[r].copy_(pen[4][i])
+        elif getattr(st, "row_params", None) is not None:
+            st.row_params[r].zero_()                  # the previous occupant's processors must not apply to this request
+            st.hist_len[r:r + 1].zero_()
+
+    def _move_row_penalties(self, dst: int, src: int):
+        st = self._st
+        if getattr(st, "row_params", None) is not None:
+            for buf in (st.hist, st.row_params, st.row_bias_idx, st.row_bias_val):
+                buf[dst].copy_(buf[src])
+            st.hist_len[dst:dst + 1].copy_(st.hist_len[src:src + 1])
+
     # ------------------------------------------------------------------ membership
     def _drop_rows(self, gone: List[int]):
         """Release the sequences in batch rows `gone`; keep the live rows dense by moving rows from the end into the
@@ -356,6 +426,7 @@ class BatchGenerator:
             for buf in (st.tok, st.pos, st.ctx, self._lp):
                 buf[dst:dst + 1].copy_(buf[src:src + 1])
             self._table[dst].copy_(self._table[src])
+            self._move_row_penalties(dst, src)
             self._rows[dst] = self._rows[src]
         del self._rows[live_after:]
         self._table[live_after:] = self._idle_row
@@ -368,6 +439,8 @@ class BatchGenerator:
             self._st.ctx[n:].zero_()
             self._st.pos[n:].zero_()
             self._st.tok[n:].zero_()
+            if getattr(self._st, "row_params", None) is not None:
+                self._st.row_params[n:].zero_()
         self._idle_steps = 0
 
     def _admit_begin(self):
@@ -391,7 +464,8 @@ class BatchGenerator:
             caches, lens, tok0, lp0, state = self._prefill_requests(batch)
             ev = self._event()
             ev.record()
-        self._pending.append(_Admission(batch, caches, lens, tok0, lp0, state, ev, tic))
+        self._pending.append(_Admission(batch, caches, lens, tok0, lp0, state, ev, tic, pen=getattr(self, "_last_pen", None)))
+        self._last_pen = None
 
     def _admit_join(self) -> List[PromptProgress]:
         """Give free rows to prefilled requests, oldest admission first; an admission whose event has not fired is
@@ -424,7 +498,9 @@ class BatchGenerator:
                 if p.lp0 is not None:
                     self._lp[r:r + 1].copy_(p.lp0[i:i + 1])
                 self._table[r].copy_(lm.pool.block_table[seq.seq])
-                self._rows.append(_Row(uid=b[0], seq=seq, max_tokens=b[2], prompt_tokens=L))
+                spec = b[3].get(_PROCS_KEY)
+                self._set_row_penalties(r, p.pen, i, spec)
+                self._rows.append(_Row(uid=b[0], seq=seq, max_tokens=b[2], prompt_tokens=L, procs=spec))
                 out.append(PromptProgress(uid=b[0], prompt_tokens=L, prompt_tps=L / dt if dt > 0 else 0.0, prompt_time=dt))
             if p.joined >= len(p.batch):
                 self._pending.pop(0)
@@ -497,10 +573,11 @@ class BatchGenerator:
 
 def generate_batch_continuous(model, input_ids_list, pixel_values_list, grids, *, max_tokens=128, stop_ids=(),
                               sampler: Optional[Sampler] = None, batch_size: int = MAX_ROWS, use_graph: bool = True,
-                              extras: Optional[List[Optional[dict]]] = None):
+                              extras: Optional[List[Optional[dict]]] = None, logits_processors=None):
     """The reference's `_generate_batch` loop (ar.py:3212-3232) over the continuous generator: every request is queued
     at once, the generator keeps up to `batch_size` of them decoding and admits the next ones as rows free up.
     extras: per-request keyword arguments of the model's `get_input_embeddings` besides pixels / grid (phi3_v: image_sizes).
+    logits_processors: one `make_logits_processors` spec (or None) per request, or ONE spec for all of them.
     -> (tokens per request without the stop token, BatchStats)"""
     gen = BatchGenerator(model, None, max_tokens=max(max_tokens) if isinstance(max_tokens, (list, tuple)) else max_tokens,
                          stop_tokens=set(stop_ids), sampler=sampler,
@@ -513,7 +590,10 @@ def generate_batch_continuous(model, input_ids_list, pixel_values_list, grids, *
             k.update(e)
             if k.get("image_grid_thw") is None:
                 del k["image_grid_thw"]
-    uids = gen.insert([np.asarray(i).reshape(-1) for i in input_ids_list], max_tokens, prompt_kwargs=kw)
+    if logits_processors is not None and not isinstance(logits_processors, (list, tuple)):
+        logits_processors = [logits_processors] * len(input_ids_list)
+    uids = gen.insert([np.asarray(i).reshape(-1) for i in input_ids_list], max_tokens, prompt_kwargs=kw,
+                      logits_processors=logits_processors)
     results = {u: [] for u in uids}
     tic = time.perf_counter()
     while gen.has_work:

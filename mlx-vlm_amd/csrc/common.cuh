@@ -79,18 +79,23 @@ __device__ __forceinline__ float wave_max(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 // lane l <-> lane l ^ 16 / l ^ 32 exchanges as ONE gfx950 instruction each (v_permlane16_swap_b32 / v_permlane32_swap_b32:
-// with both operands = v, the results are [r0 r0 r2 r2] | [r1 r1 r3 r3] resp. [lo lo] | [hi hi]) instead of a ds_bpermute
+// with both operands = v, the results are [r0 r0 r2 r2] | [r1 r1 r3 r3] resp. [lo lo] | [hi hi]) instead of a ds_bpermute.
+// COMPILER TRAP (hipcc / ROCm 7.2; the one gemv_bf16.hip documents): __builtin_bit_cast applied to a vector ELEMENT
+// (r[1]) silently reads element 0 - found in the .s as `v_add_f32 v2, v66, v66` after the swap, and on the GPU as wrong
+// attention.  The elements are copied to scalars first.
 __device__ __forceinline__ void vlm_xor16_pair(float v, float& a, float& b) {
   typedef unsigned int u32x2_t_ __attribute__((ext_vector_type(2)));
   const u32x2_t_ r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-  a = __builtin_bit_cast(float, r[0]);
-  b = __builtin_bit_cast(float, r[1]);
+  const unsigned r0 = r[0], r1 = r[1];
+  a = __builtin_bit_cast(float, r0);
+  b = __builtin_bit_cast(float, r1);
 }
 __device__ __forceinline__ void vlm_xor32_pair(float v, float& a, float& b) {
   typedef unsigned int u32x2_t_ __attribute__((ext_vector_type(2)));
   const u32x2_t_ r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-  a = __builtin_bit_cast(float, r[0]);
-  b = __builtin_bit_cast(float, r[1]);
+  const unsigned r0 = r[0], r1 = r[1];
+  a = __builtin_bit_cast(float, r0);
+  b = __builtin_bit_cast(float, r1);
 }
 // reductions over the 4 lanes {l & 15, + 16, + 32, + 48} (one MFMA column held by the four 16-lane rows)
 __device__ __forceinline__ float col4_max(float v) {

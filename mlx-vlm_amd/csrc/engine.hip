@@ -65,8 +65,11 @@ struct Llm {
   int* progress = nullptr;                // [0] pacing word, [1] exit counter of the persistent prefetcher (device)
   void* mfma_ws = nullptr;                // split-K partial tiles + tickets of the skinny-M decode GEMM (gemv_mfma.hip)
   unsigned* attn_tickets = nullptr;       // [64] arrival words of the page-split decode attention (zero between launches)
-  void* wscratch = nullptr;               // bf16 scratch for the prefill GEMMs over 4-bit weights (largest matrix)
-  size_t wscratch_bytes = 0;
+  // bf16 scratch of the prefill GEMMs over 4-bit weights: ONE buffer PER STREAM (an admission prefill on the side stream
+  // and a generate_step prefill on the main stream of the same quantized model must not share dequantised weights),
+  // each sized once for the largest matrix of the model - never grown, never freed while the engine lives
+  struct WScratch { hipStream_t st; void* p; };
+  std::vector<WScratch> wscratch;
   char* fm_buf = nullptr;                 // fused-MLP hand-off buffers: [256 B err] then per layer [256 B epoch | D granules | I granules]
   size_t fm_stride = 0;
   vlm_llm_config cfg;
@@ -85,7 +88,7 @@ inline bool same_pen(const vlm_penalty_args& x, const vlm_penalty_args* y) {
   return x.hist == y->hist && x.hist_len == y->hist_len && x.hist_cap == y->hist_cap && x.rep_penalty == y->rep_penalty &&
          x.rep_ctx == y->rep_ctx && x.pres_penalty == y->pres_penalty && x.pres_ctx == y->pres_ctx &&
          x.freq_penalty == y->freq_penalty && x.freq_ctx == y->freq_ctx && x.bias_idx == y->bias_idx &&
-         x.bias_val == y->bias_val && x.n_bias == y->n_bias;
+         x.bias_val == y->bias_val && x.n_bias == y->n_bias && x.row_params == y->row_params && x.bias_stride == y->bias_stride;
 }
 
 inline bool same_key(const DecodeGraph& g, const vlm_decode_args& a, const vlm_kv_pool& kv) {
@@ -153,7 +156,7 @@ extern "C" int vlm_llm_destroy(void* handle) {
   for (DecodeGraph& g : m->graphs) drop_graph(g);
   if (m->progress) (void)hipFree(m->progress);
   if (m->fm_buf) (void)hipFree(m->fm_buf);
-  if (m->wscratch) (void)hipFree(m->wscratch);
+  for (auto& ws : m->wscratch) (void)hipFree(ws.p);
   if (m->mfma_ws) (void)hipFree(m->mfma_ws);
   if (m->attn_tickets) (void)hipFree(m->attn_tickets);
   delete m;
@@ -269,14 +272,19 @@ extern "C" int vlm_llm_set_kv(void* handle, const vlm_kv_pool* kv) {
 static int lin_gemm(Llm* m, const void* A, const void* W, const void* Wsb, const void* bias, const void* res, void* C, int M,
                     int N, int K, int ldc, int ldres, int epi, void* stream) {
   if (Wsb) {
-    const size_t need = (size_t)N * K * 2;
-    if (m->wscratch_bytes < need) {
-      if (m->wscratch) { (void)hipDeviceSynchronize(); (void)hipFree(m->wscratch); m->wscratch = nullptr; m->wscratch_bytes = 0; }
-      if (hipMalloc(&m->wscratch, need) != hipSuccess) return 1011;
-      m->wscratch_bytes = need;
+    const vlm_llm_config& c = m->cfg;
+    const size_t D = (size_t)c.hidden, KO = (size_t)c.n_heads * c.head_dim, QKV = (size_t)(c.n_heads + 2 * c.n_kv_heads) * c.head_dim;
+    size_t cap = QKV * D;
+    for (size_t v : {D * KO, 2 * (size_t)c.inter * D, (size_t)c.inter * D, (size_t)((c.vocab + 7) & ~7) * D}) cap = v > cap ? v : cap;
+    if ((size_t)N * K > cap) return 1011;
+    void* buf = nullptr;
+    for (auto& ws : m->wscratch) if (ws.st == (hipStream_t)stream) buf = ws.p;
+    if (!buf) {
+      if (hipMalloc(&buf, cap * 2) != hipSuccess) return 1011;
+      m->wscratch.push_back({(hipStream_t)stream, buf});
     }
-    TRY(vlm_dequant_w4(W, Wsb, nullptr, m->wscratch, N, K, K, N, stream));
-    W = m->wscratch;
+    TRY(vlm_dequant_w4(W, Wsb, nullptr, buf, N, K, K, N, stream));
+    W = buf;
   }
   return vlm_gemm_bf16(A, W, bias, res, C, M, N, K, K, K, ldc, ldres, epi, stream);
 }
@@ -305,7 +313,11 @@ extern "C" int vlm_llm_prefill(void* handle, const vlm_prefill_args* a, void* st
     // M-RoPE on q, k in place + paged KV write
     void* kp = m->kv.kpool ? off(m->kv.kpool, (size_t)i * m->kv.layer_stride * 2) : nullptr;
     void* vp = m->kv.vpool ? off(m->kv.vpool, (size_t)i * m->kv.layer_stride * 2) : nullptr;
-    TRY(vlm_mrope_kvwrite_scaled(a->qkv, QKV, T, Hq, Hkv, hd, a->pos_t, a->pos_h, a->pos_w, m->g.inv_freq, c.mrope_sec0,
+    // SuScaledRoPE: the caller names the regime of THIS call (rope_utils.py:168-172: long iff max(cache offset) + tokens of
+    // the call > original_max); the long table sits behind the short one
+    const void* inv_freq = (a->rope_long && c.rope_long_from > 0) ? off(const_cast<void*>(m->g.inv_freq), (size_t)(hd / 2) * sizeof(float))
+                                                                : m->g.inv_freq;
+    TRY(vlm_mrope_kvwrite_scaled(a->qkv, QKV, T, Hq, Hkv, hd, a->pos_t, a->pos_h, a->pos_w, inv_freq, c.mrope_sec0,
                                  c.mrope_sec1, a->kv_seq, a->kv_slot, m->kv.block_table, m->kv.max_pages, kp, vp, qk_scale,
                                  stream));
     // causal flash attention over each sequence
@@ -423,11 +435,11 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
     if (w.wqkv_sb) {
       TRY(vlm_gemv_w4_qkv_rope_kvwrite_ex(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.wqkv_sb, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos,
                                           a->ctx, m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, m->tune.mfma_gemv,
-                                          m->mfma_ws, qk_scale, stream)); ++n;
+                                          m->mfma_ws, qk_scale, c.rope_long_from, stream)); ++n;
     } else {
     TRY(vlm_gemv_qkv_rope_kvwrite_ex(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos, a->ctx,
                                      m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, m->tune.mfma_gemv, m->mfma_ws,
-                                     qk_scale, stream)); ++n;
+                                     qk_scale, c.rope_long_from, stream)); ++n;
     }
     }
     // attention over the pages (the new token is already in the cache: kv_len = ctx + 1)

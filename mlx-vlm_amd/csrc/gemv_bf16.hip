@@ -42,6 +42,9 @@ struct RopeKvArgs {
   bf16_t* kpool;             // [page][Hkv][D/8][64][8]
   bf16_t* vpool;             // [page][Hkv][D][64 key slots]
   float qk_scale = 1.f;      // q and k are multiplied by this (a typed op: rounded to bf16) before the rotation - SuScaledRoPE
+  int long_from = 0;         // > 0: inv_freq holds [2][D/2] (short, long factors); the LONG row applies to every row of the step
+                             // when ANY row's slot (= cache offset) >= long_from: SuScaledRoPE's per-call rule
+                             // (rope_utils.py:168-172: position_end = max(offset) + tokens of the call > original_max)
 };
 
 struct AttnProArgs {
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
   // (raw values only - any arithmetic on them here would force a wait before the weight loads are issued)
   bf16_t e_b0 = 0, e_b1 = 0, e_r = 0;
   int e_pos = 0, e_slot = 0;
-  float e_if = 0.f;
+  float e_if = 0.f, e_if2 = 0.f;
   if (EPI == EPI_ROPE_KV) {
     const int mm = min(lane, MB - 1), r0 = min(row[0], N - 1), r1 = min(row[R - 1], N - 1);
     e_b0 = bias[r0];
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
     e_slot = rk.slot[mm];
     e_pos = rk.pos[mm];
     e_if = rk.inv_freq[rope_j];
+    e_if2 = rk.inv_freq[(rk.long_from > 0 ? (rk.D >> 1) : 0) + rope_j];       // (the same word again when there is one table)
   } else if (!(EPI & VLM_EPI_SWIGLU)) {
     const int ll = min(lane, R * MB - 1), r = ll / MB, m = ll % MB;
     int rr = row[0];
@@ -362,6 +366,8 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
       a0 = (lane == m) ? acc[0][m] : a0;
       a1 = (lane == m) ? acc[R - 1][m] : a1;
     }
+    // lanes >= MB hold row MB - 1's slot again: the vote covers exactly the rows of the step (wave-uniform result)
+    const bool use_long = rk.long_from > 0 && __any(e_slot >= rk.long_from);
     if (lane < MB) {
       const int m = lane;
       const float y0 = rbf(a0 + bf2f(e_b0)), y1 = rbf(a1 + bf2f(e_b1));
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
       const int e_within = e_slot & 63;
       if (rope_pair) {
         float sn, cs;
-        sincosf((float)e_pos * e_if, &sn, &cs);
+        sincosf((float)e_pos * (use_long ? e_if2 : e_if), &sn, &cs);
         const float z0 = rbf(y0 * rk.qk_scale), z1 = rbf(y1 * rk.qk_scale);      // (exact no-op at scale 1)
         const float o0 = z0 * cs - z1 * sn, o1 = z1 * cs + z0 * sn;
         if (rope_head < rk.Hq) {
@@ -605,7 +611,7 @@ extern "C" int vlm_gemv_qkv_rope_kvwrite_ws(const void* h, const void* norm_w, f
                                             const void* slot, const void* inv_freq, const void* block_table, int max_pages,
                                             void* kpool, void* vpool, void* workspace, void* stream) {
   return vlm_gemv_qkv_rope_kvwrite_ex(h, norm_w, eps, Wqkv, bqkv, qkv, ldq, M, hidden, Hq, Hkv, D, pos, slot, inv_freq, block_table,
-                                      max_pages, kpool, vpool, 1, workspace, 1.f, stream);
+                                      max_pages, kpool, vpool, 1, workspace, 1.f, 0, stream);
 }
 
 // mfma: 0 = v_dot2c kernels only; ws: the engine's workspace for vlm_gemv_mfma_try (nullptr: no K split over workgroups)
@@ -657,20 +663,20 @@ extern "C" int vlm_gemv_qkv_rope_kvwrite(const void* h, const void* norm_w, floa
                                          const void* block_table, int max_pages, void* kpool, void* vpool,
                                          void* stream) {
   return vlm_gemv_qkv_rope_kvwrite_ex(h, norm_w, eps, Wqkv, bqkv, qkv, ldq, M, hidden, Hq, Hkv, D, pos, slot, inv_freq, block_table,
-                                      max_pages, kpool, vpool, 1, nullptr, 1.f, stream);
+                                      max_pages, kpool, vpool, 1, nullptr, 1.f, 0, stream);
 }
 
 VLM_INTERNAL int vlm_gemv_qkv_rope_kvwrite_ex(const void* h, const void* norm_w, float eps, const void* Wqkv,
                                               const void* bqkv, void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D,
                                               const void* pos, const void* slot, const void* inv_freq,
                                               const void* block_table, int max_pages, void* kpool, void* vpool, int mfma,
-                                              void* ws, float qk_scale, void* stream) {
+                                              void* ws, float qk_scale, int long_from, void* stream) {
   if (!h || !norm_w || !Wqkv || !bqkv || !qkv || !pos || !slot || !inv_freq || !kpool || !vpool || max_pages <= 0)
     return VLM_ERR_ARG;
   const int N = (Hq + 2 * Hkv) * D;
   if (mfma) {
     const VlmRopeKv rk{(const int*)pos, (const int*)slot, (const float*)inv_freq, (const int*)block_table, max_pages, Hq, Hkv, D,
-                       (unsigned short*)kpool, (unsigned short*)vpool, qk_scale};
+                       (unsigned short*)kpool, (unsigned short*)vpool, qk_scale, long_from};
     const int rc = vlm_gemv_mfma_try(h, Wqkv, bqkv, nullptr, norm_w, qkv, M, N, hidden, hidden, hidden, ldq, 0, eps, VLM_EPI_BIAS, &rk,
                                      ws, stream);
     if (rc >= 0) return rc;
@@ -678,7 +684,7 @@ VLM_INTERNAL int vlm_gemv_qkv_rope_kvwrite_ex(const void* h, const void* norm_w,
   if (hidden % 8 || D % 16 || hidden > 4096 || (size_t)M * hidden * 2 > 64 * 1024) return VLM_ERR_SHAPE;
   Args a{h, Wqkv, bqkv, nullptr, norm_w, qkv, N, hidden, hidden, hidden, ldq, 0, eps,
          RopeKvArgs{(const int*)pos, (const int*)slot, (const float*)inv_freq, (const int*)block_table, max_pages, Hq, Hkv,
-                    D, (bf16_t*)kpool, (bf16_t*)vpool, qk_scale},
+                    D, (bf16_t*)kpool, (bf16_t*)vpool, qk_scale, long_from},
          AttnProArgs{}, (hipStream_t)stream};
   return launch_rw_m<PRO_RMSNORM, EPI_ROPE_KV>(M, a);
 }

@@ -372,6 +372,14 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
       }
       if (EPI == MEPI_ROPE_KV) {
         const int half = a.rk.D >> 1, tph = half >> 3, n_rot = (a.rk.Hq + a.rk.Hkv) * tph;
+        // SuScaledRoPE's per-call rule (rope_utils.py:168-172): long factors for every row of the step once ANY row's
+        // cache offset has reached original_max (scalar loop over the <= 16 rows: uniform, only when the model has two tables)
+        const float* inv_tab = a.rk.inv_freq;
+        if (a.rk.long_from > 0) {
+          bool any_long = false;
+          for (int mm = 0; mm < a.M; ++mm) any_long |= a.rk.slot[mm] >= a.rk.long_from;
+          inv_tab += any_long ? half : 0;
+        }
         if (m < a.M) {
           const int e_slot = a.rk.slot[m];
           const size_t e_page = a.rk.block_table ? (size_t)a.rk.block_table[(size_t)m * a.rk.max_pages + (e_slot >> 6)]
@@ -383,7 +391,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
               // (4-bit: quantized_matmul rounds to bf16, the bias add is a second typed op)
               const float y0 = rbf((W4 ? rbf(v) : v) + bf2f(a.bias[n])), y1 = rbf((W4 ? rbf(part[tid + 128]) : part[tid + 128]) + bf2f(a.bias[n1]));
               float sn, cs;
-              sincosf((float)a.rk.pos[m] * a.rk.inv_freq[j], &sn, &cs);
+              sincosf((float)a.rk.pos[m] * inv_tab[j], &sn, &cs);
               const float z0 = rbf(y0 * a.rk.qk_scale), z1 = rbf(y1 * a.rk.qk_scale);      // SuScaledRoPE's typed x * scale
               const float o0 = z0 * cs - z1 * sn, o1 = z1 * cs + z0 * sn;
               if (head < a.rk.Hq) {

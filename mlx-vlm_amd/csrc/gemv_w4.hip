@@ -35,6 +35,7 @@ struct W4RopeKv {
   bf16_t* kpool;
   bf16_t* vpool;
   float qk_scale = 1.f;      // SuScaledRoPE: q / k times this (typed op) before the rotation
+  int long_from = 0;         // > 0: inv_freq = [2][D/2] (short, long); long for the whole step when any row's slot >= long_from
 };
 
 __device__ __forceinline__ float wdot2(unsigned w, unsigned x, float acc) {
@@ -234,6 +235,10 @@ __global__ __launch_bounds__(256) void gemv_w4_kernel(const bf16_t* __restrict__
         a0 = (lane == m) ? acc[0][m] : a0;
         a1 = (lane == m) ? acc[R - 1][m] : a1;
       }
+      // SuScaledRoPE's per-call rule (rope_utils.py:168-172): the long factors for every row once ANY row's cache offset
+      // has reached original_max (wave-uniform vote over the rows of the step)
+      const bool use_long = rk.long_from > 0 && __any(rk.slot[min(lane, MB - 1)] >= rk.long_from);
+      const float* inv_tab = rk.inv_freq + (use_long ? (rk.D >> 1) : 0);
       if (lane < MB) {
         const int m = lane;
         const int r0 = min(row[0], N - 1), r1 = min(row[R - 1], N - 1);
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256) void gemv_w4_kernel(const bf16_t* __restrict__
         const int e_within = e_slot & 63;
         if (rope_pair) {
           float sn, cs;
-          sincosf((float)e_pos * rk.inv_freq[rope_j], &sn, &cs);
+          sincosf((float)e_pos * inv_tab[rope_j], &sn, &cs);
           const float z0 = rbf(y0 * rk.qk_scale), z1 = rbf(y1 * rk.qk_scale);
           const float o0 = z0 * cs - z1 * sn, o1 = z1 * cs + z0 * sn;
           if (rope_head < rk.Hq) {
@@ -408,7 +413,7 @@ extern "C" int vlm_gemv_w4_qkv_rope_kvwrite_ws(const void* h, const void* norm_w
                                                const void* pos, const void* slot, const void* inv_freq, const void* block_table,
                                                int max_pages, void* kpool, void* vpool, void* workspace, void* stream) {
   return vlm_gemv_w4_qkv_rope_kvwrite_ex(h, norm_w, eps, Wq, Wsb, bqkv, qkv, ldq, M, hidden, Hq, Hkv, D, pos, slot, inv_freq,
-                                         block_table, max_pages, kpool, vpool, 1, workspace, 1.f, stream);
+                                         block_table, max_pages, kpool, vpool, 1, workspace, 1.f, 0, stream);
 }
 
 // mfma / ws as vlm_gemv_bf16_ex: batched steps (5..16 rows) go to the dequant-fused MFMA form of csrc/gemv_mfma.hip
@@ -452,19 +457,19 @@ extern "C" int vlm_gemv_w4_qkv_rope_kvwrite(const void* h, const void* norm_w, f
                                             const void* block_table, int max_pages, void* kpool, void* vpool,
                                             void* stream) {
   return vlm_gemv_w4_qkv_rope_kvwrite_ex(h, norm_w, eps, Wq, Wsb, bqkv, qkv, ldq, M, hidden, Hq, Hkv, D, pos, slot, inv_freq,
-                                         block_table, max_pages, kpool, vpool, 1, nullptr, 1.f, stream);
+                                         block_table, max_pages, kpool, vpool, 1, nullptr, 1.f, 0, stream);
 }
 
 VLM_INTERNAL int vlm_gemv_w4_qkv_rope_kvwrite_ex(const void* h, const void* norm_w, float eps, const void* Wq, const void* Wsb,
                                                  const void* bqkv, void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D,
                                                  const void* pos, const void* slot, const void* inv_freq,
                                                  const void* block_table, int max_pages, void* kpool, void* vpool, int mfma,
-                                                 void* ws, float qk_scale, void* stream) {
+                                                 void* ws, float qk_scale, int long_from, void* stream) {
   if (!h || !norm_w || !Wq || !Wsb || !bqkv || !qkv || !pos || !slot || !inv_freq || !kpool || !vpool || max_pages <= 0)
     return VLM_ERR_ARG;
   if (mfma) {
     const VlmRopeKv rk{(const int*)pos, (const int*)slot, (const float*)inv_freq, (const int*)block_table, max_pages, Hq, Hkv, D,
-                       (unsigned short*)kpool, (unsigned short*)vpool, qk_scale};
+                       (unsigned short*)kpool, (unsigned short*)vpool, qk_scale, long_from};
     const int rc = vlm_gemv_mfma_try_w4(h, Wq, Wsb, bqkv, nullptr, norm_w, qkv, M, (Hq + 2 * Hkv) * D, hidden, hidden, ldq, 0, eps,
                                         VLM_EPI_BIAS, &rk, ws, stream);
     if (rc >= 0) return rc;
@@ -473,7 +478,7 @@ VLM_INTERNAL int vlm_gemv_w4_qkv_rope_kvwrite_ex(const void* h, const void* norm
   const int N = (Hq + 2 * Hkv) * D;
   W4Args a{h, Wq, Wsb, bqkv, nullptr, norm_w, qkv, N, hidden, hidden, ldq, 0, eps,
            W4RopeKv{(const int*)pos, (const int*)slot, (const float*)inv_freq, (const int*)block_table, max_pages, Hq, Hkv, D,
-                    (bf16_t*)kpool, (bf16_t*)vpool, qk_scale},
+                    (bf16_t*)kpool, (bf16_t*)vpool, qk_scale, long_from},
            (hipStream_t)stream};
   return w4_m<WPRO_RMSNORM, WEPI_ROPE_KV>(M, a);
 }

@@ -67,6 +67,7 @@ struct VlmRopeKv {
   unsigned short* kpool;     // [page][Hkv][D/8][64][8]
   unsigned short* vpool;     // [page][Hkv][D][64 key slots]
   float qk_scale = 1.f;      // q and k times this, rounded to bf16, before the rotation (SuScaledRoPE, rope_utils.py:174-176)
+  int long_from = 0;         // > 0: inv_freq = [2][D/2] (short, long); long for the whole step when any row's slot >= long_from
 };
 VLM_INTERNAL size_t vlm_gemv_mfma_ws_bytes(void);
 // -> 0 done, > 0 error, -1 shape not handled (take the v_dot2c kernels).  ws: zero-initialised workspace of
@@ -85,7 +86,8 @@ VLM_INTERNAL int vlm_gemv_bf16_ex(const void* x, const void* W, const void* bias
 VLM_INTERNAL int vlm_gemv_qkv_rope_kvwrite_ex(const void* h, const void* norm_w, float eps, const void* Wqkv, const void* bqkv,
                                               void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D, const void* pos,
                                               const void* slot, const void* inv_freq, const void* block_table, int max_pages,
-                                              void* kpool, void* vpool, int mfma, void* ws, float qk_scale, void* stream);
+                                              void* kpool, void* vpool, int mfma, void* ws, float qk_scale, int long_from,
+                                              void* stream);
 VLM_INTERNAL int vlm_gemv_w4_ex(const void* x, const void* Wq, const void* Wsb, const void* bias, const void* res, const void* norm_w,
                                 void* y, int M, int N, int K, int ldx, int ldy, int ldres, float eps, int epilogue, int mfma, void* ws,
                                 void* stream);
@@ -93,5 +95,5 @@ VLM_INTERNAL int vlm_gemv_w4_qkv_rope_kvwrite_ex(const void* h, const void* norm
                                                  const void* bqkv, void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D,
                                                  const void* pos, const void* slot, const void* inv_freq, const void* block_table,
                                                  int max_pages, void* kpool, void* vpool, int mfma, void* ws, float qk_scale,
-                                                 void* stream);
+                                                 int long_from, void* stream);
 

@@ -213,6 +213,8 @@ struct PenaltyK {
   const int* bias_idx;
   const float* bias_val;
   int n_bias;
+  const float* row_params;   // per-row form (continuous batch): [B][8] = rep_p, rep_ctx, pres_p, pres_ctx, freq_p, freq_ctx, n_bias, -
+  int bias_stride;           // per-row form: row b's bias entries at bias_idx / bias_val + b * bias_stride
 };
 
 __global__ __launch_bounds__(1024) void logit_penalties_kernel(bf16_t* __restrict__ logits, int ld, int V,
@@ -233,6 +235,18 @@ __global__ __launch_bounds__(1024) void logit_penalties_kernel(bf16_t* __restric
   }
   __syncthreads();
   const int len = s_len, n = min(len, p.hist_cap);
+  // per-request processors of a continuous batch (ar.py:2584-2606 insert(..., logits_processors=)): row b reads its own
+  // penalties / contexts / bias list from a device table the host rewrites as requests come and go (the captured step
+  // keeps its arguments); a row with all-zero parameters passes through untouched
+  if (p.row_params) {
+    const float* rp = p.row_params + (size_t)b * 8;
+    p.rep_p = rp[0]; p.rep_ctx = min((int)rp[1], p.hist_cap);
+    p.pres_p = rp[2]; p.pres_ctx = min((int)rp[3], p.hist_cap);
+    p.freq_p = rp[4]; p.freq_ctx = min((int)rp[5], p.hist_cap);
+    p.n_bias = min((int)rp[6], p.bias_stride);
+    p.bias_idx += (size_t)b * p.bias_stride;
+    p.bias_val += (size_t)b * p.bias_stride;
+  }
   // logit_bias: x + bf16(v), distinct indices
   for (int i = tid; i < p.n_bias; i += blockDim.x) {
     const int t = p.bias_idx[i];
@@ -539,8 +553,11 @@ extern "C" int vlm_apply_logit_penalties(void* logits, int ld, int B, int V, con
       p->freq_ctx > p->hist_cap)
     return VLM_ERR_SHAPE;
   if (p->n_bias > 0 && (!p->bias_idx || !p->bias_val)) return VLM_ERR_ARG;
+  if (p->row_params && p->bias_stride > 0 && (!p->bias_idx || !p->bias_val)) return VLM_ERR_ARG;
+  if (p->row_params && p->bias_stride < 0) return VLM_ERR_ARG;
   PenaltyK k{(int*)p->hist, (int*)p->hist_len, p->hist_cap, p->rep_penalty, p->rep_ctx, p->pres_penalty, p->pres_ctx,
-             p->freq_penalty, p->freq_ctx, (const int*)p->bias_idx, (const float*)p->bias_val, p->n_bias};
+             p->freq_penalty, p->freq_ctx, (const int*)p->bias_idx, (const float*)p->bias_val, p->n_bias,
+             (const float*)p->row_params, p->bias_stride};
   hipLaunchKernelGGL(logit_penalties_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, (bf16_t*)logits, ld, V,
                      (const int*)push_tok, k);
   VLM_CHECK_LAUNCH();

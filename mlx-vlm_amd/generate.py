@@ -89,8 +89,27 @@ class PromptCacheState:
         return n
 
     def update(self, token_ids, kv_cache):
+        if self.cache is not None and kv_cache is not self.cache:
+            self.release()                      # a replaced cache gives its pool slot and pages back
         self.token_ids = [int(t) for t in token_ids]
         self.cache = kv_cache
+
+    def release(self):
+        """Return the pooled KV sequence (slot + pages) of the kept cache to the engine's pool.  The reference's arrays are
+        garbage collected; here the pool is a fixed preallocation, so dropping a state without this would leak its slot."""
+        cache, self.cache, self.token_ids = self.cache, None, None
+        seq = getattr(cache[0], "_seq", None) if cache else None
+        if seq is not None and not getattr(seq, "released", False):
+            try:
+                seq.release()
+            except Exception:       # (interpreter teardown: the pool may already be gone)
+                pass
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 def _peak_gb():
@@ -538,8 +557,20 @@ def batch_generate(model, processor, images=None, audios=None, prompts: Optional
     stop_ids = tuple(getattr(stop, "eos_token_ids", ()) or ())
     smp = _resolve_sampler(kwargs.pop("sampler", None), kwargs.pop("temperature", 0.0), kwargs.pop("top_p", 1.0),
                            kwargs.pop("min_p", 0.0), kwargs.pop("top_k", 0), kwargs.pop("seed", None))
-    run = generate_batch_continuous if kwargs.pop("continuous", True) else batch_generate_ids
-    toks, stats = run(model, ids_l, pix_l, grid_l, max_tokens=max_tokens, stop_ids=stop_ids, sampler=smp, extras=extras)
+    # the reference's batch_generate hands its penalty keywords to the generator (ar.py:2890-3096): one spec for every request
+    from .sample_utils import make_logits_processors
+    procs = make_logits_processors(kwargs.pop("logit_bias", None), kwargs.pop("repetition_penalty", None),
+                                   kwargs.pop("repetition_context_size", 20), kwargs.pop("presence_penalty", None),
+                                   kwargs.pop("presence_context_size", 20), kwargs.pop("frequency_penalty", None),
+                                   kwargs.pop("frequency_context_size", 20))
+    if kwargs.pop("continuous", True):
+        toks, stats = generate_batch_continuous(model, ids_l, pix_l, grid_l, max_tokens=max_tokens, stop_ids=stop_ids, sampler=smp,
+                                                extras=extras, logits_processors=procs if procs else None)
+    else:
+        if procs:
+            raise NotImplementedError("static batches (continuous=False) run without logits processors; use the continuous generator")
+        toks, stats = batch_generate_ids(model, ids_l, pix_l, grid_l, max_tokens=max_tokens, stop_ids=stop_ids, sampler=smp,
+                                         extras=extras)
     texts = [tokenizer.decode(t) if hasattr(tokenizer, "decode") else "" for t in toks]
     return BatchResponse(texts=texts, stats=stats, tokens=toks, image_sizes=sizes if track_image_sizes else None)
 

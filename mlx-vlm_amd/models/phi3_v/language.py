@@ -72,17 +72,20 @@ class LanguageModel(_Engine):
             pad = np.zeros(ENGINE_HEAD_DIM // 2 - hd // 2, dtype=np.float32)
             self._inv_tables = (np.concatenate([np.float32(1.0) / freqs, pad]),
                                 np.concatenate([np.float32(1.0) / (np.asarray(rs["long_factor"], dtype=np.float32) * base), pad]))
-        self._long_regime = False
         self.real_head_dim = hd
         self.model_config = c
         self.max_context = int(c.original_max_position_embeddings) if su else None
+        # both frequency tables live on the device (short, then long); the decode qkv epilogues pick the long one for a whole
+        # step when any row's cache offset has reached original_max, a prefill call is told its regime (_prefill_rope_long)
+        self.rope_long_from = self.max_context or 0
         eng = SimpleNamespace(model_type="phi3_v", hidden_size=c.hidden_size, num_hidden_layers=c.num_hidden_layers,
                               intermediate_size=c.intermediate_size, num_attention_heads=c.num_attention_heads,
                               num_key_value_heads=c.num_key_value_heads, rms_norm_eps=c.rms_norm_eps,
                               vocab_size=c.vocab_size, rope_theta=c.rope_theta, rope_scaling=None,
                               tie_word_embeddings=bool(getattr(c, "tie_word_embeddings", False)),
                               head_dim=ENGINE_HEAD_DIM if hd != ENGINE_HEAD_DIM else None, rope_dim=hd,
-                              inv_freq=(np.float32(1.0) / freqs).tolist(), attn_scale=float(hd) ** -0.5,
+                              inv_freq=(np.float32(1.0) / freqs).tolist(),
+                              inv_freq_long=self._inv_tables[1][: hd // 2].tolist() if su else None, attn_scale=float(hd) ** -0.5,
                               rope_qk_scale=scale if scale != 1.0 else None)
         super().__init__(eng, config, device=device, **engine_kwargs)
 
@@ -187,59 +190,22 @@ class LanguageModel(_Engine):
         return pos, np.zeros((B, 1), dtype=np.int64)
 
     # ------------------------------------------------------------------ short / long factor regimes (rope_utils.py:168-172)
-    def _set_regime(self, long: bool):
-        """Switch the CONTENTS of the engine's frequency table (stream-ordered copy; pointer and graphs unchanged)."""
-        if self._inv_tables is None or bool(long) == self._long_regime:
-            return
-        if not hasattr(self, "_inv_dev"):
-            self._inv_dev = tuple(torch.from_numpy(t).to(self.device) for t in self._inv_tables)
-        self._w["inv_freq"].copy_(self._inv_dev[1 if long else 0])
-        self._long_regime = bool(long)
-
-    def _check_context(self, total: int):
-        """Batched paths (several sequences share the table, admissions run on a second stream): short regime only."""
-        if self.max_context is not None and total > self.max_context:
-            raise NotImplementedError(
-                f"{total} positions exceed original_max_position_embeddings = {self.max_context} in a batch: the long-factor "
-                "regime of SuScaledRoPE is built for one sequence at a time (generate / stream_generate)")
+    # SuScaledRoPE decides PER CALL: position_end = max(cache offset over the rows of the call) + tokens of the call;
+    # long factors (for every row of the call) iff position_end > original_max_position_embeddings.
+    #   * decode steps: evaluated inside the qkv epilogue from the rows' cache offsets (vlm_llm_config.rope_long_from) -
+    #     a captured step crosses the limit by itself, a continuous batch switches all its rows when its longest row
+    #     crosses, exactly as the reference's batched call does;
+    #   * prefill calls (single prompt, chunk onto a cache, an admission of several prompts): the regime of the call is
+    #     computed here and handed to the engine (vlm_prefill_args.rope_long).
+    def _call_regime(self, caches, lengths) -> bool:
+        if self.max_context is None:
+            return False
+        offs = [int(cch[0]._seq.offset) for cch in caches]
+        return max(offs) + max(int(n) for n in lengths) > self.max_context
 
     def prefill(self, inputs_embeds, position_ids, caches, lengths, logits_rows="last", reserve_extra=0):
-        from ..cache import PAGE
-
-        ends = [int(cch[0]._seq.offset) + int(n) for cch, n in zip(caches, lengths)]
-        if len(caches) == 1 and not getattr(self, "_batch_users", 0):
-            self._set_regime(self.max_context is not None and ends[0] > self.max_context)     # the regime of THIS call
-        else:
-            # a BatchGenerator is alive (it registers itself in `_batch_users`) or several sequences share the call: every
-            # sequence must stay in the short regime for its whole life - its page reservation (made by the generator
-            # before the admission prefill: prompt + max_tokens) tells how far it may grow
-            for cch, e in zip(caches, ends):
-                self._check_context(max(e, (len(cch[0]._seq.pages) - 1) * PAGE))
-            self._set_regime(False)
-        return super().prefill(inputs_embeds, position_ids, caches, lengths, logits_rows, reserve_extra)
-
-    def decode_begin(self, caches, first_tokens, rope_deltas, max_new_tokens):
-        if len(caches) > 1 or getattr(self, "_batch_users", 0):
-            for cch in caches:
-                self._check_context(int(cch[0]._seq.offset) + int(max_new_tokens))
-        elif self.max_context is not None:
-            self._set_regime(int(caches[0][0]._seq.offset) >= self.max_context)       # the regime of the first step
-        return super().decode_begin(caches, first_tokens, rope_deltas, max_new_tokens)
-
-    def decode_run(self, st, n_steps, sampler_args, use_graph=True, penalties=None):
-        """A decode step is a call of one token at cache offset o: long factors iff o + 1 > original_max, i.e. from o =
-        original_max on.  A run that crosses is split there, the table switched between the two halves."""
-        if self.max_context is None or n_steps <= 0:
-            return super().decode_run(st, n_steps, sampler_args, use_graph, penalties)
-        o0 = max(int(s.offset) for s in st.seqs)
-        n_short = max(0, min(n_steps, self.max_context - o0))
-        if n_short < n_steps and len(st.seqs) > 1:
-            self._check_context(o0 + n_steps)
-        if n_short > 0:
-            self._set_regime(False)
-            super().decode_run(st, n_short, sampler_args, use_graph, penalties)
-        if n_short < n_steps:
-            self._set_regime(True)
-            super().decode_run(st, n_steps - n_short, sampler_args, use_graph, penalties)
-
-
+        self._prefill_rope_long = self._call_regime(caches, lengths)
+        try:
+            return super().prefill(inputs_embeds, position_ids, caches, lengths, logits_rows, reserve_extra)
+        finally:
+            self._prefill_rope_long = False

@@ -73,8 +73,47 @@ class DecodeState:
         self._pen = None            # (key, PenaltyArgs, device bias tensors) kept alive while a graph may use them
         self.graph_key = None
 
+    MAX_ROW_BIAS = 64           # logit_bias entries per request in the per-row form
+
+    def row_penalty_tables(self):
+        """Device tables of the per-request processors of a continuous batch (vlm_penalty_args.row_params): fp32 [B, 8]
+        parameters and [B, MAX_ROW_BIAS] bias lists, allocated on first use, all zero = every row passes through."""
+        if getattr(self, "row_params", None) is None:
+            dev = self.hist.device
+            self.row_params = torch.zeros(self.B, 8, dtype=torch.float32, device=dev)
+            self.row_bias_idx = torch.zeros(self.B, self.MAX_ROW_BIAS, dtype=torch.int32, device=dev)
+            self.row_bias_val = torch.zeros(self.B, self.MAX_ROW_BIAS, dtype=torch.float32, device=dev)
+            self._pen_rows = _lib.PenaltyArgs(self.hist.data_ptr(), self.hist_len.data_ptr(), self.hist.shape[1], 0.0, 0, 0.0, 0,
+                                              0.0, 0, self.row_bias_idx.data_ptr(), self.row_bias_val.data_ptr(), 0,
+                                              self.row_params.data_ptr(), self.MAX_ROW_BIAS)
+        return self._pen_rows
+
+    @classmethod
+    def pack_row_penalties(cls, specs, hist_cap: int):
+        """specs: one sample_utils.LogitsProcessors (or None) per row -> host arrays (params f32 [n, 8], bias_idx i32
+        [n, MAX_ROW_BIAS], bias_val f32 [n, MAX_ROW_BIAS]) in the layout of vlm_penalty_args.row_params"""
+        n = len(specs)
+        params = np.zeros((n, 8), dtype=np.float32)
+        bidx = np.zeros((n, cls.MAX_ROW_BIAS), dtype=np.int32)
+        bval = np.zeros((n, cls.MAX_ROW_BIAS), dtype=np.float32)
+        for r, sp in enumerate(specs):
+            if not sp:
+                continue
+            bias = sp.logit_bias or {}
+            if len(bias) > cls.MAX_ROW_BIAS:
+                raise NotImplementedError(f"more than {cls.MAX_ROW_BIAS} logit_bias entries per request in a continuous batch")
+            params[r, :6] = (sp.repetition_penalty, min(sp.repetition_context_size, hist_cap), sp.presence_penalty,
+                             min(sp.presence_context_size, hist_cap), sp.frequency_penalty, min(sp.frequency_context_size, hist_cap))
+            params[r, 6] = len(bias)
+            bidx[r, :len(bias)] = list(bias.keys())
+            bval[r, :len(bias)] = list(bias.values())
+        return params, bidx, bval
+
     def penalty_args(self, spec):
-        """_lib.PenaltyArgs over this state's history for a sample_utils.LogitsProcessors spec (cached per spec)."""
+        """_lib.PenaltyArgs over this state's history for a sample_utils.LogitsProcessors spec (cached per spec);
+        spec == "rows": the per-row tables of a continuous batch (row_penalty_tables)."""
+        if isinstance(spec, str) and spec == "rows":
+            return self.row_penalty_tables()
         if not spec:
             return None
         if self._pen is None or self._pen[0] != spec.key():
@@ -196,7 +235,8 @@ class LanguageModel:
         cfg = _lib.LlmConfig(t.hidden_size, t.num_hidden_layers, t.intermediate_size, t.num_attention_heads,
                              t.num_key_value_heads, self.head_dim, t.vocab_size, float(t.rms_norm_eps),
                              int(self.mrope_section[0]), int(self.mrope_section[1]),
-                             float(getattr(t, "attn_scale", 0.0) or 0.0), float(getattr(t, "rope_qk_scale", 0.0) or 0.0))
+                             float(getattr(t, "attn_scale", 0.0) or 0.0), float(getattr(t, "rope_qk_scale", 0.0) or 0.0),
+                             int(getattr(self, "rope_long_from", 0) or 0))
         h = C.c_void_p()
         check(L.vlm_llm_create(C.byref(cfg), C.byref(h)), "llm_create")
         self._handle = h
@@ -260,6 +300,10 @@ class LanguageModel:
             own = torch.as_tensor(t.inv_freq, dtype=torch.float32).reshape(-1)
             inv.zero_()
             inv[: own.numel()] = own
+        if getattr(t, "inv_freq_long", None) is not None:   # second table behind the first (vlm_llm_config.rope_long_from)
+            own = torch.as_tensor(t.inv_freq_long, dtype=torch.float32).reshape(-1)
+            inv = torch.cat([inv, torch.zeros(hd // 2, dtype=torch.float32)])
+            inv[hd // 2: hd // 2 + own.numel()] = own
         inv_freq = self.arena.put(inv.to(dev))
         self._w.update(embed=embed, head=head, norm=norm, inv_freq=inv_freq)
         isq = lambda x: isinstance(x, Qz.QuantW)    # noqa: E731
@@ -446,7 +490,7 @@ class LanguageModel:
         a = _lib.PrefillArgs(h.data_ptr(), T, pos_d[0].data_ptr(), pos_d[1].data_ptr(), pos_d[2].data_ptr(),
                              kv_seq_d.data_ptr(), kv_slot_d.data_ptr(), cu_d.data_ptr(), len(lengths), nqb,
                              xn.data_ptr(), qkv.data_ptr(), attn.data_ptr(), act.data_ptr(), rows_d.data_ptr(),
-                             len(rows), xlast.data_ptr(), logits.data_ptr())
+                             len(rows), xlast.data_ptr(), logits.data_ptr(), int(bool(getattr(self, "_prefill_rope_long", False))))
         check(_lib.lib().vlm_llm_prefill(self._handle, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
               "llm_prefill")
         for n, s in zip(lengths, seqs):
@@ -494,12 +538,14 @@ class LanguageModel:
             return ops.dequant_w4(x.wq, x.sb) if hasattr(x, "wq") else x
 
         for i in range(t.num_hidden_layers):
-            w = {k: (dense(v) if k.startswith(f"{i}.") or k in ("head",) else v) for k, v in self._w.items()
-                 if k.startswith(f"{i}.") or k in ("inv_freq", "norm", "head")} if self.quantized else self._w
+            # only THIS layer's matrices are dequantised here (the head once, after the loop)
+            w = {k: (dense(v) if k.startswith(f"{i}.") else v) for k, v in self._w.items()
+                 if k.startswith(f"{i}.") or k in ("inv_freq", "norm")} if self.quantized else self._w
             kp, vp = pool.kpool[i], pool.vpool[i]          # this layer's K / V pools (flat views)
             xn = ops.rmsnorm(h, w[f"{i}.ln1"], t.rms_norm_eps)
             qkv = ops.gemm(xn, w[f"{i}.wqkv"], bias=w[f"{i}.bqkv"], epilogue=ops.EPI_BIAS)
-            ops.mrope_kvwrite_(qkv, Hq, Hkv, hd, pos_d[0], pos_d[1], pos_d[2], w["inv_freq"], int(sec[0]), int(sec[1]),
+            inv_tab = w["inv_freq"][hd // 2:] if getattr(self, "_prefill_rope_long", False) else w["inv_freq"]   # SuScaledRoPE regime of this call
+            ops.mrope_kvwrite_(qkv, Hq, Hkv, hd, pos_d[0], pos_d[1], pos_d[2], inv_tab, int(sec[0]), int(sec[1]),
                                kv_seq=new_seq_d.contiguous(), kv_slot=new_slot_d.contiguous(), block_table=bt, kpool=kp, vpool=vp,
                                qk_scale=getattr(t, "rope_qk_scale", None))
             full = torch.zeros(Tf, QKV, dtype=bf, device=dev)
@@ -515,8 +561,8 @@ class LanguageModel:
             h = ops.gemm(act, w[f"{i}.wdown"], res=h, epilogue=ops.EPI_RESIDUAL)
         cu_new = np.concatenate([[0], np.cumsum(lengths)])
         rows = (cu_new[1:] - 1) if logits_rows == "last" else np.arange(T)
-        xl = ops.rmsnorm(h[_lib.h2d(rows.astype(np.int64), dev)].contiguous(), w["norm"], t.rms_norm_eps)
-        logits = ops.gemm(xl, w["head"])[:, : t.vocab_size]
+        xl = ops.rmsnorm(h[_lib.h2d(rows.astype(np.int64), dev)].contiguous(), self._w["norm"], t.rms_norm_eps)
+        logits = ops.gemm(xl, dense(self._w["head"]))[:, : t.vocab_size]
         for n, s in zip(lengths, seqs):
             s.offset += n
         return logits
@@ -628,7 +674,7 @@ class LanguageModel:
             s.offset += n_steps
 
     def decode_step_rows(self, st: DecodeState, B: int, block_table: torch.Tensor, sampler_args: dict,
-                         use_graph: bool = True, with_logprobs: bool = True):
+                         use_graph: bool = True, with_logprobs: bool = True, row_penalties: bool = False):
         """One decode step over rows 0..B-1 of `st` (B in {1, 2, 4, 8}), addressing the KV pool through the caller's own
         `block_table` (int32 [>= B, max_pages]).  A continuous batch keeps such a table so that a sequence changes
         batch row by copying one table row - no KV bytes move (the reference's `filter`/`extend` copy the caches,
@@ -639,9 +685,10 @@ class LanguageModel:
         kv = _lib.KvPool(pool.kpool.data_ptr(), pool.vpool.data_ptr(), pool.layer_stride, block_table.data_ptr(),
                          pool.max_pages)
         check(L.vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
-        args = st.args(B=B, with_logprobs=with_logprobs, **sampler_args)
+        # row_penalties: the step applies every row's own logits processors (device tables of the state) before sampling
+        args = st.args(B=B, with_logprobs=with_logprobs, penalties="rows" if row_penalties else None, **sampler_args)
         if use_graph:
-            key = ("rows", B, st.nsplit, block_table.data_ptr(), with_logprobs, tuple(sorted(sampler_args.items())))
+            key = ("rows", B, st.nsplit, block_table.data_ptr(), with_logprobs, bool(row_penalties), tuple(sorted(sampler_args.items())))
             if st.graph_key != key or getattr(self, "_graph_owner", None) is not st:
                 check(L.vlm_llm_decode_graph_build(self._handle, C.byref(args), stream), "decode_graph_build")
                 st.graph_key = key

@@ -165,13 +165,24 @@ def detokenizer_class_for(model_path: str):
         return NaiveStreamingDetokenizer
     with open(path, "r", encoding="utf-8") as f:
         dec = json.load(f).get("decoder")          # a malformed file raises JSONDecodeError, as the reference does
-    if isinstance(dec, dict):
-        if dec.get("type") == "ByteLevel":
-            return BPEStreamingDetokenizer
-        if dec.get("type") == "Sequence":
-            steps = dec.get("decoders")
-            if steps == _SPM_STEPS + [_SPM_STRIP]:
-                return SPMStreamingDetokenizer
-            if steps == _SPM_STEPS:
-                return partial(SPMStreamingDetokenizer, trim_space=False)
+    # the reference compares the WHOLE decoder description (tokenizer_utils.py:413-452: same keys, same values, nothing
+    # extra anywhere in the structure - python's == on the parsed JSON is that comparison, bool / int type included) for the
+    # two SPM forms, and only the type for ByteLevel; SPM forms are tried first, as there
+    if dec is not None and _same_json(dec, {"type": "Sequence", "decoders": _SPM_STEPS + [_SPM_STRIP]}):
+        return SPMStreamingDetokenizer
+    if dec is not None and _same_json(dec, {"type": "Sequence", "decoders": _SPM_STEPS}):
+        return partial(SPMStreamingDetokenizer, trim_space=False)
+    if isinstance(dec, dict) and dec.get("type") == "ByteLevel":
+        return BPEStreamingDetokenizer
     return NaiveStreamingDetokenizer
+
+
+def _same_json(a, b) -> bool:
+    """structural equality with equal TYPES at every node (1 != True, 1 != 1.0), no extra or missing keys / items"""
+    if type(a) is not type(b):
+        return False
+    if isinstance(a, dict):
+        return len(a) == len(b) and all(k in b and _same_json(v, b[k]) for k, v in a.items())
+    if isinstance(a, list):
+        return len(a) == len(b) and all(_same_json(x, y) for x, y in zip(a, b))
+    return a == b

@@ -998,12 +998,21 @@ class _Fast:
         t = _a(x)._t
         L = t.shape[-2]
         off = _py(offset)
-        pos = (torch.arange(L, dtype=torch.float32) + float(off if not isinstance(off, list) else off[0])) * scale
         if freqs is not None:
             inv = 1.0 / _a(freqs)._t.to(torch.float32)
         else:
             inv = 1.0 / (base ** (torch.arange(0, dims, 2, dtype=torch.float32) / dims))
-        ang = pos[:, None] * inv[None, :]
+        if isinstance(off, list) and len(off) > 1:
+            # mx.fast.rope: "offset (int or array): ... a scalar or a vector of B offsets, one for each example in the batch":
+            # row b of x [B, ..., L, D] rotates at positions offset[b] + 0 .. L-1
+            if len(off) != t.shape[0]:
+                raise ValueError(f"mlx shim: rope offset vector of {len(off)} for a batch of {t.shape[0]}")
+            pos = (torch.arange(L, dtype=torch.float32)[None, :] + torch.tensor([float(o) for o in off])[:, None]) * scale
+            ang = pos[:, :, None] * inv[None, None, :]                           # [B, L, dims/2]
+            ang = ang.reshape((t.shape[0],) + (1,) * (t.dim() - 3) + (L, inv.numel()))
+        else:
+            pos = (torch.arange(L, dtype=torch.float32) + float(off if not isinstance(off, list) else off[0])) * scale
+            ang = pos[:, None] * inv[None, :]
         c, s_ = torch.cos(ang), torch.sin(ang)
         xf = t.to(torch.float32)
         rot, rest = xf[..., :dims], xf[..., dims:]

@@ -342,20 +342,23 @@ def su_rope_tables(t: TextCfg, dtype=torch.bfloat16):
     return (1.0 / (torch.tensor(t.short_factor, dtype=F32) * freqs), 1.0 / (torch.tensor(t.long_factor, dtype=F32) * freqs), s)
 
 
-def su_rope(x: torch.Tensor, offset: int, t: TextCfg) -> torch.Tensor:
-    """SuScaledRoPE.__call__ (rope_utils.py:168-189): long factors iff offset + L > original_max_position_embeddings
-    (decided per call, for the rows of that call only); x * T(scale) is a typed multiply; mx.fast.rope then rotates
-    half-split pairs with fp32 angles pos / freqs and one rounding."""
+def su_rope(x: torch.Tensor, offset: int, t: TextCfg, position_end: Optional[int] = None) -> torch.Tensor:
+    """SuScaledRoPE.__call__ (rope_utils.py:168-189): position_end = max(offset over the rows of the CALL) + L; long
+    factors (and the long scale) for EVERY row of the call iff position_end > original_max_position_embeddings; x *
+    T(scale) is a typed multiply; mx.fast.rope then rotates half-split pairs with fp32 angles pos / freqs and one
+    rounding.  This function rotates ONE sequence at cache offset `offset`; `position_end` carries the call-wide value
+    when the sequence is a row of a batched call (None: the sequence is the whole call, position_end = offset + L)."""
     L = x.shape[-2]
     inv_s, inv_l, s = su_rope_tables(t, x.dtype)
-    inv = inv_l if offset + L > t.original_max_position_embeddings else inv_s
+    pe = offset + L if position_end is None else int(position_end)
+    inv = inv_l if pe > t.original_max_position_embeddings else inv_s
     if t.short_factor is not None:
         x = (x.to(F32) * s).to(x.dtype)
     pos = torch.arange(offset, offset + L)[None].expand(x.shape[0], L)
     return ops.mrope_apply(x, pos, inv, None, "fused")
 
 
-def attention(W, p: str, cfg: Cfg, x: torch.Tensor, cache: Optional[ops.KVCache]) -> torch.Tensor:
+def attention(W, p: str, cfg: Cfg, x: torch.Tensor, cache: Optional[ops.KVCache], position_end: Optional[int] = None) -> torch.Tensor:
     """Attention (phi3_v.py:17-94): one qkv Linear (no bias) split [q | k | v], rope at cache.offset, KVCache, causal
     SDPA at head_dim ** -0.5, o_proj."""
     t = cfg.text
@@ -366,29 +369,31 @@ def attention(W, p: str, cfg: Cfg, x: torch.Tensor, cache: Optional[ops.KVCache]
     k = qkv[..., H * hd: (H + Hkv) * hd].reshape(B, L, Hkv, hd).permute(0, 2, 1, 3)
     v = qkv[..., (H + Hkv) * hd:].reshape(B, L, Hkv, hd).permute(0, 2, 1, 3)
     off = cache.offset if cache is not None else 0
-    q, k = su_rope(q, off, t), su_rope(k, off, t)
+    q, k = su_rope(q, off, t, position_end), su_rope(k, off, t, position_end)
     if cache is not None:
         k, v = cache.update_and_fetch(k, v)
     o = ops.sdpa(q, k, v, scale=hd ** -0.5, causal=L > 1, q_offset=k.shape[2] - L)
     return ops.linear(o.permute(0, 2, 1, 3).reshape(B, L, -1), W[p + "o_proj.weight"])
 
 
-def decoder_layer(W, i: int, cfg: Cfg, x: torch.Tensor, cache) -> torch.Tensor:
+def decoder_layer(W, i: int, cfg: Cfg, x: torch.Tensor, cache, position_end: Optional[int] = None) -> torch.Tensor:
     """TransformerBlock (phi3_v.py:109-133) with MLP (96-106): gate_up Linear split [gate | up], silu(gate) * up, down."""
     p = f"{M}layers.{i}."
     eps = cfg.text.rms_norm_eps
-    h = ops.add(x, attention(W, p + "self_attn.", cfg, ops.rms_norm(x, W[p + "input_layernorm.weight"], eps), cache))
+    h = ops.add(x, attention(W, p + "self_attn.", cfg, ops.rms_norm(x, W[p + "input_layernorm.weight"], eps), cache, position_end))
     gu = ops.linear(ops.rms_norm(h, W[p + "post_attention_layernorm.weight"], eps), W[p + "mlp.gate_up_proj.weight"])
     I = gu.shape[-1] // 2
     return ops.add(h, ops.linear(ops.swiglu(gu[..., :I], gu[..., I:]), W[p + "mlp.down_proj.weight"]))
 
 
-def language_model(W, cfg: Cfg, inputs_embeds: torch.Tensor, cache=None, last_only: bool = False) -> torch.Tensor:
-    """Phi3V layers -> norm -> lm_head (phi3_v.py:136-197).  -> logits [B, L, V] (last_only: [B, 1, V], same values)"""
+def language_model(W, cfg: Cfg, inputs_embeds: torch.Tensor, cache=None, last_only: bool = False,
+                   position_end: Optional[int] = None) -> torch.Tensor:
+    """Phi3V layers -> norm -> lm_head (phi3_v.py:136-197).  -> logits [B, L, V] (last_only: [B, 1, V], same values).
+    position_end: see su_rope (the rope regime of a batched call is decided by its longest row)."""
     h = inputs_embeds
     cache = cache or [None] * cfg.text.num_hidden_layers
     for i in range(cfg.text.num_hidden_layers):
-        h = decoder_layer(W, i, cfg, h, cache[i])
+        h = decoder_layer(W, i, cfg, h, cache[i], position_end)
     if last_only:
         h = h[:, -1:, :]
     return ops.linear(ops.rms_norm(h, W[M + "norm.weight"], cfg.text.rms_norm_eps), W["lm_head.weight"])

@@ -216,6 +216,13 @@ def main():
     blob["su_rope.short_at_100"] = f32(rope(x, offset=100))
     blob["su_rope.long_at_4095"] = f32(rope(x, offset=4095))
     blob["su_rope.scale"] = np.array([float(rope._short_scale)], dtype=np.float64)
+    # a BATCHED decode call, L = 1 (rope_utils.py:168-172: position_end = max(offset) + L decides for every row): row 0 at
+    # offset 100 rides the long factors because row 1 sits at 4096 (4097 > 4096); a batch whose longest row is at 4095
+    # (4096 > 4096 is false) stays short
+    xb = mx.array(torch.randn(2, 2, 1, 96, generator=torch.Generator().manual_seed(4)).to(torch.bfloat16))
+    blob["su_rope.xb"] = f32(xb)
+    blob["su_rope.batched_100_4096"] = f32(rope(xb, offset=mx.array([100, 4096])))
+    blob["su_rope.batched_100_4095"] = f32(rope(xb, offset=mx.array([100, 4095])))
 
     # ---- VisionModel.sanitize (vision.py:264-280): conv layout + position_ids
     hf = {"model.vision_embed_tokens.img_processor.vision_model.embeddings.patch_embedding.weight": mx.array(torch.zeros(8, 3, 14, 14)),

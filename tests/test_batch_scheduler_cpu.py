@@ -216,3 +216,33 @@ def test_rejects_what_the_built_path_does_not_do():
     with pytest.raises(ValueError):
         gen.insert([np.arange(3)], max_tokens=[1, 2])
     gen.close()
+
+
+def test_per_request_logits_processors_travel_with_their_rows():
+    """insert(..., logits_processors=) (ar.py:2584-2606): the spec of a request reaches the row it is given, follows the
+    row when the scheduler moves it into a hole, and a row re-used by a request without processors carries none; the
+    streams themselves are untouched by the bookkeeping (mock engine)."""
+    from mlx_vlm_amd.sample_utils import make_logits_processors
+
+    pool = make_pool()
+    gen = MockEngineGenerator(pool, completion_batch_size=2, prefill_batch_size=2, async_prefill=False)
+    prompts = [np.arange(3 + i) + 5 for i in range(5)]
+    specs = [make_logits_processors(repetition_penalty=1.2), None, [make_logits_processors(logit_bias={3: 1.0})], None,
+             make_logits_processors(presence_penalty=0.5)]
+    uids = gen.insert(prompts, [3, 7, 4, 2, 5], logits_processors=specs)
+    want = {u: (s[0] if isinstance(s, list) else s) for u, s in zip(uids, specs)}
+    seen = {}
+    got = {u: [] for u in uids}
+    while gen.has_work:
+        _, out = gen.next()
+        for row in gen._rows:
+            seen.setdefault(row.uid, row.procs)
+            assert row.procs is want[row.uid]
+        for r in out:
+            got[r.uid].append(r.token)
+    assert set(seen) == set(uids)
+    for u, p, m in zip(uids, prompts, [3, 7, 4, 2, 5]):
+        assert got[u] == stream_alone(p, m)
+    with pytest.raises(ValueError):
+        gen.insert([np.arange(3)], logits_processors=[None, None])
+    gen.close()

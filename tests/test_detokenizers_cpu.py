@@ -80,6 +80,15 @@ def test_detokenizer_class_is_picked_from_tokenizer_json(tmp_path):
     assert isinstance(got, partial) and got.func is SPMStreamingDetokenizer and got.keywords == {"trim_space": False}
     (tmp_path / "tokenizer.json").write_text(json.dumps({"decoder": {"type": "WordPiece"}}))
     assert detokenizer_class_for(str(tmp_path)) is NaiveStreamingDetokenizer
+    # the reference's _match compares the WHOLE description (tokenizer_utils.py:413-421): an SPM Sequence with an extra key
+    # anywhere, or a value of another type, is NOT the SPM decoder there and falls back to the naive detokenizer
+    spm = json.loads(str(G["spm.json"][0]))
+    for mutate in (lambda d: d["decoder"].update(extra=1), lambda d: d["decoder"]["decoders"][0].update(note="x"),
+                   lambda d: d["decoder"]["decoders"][3].update(start=1.0), lambda d: d["decoder"]["decoders"].append({"type": "Fuse"})):
+        d = json.loads(json.dumps(spm))
+        mutate(d)
+        (tmp_path / "tokenizer.json").write_text(json.dumps(d))
+        assert detokenizer_class_for(str(tmp_path)) is NaiveStreamingDetokenizer
     (tmp_path / "tokenizer.json").write_text("{ not json")
     with pytest.raises(json.JSONDecodeError):
         detokenizer_class_for(str(tmp_path))

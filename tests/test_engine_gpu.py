@@ -721,6 +721,52 @@ def test_batch_generator_continuous_equals_single_requests(tiny, async_prefill):
     assert len(model.language_model.pool._free_seqs) == free_before      # every sequence and the scratch page returned
 
 
+@pytest.mark.parametrize("async_prefill", [True, False])
+def test_batch_generator_per_request_logits_processors_equal_single_requests(tiny, async_prefill):
+    """BatchGenerator.insert(..., logits_processors=) (reference ar.py:2584-2606): 10 requests through 4 decode rows, each
+    with ITS OWN processors - repetition penalty, presence + frequency penalties with short contexts, a logit_bias list,
+    all of them, or none - must produce exactly the tokens and token log-probs they produce alone through generate_step
+    with the same keywords (the single-stream device pass, pinned to the reference's processors in test_ops_gpu.py).
+    Rows finish at different steps and move (their history / parameter rows move with them); a row that had processors
+    is re-used by a request without any."""
+    from mlx_vlm_amd.batch import BatchGenerator
+    from mlx_vlm_amd.generate import generate_step
+    from mlx_vlm_amd.sample_utils import make_logits_processors
+
+    cfg, W, model = tiny
+    reqs = _mixed_requests(cfg, 10, seed0=240)
+    max_tokens = [6 + (5 * i) % 9 for i in range(10)]
+    kws = [dict(repetition_penalty=1.3, repetition_context_size=12), None, dict(presence_penalty=0.75, presence_context_size=5,
+           frequency_penalty=0.25, frequency_context_size=9), dict(logit_bias={7: 4.0, 901: -3.0, 333: 2.5}), None,
+           dict(repetition_penalty=1.1, presence_penalty=0.5, frequency_penalty=0.125, logit_bias={5: 1.0}),
+           dict(repetition_penalty=1.5), None, dict(frequency_penalty=0.5, frequency_context_size=20), dict(logit_bias={11: 6.0})]
+    singles = []
+    for (ids, pix, thw), m, kw in zip(reqs, max_tokens, kws):
+        a = dict(image_grid_thw=thw) if thw is not None else {}
+        a.update(kw or {})
+        singles.append([(t, float(lp[t])) for t, lp in generate_step(ids, model, torch.from_numpy(pix) if pix is not None else None,
+                                                                      None, max_tokens=m, **a)])
+    plain = _single_runs(model, reqs, max_tokens)
+    assert sum(a != b for a, b in zip(singles, plain)) >= 4              # the processors do change these streams
+    gen = BatchGenerator(model, None, max_tokens=7, completion_batch_size=4, prefill_batch_size=2, async_prefill=async_prefill)
+    pk = [dict(pixel_values=torch.from_numpy(p), image_grid_thw=g) if p is not None else {} for _, p, g in reqs]
+    specs = [make_logits_processors(**kw) if kw else None for kw in kws]
+    uids = gen.insert([r[0].reshape(-1) for r in reqs], list(max_tokens), prompt_kwargs=pk, logits_processors=specs)
+    got = {u: [] for u in uids}
+    while gen.has_work:
+        _, out = gen.next()
+        for r in out:
+            got[r.uid].append((r.token, r.token_logprob))
+    gen.close()
+    for u in uids:
+        assert [t for t, _ in got[u]] == [t for t, _ in singles[u]], (u, kws[u], got[u], singles[u])
+        np.testing.assert_allclose([lp for _, lp in got[u]], [lp for _, lp in singles[u]], atol=2 ** -6, rtol=2 ** -7)
+    gen2 = BatchGenerator(model, None)
+    with pytest.raises(NotImplementedError):            # a Python callable cannot run inside the captured step
+        gen2.insert([reqs[2][0].reshape(-1)], logits_processors=[[lambda toks, logits: logits]])
+    gen2.close()
+
+
 def test_batch_generator_16_rows_matrix_core_steps_equal_single_requests(tiny):
     """20 requests through 16 decode rows: steps of 16 and 8 rows run their projections on the matrix cores
     (csrc/gemv_mfma.hip), narrower ones on the v_dot2c GEMVs, single requests on the latter only.  The two kernel families

@@ -170,6 +170,16 @@ def test_su_scaled_rope_short_and_long_factors_vs_reference():
     assert np.array_equal(op.su_rope(x, 4095, t).float().numpy(), G["su_rope.long_at_4095"])
     _, _, s = op.su_rope_tables(t, torch.float32)
     assert abs(s - float(G["su_rope.scale"][0])) < 1e-6
+    # a BATCHED decode call of the reference's class (offset = array, L = 1): position_end = max(offset) + L decides for
+    # EVERY row - row 0 at offset 100 takes the long factors when row 1 sits at 4096, the short ones when the longest row
+    # is at 4095
+    xb = torch.from_numpy(G["su_rope.xb"]).to(torch.bfloat16)
+    for key, offs in (("su_rope.batched_100_4096", (100, 4096)), ("su_rope.batched_100_4095", (100, 4095))):
+        pe = max(offs) + xb.shape[-2]
+        got = torch.cat([op.su_rope(xb[r:r + 1], offs[r], t, position_end=pe) for r in range(2)])
+        assert np.array_equal(got.float().numpy(), G[key]), key
+    alone = op.su_rope(xb[0:1], 100, t).float().numpy()                    # row 0 alone: short factors
+    assert np.array_equal(alone, G["su_rope.batched_100_4095"][0:1]) and not np.array_equal(alone, G["su_rope.batched_100_4096"][0:1])
 
 
 def test_prompt_assembly_vs_reference():

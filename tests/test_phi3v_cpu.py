@@ -137,13 +137,21 @@ def test_model_construction_and_weight_packing_run_without_a_device(w4):
     inv = lm._w["inv_freq"]
     short = torch.tensor(t.short_factor)
     want = 1.0 / (short * t.rope_theta ** (torch.arange(0, 96, 2).float() / 96))
-    assert torch.allclose(inv[:48], want, rtol=1e-6) and float(inv[48:].abs().max()) == 0.0
+    assert torch.allclose(inv[:48], want, rtol=1e-6) and float(inv[48:64].abs().max()) == 0.0
+    # both regimes are resident: the long-factor table sits behind the short one (vlm_llm_config.rope_long_from)
+    want_long = 1.0 / (torch.tensor(t.long_factor) * t.rope_theta ** (torch.arange(0, 96, 2).float() / 96))
+    assert inv.numel() == 128 and torch.allclose(inv[64:112], want_long, rtol=1e-6) and float(inv[112:].abs().max()) == 0.0
+    assert lm.rope_long_from == t.original_max_position_embeddings
     assert abs(lm.args.attn_scale - 96 ** -0.5) < 1e-7 and lm.args.rope_qk_scale == 1.1875
     vt = model.vision_model
     assert vt.n_run_layers == cfg.vision.num_hidden_layers - 1 and f"{vt.n_run_layers}.wqkv" not in vt._w
     assert vt._w["0.wqkv"].shape == (3 * 1024, 1024) and vt._w["wpatch"].shape == (1024, 640)
-    with pytest.raises(NotImplementedError):
-        lm._check_context(4097)
+    # SuScaledRoPE's per-call rule (rope_utils.py:168-172): max cache offset + tokens of the call > original_max
+    from types import SimpleNamespace as NS
+    mk = lambda off: [NS(_seq=NS(offset=off))]   # noqa: E731
+    lim = t.original_max_position_embeddings
+    assert lm._call_regime([mk(0)], [lim]) is False and lm._call_regime([mk(0)], [lim + 1]) is True
+    assert lm._call_regime([mk(0), mk(lim - 3)], [2, 4]) is True and lm._call_regime([mk(lim - 5), mk(7)], [2, 5]) is False
 
 
 def test_processor_bit_exact_and_token_rule():

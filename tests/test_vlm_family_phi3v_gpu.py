@@ -337,3 +337,81 @@ def test_su_rope_long_factor_regime_switches_per_call(tiny, prompt_len):
     _check_rows(_engine_teacher_forced(model, ids2, None, None, f2)[0], op.decode_teacher_forced(W, cfg, ids2, None, None, f2), 2e-2,
                 "phi3v short again")
     print(f"phi3v long-factor regime, prompt {prompt_len}: worst row rel-rms {worst:.4f}")
+
+
+@pytest.mark.parametrize("w4", [False, True])
+def test_su_rope_regime_of_a_batched_decode_step_follows_its_longest_row(w4):
+    """SuScaledRoPE decides per CALL (rope_utils.py:168-172): position_end = max(cache offset over the rows) + 1.  Two rows
+    decode together: row 0 stays near offset 30, row 1 runs from offset 4090 across 4096 - from the step where row 1's
+    offset is 4096 on, BOTH rows rotate with the long factors (row 0's new keys too), exactly as the reference's batched
+    call does (pinned in test_oracle_ref_golden_phi3v.py against the reference's own class run with an offset array).
+    The engine evaluates the rule inside the qkv epilogue from the rows' cache offsets (vlm_llm_config.rope_long_from):
+    every row of every step against the oracle with the call-wide position_end; and a control - row 0 decoded ALONE over
+    the same steps stays short and must differ from its batched logits after the crossing."""
+    if w4:
+        cfg, ck, ow = _quantized_tiny(seed=777)
+    else:
+        cfg = op.tiny_cfg()
+        ck = ow = op.random_weights(cfg, seed=777, dtype=BF, **SCALES)
+    model = build_phi3v_model(cfg, ck, kv_pool_tokens=16384, max_seqs=8)
+    lm = model.language_model
+    lim = cfg.text.original_max_position_embeddings
+    rng = np.random.default_rng(910)
+    prompts = [rng.integers(3, 1000, 30).astype(np.int64), rng.integers(3, 1000, lim - 6).astype(np.int64)]
+    n_steps = 10
+    forced = rng.integers(3, 1000, (n_steps, 2))
+    caches, ocaches = [], []
+    for p in prompts:
+        c = lm.make_cache()
+        lm(p[None], cache=c, logits_to_keep=1)
+        caches.append(c)
+        oc = [O.KVCache() for _ in range(cfg.text.num_hidden_layers)]
+        op.language_model(ow, cfg, op.embed_tokens(ow, p[None]), oc, last_only=True)
+        ocaches.append(oc)
+    worst, crossed = 0.0, 0
+    row0_batched = []
+    for s in range(n_steps):
+        pe = max(len(p) + s for p in prompts) + 1                      # the call's position_end
+        crossed += pe > lim
+        got = lm(forced[s].reshape(2, 1), cache=caches).logits[:, 0]
+        row0_batched.append(got[0].float().cpu())
+        for r in range(2):
+            ref = op.language_model(ow, cfg, op.embed_tokens(ow, np.array([[int(forced[s, r])]])), ocaches[r], position_end=pe)[0, 0]
+            e = _rel_rms(got[r], ref)
+            worst = max(worst, e)
+            assert e < 2.5e-2, (s, r, pe, e)
+    assert 0 < crossed < n_steps                                        # steps on both sides of the limit
+    for c in caches:
+        c[0]._seq.release()
+    # control: row 0 alone never leaves the short regime - same tokens, different logits once the batch has crossed
+    c0 = lm.make_cache()
+    lm(prompts[0][None], cache=c0, logits_to_keep=1)
+    alone = [lm(np.array([[int(forced[s, 0])]]), cache=c0).logits[0, 0].float().cpu() for s in range(n_steps)]
+    c0[0]._seq.release()
+    first_long = n_steps - crossed
+    assert _rel_rms(alone[first_long - 1], row0_batched[first_long - 1]) < 2.5e-2      # before: the same computation
+    assert _rel_rms(alone[n_steps - 1], row0_batched[n_steps - 1]) > 5e-2               # after: another rope regime
+    print(f"batched Su-RoPE regime (w4={w4}): worst row rel-rms {worst:.4f}, {crossed} long steps of {n_steps}")
+
+
+def test_batch_generator_row_crossing_the_su_rope_limit():
+    """A continuous batch whose row crosses original_max_position_embeddings used to raise; it now decodes, the regime of
+    every step being decided on the device by the longest live row.  One request alone in the generator (the batch IS the
+    sequence): tokens equal generate_step's."""
+    from mlx_vlm_amd.batch import BatchGenerator
+    from mlx_vlm_amd.generate import generate_step
+
+    cfg = op.tiny_cfg()
+    W = op.random_weights(cfg, seed=778, dtype=BF, **SCALES)
+    model = build_phi3v_model(cfg, W, kv_pool_tokens=16384, max_seqs=40)
+    lim = cfg.text.original_max_position_embeddings
+    ids = np.random.default_rng(911).integers(3, 1000, (1, lim - 5))
+    single = [t for t, _ in generate_step(ids, model, None, None, max_tokens=12, temperature=0.0)]
+    gen = BatchGenerator(model, None, max_tokens=12, completion_batch_size=4)
+    (uid,) = gen.insert([ids.reshape(-1)], [12])
+    got = []
+    while gen.has_work:
+        _, out = gen.next()
+        got += [r.token for r in out if r.uid == uid]
+    gen.close()
+    assert got == single and len(got) == 12
