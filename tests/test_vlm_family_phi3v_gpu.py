@@ -339,12 +339,14 @@ def test_su_rope_long_factor_regime_switches_per_call(tiny, prompt_len):
     print(f"phi3v long-factor regime, prompt {prompt_len}: worst row rel-rms {worst:.4f}")
 
 
+@pytest.mark.parametrize("B", [2, 9])
 @pytest.mark.parametrize("w4", [False, True])
-def test_su_rope_regime_of_a_batched_decode_step_follows_its_longest_row(w4):
+def test_su_rope_regime_of_a_batched_decode_step_follows_its_longest_row(w4, B):
     """SuScaledRoPE decides per CALL (rope_utils.py:168-172): position_end = max(cache offset over the rows) + 1.  Two rows
     decode together: row 0 stays near offset 30, row 1 runs from offset 4090 across 4096 - from the step where row 1's
     offset is 4096 on, BOTH rows rotate with the long factors (row 0's new keys too), exactly as the reference's batched
     call does (pinned in test_oracle_ref_golden_phi3v.py against the reference's own class run with an offset array).
+    B = 2: the v_dot2c qkv epilogues (bf16 / 4-bit); B = 9: the skinny-M MFMA form (8 short rows + the long one).
     The engine evaluates the rule inside the qkv epilogue from the rows' cache offsets (vlm_llm_config.rope_long_from):
     every row of every step against the oracle with the call-wide position_end; and a control - row 0 decoded ALONE over
     the same steps stays short and must differ from its batched logits after the crossing."""
@@ -353,13 +355,13 @@ def test_su_rope_regime_of_a_batched_decode_step_follows_its_longest_row(w4):
     else:
         cfg = op.tiny_cfg()
         ck = ow = op.random_weights(cfg, seed=777, dtype=BF, **SCALES)
-    model = build_phi3v_model(cfg, ck, kv_pool_tokens=16384, max_seqs=8)
+    model = build_phi3v_model(cfg, ck, kv_pool_tokens=16384, max_seqs=16)
     lm = model.language_model
     lim = cfg.text.original_max_position_embeddings
     rng = np.random.default_rng(910)
-    prompts = [rng.integers(3, 1000, 30).astype(np.int64), rng.integers(3, 1000, lim - 6).astype(np.int64)]
+    prompts = [rng.integers(3, 1000, 30 + 7 * r).astype(np.int64) for r in range(B - 1)] + [rng.integers(3, 1000, lim - 6).astype(np.int64)]
     n_steps = 10
-    forced = rng.integers(3, 1000, (n_steps, 2))
+    forced = rng.integers(3, 1000, (n_steps, B))
     caches, ocaches = [], []
     for p in prompts:
         c = lm.make_cache()
@@ -373,9 +375,9 @@ def test_su_rope_regime_of_a_batched_decode_step_follows_its_longest_row(w4):
     for s in range(n_steps):
         pe = max(len(p) + s for p in prompts) + 1                      # the call's position_end
         crossed += pe > lim
-        got = lm(forced[s].reshape(2, 1), cache=caches).logits[:, 0]
+        got = lm(forced[s].reshape(B, 1), cache=caches).logits[:, 0]
         row0_batched.append(got[0].float().cpu())
-        for r in range(2):
+        for r in range(B):
             ref = op.language_model(ow, cfg, op.embed_tokens(ow, np.array([[int(forced[s, r])]])), ocaches[r], position_end=pe)[0, 0]
             e = _rel_rms(got[r], ref)
             worst = max(worst, e)
@@ -391,7 +393,7 @@ def test_su_rope_regime_of_a_batched_decode_step_follows_its_longest_row(w4):
     first_long = n_steps - crossed
     assert _rel_rms(alone[first_long - 1], row0_batched[first_long - 1]) < 2.5e-2      # before: the same computation
     assert _rel_rms(alone[n_steps - 1], row0_batched[n_steps - 1]) > 5e-2               # after: another rope regime
-    print(f"batched Su-RoPE regime (w4={w4}): worst row rel-rms {worst:.4f}, {crossed} long steps of {n_steps}")
+    print(f"batched Su-RoPE regime (w4={w4}, B={B}): worst row rel-rms {worst:.4f}, {crossed} long steps of {n_steps}")
 
 
 def test_batch_generator_row_crossing_the_su_rope_limit():
