@@ -406,6 +406,9 @@ int vlm_llm_decode_launches(void* handle);
 #define VLM_TUNE_ATTN_MERGE 9       /* where the page-split attention of a ONE-row step is merged: 1 (default) = in the o_proj
                                        GEMV's prologue (partial-only attention launch, vlm_gemv_attn_out_bf16; needs bf16 Wo,
                                        Hq * D <= 2048, <= 16 splits), 0 = by the attention launch's last-arriving workgroup */
+#define VLM_TUNE_TLB_TOUCH 10       /* experiment: 1 = the page-split attention launch carries 16 extra workgroups that issue one
+                                       4-byte load per 64 KiB of the layer's o_proj / gate-up / down weights (bit 1: + the next
+                                       layer's qkv), warming their address translations ahead of the launches that stream them */
 int vlm_llm_set_tuning(void* handle, int key, int value);
 int vlm_llm_get_tuning(void* handle, int key);
 /* diagnostic of the in-launch hand-offs (VLM_TUNE_FUSED_MLP): 0 = every bounded wait completed since the last call;

@@ -81,7 +81,7 @@ class VitArgs(C.Structure):
 
 DECODE_FUSED_TAIL = 1                       # vlm_decode_args.flags
 TUNE_PREFETCH, TUNE_PREFETCH_WGS, TUNE_PREFETCH_MASK, TUNE_PREFETCH_HEAD_MB, TUNE_DEBUG_SKIP, TUNE_FUSED_MLP, TUNE_MFMA_GEMV = 0, 1, 2, 3, 4, 5, 6  # vlm_llm_set_tuning keys
-TUNE_ATTN_PAGESPLIT, TUNE_GEMV_VARIANT, TUNE_ATTN_MERGE = 7, 8, 9
+TUNE_ATTN_PAGESPLIT, TUNE_GEMV_VARIANT, TUNE_ATTN_MERGE, TUNE_TLB_TOUCH = 7, 8, 9, 10
 
 P = C.POINTER
 # name -> (restype, argtypes); every symbol include/vlm_hip.h declares

@@ -50,6 +50,7 @@ struct Tuning {
   int attn_pagesplit = 16;                // vlm_attn_decode_paged_split with up to this many workgroups per (row, kv head)
   int gemv_variant = 0;                   // A/B bits of the batch-1 GEMV launch shapes (VLM_TUNE_GEMV_VARIANT)
   int attn_merge = 1;                     // 1: one-row steps merge the page-split partials in the o_proj prologue
+  int tlb_touch = 0;                      // 1: the attention launch warms the translations of the layer's next weight streams
 };
 
 // the second branch of a captured step (prefetch side chain)
@@ -177,6 +178,7 @@ extern "C" int vlm_llm_set_tuning(void* handle, int key, int value) {
     case VLM_TUNE_ATTN_PAGESPLIT: if (value < 0 || value > 32) return 1; slot = &m->tune.attn_pagesplit; break;
     case VLM_TUNE_GEMV_VARIANT: if (value < 0) return 1; slot = &m->tune.gemv_variant; break;
     case VLM_TUNE_ATTN_MERGE: if (value < 0 || value > 1) return 1; slot = &m->tune.attn_merge; break;
+    case VLM_TUNE_TLB_TOUCH: if (value < 0 || value > 3) return 1; slot = &m->tune.tlb_touch; break;
     case VLM_TUNE_FUSED_MLP: {
       if (value < 0 || value > 1) return 1;
       slot = &m->tune.fused_mlp;
@@ -242,6 +244,7 @@ extern "C" int vlm_llm_get_tuning(void* handle, int key) {
     case VLM_TUNE_ATTN_PAGESPLIT: return m->tune.attn_pagesplit;
     case VLM_TUNE_GEMV_VARIANT: return m->tune.gemv_variant;
     case VLM_TUNE_ATTN_MERGE: return m->tune.attn_merge;
+    case VLM_TUNE_TLB_TOUCH: return m->tune.tlb_touch;
     default: return -1;
   }
 }
@@ -448,7 +451,7 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
     // few (row, kv head) pairs: the page-split form - one wave per page stride over up to 256 CUs, the last arriver
     // writes the final vector (part_o / part_ml are sized for 32 splits by the caller)
     int psplit = 0;
-    if (tn.attn_pagesplit > 0 && m->attn_tickets && B * Hkv <= 64 && pf != 2) {
+    if (tn.attn_pagesplit > 0 && m->attn_tickets && B * Hkv <= 64) {
       psplit = a->nsplit > 1 ? 32 : tn.attn_pagesplit;
       if (psplit > 256 / (B * Hkv)) psplit = 256 / (B * Hkv);
       if (psplit < 2) psplit = 0;
@@ -459,9 +462,14 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
                                 !(tn.fused_mlp && m->fm_buf);
     if (skip & 2) {
     } else if (psplit) {
-      TRY(vlm_attn_decode_paged_split(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale,
-                                      psplit, a->part_o, a->part_ml, m->attn_tickets, merge_in_oproj ? nullptr : a->attn, Hq * hd,
-                                      stream)); ++n;
+      // (bf16 layers) the launch also warms the address translations of what the layer streams next
+      const void* tp[4] = {w.wo, w.wgu, w.wdown, i + 1 < NL ? m->layers[i + 1].wqkv : m->g.lm_head};
+      const size_t tb[4] = {(size_t)D * Hq * hd * 2, (size_t)2 * c.inter * D * 2, (size_t)c.inter * D * 2,
+                            i + 1 < NL ? (size_t)QKV * D * 2 : (size_t)64 << 20};
+      const int nt = (tn.tlb_touch && !w.wo_sb && !w.wgu_sb && !w.wdown_sb) ? ((tn.tlb_touch & 2) ? 4 : 3) : 0;
+      TRY(vlm_attn_decode_paged_split_ex(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale,
+                                         psplit, a->part_o, a->part_ml, m->attn_tickets, merge_in_oproj ? nullptr : a->attn,
+                                         Hq * hd, tp, tb, nt, prog, stream)); ++n;
     } else if (a->nsplit == 1) {
       // short contexts: one workgroup per (sequence, kv head) -> final bf16 vector, plain o_proj GEMV + residual
       TRY(vlm_attn_decode_paged_ex(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale, 1,

@@ -333,6 +333,16 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
       reinterpret_cast<uint4*>(smem + (size_t)m * K * 2)[ch] = reinterpret_cast<const uint4*>(x + (size_t)m * ldx)[ch];
     }
   }
+  // the rotation's sine / cosine depend on the position and the frequency table only: computed HERE, while the weight
+  // stream is still in flight (the precise sincosf is a few hundred instructions - at the tail of the kernel it sat on
+  // the critical path of every qkv launch)
+  float rope_sn = 0.f, rope_cs = 1.f;
+  bool use_long = false;
+  if (EPI == EPI_ROPE_KV) {
+    // lanes >= MB hold row MB - 1's slot again: the vote covers exactly the rows of the step (wave-uniform result)
+    use_long = rk.long_from > 0 && __any(e_slot >= rk.long_from);
+    sincosf((float)e_pos * (use_long ? e_if2 : e_if), &rope_sn, &rope_cs);
+  }
   __syncthreads();
   if (!active) return;
 
@@ -366,8 +376,6 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
       a0 = (lane == m) ? acc[0][m] : a0;
       a1 = (lane == m) ? acc[R - 1][m] : a1;
     }
-    // lanes >= MB hold row MB - 1's slot again: the vote covers exactly the rows of the step (wave-uniform result)
-    const bool use_long = rk.long_from > 0 && __any(e_slot >= rk.long_from);
     if (lane < MB) {
       const int m = lane;
       const float y0 = rbf(a0 + bf2f(e_b0)), y1 = rbf(a1 + bf2f(e_b1));
@@ -377,8 +385,7 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
                                            : (size_t)m * rk.max_pages + (e_slot >> 6);
       const int e_within = e_slot & 63;
       if (rope_pair) {
-        float sn, cs;
-        sincosf((float)e_pos * (use_long ? e_if2 : e_if), &sn, &cs);
+        const float sn = rope_sn, cs = rope_cs;
         const float z0 = rbf(y0 * rk.qk_scale), z1 = rbf(y1 * rk.qk_scale);      // (exact no-op at scale 1)
         const float o0 = z0 * cs - z1 * sn, o1 = z1 * cs + z0 * sn;
         if (rope_head < rk.Hq) {

@@ -19,6 +19,12 @@ VLM_INTERNAL int vlm_attn_decode_paged_ex(const void* q, int ldq, const void* kp
                                           int Hq, int Hkv, int D, float scale, int nsplit, void* part_o, void* part_ml,
                                           void* out, int ldo, VlmProgress prog, void* stream);
 
+VLM_INTERNAL int vlm_attn_decode_paged_split_ex(const void* q, int ldq, const void* kpool, const void* vpool,
+                                                const void* block_table, int max_pages, const void* kv_len, int kv_len_add,
+                                                int B, int Hq, int Hkv, int D, float scale, int nsplit, void* part_o,
+                                                void* part_ml, void* tickets, void* out, int ldo, const void* const* touch_ptr,
+                                                const size_t* touch_bytes, int n_touch, VlmProgress prog, void* stream);
+
 VLM_INTERNAL int vlm_sample_ex(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
                                void* workspace, float temperature, float top_p, float min_p, int top_k, unsigned seed,
                                const void* step_ptr, VlmProgress prog, void* stream);

@@ -317,7 +317,7 @@ class LanguageModel:
     # environment overrides for A/B runs): VLM_DECODE_PREFETCH 0 / 1 (event-paced side branch) / 2 (persistent side
     # kernel), VLM_DECODE_PREFETCH_MASK, VLM_DECODE_PREFETCH_WGS, VLM_DECODE_FUSED_TAIL 0 / 1
     TUNING_DEFAULTS = {"prefetch": 0, "prefetch_wgs": 256, "prefetch_mask": 0x7f, "prefetch_head_mb": 96, "fused_tail": 1, "mfma_gemv": 1,
-                       "fused_mlp": 0, "attn_pagesplit": 16, "gemv_variant": 0, "attn_merge": 1}
+                       "fused_mlp": 0, "attn_pagesplit": 16, "gemv_variant": 1, "attn_merge": 1, "tlb_touch": 0}
 
     def apply_tuning(self, **over):
         L = _lib.lib()
@@ -332,7 +332,7 @@ class LanguageModel:
                           (_lib.TUNE_PREFETCH_MASK, "prefetch_mask"), (_lib.TUNE_PREFETCH_HEAD_MB, "prefetch_head_mb"),
                           (_lib.TUNE_FUSED_MLP, "fused_mlp"), (_lib.TUNE_MFMA_GEMV, "mfma_gemv"),
                           (_lib.TUNE_ATTN_PAGESPLIT, "attn_pagesplit"), (_lib.TUNE_GEMV_VARIANT, "gemv_variant"),
-                          (_lib.TUNE_ATTN_MERGE, "attn_merge")):
+                          (_lib.TUNE_ATTN_MERGE, "attn_merge"), (_lib.TUNE_TLB_TOUCH, "tlb_touch")):
             check(L.vlm_llm_set_tuning(self._handle, key, int(t[name])), "llm_set_tuning")
         for st in getattr(self, "_decode_states", {}).values():
             st.graph_key = None          # the engine dropped its captured steps

@@ -203,10 +203,10 @@ static void reset_state(const Model& m, State& s, int ctx0, hipStream_t st) {
 }
 
 struct Variant {
-  int pf = 0, wgs = 256, mask = 0x7f, flags = 0, headmb = 96, skip = 0, fmlp = 0, psplit = 16, gv = 0, am = 1;
+  int pf = 0, wgs = 256, mask = 0x7f, flags = 0, headmb = 96, skip = 0, fmlp = 0, psplit = 16, gv = 0, am = 1, tt = 0;
   std::string name() const {
     char b[160];
-    snprintf(b, sizeof b, "pf=%d flags=%d skip=0x%02x fmlp=%d psplit=%d gv=%d am=%d", pf, flags, skip, fmlp, psplit, gv, am);
+    snprintf(b, sizeof b, "pf=%d flags=%d skip=0x%02x fmlp=%d psplit=%d gv=%d am=%d tt=%d", pf, flags, skip, fmlp, psplit, gv, am, tt);
     return b;
   }
 };
@@ -223,6 +223,7 @@ static double run_variant(const Model& m, State& s, const Variant& v, int ctx0, 
   RC(vlm_llm_set_tuning(m.h, VLM_TUNE_ATTN_PAGESPLIT, v.psplit));
   RC(vlm_llm_set_tuning(m.h, VLM_TUNE_GEMV_VARIANT, v.gv));
   RC(vlm_llm_set_tuning(m.h, VLM_TUNE_ATTN_MERGE, v.am));
+  RC(vlm_llm_set_tuning(m.h, VLM_TUNE_TLB_TOUCH, v.tt));
   if (v.fmlp && !vlm_llm_get_tuning(m.h, VLM_TUNE_FUSED_MLP)) printf("   (fused MLP not available on this device / shape)\n");
   s.a.flags = v.flags;
   RC(vlm_llm_set_kv(m.h, &m.kv));
@@ -320,7 +321,7 @@ int main(int argc, char** argv) {
     else if (a == "--block-table") use_table = true;
     else if (a == "--variant" && i + 1 < argc) {
       Variant v;
-      sscanf(argv[++i], "%d,%d,%i,%d,%d,%i,%d,%d,%i,%d", &v.pf, &v.wgs, &v.mask, &v.flags, &v.headmb, &v.skip, &v.fmlp, &v.psplit, &v.gv, &v.am);
+      sscanf(argv[++i], "%d,%d,%i,%d,%d,%i,%d,%d,%i,%d,%d", &v.pf, &v.wgs, &v.mask, &v.flags, &v.headmb, &v.skip, &v.fmlp, &v.psplit, &v.gv, &v.am, &v.tt);
       variants.push_back(v);
     }
   }

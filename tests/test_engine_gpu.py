@@ -672,12 +672,36 @@ def _insert_all(gen, reqs, max_tokens):
     return gen.insert([r[0].reshape(-1) for r in reqs], list(max_tokens), prompt_kwargs=kw)
 
 
+# A request decoded inside a batch and the same request decoded alone run DIFFERENT reduction structures since round 3 (one
+# row: page-split attention merged in the o_proj prologue from bf16 partials; 2..8 rows: merged by the attention launch's last
+# arriver from fp32 partials; 9..16 rows: projections on the matrix cores): every step's hidden state may differ by a bf16 ulp.
+# A token log-prob is bf16(logit - bf16(logsumexp)): one ulp of a logsumexp in [8, 16) is 0.0625, the logit adds its own, so
+# two correct runs agree to LP_ATOL; greedy tokens agree until a step whose top two candidates lie inside that noise.
+LP_ATOL = 0.13
+
+
+def _assert_streams_equal_up_to_ties(got, singles, min_equal=0.9):
+    """got / singles: per request [(token, token log-prob)].  Every compared step's log-probs within LP_ATOL; tokens equal up
+    to the first tie (after which the two streams feed different tokens and are no longer comparable); at least `min_equal`
+    of all tokens compared equal."""
+    n_equal = n_total = 0
+    for u, (a, b) in enumerate(zip(got, singles)):
+        assert len(a) == len(b), (u, a, b)
+        n_total += len(b)
+        for i, ((ta, la), (tb, lb)) in enumerate(zip(a, b)):
+            assert abs(la - lb) <= LP_ATOL, (u, i, la, lb, a, b)
+            if ta != tb:
+                break
+            n_equal += 1
+    assert n_equal >= min_equal * n_total, (n_equal, n_total)
+
+
 @pytest.mark.parametrize("async_prefill", [True, False])
 def test_batch_generator_continuous_equals_single_requests(tiny, async_prefill):
     """11 requests (images and text, different lengths, different max_tokens) through 4 decode rows: rows finish at
     different steps, the last row moves into the hole, queued prompts are admitted as rows free up, the step width
-    goes 4 -> 2 -> 1 at the end.  Every request must produce exactly the tokens (and the token logprobs) it produces
-    alone; the reference's finish rules (ar.py:1313-1316) and response fields are checked on the way.
+    goes 4 -> 2 -> 1 at the end.  Every request must produce the tokens (and the token logprobs) it produces alone - up
+    to bf16 ties, see LP_ATOL; the reference's finish rules (ar.py:1313-1316) and response fields are checked on the way.
     async_prefill: admissions run on a second stream under the decode steps and join when their event fires (the
     round at which a request joins then depends on timing - its tokens must not)."""
     from mlx_vlm_amd.batch import BatchGenerator
@@ -711,9 +735,7 @@ def test_batch_generator_continuous_equals_single_requests(tiny, async_prefill):
     assert widths >= {1, 2, 4}
     assert prompt_seen == {u: reqs[u][0].size for u in uids}
     assert finished == {u: "length" for u in uids}
-    for u in uids:
-        assert [t for t, _ in got[u]] == [t for t, _ in singles[u]], (u, got[u], singles[u])
-        np.testing.assert_allclose([lp for _, lp in got[u]], [lp for _, lp in singles[u]], atol=2 ** -6, rtol=2 ** -7)
+    _assert_streams_equal_up_to_ties([got[u] for u in uids], singles)
     st = gen.stats()
     assert st.generation_tokens == sum(max_tokens) and st.prompt_tokens == sum(r[0].size for r in reqs)
     assert st.prompt_tps > 0 and st.generation_tps > 0
@@ -758,9 +780,9 @@ def test_batch_generator_per_request_logits_processors_equal_single_requests(tin
         for r in out:
             got[r.uid].append((r.token, r.token_logprob))
     gen.close()
-    for u in uids:
-        assert [t for t, _ in got[u]] == [t for t, _ in singles[u]], (u, kws[u], got[u], singles[u])
-        np.testing.assert_allclose([lp for _, lp in got[u]], [lp for _, lp in singles[u]], atol=2 ** -6, rtol=2 ** -7)
+    _assert_streams_equal_up_to_ties([got[u] for u in uids], singles)
+    # the processors really reached the rows: the batch's streams follow the processed singles, not the plain ones
+    assert sum([t for t, _ in got[u]] != [t for t, _ in plain[u]] for u in uids) >= 4
     gen2 = BatchGenerator(model, None)
     with pytest.raises(NotImplementedError):            # a Python callable cannot run inside the captured step
         gen2.insert([reqs[2][0].reshape(-1)], logits_processors=[[lambda toks, logits: logits]])
@@ -791,14 +813,8 @@ def test_batch_generator_16_rows_matrix_core_steps_equal_single_requests(tiny):
             got[r.uid].append((r.token, r.token_logprob))
     gen.close()
     assert 16 in widths and 8 in widths
-    for u in uids:
-        a, b = got[u], singles[u]
-        assert len(a) == len(b) == max_tokens[u]
-        for i, ((ta, la), (tb, lb)) in enumerate(zip(a, b)):
-            if ta != tb:      # a tie inside bf16 noise: both runs rate the two candidates within 2 ulps of each other
-                assert abs(la - lb) <= 2 ** -6 * max(1.0, abs(lb)), (u, i, a, b)
-                break
-            assert abs(la - lb) <= 2 ** -6 * max(1.0, abs(lb)), (u, i, la, lb)
+    assert all(len(got[u]) == max_tokens[u] for u in uids)
+    _assert_streams_equal_up_to_ties([got[u] for u in uids], singles)
 
 
 def test_batch_generator_stop_token_and_remove(tiny):

@@ -133,8 +133,8 @@ def test_generate_step_and_batch_generator_multi_image_requests(tiny):
     singles = []
     for ids, pv, pm in reqs:
         kw = dict(pixel_attention_mask=pm) if pv is not None else {}
-        singles.append([t for t, _ in generate_step(ids, model, torch.from_numpy(pv) if pv is not None else None, None,
-                                                    max_tokens=n_new, **kw)])
+        singles.append([(t, float(lp[t])) for t, lp in generate_step(ids, model, torch.from_numpy(pv) if pv is not None else None,
+                                                                     None, max_tokens=n_new, **kw)])
     ids, pv, pm = reqs[1]
     ref_toks, ref_logits = oi.generate_greedy(W, cfg, ids, torch.from_numpy(pv), pm, max_tokens=n_new, return_logits=True)
     for use_graph in (True, False):
@@ -154,9 +154,11 @@ def test_generate_step_and_batch_generator_multi_image_requests(tiny):
     while gen.has_work:
         _, out = gen.next()
         for r in out:
-            got[r.uid].append(r.token)
+            got[r.uid].append((r.token, r.token_logprob))
     gen.close()
-    assert [got[u] for u in uids] == singles
+    # batch rows and single requests run different reduction structures: equal up to bf16 ties (test_engine_gpu.py)
+    from tests.test_engine_gpu import _assert_streams_equal_up_to_ties
+    _assert_streams_equal_up_to_ties([got[u] for u in uids], singles, min_equal=0.85)
 
 
 def test_load_from_hf_layout_checkpoint_and_generate(tmp_path):
