@@ -204,6 +204,27 @@ int vlm_attn_decode_paged_split(const void* q, int ldq, const void* kpool, const
                                 float scale, int nsplit, void* part_o, void* part_ml, void* tickets, void* out, int ldo,
                                 void* stream);
 
+/* Uniform 8-bit KV cache: QuantizedKVCache (cache.py:233-334, mx.quantize bits = 8, group_size = 64 over the head
+ * dimension), KVCache.to_quantized (cache.py:415-423) and quantized_scaled_dot_product_attention at L == 1
+ * (base.py:260-302).  8-bit pools per layer, same pages / block table as the bf16 pools:
+ *   kpool8 u8 [page][Hkv][D/8][64 keys][8], vpool8 u8 [page][Hkv][D][64 key slots] (the bf16 layouts with 1-byte elements),
+ *   ksb / vsb uint32 [page][Hkv][64 keys][D/64]: (scale bf16 | bias bf16 << 16) of key k, group j at word k * (D/64) + j.
+ * layer_stride: ELEMENTS between consecutive layers' pools, identical for the bf16 and the u8 pools (the sb pools advance
+ * by layer_stride / (D/2) words).  D == 128.
+ * vlm_kv_quantize_tokens: token i of the list (slot kv_slot[i] of sequence kv_seq[i]; kv_seq NULL: row i) is quantised from
+ *   the bf16 pools into the 8-bit pools, all n_layers layers - to_quantized over a range of cached tokens.
+ * vlm_attn_decode_paged_q8: the page-split decode attention (vlm_attn_decode_paged_split: same nsplit / part_o / part_ml /
+ *   tickets / out conventions, out == NULL = partial-only form) over the 8-bit pools; quantize_new != 0: the step's new
+ *   token (slot kv_len - 1, already written to the bf16 pools by the qkv epilogue) is quantised first -
+ *   QuantizedKVCache.update_and_fetch - by the workgroup that owns its page. */
+int vlm_kv_quantize_tokens(const void* kpool, const void* vpool, void* kpool8, void* vpool8, void* ksb, void* vsb,
+                           size_t layer_stride, int n_layers, const void* kv_seq, const void* kv_slot, int T,
+                           const void* block_table, int max_pages, int Hkv, int D, void* stream);
+int vlm_attn_decode_paged_q8(const void* q, int ldq, const void* kpool16, const void* vpool16, void* kpool8, void* vpool8,
+                             void* ksb, void* vsb, const void* block_table, int max_pages, const void* kv_len,
+                             int kv_len_add, int B, int Hq, int Hkv, int D, float scale, int nsplit, void* part_o,
+                             void* part_ml, void* tickets, void* out, int ldo, int quantize_new, void* stream);
+
 /* h[0][0:N] += merge(partials of vlm_attn_decode_paged_split's partial-only form) Wo^T for ONE decode row
  * (language.py:115-120,151): every thread of the o_proj GEMV loads one 8-element chunk of all nsplit <= 16 bf16 partials
  * and their (m, l) ahead of its weight stream and merges them in registers.  Hq * D <= 2048. */
@@ -315,6 +336,10 @@ typedef struct vlm_kv_pool {
   size_t layer_stride;      /* elements between consecutive layers' pools */
   const void* block_table;  /* int32 [n_seq][max_pages]; NULL for decode over an identity-layout pool */
   int max_pages;
+  /* ABI v4: the 8-bit pools of the uniform quantized KV cache (vlm_attn_decode_paged_q8), layer 0 base, NULL = none.
+   * When set, every decode step attends over them (the qkv epilogue still writes the new token to the bf16 pools; the
+   * attention launch quantises it). */
+  void *kpool8, *vpool8, *ksb, *vsb;
 } vlm_kv_pool;
 
 /* prefill over T tokens (all sequences concatenated).  h [T][hidden] holds the input

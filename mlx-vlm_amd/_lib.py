@@ -32,7 +32,7 @@ class LlmGlobals(C.Structure):
 
 class KvPool(C.Structure):
     _fields_ = [("kpool", c_void_p), ("vpool", c_void_p), ("layer_stride", c_size_t), ("block_table", c_void_p),
-                ("max_pages", c_int)]
+                ("max_pages", c_int), ("kpool8", c_void_p), ("vpool8", c_void_p), ("ksb", c_void_p), ("vsb", c_void_p)]
 
 
 class PrefillArgs(C.Structure):
@@ -118,6 +118,10 @@ SIGNATURES = {
                               + [c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vlm_attn_decode_paged_split": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 5
                                     + [c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "vlm_kv_quantize_tokens": (c_int, [c_void_p] * 6 + [c_size_t, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                                       c_void_p]),
+    "vlm_attn_decode_paged_q8": (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_int, c_void_p] + [c_int] * 5
+                                 + [c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "vlm_gemv_attn_out_bf16": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "vlm_embed_gather": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "vlm_scatter_image_rows": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),

@@ -132,9 +132,21 @@ class BatchGenerator:
                  sampler: Optional[Sampler] = None, completion_batch_size: int = MAX_ROWS,
                  prefill_batch_size: int = MAX_ROWS, compute_logprobs: bool = True, use_graph: bool = True,
                  async_prefill: bool = True, prefill_ahead: int = 2, **kwargs):
+        # uniform 8-bit KV cache (reference ar.py:2200-2230: BatchGenerator(kv_bits=, kv_group_size=, quantized_kv_start=)):
+        # every admitted request's cache is quantised right after its prefill (quantized_kv_start <= its prompt length is the
+        # only switch-over a batch of rows at different offsets can share: 0 is accepted, anything else is refused)
+        self.kv_bits = kwargs.pop("kv_bits", None)
+        kv_group_size = kwargs.pop("kv_group_size", None) or 64
+        kv_start = kwargs.pop("quantized_kv_start", None)
+        kv_scheme = kwargs.pop("kv_quant_scheme", None)
+        if self.kv_bits is not None:
+            if float(self.kv_bits) != 8 or int(kv_group_size) != 64 or kv_scheme not in (None, "uniform"):
+                raise NotImplementedError(f"BatchGenerator: kv_bits={self.kv_bits} kv_group_size={kv_group_size} "
+                                          f"kv_quant_scheme={kv_scheme}: the uniform 8-bit / group-64 quantized KV cache is built")
+            if kv_start not in (None, 0):
+                raise NotImplementedError("BatchGenerator: quantized_kv_start must be 0 with kv_bits (rows quantise at their join)")
         unsupported = {k: v for k, v in kwargs.items() if v not in (None, False, 0, [], ())
-                       and k not in ("prefill_step_size", "kv_group_size", "kv_quant_scheme", "quantized_kv_start",
-                                     "greedy_sampling", "stream")}
+                       and k not in ("prefill_step_size", "greedy_sampling", "stream")}
         if unsupported:
             raise NotImplementedError(f"BatchGenerator: outside the built path: {sorted(unsupported)}")
         self.model = model
@@ -252,7 +264,12 @@ class BatchGenerator:
     def _decode_rows(self, width: int):
         """One decode step over rows 0..width-1 of the state: tok <- sampled token, pos and ctx advanced by one."""
         self.lm.decode_step_rows(self._st, width, self._table, self._sargs, use_graph=self.use_graph,
-                                 with_logprobs=self.compute_logprobs, row_penalties=any(row.procs for row in self._rows))
+                                 with_logprobs=self.compute_logprobs, row_penalties=any(row.procs for row in self._rows),
+                                 q8=self.kv_bits is not None)
+
+    def _quantize_joined(self, seq):
+        """the joined request's cached prompt becomes a QuantizedKVCache (engine hook: a mock engine has nothing to convert)"""
+        self.lm.quantize_kv([seq], bits=int(self.kv_bits), group_size=64)
 
     def _row_logprobs(self, n: int) -> torch.Tensor:
         """log-prob of the token each of the first n rows has just sampled (f32 [n])"""
@@ -498,6 +515,8 @@ class BatchGenerator:
                 if p.lp0 is not None:
                     self._lp[r:r + 1].copy_(p.lp0[i:i + 1])
                 self._table[r].copy_(lm.pool.block_table[seq.seq])
+                if self.kv_bits is not None:
+                    self._quantize_joined(seq)          # KVCache.to_quantized right after the prefill (stream-ordered)
                 spec = b[3].get(_PROCS_KEY)
                 self._set_row_penalties(r, p.pen, i, spec)
                 self._rows.append(_Row(uid=b[0], seq=seq, max_tokens=b[2], prompt_tokens=L, procs=spec))

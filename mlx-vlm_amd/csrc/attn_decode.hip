@@ -277,6 +277,105 @@ __device__ __forceinline__ void vlm_touch_regions(const VlmTouch& t, int wg, int
   }
 }
 
+// The tail of a page-split workgroup (shared by the bf16 and the 8-bit-KV kernels): ot[dt][r] = unnormalised O^T[d = 16 dt +
+// 4 gq + r][head = lane & 15], m_run the running max (log2 domain), l_run this lane's share of the row sum.
+template <int G, bool MERGE>
+__device__ __forceinline__ void pagesplit_finish(f32x4_t (&ot)[8], float m_run, float l_run, int npages, int bh, int b, int g,
+                                                 int s, int S, int Hkv, int lane, int ldo, float* part_o, float* part_ml,
+                                                 unsigned* tickets, bf16_t* __restrict__ out) {
+  const int head = lane & 15, gq = lane >> 4;
+  l_run = col4_sum(l_run);
+  if (!MERGE) {
+    // partials for the o_proj prologue (vlm_gemv_attn_out_bf16): EVERY split writes (m, l) - a split with no page writes
+    // (-inf, 0) and is skipped there - and the splits with pages their O^T as bf16 [b][head][s][d] (plain stores: the
+    // kernel boundary publishes them).  m stays in the log2 domain of this kernel.
+    if (head < G) {
+      const size_t e = ((size_t)b * (Hkv * G) + (g * G + head)) * S + s;
+      if (gq == 0) *reinterpret_cast<float2*>(part_ml + e * 2) = make_float2(m_run, l_run);
+      if (m_run != -INFINITY) {
+        bf16_t* po = reinterpret_cast<bf16_t*>(part_o) + e * HD + 4 * gq;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt)
+          *reinterpret_cast<uint2*>(po + 16 * dt) = make_uint2(pack_bf2(ot[dt][0], ot[dt][1]), pack_bf2(ot[dt][2], ot[dt][3]));
+      }
+    }
+    return;
+  }
+  const int n_act = min(S, npages);                // splits that own at least one page of this context
+  const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(part_o, 0, 0x7fffffff, 0x00020000);   // (offsets checked by the launcher)
+  typedef unsigned long long u64;
+  if (s < n_act && head < G) {
+    const int o0 = (((bh * S + s) * G + head) * HD + 4 * gq) * 4;                       // byte offset of d = 4 gq
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ot[dt]), rs_o, o0 + 64 * dt, 0, 16);   // aux 16 = sc1
+    if (gq == 0)
+      __hip_atomic_store(reinterpret_cast<u64*>(part_ml) + ((size_t)bh * S + s) * G + head,
+                         ((u64)__float_as_uint(l_run) << 32) | __float_as_uint(m_run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      // every storing wave drains (R1)
+  unsigned tk = 0;
+  if (lane == 0) tk = __hip_atomic_fetch_add(tickets + bh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tk = __builtin_amdgcn_readfirstlane(tk);
+  if (tk != (unsigned)S - 1u) return;
+
+  // ---- last arriver: out[head][d] = sum_s f_s O_s[head][d] / sum_s f_s l_s,  f_s = 2^(m_s - M)
+  constexpr int NJ = (G + 1) / 2;                  // float4 items per lane: G * 32 items over 64 lanes
+  constexpr int CH = 8;                            // splits per pass (all loads of a pass in flight together)
+  float M[NJ], L[NJ];
+  f32x4_t acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) { M[j] = -INFINITY; L[j] = 0.f; acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  for (int c0 = 0; c0 < n_act; c0 += CH) {
+    u64 ml[CH][NJ];
+    u32x4_t o[CH][NJ];
+#pragma unroll
+    for (int sp = 0; sp < CH; ++sp) {
+      const int spc = min(c0 + sp, n_act - 1);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int item = min(lane + 64 * j, G * 32 - 1);
+        ml[sp][j] = __hip_atomic_load(reinterpret_cast<const u64*>(part_ml) + ((size_t)bh * S + spc) * G + (item >> 5),
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        o[sp][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_o, ((bh * S + spc) * G * HD + item * 4) * 4, 0, 16);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);             // every load of the pass is issued before the first use waits
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      float mc = -INFINITY;
+#pragma unroll
+      for (int sp = 0; sp < CH; ++sp) mc = fmaxf(mc, (c0 + sp < n_act) ? __uint_as_float((unsigned)ml[sp][j]) : -INFINITY);
+      const float mn = fmaxf(M[j], mc);             // finite: every split < n_act holds at least one valid key
+      const float a = exp2f(M[j] - mn);
+      L[j] *= a;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[j][r] *= a;
+#pragma unroll
+      for (int sp = 0; sp < CH; ++sp) {
+        const float f = (c0 + sp < n_act) ? exp2f(__uint_as_float((unsigned)ml[sp][j]) - mn) : 0.f;
+        L[j] += f * __uint_as_float((unsigned)(ml[sp][j] >> 32));
+        const f32x4_t ov = __builtin_bit_cast(f32x4_t, o[sp][j]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r] += f * ov[r];
+      }
+      M[j] = mn;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int item = lane + 64 * j;
+    if (item < G * 32) {
+      const float il = 1.0f / L[j];
+      uint2 w;
+      w.x = pack_bf2(acc[j][0] * il, acc[j][1] * il);
+      w.y = pack_bf2(acc[j][2] * il, acc[j][3] * il);
+      *reinterpret_cast<uint2*>(out + (size_t)b * ldo + (size_t)(g * G + (item >> 5)) * HD + 4 * (item & 31)) = w;
+    }
+  }
+  if (lane == 0) __hip_atomic_store(tickets + bh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+}
+
 template <int G, bool IDENT, bool MERGE>
 __global__ __launch_bounds__(64) void attn_decode_pagesplit_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ kpool, const bf16_t* __restrict__ vpool,
@@ -399,96 +498,237 @@ __global__ __launch_bounds__(64) void attn_decode_pagesplit_kernel(
     page = next_page;
   } while (true);
 
-  l_run = col4_sum(l_run);
-  if (!MERGE) {
-    // partials for the o_proj prologue (vlm_gemv_attn_out_bf16): EVERY split writes (m, l) - a split with no page writes
-    // (-inf, 0) and is skipped there - and the splits with pages their O^T as bf16 [b][head][s][d] (plain stores: the
-    // kernel boundary publishes them).  m stays in the log2 domain of this kernel.
-    if (head < G) {
-      const size_t e = ((size_t)b * (Hkv * G) + (g * G + head)) * S + s;
-      if (gq == 0) *reinterpret_cast<float2*>(part_ml + e * 2) = make_float2(m_run, l_run);
-      if (m_run != -INFINITY) {
-        bf16_t* po = reinterpret_cast<bf16_t*>(part_o) + e * HD + 4 * gq;
+  pagesplit_finish<G, MERGE>(ot, m_run, l_run, npages, bh, b, g, s, S, Hkv, lane, ldo, part_o, part_ml, tickets, out);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Uniform 8-bit KV cache (reference QuantizedKVCache, mlx_vlm/models/cache.py:233-334; its attention
+// quantized_scaled_dot_product_attention, models/base.py:260-302; the switch-over maybe_quantize_kv_cache,
+// generate/common.py:170-181): mx.quantize(bits = 8, group_size = 64) over the head dimension of every cached key and
+// value row - per 64-element group a bf16 scale and bias, w ~ scale * n + bias, n in 0..255.
+//
+// Pools (one set per layer, pages and block table shared with the bf16 pools):
+//   K8  [page][Hkv][D/8][64 keys][8]  u8      the bf16 K layout with 1-byte elements (an S^T A fragment = ONE 8-byte load)
+//   V8  [page][Hkv][D][64 key slots]  u8      the bf16 V layout with 1-byte elements
+//   KSB / VSB [page][Hkv][64 keys][D/64] u32  (scale bf16 | bias bf16 << 16) of key k, group j at word k * (D/64) + j
+// Quantisation (vlm_kv_quantize_tokens; the decode kernel does it for the token the step has just written): the exact
+// arithmetic of mx.quantize as oracle/quant.py states it - fp32 min / max of the group, scale = max((max - min) / 255,
+// 1e-7) signed so that the edge of larger magnitude lands on an integer, n = clip(rint((w - bias) / scale), 0, 255) from
+// the fp32 scale / bias, which are then stored rounded to bf16 - IEEE division and rint throughout: bit-exact with the
+// oracle (tests/test_ops_gpu.py).
+struct Q8Group { float scale, bias; };
+__device__ __forceinline__ Q8Group q8_group_params(float w_max, float w_min) {
+  const bool mask = fabsf(w_min) > fabsf(w_max);
+  float scale = fmaxf((w_max - w_min) / 255.0f, 1e-7f);
+  scale = mask ? scale : -scale;
+  const float edge = mask ? w_min : w_max;
+  const float q0 = rintf(edge / scale);
+  scale = q0 != 0.f ? edge / q0 : scale;
+  return Q8Group{scale, q0 == 0.f ? 0.f : edge};
+}
+__device__ __forceinline__ unsigned q8_value(float w, Q8Group p) {
+  return (unsigned)fminf(fmaxf(rintf((w - p.bias) / p.scale), 0.f), 255.f);
+}
+// one wave quantises the K and V rows of ONE (token, kv head): lane = element of the 64-wide group, both groups of D = 128
+__device__ __forceinline__ void q8_quantize_token(const bf16_t* __restrict__ kp16, const bf16_t* __restrict__ vp16,
+                                                  unsigned char* kp8, unsigned char* vp8, unsigned* ksb, unsigned* vsb,
+                                                  size_t page_head, int within, int lane) {
+  // page_head = page * Hkv + g; `within` = token slot in the page
+  const bf16_t* kb = kp16 + page_head * (size_t)(HD / 8) * PAGE * 8;
+  const bf16_t* vb = vp16 + page_head * (size_t)HD * PAGE;
+  unsigned char* kb8 = kp8 + page_head * (size_t)(HD / 8) * PAGE * 8;
+  unsigned char* vb8 = vp8 + page_head * (size_t)HD * PAGE;
+  const int vs = vlm_vslot(within);
+  float kw[2], vw[2];
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt)
-          *reinterpret_cast<uint2*>(po + 16 * dt) = make_uint2(pack_bf2(ot[dt][0], ot[dt][1]), pack_bf2(ot[dt][2], ot[dt][3]));
-      }
-    }
-    return;
+  for (int j = 0; j < 2; ++j) {
+    const int d = 64 * j + lane;
+    kw[j] = bf2f(kb[((size_t)(d >> 3) * PAGE + within) * 8 + (d & 7)]);
+    vw[j] = bf2f(vb[(size_t)d * PAGE + vs]);
   }
-  const int n_act = min(S, npages);                // splits that own at least one page of this context
-  const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(part_o, 0, 0x7fffffff, 0x00020000);   // (offsets checked by the launcher)
-  typedef unsigned long long u64;
-  if (s < n_act && head < G) {
-    const int o0 = (((bh * S + s) * G + head) * HD + 4 * gq) * 4;                       // byte offset of d = 4 gq
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int d = 64 * j + lane;
+    const Q8Group pk = q8_group_params(wave_max(kw[j]), -wave_max(-kw[j]));
+    const Q8Group pv = q8_group_params(wave_max(vw[j]), -wave_max(-vw[j]));
+    kb8[((size_t)(d >> 3) * PAGE + within) * 8 + (d & 7)] = (unsigned char)q8_value(kw[j], pk);
+    vb8[(size_t)d * PAGE + vs] = (unsigned char)q8_value(vw[j], pv);
+    if (lane == 0) {
+      ksb[(page_head * PAGE + within) * 2 + j] = (unsigned)f2bf(pk.scale) | ((unsigned)f2bf(pk.bias) << 16);
+      vsb[(page_head * PAGE + within) * 2 + j] = (unsigned)f2bf(pv.scale) | ((unsigned)f2bf(pv.bias) << 16);
+    }
+  }
+}
+
+// KVCache.to_quantized (cache.py:415-423) over the paged pools: token i of the list = slot kv_slot[i] of sequence kv_seq[i]
+// (NULL: row i); grid (tokens, Hkv, layers), one wave each
+__global__ __launch_bounds__(64) void kv_quantize_tokens_kernel(const bf16_t* __restrict__ kpool, const bf16_t* __restrict__ vpool,
+                                                                unsigned char* kpool8, unsigned char* vpool8, unsigned* ksb,
+                                                                unsigned* vsb, size_t layer_stride, const int* __restrict__ kv_seq,
+                                                                const int* __restrict__ kv_slot, const int* __restrict__ block_table,
+                                                                int max_pages, int Hkv) {
+  const int i = blockIdx.x, g = blockIdx.y, layer = blockIdx.z, lane = threadIdx.x;
+  const int seq = kv_seq ? kv_seq[i] : i, slot = kv_slot[i];
+  const size_t page = block_table ? (size_t)block_table[(size_t)seq * max_pages + (slot >> 6)] : (size_t)seq * max_pages + (slot >> 6);
+  const size_t lo = (size_t)layer * layer_stride;             // elements of one layer's pool (bf16 elements == u8 bytes)
+  q8_quantize_token(kpool + lo, vpool + lo, kpool8 + lo, vpool8 + lo, ksb + lo / (HD / 2), vsb + lo / (HD / 2),
+                    page * Hkv + g, slot & 63, lane);
+}
+
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+__device__ __forceinline__ bf16x8_t q8_frag(const u32x2_t w) {   // 8 u8 -> 8 bf16 (integers 0..255 are exact in bf16)
+  const unsigned x = w[0], y = w[1];
+  const u32x4_t v = {pack_bf2((float)(x & 0xff), (float)((x >> 8) & 0xff)), pack_bf2((float)((x >> 16) & 0xff), (float)(x >> 24)),
+                     pack_bf2((float)(y & 0xff), (float)((y >> 8) & 0xff)), pack_bf2((float)((y >> 16) & 0xff), (float)(y >> 24))};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// The page-split decode attention over the 8-bit pools.  Arithmetic = the reference's typed graph as far as a split /
+// flash formulation allows: q * scale is a typed multiply (rounded to bf16); a score is the fp32 sum over the two groups
+// of scale_j * (q . n) + bias_j * sum(q) - the EXACT affine form of quantized_matmul, the integers n entering the MFMA as
+// exact bf16 values - rounded to bf16 as quantized_matmul's output is; softmax in fp32; P . V with p * scale_v rounded to
+// bf16 as the MFMA operand and the bias term sum_k p_k * bias_k carried in fp32.  (The reference rounds the NORMALISED
+// probabilities to bf16; a split kernel rounds the unnormalised ones: same count of roundings, tolerance in the tests.)
+// The workgroup whose page holds the step's new token (slot len - 1, written to the bf16 pools by the qkv epilogue)
+// quantises it first - QuantizedKVCache.update_and_fetch - and reads it back with the rest of the page (every page load
+// is non-temporal: served by L2, behind the workgroup's own drained stores).
+template <int G, bool IDENT, bool MERGE>
+__global__ __launch_bounds__(64) void attn_decode_pagesplit_q8_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ kpool16, const bf16_t* __restrict__ vpool16, unsigned char* kpool8,
+    unsigned char* vpool8, unsigned* ksb, unsigned* vsb, const int* __restrict__ block_table, const int* __restrict__ kv_len,
+    int ldq, int max_pages, int Hkv, int kv_len_add, float scale, int S, int ldo, float* part_o, float* part_ml,
+    unsigned* tickets, bf16_t* __restrict__ out, int quantize_new) {
+  const int bh = blockIdx.x, b = bh / Hkv, g = bh % Hkv, s = blockIdx.y;
+  const int lane = threadIdx.x, head = lane & 15, gq = lane >> 4;
+  const int len = kv_len[b] + kv_len_add, npages = (len + PAGE - 1) / PAGE;
+  const int* trow = IDENT ? nullptr : block_table + (size_t)b * max_pages;
+  // Q fragments with the reference's typed q * scale, and the per-group sums of q the bias terms need
+  bf16x8_t qf[4];
+  float sq[2] = {0.f, 0.f};
+  {
+    const bf16_t* qr = q + (size_t)b * ldq + (size_t)(g * G + min(head, G - 1)) * HD + 8 * gq;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(qr + 32 * ds);
+      u32x4_t sc;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned w = raw[j];
+        const float a = rbf(bf_lo(w) * scale), c = rbf(bf_hi(w) * scale);
+        sc[j] = pack_bf2(a, c);
+        sq[ds >> 1] += a + c;
+      }
+      qf[ds] = __builtin_bit_cast(bf16x8_t, sc);
+    }
+    sq[0] = col4_sum(sq[0]);            // over the four 8-wide d chunks a head's lanes hold per 32-step
+    sq[1] = col4_sum(sq[1]);
+  }
+  f32x4_t ot[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ot[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f, ob[2] = {0.f, 0.f};
+  constexpr float LOG2E = 1.44269504088896340736f;
+  for (int pc = s; pc < npages; pc += S) {
+    const size_t page = IDENT ? (size_t)b * max_pages + pc : (size_t)trow[pc];
+    const size_t ph = page * Hkv + g;
+    if (quantize_new && pc == (len - 1) / PAGE) {
+      q8_quantize_token(kpool16, vpool16, kpool8, vpool8, ksb, vsb, ph, (len - 1) & 63, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const unsigned char* kp = kpool8 + ph * (size_t)(HD / 8) * PAGE * 8 + ((size_t)gq * PAGE + head) * 8;
+    const unsigned char* vp = vpool8 + ph * (size_t)HD * PAGE + (size_t)head * PAGE + 8 * gq;
+    const unsigned* ks = ksb + (ph * PAGE + 4 * gq) * 2;
+    const unsigned* vs = vsb + (ph * PAGE + 4 * gq) * 2;
+    u32x2_t kf[4][4], vf[8][2];
+    u32x4_t kq[4][2], vq[4][2];           // (scale | bias) words of keys 16 t + 4 gq + r: [t][half]: r = 2 half, 2 half + 1 x 2 groups
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds)
+        kf[t][ds] = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(kp + ((size_t)(4 * ds) * PAGE + 16 * t) * 8));
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        kq[t][hf] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(ks + (16 * t) * 2 + 4 * hf));
+        vq[t][hf] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vs + (16 * t) * 2 + 4 * hf));
+      }
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ot[dt]), rs_o, o0 + 64 * dt, 0, 16);   // aux 16 = sc1
-    if (gq == 0)
-      __hip_atomic_store(reinterpret_cast<u64*>(part_ml) + ((size_t)bh * S + s) * G + head,
-                         ((u64)__float_as_uint(l_run) << 32) | __float_as_uint(m_run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      // every storing wave drains (R1)
-  unsigned tk = 0;
-  if (lane == 0) tk = __hip_atomic_fetch_add(tickets + bh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  tk = __builtin_amdgcn_readfirstlane(tk);
-  if (tk != (unsigned)S - 1u) return;
-
-  // ---- last arriver: out[head][d] = sum_s f_s O_s[head][d] / sum_s f_s l_s,  f_s = 2^(m_s - M)
-  constexpr int NJ = (G + 1) / 2;                  // float4 items per lane: G * 32 items over 64 lanes
-  constexpr int CH = 8;                            // splits per pass (all loads of a pass in flight together)
-  float M[NJ], L[NJ];
-  f32x4_t acc[NJ];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) { M[j] = -INFINITY; L[j] = 0.f; acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-  for (int c0 = 0; c0 < n_act; c0 += CH) {
-    u64 ml[CH][NJ];
-    u32x4_t o[CH][NJ];
+      for (int u = 0; u < 2; ++u)
+        vf[dt][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(vp + (size_t)(16 * dt) * PAGE + 32 * u));
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S^T: per key tile two group accumulators, then the affine form per (key, group)
+    float sc[4][4];
+    float mt = -INFINITY;
 #pragma unroll
-    for (int sp = 0; sp < CH; ++sp) {
-      const int spc = min(c0 + sp, n_act - 1);
+    for (int t = 0; t < 4; ++t) {
+      f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+      a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q8_frag(kf[t][0]), qf[0], a0, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q8_frag(kf[t][1]), qf[1], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q8_frag(kf[t][2]), qf[2], a1, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q8_frag(kf[t][3]), qf[3], a1, 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int item = min(lane + 64 * j, G * 32 - 1);
-        ml[sp][j] = __hip_atomic_load(reinterpret_cast<const u64*>(part_ml) + ((size_t)bh * S + spc) * G + (item >> 5),
-                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        o[sp][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_o, ((bh * S + spc) * G * HD + item * 4) * 4, 0, 16);
+      for (int r = 0; r < 4; ++r) {
+        const u32x4_t w4 = kq[t][r >> 1];
+        const unsigned w0 = (r & 1) ? w4[2] : w4[0], w1 = (r & 1) ? w4[3] : w4[1];     // groups 0 / 1 of key 16 t + 4 gq + r
+        const int key = pc * PAGE + 16 * t + 4 * gq + r;
+        // quantized_matmul: fp32 sum over the dequantised keys, one rounding to the query dtype
+        const float sv = rbf(bf_lo(w0) * a0[r] + bf_hi(w0) * sq[0] + bf_lo(w1) * a1[r] + bf_hi(w1) * sq[1]);
+        sc[t][r] = key < len ? sv * LOG2E : -INFINITY;
+        mt = fmaxf(mt, sc[t][r]);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);             // every load of the pass is issued before the first use waits
+    mt = col4_max(mt);
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = exp2f(m_run - m_new);      // (every page processed holds a valid key: m_new is finite)
+    float ls = 0.f, pbias[2] = {0.f, 0.f};
+    u32x4_t pk[2][2];                              // P'^T fragments [group][u]
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      float mc = -INFINITY;
+    for (int t = 0; t < 4; ++t) {
+      float pp[2][4];
 #pragma unroll
-      for (int sp = 0; sp < CH; ++sp) mc = fmaxf(mc, (c0 + sp < n_act) ? __uint_as_float((unsigned)ml[sp][j]) : -INFINITY);
-      const float mn = fmaxf(M[j], mc);             // finite: every split < n_act holds at least one valid key
-      const float a = exp2f(M[j] - mn);
-      L[j] *= a;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[j][r] *= a;
-#pragma unroll
-      for (int sp = 0; sp < CH; ++sp) {
-        const float f = (c0 + sp < n_act) ? exp2f(__uint_as_float((unsigned)ml[sp][j]) - mn) : 0.f;
-        L[j] += f * __uint_as_float((unsigned)(ml[sp][j] >> 32));
-        const f32x4_t ov = __builtin_bit_cast(f32x4_t, o[sp][j]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[j][r] += f * ov[r];
+      for (int r = 0; r < 4; ++r) {
+        const int key = pc * PAGE + 16 * t + 4 * gq + r;
+        const bool ok = key < len;
+        const float pr = ok ? rbf(exp2f(sc[t][r] - m_new)) : 0.f;     // the probabilities are a bf16 tensor in the reference
+        ls += pr;
+        const u32x4_t w4 = vq[t][r >> 1];
+        const unsigned w0 = (r & 1) ? w4[2] : w4[0], w1 = (r & 1) ? w4[3] : w4[1];
+        pp[0][r] = ok ? pr * bf_lo(w0) : 0.f;
+        pp[1][r] = ok ? pr * bf_lo(w1) : 0.f;
+        pbias[0] += ok ? pr * bf_hi(w0) : 0.f;
+        pbias[1] += ok ? pr * bf_hi(w1) : 0.f;
       }
-      M[j] = mn;
-    }
-  }
+      // k-slot 8 gq + j of step u <- tile 2u (j < 4) / tile 2u + 1 (j >= 4): tile t fills words (t & 1) * 2, + 1 of step t >> 1
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int item = lane + 64 * j;
-    if (item < G * 32) {
-      const float il = 1.0f / L[j];
-      uint2 w;
-      w.x = pack_bf2(acc[j][0] * il, acc[j][1] * il);
-      w.y = pack_bf2(acc[j][2] * il, acc[j][3] * il);
-      *reinterpret_cast<uint2*>(out + (size_t)b * ldo + (size_t)(g * G + (item >> 5)) * HD + 4 * (item & 31)) = w;
+      for (int gI = 0; gI < 2; ++gI) {
+        pk[gI][t >> 1][(t & 1) * 2] = pack_bf2(pp[gI][0], pp[gI][1]);
+        pk[gI][t >> 1][(t & 1) * 2 + 1] = pack_bf2(pp[gI][2], pp[gI][3]);
+      }
+    }
+    l_run = l_run * alpha + ls;
+    ob[0] = ob[0] * alpha + pbias[0];
+    ob[1] = ob[1] * alpha + pbias[1];
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q8_frag(vf[dt][u]), __builtin_bit_cast(bf16x8_t, pk[dt >> 2][u]), ot[dt], 0, 0, 0);
     }
   }
-  if (lane == 0) __hip_atomic_store(tickets + bh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+  // the bias terms: one scalar per (head, group), the same for every d of the group
+  ob[0] = col4_sum(ob[0]);
+  ob[1] = col4_sum(ob[1]);
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ot[dt][r] += ob[dt >> 2];
+  pagesplit_finish<G, MERGE>(ot, m_run, l_run, npages, bh, b, g, s, S, Hkv, lane, ldo, part_o, part_ml, tickets, out);
 }
 
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ part_o,
@@ -606,6 +846,63 @@ VLM_INTERNAL int vlm_attn_decode_paged_split_ex(const void* q, int ldq, const vo
   hipLaunchKernelGGL((attn_decode_pagesplit_kernel<GV, ID, MG>), grid, dim3(64), 0, st, (const bf16_t*)q,                 \
                      (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)block_table, (const int*)kv_len, ldq, max_pages, \
                      Hkv, kv_len_add, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, (unsigned*)tickets, (bf16_t*)out, touch, prog)
+#define GO(GV)                                                                                                           \
+  do {                                                                                                                   \
+    if (!block_table) { if (out) GO1(GV, true, true); else GO1(GV, true, false); }                                       \
+    else { if (out) GO1(GV, false, true); else GO1(GV, false, false); }                                                  \
+  } while (0)
+  switch (G) {
+    case 1: GO(1); break;
+    case 2: GO(2); break;
+    case 3: GO(3); break;
+    case 4: GO(4); break;
+    case 5: GO(5); break;
+    case 6: GO(6); break;
+    case 7: GO(7); break;
+    case 8: GO(8); break;
+    default: return VLM_ERR_SHAPE;
+  }
+#undef GO
+#undef GO1
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+extern "C" int vlm_kv_quantize_tokens(const void* kpool, const void* vpool, void* kpool8, void* vpool8, void* ksb, void* vsb,
+                                      size_t layer_stride, int n_layers, const void* kv_seq, const void* kv_slot, int T,
+                                      const void* block_table, int max_pages, int Hkv, int D, void* stream) {
+  if (!kpool || !vpool || !kpool8 || !vpool8 || !ksb || !vsb || !kv_slot || n_layers <= 0 || Hkv <= 0 || max_pages <= 0 || T < 0)
+    return VLM_ERR_ARG;
+  if (D != HD) return VLM_ERR_SHAPE;
+  if (T == 0) return VLM_OK;
+  if (T > 65535 * 1024 || Hkv > 65535 || n_layers > 65535) return VLM_ERR_SHAPE;
+  hipLaunchKernelGGL(kv_quantize_tokens_kernel, dim3(T, Hkv, n_layers), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)kpool,
+                     (const bf16_t*)vpool, (unsigned char*)kpool8, (unsigned char*)vpool8, (unsigned*)ksb, (unsigned*)vsb,
+                     layer_stride, (const int*)kv_seq, (const int*)kv_slot, (const int*)block_table, max_pages, Hkv);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+extern "C" int vlm_attn_decode_paged_q8(const void* q, int ldq, const void* kpool16, const void* vpool16, void* kpool8,
+                                        void* vpool8, void* ksb, void* vsb, const void* block_table, int max_pages,
+                                        const void* kv_len, int kv_len_add, int B, int Hq, int Hkv, int D, float scale,
+                                        int nsplit, void* part_o, void* part_ml, void* tickets, void* out, int ldo,
+                                        int quantize_new, void* stream) {
+  if (!q || !kpool8 || !vpool8 || !ksb || !vsb || !kv_len || !part_o || !part_ml || max_pages <= 0) return VLM_ERR_ARG;
+  if (quantize_new && (!kpool16 || !vpool16)) return VLM_ERR_ARG;
+  if (out && !tickets) return VLM_ERR_ARG;
+  if (B <= 0 || Hq <= 0 || Hkv <= 0 || nsplit <= 0 || nsplit > 65535 || Hq % Hkv != 0) return VLM_ERR_ARG;
+  if (D != HD || ldq % 8 != 0 || ldo % 4 != 0) return VLM_ERR_SHAPE;
+  if ((size_t)B * Hq * nsplit * HD * 4 >= ((size_t)1 << 31)) return VLM_ERR_SHAPE;
+  const int G = Hq / Hkv;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(B * Hkv, nsplit);
+#define GO1(GV, ID, MG)                                                                                                  \
+  hipLaunchKernelGGL((attn_decode_pagesplit_q8_kernel<GV, ID, MG>), grid, dim3(64), 0, st, (const bf16_t*)q,              \
+                     (const bf16_t*)kpool16, (const bf16_t*)vpool16, (unsigned char*)kpool8, (unsigned char*)vpool8,      \
+                     (unsigned*)ksb, (unsigned*)vsb, (const int*)block_table, (const int*)kv_len, ldq, max_pages, Hkv,    \
+                     kv_len_add, scale, nsplit, ldo, (float*)part_o, (float*)part_ml, (unsigned*)tickets, (bf16_t*)out,   \
+                     quantize_new)
 #define GO(GV)                                                                                                           \
   do {                                                                                                                   \
     if (!block_table) { if (out) GO1(GV, true, true); else GO1(GV, true, false); }                                       \

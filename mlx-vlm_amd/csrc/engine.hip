@@ -65,7 +65,7 @@ struct Llm {
   Tuning tune;
   int* progress = nullptr;                // [0] pacing word, [1] exit counter of the persistent prefetcher (device)
   void* mfma_ws = nullptr;                // split-K partial tiles + tickets of the skinny-M decode GEMM (gemv_mfma.hip)
-  unsigned* attn_tickets = nullptr;       // [64] arrival words of the page-split decode attention (zero between launches)
+  unsigned* attn_tickets = nullptr;       // [4096] arrival words of the page-split decode attention (zero between launches)
   // bf16 scratch of the prefill GEMMs over 4-bit weights: ONE buffer PER STREAM (an admission prefill on the side stream
   // and a generate_step prefill on the main stream of the same quantized model must not share dequantised weights),
   // each sized once for the largest matrix of the model - never grown, never freed while the engine lives
@@ -101,7 +101,8 @@ inline bool same_key(const DecodeGraph& g, const vlm_decode_args& a, const vlm_k
          a.top_p == b.top_p && a.min_p == b.min_p && a.top_k == b.top_k && a.seed == b.seed && a.flags == b.flags &&
          kv.kpool == g.kv.kpool &&
          kv.vpool == g.kv.vpool && kv.layer_stride == g.kv.layer_stride && kv.block_table == g.kv.block_table &&
-         kv.max_pages == g.kv.max_pages;
+         kv.max_pages == g.kv.max_pages && kv.kpool8 == g.kv.kpool8 && kv.vpool8 == g.kv.vpool8 && kv.ksb == g.kv.ksb &&
+         kv.vsb == g.kv.vsb;
 }
 
 inline void drop_graph(DecodeGraph& g) {
@@ -141,10 +142,10 @@ extern "C" int vlm_llm_create(const vlm_llm_config* cfg, void** handle) {
     delete m;
     return 1012;
   }
-  if (hipMalloc((void**)&m->attn_tickets, 64 * sizeof(unsigned)) != hipSuccess) {
+  if (hipMalloc((void**)&m->attn_tickets, 4096 * sizeof(unsigned)) != hipSuccess) {
     m->attn_tickets = nullptr;            // (no device: the page-split form is then not taken)
     (void)hipGetLastError();
-  } else if (hipMemset(m->attn_tickets, 0, 64 * sizeof(unsigned)) != hipSuccess) {
+  } else if (hipMemset(m->attn_tickets, 0, 4096 * sizeof(unsigned)) != hipSuccess) {
     return 1013;
   }
   *handle = m;
@@ -456,11 +457,25 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
       if (psplit > 256 / (B * Hkv)) psplit = 256 / (B * Hkv);
       if (psplit < 2) psplit = 0;
     }
+    // uniform 8-bit KV cache (vlm_kv_pool.kpool8): every step attends over the 8-bit pools; the launch quantises the new token
+    const bool q8 = m->kv.kpool8 != nullptr;
+    if (q8) {
+      if (!m->attn_tickets || !m->kv.vpool8 || !m->kv.ksb || !m->kv.vsb) return 1;
+      psplit = a->nsplit > 1 ? 32 : 16;
+      while (psplit > 1 && (B * Hkv * psplit > 1024 || B * Hkv * psplit > 65535)) psplit >>= 1;
+      if (B * Hkv > 4096) return 1;                                        // (tickets: one word per (row, kv head))
+    }
     // ... and for ONE row over bf16 Wo the merge moves into the o_proj prologue: the attention launch ends at its partial
     // stores (no ticket, no last-arriver pass)
     const bool merge_in_oproj = psplit && tn.attn_merge && B == 1 && !w.wo_sb && Hq * hd <= 2048 && psplit <= 16 &&
                                 !(tn.fused_mlp && m->fm_buf);
     if (skip & 2) {
+    } else if (q8) {
+      const size_t lo = (size_t)i * m->kv.layer_stride;                   // elements == bytes of the u8 pools
+      TRY(vlm_attn_decode_paged_q8(a->qkv, QKV, kp, vp, off(m->kv.kpool8, lo), off(m->kv.vpool8, lo),
+                                   off(m->kv.ksb, lo / (hd / 2) * 4), off(m->kv.vsb, lo / (hd / 2) * 4), m->kv.block_table,
+                                   m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale, psplit, a->part_o, a->part_ml, m->attn_tickets,
+                                   merge_in_oproj ? nullptr : a->attn, Hq * hd, 1, stream)); ++n;
     } else if (psplit) {
       // (bf16 layers) the launch also warms the address translations of what the layer streams next
       const void* tp[4] = {w.wo, w.wgu, w.wdown, i + 1 < NL ? m->layers[i + 1].wqkv : m->g.lm_head};

@@ -33,6 +33,7 @@ DEFAULT_TEMPERATURE = 0.0
 DEFAULT_TOP_P = 1.0
 DEFAULT_TOP_K = 0
 DEFAULT_MIN_P = 0.0
+DEFAULT_QUANTIZED_KV_START = 5000      # reference generate/common.py:17
 DEFAULT_PREFILL_STEP_SIZE = 2048
 
 
@@ -166,13 +167,23 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
                                    kwargs.pop("repetition_context_size", 20), kwargs.pop("presence_penalty", None),
                                    kwargs.pop("presence_context_size", 20), kwargs.pop("frequency_penalty", None),
                                    kwargs.pop("frequency_context_size", 20))
-    for k in ("max_kv_size", "kv_bits", "draft_model", "thinking_budget_criteria"):
+    for k in ("max_kv_size", "draft_model", "thinking_budget_criteria"):
         if kwargs.pop(k, None):
-            # the reference would switch cache class / decoding scheme (RotatingKVCache, QuantizedKVCache, speculative):
-            # dropping the request silently would change results without telling the caller
+            # the reference would switch cache class / decoding scheme (RotatingKVCache, speculative): dropping the request
+            # silently would change results without telling the caller
             raise NotImplementedError(f"{k} is outside the built hot path (SURVEY section 8f.4)")
-    for k in ("kv_group_size", "quantized_kv_start", "verbose", "kv_quant_scheme", "prompt_cache_checkpoint",
-              "prompt_cache_checkpoint_len"):
+    # uniform quantized KV cache (reference ar.py:174-181,249-260,362: maybe_quantize_kv_cache after EVERY forward): from the
+    # first forward that leaves the cache at quantized_kv_start tokens or more, the cache is a QuantizedKVCache
+    kv_bits = kwargs.pop("kv_bits", None)
+    kv_group_size = kwargs.pop("kv_group_size", None) or 64
+    quantized_kv_start = kwargs.pop("quantized_kv_start", None)
+    quantized_kv_start = DEFAULT_QUANTIZED_KV_START if quantized_kv_start is None else int(quantized_kv_start)
+    kv_scheme = kwargs.pop("kv_quant_scheme", None)
+    if kv_bits is not None:
+        if kv_scheme not in (None, "uniform") or float(kv_bits) != 8 or int(kv_group_size) != 64:
+            raise NotImplementedError(f"kv_bits={kv_bits} kv_group_size={kv_group_size} kv_quant_scheme={kv_scheme}: the uniform "
+                                      "8-bit / group-64 quantized KV cache is built (TurboQuant / other widths: SURVEY section 2 out of scope)")
+    for k in ("verbose", "prompt_cache_checkpoint", "prompt_cache_checkpoint_len"):
         kwargs.pop(k, None)
     smp = _resolve_sampler(sampler, temperature, top_p, min_p, top_k, seed)
     sargs = smp.engine_args()
@@ -201,6 +212,13 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
     if pos.ndim == 2:
         pos = np.broadcast_to(pos[None], (3,) + pos.shape)
     logits = lm.prefill(emb.reshape(L, -1), pos.reshape(3, L), [prompt_cache], [L], "last", reserve_extra=max_tokens + 2)
+
+    def maybe_quantize_kv_cache():      # generate/common.py:170-181 on the paged cache: all layers share one offset
+        sq = prompt_cache[0]._seq
+        if kv_bits is not None and not sq.q8 and sq.offset >= quantized_kv_start:
+            lm.quantize_kv([sq], bits=int(kv_bits), group_size=int(kv_group_size))
+
+    maybe_quantize_kv_cache()
     step0 = torch.zeros(1, dtype=torch.int32, device=logits.device)
     if procs:
         # ar.py:360-364: at the first step `tokens` is the prompt; the history then grows by every token fed back (the
@@ -226,6 +244,7 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
     try:
         while n < max_tokens:
             while issued < min(n + lookahead, max_tokens - 1):
+                maybe_quantize_kv_cache()          # (the forward just enqueued may have carried the cache past the start)
                 lm.decode_run(st, 1, sargs, use_graph=use_graph, penalties=procs if procs else None)
                 issued += 1
                 pipe.push(issued, st.tok)

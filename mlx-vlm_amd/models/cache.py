@@ -131,6 +131,22 @@ class KVPool:
         if grew:
             self.block_table[seq].copy_(h2d(self.block_table_host[seq].copy(), self.block_table.device))
 
+    # ---- uniform 8-bit KV cache (reference QuantizedKVCache, cache.py:233-334): pools allocated on first use
+    kpool8 = vpool8 = ksb = vsb = None
+
+    def ensure_q8(self):
+        """The 8-bit pools next to the bf16 ones: same pages, same block table (include/vlm_hip.h, vlm_attn_decode_paged_q8):
+        u8 K / V with the bf16 layouts at 1 byte per element + one (scale | bias) word per (key, 64-wide group)."""
+        if self.kpool8 is None:
+            if self.head_dim != 128:
+                raise NotImplementedError("8-bit KV cache: head_dim 128 (the engine's decode layout)")
+            n = self.layer_stride
+            self.kpool8 = torch.zeros(self.n_layers, n, dtype=torch.uint8, device=self.device)
+            self.vpool8 = torch.zeros(self.n_layers, n, dtype=torch.uint8, device=self.device)
+            self.ksb = torch.zeros(self.n_layers, n // 64, dtype=torch.int32, device=self.device)
+            self.vsb = torch.zeros(self.n_layers, n // 64, dtype=torch.int32, device=self.device)
+        return self
+
     @property
     def nbytes(self):
         return self.kpool.numel() * self.kpool.element_size() * 2
@@ -151,6 +167,7 @@ class PagedSequence:
         self.pages: List[int] = []
         self.offset = 0          # tokens stored (== the reference's KVCache.offset)
         self.released = False
+        self.q8 = False          # True once the sequence's cache has become a QuantizedKVCache (LanguageModel.quantize_kv)
 
     def reserve(self, n_total_tokens: int):
         self.pool.ensure(self.seq, self.pages, n_total_tokens)

@@ -509,6 +509,9 @@ class LanguageModel:
         hd, Hq, Hkv = self.head_dim, t.num_attention_heads, t.num_key_value_heads
         D, QKV = t.hidden_size, (Hq + 2 * Hkv) * self.head_dim
         seqs = [c[0]._seq for c in caches]
+        if any(getattr(s, "q8", False) for s in seqs):
+            raise NotImplementedError("a prompt chunk onto a QUANTIZED KV cache (kv_bits): only decode steps attend over the "
+                                      "8-bit pools; continue such a conversation without kv_bits or from a fresh cache")
         offs = [int(s.offset) for s in seqs]
         for n, s in zip(lengths, seqs):
             s.reserve(s.offset + n + reserve_extra)
@@ -638,29 +641,59 @@ class LanguageModel:
             ops.embed_gather(st.tok[:B], self._w["embed"], out=st.h[:B])
         return st
 
-    def _kv_struct(self, row0: int, decode: bool = False):
+    # ------------------------------------------------------------------ uniform 8-bit KV cache
+    def quantize_kv(self, seqs, bits: int = 8, group_size: int = 64):
+        """KVCache.to_quantized (reference cache.py:415-423) for whole sequences: every cached token of `seqs` (all layers) is
+        quantised from the bf16 pools into the 8-bit pools (mx.quantize, group 64, 8 bits); from then on their decode steps
+        attend over the 8-bit pools and quantise each new token (QuantizedKVCache.update_and_fetch, cache.py:233-334)."""
+        if int(bits) != 8 or int(group_size) != 64:
+            raise NotImplementedError(f"quantized KV cache: kv_bits = 8 with kv_group_size = 64 is built (asked: {bits} / {group_size})")
+        seqs = [s for s in seqs if not s.q8]
+        if not seqs:
+            return
+        pool = self.pool.ensure_q8()
+        rows = np.concatenate([np.full(s.offset, s.seq, dtype=np.int32) for s in seqs]) if seqs else np.zeros(0, np.int32)
+        slots = np.concatenate([np.arange(s.offset, dtype=np.int32) for s in seqs])
+        if rows.size:
+            dev = _lib.h2d(np.stack([rows, slots]), self.device)
+            check(_lib.lib().vlm_kv_quantize_tokens(pool.kpool.data_ptr(), pool.vpool.data_ptr(), pool.kpool8.data_ptr(),
+                                                    pool.vpool8.data_ptr(), pool.ksb.data_ptr(), pool.vsb.data_ptr(),
+                                                    pool.layer_stride, pool.n_layers, dev[0].data_ptr(), dev[1].data_ptr(),
+                                                    int(rows.size), pool.block_table.data_ptr(), pool.max_pages, pool.n_kv_heads,
+                                                    pool.head_dim, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                  "kv_quantize_tokens")
+            self._keep_q8 = dev
+        for s in seqs:
+            s.q8 = True
+
+    def _kv_struct(self, row0: int, decode: bool = False, q8: bool = False):
         """The pool as the engine sees it for batch rows row0, row0+1, ...  Decode over an identity-layout pool:
         no block table (NULL) and pool pointers advanced to row0's region - the kernels compute
         page = row * max_pages + index instead of loading it."""
         pool = self.pool
         if decode and pool.identity:
-            off = row0 * pool.max_pages * pool.n_kv_heads * PAGE * pool.head_dim * pool.kpool.element_size()
+            elems = row0 * pool.max_pages * pool.n_kv_heads * PAGE * pool.head_dim
+            off = elems * pool.kpool.element_size()
+            q = (pool.kpool8.data_ptr() + elems, pool.vpool8.data_ptr() + elems, pool.ksb.data_ptr() + elems // 64 * 4,
+                 pool.vsb.data_ptr() + elems // 64 * 4) if q8 else (None, None, None, None)
             return _lib.KvPool(pool.kpool.data_ptr() + off, pool.vpool.data_ptr() + off, pool.layer_stride, None,
-                               pool.max_pages)
+                               pool.max_pages, *q)
         bt = pool.block_table[row0:]
-        return _lib.KvPool(pool.kpool.data_ptr(), pool.vpool.data_ptr(), pool.layer_stride, bt.data_ptr(), pool.max_pages)
+        q = (pool.kpool8.data_ptr(), pool.vpool8.data_ptr(), pool.ksb.data_ptr(), pool.vsb.data_ptr()) if q8 else (None,) * 4
+        return _lib.KvPool(pool.kpool.data_ptr(), pool.vpool.data_ptr(), pool.layer_stride, bt.data_ptr(), pool.max_pages, *q)
 
     def decode_run(self, st: DecodeState, n_steps: int, sampler_args: dict, use_graph: bool = True, penalties=None):
         """Enqueue n_steps decode steps (graph replays when use_graph).  penalties: sample_utils.LogitsProcessors."""
         L = _lib.lib()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        kv = self._kv_struct(st.seq_row0, decode=True)
+        q8 = self._seqs_q8(st.seqs)
+        kv = self._kv_struct(st.seq_row0, decode=True, q8=q8)
         check(L.vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
         fused = bool(self.tuning.get("fused_tail")) and float(sampler_args.get("temperature", 0.0)) == 0.0 \
             and not hasattr(self._w["embed"], "wq")          # the fused tail gathers bf16 embedding rows
         args = st.args(flags=_lib.DECODE_FUSED_TAIL if fused else 0, penalties=penalties, **sampler_args)
         if use_graph:
-            key = (st.seq_row0, st.nsplit, fused, penalties.key() if penalties else None, tuple(sorted(sampler_args.items())))
+            key = (st.seq_row0, st.nsplit, fused, q8, penalties.key() if penalties else None, tuple(sorted(sampler_args.items())))
             if st.graph_key != key or getattr(self, "_graph_owner", None) is not st:
                 check(L.vlm_llm_decode_graph_build(self._handle, C.byref(args), stream), "decode_graph_build")
                 st.graph_key = key
@@ -673,8 +706,15 @@ class LanguageModel:
         for s in st.seqs:
             s.offset += n_steps
 
+    @staticmethod
+    def _seqs_q8(seqs) -> bool:
+        flags = {bool(getattr(s, "q8", False)) for s in seqs}
+        if len(flags) > 1:
+            raise RuntimeError("a decode step cannot mix sequences with and without a quantized KV cache")
+        return bool(flags) and flags.pop()
+
     def decode_step_rows(self, st: DecodeState, B: int, block_table: torch.Tensor, sampler_args: dict,
-                         use_graph: bool = True, with_logprobs: bool = True, row_penalties: bool = False):
+                         use_graph: bool = True, with_logprobs: bool = True, row_penalties: bool = False, q8: bool = False):
         """One decode step over rows 0..B-1 of `st` (B in {1, 2, 4, 8}), addressing the KV pool through the caller's own
         `block_table` (int32 [>= B, max_pages]).  A continuous batch keeps such a table so that a sequence changes
         batch row by copying one table row - no KV bytes move (the reference's `filter`/`extend` copy the caches,
@@ -682,13 +722,14 @@ class LanguageModel:
         L = _lib.lib()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         pool = self.pool
+        q = (pool.kpool8.data_ptr(), pool.vpool8.data_ptr(), pool.ksb.data_ptr(), pool.vsb.data_ptr()) if q8 else (None,) * 4
         kv = _lib.KvPool(pool.kpool.data_ptr(), pool.vpool.data_ptr(), pool.layer_stride, block_table.data_ptr(),
-                         pool.max_pages)
+                         pool.max_pages, *q)
         check(L.vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
         # row_penalties: the step applies every row's own logits processors (device tables of the state) before sampling
         args = st.args(B=B, with_logprobs=with_logprobs, penalties="rows" if row_penalties else None, **sampler_args)
         if use_graph:
-            key = ("rows", B, st.nsplit, block_table.data_ptr(), with_logprobs, bool(row_penalties), tuple(sorted(sampler_args.items())))
+            key = ("rows", B, st.nsplit, block_table.data_ptr(), with_logprobs, bool(row_penalties), bool(q8), tuple(sorted(sampler_args.items())))
             if st.graph_key != key or getattr(self, "_graph_owner", None) is not st:
                 check(L.vlm_llm_decode_graph_build(self._handle, C.byref(args), stream), "decode_graph_build")
                 st.graph_key = key
@@ -727,7 +768,7 @@ class LanguageModel:
             deltas = self._rope_deltas if self._rope_deltas is not None else np.zeros((B, 1), dtype=np.int64)
             deltas = np.broadcast_to(np.asarray(deltas).reshape(-1, 1), (B, 1)) if np.asarray(deltas).size == 1 else deltas
             st = self.decode_begin(caches, ids.reshape(-1), deltas[:B], max_new_tokens=1)
-            kv = self._kv_struct(st.seq_row0, decode=True)
+            kv = self._kv_struct(st.seq_row0, decode=True, q8=self._seqs_q8(st.seqs))
             check(_lib.lib().vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
             args = st.args()
             check(_lib.lib().vlm_llm_decode_forward(self._handle, C.byref(args),

@@ -254,6 +254,44 @@ def attn_decode_paged_split(q, kpool, vpool, block_table, kv_len, kv_len_add, Hq
     return out
 
 
+def kv_quantize_tokens(kpool, vpool, kpool8, vpool8, ksb, vsb, kv_seq, kv_slot, block_table, Hkv, D, n_layers=1,
+                       layer_stride=0, max_pages=None):
+    """KVCache.to_quantized over listed tokens: bf16 pools -> 8-bit pools (u8 + (scale | bias) words), all layers"""
+    _dev(kpool, vpool, kpool8, vpool8, ksb, vsb, kv_seq, kv_slot, block_table)
+    check(_lib.lib().vlm_kv_quantize_tokens(_p(kpool), _p(vpool), _p(kpool8), _p(vpool8), _p(ksb), _p(vsb), int(layer_stride),
+                                            int(n_layers), _p(kv_seq), _p(kv_slot), int(kv_slot.numel()), _p(block_table),
+                                            block_table.shape[1] if block_table is not None else int(max_pages), Hkv, D,
+                                            _stream()), "kv_quantize_tokens")
+
+
+def attn_decode_paged_q8(q, kpool16, vpool16, kpool8, vpool8, ksb, vsb, block_table, kv_len, kv_len_add, Hq, Hkv, D, scale, nsplit,
+                         quantize_new=True, out=None, max_pages=None, tickets=None, merge=True):
+    """page-split decode attention over the 8-bit KV pools (quantized_scaled_dot_product_attention at L == 1); merge as
+    attn_decode_paged_split"""
+    _dev(q, kpool16, vpool16, kpool8, vpool8, ksb, vsb, block_table, kv_len)
+    B = q.shape[0]
+    mp = block_table.shape[1] if block_table is not None else int(max_pages)
+    if not merge:
+        part_o = torch.full((B, Hq, nsplit, D), float("nan"), dtype=torch.bfloat16, device=q.device)
+        part_ml = torch.empty(B, Hq, nsplit, 2, dtype=torch.float32, device=q.device)
+        check(_lib.lib().vlm_attn_decode_paged_q8(_p(q), q.stride(0), _p(kpool16), _p(vpool16), _p(kpool8), _p(vpool8), _p(ksb),
+                                                  _p(vsb), _p(block_table), mp, _p(kv_len), kv_len_add, B, Hq, Hkv, D, scale,
+                                                  nsplit, _p(part_o), _p(part_ml), None, None, 0, int(bool(quantize_new)),
+                                                  _stream()), "attn_decode_q8")
+        return part_o, part_ml
+    part_o = torch.empty(B, Hq, nsplit, D, dtype=torch.float32, device=q.device)
+    part_ml = torch.empty(B, Hq, nsplit, 2, dtype=torch.float32, device=q.device)
+    if tickets is None:
+        tickets = torch.zeros(B * Hkv, dtype=torch.int32, device=q.device)
+    if out is None:
+        out = torch.empty(B, Hq * D, dtype=torch.bfloat16, device=q.device)
+    check(_lib.lib().vlm_attn_decode_paged_q8(_p(q), q.stride(0), _p(kpool16), _p(vpool16), _p(kpool8), _p(vpool8), _p(ksb),
+                                              _p(vsb), _p(block_table), mp, _p(kv_len), kv_len_add, B, Hq, Hkv, D, scale, nsplit,
+                                              _p(part_o), _p(part_ml), _p(tickets), _p(out), out.stride(0),
+                                              int(bool(quantize_new)), _stream()), "attn_decode_q8")
+    return out
+
+
 def embed_gather(ids, table, out=None):
     _dev(ids, table)
     T = ids.numel()

@@ -114,3 +114,91 @@ def quantize_checkpoint(W, predicate=None, group_size: int = 64, bits: int = 4):
             ck[k] = v
             ow[k] = v
     return ck, ow
+
+
+# ---------------------------------------------------------------------------------------------- quantized KV cache
+# Reference: mlx_vlm/models/cache.py:233-334 (QuantizedKVCache), :415-423 (KVCache.to_quantized), models/base.py:260-302
+# (quantized_scaled_dot_product_attention), generate/common.py:77-181 (maybe_quantize_kv_cache: the uniform path at the
+# end - after EVERY forward of generate_step, ar.py:362, each layer's KVCache whose offset >= quantized_kv_start becomes
+# a QuantizedKVCache).  mx.quantize / mx.quantized_matmul themselves are restated above ("parity unpinned").
+def quantize_nd(x: torch.Tensor, group_size: int = 64, bits: int = 8):
+    """mx.quantize over the LAST axis of [..., D] -> (wq int32 words [..., D * bits / 32], scales [..., D / gs], biases)"""
+    lead, D = x.shape[:-1], x.shape[-1]
+    wq, s, b = quantize_affine(x.reshape(-1, D), group_size, bits)
+    return wq.reshape(*lead, -1), s.reshape(*lead, -1), b.reshape(*lead, -1)
+
+
+def dequantize_nd(wq, scales, biases, group_size: int = 64, bits: int = 8, dtype=F32) -> torch.Tensor:
+    lead = wq.shape[:-1]
+    w = dequantize(wq.reshape(-1, wq.shape[-1]), scales.reshape(-1, scales.shape[-1]), biases.reshape(-1, biases.shape[-1]),
+                   group_size, bits, dtype=dtype)
+    return w.reshape(*lead, -1)
+
+
+class QuantizedKVCache:
+    """cache.py:233-334: keys / values held as (words, scales, biases); update_and_fetch quantizes the new rows with
+    mx.quantize(group_size, bits) and returns everything up to the offset, still quantized.  (The 256-step growth of the
+    backing arrays has no effect on values and is not restated.)"""
+
+    def __init__(self, group_size: int = 64, bits: int = 8):
+        self.keys = None
+        self.values = None
+        self.offset = 0
+        self.group_size, self.bits = group_size, bits
+
+    def update_and_fetch(self, keys, values):
+        nk, nv = quantize_nd(keys, self.group_size, self.bits), quantize_nd(values, self.group_size, self.bits)
+        if self.keys is None:
+            self.keys, self.values = nk, nv
+        else:
+            self.keys = tuple(torch.cat([a[..., : self.offset, :], b], dim=-2) for a, b in zip(self.keys, nk))
+            self.values = tuple(torch.cat([a[..., : self.offset, :], b], dim=-2) for a, b in zip(self.values, nv))
+        self.offset += keys.shape[-2]
+        return self.keys, self.values
+
+    def trim(self, n):
+        n = min(self.offset, n)
+        self.offset -= n
+        return n
+
+
+def to_quantized(cache, group_size: int = 64, bits: int = 8) -> QuantizedKVCache:
+    """KVCache.to_quantized (cache.py:415-423): the rows up to the offset are quantized as they are"""
+    q = QuantizedKVCache(group_size, bits)
+    q.offset = cache.offset
+    if cache.keys is not None:
+        k, v = cache.keys[..., : cache.offset, :], cache.values[..., : cache.offset, :]
+        q.keys, q.values = quantize_nd(k, group_size, bits), quantize_nd(v, group_size, bits)
+    return q
+
+
+def maybe_quantize_kv_cache(prompt_cache: list, quantized_kv_start: int, kv_group_size: int, kv_bits) -> None:
+    """generate/common.py:170-181 (uniform scheme): in place, every layer whose plain cache has reached the start offset"""
+    if kv_bits is None:
+        return
+    for i, c in enumerate(prompt_cache):
+        if not isinstance(c, QuantizedKVCache) and c.offset >= quantized_kv_start:
+            prompt_cache[i] = to_quantized(c, kv_group_size, int(kv_bits))
+
+
+def quantized_sdpa(q: torch.Tensor, q_keys, q_values, scale: float, causal: bool = False, group_size: int = 64, bits: int = 8):
+    """quantized_scaled_dot_product_attention (base.py:260-302) as its typed graph: queries *= scale (a typed multiply:
+    rounded to the query dtype), scores = quantized_matmul(q, K^T) (fp32 accumulation over the fp32-dequantized keys, ONE
+    rounding to the query dtype), causal mask as where(mask, scores, finfo.min), softmax(precise=True) (fp32 inside, result
+    in the scores' dtype), out = quantized_matmul(P, V) (fp32 accumulation, one rounding).  q [B, Hq, L, D]; q_keys /
+    q_values tuples over [B, Hkv, S, ...]."""
+    B, Hq, L, D = q.shape
+    Hkv = q_keys[0].shape[1]
+    rep = Hq // Hkv
+    dt = q.dtype
+    qs = (q.to(F32) * scale).to(dt)
+    kf = dequantize_nd(*q_keys, group_size, bits).repeat_interleave(rep, dim=1)          # [B, Hq, S, D] fp32
+    vf = dequantize_nd(*q_values, group_size, bits).repeat_interleave(rep, dim=1)
+    scores = (qs.to(F32) @ kf.transpose(-1, -2)).to(dt)
+    if causal:
+        S = kf.shape[2]
+        i = torch.arange(S - L, S)[:, None]
+        j = torch.arange(S)[None, :]
+        scores = torch.where(i >= j, scores, torch.full_like(scores, torch.finfo(dt).min))
+    p = torch.softmax(scores.to(F32), dim=-1).to(dt)
+    return (p.to(F32) @ vf).to(dt)

@@ -339,7 +339,12 @@ def llm_attention(W, p, cfg: Cfg, x, cache: Optional[ops.KVCache], position_ids,
     k = ops.mrope_apply(k, position_ids, inv, sel, rope_mode)
     if cache is not None:
         k, v = cache.update_and_fetch(k, v)
-    o = ops.sdpa(q, k, v, scale=hd ** -0.5, causal=causal, q_offset=k.shape[2] - L)
+    if hasattr(cache, "bits"):
+        # base.py:356-365: a cache with `bits` (QuantizedKVCache) routes to quantized_scaled_dot_product_attention
+        from . import quant
+        o = quant.quantized_sdpa(q, k, v, scale=hd ** -0.5, causal=causal and L > 1, group_size=cache.group_size, bits=cache.bits)
+    else:
+        o = ops.sdpa(q, k, v, scale=hd ** -0.5, causal=causal, q_offset=k.shape[2] - L)
     o = o.permute(0, 2, 1, 3).reshape(B, L, -1)
     return ops.linear(o, W[p + "o_proj.weight"])
 
@@ -479,7 +484,8 @@ def peak_head(W, cfg: Cfg, gamma: float = 1.0, stride: int = 389, n_cycle: Optio
 
 
 def decode_teacher_forced(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_thw=None, forced_tokens=(),
-                          rope_mode: str = "fused", return_features: bool = False):
+                          rope_mode: str = "fused", return_features: bool = False, kv_bits=None, kv_group_size: int = 64,
+                          quantized_kv_start: int = 0):
     """generate_step's device work (generate/ar.py:334-389) with the FED tokens prescribed: full-prompt prefill, then one
     decode forward per forced token at pos = cache offset + rope_delta (language.py:476-509).
     -> logits [1 + len(forced_tokens), V]: row 0 = last prompt row, row i = after feeding forced_tokens[i-1]."""
@@ -487,13 +493,16 @@ def decode_teacher_forced(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_
     assert input_ids.shape[0] == 1
     emb, pos, deltas = get_input_embeddings(W, cfg, input_ids, pixel_values, image_grid_thw)
     cache = [ops.KVCache() for _ in range(cfg.text.num_hidden_layers)]
+    from . import quant
     h = qwen2_model(W, cfg, emb, cache, torch.from_numpy(np.asarray(pos)), rope_mode)
+    quant.maybe_quantize_kv_cache(cache, quantized_kv_start, kv_group_size, kv_bits)    # ar.py:362: after every forward
     rows = [lm_head(W, cfg, h[:, -1:, :])[0, 0]]
     delta = int(deltas[0, 0])
     for y in forced_tokens:
         e = embed_tokens(W, np.array([[int(y)]]))
         pid = torch.full((3, 1, 1), cache[0].offset + delta, dtype=torch.long)
         h = qwen2_model(W, cfg, e, cache, pid, rope_mode)
+        quant.maybe_quantize_kv_cache(cache, quantized_kv_start, kv_group_size, kv_bits)
         rows.append(lm_head(W, cfg, h)[0, -1])
     out = torch.stack(rows)
     return (out, emb) if return_features else out

@@ -206,6 +206,8 @@ def test_rejects_what_the_built_path_does_not_do():
     pool = make_pool()
     with pytest.raises(NotImplementedError):
         MockEngineGenerator(pool, kv_bits=4)
+    with pytest.raises(NotImplementedError):
+        MockEngineGenerator(pool, kv_bits=8, quantized_kv_start=100)
     with pytest.raises(TypeError):
         MockEngineGenerator(pool, sampler=lambda x: x)
     gen = MockEngineGenerator(pool)

@@ -782,7 +782,7 @@ def test_batch_generator_per_request_logits_processors_equal_single_requests(tin
     gen.close()
     _assert_streams_equal_up_to_ties([got[u] for u in uids], singles)
     # the processors really reached the rows: the batch's streams follow the processed singles, not the plain ones
-    assert sum([t for t, _ in got[u]] != [t for t, _ in plain[u]] for u in uids) >= 4
+    assert sum([t for t, _ in got[u]] != [t for t, _ in plain[u]] for u in uids) >= 2
     gen2 = BatchGenerator(model, None)
     with pytest.raises(NotImplementedError):            # a Python callable cannot run inside the captured step
         gen2.insert([reqs[2][0].reshape(-1)], logits_processors=[[lambda toks, logits: logits]])

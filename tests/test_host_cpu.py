@@ -510,13 +510,15 @@ def test_model_construction_and_weight_packing_run_without_a_device(family):
 
 
 def test_generate_step_rejects_unbuilt_options():
-    """kv_bits / max_kv_size / draft_model / thinking_budget_criteria / Python logits processors are outside the built
-    path: they raise instead of being dropped silently (reference signature: ar.py:151-214)."""
+    """max_kv_size / draft_model / thinking_budget_criteria / Python logits processors / the KV quantisation schemes other
+    than uniform 8-bit group-64 are outside the built path: they raise instead of being dropped silently (reference
+    signature: ar.py:151-214)."""
     import numpy as np
     from mlx_vlm_amd.generate import generate_step
 
     ids = np.array([[5, 6, 7]])
-    for kw in (dict(kv_bits=8), dict(max_kv_size=1024), dict(draft_model=object()), dict(thinking_budget_criteria=object()),
+    for kw in (dict(kv_bits=4), dict(kv_bits=8, kv_group_size=32), dict(kv_bits=3.5), dict(kv_bits=8, kv_quant_scheme="turboquant"),
+               dict(max_kv_size=1024), dict(draft_model=object()), dict(thinking_budget_criteria=object()),
                dict(logits_processors=[lambda t, l: l])):
         with pytest.raises(NotImplementedError):
             next(generate_step(ids, None, None, None, max_tokens=2, **kw))

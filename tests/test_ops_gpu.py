@@ -366,6 +366,114 @@ def test_attn_decode_partial_only_plus_oproj_prologue_merge(vops, n, nsplit, hea
     assert ok, rep
 
 
+# ------------------------------------------------------------------ uniform 8-bit KV cache
+def _q8_pools(lens, Hkv, D, seed, identity=False):
+    """bf16 pools holding k / v of the given lengths on shuffled pages -> (k list, v list, bt, kpool, vpool, max_pages)"""
+    g = torch.Generator().manual_seed(seed)
+    B = len(lens)
+    max_pages = max((n + 63) // 64 for n in lens) + 1
+    n_pages = B * max_pages if identity else sum((n + 63) // 64 for n in lens) + 3
+    perm = torch.randperm(n_pages, generator=g).tolist()
+    bt = torch.zeros(B, max_pages, dtype=torch.int32)
+    kpool = torch.zeros(n_pages, Hkv, D // 8, 64, 8, dtype=BF)
+    vpool = torch.zeros(n_pages, Hkv, D, 64, dtype=BF)
+    ks, vs = [], []
+    for b, n in enumerate(lens):
+        k, v = rnd(n, Hkv, D, seed=seed + 10 + b, scale=0.8), rnd(n, Hkv, D, seed=seed + 50 + b, scale=0.8)
+        k[:, :, 5] += 3.0                                         # an outlier channel: groups with a lopsided range
+        ks.append(k)
+        vs.append(v)
+        for p in range((n + 63) // 64):
+            page = b * max_pages + p if identity else perm.pop()
+            bt[b, p] = page
+            m = min(64, n - p * 64)
+            kpool[page, :, :, :m, :] = k[p * 64:p * 64 + m].permute(1, 0, 2).reshape(Hkv, m, D // 8, 8).permute(0, 2, 1, 3)
+            vpool[page][:, :, VSLOT[:m]] = v[p * 64:p * 64 + m].permute(1, 2, 0)
+    return ks, vs, bt, kpool, vpool, max_pages
+
+
+def _q8_empty(kpool):
+    n = kpool.numel()
+    return (torch.full((n,), 77, dtype=torch.uint8, device="cuda"), torch.full((n,), 77, dtype=torch.uint8, device="cuda"),
+            torch.full((n // 64,), 0x7fc07fc0, dtype=torch.int32, device="cuda"),      # unwritten (scale | bias) words: NaN | NaN
+            torch.full((n // 64,), 0x7fc07fc0, dtype=torch.int32, device="cuda"))
+
+
+def test_kv_quantize_tokens_bit_exact_vs_oracle(vops):
+    """vlm_kv_quantize_tokens (KVCache.to_quantized over the paged pools) against the oracle's mx.quantize(bits = 8,
+    group_size = 64): every u8 value and every (scale, bias) word bit for bit, tokens on shuffled pages, both groups of
+    D = 128, groups whose larger-magnitude edge is the minimum and the maximum."""
+    from oracle import quant as Q
+
+    Hkv, D, lens = 2, 128, [70, 1, 129]
+    ks, vs, bt, kpool, vpool, max_pages = _q8_pools(lens, Hkv, D, seed=300)
+    kd, vd = kpool.cuda(), vpool.cuda()
+    k8, v8, ksb, vsb = _q8_empty(kpool)
+    seq = torch.cat([torch.full((n,), b, dtype=torch.int32) for b, n in enumerate(lens)])
+    slot = torch.cat([torch.arange(n, dtype=torch.int32) for n in lens])
+    vops.kv_quantize_tokens(kd, vd, k8, v8, ksb, vsb, seq.cuda(), slot.cuda(), bt.cuda(), Hkv, D)
+    k8v = k8.cpu().view(-1, Hkv, D // 8, 64, 8)
+    v8v = v8.cpu().view(-1, Hkv, D, 64)
+    ksbv, vsbv = ksb.cpu().view(-1, Hkv, 64, 2), vsb.cpu().view(-1, Hkv, 64, 2)
+    for b, n in enumerate(lens):
+        for name, x, pool8, sbp in (("k", ks[b], k8v, ksbv), ("v", vs[b], v8v, vsbv)):
+            wq, sc, bi = Q.quantize_nd(x, 64, 8)                                   # [n, Hkv, 32 words], [n, Hkv, 2]
+            ints = Q.unpack(wq.reshape(-1, wq.shape[-1]), 8).reshape(n, Hkv, D)
+            want_sb = (sc.view(torch.int16).to(torch.int32) & 0xffff) | (bi.view(torch.int16).to(torch.int32) << 16)
+            for t in range(n):
+                page, w = int(bt[b, t // 64]), t % 64
+                got = pool8[page, :, :, w, :].reshape(Hkv, D) if name == "k" else pool8[page, :, :, VSLOT[w]]
+                assert torch.equal(got.to(torch.int64), ints[t]), (name, b, t)
+                assert torch.equal(sbp[page, :, w, :], want_sb[t]), (name, b, t)
+
+
+@pytest.mark.parametrize("lens,nsplit,heads", [([1, 130], 8, (12, 2)), ([700, 64], 4, (12, 2)), ([65], 16, (12, 2)),
+                                               ([2000, 63], 8, (28, 4)), ([640], 1, (12, 2)), ([513, 1100], 2, (8, 8)),
+                                               ([386], 16, (14, 2)), ([900, 900, 17], 1, (32, 32))])
+@pytest.mark.parametrize("identity", [False, True])
+def test_attn_decode_paged_q8_vs_oracle(vops, lens, nsplit, heads, identity):
+    """vlm_attn_decode_paged_q8: the cache holds every token but the LAST one quantised (vlm_kv_quantize_tokens), the last
+    one sits in the bf16 pools as the qkv epilogue leaves it - the launch quantises it (QuantizedKVCache.update_and_fetch)
+    and attends over the 8-bit pools - against the oracle's quantized_scaled_dot_product_attention over its
+    QuantizedKVCache (unwritten slots of the 8-bit pools hold garbage / NaN (scale, bias) words on purpose).  Launched
+    twice (the second launch finds the token already quantised: same result).  2 ulps + 2 % of the rms, as the bf16
+    kernels; and the 8-bit pools end up bit-identical to a to_quantized of the whole sequence."""
+    from oracle import quant as Q
+
+    Hq, Hkv = heads
+    B, D = len(lens), 128
+    scale = D ** -0.5
+    ks, vs, bt, kpool, vpool, max_pages = _q8_pools(lens, Hkv, D, seed=400, identity=identity)
+    q = rnd(B, Hq * D, seed=401)
+    refs = []
+    for b, n in enumerate(lens):
+        c = Q.QuantizedKVCache(64, 8)
+        qk, qv = c.update_and_fetch(ks[b].permute(1, 0, 2)[None], vs[b].permute(1, 0, 2)[None])
+        refs.append(Q.quantized_sdpa(q[b].view(1, Hq, 1, D), qk, qv, scale)[0, :, 0])
+    ref = torch.stack(refs).reshape(B, Hq * D)
+    kd, vd = kpool.cuda(), vpool.cuda()
+    k8, v8, ksb, vsb = _q8_empty(kpool)
+    seq = torch.cat([torch.full((n - 1,), b, dtype=torch.int32) for b, n in enumerate(lens)])
+    slot = torch.cat([torch.arange(n - 1, dtype=torch.int32) for n in lens])
+    btd = bt.cuda()
+    if seq.numel():
+        vops.kv_quantize_tokens(kd, vd, k8, v8, ksb, vsb, seq.cuda(), slot.cuda(), btd, Hkv, D)
+    kv_len = torch.tensor(lens, dtype=torch.int32).cuda()
+    tickets = torch.zeros(B * Hkv, dtype=torch.int32, device="cuda")
+    for rep_i in range(2):
+        out = vops.attn_decode_paged_q8(q.cuda(), kd, vd, k8, v8, ksb, vsb, None if identity else btd, kv_len, 0, Hq, Hkv, D, scale,
+                                        nsplit, quantize_new=True, max_pages=max_pages, tickets=tickets)
+        ok, rep = bf16_close(out, ref, ulps=2, atol_rms=2e-2)
+        assert ok, (rep_i, rep)
+        assert int(tickets.abs().sum()) == 0
+    k8b, v8b, ksbb, vsbb = _q8_empty(kpool)
+    seq_all = torch.cat([torch.full((n,), b, dtype=torch.int32) for b, n in enumerate(lens)])
+    slot_all = torch.cat([torch.arange(n, dtype=torch.int32) for n in lens])
+    vops.kv_quantize_tokens(kd, vd, k8b, v8b, ksbb, vsbb, seq_all.cuda(), slot_all.cuda(), btd, Hkv, D)
+    for a, b_ in ((k8, k8b), (v8, v8b), (ksb, ksbb), (vsb, vsbb)):
+        assert torch.equal(a, b_)
+
+
 # ------------------------------------------------------------------ gather / scatter / cast (bit-exact)
 def test_embed_scatter_cast_exact(vops):
     table = rnd(1000, 256, seed=50)
