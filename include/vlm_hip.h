@@ -57,6 +57,15 @@ int vlm_gemm_bf16(const void* A, const void* W, const void* bias, const void* re
 int vlm_gemm_bf16_rope2d(const void* A, const void* W, const void* bias, const void* cos_sin, void* C, int M, int N, int K,
                          int lda, int ldw, int ldc, int head_dim, int rope_cols, void* stream);
 
+/* The same GEMM over MLX affine 4-bit weights, dequantisation FUSED into the W-tile staging (nn.QuantizedLinear /
+ * mx.quantized_matmul at L > 1, reference utils.py:918-967): Wq uint32 [N][K/8] (element k of a row in word k / 8, nibble
+ * k % 8), Wsb uint32 [N][K/64] (scale bf16 | bias bf16 << 16 per 64-wide group), K % 64 == 0.  The LDS image of a W tile
+ * is the one vlm_gemm_bf16 builds from vlm_dequant_w4's output, so C is bit-identical to dequantise-then-GEMM while the
+ * weights move at 4.5 bits instead of being written and re-read at 16.  Epilogues: NONE, BIAS, RESIDUAL, BIAS | RESIDUAL,
+ * SWIGLU. */
+int vlm_gemm_w4(const void* A, const void* Wq, const void* Wsb, const void* bias, const void* res, void* C, int M, int N,
+                int K, int lda, int ldc, int ldres, int epilogue, void* stream);
+
 /* test / A-B knob for vlm_gemm_bf16 kernel selection: 0 = automatic (LDS-DMA staging when K % 64 == 0; the phased
  * 256x256 kernel from ~120 tiles up), 1 = 128x128 kernel with global -> VGPR -> LDS staging, 2 = 128x128 kernel with
  * LDS-DMA staging, 3 = 256x256 phased kernel whenever legal (K % 64 == 0, K >= 128, no SwiGLU), 4 = its 2-phase

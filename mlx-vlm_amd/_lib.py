@@ -118,6 +118,7 @@ SIGNATURES = {
                               + [c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vlm_attn_decode_paged_split": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 5
                                     + [c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "vlm_gemm_w4": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "vlm_kv_quantize_tokens": (c_int, [c_void_p] * 6 + [c_size_t, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                                        c_void_p]),
     "vlm_attn_decode_paged_q8": (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_int, c_void_p] + [c_int] * 5

@@ -275,6 +275,11 @@ extern "C" int vlm_llm_set_kv(void* handle, const vlm_kv_pool* kv) {
 // prefill: C = epi(A . W^T): 4-bit weights are materialised as bf16 once per projection (vlm_dequant_w4 -> scratch)
 static int lin_gemm(Llm* m, const void* A, const void* W, const void* Wsb, const void* bias, const void* res, void* C, int M,
                     int N, int K, int ldc, int ldres, int epi, void* stream) {
+  // MLX 4-bit weights: up to 2048 rows the dequant-fused GEMM (vlm_gemm_w4: the packed weights are read once, 4.5 bits
+  // each); beyond that the matrix is dequantised once into the stream's scratch and the phased 256x256 bf16 kernel runs
+  // (1.4 vs 0.9 PFLOP/s: at that many rows the GEMM time, not the weight traffic, decides).  Same values either way.
+  if (Wsb && M <= 2048 && K % 64 == 0)
+    return vlm_gemm_w4(A, W, Wsb, bias, res, C, M, N, K, K, ldc, ldres, epi, stream);
   if (Wsb) {
     const vlm_llm_config& c = m->cfg;
     const size_t D = (size_t)c.hidden, KO = (size_t)c.n_heads * c.head_dim, QKV = (size_t)(c.n_heads + 2 * c.n_kv_heads) * c.head_dim;

@@ -47,16 +47,28 @@ __device__ __forceinline__ int lds_off(int row, int slot) { return row * ROWB + 
 // PARTIAL (split-K, small M x N with a long K - the LLM down projection at prompt length): blockIdx.y selects a K range
 // of kchunk elements; the workgroup writes its fp32 accumulators to part[split][M][N] (C reinterpreted) and
 // splitk_reduce_kernel sums the splits in a fixed order and applies the epilogue.
-template <int BM, int BN, int EPI, bool GLDS, bool PARTIAL = false>
+// W4 = true (register-staged form only): W holds MLX affine 4-bit weights - uint32 words [N][K/8] (ldw = K) with
+// Wsb uint32 [N][K/64] = (scale bf16 | bias bf16 << 16) per 64-wide group - and the W tile is DEQUANTISED ON ITS WAY
+// INTO LDS: a thread's 16-byte LDS chunk (8 consecutive k of one row) is exactly one q word, and BK = 64 = the group
+// size, so a K tile of a row has ONE (scale, bias).  The LDS image is bit for bit the one the bf16 kernel builds from
+// vlm_dequant_w4's output (same fp32 scale * q + bias, one rounding: mx.dequantize), so the fused GEMM equals
+// dequantise-then-GEMM bit for bit while reading 4.5 instead of 16 + 16 + 16 bits per weight (nn.QuantizedLinear /
+// mx.quantized_matmul at L > 1, reference utils.py:918-967).
+template <int BM, int BN, int EPI, bool GLDS, bool PARTIAL = false, bool W4 = false>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                         const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
                                                         bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldw,
-                                                        int ldc, int ldres, int tiles_n, int nwg, int kchunk) {
+                                                        int ldc, int ldres, int tiles_n, int nwg, int kchunk,
+                                                        const unsigned* __restrict__ Wsb = nullptr) {
+  static_assert(!W4 || !GLDS, "the 4-bit form stages W through registers");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ksplit = PARTIAL ? (int)blockIdx.y : 0;
+  const unsigned* Wq = reinterpret_cast<const unsigned*>(W);      // (W4) q words, row pitch ldw / 8
+  const int sb_pitch = ldw >> 6;                                  // (W4) groups per row
   if (PARTIAL) {
     A += (size_t)ksplit * kchunk;
-    W += (size_t)ksplit * kchunk;
+    if (W4) { Wq += (size_t)ksplit * kchunk / 8; Wsb += (size_t)ksplit * kchunk / 64; }
+    else W += (size_t)ksplit * kchunk;
     K = min(kchunk, K - ksplit * kchunk);
   }
   constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16;
@@ -96,7 +108,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     for (int i = 0; i < W_PER; ++i) {
       const int c = tid + 256 * i, row = c >> 3, slot = c & 7;
       const int gn = min(n0 + row, N - 1), gk = k0 + slot * 8;
-      rw[i] = (gk < K) ? *reinterpret_cast<const uint4*>(W + (size_t)gn * ldw + gk) : make_uint4(0, 0, 0, 0);
+      if constexpr (W4) {
+        // raw words now (q word + the group's scale | bias); dequantised in lstore, after the MFMAs of the current tile
+        rw[i] = (gk < K) ? make_uint4(Wq[(size_t)gn * (ldw >> 3) + (gk >> 3)], Wsb[(size_t)gn * sb_pitch + kt], 0, 0)
+                         : make_uint4(0, 0, 0, 0);
+      } else {
+        rw[i] = (gk < K) ? *reinterpret_cast<const uint4*>(W + (size_t)gn * ldw + gk) : make_uint4(0, 0, 0, 0);
+      }
     }
   };
   auto lstore = [&](int buf) {
@@ -110,7 +128,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int i = 0; i < W_PER; ++i) {
       const int c = tid + 256 * i;
-      *reinterpret_cast<uint4*>(ws + lds_off(c >> 3, c & 7)) = rw[i];
+      uint4 o = rw[i];
+      if constexpr (W4) {
+        const unsigned w = rw[i].x, sbw = rw[i].y;
+        const float sc = bf_lo(sbw), bi = bf_hi(sbw);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = __fadd_rn(__fmul_rn(sc, (float)((w >> (4 * j)) & 0xFu)), bi);    // == dequant_w4_kernel
+        o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
+      }
+      *reinterpret_cast<uint4*>(ws + lds_off(c >> 3, c & 7)) = o;
     }
   };
 
@@ -404,6 +431,55 @@ int launch_cfg(const void* A, const void* W, const void* bias, const void* res, 
   return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
 }
 
+// ---- MLX 4-bit W (dequant-fused form): register-staged kernels only
+template <int EPI>
+int launch_splitk_w4(const void* A, const void* Wq, const void* Wsb, const void* bias, const void* res, void* C, int M, int N,
+                     int K, int lda, int ldc, int ldres, int splits, float* ws, hipStream_t st) {
+  const int kchunk = vlm_cdiv(vlm_cdiv(K, splits), BK) * BK;
+  splits = vlm_cdiv(K, kchunk);
+  const int tiles_m = vlm_cdiv(M, 64), tiles_n = vlm_cdiv(N, 64), nwg = tiles_m * tiles_n;
+  const size_t lds = 2 * (size_t)(64 + 64) * ROWB;
+  hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, VLM_EPI_NONE, false, true, true>), dim3(nwg, splits), dim3(256), lds, st,
+                     (const bf16_t*)A, (const bf16_t*)Wq, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
+                     reinterpret_cast<bf16_t*>(ws), M, N, K, lda, K, N, 0, tiles_n, nwg, kchunk, (const unsigned*)Wsb);
+  const long items = (long)M * (N >> 3);
+  hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
+                     (const float*)ws, splits, (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, ldc, ldres);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
+}
+
+template <int BM, int BN, int EPI>
+int launch_cfg_w4(const void* A, const void* Wq, const void* Wsb, const void* bias, const void* res, void* C, int M, int N, int K,
+                  int lda, int ldc, int ldres, hipStream_t st) {
+  const int tiles_m = vlm_cdiv(M, BM), tiles_n = vlm_cdiv(N, BN), nwg = tiles_m * tiles_n;
+  const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, false, false, true>), dim3(nwg), dim3(256), lds, st, (const bf16_t*)A,
+                     (const bf16_t*)Wq, (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, K, ldc, ldres, tiles_n,
+                     nwg, 0, (const unsigned*)Wsb);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
+}
+
+template <int EPI>
+int launch_epi_w4(const void* A, const void* Wq, const void* Wsb, const void* bias, const void* res, void* C, int M, int N, int K,
+                  int lda, int ldc, int ldres, hipStream_t st) {
+  const long t128 = (long)vlm_cdiv(M, 128) * vlm_cdiv(N, 128);
+  const long t64n = (long)vlm_cdiv(M, 64) * vlm_cdiv(N, 128);
+  if (!(EPI & VLM_EPI_SWIGLU) && g_splitk >= 0 && N % 8 == 0) {          // same split-K policy as the bf16 form
+    const long t64 = (long)vlm_cdiv(M, 64) * vlm_cdiv(N, 64);
+    int splits = g_splitk > 1 ? g_splitk : 0;
+    if (!splits && t64 < 256 && K >= 2048) splits = (int)std::min<long>(8, std::max<long>(2, (512 + t64 - 1) / t64));
+    if (splits > 1 && K / splits >= 4 * BK) {
+      if (float* ws = splitk_workspace((size_t)splits * M * N * sizeof(float), st))
+        return launch_splitk_w4<EPI>(A, Wq, Wsb, bias, res, C, M, N, K, lda, ldc, ldres, splits, ws, st);
+    }
+  }
+  if (t128 >= 200) return launch_cfg_w4<128, 128, EPI>(A, Wq, Wsb, bias, res, C, M, N, K, lda, ldc, ldres, st);
+  if (t64n >= 200) return launch_cfg_w4<64, 128, EPI>(A, Wq, Wsb, bias, res, C, M, N, K, lda, ldc, ldres, st);
+  return launch_cfg_w4<64, 64, EPI>(A, Wq, Wsb, bias, res, C, M, N, K, lda, ldc, ldres, st);
+}
+
 template <int EPI>
 int launch_epi(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
                int ldw, int ldc, int ldres, hipStream_t st) {
@@ -502,6 +578,28 @@ static int gemm_dispatch(const void* A, const void* W, const void* bias, const v
     case VLM_EPI_BIAS | VLM_EPI_ROPE2D: GO(VLM_EPI_BIAS | VLM_EPI_ROPE2D);
     case VLM_EPI_BIAS | VLM_EPI_GELU_FAST: GO(VLM_EPI_BIAS | VLM_EPI_GELU_FAST);
     case VLM_EPI_BIAS | VLM_EPI_GELU_ERF: GO(VLM_EPI_BIAS | VLM_EPI_GELU_ERF);
+    case VLM_EPI_BIAS | VLM_EPI_RESIDUAL: GO(VLM_EPI_BIAS | VLM_EPI_RESIDUAL);
+    case VLM_EPI_RESIDUAL: GO(VLM_EPI_RESIDUAL);
+    case VLM_EPI_SWIGLU: GO(VLM_EPI_SWIGLU);
+    default: return VLM_ERR_ARG;
+  }
+#undef GO
+}
+
+extern "C" int vlm_gemm_w4(const void* A, const void* Wq, const void* Wsb, const void* bias, const void* res, void* C, int M,
+                           int N, int K, int lda, int ldc, int ldres, int epilogue, void* stream) {
+  if (!A || !Wq || !Wsb || !C || M < 0 || N <= 0 || K <= 0) return VLM_ERR_ARG;
+  if ((epilogue & VLM_EPI_BIAS) && !bias) return VLM_ERR_ARG;
+  if ((epilogue & VLM_EPI_RESIDUAL) && !res) return VLM_ERR_ARG;
+  if (K % 64 != 0 || N % 8 != 0 || lda % 8 != 0 || ldc % 8 != 0) return VLM_ERR_SHAPE;
+  if ((epilogue & VLM_EPI_RESIDUAL) && ldres % 8 != 0) return VLM_ERR_SHAPE;
+  if ((epilogue & VLM_EPI_SWIGLU) && N % 16 != 0) return VLM_ERR_SHAPE;
+  if (M == 0) return VLM_OK;
+  hipStream_t st = (hipStream_t)stream;
+#define GO(E) return launch_epi_w4<E>(A, Wq, Wsb, bias, res, C, M, N, K, lda, ldc, ldres, st)
+  switch (epilogue) {
+    case VLM_EPI_NONE: GO(VLM_EPI_NONE);
+    case VLM_EPI_BIAS: GO(VLM_EPI_BIAS);
     case VLM_EPI_BIAS | VLM_EPI_RESIDUAL: GO(VLM_EPI_BIAS | VLM_EPI_RESIDUAL);
     case VLM_EPI_RESIDUAL: GO(VLM_EPI_RESIDUAL);
     case VLM_EPI_SWIGLU: GO(VLM_EPI_SWIGLU);

@@ -254,6 +254,20 @@ def attn_decode_paged_split(q, kpool, vpool, block_table, kv_len, kv_len_add, Hq
     return out
 
 
+def gemm_w4(a, wq, sb, bias=None, res=None, epilogue=EPI_NONE, out=None):
+    """prefill GEMM over MLX 4-bit weights with the dequantisation fused into the tile staging: wq int32 [N, K/8], sb int32
+    [N, K/64] (as gemv_w4)"""
+    _dev(a, wq, sb, bias, res, out)
+    M, K = a.shape
+    N = wq.shape[0]
+    n_out = N // 2 if epilogue & EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.bfloat16, device=a.device)
+    check(_lib.lib().vlm_gemm_w4(_p(a), _p(wq), _p(sb), _p(bias), _p(res), _p(out), M, N, K, a.stride(0), out.stride(0),
+                                 res.stride(0) if res is not None else 0, epilogue, _stream()), "gemm_w4")
+    return out
+
+
 def kv_quantize_tokens(kpool, vpool, kpool8, vpool8, ksb, vsb, kv_seq, kv_slot, block_table, Hkv, D, n_layers=1,
                        layer_stride=0, max_pages=None):
     """KVCache.to_quantized over listed tokens: bf16 pools -> 8-bit pools (u8 + (scale | bias) words), all layers"""

@@ -950,6 +950,29 @@ def test_dequant_w4_bit_exact_and_row_gather(vops, N, K):
     assert torch.equal(ow.rows(idx), ref[idx.long()])
 
 
+@pytest.mark.parametrize("M,N,K", [(200, 512, 256), (885, 3072, 3072), (130, 1536, 8960), (77, 1280, 1216 + 64), (5, 64, 64),
+                                   (1400, 8192, 1536), (386, 3072, 8192)])
+def test_gemm_w4_fused_bit_identical_to_dequant_then_gemm(vops, M, N, K):
+    """vlm_gemm_w4 (BASELINE configs[4]: the dequant-fused prefill GEMM) against dequantise-then-GEMM (vlm_dequant_w4 +
+    vlm_gemm_bf16): BIT-IDENTICAL - the fused kernel builds the same LDS image of every W tile - for every tile shape
+    (128x128, 64x128, 64x64), the split-K form (few tiles x long K: the down projection at prompt length), ragged M, and
+    the epilogues of the decoder (bias, residual, SwiGLU on interleaved rows); and against the oracle's
+    nn.QuantizedLinear (fp32 dequantised weights: 2 ulps + 2e-3 rms)."""
+    ow, dw = _q4(N, K, seed=500 + M)
+    a, b, r = rnd(M, K, seed=501), rnd(N, seed=502, scale=0.3), rnd(M, N, seed=503)
+    wd = vops.dequant_w4(dw.wq, dw.sb)
+    ad = a.cuda()
+    assert torch.equal(vops.gemm_w4(ad, dw.wq, dw.sb), vops.gemm(ad, wd))
+    assert torch.equal(vops.gemm_w4(ad, dw.wq, dw.sb, bias=b.cuda(), epilogue=vops.EPI_BIAS),
+                       vops.gemm(ad, wd, bias=b.cuda(), epilogue=vops.EPI_BIAS))
+    assert torch.equal(vops.gemm_w4(ad, dw.wq, dw.sb, res=r.cuda(), epilogue=vops.EPI_RESIDUAL),
+                       vops.gemm(ad, wd, res=r.cuda(), epilogue=vops.EPI_RESIDUAL))
+    if N % 16 == 0:
+        assert torch.equal(vops.gemm_w4(ad, dw.wq, dw.sb, epilogue=vops.EPI_SWIGLU), vops.gemm(ad, wd, epilogue=vops.EPI_SWIGLU))
+    ok, rep = bf16_close(vops.gemm_w4(ad, dw.wq, dw.sb), ow.linear(a), ulps=2, atol_rms=2e-3)
+    assert ok, rep
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 512, 256), (2, 1536, 1536), (8, 8192, 1536), (4, 1536, 8960), (1, 302, 4096),
                                    (1, 1024, 18944)])
 def test_gemv_w4_plain_bias_residual_vs_oracle(vops, M, N, K):
