@@ -734,7 +734,7 @@ def workload_idefics2_b8(args, rank, ws, dev):
 
 def workload_phi35v_w4_b16(args, rank, ws, dev):
     """BASELINE configs[4]: Phi-3.5-vision-instruct with an MLX affine 4-bit language model (the dequant-fused kernels:
-    csrc/gemv_w4.hip at 1-4 rows, the W4 form of csrc/gemv_mfma.hip at 5-16 rows; prefill = dequantise + bf16 GEMM), batch
+    csrc/gemv_w4.hip at 1-4 rows, the W4 form of csrc/gemv_mfma.hip at 5-16 rows; prefill = the dequant-fused GEMM vlm_gemm_w4 up to 2048 rows per call, dequantise + the 256x256 bf16 GEMM beyond), batch
     16 PER GPU: 16 requests of one 336 x 336 image (HD transform at num_crops 4: 5 CLIP views -> 757 image tokens) + 128
     text tokens, greedy 64 new tokens, through the continuous generator at 16 decode rows (weak scaling: every rank
     serves its own 16)."""
@@ -754,7 +754,9 @@ def workload_phi35v_w4_b16(args, rank, ws, dev):
         ids_l.append(np.concatenate([text[:64], np.full(n_img, -1), text[64:]]).astype(np.int64))
         pix_l.append(torch.from_numpy(out["pixel_values"]).to(dev))
         ex_l.append({"image_sizes": out["image_sizes"]})
-    run = lambda n, mt: generate_batch_continuous(model, ids_l[:n], pix_l[:n], [None] * n, max_tokens=mt, extras=ex_l[:n])  # noqa: E731
+    kv_bits = args.kv_bits or None             # --kv-bits 8: the uniform 8-bit KV cache (QuantizedKVCache) for every row
+    run = lambda n, mt: generate_batch_continuous(model, ids_l[:n], pix_l[:n], [None] * n, max_tokens=mt, extras=ex_l[:n],  # noqa: E731
+                                                  kv_bits=kv_bits)
     for _ in range(args.warmup):
         run(n_req, 8)
     parallel.barrier()
@@ -774,6 +776,8 @@ def workload_phi35v_w4_b16(args, rank, ws, dev):
     # per 16-row step: the weights once (4 bits + 32 / 64 bits per weight) + every row's K / V (MHA: 32 kv heads of 96 in
     # 32 layers = 393,216 B per cached token; the engine's 128-wide pages move 4 / 3 of that) at the mean context
     kv_tok = 2 * cfg.num_hidden_layers * cfg.num_key_value_heads * (D // H) * 2
+    if kv_bits:                                # 8 bits + one (scale, bias) bf16 pair per 64 elements: 8.5 bits per element
+        kv_tok = kv_tok * 17 // 32
     ctx_mid = int(ids_l[0].size) + max_tokens // 2
     step_bytes = lm_params * 9 // 16 + n_req * ctx_mid * kv_tok
     steps_per_s = gen_tok / n_req / gen_t_max
@@ -781,7 +785,8 @@ def workload_phi35v_w4_b16(args, rank, ws, dev):
     N = 577
     clip_tflop = 5 * ((v.num_hidden_layers - 1) * (8 * N * v.hidden_size ** 2 + 4 * N * v.hidden_size * v.intermediate_size
                                                    + 4 * N * N * v.hidden_size) + 2 * 576 * 588 * v.hidden_size) / 1e12
-    out = {"metric": "decode tokens/sec, Phi-3.5-vision int4 (MLX affine, group 64), batch=16 per GPU", "value": ws * gen_tok / gen_t_max,
+    out = {"metric": "decode tokens/sec, Phi-3.5-vision int4 (MLX affine, group 64), batch=16 per GPU" + (", 8-bit KV cache" if kv_bits else ""),
+           "kv_bits": kv_bits, "value": ws * gen_tok / gen_t_max,
            "unit": "tokens/s", "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16 activations, int4 affine weights (fp32 accumulate)", "data": "synthetic",
@@ -809,6 +814,7 @@ def main():
     ap.add_argument("--lookahead", type=int, default=8)
     ap.add_argument("--vit-batch", type=int, default=16)
     ap.add_argument("--workload", default="qwen2vl-2b", choices=["qwen2vl-2b", "nanollava", "qwen2vl-7b-b32", "qwen2vl-2b-w4", "phi35v-w4-b16", "idefics2-b8"])
+    ap.add_argument("--kv-bits", type=int, default=0, help="phi35v-w4-b16: 8 = uniform 8-bit KV cache (kv_bits of the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-hf", action="store_true", help="skip the HuggingFace torch-CPU second opinion of cpu_baseline")
     ap.add_argument("--no-extras", action="store_true", help="skip kernel rooflines / ViT throughput (profiling runs)")

@@ -449,6 +449,21 @@ int vlm_llm_get_tuning(void* handle, int key);
  * non-zero = a wait gave up (results of that step are garbage).  Synchronises the device; clears the word. */
 int vlm_llm_fused_error(void* handle);
 
+/* The encoder-layer loop of the SigLIP / CLIP vision towers (idefics2/vision.py:141-187, llava_bunny/vision.py:139-200,
+ * phi3_v/vision.py:117-175: x = x + out_proj(attention(LN1(x))); x = x + fc2(act(fc1(LN2(x)))), biases everywhere, no
+ * rope, no mask) as one native call: n_layers x [LayerNorm, qkv GEMM + bias, varlen flash attention, out GEMM + bias +
+ * residual, LayerNorm, fc1 GEMM + bias + activation, fc2 GEMM + bias + residual] enqueued back to back.
+ * x [N][E] residual stream (in / out); workspaces xn [N][E], qkv [N][3 H head_dim], attn [N][H head_dim], mlp [N][MH];
+ * wqkv rows [q | k | v] of H * head_dim each (head_dim = the kernel's width: 64 / 80 / 128 - narrower heads zero-padded
+ * by the caller, wo's columns likewise); act_epilogue VLM_EPI_GELU_FAST / VLM_EPI_GELU_ERF / 0; cu_seqlens int32
+ * [nseg + 1], total_qblocks = sum ceil(len / 128); uniform_segments: vlm_attn_prefill's placement hint. */
+typedef struct vlm_enc_layer {
+  const void *ln1_w, *ln1_b, *wqkv, *bqkv, *wo, *bo, *ln2_w, *ln2_b, *w1, *b1, *w2, *b2;
+} vlm_enc_layer;
+int vlm_encoder_forward(const vlm_enc_layer* layers /* host array */, int n_layers, void* x, void* xn, void* qkv, void* attn,
+                        void* mlp, int N, int E, int H, int head_dim, int MH, float ln_eps, int act_epilogue,
+                        const void* cu_seqlens, int nseg, int total_qblocks, float scale, int uniform_segments, void* stream);
+
 typedef struct vlm_vit_config {
   int depth, embed_dim, n_heads, mlp_hidden, patch_k /* padded K of the patch GEMM */, merge /* 2 */, out_dim;
   float ln_eps;

@@ -42,6 +42,10 @@ class PrefillArgs(C.Structure):
                 ("last_rows", c_void_p), ("n_last", c_int), ("xlast", c_void_p), ("logits", c_void_p), ("rope_long", c_int)]
 
 
+class EncLayer(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("ln1_w", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")]
+
+
 class PenaltyArgs(C.Structure):
     _fields_ = [("hist", c_void_p), ("hist_len", c_void_p), ("hist_cap", c_int), ("rep_penalty", c_float), ("rep_ctx", c_int),
                 ("pres_penalty", c_float), ("pres_ctx", c_int), ("freq_penalty", c_float), ("freq_ctx", c_int),
@@ -118,6 +122,8 @@ SIGNATURES = {
                               + [c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vlm_attn_decode_paged_split": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 5
                                     + [c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "vlm_encoder_forward": (c_int, [c_void_p, c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_float, c_int, c_void_p, c_int, c_int,
+                                                                                          c_float, c_int, c_void_p]),
     "vlm_gemm_w4": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "vlm_kv_quantize_tokens": (c_int, [c_void_p] * 6 + [c_size_t, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                                        c_void_p]),

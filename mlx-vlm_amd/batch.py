@@ -592,16 +592,17 @@ class BatchGenerator:
 
 def generate_batch_continuous(model, input_ids_list, pixel_values_list, grids, *, max_tokens=128, stop_ids=(),
                               sampler: Optional[Sampler] = None, batch_size: int = MAX_ROWS, use_graph: bool = True,
-                              extras: Optional[List[Optional[dict]]] = None, logits_processors=None):
+                              extras: Optional[List[Optional[dict]]] = None, logits_processors=None, kv_bits=None):
     """The reference's `_generate_batch` loop (ar.py:3212-3232) over the continuous generator: every request is queued
     at once, the generator keeps up to `batch_size` of them decoding and admits the next ones as rows free up.
     extras: per-request keyword arguments of the model's `get_input_embeddings` besides pixels / grid (phi3_v: image_sizes).
     logits_processors: one `make_logits_processors` spec (or None) per request, or ONE spec for all of them.
+    kv_bits: 8 = every request's cache is a QuantizedKVCache from its first decode step on (BatchGenerator(kv_bits=8)).
     -> (tokens per request without the stop token, BatchStats)"""
     gen = BatchGenerator(model, None, max_tokens=max(max_tokens) if isinstance(max_tokens, (list, tuple)) else max_tokens,
                          stop_tokens=set(stop_ids), sampler=sampler,
                          completion_batch_size=batch_size, prefill_batch_size=batch_size, compute_logprobs=False,
-                         use_graph=use_graph)
+                         use_graph=use_graph, kv_bits=kv_bits)
     kw: List[Dict[str, Any]] = [dict(pixel_values=p, image_grid_thw=g) if p is not None else {}
                                 for p, g in zip(pixel_values_list, grids)]
     for k, e in zip(kw, extras or []):

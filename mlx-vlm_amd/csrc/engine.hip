@@ -737,3 +737,31 @@ extern "C" int vlm_vit_forward(void* handle, const vlm_vit_args* a, void* stream
   TRY(vlm_gemm_bf16(a->mrg, v->g.wm2, v->g.bm2, nullptr, a->out, Nm, c.out_dim, EM, EM, EM, c.out_dim, 0, VLM_EPI_BIAS, stream));
   return 0;
 }
+
+// ------------------------------------------------------------------ generic pre-LN encoder layers (SigLIP / CLIP towers)
+// The layer loop of the other model families' vision towers as ONE native call (reference: the Python loops of
+// mlx_vlm/models/idefics2/vision.py:141-187, llava_bunny/vision.py:139-200, phi3_v/vision.py:117-175 - EncoderLayer:
+// x = x + out_proj(attn(LN1(x))); x = x + fc2(act(fc1(LN2(x))))): n_layers x 7 launches enqueued with no host work in
+// between (the Python loops paid ~10 us of host time per launch: Idefics2's 4-image prefill was host-bound).
+extern "C" int vlm_encoder_forward(const vlm_enc_layer* layers, int n_layers, void* x, void* xn, void* qkv, void* attn,
+                                   void* mlp, int N, int E, int H, int head_dim, int MH, float ln_eps, int act_epilogue,
+                                   const void* cu_seqlens, int nseg, int total_qblocks, float scale, int uniform_segments,
+                                   void* stream) {
+  if (!layers || n_layers < 0 || !x || !xn || !qkv || !attn || !mlp || !cu_seqlens || N <= 0 || E <= 0 || H <= 0 || head_dim <= 0 ||
+      MH <= 0)
+    return 1;
+  if (act_epilogue != VLM_EPI_GELU_FAST && act_epilogue != VLM_EPI_GELU_ERF && act_epilogue != 0) return 1;
+  const int HD = H * head_dim;                       // (padded) attention width: qkv rows are [q | k | v] of HD columns each
+  for (int i = 0; i < n_layers; ++i) {
+    const vlm_enc_layer& w = layers[i];
+    TRY(vlm_layernorm(x, w.ln1_w, w.ln1_b, xn, N, E, ln_eps, stream));
+    TRY(vlm_gemm_bf16(xn, w.wqkv, w.bqkv, nullptr, qkv, N, 3 * HD, E, E, E, 3 * HD, 0, VLM_EPI_BIAS, stream));
+    TRY(vlm_attn_prefill(qkv, off(qkv, (size_t)HD * 2), off(qkv, (size_t)2 * HD * 2), attn, 3 * HD, 3 * HD, 3 * HD, HD, cu_seqlens,
+                         nseg, total_qblocks, H, H, head_dim, scale, uniform_segments ? 2 : 0, stream));
+    TRY(vlm_gemm_bf16(attn, w.wo, w.bo, x, x, N, E, HD, HD, HD, E, E, VLM_EPI_BIAS | VLM_EPI_RESIDUAL, stream));
+    TRY(vlm_layernorm(x, w.ln2_w, w.ln2_b, xn, N, E, ln_eps, stream));
+    TRY(vlm_gemm_bf16(xn, w.w1, w.b1, nullptr, mlp, N, MH, E, E, E, MH, 0, VLM_EPI_BIAS | act_epilogue, stream));
+    TRY(vlm_gemm_bf16(mlp, w.w2, w.b2, x, x, N, E, MH, MH, MH, E, E, VLM_EPI_BIAS | VLM_EPI_RESIDUAL, stream));
+  }
+  return 0;
+}

@@ -42,6 +42,7 @@ class VisionModel:
     def load_weights(self, W: Dict[str, torch.Tensor]):
         """W: names relative to `vision_tower.vision_tower.vision_model.` (patch weight (O, kH, kW, C), as the
         reference's sanitize leaves it)."""
+        self._enc = None            # (the native layer loop's weight table is rebuilt on first use)
         c, dev, bf = self.config, self.device, torch.bfloat16
         E, H, hd, hp = c.hidden_size, c.num_attention_heads, self.head_dim, self.head_pad
 
@@ -104,17 +105,10 @@ class VisionModel:
         cu = _lib.h2d(np.arange(B + 1, dtype=np.int32) * Np, self.device)
         nqb = B * ((Np + 127) // 128)
         scale = float(self.head_dim) ** -0.5
-        xn = torch.empty_like(x)
-        for i in range(c.num_hidden_layers):
-            ops.layernorm(x, w[f"{i}.ln1w"], w[f"{i}.ln1b"], c.layer_norm_eps, out=xn)
-            qkv = ops.gemm(xn, w[f"{i}.wqkv"], bias=w[f"{i}.bqkv"], epilogue=ops.EPI_BIAS)
-            q, k, v = qkv[:, : H * hp], qkv[:, H * hp: 2 * H * hp], qkv[:, 2 * H * hp:]
-            o = ops.attn_prefill(q, k, v, cu, nqb, H, H, hp, scale, causal=False, uniform_segments=True)
-            ops.gemm(o, w[f"{i}.wo"], bias=w[f"{i}.bo"], res=x, out=x, epilogue=ops.EPI_BIAS | ops.EPI_RESIDUAL)
-            ops.layernorm(x, w[f"{i}.ln2w"], w[f"{i}.ln2b"], c.layer_norm_eps, out=xn)
-            h = ops.gemm(xn, w[f"{i}.w1"], bias=w[f"{i}.b1"], epilogue=ops.EPI_BIAS | ops.EPI_GELU_FAST)
-            ops.gemm(h, w[f"{i}.w2"], bias=w[f"{i}.b2"], res=x, out=x, epilogue=ops.EPI_BIAS | ops.EPI_RESIDUAL)
-        return x
+        # the encoder layers as ONE native call (vlm_encoder_forward: 7 launches per layer, no host work in between)
+        if getattr(self, "_enc", None) is None:
+            self._enc = ops.EncoderLayers(w, c.num_hidden_layers)
+        return self._enc.forward_(x, H, hp, c.layer_norm_eps, ops.EPI_GELU_FAST, cu, nqb, scale)
 
     # ------------------------------------------------------------------ checkpoint fix-ups (reference vision.py:243-266)
     def sanitize(self, weights):

@@ -49,6 +49,7 @@ class VisionModel:
         """W: names relative to `model.vision_embed_tokens.` (`img_processor.vision_model.*`, `glb_GN`, `sub_GN`,
         `img_projection.{0,2}.*`); patch weight (O, kH, kW, C) as `sanitize` leaves it.  A quantized `img_projection`
         (`.scales` present) is dequantized once: the projection runs on the bf16 GEMM."""
+        self._enc = None            # (the native layer loop's weight table is rebuilt on first use)
         from .. import quantized as Qz
 
         c, dev, bf = self.config, self.device, torch.bfloat16
@@ -115,15 +116,10 @@ class VisionModel:
         cu = _lib.h2d(np.arange(N + 1, dtype=np.int32) * L, self.device)
         nqb = N * ((L + 127) // 128)
         scale = float(hd) ** -0.5
-        for i in range(self.n_run_layers):
-            ops.layernorm(x, w[f"{i}.ln1w"], w[f"{i}.ln1b"], c.layer_norm_eps, out=xn)
-            qkv = ops.gemm(xn, w[f"{i}.wqkv"], bias=w[f"{i}.bqkv"], epilogue=ops.EPI_BIAS)
-            q, k, v = qkv[:, :E], qkv[:, E: 2 * E], qkv[:, 2 * E:]
-            o = ops.attn_prefill(q, k, v, cu, nqb, H, H, hd, scale, causal=False, uniform_segments=True)
-            ops.gemm(o, w[f"{i}.wo"], bias=w[f"{i}.bo"], res=x, out=x, epilogue=ops.EPI_BIAS | ops.EPI_RESIDUAL)
-            ops.layernorm(x, w[f"{i}.ln2w"], w[f"{i}.ln2b"], c.layer_norm_eps, out=xn)
-            h = ops.gemm(xn, w[f"{i}.w1"], bias=w[f"{i}.b1"], epilogue=ops.EPI_BIAS | ops.EPI_GELU_FAST)
-            ops.gemm(h, w[f"{i}.w2"], bias=w[f"{i}.b2"], res=x, out=x, epilogue=ops.EPI_BIAS | ops.EPI_RESIDUAL)
+        # the encoder layers as ONE native call (vlm_encoder_forward: 7 launches per layer, no host work in between)
+        if getattr(self, "_enc", None) is None:
+            self._enc = ops.EncoderLayers(w, self.n_run_layers)
+        self._enc.forward_(x, H, hd, c.layer_norm_eps, ops.EPI_GELU_FAST, cu, nqb, scale)
         return x.view(N, L, E)[:, 1:]
 
     # ------------------------------------------------------------------ HD transform (vision.py:228-256)

@@ -254,6 +254,41 @@ def attn_decode_paged_split(q, kpool, vpool, block_table, kv_len, kv_len_add, Hq
     return out
 
 
+class EncoderLayers:
+    """The weights of a SigLIP / CLIP encoder stack as the native layer loop takes them (vlm_enc_layer array, built once at
+    load from a tower's `_w` dict: keys "<i>.ln1w", "<i>.ln1b", "<i>.wqkv", "<i>.bqkv", "<i>.wo", "<i>.bo", "<i>.ln2w",
+    "<i>.ln2b", "<i>.w1", "<i>.b1", "<i>.w2", "<i>.b2") + the per-call workspaces, cached by token count."""
+
+    def __init__(self, w: dict, n_layers: int):
+        self.n = n_layers
+        self._keep = [w[f"{i}.{k}"].contiguous() for i in range(n_layers) for k in ("ln1w", "ln1b", "wqkv", "bqkv", "wo", "bo", "ln2w",
+                                                                                    "ln2b", "w1", "b1", "w2", "b2")]
+        for t in self._keep:
+            if not (t.is_cuda and t.dtype == torch.bfloat16):
+                raise ValueError("encoder weights must be bf16 device tensors")
+        self.arr = (_lib.EncLayer * n_layers)(*[_lib.EncLayer(*[t.data_ptr() for t in self._keep[12 * i: 12 * i + 12]])
+                                                for i in range(n_layers)])
+        self._ws = {}
+
+    def forward_(self, x, H, head_dim, ln_eps, act_epilogue, cu_seqlens, total_qblocks, scale, uniform_segments=True):
+        """x [N, E] bf16 (device, contiguous) is the residual stream: overwritten with the output of the last layer"""
+        _dev(x, cu_seqlens)
+        N, E = x.shape
+        MH = self._keep[8].shape[0]                 # fc1 rows
+        key = (N, x.device, torch.cuda.current_stream().cuda_stream)      # (an admission prefill may run on a side stream)
+        ws = self._ws.get(key)
+        if ws is None:
+            if len(self._ws) > 4:
+                self._ws.clear()
+            mk = lambda c: torch.empty(N, c, dtype=torch.bfloat16, device=x.device)   # noqa: E731
+            ws = self._ws[key] = (mk(E), mk(3 * H * head_dim), mk(H * head_dim), mk(MH))
+        check(_lib.lib().vlm_encoder_forward(self.arr, self.n, _p(x), _p(ws[0]), _p(ws[1]), _p(ws[2]), _p(ws[3]), N, E, H, head_dim,
+                                             MH, float(ln_eps), int(act_epilogue), _p(cu_seqlens), cu_seqlens.numel() - 1,
+                                             int(total_qblocks), float(scale), int(bool(uniform_segments)), _stream()),
+              "encoder_forward")
+        return x
+
+
 def gemm_w4(a, wq, sb, bias=None, res=None, epilogue=EPI_NONE, out=None):
     """prefill GEMM over MLX 4-bit weights with the dequantisation fused into the tile staging: wq int32 [N, K/8], sb int32
     [N, K/64] (as gemv_w4)"""
