@@ -576,18 +576,29 @@ __global__ __launch_bounds__(64) void kv_quantize_tokens_kernel(const bf16_t* __
 }
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-__device__ __forceinline__ bf16x8_t q8_frag(const u32x2_t w) {   // 8 u8 -> 8 bf16 (integers 0..255 are exact in bf16)
-  const unsigned x = w[0], y = w[1];
-  const u32x4_t v = {pack_bf2((float)(x & 0xff), (float)((x >> 8) & 0xff)), pack_bf2((float)((x >> 16) & 0xff), (float)(x >> 24)),
-                     pack_bf2((float)(y & 0xff), (float)((y >> 8) & 0xff)), pack_bf2((float)((y >> 16) & 0xff), (float)(y >> 24))};
-  return __builtin_bit_cast(bf16x8_t, v);
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+// 8 u8 -> 8 fp16 values 1024 + n, ONE v_perm_b32 per two elements: byte n under the constant byte 0x64 is the half-precision
+// number 0x64nn = 1024 + n exactly (10 mantissa bits).  The constant 1024 is taken out again in the affine forms below
+// (scale * (q . (1024 + n)) + (bias - 1024 scale) * sum(q)), so no subtraction is spent per element - the u8 -> operand
+// conversion costs 4 VALU instructions per 8 elements instead of 12 (v_cvt_f32_ubyte + v_cvt_pk_bf16_f32).
+__device__ __forceinline__ f16x8_t q8_frag(const u32x2_t w) {
+  const unsigned x = w[0], y = w[1], k = 0x64646464u;
+  const u32x4_t v = {__builtin_amdgcn_perm(k, x, 0x04010400u), __builtin_amdgcn_perm(k, x, 0x04030402u),
+                     __builtin_amdgcn_perm(k, y, 0x04010400u), __builtin_amdgcn_perm(k, y, 0x04030402u)};
+  return __builtin_bit_cast(f16x8_t, v);
+}
+__device__ __forceinline__ unsigned pack_h2(float lo, float hi) {      // two fp32 -> packed fp16x2 (round to nearest even)
+  typedef _Float16 h2_t_ __attribute__((ext_vector_type(2)));
+  const h2_t_ v = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(unsigned, v);
 }
 
 // The page-split decode attention over the 8-bit pools.  Arithmetic = the reference's typed graph as far as a split /
 // flash formulation allows: q * scale is a typed multiply (rounded to bf16); a score is the fp32 sum over the two groups
-// of scale_j * (q . n) + bias_j * sum(q) - the EXACT affine form of quantized_matmul, the integers n entering the MFMA as
-// exact bf16 values - rounded to bf16 as quantized_matmul's output is; softmax in fp32; P . V with p * scale_v rounded to
-// bf16 as the MFMA operand and the bias term sum_k p_k * bias_k carried in fp32.  (The reference rounds the NORMALISED
+// of scale_j * (q . n) + bias_j * sum(q) - the EXACT affine form of quantized_matmul, the integers entering the fp16 MFMA
+// (v_mfma_f32_16x16x32_f16) as exact values 1024 + n and q as the exact fp16 image of its bf16 value - rounded to bf16 as
+// quantized_matmul's output is; softmax in fp32; P . V with p * scale_v as the fp16 MFMA operand and the bias term
+// sum_k p_k * (bias_k - 1024 scale_k) carried in fp32.  (The reference rounds the NORMALISED
 // probabilities to bf16; a split kernel rounds the unnormalised ones: same count of roundings, tolerance in the tests.)
 // The workgroup whose page holds the step's new token (slot len - 1, written to the bf16 pools by the qkv epilogue)
 // quantises it first - QuantizedKVCache.update_and_fetch - and reads it back with the rest of the page (every page load
@@ -603,7 +614,7 @@ __global__ __launch_bounds__(64) void attn_decode_pagesplit_q8_kernel(
   const int len = kv_len[b] + kv_len_add, npages = (len + PAGE - 1) / PAGE;
   const int* trow = IDENT ? nullptr : block_table + (size_t)b * max_pages;
   // Q fragments with the reference's typed q * scale, and the per-group sums of q the bias terms need
-  bf16x8_t qf[4];
+  f16x8_t qf[4];
   float sq[2] = {0.f, 0.f};
   {
     const bf16_t* qr = q + (size_t)b * ldq + (size_t)(g * G + min(head, G - 1)) * HD + 8 * gq;
@@ -614,11 +625,11 @@ __global__ __launch_bounds__(64) void attn_decode_pagesplit_q8_kernel(
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const unsigned w = raw[j];
-        const float a = rbf(bf_lo(w) * scale), c = rbf(bf_hi(w) * scale);
-        sc[j] = pack_bf2(a, c);
+        const float a = rbf(bf_lo(w) * scale), c = rbf(bf_hi(w) * scale);      // the typed q * scale (bf16)
+        sc[j] = pack_h2(a, c);                                                 // exact in fp16 (8 significant bits)
         sq[ds >> 1] += a + c;
       }
-      qf[ds] = __builtin_bit_cast(bf16x8_t, sc);
+      qf[ds] = __builtin_bit_cast(f16x8_t, sc);
     }
     sq[0] = col4_sum(sq[0]);            // over the four 8-wide d chunks a head's lanes hold per 32-step
     sq[1] = col4_sum(sq[1]);
@@ -665,17 +676,19 @@ __global__ __launch_bounds__(64) void attn_decode_pagesplit_q8_kernel(
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-      a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q8_frag(kf[t][0]), qf[0], a0, 0, 0, 0);
-      a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q8_frag(kf[t][1]), qf[1], a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q8_frag(kf[t][2]), qf[2], a1, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q8_frag(kf[t][3]), qf[3], a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(q8_frag(kf[t][0]), qf[0], a0, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(q8_frag(kf[t][1]), qf[1], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(q8_frag(kf[t][2]), qf[2], a1, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(q8_frag(kf[t][3]), qf[3], a1, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const u32x4_t w4 = kq[t][r >> 1];
         const unsigned w0 = (r & 1) ? w4[2] : w4[0], w1 = (r & 1) ? w4[3] : w4[1];     // groups 0 / 1 of key 16 t + 4 gq + r
         const int key = pc * PAGE + 16 * t + 4 * gq + r;
         // quantized_matmul: fp32 sum over the dequantised keys, one rounding to the query dtype
-        const float sv = rbf(bf_lo(w0) * a0[r] + bf_hi(w0) * sq[0] + bf_lo(w1) * a1[r] + bf_hi(w1) * sq[1]);
+        // (a_j = q . (1024 + n): the constant leaves through the bias factor)
+        const float sv = rbf(bf_lo(w0) * a0[r] + (bf_hi(w0) - 1024.f * bf_lo(w0)) * sq[0] +
+                             bf_lo(w1) * a1[r] + (bf_hi(w1) - 1024.f * bf_lo(w1)) * sq[1]);
         sc[t][r] = key < len ? sv * LOG2E : -INFINITY;
         mt = fmaxf(mt, sc[t][r]);
       }
@@ -698,14 +711,14 @@ __global__ __launch_bounds__(64) void attn_decode_pagesplit_q8_kernel(
         const unsigned w0 = (r & 1) ? w4[2] : w4[0], w1 = (r & 1) ? w4[3] : w4[1];
         pp[0][r] = ok ? pr * bf_lo(w0) : 0.f;
         pp[1][r] = ok ? pr * bf_lo(w1) : 0.f;
-        pbias[0] += ok ? pr * bf_hi(w0) : 0.f;
-        pbias[1] += ok ? pr * bf_hi(w1) : 0.f;
+        pbias[0] += ok ? pr * (bf_hi(w0) - 1024.f * bf_lo(w0)) : 0.f;         // the V operands are 1024 + n as well
+        pbias[1] += ok ? pr * (bf_hi(w1) - 1024.f * bf_lo(w1)) : 0.f;
       }
       // k-slot 8 gq + j of step u <- tile 2u (j < 4) / tile 2u + 1 (j >= 4): tile t fills words (t & 1) * 2, + 1 of step t >> 1
 #pragma unroll
       for (int gI = 0; gI < 2; ++gI) {
-        pk[gI][t >> 1][(t & 1) * 2] = pack_bf2(pp[gI][0], pp[gI][1]);
-        pk[gI][t >> 1][(t & 1) * 2 + 1] = pack_bf2(pp[gI][2], pp[gI][3]);
+        pk[gI][t >> 1][(t & 1) * 2] = pack_h2(pp[gI][0], pp[gI][1]);
+        pk[gI][t >> 1][(t & 1) * 2 + 1] = pack_h2(pp[gI][2], pp[gI][3]);
       }
     }
     l_run = l_run * alpha + ls;
@@ -718,7 +731,7 @@ __global__ __launch_bounds__(64) void attn_decode_pagesplit_q8_kernel(
       for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
 #pragma unroll
       for (int u = 0; u < 2; ++u)
-        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q8_frag(vf[dt][u]), __builtin_bit_cast(bf16x8_t, pk[dt >> 2][u]), ot[dt], 0, 0, 0);
+        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q8_frag(vf[dt][u]), __builtin_bit_cast(f16x8_t, pk[dt >> 2][u]), ot[dt], 0, 0, 0);
     }
   }
   // the bias terms: one scalar per (head, group), the same for every d of the group

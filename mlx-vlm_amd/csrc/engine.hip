@@ -467,7 +467,7 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
     if (q8) {
       if (!m->attn_tickets || !m->kv.vpool8 || !m->kv.ksb || !m->kv.vsb) return 1;
       psplit = a->nsplit > 1 ? 32 : 16;
-      while (psplit > 1 && (B * Hkv * psplit > 1024 || B * Hkv * psplit > 65535)) psplit >>= 1;
+      while (psplit > 1 && B * Hkv * psplit > 2048) psplit >>= 1;          // up to 2 one-wave workgroups per SIMD (209 VGPRs)
       if (B * Hkv > 4096) return 1;                                        // (tickets: one word per (row, kv head))
     }
     // ... and for ONE row over bf16 Wo the merge moves into the o_proj prologue: the attention launch ends at its partial

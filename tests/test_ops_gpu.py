@@ -957,7 +957,7 @@ def test_gemm_w4_fused_bit_identical_to_dequant_then_gemm(vops, M, N, K):
     vlm_gemm_bf16): BIT-IDENTICAL - the fused kernel builds the same LDS image of every W tile - for every tile shape
     (128x128, 64x128, 64x64), the split-K form (few tiles x long K: the down projection at prompt length), ragged M, and
     the epilogues of the decoder (bias, residual, SwiGLU on interleaved rows); and against the oracle's
-    nn.QuantizedLinear (fp32 dequantised weights: 2 ulps + 2e-3 rms)."""
+    nn.QuantizedLinear (fp32 dequantised weights)."""
     ow, dw = _q4(N, K, seed=500 + M)
     a, b, r = rnd(M, K, seed=501), rnd(N, seed=502, scale=0.3), rnd(M, N, seed=503)
     wd = vops.dequant_w4(dw.wq, dw.sb)
@@ -969,7 +969,10 @@ def test_gemm_w4_fused_bit_identical_to_dequant_then_gemm(vops, M, N, K):
                        vops.gemm(ad, wd, res=r.cuda(), epilogue=vops.EPI_RESIDUAL))
     if N % 16 == 0:
         assert torch.equal(vops.gemm_w4(ad, dw.wq, dw.sb, epilogue=vops.EPI_SWIGLU), vops.gemm(ad, wd, epilogue=vops.EPI_SWIGLU))
-    ok, rep = bf16_close(vops.gemm_w4(ad, dw.wq, dw.sb), ow.linear(a), ulps=2, atol_rms=2e-3)
+    # against the oracle: the prefill forms multiply by the bf16-ROUNDED dequantised weights (mx.dequantize's output dtype;
+    # the reference's quantized_matmul keeps them in fp32) - each weight off by up to 2^-9 relative, the sum over K of those
+    # independent errors is ~0.2 % of the output rms, a few of 10^5..10^7 outputs reach 5 sigma: 2 ulps + 2 % of the rms
+    ok, rep = bf16_close(vops.gemm_w4(ad, dw.wq, dw.sb), ow.linear(a), ulps=2, atol_rms=2e-2)
     assert ok, rep
 
 
