@@ -58,7 +58,8 @@ class Arena:
 class KVPool:
     """Device pools + page allocator + block table for one language model."""
 
-    IDENTITY_BUDGET = 16 << 30   # bytes of KV the "auto" layout may reserve for the identity mapping
+    IDENTITY_BUDGET = 64 << 30   # bytes of KV the "auto" layout may reserve for the identity mapping (288 GB of HBM per GPU:
+                                 # the benchmark's 40 sequence slots x 32 Ki tokens of a 2B model are 37 GB)
 
     def __init__(self, n_layers: int, n_kv_heads: int, head_dim: int, max_tokens: int = 32768, max_seqs: int = 64,
                  max_pages_per_seq: Optional[int] = None, device="cuda", dtype=torch.bfloat16,
