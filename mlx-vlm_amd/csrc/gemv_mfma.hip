@@ -254,6 +254,70 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
         }
     }
     __syncthreads();
+  } else if constexpr (XS < 0) {
+    // row-trip form (any row count, K <= 64 * 8 * CP): wave w owns batch rows w, w + 4, ..; per trip it loads RPT of its rows
+    // whole (CP chunks per lane and row, all loads of the trip in flight together), takes their RMS statistics from the
+    // registers and writes them normalised to LDS - the loop form above costs one dependent L2 round trip per chunk and
+    // row (56 of them at K = 3584 and 16 rows).  The first unit's weights go out behind the LAST trip's loads.
+    constexpr int CP = XS == -2 ? 3 : 8, RPT = XS == -2 ? 4 : 2;
+    const int nch = kx >> 3, k0 = kb_fix * 128;
+    const int ntrip = (((a.M + 3) >> 2) + RPT - 1) / RPT;
+    u32x4_t nw[PRO == MPRO_RMSNORM ? CP : 1];
+    if (PRO == MPRO_RMSNORM) {
+#pragma unroll
+      for (int j = 0; j < CP; ++j) nw[j] = *reinterpret_cast<const u32x4_t*>(a.norm_w + min(k0 + min(lane + 64 * j, nch - 1) * 8, a.K - 8));
+    }
+    auto trip = [&](int t, auto last) __attribute__((always_inline)) {
+      u32x4_t xr[RPT][CP];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const bf16_t* xrow = a.x + (size_t)min(wave + 4 * (t * RPT + r), a.M - 1) * a.ldx;
+#pragma unroll
+        for (int j = 0; j < CP; ++j) xr[r][j] = *reinterpret_cast<const u32x4_t*>(xrow + min(k0 + min(lane + 64 * j, nch - 1) * 8, a.K - 8));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // behind the small loads (they return first); the 7-chunk register set goes out after the prologue instead: together
+      // with a trip's rows it would cost the second workgroup of a CU
+      if (decltype(last)::value && NCW == 3) load_w(min(u, n_units - 1), wvA);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const int m = wave + 4 * (t * RPT + r);
+        float inv = 1.f;
+        if (PRO == MPRO_RMSNORM) {
+          float ss = 0.f;
+#pragma unroll
+          for (int j = 0; j < CP; ++j) {
+            const bool in = lane + 64 * j < nch;           // chunks past the row count as zeros: ss + 0 * 0 is exact
+            const u32x4_t v = xr[r][j];
+            const unsigned w0 = in ? v[0] : 0u, w1 = in ? v[1] : 0u, w2 = in ? v[2] : 0u, w3 = in ? v[3] : 0u;
+            const float f[8] = {bf_lo(w0), bf_hi(w0), bf_lo(w1), bf_hi(w1), bf_lo(w2), bf_hi(w2), bf_lo(w3), bf_hi(w3)};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ss += f[q] * f[q];
+          }
+          inv = rsqrtf(wave_sum(ss) / (float)a.K + a.eps);
+        }
+#pragma unroll
+        for (int j = 0; j < CP; ++j) {
+          const int c = lane + 64 * j;
+          u32x4_t v = xr[r][j];
+          if (PRO == MPRO_RMSNORM) {
+            const u32x4_t wu = nw[PRO == MPRO_RMSNORM ? j : 0];
+            u32x4_t o;
+            o[0] = pack_bf2(bf_lo(wu[0]) * rbf(bf_lo(v[0]) * inv), bf_hi(wu[0]) * rbf(bf_hi(v[0]) * inv));
+            o[1] = pack_bf2(bf_lo(wu[1]) * rbf(bf_lo(v[1]) * inv), bf_hi(wu[1]) * rbf(bf_hi(v[1]) * inv));
+            o[2] = pack_bf2(bf_lo(wu[2]) * rbf(bf_lo(v[2]) * inv), bf_hi(wu[2]) * rbf(bf_hi(v[2]) * inv));
+            o[3] = pack_bf2(bf_lo(wu[3]) * rbf(bf_lo(v[3]) * inv), bf_hi(wu[3]) * rbf(bf_hi(v[3]) * inv));
+            v = o;
+          }
+          if (m < a.M && c < nch) *reinterpret_cast<u32x4_t*>(smem + (size_t)m * P + (size_t)c * 16) = x_order(v);
+        }
+      }
+    };
+    for (int t = 0; t + 1 < ntrip; ++t) trip(t, std::false_type{});
+    trip(ntrip - 1, std::true_type{});
+    if (NCW != 3) load_w(min(u, n_units - 1), wvA);
+    __syncthreads();
   } else {
     stage_x(kb_fix);
     load_w(min(u, n_units - 1), wvA);
@@ -460,13 +524,21 @@ int mfma_launch1(const MfmaArgs& a, size_t lds, int n_units, hipStream_t st) {
   const int kx = FULLX ? a.K : a.bpk * 128;
   const int cpl = ((kx >> 3) + 63) / 64, slots = ((a.M + 3) / 4) * cpl;
   constexpr int S6 = 6, S14 = 14;
+  // activation prologue: S6 / S14 = everything in registers at once; T3 / T8 = the row-trip form (K <= 1536 / <= 4096 staged
+  // elements per row); 0 = the loop form (longer rows: none of the models here)
+  constexpr int T3 = -2, T8 = -1;
+  static const bool trips = [] { const char* e = getenv("VLM_GEMV_MFMA_TRIPS"); return !e || atoi(e) != 0; }();   // A/B knob
   if (ncw3) {
     if (cpl <= 3 && slots <= 6) return mfma_launch2<PRO, EPI, FULLX, 3, S6, W4>(a, lds, n_units, st);
     if constexpr (PRO == MPRO_NONE)
       if (slots <= 14) return mfma_launch2<PRO, EPI, FULLX, 3, S14, W4>(a, lds, n_units, st);
+    if (trips && cpl <= 3) return mfma_launch2<PRO, EPI, FULLX, 3, T3, W4>(a, lds, n_units, st);
+    if (trips && cpl <= 8) return mfma_launch2<PRO, EPI, FULLX, 3, T8, W4>(a, lds, n_units, st);
     return mfma_launch2<PRO, EPI, FULLX, 3, 0, W4>(a, lds, n_units, st);
   }
   if (cpl <= 3 && slots <= 6) return mfma_launch2<PRO, EPI, FULLX, 7, S6, W4>(a, lds, n_units, st);
+  if (trips && cpl <= 3) return mfma_launch2<PRO, EPI, FULLX, 7, T3, W4>(a, lds, n_units, st);
+  if (trips && cpl <= 8) return mfma_launch2<PRO, EPI, FULLX, 7, T8, W4>(a, lds, n_units, st);
   return mfma_launch2<PRO, EPI, FULLX, 7, 0, W4>(a, lds, n_units, st);
 }
 

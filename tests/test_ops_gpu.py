@@ -8,6 +8,7 @@ MFMA (flash-attention convention), stated below.  Integer outputs (tokens,
 indices, copies) are bit-exact.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -1081,9 +1082,11 @@ def test_gemv_mfma_rows_plain_bias_residual(vops, M, N, K):
     assert ok, rep
 
 
-@pytest.mark.parametrize("M", [6, 8, 16])
-@pytest.mark.parametrize("K,I", [(1536, 2048), (3584, 1024)])
+@pytest.mark.parametrize("M", [6, 8, 13, 16])
+@pytest.mark.parametrize("K,I", [(1536, 2048), (3584, 1024), (896, 256), (3072, 512), (4096, 512)])
 def test_gemv_mfma_rows_norm_prologue_swiglu_and_head(vops, M, K, I):
+    """(every activation prologue of the kernel: everything in registers at <= 8 rows x K <= 1536, the row-trip forms with
+    3 / 8 chunks per lane and 1 / 2 trips above that, rows that end inside a lane's chunk range - K = 896, 3072)"""
     h, nw = rnd(M, K, seed=10), (1 + 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(11))).to(BF)
     wgu = rnd(2 * I, K, seed=12, scale=0.05)
     xn = O.rms_norm(h, nw, 1e-6)
@@ -1133,6 +1136,45 @@ def test_gemv_mfma_rows_qkv_rope_kvwrite(vops, M, paged):
         ok, rep = bf16_close(vp[page, :, within], qkv[m, Hq + Hkv:], ulps=2)
         assert ok, (m, rep)
     assert int((kpool != 0).sum().cpu()) <= M * Hkv * D and int((vpool != 0).sum().cpu()) <= M * Hkv * D
+
+
+_TRIPS_CHILD = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from mlx_vlm_amd import ops as vops
+BF = torch.bfloat16
+def rnd(*shape, seed, scale=1.0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).to(BF)
+out = {}
+for M in (9, 16):
+    for K, I in ((1536, 1024), (3584, 512), (896, 256)):
+        h = rnd(M, K, seed=M + K).cuda()
+        nw = (1 + 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(5))).to(BF).cuda()
+        w = rnd(2 * I, K, seed=K, scale=0.05).cuda()
+        out[f"swiglu_{M}_{K}"] = vops.gemv_ws(h, w, norm_w=nw, eps=1e-6, epilogue=vops.EPI_SWIGLU).cpu()
+        out[f"plain_{M}_{K}"] = vops.gemv_ws(h, w).cpu()
+torch.save(out, sys.argv[2])
+"""
+
+
+def test_gemv_mfma_row_trip_prologue_is_bit_identical_to_the_loop_form(vops, tmp_path):
+    """The activation prologue only changes HOW the rows reach LDS (all loads of a trip in flight vs one dependent round
+    trip per chunk): same sum-of-squares order, same typed normalisation -> the outputs are the same bits.  The loop form
+    is selected by an environment knob read once per process, so it runs in a child process."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for knob in ("0", "1"):
+        path = str(tmp_path / f"trips{knob}.pt")
+        env = dict(os.environ, VLM_GEMV_MFMA_TRIPS=knob)
+        r = subprocess.run([sys.executable, "-c", _TRIPS_CHILD, root, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[knob] = torch.load(path)
+    assert res["0"].keys() == res["1"].keys() and len(res["0"]) == 12
+    for k in res["0"]:
+        assert torch.equal(res["0"][k], res["1"][k]), k
 
 
 # ------------------------------------------------------------------ batched decode rows over 4-bit weights (gemv_mfma.hip, W4 form)
