@@ -91,6 +91,7 @@ class _Admission:
     tic: float
     removed: set = field(default_factory=set)
     joined: int = 0                # requests of `batch` already given a row (a join takes as many as there are free rows)
+    done_t: Optional[float] = None # host clock when the prefill's event was first seen fired (it may WAIT for a row after that)
     pen: Any = None                # device (hist, hist_len, params, bias_idx, bias_val) of the admitted requests, or None
 
     def waiting(self) -> int:
@@ -204,6 +205,11 @@ class BatchGenerator:
         self._gen_tokens_counter = 0
         self._gen_time_counter = 0.0
         self._steps_counter = 0
+        # decode time = wall time with a step in flight: [launch, results back] of every step PLUS the host's share of the loop up
+        # to the next launch (the steps are pipelined one ahead, so that share is hidden behind the GPU but it is decode time),
+        # minus what a round spent blocked on a prefill
+        self._t_results: Optional[float] = None
+        self._blocked = 0.0
 
     # ------------------------------------------------------------------ engine hooks
     # Everything that touches the device sits behind these five methods; the scheduler (queue, admission, joins,
@@ -494,10 +500,16 @@ class BatchGenerator:
             if not p.event.query():
                 if self._side is not None and (self._rows or out):
                     break                             # keep decoding; it joins at a later round
+                t_w = time.perf_counter()
                 p.event.synchronize()                 # synchronous mode, or nothing to decode meanwhile
+                self._blocked += time.perf_counter() - t_w
+            if p.done_t is None:
+                p.done_t = time.perf_counter()
             if self._cuda:
                 torch.cuda.current_stream().wait_event(p.event)
-            dt = time.perf_counter() - p.tic          # wall time to the first token, as the reference reports it
+            # wall time to the first token, as the reference reports it - up to the moment the prefill was seen complete: an
+            # admission prefilled AHEAD under the decode steps then waits for rows, which is not prompt time
+            dt = p.done_t - p.tic
             if p.joined == 0:
                 self._prompt_tokens_counter += int(sum(p.lens))
                 self._prompt_time_counter += dt
@@ -537,7 +549,8 @@ class BatchGenerator:
             slot, ev, uids, t_launch = self._inflight
             self._inflight = None
             ev.synchronize()
-            self._gen_time_counter += time.perf_counter() - t_launch
+            self._t_results = time.perf_counter()
+            self._gen_time_counter += self._t_results - t_launch
             toks, lps = self._pin_tok[slot].numpy(), self._pin_lp[slot].numpy()
             live = {row.uid: r for r, row in enumerate(self._rows)}
             gone = []
@@ -555,11 +568,17 @@ class BatchGenerator:
             self._gen_tokens_counter += len(responses)
             if gone:
                 self._drop_rows(gone)
+        now = time.perf_counter()
+        for p in self._pending:                      # (polled once per round: the granularity of prompt_time is one decode step)
+            if p.done_t is None and p.event.query():
+                p.done_t = now
         if self._side is None:
             self._admit_begin()                      # synchronous mode: prefill, join, then decode (the reference's order)
+            self._blocked += time.perf_counter() - now
         prompt_responses = self._admit_join()
         if self._rows:
             self._launch_step()
+        self._t_results, self._blocked = None, 0.0
         if self._side is not None:
             self._admit_begin()                      # under the step just enqueued
         return prompt_responses, responses
@@ -577,7 +596,10 @@ class BatchGenerator:
             self._pin_lp[slot, :n].copy_(self._lp[:n], non_blocking=True)
         ev = self._event()
         ev.record()
-        self._inflight = (slot, ev, [row.uid for row in self._rows], time.perf_counter())
+        t_launch = time.perf_counter()
+        if self._t_results is not None:              # the loop went straight from the last step's results to this launch
+            self._gen_time_counter += max(0.0, t_launch - self._t_results - self._blocked)
+        self._inflight = (slot, ev, [row.uid for row in self._rows], t_launch)
         longest = max(row.prompt_tokens + row.max_tokens for row in self._rows) + 2
         # (16-row steps keep the single-pass attention: the split merge lives in the o_proj prologue of the <= 8-row GEMV)
         st.nsplit = 1 if longest <= 2048 or width > 8 else max(2, min(32, (longest + 16 * PAGE - 1) // (16 * PAGE)))
@@ -622,8 +644,7 @@ def generate_batch_continuous(model, input_ids_list, pixel_values_list, grids, *
             if r.finish_reason != "stop":
                 results[r.uid].append(r.token)
     total = time.perf_counter() - tic
-    stats = gen.stats()
+    stats = gen.stats()               # generation_time: wall time with decode steps in flight (prefills admitted under them included)
     gen.close()
-    stats.generation_time = max(total - stats.prompt_time, 1e-9)
-    stats.generation_tps = stats.generation_tokens / stats.generation_time
+    stats.wall_time = total
     return [results[u] for u in uids], stats

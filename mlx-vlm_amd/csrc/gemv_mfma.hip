@@ -27,6 +27,7 @@
 // Epilogues as gemv_bf16.hip, one thread per (n, m) of the tile: bias, residual, SwiGLU on interleaved gate / up rows, and
 // M-RoPE + paged KV write, for which a tile's 16 rows are (d0 .. d0 + 7, d0 + D/2 .. d0 + D/2 + 7) of one q / k head so
 // that both elements of a rotation pair sit in the tile.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -511,7 +512,8 @@ int mfma_launch2(const MfmaArgs& a, size_t lds, int n_units, hipStream_t st) {
   }
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess || nb < 1) nb = 1;
-  int grid = min(n_units, 256 * min(nb, 2));       // few resident workgroups: the activation staging is paid per workgroup
+  static const int wgs_per_cu = [] { const char* e = getenv("VLM_GEMV_MFMA_WGS_PER_CU"); return e ? max(1, min(4, atoi(e))) : 2; }();
+  int grid = min(n_units, 256 * min(nb, wgs_per_cu));   // few resident workgroups: the activation staging is paid per workgroup
   grid -= grid % a.KS;                             // a workgroup keeps its K segment (unit id = tile * KS + ks)
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
   hipError_t e = hipGetLastError();
@@ -607,9 +609,14 @@ static int mfma_try(const void* x, const void* W, const void* Wsb, const void* b
   // (partial store -> vmcnt(0), which also drains the next unit's weight loads -> ticket -> partial loads), ~5-10 us per
   // unit with one workgroup per CU.  Measured at Phi-3.5 dims (K = 3072, 1024 / 768 row tiles, 16 rows): gate/up and qkv
   // 48 us at KS = 2 (profiles/r02_phi35v_kernel_stats.txt)
+  // Policy knobs (A/B runs, scripts/mfma_shapes.py): chunks per unit the segment forms aim at, whether the norm-prologue forms
+  // split K at all, the LDS a form without a norm may take (KB; above 80 a CU holds one workgroup)
+  static const int seg_chunks = [] { const char* e = getenv("VLM_GEMV_MFMA_SEG_CHUNKS"); return e ? max(4, min(28, atoi(e))) : 12; }();
+  static const int norm_split = [] { const char* e = getenv("VLM_GEMV_MFMA_NORM_SPLIT"); return e ? atoi(e) : 640; }();
+  static const int lds_cap_kb = [] { const char* e = getenv("VLM_GEMV_MFMA_LDS_KB"); return e ? max(48, min(160, atoi(e))) : 100; }();
   if (ws)
-    while (vlm_cdiv(a.nblk, KS) > 12 && KS < 16 && (size_t)a.n_tiles * (KS + 1) <= 4096 &&
-           (!norm_w || a.n_tiles * KS < 640))      // (the segment forms without a norm also split to fit their x segment in LDS)
+    while (vlm_cdiv(a.nblk, KS) > (norm_w ? 12 : seg_chunks) && KS < 16 && (size_t)a.n_tiles * (KS + 1) <= 4096 &&
+           (!norm_w || a.n_tiles * KS < norm_split))      // (the segment forms without a norm also split to fit their x segment in LDS)
       ++KS;
   if (KS > 1 && (!ws || a.n_tiles > 8192 || (size_t)a.n_tiles * KS > 4096)) return -1;
   a.KS = KS;
@@ -620,8 +627,13 @@ static int mfma_try(const void* x, const void* W, const void* Wsb, const void* b
   const int n_units = a.n_tiles * KS;
   const size_t tail = 4 * WREG + 4096 + 256 + 64 + 4 * 7 * 128 + (Wsb ? (size_t)M * (K / 64) * 4 : 0);      // + sbr, xsum (4-bit)
   const size_t lds_full = (size_t)M * ((size_t)K * 2 + 16) + tail, lds_seg = (size_t)M * ((size_t)a.bpk * 256 + 16) + tail;
-  const bool fullx = lds_full <= (norm_w ? 152 : 100) * 1024;      // (one workgroup per CU above 80 KB: only when the norm needs it)
-  if (!fullx && (norm_w || lds_seg > 100 * 1024)) return -1;
+  const bool fullx = lds_full <= (size_t)(norm_w ? 160 : lds_cap_kb) * 1024;      // (one workgroup per CU above 80 KB: only when the norm needs it)
+  if (!fullx && (norm_w || lds_seg > (size_t)lds_cap_kb * 1024)) return -1;
+  static const bool debug = [] { const char* e = getenv("VLM_GEMV_MFMA_DEBUG"); return e && atoi(e) != 0; }();
+  if (debug)
+    fprintf(stderr, "[gemv_mfma] M=%d N=%d K=%d %s%s epi=%d: tiles=%d KS=%d bpk=%d units=%d %s lds=%zu KB\n", M, N, K, Wsb ? "w4 " : "",
+            norm_w ? "norm" : "plain", rope ? -1 : epilogue, a.n_tiles, KS, a.bpk, n_units, fullx ? "fullx" : "seg",
+            (fullx ? lds_full : lds_seg) >> 10);
   hipStream_t st = (hipStream_t)stream;
 #define GO(P, E) return fullx ? mfma_launch<P, E, true>(a, lds_full, n_units, st) : mfma_launch<P, E, false>(a, lds_seg, n_units, st)
 #define GOF(P, E) return mfma_launch<P, E, true>(a, lds_full, n_units, st)

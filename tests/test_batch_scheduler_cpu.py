@@ -248,3 +248,39 @@ def test_per_request_logits_processors_travel_with_their_rows():
     with pytest.raises(ValueError):
         gen.insert([np.arange(3)], logits_processors=[None, None])
     gen.close()
+
+
+def test_stats_split_wall_time_into_prompt_and_decode_time():
+    """prompt_time ends when a prefill is seen complete - not when its requests get a row (an admission prefilled AHEAD
+    waits for rows while the others decode) - and generation_time is the wall time with decode steps in flight: the two
+    add up to the wall time of the job, to within a step (reference stats: ar.py:863-884, 2705-2887)."""
+    import time
+
+    T_PRE, T_STEP, N_TOK = 0.040, 0.004, 12
+
+    class Slow(MockEngineGenerator):
+        def _prefill_requests(self, batch):
+            time.sleep(T_PRE)
+            return super()._prefill_requests(batch)
+
+        def _decode_rows(self, width):
+            time.sleep(T_STEP)
+            return super()._decode_rows(width)
+
+    pool = make_pool()
+    gen = Slow(pool, completion_batch_size=2, prefill_batch_size=2, prefill_ahead=2)
+    prompts = [np.arange(1, 9) + i for i in range(4)]
+    gen.insert(prompts, N_TOK)
+    t0 = time.perf_counter()
+    got, reasons, _, rounds = drain(gen)
+    wall = time.perf_counter() - t0
+    st = gen.stats()
+    assert len(gen.prefill_sizes) == 2 and st.generation_tokens == 4 * N_TOK
+    # two prefills of T_PRE; the second one waited ~ N_TOK steps for its rows, which must not count
+    assert 2 * T_PRE * 0.9 < st.prompt_time < 2 * T_PRE + 4 * T_STEP + 0.02, st.prompt_time
+    steps = st.decode_steps
+    assert steps >= 2 * (N_TOK - 1)
+    assert steps * T_STEP * 0.9 < st.generation_time < steps * T_STEP + 0.05, (st.generation_time, steps)
+    assert st.prompt_time + st.generation_time < wall + 2 * T_STEP + 0.005
+    assert st.prompt_time + st.generation_time > 0.8 * wall
+    gen.close()
