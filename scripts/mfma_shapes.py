@@ -1,7 +1,7 @@
 """Per-projection time of the batched decode step's GEMVs (csrc/gemv_mfma.hip) at the dims of the benchmark models:
 every call site of a decoder layer (qkv + RoPE + KV write, o_proj + residual, RMSNorm + gate/up + SwiGLU, down + residual)
 at 8 / 16 rows, each timed over rotating weight copies that together exceed the Infinity Cache (HIP events around N
-launches on torch's stream).  Policy knobs of the kernel are environment variables read once per process, so an A/B is
+launches captured in one graph - as in the engine's step, no host cost between the launches).  Policy knobs of the kernel are environment variables read once per process, so an A/B is
 two runs of this script.
     python scripts/mfma_shapes.py [2b|7b|mistral|phi-w4 ...] [--rows 16,8] [--reps 40]"""
 import argparse
@@ -40,16 +40,25 @@ def w4(N, K):
 
 
 def timed(fn, n_copies, reps):
+    """us per launch: `reps` launches captured in ONE graph (no host launch cost between them), best of 3 replays"""
     for i in range(n_copies):
         fn(i)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for r in range(reps):
-        fn(r % n_copies)
-    e1.record()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for r in range(reps):
+            fn(r % n_copies)
+    g.replay()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / reps
+    best = 1e30
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+    return best
 
 
 def run(name, M, reps):
