@@ -657,8 +657,10 @@ def workload_7b_b32(args, rank, ws, dev):
            "load": load, "distributed": _dist_info(ws, load),
            }
     if rank == 0:
-        # decode steps of the job (graph replays summed over the ranks; decode time = the slowest rank's): a step streams the
-        # weights once and, per row it serves, that row's K / V (57,344 B per cached token at 7B) at the mean context
+        # decode steps of the job (graph replays summed over the ranks; decode time = the slowest rank's wall time with decode
+        # steps in flight, BatchGenerator.stats().generation_time - the prefills admitted UNDER those steps are inside it):
+        # a step streams the weights once and, per row it serves, that row's K / V (57,344 B per cached token at 7B) at
+        # the mean context
         kv_tok = 2 * t.num_hidden_layers * t.num_key_value_heads * 128 * 2
         ctx_mid = int(reqs[0]["input_ids"].size) + max_tokens // 2
         job_bytes = dec_steps * 2 * lm_params + dec_tok * ctx_mid * kv_tok
@@ -797,7 +799,7 @@ def workload_phi35v_w4_b16(args, rank, ws, dev):
            "e2e_tokens_per_s": ws * gen_tok / wall, "prompt_tps": ws * pre_tok / max(pre_t, 1e-9),
            "images_per_s_prefill": ws * n_req * args.steps / max(pre_t, 1e-9), "clip_tflop_per_image": clip_tflop,
            "load": load, "distributed": _dist_info(ws, load),
-           "roofline": {"bound": "hbm", "kernel": "whole 16-row decode step (4-bit weights once + 16 rows of bf16 K / V)",
+           "roofline": {"bound": "hbm", "kernel": "whole 16-row decode step (4-bit weights once + 16 rows of " + ("8-bit (group 64) K / V)" if kv_bits else "bf16 K / V)"),
                         "achieved": step_bytes * steps_per_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": step_bytes * steps_per_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes_per_step": step_bytes, "weight_bytes_per_step": lm_params * 9 // 16,
