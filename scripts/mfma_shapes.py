@@ -107,8 +107,43 @@ def run(name, M, reps):
     print(f"  layer (projections)    {tot_b / 1e6:8.1f} MB {tot_us:8.2f} us {tot_b / tot_us / 1e6:6.2f} TB/s", flush=True)
 
 
+def run_gemm(name, M, reps):
+    """the same projections through the prefill GEMMs (vlm_gemm_bf16): what a decode step of MORE than 16 rows would use"""
+    d = DIMS[name]
+    H, I, Hq, Hkv, D = d["H"], d["I"], d["Hq"], d["Hkv"], d["D"]
+    if d["w4"]:
+        return
+    x, xi, xo = bf(M, H, scale=1.0), bf(M, I, scale=1.0), bf(M, Hq * D, scale=1.0)
+    res = bf(M, H, scale=1.0)
+    Nqkv = (Hq + 2 * Hkv) * D
+    bq = bf(Nqkv, scale=0.3)
+    out = []
+
+    def add(tag, N, K, fn):
+        nbytes = N * K * 2
+        n = copies(nbytes)
+        ws = [bf(N, K) for _ in range(n)]
+        us = timed(lambda i: fn(ws[i]), n, reps)
+        out.append((tag, N, K, nbytes, us))
+        del ws
+        torch.cuda.empty_cache()
+
+    oq = torch.empty(M, Nqkv, dtype=BF, device="cuda")
+    oa = torch.empty(M, I, dtype=BF, device="cuda")
+    add("qkv +bias (gemm)", Nqkv, H, lambda w: vops.gemm(x, w, bias=bq, out=oq, epilogue=vops.EPI_BIAS))
+    add("o_proj +res (gemm)", H, Hq * D, lambda w: vops.gemm(xo, w, res=res, out=res, epilogue=vops.EPI_RESIDUAL))
+    add("gate/up swiglu (gemm)", 2 * I, H, lambda w: vops.gemm(x, w, out=oa, epilogue=vops.EPI_SWIGLU))
+    add("down +res (gemm)", H, I, lambda w: vops.gemm(xi, w, res=res, out=res, epilogue=vops.EPI_RESIDUAL))
+    tot_us, tot_b = sum(o[4] for o in out), sum(o[3] for o in out)
+    print(f"== {name} rows={M} through the prefill GEMMs")
+    for tag, N, K, nbytes, us in out:
+        print(f"  {tag:22s} N={N:6d} K={K:6d} {nbytes / 1e6:8.1f} MB {us:8.2f} us {nbytes / us / 1e6:6.2f} TB/s")
+    print(f"  layer (projections)    {tot_b / 1e6:8.1f} MB {tot_us:8.2f} us {tot_b / tot_us / 1e6:6.2f} TB/s", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gemm-rows", default="")
     ap.add_argument("models", nargs="*", default=["2b", "7b"])
     ap.add_argument("--rows", default="16")
     ap.add_argument("--reps", type=int, default=40)
@@ -116,8 +151,10 @@ def main():
     knobs = {k: v for k, v in os.environ.items() if k.startswith("VLM_GEMV_MFMA")}
     print("knobs:", knobs or "defaults")
     for name in a.models:
-        for M in [int(r) for r in a.rows.split(",")]:
+        for M in [int(r) for r in a.rows.split(",") if r]:
             run(name, M, a.reps)
+        for M in [int(r) for r in a.gemm_rows.split(",") if r]:
+            run_gemm(name, M, a.reps)
 
 
 if __name__ == "__main__":
