@@ -20,7 +20,10 @@
 //   unit   = (16-row tile, K segment ks of KS); the 4 waves of a workgroup interleave the unit's 128-wide K chunks (<= 7
 //            each, up to 28 loads of a lane in flight), their partial tiles meet in LDS
 //   KS > 1 (few row tiles x long K: o_proj, down): fp32 partial tiles go to a workspace, the LAST workgroup of a tile
-//            to arrive (agent-scope ticket) sums them in the fixed order ks = 0..KS-1 - deterministic - and runs the epilogue
+//            to arrive (agent-scope ticket) sums them in the fixed order ks = 0..KS-1 - deterministic - and runs the epilogue;
+//            the tickets and merges of a workgroup come after its LAST unit (round 3: the first version ended EVERY unit with
+//            partial store -> vmcnt(0) -> ticket -> partial loads), and which projections split at all follows the measured
+//            policy in mfma_try (profiles/r03_mfma_shapes.txt)
 //   the activations (normalised when the RMSNorm prologue is on) are staged ONCE per workgroup, which then walks units
 //            blockIdx.x, + gridDim.x, ...: all of K (FULLX), or - long K, no norm: the down projection - only the K
 //            segment ks = blockIdx.x % KS that all its units share (the grid is a multiple of KS)
@@ -65,10 +68,12 @@ __device__ __forceinline__ int tile_row(const MfmaArgs& a, int tile, int r) {
   return tile * 16 + r;
 }
 
-// NCW: 128-wide K chunks per wave and unit (3: two register sets, the next unit's weights are in flight while this one
-// is multiplied; 7: one set).  XS > 0: the activations fit the prologue's registers (rows_per_wave * chunks_per_lane <= XS):
-// x and the norm weight are loaded ONCE, ahead of the weight stream (vector loads return in issue order), and the RMS
-// statistics come from the registers; otherwise the activations are staged before any weight load is issued.
+// NCW: 128-wide K chunks per wave and unit (3: three register sets, the next two units' weights are in flight while this
+// one is multiplied; 7: one set).  XS > 0: the activations fit the prologue's registers (rows_per_wave * chunks_per_lane <=
+// XS): x and the norm weight are loaded ONCE, ahead of the weight stream (vector loads return in issue order), and the RMS
+// statistics come from the registers; XS < 0 (round 3): the row-trip form of the same for any row count - a wave loads 2 or
+// 4 of its rows whole per trip (K <= 4096 / <= 1536 staged elements per row); XS == 0: the loop form (longer rows only: one
+// dependent L2 round trip per chunk and row).
 //
 // W4 (MLX affine 4-bit weights, group 64 - nn.QuantizedLinear at a batched decode step, reference utils.py:918-967): a
 // chunk is 64 bytes of nibbles per row, ONE 16-byte load per lane + the row's (scale | bias) pair.  A q word IS 8
