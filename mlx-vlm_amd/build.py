@@ -9,6 +9,7 @@ with the repo snapshot (it is git-ignored, not gpurun-ignored).
 from __future__ import annotations
 
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -40,7 +41,9 @@ def _deps_mtime():
 
 def _compile(src: str, force: bool) -> str:
     obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
-    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), _deps_mtime()):
+    inc = [os.path.join(CSRC, m) for m in re.findall(r'#include "([^"/]+\.hip)"', open(src).read())]      # a TU that includes another
+    newest = max([os.path.getmtime(src), _deps_mtime()] + [os.path.getmtime(i) for i in inc if os.path.exists(i)])
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj
     cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -572,17 +572,24 @@ int mfma_launch1(const MfmaArgs& a, size_t lds, int n_units, hipStream_t st) {
 
 template <int PRO, int EPI, bool FULLX>
 int mfma_launch(const MfmaArgs& a, size_t lds, int n_units, hipStream_t st) {
-  return a.Wsb ? mfma_launch1<PRO, EPI, FULLX, true>(a, lds, n_units, st) : mfma_launch1<PRO, EPI, FULLX, false>(a, lds, n_units, st);
+  // the bf16 and the 4-bit instantiations are two translation units (gemv_mfma_w4.hip includes this file with
+  // VLM_MFMA_W4_TU defined): ~120 kernels each, compiled in parallel
+#ifdef VLM_MFMA_W4_TU
+  return a.Wsb ? mfma_launch1<PRO, EPI, FULLX, true>(a, lds, n_units, st) : -1;
+#else
+  return a.Wsb ? -1 : mfma_launch1<PRO, EPI, FULLX, false>(a, lds, n_units, st);
+#endif
 }
 
 }  // namespace
-
-VLM_INTERNAL size_t vlm_gemv_mfma_ws_bytes(void) { return (size_t)4096 * 256 * 4 + 8192 * 4; }   // 4096 units of partials + tickets
 
 // -> VLM_OK, an error, or -1: shape not handled here (the caller takes the v_dot2c kernels)
 static int mfma_try(const void* x, const void* W, const void* Wsb, const void* bias, const void* res, const void* norm_w, void* y,
                     int M, int N, int K, int ldx, int ldw, int ldy, int ldres, float eps, int epilogue, const VlmRopeKv* rk,
                     void* ws, void* stream);
+
+#ifndef VLM_MFMA_W4_TU
+VLM_INTERNAL size_t vlm_gemv_mfma_ws_bytes(void) { return (size_t)4096 * 256 * 4 + 8192 * 4; }   // 4096 units of partials + tickets
 
 VLM_INTERNAL int vlm_gemv_mfma_try(const void* x, const void* W, const void* bias, const void* res, const void* norm_w, void* y, int M, int N,
                                    int K, int ldx, int ldw, int ldy, int ldres, float eps, int epilogue, const VlmRopeKv* rk,
@@ -590,6 +597,7 @@ VLM_INTERNAL int vlm_gemv_mfma_try(const void* x, const void* W, const void* bia
   return mfma_try(x, W, nullptr, bias, res, norm_w, y, M, N, K, ldx, ldw, ldy, ldres, eps, epilogue, rk, ws, stream);
 }
 
+#else
 // the same over MLX affine 4-bit weights (Wq words [N][K/8], Wsb (scale | bias << 16) [N][K/64]): all supported row counts
 // (the v_dot2c 4-bit GEMVs stop at 8 rows)
 VLM_INTERNAL int vlm_gemv_mfma_try_w4(const void* x, const void* Wq, const void* Wsb, const void* bias, const void* res,
@@ -598,6 +606,8 @@ VLM_INTERNAL int vlm_gemv_mfma_try_w4(const void* x, const void* Wq, const void*
   if (!Wsb) return -1;
   return mfma_try(x, Wq, Wsb, bias, res, norm_w, y, M, N, K, ldx, 8, ldy, ldres, eps, epilogue, rk, ws, stream);
 }
+
+#endif
 
 static int mfma_try(const void* x, const void* W, const void* Wsb, const void* bias, const void* res, const void* norm_w, void* y,
                     int M, int N, int K, int ldx, int ldw, int ldy, int ldres, float eps, int epilogue, const VlmRopeKv* rk,
