@@ -256,7 +256,7 @@ def test_stats_split_wall_time_into_prompt_and_decode_time():
     add up to the wall time of the job, to within a step (reference stats: ar.py:863-884, 2705-2887)."""
     import time
 
-    T_PRE, T_STEP, N_TOK = 0.040, 0.004, 12
+    T_PRE, T_STEP, N_TOK = 0.040, 0.004, 40      # the admission prefilled ahead waits ~ N_TOK steps = 160 ms for its rows
 
     class Slow(MockEngineGenerator):
         def _prefill_requests(self, batch):
@@ -277,10 +277,10 @@ def test_stats_split_wall_time_into_prompt_and_decode_time():
     st = gen.stats()
     assert len(gen.prefill_sizes) == 2 and st.generation_tokens == 4 * N_TOK
     # two prefills of T_PRE; the second one waited ~ N_TOK steps for its rows, which must not count
-    assert 2 * T_PRE * 0.9 < st.prompt_time < 2 * T_PRE + 4 * T_STEP + 0.02, st.prompt_time
+    assert 2 * T_PRE * 0.9 < st.prompt_time < 3 * T_PRE + 0.05, st.prompt_time      # (the bug: 2 T_PRE + 160 ms; bounds loose for a busy host)
     steps = st.decode_steps
     assert steps >= 2 * (N_TOK - 1)
-    assert steps * T_STEP * 0.9 < st.generation_time < steps * T_STEP + 0.05, (st.generation_time, steps)
-    assert st.prompt_time + st.generation_time < wall + 2 * T_STEP + 0.005
+    assert steps * T_STEP * 0.9 < st.generation_time < 2 * steps * T_STEP + 0.1, (st.generation_time, steps)
+    assert st.prompt_time + st.generation_time < wall + 2 * T_STEP + 0.01
     assert st.prompt_time + st.generation_time > 0.8 * wall
     gen.close()
