@@ -621,14 +621,17 @@ def workload_7b_b32(args, rank, ws, dev):
     from mlx_vlm_amd import parallel, synthetic
     from mlx_vlm_amd.models import qwen2_vl
 
-    cfg, model, load = _load_synthetic(synthetic.QWEN2_VL_7B, qwen2_vl, rank, dev, kv_pool_tokens=32768, max_seqs=40)
+    # up to 32 decode rows per GPU: with one rank the 32 requests decode in ONE wave of wide steps (prefill GEMMs, engine.hip
+    # decode_impl); dealt over more ranks a rank's 16 / 8 / 4 requests run the 16-row (or narrower) GEMV steps
+    rows = int(os.environ.get("VLM_BENCH_7B_ROWS", "32"))
+    cfg, model, load = _load_synthetic(synthetic.QWEN2_VL_7B, qwen2_vl, rank, dev, kv_pool_tokens=32768, max_seqs=2 * rows + 8)
     n_req, max_tokens = 32, args.max_tokens or 64
     reqs = []
     for i in range(n_req):
         ids, pix, thw = build_request(cfg, 336, 128, seed=i)
         reqs.append({"input_ids": ids.reshape(-1), "pixel_values": pix, "image_grid_thw": thw, "max_tokens": max_tokens})
     for _ in range(args.warmup):
-        parallel.dp_batch_generate(model, None, requests=reqs[: 2 * ws], max_tokens=8)
+        parallel.dp_batch_generate(model, None, requests=reqs[: 2 * ws], max_tokens=8, batch_size=rows)
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -636,7 +639,7 @@ def workload_7b_b32(args, rank, ws, dev):
     dec_tok = dec_steps = 0
     dec_t = 0.0
     for _ in range(args.steps):
-        res = parallel.dp_batch_generate(model, None, requests=reqs, max_tokens=max_tokens)
+        res = parallel.dp_batch_generate(model, None, requests=reqs, max_tokens=max_tokens, batch_size=rows)
         if rank == 0:
             total += res["generation_tokens"]
             dec_tok, dec_steps, dec_t = dec_tok + res["decode_tokens"], dec_steps + res["decode_steps"], dec_t + res["decode_time_s"]
@@ -651,10 +654,11 @@ def workload_7b_b32(args, rank, ws, dev):
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "Qwen2-VL-7B-Instruct dims (random-init bf16), 32 requests (one 336x336 image -> 144 image tokens + "
                                   f"128 text tokens each, greedy {max_tokens} new tokens, EOS disabled) dealt data-parallel over the "
-                                  "ranks, continuous batching with up to 16 decode rows per GPU (projections of 8 / 16-row steps on the matrix cores)",
+                                  f"ranks, continuous batching with up to {rows} decode rows per GPU (8 / 16-row steps: skinny-M MFMA decode GEMM; "
+                                  "32-row steps: the prefill GEMMs + paged decode attention)",
                       "requests": n_req, "max_tokens": max_tokens, "parallelism": f"dp{ws}",
                       "per_rank_requests": res["per_rank_requests"] if rank == 0 else None},
-           "load": load, "distributed": _dist_info(ws, load),
+           "load": load, "distributed": _dist_info(ws, load), "decode_rows_per_gpu": rows,
            }
     if rank == 0:
         # decode steps of the job (graph replays summed over the ranks; decode time = the slowest rank's wall time with decode

@@ -40,8 +40,10 @@ from .models.qwen2_vl.language import DecodeState
 from .sample_utils import Sampler, make_sampler
 
 _PROCS_KEY = "__logits_processors__"     # a request's LogitsProcessors spec inside its keyword arguments
-MAX_ROWS = 16         # widest decode step: one N tile of the skinny-M MFMA GEMM (csrc/gemv_mfma.hip), bf16 or 4-bit weights
-WIDTHS = (1, 2, 4, 8, 16)
+MAX_ROWS = 16         # default widest decode step: one N tile of the skinny-M MFMA GEMM (csrc/gemv_mfma.hip), bf16 or 4-bit weights
+WIDE_ROWS = 64        # on request (completion_batch_size > 16): WIDE steps of 32 / 64 rows on the prefill GEMMs (engine.hip decode_impl:
+                      # 192.6 us per Qwen2-VL-7B layer at 32 rows, 210 at 64, against 120 per 16-row step - profiles/r03_mfma_shapes.txt)
+WIDTHS = (1, 2, 4, 8, 16, 32, 64)
 
 
 class _NullEvent:
@@ -161,9 +163,11 @@ class BatchGenerator:
         self.async_prefill = async_prefill
         self.prefill_ahead = max(0, int(prefill_ahead)) if async_prefill else 0
         max_rows = MAX_ROWS
+        if int(completion_batch_size) > MAX_ROWS:      # wide steps: where the language model's engine has them
+            max_rows = max(MAX_ROWS, min(WIDE_ROWS, int(getattr(self.lm, "MAX_DECODE_ROWS", MAX_ROWS))))
         pool_seqs = getattr(getattr(self.lm, "pool", None), "max_seqs", 64)
-        if pool_seqs < 2 * MAX_ROWS + 2:      # rows + admissions prefilled ahead + the scratch page each hold a sequence slot
-            max_rows = min(max_rows, 8)
+        while max_rows > 8 and pool_seqs < 2 * max_rows + 2:      # rows + admissions prefilled ahead + the scratch page each hold a sequence slot
+            max_rows //= 2
         self.completion_batch_size = max(1, min(int(completion_batch_size), max_rows))
         self.prefill_batch_size = max(1, int(prefill_batch_size))
         self.sampler = sampler or make_sampler()

@@ -403,6 +403,16 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
   if ((a->flags & VLM_DECODE_FUSED_TAIL) && !fused_tail) return 1;   // the flag promises h == embed[tok] at entry
   const Tuning& tn = m->tune;
   const int skip = tn.debug_skip;      // measurement only
+  // WIDE steps (more than 16 rows): beyond one N tile of the skinny-M MFMA GEMM the projections run on the prefill GEMMs,
+  // i.e. a layer is the prefill's launch sequence (vlm_llm_prefill above) with the paged decode attention in place of
+  // the flash attention: RMSNorm -> qkv GEMM + bias -> M-RoPE + KV write at slot ctx[b] -> attention over the pages ->
+  // o_proj GEMM + residual -> RMSNorm -> gate/up GEMM + SwiGLU -> down GEMM + residual.  Measured per 7B layer
+  // (profiles/r03_mfma_shapes.txt D): 192.6 us at 32 rows, 210 at 64 - against 120 per 16-row step.  The normalised rows
+  // borrow the attention output buffer (free before the qkv GEMM and again after o_proj).  Not for two-table RoPE models
+  // (SuScaledRoPE's per-call regime is decided in the fused qkv kernel from the rows' device-resident offsets).
+  const bool wide = B > 16;
+  if (wide && (!m->kv.block_table || c.rope_long_from > 0 || Hq * hd < D || B > 64)) return 1;
+  void* const xn = a->attn;
   const int pf = (fork && fork->side && m->progress && B <= 8) ? tn.prefetch : 0;
   const VlmPfKv pfkv{(const int*)a->ctx, (const int*)m->kv.block_table, m->kv.max_pages, B,
                      (size_t)Hkv * hd * 64 * 2};
@@ -440,7 +450,13 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
     void* kp = off(m->kv.kpool, (size_t)i * m->kv.layer_stride * 2);
     void* vp = off(m->kv.vpool, (size_t)i * m->kv.layer_stride * 2);
     // [RMSNorm + qkv GEMV + bias + M-RoPE at pos[b] + k/v write at slot ctx[b]] in one launch
-    if (!(skip & 1)) {
+    if (wide) {
+      TRY(vlm_rmsnorm_residual(a->h, nullptr, w.ln1_w, xn, nullptr, B, D, c.rms_eps, stream));
+      TRY(lin_gemm(m, xn, w.wqkv, w.wqkv_sb, w.bqkv, nullptr, a->qkv, B, QKV, D, QKV, 0, VLM_EPI_BIAS, stream));
+      TRY(vlm_mrope_kvwrite_scaled(a->qkv, QKV, B, Hq, Hkv, hd, a->pos, a->pos, a->pos, m->g.inv_freq, c.mrope_sec0, c.mrope_sec1,
+                                   nullptr, a->ctx, m->kv.block_table, m->kv.max_pages, kp, vp, qk_scale, stream));
+      n += 3;
+    } else if (!(skip & 1)) {
     if (w.wqkv_sb) {
       TRY(vlm_gemv_w4_qkv_rope_kvwrite_ex(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.wqkv_sb, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos,
                                           a->ctx, m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, m->tune.mfma_gemv,
@@ -526,6 +542,14 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
                                fmode, stream)); ++n;
       continue;
     }
+    if (wide) {
+      TRY(lin_gemm(m, a->attn, w.wo, w.wo_sb, nullptr, a->h, a->h, B, D, Hq * hd, D, D, VLM_EPI_RESIDUAL, stream));
+      TRY(vlm_rmsnorm_residual(a->h, nullptr, w.ln2_w, xn, nullptr, B, D, c.rms_eps, stream));
+      TRY(lin_gemm(m, xn, w.wgu, w.wgu_sb, nullptr, nullptr, a->act, B, 2 * c.inter, D, c.inter, 0, VLM_EPI_SWIGLU, stream));
+      TRY(lin_gemm(m, a->act, w.wdown, w.wdown_sb, nullptr, a->h, a->h, B, D, c.inter, D, D, VLM_EPI_RESIDUAL, stream));
+      n += 4;
+      continue;
+    }
     if (skip & 4) {
     } else if (merge_in_oproj) {
       TRY(vlm_gemv_attn_out_bf16(a->part_o, a->part_ml, psplit, w.wo, a->h, D, D, Hq, hd, stream)); ++n;
@@ -543,9 +567,15 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
   }
   // logits = RMSNorm(h) lm_head^T
   const int VL = (c.vocab + 7) & ~7;      // row pitch of logits / logprobs / scratch (see vlm_llm_prefill)
-  if (!(skip & 32))
+  if (wide) {
+    // (the head matrix has VL rows: the loader pads a vocabulary that is not a multiple of 8 with zero rows, as in the prefill)
+    TRY(vlm_rmsnorm_residual(a->h, nullptr, m->g.final_norm_w, xn, nullptr, B, D, c.rms_eps, stream));
+    TRY(lin_gemm(m, xn, m->g.lm_head, m->g.lm_head_sb, nullptr, nullptr, a->logits, B, VL, D, VL, 0, VLM_EPI_NONE, stream));
+    n += 2;
+  } else if (!(skip & 32)) {
   TRY(lin_gemv(m, a->h, m->g.lm_head, m->g.lm_head_sb, nullptr, nullptr, m->g.final_norm_w, a->logits, B, c.vocab, D, VL, 0,
                c.rms_eps, VLM_EPI_NONE, stream)); ++n;
+  }
   if (sample && a->penalties) {
     // logits processors (ar.py:360-364): the fed token joins the history, then bias / penalties on the step's logits
     TRY(vlm_apply_logit_penalties(a->logits, VL, B, c.vocab, a->tok, a->penalties, stream)); ++n;
@@ -635,10 +665,17 @@ extern "C" int vlm_llm_decode_graph_build(void* handle, const vlm_decode_args* a
       fork.n_items = (int)items.size();
     }
   }
+  // wide steps run split-K GEMMs: the capture stream borrows the launch stream's workspace (the replays are ordered there)
+  const bool wide = a->B > 16;
+  if (wide && vlm_gemm_splitk_share(stream, (void*)cap) != 0) { drop_graph(ng); (void)hipStreamDestroy(cap); if (side) (void)hipStreamDestroy(side); return 1008; }
   e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
-  if (e != hipSuccess) { drop_graph(ng); (void)hipStreamDestroy(cap); if (side) (void)hipStreamDestroy(side); return 1000 + (int)e; }
+  if (e != hipSuccess) {
+    if (wide) vlm_gemm_splitk_unshare((void*)cap);
+    drop_graph(ng); (void)hipStreamDestroy(cap); if (side) (void)hipStreamDestroy(side); return 1000 + (int)e;
+  }
   int rc = decode_impl(m, a, (void*)cap, &ng.launches, true, side ? &fork : nullptr);
   e = hipStreamEndCapture(cap, &ng.graph);
+  if (wide) vlm_gemm_splitk_unshare((void*)cap);
   (void)hipStreamDestroy(cap);
   if (side) (void)hipStreamDestroy(side);
   if (rc != 0) { drop_graph(ng); return rc; }

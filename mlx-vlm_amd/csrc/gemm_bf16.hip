@@ -21,6 +21,7 @@
 #include <algorithm>
 
 #include "common.cuh"
+#include "internal.h"
 #include "../../include/vlm_hip.h"
 
 // gemm256_bf16.hip: the 256x256 phased kernel (-1: shape / epilogue not taken)
@@ -372,6 +373,7 @@ struct SplitkWs {
   hipStream_t st;
   float* p;
   size_t bytes;
+  bool borrowed;      // an alias of another stream's workspace (vlm_gemm_splitk_share): never freed through this entry
 };
 constexpr size_t SPLITK_WS_BYTES = 34u << 20;
 constexpr int MAX_SPLITK_WS = 8;
@@ -389,8 +391,9 @@ float* splitk_workspace(size_t bytes, hipStream_t st) {
   if (!slot) {
     if (g_n_splitk_ws == MAX_SPLITK_WS) return nullptr;      // caller falls back to the single-pass kernels
     slot = &g_splitk_ws[g_n_splitk_ws];
-    *slot = SplitkWs{st, nullptr, 0};
+    *slot = SplitkWs{st, nullptr, 0, false};
   } else {
+    if (slot->borrowed) return nullptr;
     if (hipStreamSynchronize(st) != hipSuccess) return nullptr;   // forced-split hook only: nobody may still read the old one
     (void)hipFree(slot->p);
     slot->p = nullptr;
@@ -402,6 +405,36 @@ float* splitk_workspace(size_t bytes, hipStream_t st) {
   if (slot == &g_splitk_ws[g_n_splitk_ws]) ++g_n_splitk_ws;
   return slot->p;
 }
+
+}  // namespace
+
+// A graph is captured on a stream of its own, where nothing may be allocated - but its replays are ordered on the LAUNCH
+// stream, so the captured split-K GEMMs may use that stream's workspace: `to` borrows the workspace of `from` (allocated
+// here if need be) until vlm_gemm_splitk_unshare(to).  (Without it a captured GEMM falls back to the single-pass kernels:
+// a wide decode step's down projection - 56 tiles x K = 18944 - on 56 workgroups.)
+VLM_INTERNAL int vlm_gemm_splitk_share(void* from, void* to) {
+  float* p = splitk_workspace(1, (hipStream_t)from);
+  if (!p) return VLM_ERR_HIP;
+  size_t bytes = 0;
+  for (int i = 0; i < g_n_splitk_ws; ++i)
+    if (g_splitk_ws[i].st == (hipStream_t)from) bytes = g_splitk_ws[i].bytes;
+  for (int i = 0; i < g_n_splitk_ws; ++i)
+    if (g_splitk_ws[i].st == (hipStream_t)to) return g_splitk_ws[i].borrowed ? VLM_OK : VLM_ERR_ARG;
+  if (g_n_splitk_ws == MAX_SPLITK_WS) return VLM_ERR_ARG;
+  g_splitk_ws[g_n_splitk_ws++] = SplitkWs{(hipStream_t)to, p, bytes, true};
+  return VLM_OK;
+}
+
+VLM_INTERNAL void vlm_gemm_splitk_unshare(void* to) {
+  for (int i = 0; i < g_n_splitk_ws; ++i)
+    if (g_splitk_ws[i].st == (hipStream_t)to && g_splitk_ws[i].borrowed) {
+      g_splitk_ws[i] = g_splitk_ws[g_n_splitk_ws - 1];
+      --g_n_splitk_ws;
+      return;
+    }
+}
+
+namespace {
 
 template <int EPI>
 int launch_splitk(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,

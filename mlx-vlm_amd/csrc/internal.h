@@ -75,6 +75,9 @@ struct VlmRopeKv {
   float qk_scale = 1.f;      // q and k times this, rounded to bf16, before the rotation (SuScaledRoPE, rope_utils.py:174-176)
   int long_from = 0;         // > 0: inv_freq = [2][D/2] (short, long); long for the whole step when any row's slot >= long_from
 };
+// split-K workspace of the bf16 GEMMs for kernels captured on another stream than the one that replays them (gemm_bf16.hip)
+VLM_INTERNAL int vlm_gemm_splitk_share(void* from_stream, void* to_stream);
+VLM_INTERNAL void vlm_gemm_splitk_unshare(void* to_stream);
 VLM_INTERNAL size_t vlm_gemv_mfma_ws_bytes(void);
 // -> 0 done, > 0 error, -1 shape not handled (take the v_dot2c kernels).  ws: zero-initialised workspace of
 // vlm_gemv_mfma_ws_bytes() owned by the caller (one per engine: launches that share it must be stream-ordered), or nullptr

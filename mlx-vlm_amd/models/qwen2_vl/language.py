@@ -156,6 +156,10 @@ class DecodeState:
 
 
 class LanguageModel:
+    # rows of one decode step (decode_step_rows): up to 16 on the GEMV family (v_dot2c: 1 / 2 / 4 / 8, skinny-M MFMA: 5..16), 17..64 as
+    # WIDE steps on the prefill GEMMs (needs the caller's block table; not for two-table RoPE models: phi3_v sets 16)
+    MAX_DECODE_ROWS = 64
+
     supports_logits_to_keep = True
 
     def __init__(self, args: TextConfig, config: ModelConfig, device="cuda", kv_pool_tokens: int = 32768,
@@ -762,13 +766,14 @@ class LanguageModel:
         caches = [cache] if isinstance(cache[0], KVCache) else cache
         cache_offset = caches[0][0].offset
 
-        # decode widths of the engine: 1 / 2 / 4 / 8 rows on the v_dot2c GEMVs, 9..16 rows on the skinny-M MFMA GEMM
-        if Lq == 1 and cache_offset > 0 and inputs_embeds is None and (B in (1, 2, 4, 8) or 9 <= B <= 16):
+        # decode widths of the engine: 1 / 2 / 4 / 8 rows on the v_dot2c GEMVs, 9..16 rows on the skinny-M MFMA GEMM, 17..64 as
+        # WIDE steps on the prefill GEMMs (these walk the pool's block table in either layout)
+        if Lq == 1 and cache_offset > 0 and inputs_embeds is None and (B in (1, 2, 4, 8) or 9 <= B <= self.MAX_DECODE_ROWS):
             # decode: pos = cache offset + rope delta (language.py:476-509); logits only
             deltas = self._rope_deltas if self._rope_deltas is not None else np.zeros((B, 1), dtype=np.int64)
             deltas = np.broadcast_to(np.asarray(deltas).reshape(-1, 1), (B, 1)) if np.asarray(deltas).size == 1 else deltas
             st = self.decode_begin(caches, ids.reshape(-1), deltas[:B], max_new_tokens=1)
-            kv = self._kv_struct(st.seq_row0, decode=True, q8=self._seqs_q8(st.seqs))
+            kv = self._kv_struct(st.seq_row0, decode=B <= 16, q8=self._seqs_q8(st.seqs))
             check(_lib.lib().vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
             args = st.args()
             check(_lib.lib().vlm_llm_decode_forward(self._handle, C.byref(args),

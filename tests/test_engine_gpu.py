@@ -817,6 +817,49 @@ def test_batch_generator_16_rows_matrix_core_steps_equal_single_requests(tiny):
     _assert_streams_equal_up_to_ties([got[u] for u in uids], singles)
 
 
+@pytest.mark.parametrize("rows", [32, 64])
+def test_batch_generator_wide_steps_on_the_prefill_gemms_equal_single_requests(tiny, rows):
+    """More than 16 decode rows on request (completion_batch_size = 32 / 64): such WIDE steps run a layer as the prefill's
+    launch sequence - RMSNorm, GEMMs, M-RoPE + KV write at the rows' device-resident slots - with the paged decode attention
+    (engine.hip decode_impl); captured in the step's graph with the launch stream's split-K workspace.  Every request must
+    produce the tokens it produces alone up to its own bf16 ties (another kernel family = another summation order)."""
+    from mlx_vlm_amd.batch import BatchGenerator
+
+    cfg, W, _ = tiny
+    n = rows + 6
+    model = build_product_model(cfg, W, kv_pool_tokens=32768, max_seqs=2 * rows + 8)
+    reqs = _mixed_requests(cfg, n, seed0=400 + rows)
+    max_tokens = [5 + (5 * i) % 8 for i in range(n)]
+    singles = _single_runs(model, reqs, max_tokens)
+    gen = BatchGenerator(model, None, max_tokens=8, completion_batch_size=rows, prefill_batch_size=rows)
+    assert gen.completion_batch_size == rows
+    uids = _insert_all(gen, reqs, max_tokens)
+    got = {u: [] for u in uids}
+    widths = set()
+    while gen.has_work:
+        _, out = gen.next()
+        widths.add(gen._width)
+        for r in out:
+            got[r.uid].append((r.token, r.token_logprob))
+    gen.close()
+    assert rows in widths
+    assert all(len(got[u]) == max_tokens[u] for u in uids)
+    _assert_streams_equal_up_to_ties([got[u] for u in uids], singles)
+
+
+def test_batch_generator_wide_rows_are_refused_where_the_engine_has_none(tiny):
+    """a language model that caps its decode rows (phi3_v: two-table RoPE) keeps 16-row steps whatever is asked for"""
+    from mlx_vlm_amd.batch import BatchGenerator
+
+    cfg, W, _ = tiny
+    model = build_product_model(cfg, W, kv_pool_tokens=16384, max_seqs=80)
+    model.language_model.MAX_DECODE_ROWS = 16
+    gen = BatchGenerator(model, None, completion_batch_size=32)
+    assert gen.completion_batch_size == 16
+    gen.close()
+    del model.language_model.MAX_DECODE_ROWS
+
+
 def test_batch_generator_stop_token_and_remove(tiny):
     """A stop token ends one request with finish_reason "stop" (the token is still reported, as in the reference);
     remove(uid) drops a running request between rounds; the other rows are untouched by either."""

@@ -174,16 +174,17 @@ def _rows_vs_oracle(model, lm_decode_ref, prompts, forced, tol, tag):
     return worst
 
 
-@pytest.mark.parametrize("B", [16, 9])
+@pytest.mark.parametrize("B", [16, 9, 32, 57])
 def test_decode_forward_16_rows_every_row_vs_oracle_bf16(B):
     """Qwen2-VL tiny dims, B rows of different context lengths (3 .. 140 tokens: rows on their first page, rows past a page
     boundary) through the B-row decode forward (B = 9 runs as its own width: rows as the MFMA N dimension, 7 idle
-    columns): 4 steps, every row's logits vs the oracle; 2 layers of bf16: 2e-2."""
+    columns; B = 32 / 57: WIDE steps - the prefill GEMMs, M-RoPE + KV write at the rows' slots, paged decode attention):
+    4 steps, every row's logits vs the oracle; 2 layers of bf16: 2e-2."""
     from oracle import qwen2_vl as oq
 
     cfg = oq.tiny_cfg()
     W = oq.random_weights(cfg, seed=1234, dtype=BF, std=0.05, embed_std=0.2)
-    model = build_product_model(cfg, W, kv_pool_tokens=16384, max_seqs=32)
+    model = build_product_model(cfg, W, kv_pool_tokens=32768, max_seqs=72)
     rng = np.random.default_rng(500 + B)
     prompts = [rng.integers(3, 1000, 3 + (b * 37) % 138).astype(np.int64) for b in range(B)]
     forced = rng.integers(3, 1000, (4, B))
