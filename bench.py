@@ -616,8 +616,10 @@ def workload_2b_w4(args, rank, ws, dev):
 
 def workload_7b_b32(args, rank, ws, dev):
     """BASELINE configs[2]: Qwen2-VL-7B dims, 32 requests (336x336 image + 128-token prompt each) dealt data-parallel over
-    the ranks by parallel.dp_batch_generate (length-sorted deal; every rank a continuous BatchGenerator of <= 8 rows; no
-    collective inside the steps).  Total work is fixed: strong scaling."""
+    the ranks by parallel.dp_batch_generate (length-sorted deal; every rank a continuous BatchGenerator of up to 32 rows -
+    VLM_BENCH_7B_ROWS; no collective inside the steps).  On one GPU the 32 requests decode in one wave of 32-row WIDE
+    steps (prefill GEMMs + paged decode attention); a rank with <= 16 requests runs the 16-row MFMA decode GEMM steps.
+    Total work is fixed: strong scaling."""
     from mlx_vlm_amd import parallel, synthetic
     from mlx_vlm_amd.models import qwen2_vl
 
