@@ -144,6 +144,37 @@ def batch_decode_throughput(model, cfg, B=8, max_tokens=64):
             "prompt_tps": stats.prompt_tps, "e2e_tokens_per_s": sum(len(t) for t in toks) / dt}
 
 
+def wide_decode_throughput(model, cfg, rows=64, max_tokens=48):
+    """Extra: `rows` concurrent requests (336x336 image + 128 text tokens each) through the continuous generator with that many
+    decode rows - WIDE steps (17..64 rows: the prefill GEMMs + paged decode attention, engine.hip decode_impl); decode
+    tokens/s of the generator's own clock (wall time with decode steps in flight)."""
+    from mlx_vlm_amd import synthetic
+    from mlx_vlm_amd.batch import generate_batch_continuous
+    from mlx_vlm_amd.models import qwen2_vl
+
+    # an engine of its own: 64 rows + the admissions prefilled ahead need 2 * rows + 2 sequence slots - a pool of that many
+    # sequences would move the headline model from the identity to the paged KV layout
+    del model
+    dev = torch.device("cuda", torch.cuda.current_device())
+    W = synthetic.random_weights(cfg, seed=0, device=dev)
+    model = qwen2_vl.Model(cfg, device=dev, kv_pool_tokens=49152, max_seqs=2 * rows + 8)
+    model.load_weights(W)
+    del W
+    reqs = [build_request(cfg, 336, 128, 900 + i) for i in range(rows)]
+    ids = [r[0].reshape(-1) for r in reqs]
+    pix = [r[1] for r in reqs]
+    thw = [r[2] for r in reqs]
+    generate_batch_continuous(model, ids, pix, thw, max_tokens=6, batch_size=rows)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    toks, st = generate_batch_continuous(model, ids, pix, thw, max_tokens=max_tokens, batch_size=rows)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"rows": rows, "image": "336x336", "max_tokens": max_tokens, "generation_tps": st.generation_tps,
+            "decode_steps": st.decode_steps, "ms_per_step": 1e3 * st.generation_time / max(st.decode_steps, 1),
+            "e2e_tokens_per_s": sum(len(t) for t in toks) / dt}
+
+
 def continuous_batch_throughput(model, cfg, n_requests=24, rows=8):
     """Extra: a queue of requests with different lengths (336x336 image + 64-token prompt, 24..96 new tokens) through the
     continuous `BatchGenerator` (8 decode rows; rows are refilled from the queue as requests finish) vs the same queue
@@ -909,6 +940,7 @@ def main():
         # exploratory single-GPU extras: not part of the scaling runs (the other ranks would only wait for rank 0)
         for key, fn in (("batch8", lambda: batch_decode_throughput(model, cfg, 8, 64)),
                         ("batch16", lambda: batch_decode_throughput(model, cfg, 16, 64)),
+                        ("wide64", lambda: wide_decode_throughput(model, cfg, 64, 48)),
                         ("continuous", lambda: continuous_batch_throughput(model, cfg))):
             if ws > 1:
                 extras[key] = None
@@ -962,6 +994,7 @@ def main():
                                    "ms_per_call": dt336 * 1e3}
             out["batch8_decode"] = extras["batch8"]
             out["batch16_decode"] = extras.get("batch16")
+            out["wide64_decode"] = extras.get("wide64")
             out["continuous_batching"] = extras["continuous"]
             out["vision_single_448_images_per_s"] = ips448
             out["vision_single_448_tflops"] = ips448 * VIT_TFLOP_448
