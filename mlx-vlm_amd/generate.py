@@ -582,9 +582,13 @@ def batch_generate(model, processor, images=None, audios=None, prompts: Optional
                                    kwargs.pop("repetition_context_size", 20), kwargs.pop("presence_penalty", None),
                                    kwargs.pop("presence_context_size", 20), kwargs.pop("frequency_penalty", None),
                                    kwargs.pop("frequency_context_size", 20))
+    # decode rows of the generator (the reference's completion_batch_size, ar.py:2584-2606): 16 by default; more (up to 64) run as
+    # WIDE steps where the engine and the KV pool's sequence slots (2 * rows + 2) allow
+    rows = kwargs.pop("completion_batch_size", None) or kwargs.pop("batch_size", None)
     if kwargs.pop("continuous", True):
         toks, stats = generate_batch_continuous(model, ids_l, pix_l, grid_l, max_tokens=max_tokens, stop_ids=stop_ids, sampler=smp,
-                                                extras=extras, logits_processors=procs if procs else None)
+                                                extras=extras, logits_processors=procs if procs else None,
+                                                **({"batch_size": int(rows)} if rows else {}))
     else:
         if procs:
             raise NotImplementedError("static batches (continuous=False) run without logits processors; use the continuous generator")
