@@ -284,3 +284,38 @@ def test_stats_split_wall_time_into_prompt_and_decode_time():
     assert st.prompt_time + st.generation_time < wall + 2 * T_STEP + 0.01
     assert st.prompt_time + st.generation_time > 0.8 * wall
     gen.close()
+
+
+def test_wide_rows_on_request_and_pool_limits():
+    """completion_batch_size > 16 asks for WIDE steps (32 / 64 rows): granted up to the language model's MAX_DECODE_ROWS and
+    the pool's sequence slots (2 * rows + 2: rows + admissions prefilled ahead + the scratch sequence); every request still
+    emits its own stream through 32-wide steps."""
+    rng = np.random.default_rng(77)
+    pool = KVPool(n_layers=1, n_kv_heads=1, head_dim=128, max_tokens=256 * 64, max_seqs=80, device="cpu", layout="paged")
+    gen = MockEngineGenerator(pool, completion_batch_size=64)          # 80 < 2 * 64 + 2: halved
+    assert gen.completion_batch_size == 16                              # (the mock engine has no MAX_DECODE_ROWS: 16-row default)
+    gen.close()
+    gen = MockEngineGenerator(pool, completion_batch_size=32, prefill_batch_size=32)
+    gen.lm.MAX_DECODE_ROWS = 64
+    gen.close()
+
+    class Wide(MockEngineGenerator):
+        def __init__(self, pool, **kw):
+            self.decode_widths, self.prefill_sizes = [], []
+            lm = SimpleNamespace(device="cpu", pool=pool, MAX_DECODE_ROWS=64)
+            BatchGenerator.__init__(self, SimpleNamespace(language_model=lm), None, **kw)
+
+    gen = Wide(pool, completion_batch_size=32, prefill_batch_size=32)
+    assert gen.completion_batch_size == 32
+    prompts = [rng.integers(1, 999, int(rng.integers(3, 30))) for _ in range(40)]
+    max_tokens = [int(rng.integers(2, 12)) for _ in prompts]
+    uids = gen.insert(prompts, max_tokens)
+    got, reasons, _, _ = drain(gen)
+    for u, p, m in zip(uids, prompts, max_tokens):
+        assert [t for t, _ in got[u]] == stream_alone(p, m), u
+    assert any(w == 32 for w, _ in gen.decode_widths)
+    gen.close()
+    small = KVPool(n_layers=1, n_kv_heads=1, head_dim=128, max_tokens=64 * 64, max_seqs=40, device="cpu", layout="paged")
+    gen = Wide(small, completion_batch_size=64)
+    assert gen.completion_batch_size == 16                              # 40 slots: 64 -> 32 -> 16 rows
+    gen.close()
