@@ -25,6 +25,7 @@
 // fp32 scores / statistics / accumulation; P is rounded to bf16 for the second MFMA (as in the prefill
 // flash kernel; tolerance stated in tests).
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.cuh"
 #include "internal.h"
@@ -910,6 +911,15 @@ extern "C" int vlm_attn_decode_paged_q8(const void* q, int ldq, const void* kpoo
   const int G = Hq / Hkv;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(B * Hkv, nsplit);
+  // `queries *= scale` (base.py:272) with a python float: MLX converts the weak scalar to the ARRAY's dtype first, so the
+  // typed multiply uses bf16(scale) (128 ** -0.5 -> 0.08837890625) - pinned by tests/golden/kvquant_ref.npz, where the
+  // reference's own function runs; round-to-nearest-even on the host
+  {
+    unsigned u;
+    memcpy(&u, &scale, 4);
+    u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+    memcpy(&scale, &u, 4);
+  }
 #define GO1(GV, ID, MG)                                                                                                  \
   hipLaunchKernelGGL((attn_decode_pagesplit_q8_kernel<GV, ID, MG>), grid, dim3(64), 0, st, (const bf16_t*)q,              \
                      (const bf16_t*)kpool16, (const bf16_t*)vpool16, (unsigned char*)kpool8, (unsigned char*)vpool8,      \

@@ -32,7 +32,33 @@ import torch
 Dtype = torch.dtype
 float32, float16, bfloat16, float64 = torch.float32, torch.float16, torch.bfloat16, torch.float64
 int8, int16, int32, int64 = torch.int8, torch.int16, torch.int32, torch.int64
-uint8, uint16, uint32, uint64 = torch.uint8, torch.uint16, torch.uint32, torch.uint64
+uint8, uint16, uint64 = torch.uint8, torch.uint16, torch.uint64
+
+
+class _SizedDtype:
+    """mx.uint32 with MLX's `Dtype.size` (the reference computes `8 * mx.uint32.size // bits`, models/cache.py:249);
+    torch.dtype objects cannot carry extra attributes.  Equal to, hashes like and unwraps to torch.uint32."""
+
+    def __init__(self, t, size):
+        self._torch, self.size = t, size
+
+    def __eq__(self, o):
+        return o is self or o == self._torch
+
+    def __hash__(self):
+        return hash(self._torch)
+
+    def __repr__(self):
+        return "mlx.core.uint32"
+
+
+uint32 = _SizedDtype(torch.uint32, 4)
+
+
+def _dt(d):
+    return d._torch if isinstance(d, _SizedDtype) else d
+
+
 bool_ = torch.bool
 complex64 = torch.complex64
 inf, nan, pi, e, newaxis = float("inf"), float("nan"), math.pi, math.e, None
@@ -61,6 +87,7 @@ def _py(v):
 
 
 def _to_tensor(val, dtype=None) -> torch.Tensor:
+    dtype = _dt(dtype)
     if isinstance(val, array):
         t = val._t
     elif isinstance(val, torch.Tensor):
@@ -208,7 +235,7 @@ class array:
 
     # ---- shape ops
     def astype(self, dtype, stream=None):
-        return array(self._t.to(dtype))
+        return array(self._t.to(_dt(dtype)))
 
     def reshape(self, *shape, stream=None):
         if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
@@ -238,7 +265,7 @@ class array:
         return split(self, indices_or_sections, axis)
 
     def view(self, dtype):
-        return array(self._t.view(dtype))
+        return array(self._t.view(_dt(dtype)))
 
     # ---- reductions
     def sum(self, axis=None, keepdims=False):
@@ -368,11 +395,11 @@ def arange(start, stop=None, step=1, dtype=None, stream=None):
 
 
 def zeros(shape, dtype=float32, stream=None):
-    return array(torch.zeros(tuple(_py(shape)) if not isinstance(shape, int) else (shape,), dtype=dtype))
+    return array(torch.zeros(tuple(_py(shape)) if not isinstance(shape, int) else (shape,), dtype=_dt(dtype)))
 
 
 def ones(shape, dtype=float32, stream=None):
-    return array(torch.ones(tuple(_py(shape)) if not isinstance(shape, int) else (shape,), dtype=dtype))
+    return array(torch.ones(tuple(_py(shape)) if not isinstance(shape, int) else (shape,), dtype=_dt(dtype)))
 
 
 def full(shape, vals, dtype=None, stream=None):
@@ -511,6 +538,14 @@ def pad(a, pad_width, mode="constant", constant_values=0, stream=None):
     for lo, hi in reversed(pw):
         flat += [lo, hi]
     return array(torch.nn.functional.pad(t, flat, mode="constant", value=_py(constant_values)))
+
+
+class finfo:
+    """mx.finfo(dtype): min / max / eps of a floating type"""
+
+    def __init__(self, dtype):
+        fi = torch.finfo(_dt(dtype))
+        self.min, self.max, self.eps, self.dtype = fi.min, fi.max, fi.eps, dtype
 
 
 def where(cond, x, y, stream=None):
@@ -784,11 +819,44 @@ def as_strided(a, shape=None, strides=None, offset=0, stream=None):
     return array(torch.as_strided(_a(a)._t, shape, strides, offset))
 
 
-def quantize(*a, **k):
-    raise NotImplementedError("mlx shim: quantize is outside the pinned path")
+# ---- affine quantization (mx.quantize / mx.dequantize / mx.quantized_matmul, mode="affine")
+# The arithmetic lives in the un-vendored mlx runtime; it is restated ONCE, in oracle/quant.py, from MLX's published
+# algorithm (per group: signed scale, the edge of larger magnitude lands on an integer, 1e-7 floor, little-end packing;
+# dequantize = scale * q + bias in fp32, one rounding; quantized_matmul = fp32 accumulation over the fp32 affine weights,
+# one rounding to x's dtype) and stays "parity unpinned".  What these entry points make possible is running the
+# REFERENCE'S OWN callers of them (models/cache.py QuantizedKVCache / to_quantized, models/base.py quantized SDPA,
+# generate/common.py's switch-over, utils.py's nn.quantize load path) unmodified, which pins the graph around them.
+def _words(t):
+    return t.view(torch.int32) if t.dtype == torch.uint32 else t.to(torch.int32)
 
 
-dequantize = quantized_matmul = quantize
+def quantize(w, group_size=64, bits=4, mode="affine", stream=None):
+    if mode != "affine":
+        raise NotImplementedError("mlx shim: only affine quantization is restated")
+    from oracle import quant as _q
+
+    wq, s, b = _q.quantize_nd(_a(w)._t, int(group_size), int(bits))
+    return array(wq.contiguous().view(torch.uint32)), array(s), array(b)          # (array.dtype of the words == mx.uint32)
+
+
+def dequantize(w, scales, biases=None, group_size=64, bits=4, mode="affine", dtype=None, stream=None):
+    if mode != "affine" or biases is None:
+        raise NotImplementedError("mlx shim: only affine quantization is restated")
+    from oracle import quant as _q
+
+    s = _a(scales)._t
+    return array(_q.dequantize_nd(_words(_a(w)._t.contiguous()), s, _a(biases)._t, int(group_size), int(bits), dtype=dtype or s.dtype))
+
+
+def quantized_matmul(x, w, scales, biases=None, transpose=True, group_size=64, bits=4, mode="affine", stream=None):
+    if mode != "affine" or biases is None:
+        raise NotImplementedError("mlx shim: only affine quantization is restated")
+    from oracle import quant as _q
+
+    xt = _a(x)._t
+    wf = _q.dequantize_nd(_words(_a(w)._t.contiguous()), _a(scales)._t, _a(biases)._t, int(group_size), int(bits), dtype=torch.float32)
+    y = xt.to(torch.float32) @ (wf.transpose(-1, -2) if transpose else wf)          # batch dims broadcast as mx.matmul's do
+    return array(y.to(xt.dtype))
 
 
 # ---------------------------------------------------------------------------------------------- runtime no-ops
@@ -1080,6 +1148,17 @@ class _Linalg:
 
 
 linalg = _Linalg()
+
+
+class distributed:
+    """only the names the reference's signatures mention at import time (utils.py:1124)"""
+
+    class Group:
+        pass
+
+    @staticmethod
+    def init(*a, **k):
+        raise NotImplementedError("mlx shim: mx.distributed is outside the pinned path")
 
 
 def save_safetensors(*a, **k):

@@ -352,16 +352,105 @@ class RoPE(Module):
         return mx.fast.rope(x, self.dims, traditional=self.traditional, base=self.base, scale=self.scale, offset=offset)
 
 
-def quantize(*a, **k):
-    raise NotImplementedError("mlx shim: quantization is outside the pinned path")
-
-
+# ---- quantized layers (mlx.nn.QuantizedLinear / QuantizedEmbedding / nn.quantize, mode="affine"): MLX's documented layer
+# semantics over the shim's mx.quantize / mx.quantized_matmul / mx.dequantize (oracle/mlx_shim/mlx/core.py)
 class QuantizedLinear(Module):
-    def __init__(self, *a, **k):
-        raise NotImplementedError("mlx shim: quantization is outside the pinned path")
+    def __init__(self, input_dims, output_dims, bias=True, group_size=64, bits=4, mode="affine"):
+        super().__init__()
+        self.group_size, self.bits, self.mode = group_size, bits, mode
+        s = math.sqrt(1.0 / input_dims)
+        self.weight, self.scales, self.biases = mx.quantize(_init((output_dims, input_dims), s), group_size, bits, mode=mode)
+        if bias:
+            self.bias = mx.zeros((output_dims,))
+
+    def _items(self):                       # group_size / bits / mode are attributes, not parameters
+        for k, v in self.__dict__.items():
+            if not k.startswith("_") and isinstance(v, mx.array):
+                yield k, v
+
+    def __call__(self, x):
+        x = mx.quantized_matmul(x, self.weight, scales=self.scales, biases=self.biases, transpose=True,
+                                group_size=self.group_size, bits=self.bits, mode=self.mode)
+        if "bias" in self.__dict__:
+            x = x + self.bias
+        return x
+
+    @classmethod
+    def from_linear(cls, linear_layer, group_size=64, bits=4, mode="affine"):
+        output_dims, input_dims = linear_layer.weight.shape
+        ql = cls(input_dims, output_dims, False, group_size, bits, mode=mode)
+        ql.weight, ql.scales, ql.biases = mx.quantize(linear_layer.weight, group_size, bits, mode=mode)
+        if "bias" in linear_layer.__dict__:
+            ql.bias = linear_layer.bias
+        return ql
 
 
-QuantizedEmbedding = QuantizedLinear
+class QuantizedEmbedding(Module):
+    def __init__(self, num_embeddings, dims, group_size=64, bits=4, mode="affine"):
+        super().__init__()
+        self.group_size, self.bits, self.mode = group_size, bits, mode
+        self.num_embeddings, self.dims = num_embeddings, dims
+        self.weight, self.scales, self.biases = mx.quantize(_init((num_embeddings, dims), math.sqrt(1.0 / dims)), group_size, bits, mode=mode)
+
+    _items = QuantizedLinear._items
+
+    def __call__(self, x):
+        return mx.dequantize(self.weight[x], scales=self.scales[x], biases=self.biases[x], group_size=self.group_size,
+                             bits=self.bits, mode=self.mode)
+
+    def as_linear(self, x):
+        return mx.quantized_matmul(x, self.weight, scales=self.scales, biases=self.biases, transpose=True,
+                                   group_size=self.group_size, bits=self.bits, mode=self.mode)
+
+    @classmethod
+    def from_embedding(cls, embedding_layer, group_size=64, bits=4, mode="affine"):
+        n, d = embedding_layer.weight.shape
+        ql = cls(n, d, group_size, bits, mode=mode)
+        ql.weight, ql.scales, ql.biases = mx.quantize(embedding_layer.weight, group_size, bits, mode=mode)
+        return ql
+
+
+def _linear_to_quantized(self, group_size=64, bits=4, mode="affine", **kw):
+    return QuantizedLinear.from_linear(self, group_size, bits, mode=mode)
+
+
+def _embedding_to_quantized(self, group_size=64, bits=4, mode="affine", **kw):
+    return QuantizedEmbedding.from_embedding(self, group_size, bits, mode=mode)
+
+
+Linear.to_quantized = _linear_to_quantized
+Embedding.to_quantized = _embedding_to_quantized
+
+
+def quantize(model, group_size=None, bits=None, *, mode="affine", quantize_input=False, class_predicate=None):
+    """nn.quantize: every leaf module for which class_predicate(path, module) is truthy is replaced by its
+    `to_quantized(...)` form (a dict answer carries that module's own parameters); modules without `to_quantized` that
+    the predicate accepts are an error, as in MLX."""
+    if quantize_input:
+        raise NotImplementedError("mlx shim: activation quantization is outside the pinned path")
+    class_predicate = class_predicate or (lambda _, m: hasattr(m, "to_quantized"))
+    for path, m in model.named_modules():
+        if not path or any(isinstance(v, (Module, list, dict)) and not isinstance(v, mx.array) and _has_module(v)
+                           for _, v in m._items()):
+            continue                                      # not a leaf
+        ans = class_predicate(path, m)
+        if not ans:
+            continue
+        if not hasattr(m, "to_quantized"):
+            raise ValueError(f"Unable to quantize model of type {type(m)}")
+        kwargs = dict(ans) if isinstance(ans, dict) else {"group_size": group_size, "bits": bits, "mode": mode}
+        model._set(path, m.to_quantized(**kwargs))
+    return model
+
+
+def _has_module(v):
+    if isinstance(v, Module):
+        return True
+    if isinstance(v, (list, tuple)):
+        return any(_has_module(x) for x in v)
+    if isinstance(v, dict):
+        return any(_has_module(x) for x in v.values())
+    return False
 
 
 class _Placeholder(Module):

@@ -172,6 +172,12 @@ def to_quantized(cache, group_size: int = 64, bits: int = 8) -> QuantizedKVCache
     return q
 
 
+def should_quantize_kv_layer(layer_idx: int, num_layers: int) -> bool:
+    """models/cache.py:8-21 - the BATCH policy (generate/ar.py:842-858 `_make_cache`): with kv_bits set every layer's batch
+    cache is quantised from the start, except the last layer of a stack deeper than 2 (kept in the model dtype)."""
+    return True if num_layers <= 2 else layer_idx < num_layers - 1
+
+
 def maybe_quantize_kv_cache(prompt_cache: list, quantized_kv_start: int, kv_group_size: int, kv_bits) -> None:
     """generate/common.py:170-181 (uniform scheme): in place, every layer whose plain cache has reached the start offset"""
     if kv_bits is None:
@@ -191,7 +197,9 @@ def quantized_sdpa(q: torch.Tensor, q_keys, q_values, scale: float, causal: bool
     Hkv = q_keys[0].shape[1]
     rep = Hq // Hkv
     dt = q.dtype
-    qs = (q.to(F32) * scale).to(dt)
+    # `queries *= scale` with a python float: MLX's weak scalar takes the ARRAY's dtype first (bf16(128 ** -0.5) =
+    # 0.08837890625, not 0.0883883...), then one typed multiply - pinned by tests/golden/kvquant_ref.npz
+    qs = (q.to(F32) * torch.tensor(scale, dtype=dt).to(F32)).to(dt)
     kf = dequantize_nd(*q_keys, group_size, bits).repeat_interleave(rep, dim=1)          # [B, Hq, S, D] fp32
     vf = dequantize_nd(*q_values, group_size, bits).repeat_interleave(rep, dim=1)
     scores = (qs.to(F32) @ kf.transpose(-1, -2)).to(dt)

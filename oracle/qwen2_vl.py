@@ -428,7 +428,8 @@ def get_input_embeddings(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_t
 # generate_step, greedy (generate/ar.py:151-515)
 # --------------------------------------------------------------------------
 def generate_greedy(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_thw=None,
-                    max_tokens: int = 16, rope_mode: str = "fused", return_logits: bool = False, processors=None):
+                    max_tokens: int = 16, rope_mode: str = "fused", return_logits: bool = False, processors=None,
+                    kv_bits=None, kv_group_size: int = 64, quantized_kv_start: int = 0, return_logprobs: bool = False):
     """generate_step with temperature 0: embeds -> full-prompt prefill ->
     logits[:, -1] -> logprobs = logits - logsumexp -> argmax -> decode loop with
     pos = cache offset + rope_delta (language.py:476-509)."""
@@ -437,9 +438,11 @@ def generate_greedy(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_thw=No
     emb, pos, deltas = get_input_embeddings(W, cfg, input_ids, pixel_values, image_grid_thw)
     pos_t = torch.from_numpy(np.asarray(pos))
     cache = [ops.KVCache() for _ in range(cfg.text.num_hidden_layers)]
+    from . import quant
     h = qwen2_model(W, cfg, emb, cache, pos_t, rope_mode)
     logits = lm_head(W, cfg, h)[:, -1, :]
-    toks, all_logits = [], []
+    quant.maybe_quantize_kv_cache(cache, quantized_kv_start, kv_group_size, kv_bits)    # ar.py:362: inside _step, after the forward
+    toks, all_logits, all_lp = [], [], []
     delta = int(deltas[0, 0])
     fed = list(input_ids.reshape(-1))           # ar.py:360-364: `tokens` = the prompt, then every token fed back
     for n in range(max_tokens):
@@ -449,6 +452,7 @@ def generate_greedy(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_thw=No
         y = int(ops.argmax_first(lp)[0])
         toks.append(y)
         all_logits.append(logits[0].clone())
+        all_lp.append(lp[0].clone())
         if n == max_tokens - 1:
             break
         e = embed_tokens(W, np.array([[y]]))
@@ -457,6 +461,9 @@ def generate_greedy(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_thw=No
         pid = torch.full((3, 1, 1), p, dtype=torch.long)
         h = qwen2_model(W, cfg, e, cache, pid, rope_mode)
         logits = lm_head(W, cfg, h)[:, -1, :]
+        quant.maybe_quantize_kv_cache(cache, quantized_kv_start, kv_group_size, kv_bits)
+    if return_logprobs:
+        return toks, torch.stack(all_lp)
     if return_logits:
         return toks, torch.stack(all_logits)
     return toks
