@@ -349,6 +349,10 @@ typedef struct vlm_kv_pool {
    * When set, every decode step attends over them (the qkv epilogue still writes the new token to the bf16 pools; the
    * attention launch quantises it). */
   void *kpool8, *vpool8, *ksb, *vsb;
+  /* ABI v5: 1 = the LAST layer of a stack deeper than 2 keeps attending over the bf16 pools - the reference's policy for
+   * BATCHED generation with kv_bits (models/cache.py:8-21 should_quantize_kv_layer, generate/ar.py:842-858); 0 = every
+   * layer attends over the 8-bit pools (generate_step's maybe_quantize_kv_cache, generate/common.py:170-181). */
+  int q8_skip_last;
 } vlm_kv_pool;
 
 /* prefill over T tokens (all sequences concatenated).  h [T][hidden] holds the input
@@ -412,23 +416,9 @@ int vlm_llm_decode_launches(void* handle);
 
 /* Tuning of the captured decode step (no effect on results; measured defaults in DESIGN.md).  Changing a value drops
  * the cached graphs of the handle.
- *   VLM_TUNE_PREFETCH       0 = off; 1 = a side branch of the graph pulls the next layer's weights (and the K/V pages its
- *                           attention reads) towards the 256 MB Infinity Cache while the current layer runs, one launch per
- *                           layer started by a graph edge from the chain; 2 = the same from ONE persistent side kernel per
- *                           step paced by a device word the chain publishes (no graph edge leaves the chain)
- *   VLM_TUNE_PREFETCH_WGS   workgroups of the side kernel (default 256)
- *   VLM_TUNE_PREFETCH_MASK  what is prefetched: bit 0 Wqkv, 1 Wo, 2 Wgate/up, 3 Wdown, 4 K/V pages, 5 the first
- *                           lm_head rows during the last layer, 6 layer 0 of the next step during the sampler tail */
-#define VLM_TUNE_PREFETCH 0
-#define VLM_TUNE_PREFETCH_WGS 1
-#define VLM_TUNE_PREFETCH_MASK 2
-#define VLM_TUNE_PREFETCH_HEAD_MB 3 /* MiB of lm_head rows covered by mask bit 5 (default 96) */
-#define VLM_TUNE_DEBUG_SKIP 4       /* MEASUREMENT ONLY (results become meaningless): leave launches out of the captured step
-                                       to read their marginal cost off the wall clock - bit 0 qkv, 1 attention, 2 o_proj,
-                                       3 gate/up, 4 down, 5 lm_head, 6 sampler tail */
-#define VLM_TUNE_FUSED_MLP 5        /* 1: batch-1 steps run o_proj + gate/up + down of a layer as ONE launch (csrc/mlp_fused.hip:
-                                       weight slices register-resident from entry, in-launch hand-offs); needs >= 256 CUs and
-                                       a supported shape, otherwise the step silently keeps the three launches */
+ * (keys 0..5 and 10 were the round-2 / round-3 experiments - weight prefetch on a side branch, the fused MLP launch,
+ *  launch-skipping masks, translation warm-up - which lost to the five-launch layer; they left the library in ABI v5 and
+ *  live on as sources under scripts/rejected/ with their measurements in profiles/) */
 #define VLM_TUNE_MFMA_GEMV 6        /* 1 (default): decode steps of 3..16 rows run their projections on the matrix cores
                                        (csrc/gemv_mfma.hip); 0: the v_dot2c GEMVs (rows in {4, 8}) - A/B knob */
 #define VLM_TUNE_ATTN_PAGESPLIT 7   /* decode attention of steps with at most 64 (row, kv head) pairs: N > 0 (default 16) = the
@@ -440,14 +430,8 @@ int vlm_llm_decode_launches(void* handle);
 #define VLM_TUNE_ATTN_MERGE 9       /* where the page-split attention of a ONE-row step is merged: 1 (default) = in the o_proj
                                        GEMV's prologue (partial-only attention launch, vlm_gemv_attn_out_bf16; needs bf16 Wo,
                                        Hq * D <= 2048, <= 16 splits), 0 = by the attention launch's last-arriving workgroup */
-#define VLM_TUNE_TLB_TOUCH 10       /* experiment: 1 = the page-split attention launch carries 16 extra workgroups that issue one
-                                       4-byte load per 64 KiB of the layer's o_proj / gate-up / down weights (bit 1: + the next
-                                       layer's qkv), warming their address translations ahead of the launches that stream them */
 int vlm_llm_set_tuning(void* handle, int key, int value);
 int vlm_llm_get_tuning(void* handle, int key);
-/* diagnostic of the in-launch hand-offs (VLM_TUNE_FUSED_MLP): 0 = every bounded wait completed since the last call;
- * non-zero = a wait gave up (results of that step are garbage).  Synchronises the device; clears the word. */
-int vlm_llm_fused_error(void* handle);
 
 /* The encoder-layer loop of the SigLIP / CLIP vision towers (idefics2/vision.py:141-187, llava_bunny/vision.py:139-200,
  * phi3_v/vision.py:117-175: x = x + out_proj(attention(LN1(x))); x = x + fc2(act(fc1(LN2(x)))), biases everywhere, no

@@ -32,7 +32,8 @@ class LlmGlobals(C.Structure):
 
 class KvPool(C.Structure):
     _fields_ = [("kpool", c_void_p), ("vpool", c_void_p), ("layer_stride", c_size_t), ("block_table", c_void_p),
-                ("max_pages", c_int), ("kpool8", c_void_p), ("vpool8", c_void_p), ("ksb", c_void_p), ("vsb", c_void_p)]
+                ("max_pages", c_int), ("kpool8", c_void_p), ("vpool8", c_void_p), ("ksb", c_void_p), ("vsb", c_void_p),
+                ("q8_skip_last", c_int)]
 
 
 class PrefillArgs(C.Structure):
@@ -84,8 +85,7 @@ class VitArgs(C.Structure):
 
 
 DECODE_FUSED_TAIL = 1                       # vlm_decode_args.flags
-TUNE_PREFETCH, TUNE_PREFETCH_WGS, TUNE_PREFETCH_MASK, TUNE_PREFETCH_HEAD_MB, TUNE_DEBUG_SKIP, TUNE_FUSED_MLP, TUNE_MFMA_GEMV = 0, 1, 2, 3, 4, 5, 6  # vlm_llm_set_tuning keys
-TUNE_ATTN_PAGESPLIT, TUNE_GEMV_VARIANT, TUNE_ATTN_MERGE, TUNE_TLB_TOUCH = 7, 8, 9, 10
+TUNE_MFMA_GEMV, TUNE_ATTN_PAGESPLIT, TUNE_GEMV_VARIANT, TUNE_ATTN_MERGE = 6, 7, 8, 9  # vlm_llm_set_tuning keys (include/vlm_hip.h)
 
 P = C.POINTER
 # name -> (restype, argtypes); every symbol include/vlm_hip.h declares
@@ -142,7 +142,6 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "vlm_llm_set_tuning": (c_int, [c_void_p, c_int, c_int]),
     "vlm_llm_get_tuning": (c_int, [c_void_p, c_int]),
-    "vlm_llm_fused_error": (c_int, [c_void_p]),
     "vlm_llm_create": (c_int, [P(LlmConfig), P(c_void_p)]),
     "vlm_llm_destroy": (c_int, [c_void_p]),
     "vlm_llm_set_layer": (c_int, [c_void_p, c_int, P(LlmLayer)]),

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ kpool, const bf16_t* __restrict__ vpool,
     const int* __restrict__ block_table, const int* __restrict__ kv_len, int ldq, int max_pages, int Hkv, int kv_len_add,
     int Hq, float scale_log2, int nsplit, int ldo, float* __restrict__ part_o, float* __restrict__ part_ml,
-    bf16_t* __restrict__ out, VlmProgress prog) {
+    bf16_t* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) float red_o[NW][G][HD];
   __shared__ float red_m[NW][G], red_l[NW][G];
 
@@ -235,8 +235,6 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
   }
   stamp(8);
   // pacing word of the weight prefetcher (csrc/prefetch.hip): a hint, nothing is ordered by it
-  if (prog.word && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
-    __hip_atomic_store(prog.word, prog.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -256,27 +254,6 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
 // producers stored sc1: no acquire fence needed), merges in fp32, stores bf16 and re-arms the ticket word (every
 // workgroup has arrived by then).  Workgroups whose first page lies beyond the context store nothing and only arrive.
 // tickets: one zero-initialised word per (sequence, kv head), owned by the caller, zero again after every launch.
-// Translation warm-up (VLM_TUNE_TLB_TOUCH): the weights a decode step streams are touched once per token, 3 GB apart from
-// their previous use - every launch of the layer starts on cold address translations (first K/V bytes 2.9 us after the
-// kernel start for two dependent loads, profiles/r02_attn_decode_timeline.txt; HBM latency alone is ~0.4 us).  This
-// kernel is latency-bound and leaves the memory pipes idle: a few EXTRA workgroups of its grid issue ONE 4-byte load per
-// 64 KiB of the regions the NEXT launches of the layer stream (o_proj, gate/up, down, the next layer's qkv), from every
-// XCD (workgroup b runs on XCD b % 8 - a speed assumption only), results discarded, and exit.  ~0.1 % of the layer's bytes.
-struct VlmTouch {
-  const char* p[4];
-  unsigned n64k[4];     // 64 KiB blocks of region i (0: unused)
-};
-__device__ __forceinline__ void vlm_touch_regions(const VlmTouch& t, int wg, int n_wg, int lane) {
-  const int xcd = wg & 7, per_xcd = max(n_wg >> 3, 1), slot = (wg >> 3) * 64 + lane, n_slots = per_xcd * 64;
-  (void)xcd;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    for (unsigned b = slot; b < t.n64k[r]; b += n_slots) {
-      unsigned v;
-      asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(t.p[r] + ((size_t)b << 16)) : "memory");
-    }
-  }
-}
 
 // The tail of a page-split workgroup (shared by the bf16 and the 8-bit-KV kernels): ot[dt][r] = unnormalised O^T[d = 16 dt +
 // 4 gq + r][head = lane & 15], m_run the running max (log2 domain), l_run this lane's share of the row sum.
@@ -382,16 +359,9 @@ __global__ __launch_bounds__(64) void attn_decode_pagesplit_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ kpool, const bf16_t* __restrict__ vpool,
     const int* __restrict__ block_table, const int* __restrict__ kv_len, int ldq, int max_pages, int Hkv, int kv_len_add,
     float scale_log2, int S, int ldo, float* part_o, float* part_ml, unsigned* tickets, bf16_t* __restrict__ out,
-    VlmTouch touch, VlmProgress prog) {
+    int unused_) {
   const int bh = blockIdx.x, b = bh / Hkv, g = bh % Hkv, s = blockIdx.y;
   const int lane = threadIdx.x, head = lane & 15, gq = lane >> 4;
-  // pacing word of the weight prefetcher (csrc/prefetch.hip): a hint, nothing is ordered by it
-  if (prog.word && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-    __hip_atomic_store(prog.word, prog.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if ((int)blockIdx.y >= S) {              // the extra workgroups of the grid only warm translations (VlmTouch) and leave
-    vlm_touch_regions(touch, (int)((blockIdx.y - S) * gridDim.x + blockIdx.x), (int)((gridDim.y - S) * gridDim.x), lane);
-    return;
-  }
   // every kernel argument in ONE scalar-load batch at entry (the tail's arguments would otherwise be fetched lazily,
   // one more round trip on the path to the ticket)
   asm volatile("" ::"s"(part_o), "s"(part_ml), "s"(tickets), "s"(out), "s"(S), "s"(ldo));
@@ -763,9 +733,9 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* _
 
 }  // namespace
 
-int vlm_attn_decode_paged_ex(const void* q, int ldq, const void* kpool, const void* vpool, const void* block_table,
-                             int max_pages, const void* kv_len, int kv_len_add, int B, int Hq, int Hkv, int D, float scale,
-                             int nsplit, void* part_o, void* part_ml, void* out, int ldo, VlmProgress prog, void* stream) {
+extern "C" int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, const void* vpool, const void* block_table,
+                                     int max_pages, const void* kv_len, int kv_len_add, int B, int Hq, int Hkv, int D, float scale,
+                                     int nsplit, void* part_o, void* part_ml, void* out, int ldo, void* stream) {
   if (!q || !kpool || !vpool || !kv_len || max_pages <= 0) return VLM_ERR_ARG;   // block_table == NULL: identity layout
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || nsplit <= 0 || Hq % Hkv != 0) return VLM_ERR_ARG;
   if (nsplit > 1 && (!part_o || !part_ml)) return VLM_ERR_ARG;
@@ -787,16 +757,16 @@ int vlm_attn_decode_paged_ex(const void* q, int ldq, const void* kpool, const vo
     hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, 8, true, false>), grid, dim3(8 * 64), 0, st, \
                        (const bf16_t*)q, (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)block_table,           \
                        (const int*)kv_len, ldq, max_pages, Hkv, kv_len_add, Hq, sl2, nsplit, ldo, (float*)part_o,       \
-                       (float*)part_ml, direct, prog);                                                                  \
+                       (float*)part_ml, direct);                                                                  \
   else                                                                                                                  \
   if (!block_table)                                                                                                     \
     hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, 8, false, true>), grid, dim3(8 * 64), 0, st, (const bf16_t*)q,      \
                        (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)nullptr, (const int*)kv_len, ldq,        \
-                       max_pages, Hkv, kv_len_add, Hq, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, direct, prog);\
+                       max_pages, Hkv, kv_len_add, Hq, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, direct);\
   else                                                                                                                  \
     hipLaunchKernelGGL((attn_decode_mfma_kernel<GV, 8, false, false>), grid, dim3(8 * 64), 0, st, (const bf16_t*)q,     \
                        (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)block_table, (const int*)kv_len, ldq,    \
-                       max_pages, Hkv, kv_len_add, Hq, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, direct, prog)
+                       max_pages, Hkv, kv_len_add, Hq, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, direct)
   switch (G) {
     case 1: GO(1); break;
     case 2: GO(2); break;
@@ -818,28 +788,10 @@ int vlm_attn_decode_paged_ex(const void* q, int ldq, const void* kpool, const vo
   return VLM_OK;
 }
 
-extern "C" int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, const void* vpool,
-                                     const void* block_table, int max_pages, const void* kv_len, int kv_len_add, int B,
-                                     int Hq, int Hkv, int D, float scale, int nsplit, void* part_o, void* part_ml,
-                                     void* out, int ldo, void* stream) {
-  return vlm_attn_decode_paged_ex(q, ldq, kpool, vpool, block_table, max_pages, kv_len, kv_len_add, B, Hq, Hkv, D, scale,
-                                  nsplit, part_o, part_ml, out, ldo, VlmProgress{nullptr, 0}, stream);
-}
-
 extern "C" int vlm_attn_decode_paged_split(const void* q, int ldq, const void* kpool, const void* vpool,
                                            const void* block_table, int max_pages, const void* kv_len, int kv_len_add, int B,
                                            int Hq, int Hkv, int D, float scale, int nsplit, void* part_o, void* part_ml,
                                            void* tickets, void* out, int ldo, void* stream) {
-  return vlm_attn_decode_paged_split_ex(q, ldq, kpool, vpool, block_table, max_pages, kv_len, kv_len_add, B, Hq, Hkv, D, scale,
-                                        nsplit, part_o, part_ml, tickets, out, ldo, nullptr, nullptr, 0, VlmProgress{nullptr, 0}, stream);
-}
-
-// touch_ptr / touch_bytes [n_touch <= 4]: regions whose address translations the launch warms (VlmTouch)
-VLM_INTERNAL int vlm_attn_decode_paged_split_ex(const void* q, int ldq, const void* kpool, const void* vpool,
-                                                const void* block_table, int max_pages, const void* kv_len, int kv_len_add,
-                                                int B, int Hq, int Hkv, int D, float scale, int nsplit, void* part_o,
-                                                void* part_ml, void* tickets, void* out, int ldo, const void* const* touch_ptr,
-                                                const size_t* touch_bytes, int n_touch, VlmProgress prog, void* stream) {
   if (!q || !kpool || !vpool || !kv_len || !part_o || !part_ml || max_pages <= 0) return VLM_ERR_ARG;
   if (out && !tickets) return VLM_ERR_ARG;
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || nsplit <= 0 || nsplit > 65535 || Hq % Hkv != 0) return VLM_ERR_ARG;
@@ -848,18 +800,11 @@ VLM_INTERNAL int vlm_attn_decode_paged_split_ex(const void* q, int ldq, const vo
   const int G = Hq / Hkv;
   hipStream_t st = (hipStream_t)stream;
   const float sl2 = scale * 1.44269504088896340736f;
-  VlmTouch touch{};
-  for (int i = 0; i < n_touch && i < 4; ++i) {
-    touch.p[i] = (const char*)touch_ptr[i];
-    touch.n64k[i] = (unsigned)((touch_bytes[i] + 65535) >> 16);
-  }
-  // 16 touching workgroups (2 per XCD, 128 lanes per XCD: ~11 loads per lane for a 93 MB layer)
-  const int touch_rows = n_touch > 0 ? (16 + B * Hkv - 1) / (B * Hkv) : 0;
-  dim3 grid(B * Hkv, nsplit + touch_rows);
+  dim3 grid(B * Hkv, nsplit);
 #define GO1(GV, ID, MG)                                                                                                  \
   hipLaunchKernelGGL((attn_decode_pagesplit_kernel<GV, ID, MG>), grid, dim3(64), 0, st, (const bf16_t*)q,                 \
                      (const bf16_t*)kpool, (const bf16_t*)vpool, (const int*)block_table, (const int*)kv_len, ldq, max_pages, \
-                     Hkv, kv_len_add, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, (unsigned*)tickets, (bf16_t*)out, touch, prog)
+                     Hkv, kv_len_add, sl2, nsplit, ldo, (float*)part_o, (float*)part_ml, (unsigned*)tickets, (bf16_t*)out, 0)
 #define GO(GV)                                                                                                           \
   do {                                                                                                                   \
     if (!block_table) { if (out) GO1(GV, true, true); else GO1(GV, true, false); }                                       \

@@ -39,31 +39,19 @@ struct DecodeGraph {
   hipGraphExec_t exec;
   int launches;
   unsigned long long last_use;
-  VlmPfItem* pf_items = nullptr;          // device list of the persistent prefetcher (owned)
-  std::vector<hipEvent_t> events;         // fork / join events of the capture (owned)
 };
 constexpr size_t MAX_DECODE_GRAPHS = 16;
 
-// defaults: off until DESIGN.md's measurement picks them (vlm_llm_set_tuning)
+// A/B knobs of the captured step (vlm_llm_set_tuning; measured defaults)
 struct Tuning {
-  int prefetch = 0, wgs = 256, mask = 0x7f, head_mb = 96, debug_skip = 0, fused_mlp = 0, mfma_gemv = 1;
+  int mfma_gemv = 1;
   int attn_pagesplit = 16;                // vlm_attn_decode_paged_split with up to this many workgroups per (row, kv head)
   int gemv_variant = 0;                   // A/B bits of the batch-1 GEMV launch shapes (VLM_TUNE_GEMV_VARIANT)
   int attn_merge = 1;                     // 1: one-row steps merge the page-split partials in the o_proj prologue
-  int tlb_touch = 0;                      // 1: the attention launch warms the translations of the layer's next weight streams
-};
-
-// the second branch of a captured step (prefetch side chain)
-struct Fork {
-  hipStream_t side = nullptr;
-  std::vector<hipEvent_t>* events = nullptr;
-  const VlmPfItem* items_dev = nullptr;   // persistent form: the device list (built before the capture starts)
-  int n_items = 0;
 };
 
 struct Llm {
   Tuning tune;
-  int* progress = nullptr;                // [0] pacing word, [1] exit counter of the persistent prefetcher (device)
   void* mfma_ws = nullptr;                // split-K partial tiles + tickets of the skinny-M decode GEMM (gemv_mfma.hip)
   unsigned* attn_tickets = nullptr;       // [4096] arrival words of the page-split decode attention (zero between launches)
   // bf16 scratch of the prefill GEMMs over 4-bit weights: ONE buffer PER STREAM (an admission prefill on the side stream
@@ -71,8 +59,6 @@ struct Llm {
   // each sized once for the largest matrix of the model - never grown, never freed while the engine lives
   struct WScratch { hipStream_t st; void* p; };
   std::vector<WScratch> wscratch;
-  char* fm_buf = nullptr;                 // fused-MLP hand-off buffers: [256 B err] then per layer [256 B epoch | D granules | I granules]
-  size_t fm_stride = 0;
   vlm_llm_config cfg;
   std::vector<vlm_llm_layer> layers;
   vlm_llm_globals g{};
@@ -102,14 +88,12 @@ inline bool same_key(const DecodeGraph& g, const vlm_decode_args& a, const vlm_k
          kv.kpool == g.kv.kpool &&
          kv.vpool == g.kv.vpool && kv.layer_stride == g.kv.layer_stride && kv.block_table == g.kv.block_table &&
          kv.max_pages == g.kv.max_pages && kv.kpool8 == g.kv.kpool8 && kv.vpool8 == g.kv.vpool8 && kv.ksb == g.kv.ksb &&
-         kv.vsb == g.kv.vsb;
+         kv.vsb == g.kv.vsb && kv.q8_skip_last == g.kv.q8_skip_last;
 }
 
 inline void drop_graph(DecodeGraph& g) {
   if (g.exec) (void)hipGraphExecDestroy(g.exec);
   if (g.graph) (void)hipGraphDestroy(g.graph);
-  if (g.pf_items) (void)hipFree(g.pf_items);
-  for (hipEvent_t e : g.events) (void)hipEventDestroy(e);
 }
 
 struct Vit {
@@ -122,7 +106,7 @@ inline char* off(void* p, size_t bytes) { return static_cast<char*>(p) + bytes; 
 
 }  // namespace
 
-extern "C" int vlm_abi_version(void) { return 4; }
+extern "C" int vlm_abi_version(void) { return 5; }
 
 // ------------------------------------------------------------------ LLM
 extern "C" int vlm_llm_create(const vlm_llm_config* cfg, void** handle) {
@@ -156,8 +140,6 @@ extern "C" int vlm_llm_destroy(void* handle) {
   Llm* m = static_cast<Llm*>(handle);
   if (!m) return 1;
   for (DecodeGraph& g : m->graphs) drop_graph(g);
-  if (m->progress) (void)hipFree(m->progress);
-  if (m->fm_buf) (void)hipFree(m->fm_buf);
   for (auto& ws : m->wscratch) (void)hipFree(ws.p);
   if (m->mfma_ws) (void)hipFree(m->mfma_ws);
   if (m->attn_tickets) (void)hipFree(m->attn_tickets);
@@ -170,37 +152,10 @@ extern "C" int vlm_llm_set_tuning(void* handle, int key, int value) {
   if (!m) return 1;
   int* slot = nullptr;
   switch (key) {
-    case VLM_TUNE_PREFETCH: if (value < 0 || value > 2) return 1; slot = &m->tune.prefetch; break;
-    case VLM_TUNE_PREFETCH_WGS: if (value <= 0 || value > 4096) return 1; slot = &m->tune.wgs; break;
-    case VLM_TUNE_PREFETCH_MASK: slot = &m->tune.mask; break;
-    case VLM_TUNE_PREFETCH_HEAD_MB: if (value < 0) return 1; slot = &m->tune.head_mb; break;
-    case VLM_TUNE_DEBUG_SKIP: slot = &m->tune.debug_skip; break;
     case VLM_TUNE_MFMA_GEMV: if (value < 0 || value > 1) return 1; slot = &m->tune.mfma_gemv; break;
     case VLM_TUNE_ATTN_PAGESPLIT: if (value < 0 || value > 32) return 1; slot = &m->tune.attn_pagesplit; break;
     case VLM_TUNE_GEMV_VARIANT: if (value < 0) return 1; slot = &m->tune.gemv_variant; break;
     case VLM_TUNE_ATTN_MERGE: if (value < 0 || value > 1) return 1; slot = &m->tune.attn_merge; break;
-    case VLM_TUNE_TLB_TOUCH: if (value < 0 || value > 3) return 1; slot = &m->tune.tlb_touch; break;
-    case VLM_TUNE_FUSED_MLP: {
-      if (value < 0 || value > 1) return 1;
-      slot = &m->tune.fused_mlp;
-      const vlm_llm_config& c = m->cfg;
-      if (value && !m->fm_buf) {
-        // one workgroup per CU, all resident: the in-launch hand-offs need the whole grid on the chip at once
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-          return 1000;
-        if (cus < 256 || !vlm_mlp_fused_supported(c.hidden, c.inter, c.n_heads * c.head_dim)) { value = 0; break; }
-        m->fm_stride = 256 + ((size_t)c.hidden + (size_t)c.inter) * 4;
-        m->fm_stride = (m->fm_stride + 255) & ~(size_t)255;
-        const size_t bytes = 256 + m->fm_stride * c.n_layers;
-        if (hipMalloc(&m->fm_buf, bytes) != hipSuccess) { m->fm_buf = nullptr; return 1008; }
-        if (hipMemset(m->fm_buf, 0, bytes) != hipSuccess) return 1009;
-        const unsigned one = 1;                      // launch epochs start at 1 (tag 0 = never written)
-        for (int i = 0; i < c.n_layers; ++i)
-          if (hipMemcpy(m->fm_buf + 256 + m->fm_stride * i, &one, 4, hipMemcpyHostToDevice) != hipSuccess) return 1010;
-      }
-      break;
-    }
     default: return 1;
   }
   if (key == VLM_TUNE_GEMV_VARIANT) vlm_gemv_set_variant(value);
@@ -212,40 +167,14 @@ extern "C" int vlm_llm_set_tuning(void* handle, int key, int value) {
   return 0;
 }
 
-extern "C" int vlm_llm_fused_error(void* handle) {
-  Llm* m = static_cast<Llm*>(handle);
-  if (!m) return -1;
-  if (!m->fm_buf) return 0;
-  unsigned e = 0;
-  if (hipDeviceSynchronize() != hipSuccess) return -2;
-  if (hipMemcpy(&e, m->fm_buf, 4, hipMemcpyDeviceToHost) != hipSuccess) return -2;
-  if (e) (void)hipMemset(m->fm_buf, 0, 4);
-  return (int)e;
-}
-
-// debug: the 16 phase stamps of the fused MLP launch (VLM_FUSED_STAMPS=1), microseconds; not part of the public header
-extern "C" int vlm_llm_debug_fused_stamps(void* handle, float* out16) {
-  Llm* m = static_cast<Llm*>(handle);
-  if (!m || !m->fm_buf || !out16) return 1;
-  if (hipDeviceSynchronize() != hipSuccess) return 2;
-  return hipMemcpy(out16, m->fm_buf + 64, 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
-}
-
 extern "C" int vlm_llm_get_tuning(void* handle, int key) {
   Llm* m = static_cast<Llm*>(handle);
   if (!m) return -1;
   switch (key) {
-    case VLM_TUNE_PREFETCH: return m->tune.prefetch;
-    case VLM_TUNE_PREFETCH_WGS: return m->tune.wgs;
-    case VLM_TUNE_PREFETCH_MASK: return m->tune.mask;
-    case VLM_TUNE_PREFETCH_HEAD_MB: return m->tune.head_mb;
-    case VLM_TUNE_DEBUG_SKIP: return m->tune.debug_skip;
-    case VLM_TUNE_FUSED_MLP: return m->tune.fused_mlp;
     case VLM_TUNE_MFMA_GEMV: return m->tune.mfma_gemv;
     case VLM_TUNE_ATTN_PAGESPLIT: return m->tune.attn_pagesplit;
     case VLM_TUNE_GEMV_VARIANT: return m->tune.gemv_variant;
     case VLM_TUNE_ATTN_MERGE: return m->tune.attn_merge;
-    case VLM_TUNE_TLB_TOUCH: return m->tune.tlb_touch;
     default: return -1;
   }
 }
@@ -354,46 +283,7 @@ extern "C" int vlm_llm_prefill(void* handle, const vlm_prefill_args* a, void* st
   return 0;
 }
 
-// what layer i streams, as a prefetch item (mask: bit 0 Wqkv, 1 Wo, 2 Wgu, 3 Wdown, 4 K/V pages)
-static VlmPfItem layer_item(const Llm* m, int i, int mask, int need) {
-  const vlm_llm_config& c = m->cfg;
-  const vlm_llm_layer& w = m->layers[i];
-  const size_t D = (size_t)c.hidden, QKV = (size_t)(c.n_heads + 2 * c.n_kv_heads) * c.head_dim;
-  VlmPfItem it{};
-  if (mask & 1) it.seg[it.nseg++] = VlmPfSeg{w.wqkv, QKV * D * 2};
-  if (mask & 2) it.seg[it.nseg++] = VlmPfSeg{w.wo, D * (size_t)c.n_heads * c.head_dim * 2};
-  if (mask & 4) it.seg[it.nseg++] = VlmPfSeg{w.wgu, 2 * (size_t)c.inter * D * 2};
-  if (mask & 8) it.seg[it.nseg++] = VlmPfSeg{w.wdown, (size_t)c.inter * D * 2};
-  if (mask & 16) {
-    it.kbase = off(m->kv.kpool, (size_t)i * m->kv.layer_stride * 2);
-    it.vbase = off(m->kv.vpool, (size_t)i * m->kv.layer_stride * 2);
-  }
-  it.need = need;
-  return it;
-}
-
-static VlmPfItem head_item(const Llm* m, int need) {
-  const vlm_llm_config& c = m->cfg;
-  VlmPfItem it{};
-  size_t bytes = (size_t)c.vocab * c.hidden * 2, cap = (size_t)m->tune.head_mb << 20;
-  it.seg[it.nseg++] = VlmPfSeg{m->g.lm_head, bytes < cap ? bytes : cap};
-  it.need = need;
-  return it;
-}
-
-// the walk list of the persistent prefetcher: item for layer i >= 1 starts once layer i - 1's attention is done (pacing
-// word == i); then the first lm_head rows during the last layer; then layer 0 of the NEXT step once the sampler tail
-// has started (word == n_layers + 1)
-static std::vector<VlmPfItem> persistent_items(const Llm* m) {
-  const int NL = m->cfg.n_layers, mask = m->tune.mask;
-  std::vector<VlmPfItem> items;
-  for (int i = 1; i < NL; ++i) items.push_back(layer_item(m, i, mask, i));
-  if (mask & 32) items.push_back(head_item(m, NL));
-  if (mask & 64) items.push_back(layer_item(m, 0, mask, NL + 1));
-  return items;
-}
-
-static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* launches, bool sample, Fork* fork) {
+static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* launches, bool sample) {
   const vlm_llm_config& c = m->cfg;
   const int D = c.hidden, hd = c.head_dim, Hq = c.n_heads, Hkv = c.n_kv_heads, B = a->B, NL = c.n_layers;
   const int QKV = (Hq + 2 * Hkv) * hd;
@@ -402,41 +292,18 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
   const bool fused_tail = sample && (a->flags & VLM_DECODE_FUSED_TAIL) && a->temperature == 0.f;
   if ((a->flags & VLM_DECODE_FUSED_TAIL) && !fused_tail) return 1;   // the flag promises h == embed[tok] at entry
   const Tuning& tn = m->tune;
-  const int skip = tn.debug_skip;      // measurement only
   // WIDE steps (more than 16 rows): beyond one N tile of the skinny-M MFMA GEMM the projections run on the prefill GEMMs,
   // i.e. a layer is the prefill's launch sequence (vlm_llm_prefill above) with the paged decode attention in place of
   // the flash attention: RMSNorm -> qkv GEMM + bias -> M-RoPE + KV write at slot ctx[b] -> attention over the pages ->
   // o_proj GEMM + residual -> RMSNorm -> gate/up GEMM + SwiGLU -> down GEMM + residual.  Measured per 7B layer
   // (profiles/r03_mfma_shapes.txt D): 192.6 us at 32 rows, 210 at 64 - against 120 per 16-row step.  The normalised rows
-  // borrow the attention output buffer (free before the qkv GEMM and again after o_proj).  Not for two-table RoPE models
-  // (SuScaledRoPE's per-call regime is decided in the fused qkv kernel from the rows' device-resident offsets).
+  // borrow the attention output buffer (free before the qkv GEMM and again after o_proj).  Two-table RoPE models
+  // (SuScaledRoPE): the per-call regime (rope_utils.py:168-172) reaches vlm_mrope_kvwrite_scaled as `long_from`, decided on
+  // the device from the rows' slots exactly as the fused qkv kernels of the <= 16-row steps do.
   const bool wide = B > 16;
-  if (wide && (!m->kv.block_table || c.rope_long_from > 0 || Hq * hd < D || B > 64)) return 1;
+  if (wide && (!m->kv.block_table || Hq * hd < D || B > 64)) return 1;
   void* const xn = a->attn;
-  const int pf = (fork && fork->side && m->progress && B <= 8) ? tn.prefetch : 0;
-  const VlmPfKv pfkv{(const int*)a->ctx, (const int*)m->kv.block_table, m->kv.max_pages, B,
-                     (size_t)Hkv * hd * 64 * 2};
-  hipStream_t main_s = (hipStream_t)stream;
   int n = 0;
-  auto new_event = [&](hipEvent_t* e) -> int {
-    hipError_t r = hipEventCreateWithFlags(e, hipEventDisableTiming);
-    if (r != hipSuccess) return 1000 + (int)r;
-    fork->events->push_back(*e);
-    return 0;
-  };
-  // edge chain -> side branch: everything enqueued on the chain so far precedes what the side stream does next
-  auto edge_to_side = [&]() -> int {
-    hipEvent_t e;
-    TRY(new_event(&e));
-    if (hipEventRecord(e, main_s) != hipSuccess) return 1001;
-    if (hipStreamWaitEvent(fork->side, e, 0) != hipSuccess) return 1002;
-    return 0;
-  };
-  if (pf) TRY(edge_to_side());          // fork: the side stream joins the capture
-  if (pf == 2 && fork->n_items > 0) {
-    TRY(vlm_prefetch_persistent_launch(fork->items_dev, fork->n_items, &pfkv, m->progress, (unsigned*)(m->progress + 1),
-                                       tn.wgs, fork->side)); ++n;
-  }
   // h = embed[tok]
   if (!fused_tail) {
     if (m->g.embed_sb) { TRY(vlm_dequant_w4(m->g.embed, m->g.embed_sb, a->tok, a->h, B, D, D, c.vocab, stream)); }
@@ -453,23 +320,22 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
     if (wide) {
       TRY(vlm_rmsnorm_residual(a->h, nullptr, w.ln1_w, xn, nullptr, B, D, c.rms_eps, stream));
       TRY(lin_gemm(m, xn, w.wqkv, w.wqkv_sb, w.bqkv, nullptr, a->qkv, B, QKV, D, QKV, 0, VLM_EPI_BIAS, stream));
-      TRY(vlm_mrope_kvwrite_scaled(a->qkv, QKV, B, Hq, Hkv, hd, a->pos, a->pos, a->pos, m->g.inv_freq, c.mrope_sec0, c.mrope_sec1,
-                                   nullptr, a->ctx, m->kv.block_table, m->kv.max_pages, kp, vp, qk_scale, stream));
+      TRY(vlm_mrope_kvwrite_decode(a->qkv, QKV, B, Hq, Hkv, hd, a->pos, m->g.inv_freq, c.mrope_sec0, c.mrope_sec1, a->ctx,
+                                   m->kv.block_table, m->kv.max_pages, kp, vp, qk_scale, c.rope_long_from, stream));
       n += 3;
-    } else if (!(skip & 1)) {
-    if (w.wqkv_sb) {
+    } else if (w.wqkv_sb) {
       TRY(vlm_gemv_w4_qkv_rope_kvwrite_ex(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.wqkv_sb, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos,
                                           a->ctx, m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, m->tune.mfma_gemv,
                                           m->mfma_ws, qk_scale, c.rope_long_from, stream)); ++n;
     } else {
-    TRY(vlm_gemv_qkv_rope_kvwrite_ex(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos, a->ctx,
-                                     m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, m->tune.mfma_gemv, m->mfma_ws,
-                                     qk_scale, c.rope_long_from, stream)); ++n;
-    }
+      TRY(vlm_gemv_qkv_rope_kvwrite_ex(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos, a->ctx,
+                                       m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, m->tune.mfma_gemv, m->mfma_ws,
+                                       qk_scale, c.rope_long_from, stream)); ++n;
     }
     // attention over the pages (the new token is already in the cache: kv_len = ctx + 1)
-    const bool combine = w.wo_sb != nullptr || Hq * hd > 3584;
-    const VlmProgress prog{pf == 2 ? m->progress : nullptr, i + 1};
+    // combine: the split partials are merged by the attention side (combine kernel / last arriver) into a->attn - 4-bit Wo,
+    // bf16 Wo wider than the row-wave GEMV's prologue, and EVERY wide step (its o_proj is a GEMM over a->attn)
+    const bool combine = wide || w.wo_sb != nullptr || Hq * hd > 3584;
     // few (row, kv head) pairs: the page-split form - one wave per page stride over up to 256 CUs, the last arriver
     // writes the final vector (part_o / part_ml are sized for 32 splits by the caller)
     int psplit = 0;
@@ -478,8 +344,10 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
       if (psplit > 256 / (B * Hkv)) psplit = 256 / (B * Hkv);
       if (psplit < 2) psplit = 0;
     }
-    // uniform 8-bit KV cache (vlm_kv_pool.kpool8): every step attends over the 8-bit pools; the launch quantises the new token
-    const bool q8 = m->kv.kpool8 != nullptr;
+    // uniform 8-bit KV cache (vlm_kv_pool.kpool8): the step attends over the 8-bit pools; the launch quantises the new token.
+    // q8_skip_last (ABI v5): the reference's BATCH policy keeps the last layer of a stack deeper than 2 on the unquantised
+    // cache (models/cache.py:8-21)
+    const bool q8 = m->kv.kpool8 != nullptr && !(m->kv.q8_skip_last && NL > 2 && i == NL - 1);
     if (q8) {
       if (!m->attn_tickets || !m->kv.vpool8 || !m->kv.ksb || !m->kv.vsb) return 1;
       psplit = a->nsplit > 1 ? 32 : 16;
@@ -488,59 +356,27 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
     }
     // ... and for ONE row over bf16 Wo the merge moves into the o_proj prologue: the attention launch ends at its partial
     // stores (no ticket, no last-arriver pass)
-    const bool merge_in_oproj = psplit && tn.attn_merge && B == 1 && !w.wo_sb && Hq * hd <= 2048 && psplit <= 16 &&
-                                !(tn.fused_mlp && m->fm_buf);
-    if (skip & 2) {
-    } else if (q8) {
+    const bool merge_in_oproj = psplit && tn.attn_merge && B == 1 && !w.wo_sb && Hq * hd <= 2048 && psplit <= 16;
+    if (q8) {
       const size_t lo = (size_t)i * m->kv.layer_stride;                   // elements == bytes of the u8 pools
       TRY(vlm_attn_decode_paged_q8(a->qkv, QKV, kp, vp, off(m->kv.kpool8, lo), off(m->kv.vpool8, lo),
                                    off(m->kv.ksb, lo / (hd / 2) * 4), off(m->kv.vsb, lo / (hd / 2) * 4), m->kv.block_table,
                                    m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale, psplit, a->part_o, a->part_ml, m->attn_tickets,
                                    merge_in_oproj ? nullptr : a->attn, Hq * hd, 1, stream)); ++n;
     } else if (psplit) {
-      // (bf16 layers) the launch also warms the address translations of what the layer streams next
-      const void* tp[4] = {w.wo, w.wgu, w.wdown, i + 1 < NL ? m->layers[i + 1].wqkv : m->g.lm_head};
-      const size_t tb[4] = {(size_t)D * Hq * hd * 2, (size_t)2 * c.inter * D * 2, (size_t)c.inter * D * 2,
-                            i + 1 < NL ? (size_t)QKV * D * 2 : (size_t)64 << 20};
-      const int nt = (tn.tlb_touch && !w.wo_sb && !w.wgu_sb && !w.wdown_sb) ? ((tn.tlb_touch & 2) ? 4 : 3) : 0;
-      TRY(vlm_attn_decode_paged_split_ex(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale,
-                                         psplit, a->part_o, a->part_ml, m->attn_tickets, merge_in_oproj ? nullptr : a->attn,
-                                         Hq * hd, tp, tb, nt, prog, stream)); ++n;
+      TRY(vlm_attn_decode_paged_split(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale,
+                                      psplit, a->part_o, a->part_ml, m->attn_tickets, merge_in_oproj ? nullptr : a->attn,
+                                      Hq * hd, stream)); ++n;
     } else if (a->nsplit == 1) {
       // short contexts: one workgroup per (sequence, kv head) -> final bf16 vector, plain o_proj GEMV + residual
-      TRY(vlm_attn_decode_paged_ex(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale, 1,
-                                   a->part_o, a->part_ml, a->attn, Hq * hd, prog, stream)); ++n;
+      TRY(vlm_attn_decode_paged(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale, 1,
+                                a->part_o, a->part_ml, a->attn, Hq * hd, stream)); ++n;
     } else {
       // long contexts: split-K partials, merged in the o_proj GEMV prologue (bf16 Wo up to 3584 columns: the row-wave
-      // kernel) or by the combine kernel (4-bit Wo; wider bf16 Wo, e.g. 32 heads x 128)
-      TRY(vlm_attn_decode_paged_ex(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale,
-                                   a->nsplit, a->part_o, a->part_ml, combine ? a->attn : nullptr, combine ? Hq * hd : 0, prog,
-                                   stream)); ++n;
-    }
-    if (pf == 1) {
-      // the layer's weight stream (o_proj, gate/up, down: ~20 us) starts here; the side branch pulls the NEXT layer in
-      // the meantime.  Last layer: the first lm_head rows.
-      VlmPfItem it{};
-      if (i + 1 < NL) it = layer_item(m, i + 1, tn.mask, 0);
-      else if (tn.mask & 32) it = head_item(m, 0);
-      if (it.nseg > 0 || it.kbase) {
-        TRY(edge_to_side());
-        TRY(vlm_prefetch_launch(&it, &pfkv, tn.wgs, fork->side)); ++n;
-      }
-    }
-    const bool fused_mlp = tn.fused_mlp && m->fm_buf && B == 1 && (psplit || a->nsplit == 1) && !(skip & (4 | 8 | 16)) && !w.wo_sb &&
-                           !w.wgu_sb && !w.wdown_sb;
-    if (fused_mlp) {
-      // o_proj + residual, RMSNorm + gate/up + SwiGLU, down + residual: one launch, two in-launch hand-offs
-      char* lb = m->fm_buf + 256 + m->fm_stride * (size_t)i;
-      // debug timeline (VLM_FUSED_STAMPS=1): workgroup 0 of the LAST layer's launch stamps its phases into fm_buf + 64
-      static const bool want_stamps = getenv("VLM_FUSED_STAMPS") != nullptr;
-      const char* fm = getenv("VLM_FUSED_MODE");     // measurement knobs of the fused launch (csrc/mlp_fused.hip)
-      const int fmode = fm ? (int)strtol(fm, nullptr, 0) : 0;
-      TRY(vlm_mlp_fused_launch(a->attn, a->h, w.wo, w.ln2_w, w.wgu, w.wdown, lb + 256, lb + 256 + (size_t)D * 4, lb, m->fm_buf,
-                               c.rms_eps, D, c.inter, Hq * hd, (want_stamps && i == NL - 1) ? m->fm_buf + 64 : nullptr,
-                               fmode, stream)); ++n;
-      continue;
+      // kernel) or by the combine kernel (4-bit Wo; wider bf16 Wo, e.g. 32 heads x 128; wide steps)
+      TRY(vlm_attn_decode_paged(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, B, Hq, Hkv, hd, scale,
+                                a->nsplit, a->part_o, a->part_ml, combine ? a->attn : nullptr, combine ? Hq * hd : 0,
+                                stream)); ++n;
     }
     if (wide) {
       TRY(lin_gemm(m, a->attn, w.wo, w.wo_sb, nullptr, a->h, a->h, B, D, Hq * hd, D, D, VLM_EPI_RESIDUAL, stream));
@@ -550,8 +386,7 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
       n += 4;
       continue;
     }
-    if (skip & 4) {
-    } else if (merge_in_oproj) {
+    if (merge_in_oproj) {
       TRY(vlm_gemv_attn_out_bf16(a->part_o, a->part_ml, psplit, w.wo, a->h, D, D, Hq, hd, stream)); ++n;
     } else if (psplit || a->nsplit == 1 || combine) {
       TRY(lin_gemv(m, a->attn, w.wo, w.wo_sb, nullptr, a->h, nullptr, a->h, B, D, Hq * hd, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
@@ -559,10 +394,8 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
       TRY(vlm_gemv_attn_out(a->part_o, a->part_ml, a->nsplit, w.wo, a->h, D, B, D, Hq, hd, stream)); ++n;
     }
     // act = swiglu(RMSNorm(h) Wgu^T)
-    if (!(skip & 8))
     TRY(lin_gemv(m, a->h, w.wgu, w.wgu_sb, nullptr, nullptr, w.ln2_w, a->act, B, 2 * c.inter, D, c.inter, 0, c.rms_eps, VLM_EPI_SWIGLU, stream)); ++n;
     // h = h + act Wdown^T
-    if (!(skip & 16))
     TRY(lin_gemv(m, a->act, w.wdown, w.wdown_sb, nullptr, a->h, nullptr, a->h, B, D, c.inter, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
   }
   // logits = RMSNorm(h) lm_head^T
@@ -572,38 +405,23 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
     TRY(vlm_rmsnorm_residual(a->h, nullptr, m->g.final_norm_w, xn, nullptr, B, D, c.rms_eps, stream));
     TRY(lin_gemm(m, xn, m->g.lm_head, m->g.lm_head_sb, nullptr, nullptr, a->logits, B, VL, D, VL, 0, VLM_EPI_NONE, stream));
     n += 2;
-  } else if (!(skip & 32)) {
-  TRY(lin_gemv(m, a->h, m->g.lm_head, m->g.lm_head_sb, nullptr, nullptr, m->g.final_norm_w, a->logits, B, c.vocab, D, VL, 0,
-               c.rms_eps, VLM_EPI_NONE, stream)); ++n;
+  } else {
+    TRY(lin_gemv(m, a->h, m->g.lm_head, m->g.lm_head_sb, nullptr, nullptr, m->g.final_norm_w, a->logits, B, c.vocab, D, VL, 0,
+                 c.rms_eps, VLM_EPI_NONE, stream)); ++n;
   }
   if (sample && a->penalties) {
     // logits processors (ar.py:360-364): the fed token joins the history, then bias / penalties on the step's logits
     TRY(vlm_apply_logit_penalties(a->logits, VL, B, c.vocab, a->tok, a->penalties, stream)); ++n;
   }
-  if (sample && !(skip & 64)) {
-    if (pf == 1 && (tn.mask & 64)) {
-      // the sampler tail moves 0.3 MB: pull layer 0 for the next step while it runs
-      const VlmPfItem it = layer_item(m, 0, tn.mask, 0);
-      TRY(edge_to_side());
-      TRY(vlm_prefetch_launch(&it, &pfkv, tn.wgs, fork->side)); ++n;
-    }
-    const VlmProgress tail_prog{pf == 2 ? m->progress : nullptr, NL + 1};
+  if (sample) {
     if (fused_tail) {
-      TRY(vlm_sample_greedy_advance_ex(a->logits, VL, B, c.vocab, a->logprobs, VL, a->tok, a->sample_ws, a->ctx,
-                                       a->pos, a->out_ring, a->ring_len, a->step, m->g.embed, a->h, D, D, tail_prog,
-                                       stream)); n += 2;
+      TRY(vlm_sample_greedy_advance(a->logits, VL, B, c.vocab, a->logprobs, VL, a->tok, a->sample_ws, a->ctx, a->pos,
+                                    a->out_ring, a->ring_len, a->step, m->g.embed, a->h, D, D, stream)); n += 2;
     } else {
-      TRY(vlm_sample_ex(a->logits, VL, B, c.vocab, a->logprobs, a->scratch, VL, a->tok, a->sample_ws, a->temperature,
-                        a->top_p, a->min_p, a->top_k, a->seed, a->step, tail_prog, stream)); n += 3;
+      TRY(vlm_sample(a->logits, VL, B, c.vocab, a->logprobs, a->scratch, VL, a->tok, a->sample_ws, a->temperature, a->top_p,
+                     a->min_p, a->top_k, a->seed, a->step, stream)); n += 3;
       TRY(vlm_decode_advance(a->ctx, a->pos, a->tok, a->out_ring, a->ring_len, a->step, B, stream)); ++n;
     }
-  }
-  if (pf) {
-    // join: the capture ends on the chain's stream with the side branch folded back in
-    hipEvent_t e;
-    TRY(new_event(&e));
-    if (hipEventRecord(e, fork->side) != hipSuccess) return 1005;
-    if (hipStreamWaitEvent(main_s, e, 0) != hipSuccess) return 1006;
   }
   if (launches) *launches = n;
   return 0;
@@ -612,7 +430,7 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
 extern "C" int vlm_llm_decode_step(void* handle, const vlm_decode_args* a, void* stream) {
   Llm* m = static_cast<Llm*>(handle);
   if (!m || !a || a->B <= 0 || !m->kv.kpool) return 1;
-  return decode_impl(m, a, stream, &m->launches, true, nullptr);
+  return decode_impl(m, a, stream, &m->launches, true);
 }
 
 // embeddings -> logits only (the module-contract path: language_model(y, cache=...) at L == 1;
@@ -620,7 +438,7 @@ extern "C" int vlm_llm_decode_step(void* handle, const vlm_decode_args* a, void*
 extern "C" int vlm_llm_decode_forward(void* handle, const vlm_decode_args* a, void* stream) {
   Llm* m = static_cast<Llm*>(handle);
   if (!m || !a || a->B <= 0 || !m->kv.kpool) return 1;
-  return decode_impl(m, a, stream, nullptr, false, nullptr);
+  return decode_impl(m, a, stream, nullptr, false);
 }
 
 extern "C" int vlm_llm_decode_graph_build(void* handle, const vlm_decode_args* a, void* stream) {
@@ -643,41 +461,18 @@ extern "C" int vlm_llm_decode_graph_build(void* handle, const vlm_decode_args* a
   hipError_t e = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking);
   if (e != hipSuccess) return 1000 + (int)e;
   DecodeGraph ng{a->penalties ? *a->penalties : vlm_penalty_args{}, *a, m->kv, nullptr, nullptr, 0, ++m->tick};
-  hipStream_t side = nullptr;
-  if (m->tune.prefetch) {
-    if (!m->progress) {
-      if (hipMalloc(&m->progress, 256) != hipSuccess || hipMemset(m->progress, 0, 256) != hipSuccess) return 1007;
-    }
-    e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
-    if (e != hipSuccess) { (void)hipStreamDestroy(cap); return 1000 + (int)e; }
-  }
-  Fork fork{side, &ng.events, nullptr, 0};
-  if (m->tune.prefetch == 2) {
-    // device allocations are not allowed inside a capture: the list is built first
-    const std::vector<VlmPfItem> items = persistent_items(m);
-    if (!items.empty()) {
-      if (hipMalloc(&ng.pf_items, items.size() * sizeof(VlmPfItem)) != hipSuccess ||
-          hipMemcpy(ng.pf_items, items.data(), items.size() * sizeof(VlmPfItem), hipMemcpyHostToDevice) != hipSuccess) {
-        drop_graph(ng); (void)hipStreamDestroy(cap); (void)hipStreamDestroy(side);
-        return 1003;
-      }
-      fork.items_dev = ng.pf_items;
-      fork.n_items = (int)items.size();
-    }
-  }
   // wide steps run split-K GEMMs: the capture stream borrows the launch stream's workspace (the replays are ordered there)
   const bool wide = a->B > 16;
-  if (wide && vlm_gemm_splitk_share(stream, (void*)cap) != 0) { drop_graph(ng); (void)hipStreamDestroy(cap); if (side) (void)hipStreamDestroy(side); return 1008; }
+  if (wide && vlm_gemm_splitk_share(stream, (void*)cap) != 0) { (void)hipStreamDestroy(cap); return 1008; }
   e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) {
     if (wide) vlm_gemm_splitk_unshare((void*)cap);
-    drop_graph(ng); (void)hipStreamDestroy(cap); if (side) (void)hipStreamDestroy(side); return 1000 + (int)e;
+    (void)hipStreamDestroy(cap); return 1000 + (int)e;
   }
-  int rc = decode_impl(m, a, (void*)cap, &ng.launches, true, side ? &fork : nullptr);
+  int rc = decode_impl(m, a, (void*)cap, &ng.launches, true);
   e = hipStreamEndCapture(cap, &ng.graph);
   if (wide) vlm_gemm_splitk_unshare((void*)cap);
   (void)hipStreamDestroy(cap);
-  if (side) (void)hipStreamDestroy(side);
   if (rc != 0) { drop_graph(ng); return rc; }
   if (e != hipSuccess) { drop_graph(ng); return 1000 + (int)e; }
   e = hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0);

@@ -753,13 +753,13 @@ int launch256(const void* A, const void* W, const void* bias, const void* res, v
 
 }  // namespace
 
-void vlm_gemm256_set_variant(int v) { g_variant = v; }
-void vlm_gemm256_set_nf(int nf) { g_nf = nf; }
-void vlm_gemm256_set_persist(int p) { g_persist = p; }
+__attribute__((visibility("hidden"))) void vlm_gemm256_set_variant(int v) { g_variant = v; }
+__attribute__((visibility("hidden"))) void vlm_gemm256_set_nf(int nf) { g_nf = nf; }
+__attribute__((visibility("hidden"))) void vlm_gemm256_set_persist(int p) { g_persist = p; }
 
 // Internal entry (C++ linkage, called by vlm_gemm_bf16's dispatcher).  Returns -1 when the shape / epilogue is not
 // one this kernel takes (the caller then uses the 128x128 kernel).  Needs K % 64 == 0, K >= 128, N % 8 == 0.
-int vlm_gemm256_try(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
+__attribute__((visibility("hidden"))) int vlm_gemm256_try(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
                     int lda, int ldw, int ldc, int ldres, int epilogue, void* stream) {
   if (K % BK != 0 || K < 2 * BK || N < 8) return -1;
   hipStream_t st = (hipStream_t)stream;

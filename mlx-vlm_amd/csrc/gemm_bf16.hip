@@ -25,12 +25,12 @@
 #include "../../include/vlm_hip.h"
 
 // gemm256_bf16.hip: the 256x256 phased kernel (-1: shape / epilogue not taken)
-int vlm_gemm256_try(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
+__attribute__((visibility("hidden"))) int vlm_gemm256_try(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
                     int lda, int ldw, int ldc, int ldres, int epilogue, void* stream);
 
-void vlm_gemm256_set_variant(int v);
-void vlm_gemm256_set_nf(int nf);
-void vlm_gemm256_set_persist(int p);
+__attribute__((visibility("hidden"))) void vlm_gemm256_set_variant(int v);
+__attribute__((visibility("hidden"))) void vlm_gemm256_set_nf(int nf);
+__attribute__((visibility("hidden"))) void vlm_gemm256_set_persist(int p);
 
 namespace {
 

@@ -66,8 +66,16 @@ __global__ __launch_bounds__(256) void mrope_kvwrite_kernel(
     bf16_t* __restrict__ qkv, int ld, int T, int Hq, int Hkv, int D, const int* __restrict__ pos_t,
     const int* __restrict__ pos_h, const int* __restrict__ pos_w, const float* __restrict__ inv_freq, int sec0, int sec1,
     const int* __restrict__ kv_seq, const int* __restrict__ kv_slot, const int* __restrict__ block_table, int max_pages,
-    bf16_t* __restrict__ kpool, bf16_t* __restrict__ vpool, float qk_scale) {
+    bf16_t* __restrict__ kpool, bf16_t* __restrict__ vpool, float qk_scale, int long_from) {
   const int half = D >> 1, cph = half >> 3;
+  // SuScaledRoPE's per-call regime decided on the device (decode steps: T <= 64 rows, kv_slot = the rows' cache offsets):
+  // inv_freq holds [2][D/2] (short, long) and the LONG row applies to EVERY row of the call when ANY row's offset has
+  // reached original_max_position_embeddings (rope_utils.py:168-172) - the rule of the fused qkv kernels of gemv_*.hip
+  if (long_from > 0) {
+    bool any_long = false;
+    for (int r = 0; r < T; ++r) any_long |= kv_slot[r] >= long_from;
+    if (any_long) inv_freq += half;
+  }
   const int rot_items = (Hq + Hkv) * cph;      // rotary chunks per token
   const int v_items = Hkv * (D >> 3);          // v copy chunks per token
   const int per_tok = rot_items + v_items;
@@ -206,7 +214,25 @@ extern "C" int vlm_mrope_kvwrite_scaled(void* qkv, int ld, int T, int Hq, int Hk
   hipLaunchKernelGGL(mrope_kvwrite_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (bf16_t*)qkv, ld, T, Hq, Hkv, D, (const int*)pos_t, (const int*)pos_h, (const int*)pos_w,
                      (const float*)inv_freq, sec0, sec1, (const int*)kv_seq, (const int*)kv_slot,
-                     (const int*)block_table, max_pages, (bf16_t*)kpool, (bf16_t*)vpool, qk_scale);
+                     (const int*)block_table, max_pages, (bf16_t*)kpool, (bf16_t*)vpool, qk_scale, 0);
+  VLM_CHECK_LAUNCH();
+  return VLM_OK;
+}
+
+// decode form (library-internal, csrc/engine.hip's wide steps): row b = one decoded token at text position pos[b] (all three
+// M-RoPE axes equal), written at slot[b] of block-table row b; long_from > 0: inv_freq = [2][D/2] and the call-wide regime
+// is decided from the slots on the device, so a captured wide step crosses the limit without host help
+int vlm_mrope_kvwrite_decode(void* qkv, int ld, int B, int Hq, int Hkv, int D, const void* pos, const void* inv_freq, int sec0,
+                             int sec1, const void* slot, const void* block_table, int max_pages, void* kpool, void* vpool,
+                             float qk_scale, int long_from, void* stream) {
+  if (!qkv || !pos || !inv_freq || !slot || !block_table || !kpool || !vpool || B <= 0 || B > 64 || Hq <= 0 || Hkv <= 0 || max_pages <= 0)
+    return VLM_ERR_ARG;
+  if (D % 16 != 0 || ld % 8 != 0) return VLM_ERR_SHAPE;
+  const long total = (long)B * ((Hq + Hkv) * (D / 16) + Hkv * (D / 8));
+  hipLaunchKernelGGL(mrope_kvwrite_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (bf16_t*)qkv, ld, B, Hq, Hkv, D, (const int*)pos, (const int*)pos, (const int*)pos, (const float*)inv_freq,
+                     sec0, sec1, (const int*)nullptr, (const int*)slot, (const int*)block_table, max_pages, (bf16_t*)kpool,
+                     (bf16_t*)vpool, qk_scale, long_from);
   VLM_CHECK_LAUNCH();
   return VLM_OK;
 }

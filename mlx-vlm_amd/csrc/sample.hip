@@ -23,12 +23,9 @@ __device__ __forceinline__ uint32_t bf_key(bf16_t b) { return (b & 0x8000u) ? (u
 __device__ __forceinline__ bf16_t key_bf(uint32_t k) { return (k & 0x8000u) ? (bf16_t)(k & 0x7fffu) : (bf16_t)(~k & 0xffffu); }
 
 __global__ __launch_bounds__(256) void lse_partial_kernel(const bf16_t* __restrict__ logits, int ld, int V,
-                                                          float* __restrict__ ws, VlmProgress prog) {
+                                                          float* __restrict__ ws) {
   __shared__ float red[16];
   const int b = blockIdx.y, blk = blockIdx.x;
-  // pacing word of the weight prefetcher: "the sampler tail has started" (the HBM is idle from here to the next step)
-  if (prog.word && blk == 0 && b == 0 && threadIdx.x == 0)
-    __hip_atomic_store(prog.word, prog.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int per = ((V + NBLK - 1) / NBLK + 7) & ~7;
   const int lo = blk * per, hi = min(V, lo + per);
   const bf16_t* row = logits + (size_t)b * ld;
@@ -484,9 +481,9 @@ extern "C" size_t vlm_sample_workspace_bytes(int B) { return (size_t)B * (NBLK *
 // workspace layout: 256 B arrival ticket of the fused greedy tail (must be zero at allocation; the kernel re-arms it; at a
 // fixed offset so that a step over the first B' < B rows of a state finds the same word) |
 // [B][NBLK][2] f32 lse partials | [B][NBLK] f32 cand_v | [B][NBLK] i32 cand_i | [B][65536] u32 hist
-int vlm_sample_ex(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
-                  void* workspace, float temperature, float top_p, float min_p, int top_k, unsigned seed,
-                  const void* step_ptr, VlmProgress prog, void* stream) {
+extern "C" int vlm_sample(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
+                          void* workspace, float temperature, float top_p, float min_p, int top_k, unsigned seed,
+                          const void* step_ptr, void* stream) {
   if (!logits || !tok || !workspace || B <= 0 || V <= 0) return VLM_ERR_ARG;
   if (temperature < 0.f) return VLM_ERR_ARG;
   if (temperature > 0.f && (!logprobs || !scratch)) return VLM_ERR_ARG;
@@ -495,7 +492,7 @@ int vlm_sample_ex(const void* logits, int ld, int B, int V, void* logprobs, void
   float* cand_v = ws + (size_t)B * NBLK * 2;
   int* cand_i = (int*)(cand_v + (size_t)B * NBLK);
   uint32_t* hist = (uint32_t*)(cand_i + (size_t)B * NBLK);
-  hipLaunchKernelGGL(lse_partial_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws, prog);
+  hipLaunchKernelGGL(lse_partial_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws);
   VLM_CHECK_LAUNCH();
   hipLaunchKernelGGL(logprob_argmax_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws,
                      (bf16_t*)logprobs, ldlp, cand_v, cand_i);
@@ -510,16 +507,11 @@ int vlm_sample_ex(const void* logits, int ld, int B, int V, void* logprobs, void
   return VLM_OK;
 }
 
-extern "C" int vlm_sample(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
-                          void* workspace, float temperature, float top_p, float min_p, int top_k, unsigned seed,
-                          const void* step_ptr, void* stream) {
-  return vlm_sample_ex(logits, ld, B, V, logprobs, scratch, ldlp, tok, workspace, temperature, top_p, min_p, top_k, seed,
-                       step_ptr, VlmProgress{nullptr, 0}, stream);
-}
-
-int vlm_sample_greedy_advance_ex(const void* logits, int ld, int B, int V, void* logprobs, int ldlp, void* tok,
-                                 void* workspace, void* ctx, void* pos, void* out_ring, int ring_len, void* step,
-                                 const void* embed, void* h, int D, int ldh, VlmProgress prog, void* stream) {
+/* greedy tail of the decode step in two launches: vlm_sample (temperature 0) + vlm_decode_advance + the next step's
+ * vlm_embed_gather (see logprob_argmax_tail_kernel) */
+extern "C" int vlm_sample_greedy_advance(const void* logits, int ld, int B, int V, void* logprobs, int ldlp, void* tok,
+                                         void* workspace, void* ctx, void* pos, void* out_ring, int ring_len, void* step,
+                                         const void* embed, void* h, int D, int ldh, void* stream) {
   if (!logits || !tok || !workspace || !ctx || !pos || !step || !embed || !h || B <= 0 || V <= 0) return VLM_ERR_ARG;
   if (B > TAIL_MAX_B || D % 8 || ldh % 8) return VLM_ERR_SHAPE;
   if (out_ring && ring_len <= 0) return VLM_ERR_ARG;
@@ -528,22 +520,13 @@ int vlm_sample_greedy_advance_ex(const void* logits, int ld, int B, int V, void*
   float* ws = (float*)((char*)workspace + 256);
   float* cand_v = ws + (size_t)B * NBLK * 2;
   int* cand_i = (int*)(cand_v + (size_t)B * NBLK);
-  hipLaunchKernelGGL(lse_partial_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws, prog);
+  hipLaunchKernelGGL(lse_partial_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws);
   VLM_CHECK_LAUNCH();
   hipLaunchKernelGGL(logprob_argmax_tail_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws,
                      (bf16_t*)logprobs, ldlp, cand_v, cand_i, ticket, (int*)tok, (int*)ctx, (int*)pos, (int*)out_ring, ring_len,
                      (int*)step, (const bf16_t*)embed, (bf16_t*)h, D, ldh, B);
   VLM_CHECK_LAUNCH();
   return VLM_OK;
-}
-
-/* greedy tail of the decode step in two launches: vlm_sample (temperature 0) + vlm_decode_advance + the next step's
- * vlm_embed_gather (see logprob_argmax_tail_kernel) */
-extern "C" int vlm_sample_greedy_advance(const void* logits, int ld, int B, int V, void* logprobs, int ldlp, void* tok,
-                                         void* workspace, void* ctx, void* pos, void* out_ring, int ring_len, void* step,
-                                         const void* embed, void* h, int D, int ldh, void* stream) {
-  return vlm_sample_greedy_advance_ex(logits, ld, B, V, logprobs, ldlp, tok, workspace, ctx, pos, out_ring, ring_len, step,
-                                      embed, h, D, ldh, VlmProgress{nullptr, 0}, stream);
 }
 
 extern "C" int vlm_apply_logit_penalties(void* logits, int ld, int B, int V, const void* push_tok, const vlm_penalty_args* p,

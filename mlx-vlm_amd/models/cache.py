@@ -76,7 +76,16 @@ class KVPool:
         self.max_pages = max_pages_per_seq or self.n_pages
         page_bytes = 2 * n_layers * n_kv_heads * PAGE * head_dim * torch.empty((), dtype=dtype).element_size()
         if layout == "auto":
-            layout = "identity" if max_seqs * self.max_pages * page_bytes <= self.IDENTITY_BUDGET else "paged"
+            # ... and never more than a third of what the DEVICE has free right now (weights are already resident when the
+            # pool is built; ensure_q8 may later add half of it again; several ranks per GPU or a small part must fall
+            # back to the shared free list instead of failing at load)
+            budget = self.IDENTITY_BUDGET
+            try:
+                if torch.cuda.is_available() and torch.device(device).type == "cuda":
+                    budget = min(budget, torch.cuda.mem_get_info(torch.device(device))[0] // 3)
+            except Exception:       # no device (host-side construction in the CPU tests)
+                pass
+            layout = "identity" if max_seqs * self.max_pages * page_bytes <= budget else "paged"
         if layout not in ("identity", "paged"):
             raise ValueError(f"KVPool layout {layout!r}")
         self.identity = layout == "identity"

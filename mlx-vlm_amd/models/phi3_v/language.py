@@ -51,7 +51,8 @@ def su_scale(max_pos: int, orig_max_pos: int) -> float:
 
 
 class LanguageModel(_Engine):
-    MAX_DECODE_ROWS = 16      # SuScaledRoPE's per-call regime is decided inside the fused qkv kernel of the <= 16-row steps
+    MAX_DECODE_ROWS = 64      # wide steps too: SuScaledRoPE's per-call regime is decided on the device in every rope site
+                              # (the fused qkv kernels of the <= 16-row steps, vlm_mrope_kvwrite_decode of the wide ones)
 
     def __init__(self, config, device="cuda", **engine_kwargs):
         """`config`: the ModelConfig (the reference's Phi3V reads the text parameters from the root)"""

@@ -317,11 +317,9 @@ class LanguageModel:
         check(L.vlm_llm_set_globals(h, C.byref(gl)), "llm_set_globals")
         self._init_pool()
 
-    # decode-step tuning (results are identical under every setting; defaults from the measurements in DESIGN.md,
-    # environment overrides for A/B runs): VLM_DECODE_PREFETCH 0 / 1 (event-paced side branch) / 2 (persistent side
-    # kernel), VLM_DECODE_PREFETCH_MASK, VLM_DECODE_PREFETCH_WGS, VLM_DECODE_FUSED_TAIL 0 / 1
-    TUNING_DEFAULTS = {"prefetch": 0, "prefetch_wgs": 256, "prefetch_mask": 0x7f, "prefetch_head_mb": 96, "fused_tail": 1, "mfma_gemv": 1,
-                       "fused_mlp": 0, "attn_pagesplit": 16, "gemv_variant": 1, "attn_merge": 1, "tlb_touch": 0}
+    # decode-step tuning (results are identical under every setting up to bf16 ties; defaults from the measurements in
+    # DESIGN.md, environment overrides VLM_DECODE_<NAME> for A/B runs)
+    TUNING_DEFAULTS = {"fused_tail": 1, "mfma_gemv": 1, "attn_pagesplit": 16, "gemv_variant": 1, "attn_merge": 1}
 
     def apply_tuning(self, **over):
         L = _lib.lib()
@@ -332,11 +330,8 @@ class LanguageModel:
                 t[k] = int(env, 0)
         t.update(over)
         self.tuning = t
-        for key, name in ((_lib.TUNE_PREFETCH, "prefetch"), (_lib.TUNE_PREFETCH_WGS, "prefetch_wgs"),
-                          (_lib.TUNE_PREFETCH_MASK, "prefetch_mask"), (_lib.TUNE_PREFETCH_HEAD_MB, "prefetch_head_mb"),
-                          (_lib.TUNE_FUSED_MLP, "fused_mlp"), (_lib.TUNE_MFMA_GEMV, "mfma_gemv"),
-                          (_lib.TUNE_ATTN_PAGESPLIT, "attn_pagesplit"), (_lib.TUNE_GEMV_VARIANT, "gemv_variant"),
-                          (_lib.TUNE_ATTN_MERGE, "attn_merge"), (_lib.TUNE_TLB_TOUCH, "tlb_touch")):
+        for key, name in ((_lib.TUNE_MFMA_GEMV, "mfma_gemv"), (_lib.TUNE_ATTN_PAGESPLIT, "attn_pagesplit"),
+                          (_lib.TUNE_GEMV_VARIANT, "gemv_variant"), (_lib.TUNE_ATTN_MERGE, "attn_merge")):
             check(L.vlm_llm_set_tuning(self._handle, key, int(t[name])), "llm_set_tuning")
         for st in getattr(self, "_decode_states", {}).values():
             st.graph_key = None          # the engine dropped its captured steps
@@ -727,8 +722,10 @@ class LanguageModel:
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         pool = self.pool
         q = (pool.kpool8.data_ptr(), pool.vpool8.data_ptr(), pool.ksb.data_ptr(), pool.vsb.data_ptr()) if q8 else (None,) * 4
+        # the BATCH policy of the reference (models/cache.py:8-21, generate/ar.py:842-858): with kv_bits the last layer of a
+        # stack deeper than 2 keeps its unquantised cache (vlm_kv_pool.q8_skip_last; the bf16 pools hold every token anyway)
         kv = _lib.KvPool(pool.kpool.data_ptr(), pool.vpool.data_ptr(), pool.layer_stride, block_table.data_ptr(),
-                         pool.max_pages, *q)
+                         pool.max_pages, *q, 1 if q8 else 0)
         check(L.vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
         # row_penalties: the step applies every row's own logits processors (device tables of the state) before sampling
         args = st.args(B=B, with_logprobs=with_logprobs, penalties="rows" if row_penalties else None, **sampler_args)

@@ -31,7 +31,14 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES)
     for s in declared:
         assert hasattr(L, s), s
-    assert L.vlm_abi_version() == 4
+    assert L.vlm_abi_version() == 5
+    # ... and NOTHING else: the dynamic symbol table of the .so is exactly the header (debug hooks and library-internal
+    # entry points have hidden visibility)
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
 
 
 def test_no_cpu_fallback_ops_raise_on_cpu_tensors():

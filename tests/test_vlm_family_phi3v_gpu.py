@@ -339,14 +339,15 @@ def test_su_rope_long_factor_regime_switches_per_call(tiny, prompt_len):
     print(f"phi3v long-factor regime, prompt {prompt_len}: worst row rel-rms {worst:.4f}")
 
 
-@pytest.mark.parametrize("B", [2, 9])
+@pytest.mark.parametrize("B", [2, 9, 20])
 @pytest.mark.parametrize("w4", [False, True])
 def test_su_rope_regime_of_a_batched_decode_step_follows_its_longest_row(w4, B):
     """SuScaledRoPE decides per CALL (rope_utils.py:168-172): position_end = max(cache offset over the rows) + 1.  Two rows
     decode together: row 0 stays near offset 30, row 1 runs from offset 4090 across 4096 - from the step where row 1's
     offset is 4096 on, BOTH rows rotate with the long factors (row 0's new keys too), exactly as the reference's batched
     call does (pinned in test_oracle_ref_golden_phi3v.py against the reference's own class run with an offset array).
-    B = 2: the v_dot2c qkv epilogues (bf16 / 4-bit); B = 9: the skinny-M MFMA form (8 short rows + the long one).
+    B = 2: the v_dot2c qkv epilogues (bf16 / 4-bit); B = 9: the skinny-M MFMA form (8 short rows + the long one); B = 20: a
+    WIDE step (prefill GEMMs + vlm_mrope_kvwrite_decode, which decides the regime from the rows' slots on the device).
     The engine evaluates the rule inside the qkv epilogue from the rows' cache offsets (vlm_llm_config.rope_long_from):
     every row of every step against the oracle with the call-wide position_end; and a control - row 0 decoded ALONE over
     the same steps stays short and must differ from its batched logits after the crossing."""
@@ -355,7 +356,7 @@ def test_su_rope_regime_of_a_batched_decode_step_follows_its_longest_row(w4, B):
     else:
         cfg = op.tiny_cfg()
         ck = ow = op.random_weights(cfg, seed=777, dtype=BF, **SCALES)
-    model = build_phi3v_model(cfg, ck, kv_pool_tokens=16384, max_seqs=16)
+    model = build_phi3v_model(cfg, ck, kv_pool_tokens=16384, max_seqs=max(16, B + 4))
     lm = model.language_model
     lim = cfg.text.original_max_position_embeddings
     rng = np.random.default_rng(910)
