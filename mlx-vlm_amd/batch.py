@@ -40,6 +40,8 @@ from .models.qwen2_vl.language import DecodeState
 from .sample_utils import Sampler, make_sampler
 
 _PROCS_KEY = "__logits_processors__"     # a request's LogitsProcessors spec inside its keyword arguments
+_PYPROCS_KEY = "__py_logits_processors__"   # ... its Python callables (tokens, logits) -> logits (eager steps)
+_BUDGET_KEY = "__thinking_budget_criteria__"   # ... its ThinkingBudgetCriteria
 MAX_ROWS = 16         # default widest decode step: one N tile of the skinny-M MFMA GEMM (csrc/gemv_mfma.hip), bf16 or 4-bit weights
 WIDE_ROWS = 64        # on request (completion_batch_size > 16): WIDE steps of 32 / 64 rows on the prefill GEMMs (engine.hip decode_impl:
                       # 192.6 us per Qwen2-VL-7B layer at 32 rows, 210 at 64, against 120 per 16-row step - profiles/r03_mfma_shapes.txt)
@@ -78,6 +80,9 @@ class _Row:
     prompt_tokens: int
     num_tokens: int = 0
     procs: Any = None              # this request's sample_utils.LogitsProcessors (None: none)
+    py_procs: Any = None           # its Python callables (tokens, logits) -> logits, in order (None: none)
+    tokens: Any = None             # device int32 [n]: prompt + every token fed back (kept only for rows with py_procs)
+    budget: Any = None             # its ThinkingBudgetCriteria (None: none)
 
 
 @dataclass
@@ -118,10 +123,15 @@ class BatchGenerator:
     """`insert(prompts)` queues token-id prompts (shortest first, ar.py:2620-2623); every `next()` reports one token
     per running request and advances the batch by one step.  `model` is the full `Model` (vision tower + language
     model): per-request `prompt_kwargs` carry `pixel_values` / `image_grid_thw` and the ViT runs inside the admission
-    prefill.  Per-request logits processors (`insert(..., logits_processors=)`, ar.py:2584-2606) are the reference's own
-    four - logit_bias, repetition / presence / frequency penalty, as `make_logits_processors` specs - applied by the device
-    pass inside the step from per-row parameter tables; arbitrary Python callables cannot run inside a captured step.
-    Quantised KV, APC and speculative drafts are outside the built path and are rejected, not ignored."""
+    prefill.  Per-request logits processors (`insert(..., logits_processors=)`, ar.py:2584-2606): the reference's own
+    four - logit_bias, repetition / presence / frequency penalty, as `make_logits_processors` specs - are applied by the
+    device pass inside the captured step from per-row parameter tables; any other callable `(tokens, logits) -> logits`
+    (and a Python `sampler(logprobs) -> tokens`) makes the steps EAGER while such a row is live: forward, the callables on
+    the rows' logits as device tensors, sampling, advance - four host calls instead of one graph replay
+    (ar.py:1044-1141).  `thinking_budget_criteria` per request (ar.py:1303-1350).  `kv_bits=8`: the uniform 8-bit KV
+    cache with the reference's batch policy (every layer but the last of a stack deeper than 2, models/cache.py:8-21);
+    as in the reference's batch path `quantized_kv_start` has no effect on the uniform scheme (ar.py:776-812: the batch
+    caches are quantised from the first token).  APC and speculative drafts are outside the built path and are rejected."""
 
     @dataclass
     class Response:
@@ -136,8 +146,7 @@ class BatchGenerator:
                  prefill_batch_size: int = MAX_ROWS, compute_logprobs: bool = True, use_graph: bool = True,
                  async_prefill: bool = True, prefill_ahead: int = 2, **kwargs):
         # uniform 8-bit KV cache (reference ar.py:2200-2230: BatchGenerator(kv_bits=, kv_group_size=, quantized_kv_start=)):
-        # every admitted request's cache is quantised right after its prefill (quantized_kv_start <= its prompt length is the
-        # only switch-over a batch of rows at different offsets can share: 0 is accepted, anything else is refused)
+        # every admitted request's cache is quantised right after its prefill
         self.kv_bits = kwargs.pop("kv_bits", None)
         kv_group_size = kwargs.pop("kv_group_size", None) or 64
         kv_start = kwargs.pop("quantized_kv_start", None)
@@ -146,8 +155,11 @@ class BatchGenerator:
             if float(self.kv_bits) != 8 or int(kv_group_size) != 64 or kv_scheme not in (None, "uniform"):
                 raise NotImplementedError(f"BatchGenerator: kv_bits={self.kv_bits} kv_group_size={kv_group_size} "
                                           f"kv_quant_scheme={kv_scheme}: the uniform 8-bit / group-64 quantized KV cache is built")
-            if kv_start not in (None, 0):
-                raise NotImplementedError("BatchGenerator: quantized_kv_start must be 0 with kv_bits (rows quantise at their join)")
+            # quantized_kv_start: the reference's batch path builds BatchQuantizedKVCache for the uniform scheme whatever
+            # the value (ar.py:776-812 - only the TurboQuant scheme defers on it), i.e. rows are quantised from their first
+            # token; accepted and, as there, without effect
+            if getattr(self.lm if hasattr(self, "lm") else model.language_model, "head_dim", 128) != 128:
+                raise NotImplementedError("BatchGenerator(kv_bits=8): the 8-bit KV kernels are built for 128-wide heads")
         unsupported = {k: v for k, v in kwargs.items() if v not in (None, False, 0, [], ())
                        and k not in ("prefill_step_size", "greedy_sampling", "stream")}
         if unsupported:
@@ -170,9 +182,14 @@ class BatchGenerator:
             max_rows //= 2
         self.completion_batch_size = max(1, min(int(completion_batch_size), max_rows))
         self.prefill_batch_size = max(1, int(prefill_batch_size))
+        # a sample_utils.Sampler samples on the device inside the captured step; any other callable is the reference's
+        # `sampler(logprobs [n, V]) -> tokens [n]` contract and makes every step eager
+        self._py_sampler = None
+        if sampler is not None and not isinstance(sampler, Sampler):
+            if not callable(sampler):
+                raise TypeError("sampler must be a mlx_vlm_amd.sample_utils.Sampler or a callable logprobs -> tokens")
+            self._py_sampler, sampler = sampler, None
         self.sampler = sampler or make_sampler()
-        if not isinstance(self.sampler, Sampler):
-            raise TypeError("BatchGenerator samples on the device: pass a mlx_vlm_amd.sample_utils.Sampler (make_sampler)")
         self._sargs = self.sampler.engine_args()
         crit = getattr(self.tokenizer, "stopping_criteria", None)
         self._stop = set(getattr(crit, "eos_token_ids", ()) or ())
@@ -234,7 +251,8 @@ class BatchGenerator:
         ids_l = [b[1] for b in batch]
         pix_l = [b[3].get("pixel_values") for b in batch]
         grid_l = [b[3].get("image_grid_thw") for b in batch]
-        extras = [{k: v for k, v in b[3].items() if k not in ("pixel_values", "image_grid_thw", _PROCS_KEY)} for b in batch]
+        extras = [{k: v for k, v in b[3].items() if k not in ("pixel_values", "image_grid_thw", _PROCS_KEY, _PYPROCS_KEY, _BUDGET_KEY)}
+                  for b in batch]
         emb, pos, lens, deltas = embed_requests(self.model, ids_l, pix_l, grid_l, extras)
         caches = [lm.make_cache() for _ in batch]
         for c, L, b in zip(caches, lens, batch):
@@ -265,7 +283,15 @@ class BatchGenerator:
         # (step, row) pair is used twice - neither between an admission and a decode step nor between two admissions
         self._admissions = getattr(self, "_admissions", 0) + 1
         step0 = torch.full((1,), 0x40000000 + (self._admissions & 0x3FFFFFFF), dtype=torch.int32, device=logits.device)
-        tok0, lp = ops.sample(logits, step=step0, want_logprobs=self.compute_logprobs, **self._sargs)
+        for r, b in enumerate(batch):                   # Python callables on the first token: `tokens` = the prompt (ar.py:1959-1970)
+            for proc in b[3].get(_PYPROCS_KEY) or ():
+                tk = h2d(np.asarray(b[1], dtype=np.int32).reshape(-1), logits.device)
+                logits[r:r + 1].copy_(self._call_proc(proc, tk, logits[r:r + 1]))
+        if self._py_sampler is not None:
+            _, lp = ops.sample(logits, want_logprobs=True, temperature=0.0)
+            tok0 = self._call_sampler(lp)
+        else:
+            tok0, lp = ops.sample(logits, step=step0, want_logprobs=self.compute_logprobs, **self._sargs)
         lp0 = lp.gather(1, tok0.long()[:, None]).reshape(-1).float() if self.compute_logprobs else None
         ctx = np.asarray(lens, dtype=np.int32)
         state = h2d(np.stack([ctx + np.asarray(deltas, dtype=np.int32), ctx]), lm.device)
@@ -273,9 +299,52 @@ class BatchGenerator:
 
     def _decode_rows(self, width: int):
         """One decode step over rows 0..width-1 of the state: tok <- sampled token, pos and ctx advanced by one."""
+        if self._py_sampler is not None or any(row.py_procs for row in self._rows):
+            return self._decode_rows_eager(width)
         self.lm.decode_step_rows(self._st, width, self._table, self._sargs, use_graph=self.use_graph,
                                  with_logprobs=self.compute_logprobs, row_penalties=any(row.procs for row in self._rows),
                                  q8=self.kv_bits is not None)
+
+    @staticmethod
+    def _call_proc(proc, tokens, logits_row):
+        out = proc(tokens, logits_row)
+        if not isinstance(out, torch.Tensor):
+            out = torch.as_tensor(np.asarray(out), device=logits_row.device)
+        return out.to(device=logits_row.device, dtype=logits_row.dtype).reshape(1, -1)
+
+    def _call_sampler(self, logprobs):
+        tok = self._py_sampler(logprobs)
+        if not isinstance(tok, torch.Tensor):
+            tok = torch.as_tensor(np.asarray(tok), device=logprobs.device)
+        return tok.to(device=logprobs.device, dtype=torch.int32).reshape(-1).contiguous()
+
+    def _decode_rows_eager(self, width: int):
+        """The same step with the host in the middle (reference GenerationBatch._step, ar.py:1044-1141): forward of the rows
+        (logits only), each row's device-side spec, then its Python callables on its logits row with its token context
+        (prompt + every token fed, the one of this step included), log-probs, sampler (device or Python), advance."""
+        lm, st, n = self.lm, self._st, len(self._rows)
+        lm.decode_forward_rows(st, width, self._table, q8=self.kv_bits is not None)
+        logits = st.logits[:width]
+        if any(row.procs for row in self._rows):
+            ops.apply_logit_penalties(logits, st.row_penalty_tables(), push_tok=st.tok[:width])
+        for r, row in enumerate(self._rows):
+            if row.py_procs:
+                row.tokens = torch.cat([row.tokens, st.tok[r:r + 1]])
+                for proc in row.py_procs:
+                    logits[r:r + 1].copy_(self._call_proc(proc, row.tokens, logits[r:r + 1]))
+        if self._py_sampler is not None:
+            _, lp = ops.sample(logits, want_logprobs=True, temperature=0.0)
+            tok = torch.zeros(width, dtype=torch.int32, device=logits.device)
+            tok[:n].copy_(self._call_sampler(lp[:n]))
+        else:
+            tok, lp = ops.sample(logits, step=st.step, want_logprobs=self.compute_logprobs, **self._sargs)
+        st.tok[:width].copy_(tok)
+        if lp is not None:
+            st.logprobs[:width].copy_(lp)
+        lm.decode_advance_rows(st, width)
+
+    def _force_next_token(self, r: int, token: int):
+        self._st.tok[r:r + 1].copy_(h2d(np.asarray([token], dtype=np.int32), self._st.tok.device))
 
     def _quantize_joined(self, seq):
         """the joined request's cached prompt becomes a QuantizedKVCache (engine hook: a mock engine has nothing to convert)"""
@@ -308,39 +377,45 @@ class BatchGenerator:
         """logits_processors: one entry per prompt (reference ar.py:2584-2606) - None, a `sample_utils.LogitsProcessors`
         (what `make_logits_processors` returns here) or a list holding one; they run on the device inside the step, each
         row with its own parameters and token history."""
-        if thinking_budget_criteria:
-            raise NotImplementedError("thinking budgets are outside the built path")
         if max_tokens is None or isinstance(max_tokens, int):
             max_tokens = [max_tokens or self.max_tokens] * len(prompts)
         if prompt_kwargs is None:
             prompt_kwargs = [{}] * len(prompts)
         if logits_processors is None:
             logits_processors = [None] * len(prompts)
+        if thinking_budget_criteria is None:
+            thinking_budget_criteria = [None] * len(prompts)
+        if len(thinking_budget_criteria) != len(prompts):
+            raise ValueError("Insufficient number of thinking_budget_criteria provided")
         if len(max_tokens) != len(prompts) or len(prompt_kwargs) != len(prompts) or len(logits_processors) != len(prompts):
             raise ValueError("max_tokens / prompt_kwargs / logits_processors must have one entry per prompt")
-        from .sample_utils import LogitsProcessors
-        specs = []
+        from .sample_utils import HIST_CAP, LogitsProcessors
+        specs, pys = [], []
         for lp in logits_processors:
-            if isinstance(lp, (list, tuple)):
-                lp = [x for x in lp if x] or None
-                if lp is not None and len(lp) == 1:
-                    lp = lp[0]
-            if lp is not None and not isinstance(lp, LogitsProcessors):
-                raise NotImplementedError("BatchGenerator runs logits processors on the device: pass the spec returned by "
-                                          "mlx_vlm_amd.sample_utils.make_logits_processors (logit_bias, repetition / presence / "
-                                          "frequency penalty); Python callables cannot run inside the captured step")
-            if lp:
-                from .sample_utils import HIST_CAP
-                DecodeState.pack_row_penalties([lp], HIST_CAP)                    # validates (bias list length) before queueing
-            specs.append(lp if lp else None)
+            items = [x for x in (lp if isinstance(lp, (list, tuple)) else [lp]) if x]
+            sp = [x for x in items if isinstance(x, LogitsProcessors)]
+            py = [x for x in items if not isinstance(x, LogitsProcessors)]
+            if len(sp) > 1:
+                raise NotImplementedError("one make_logits_processors spec per request")
+            for f in py:
+                if not callable(f):
+                    raise TypeError("logits_processors entries must be make_logits_processors specs or callables (tokens, logits) -> logits")
+            if sp:
+                DecodeState.pack_row_penalties(sp, HIST_CAP)                      # validates (bias list length) before queueing
+            specs.append(sp[0] if sp else None)
+            pys.append(py or None)
         uids = []
-        for p, m, kw, sp in zip(prompts, max_tokens, prompt_kwargs, specs):
+        for p, m, kw, sp, py, crit in zip(prompts, max_tokens, prompt_kwargs, specs, pys, thinking_budget_criteria):
             ids = np.asarray(p, dtype=np.int64).reshape(-1)
             if ids.size == 0:
                 raise ValueError("empty prompt")
             kw = dict(kw or {})
             if sp:
                 kw[_PROCS_KEY] = sp               # travels with the request's keyword arguments (the queue item keeps its shape)
+            if py:
+                kw[_PYPROCS_KEY] = py
+            if crit is not None:
+                kw[_BUDGET_KEY] = crit
             self._unprocessed_sequences.append((self.uid_count, ids, int(m), kw))
             uids.append(self.uid_count)
             self.uid_count += 1
@@ -535,7 +610,10 @@ class BatchGenerator:
                     self._quantize_joined(seq)          # KVCache.to_quantized right after the prefill (stream-ordered)
                 spec = b[3].get(_PROCS_KEY)
                 self._set_row_penalties(r, p.pen, i, spec)
-                self._rows.append(_Row(uid=b[0], seq=seq, max_tokens=b[2], prompt_tokens=L, procs=spec))
+                py = b[3].get(_PYPROCS_KEY)
+                self._rows.append(_Row(uid=b[0], seq=seq, max_tokens=b[2], prompt_tokens=L, procs=spec, py_procs=py,
+                                       tokens=h2d(np.asarray(b[1], dtype=np.int32).reshape(-1), lm.device) if py else None,
+                                       budget=b[3].get(_BUDGET_KEY)))
                 out.append(PromptProgress(uid=b[0], prompt_tokens=L, prompt_tps=L / dt if dt > 0 else 0.0, prompt_time=dt))
             if p.joined >= len(p.batch):
                 self._pending.pop(0)
@@ -566,6 +644,13 @@ class BatchGenerator:
                 row.num_tokens += 1
                 tok = int(toks[i])
                 reason = "stop" if tok in self._stop else "length" if row.num_tokens >= row.max_tokens else None
+                if row.budget is not None:
+                    # ar.py:1306-1314,1338-1347: the criteria sees the reported token; a pending forced id REPLACES the next
+                    # token of the row - already sampled by the step in flight, so the write is stream-ordered behind it
+                    row.budget(tok)
+                    forced = row.budget.pop_forced_token_id()
+                    if forced is not None and reason is None:
+                        self._force_next_token(r, int(forced))
                 if reason is not None:
                     gone.append(r)
                 responses.append(self.Response(uid, tok, float(lps[i]) if self.compute_logprobs else 0.0, reason))

@@ -136,13 +136,29 @@ class _TokenPipe:
         return self.buf[idx % self.cap].numpy().copy()
 
 
-def _resolve_sampler(sampler, temperature, top_p, min_p, top_k, seed) -> Sampler:
+def _resolve_sampler(sampler, temperature, top_p, min_p, top_k, seed):
+    """-> (device Sampler, python callable or None).  A `sample_utils.Sampler` runs inside the captured step; any other
+    callable is the reference's `sampler(logprobs) -> token` contract (ar.py:151-193,369-379) and runs on the host side of
+    an EAGER step (logits come back from the engine, the callable gets the log-probs as a device tensor)."""
     if sampler is None:
-        return make_sampler(temp=temperature, top_p=top_p, min_p=min_p, top_k=top_k, seed=seed)
+        return make_sampler(temp=temperature, top_p=top_p, min_p=min_p, top_k=top_k, seed=seed), None
     if isinstance(sampler, Sampler):
-        return sampler
-    raise NotImplementedError("custom Python sampler callables are not supported by the fused decode graph; "
-                              "pass a mlx_vlm_amd.sample_utils.Sampler (make_sampler)")
+        return sampler, None
+    if callable(sampler):
+        return make_sampler(temp=0.0), sampler
+    raise TypeError("sampler must be a mlx_vlm_amd.sample_utils.Sampler or a callable logprobs -> token")
+
+
+def _as_token(y) -> int:
+    if isinstance(y, torch.Tensor):
+        return int(y.reshape(-1)[0].item())
+    return int(np.asarray(y).reshape(-1)[0])
+
+
+def _logprobs_of(logits: torch.Tensor) -> torch.Tensor:
+    """logits - logsumexp(logits) in the logits dtype (ar.py:368) by the sampler kernel (the argmax it also returns is unused)"""
+    _, lp = ops.sample(logits, want_logprobs=True, temperature=0.0)
+    return lp
 
 
 def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEFAULT_MAX_TOKENS,
@@ -156,10 +172,18 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
     input_ids [1, L]; pixel_values / mask as produced by prepare_inputs; extra kwargs
     (image_grid_thw, ...) are forwarded to model.get_input_embeddings.  logprobs is a device
     bf16 [V] tensor (None when return_logprobs=False)."""
-    if logits_processors:
-        raise NotImplementedError("custom Python logits_processors cannot run inside the captured decode step; the "
-                                  "reference's own processors (logit_bias, repetition / presence / frequency penalty) are "
-                                  "built as a device pass: pass those keyword arguments instead")
+    # reference ar.py:151-193,303-304,360-364: `logits_processors` = callables (tokens, logits) -> logits appended to the
+    # built-in ones.  A `sample_utils.LogitsProcessors` spec (this package's make_logits_processors) joins the device pass;
+    # any other callable forces the EAGER step below (it cannot run inside a captured graph).
+    from .sample_utils import LogitsProcessors as _Spec
+
+    py_procs = [p for p in (logits_processors or []) if p is not None and not isinstance(p, _Spec)]
+    extra_specs = [p for p in (logits_processors or []) if isinstance(p, _Spec) and p]
+    for p in py_procs:
+        if not callable(p):
+            raise TypeError("logits_processors entries must be callables (tokens, logits) -> logits")
+    if len(extra_specs) > 1:
+        raise NotImplementedError("one make_logits_processors spec per request")
     from .sample_utils import make_logits_processors
 
     # reference ar.py:290-302: the penalties / bias of generate_step as a device-side logits pass
@@ -167,7 +191,12 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
                                    kwargs.pop("repetition_context_size", 20), kwargs.pop("presence_penalty", None),
                                    kwargs.pop("presence_context_size", 20), kwargs.pop("frequency_penalty", None),
                                    kwargs.pop("frequency_context_size", 20))
-    for k in ("max_kv_size", "draft_model", "thinking_budget_criteria"):
+    if extra_specs:
+        if procs:
+            raise NotImplementedError("penalty keyword arguments and a make_logits_processors spec: pass one of them")
+        procs = extra_specs[0]
+    thinking_budget_criteria = kwargs.pop("thinking_budget_criteria", None)
+    for k in ("max_kv_size", "draft_model"):
         if kwargs.pop(k, None):
             # the reference would switch cache class / decoding scheme (RotatingKVCache, speculative): dropping the request
             # silently would change results without telling the caller
@@ -185,8 +214,9 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
                                       "8-bit / group-64 quantized KV cache is built (TurboQuant / other widths: SURVEY section 2 out of scope)")
     for k in ("verbose", "prompt_cache_checkpoint", "prompt_cache_checkpoint_len"):
         kwargs.pop(k, None)
-    smp = _resolve_sampler(sampler, temperature, top_p, min_p, top_k, seed)
+    smp, py_sampler = _resolve_sampler(sampler, temperature, top_p, min_p, top_k, seed)
     sargs = smp.engine_args()
+    eager = bool(py_procs) or py_sampler is not None or thinking_budget_criteria is not None
     lm = model.language_model
 
     ids = input_ids.detach().cpu().numpy() if isinstance(input_ids, torch.Tensor) else np.asarray(input_ids)
@@ -218,6 +248,10 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
         if kv_bits is not None and not sq.q8 and sq.offset >= quantized_kv_start:
             lm.quantize_kv([sq], bits=int(kv_bits), group_size=int(kv_group_size))
 
+    if eager:
+        yield from _generate_step_eager(lm, ids, logits, prompt_cache, f, procs, py_procs, smp, sargs, py_sampler,
+                                        thinking_budget_criteria, max_tokens, return_logprobs, maybe_quantize_kv_cache, own_cache)
+        return
     maybe_quantize_kv_cache()
     step0 = torch.zeros(1, dtype=torch.int32, device=logits.device)
     if procs:
@@ -261,6 +295,70 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
             seq.release()
 
 
+def _generate_step_eager(lm, ids, logits, prompt_cache, f, procs, py_procs, smp, sargs, py_sampler, budget, max_tokens,
+                         return_logprobs, maybe_quantize_kv_cache, own_cache):
+    """The reference's `_step` loop (ar.py:334-389) run EAGERLY, one forward per token through the module contract
+    (`language_model(y, cache=...)` = vlm_llm_decode_forward, logits only): the route for what cannot live inside a captured
+    step - Python `logits_processors` callables (tokens, logits) -> logits, a Python `sampler(logprobs) -> token`, and the
+    thinking budget (utils.py:2252-2335, ar.py:369-379: the criteria may force the token).  Callables receive DEVICE tensors:
+    `tokens` int32 [n] = the prompt followed by every token fed back (ar.py:360), `logits` bf16 [1, V]; they must return a
+    [1, V] tensor.  Order as in the reference: built-in processors, then the caller's, then the cache switch-over, then
+    log-probs, then the sampler."""
+    seq = prompt_cache[0]._seq
+    dev = logits.device
+    lm._rope_deltas = np.asarray(f.rope_deltas).reshape(-1, 1)[:1]
+    need_tokens = bool(py_procs)
+    tokens = _lib_h2d(np.asarray(ids, dtype=np.int32).reshape(-1), dev) if need_tokens else None
+    pst = None
+    if procs:
+        pst = lm.decode_state(1)
+        pst.set_history([np.asarray(ids).reshape(-1)])
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    fed: Optional[torch.Tensor] = None          # the token fed by the forward that produced `logits` (None: the prompt)
+    n = 0
+    try:
+        while n < max_tokens:
+            logits = logits.reshape(1, -1)
+            if procs:
+                ops.apply_logit_penalties(logits, pst.penalty_args(procs), push_tok=fed)
+            for proc in py_procs:
+                out = proc(tokens, logits)
+                if not isinstance(out, torch.Tensor):
+                    out = torch.as_tensor(np.asarray(out), device=dev)
+                logits = out.to(device=dev, dtype=logits.dtype).reshape(1, -1).contiguous()
+            maybe_quantize_kv_cache()
+            if py_sampler is not None:
+                lp = _logprobs_of(logits)
+                y = _as_token(py_sampler(lp))
+            else:
+                tok, lp = ops.sample(logits, step=step, want_logprobs=return_logprobs or budget is not None, **sargs)
+                y = int(tok.reshape(-1)[0].item())
+            if budget is not None and n > 0:
+                # ar.py:510-513: after the caller has seen the previous token (it calls criteria(token), dispatch.py:1016-1018)
+                # the criteria may have a forced token pending - it REPLACES the sampled one; the log-probs stay the model's
+                forced = budget.pop_forced_token_id()
+                if forced is not None:
+                    y = int(forced)
+            step += 1
+            n += 1
+            yield y, (lp[0] if (lp is not None and return_logprobs) else None)
+            if n >= max_tokens:
+                break
+            fed = _lib_h2d(np.asarray([y], dtype=np.int32), dev)
+            if need_tokens:
+                tokens = torch.cat([tokens, fed])
+            logits = lm(np.array([[y]], dtype=np.int64), cache=prompt_cache).logits[:, -1, :]
+    finally:
+        if own_cache:
+            seq.release()
+
+
+def _lib_h2d(a, dev):
+    from ._lib import h2d
+
+    return h2d(a, dev)
+
+
 # ---------------------------------------------------------------------------------------------
 def _tokenizer_of(processor):
     return processor.tokenizer if hasattr(processor, "tokenizer") else processor
@@ -279,8 +377,11 @@ def stream_generate(model, processor, prompt: Optional[str] = None, image=None, 
     skip_ids = set(tokenizer.all_special_ids) if (skip_special_tokens and hasattr(tokenizer, "all_special_ids")) else set()
     vision_cache = kwargs.pop("vision_cache", None)
     prompt_cache_state = kwargs.pop("prompt_cache_state", None)
-    for k in ("thinking_budget", "thinking_end_token", "thinking_start_token", "enable_thinking", "resize_shape",
-              "apc_manager", "apc_tenant", "eos_tokens", "stopping_criteria"):
+    thinking_budget = kwargs.pop("thinking_budget", None)
+    thinking_end_token = kwargs.pop("thinking_end_token", "</think>")
+    thinking_start_token = kwargs.pop("thinking_start_token", "<think>")
+    enable_thinking = kwargs.pop("enable_thinking", False)
+    for k in ("resize_shape", "apc_manager", "apc_tenant", "eos_tokens", "stopping_criteria"):
         kwargs.pop(k, None)
     if audio or video:
         raise NotImplementedError("audio / video inputs are outside the built hot path")
@@ -340,6 +441,23 @@ def stream_generate(model, processor, prompt: Optional[str] = None, image=None, 
         kwargs["prompt_cache"] = _cm.make_prompt_cache(model.language_model)
     detok = make_streaming_detokenizer(processor) if processor is not None else None
     stop = getattr(tokenizer, "stopping_criteria", None) if tokenizer is not None else None
+    # thinking budget (reference dispatch.py:930-947,1016-1018): the criteria watches every token; past the budget inside a
+    # thinking block it forces "\n</think>" through generate_step (which then steps eagerly)
+    thinking_criteria = None
+    if thinking_budget is not None and tokenizer is not None:
+        from .utils import ThinkingBudgetCriteria
+
+        start_id = tokenizer.encode(thinking_start_token, add_special_tokens=False)[-1]
+        thinking_criteria = ThinkingBudgetCriteria(tokenizer=tokenizer, thinking_budget=thinking_budget,
+                                                   thinking_end_token=thinking_end_token, thinking_start_token=thinking_start_token,
+                                                   enable_thinking=enable_thinking,
+                                                   prompt_preopens_thinking=start_id in full_ids)
+        kwargs["thinking_budget_criteria"] = thinking_criteria
+    if tokenizer is not None:
+        try:
+            tokenizer.thinking_budget_criteria = thinking_criteria
+        except Exception:
+            pass
 
     gen = generate_step(ids, model, pixel_values, mask, **kwargs)
     tic = time.perf_counter()
@@ -353,6 +471,8 @@ def stream_generate(model, processor, prompt: Optional[str] = None, image=None, 
             prompt_time = time.perf_counter() - tic
             prompt_tps = total_prompt_tokens / prompt_time
             tic = time.perf_counter()
+        if thinking_criteria is not None:
+            thinking_criteria(token)
         if stop is not None and stop(token):
             finish_reason = "stop"
             break

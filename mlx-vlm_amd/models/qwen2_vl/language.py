@@ -739,6 +739,26 @@ class LanguageModel:
         else:
             check(L.vlm_llm_decode_step(self._handle, C.byref(args), stream), "decode_step")
 
+    def decode_forward_rows(self, st: DecodeState, B: int, block_table: torch.Tensor, q8: bool = False):
+        """The forward half of decode_step_rows, eager: logits of rows 0..B-1 land in st.logits; nothing is sampled, nothing
+        advanced (vlm_llm_decode_forward).  The caller finishes the step with its own processors / sampler and
+        decode_advance_rows - the route for Python callables, which cannot live inside a captured step."""
+        L = _lib.lib()
+        pool = self.pool
+        q = (pool.kpool8.data_ptr(), pool.vpool8.data_ptr(), pool.ksb.data_ptr(), pool.vsb.data_ptr()) if q8 else (None,) * 4
+        kv = _lib.KvPool(pool.kpool.data_ptr(), pool.vpool.data_ptr(), pool.layer_stride, block_table.data_ptr(),
+                         pool.max_pages, *q, 1 if q8 else 0)
+        check(L.vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
+        args = st.args(B=B)
+        check(L.vlm_llm_decode_forward(self._handle, C.byref(args), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              "decode_forward")
+
+    def decode_advance_rows(self, st: DecodeState, B: int):
+        """ctx += 1, pos += 1, token ring, sampling step counter of rows 0..B-1 (vlm_decode_advance): the tail of an eager step"""
+        check(_lib.lib().vlm_decode_advance(st.ctx.data_ptr(), st.pos.data_ptr(), st.tok.data_ptr(), st.out_ring.data_ptr(),
+                                            st.ring_len, st.step.data_ptr(), int(B),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "decode_advance")
+
     # ------------------------------------------------------------------ module contract (reference language.py:404-518)
     def __call__(self, inputs, inputs_embeds=None, mask=None, cache=None, **kwargs):
         position_ids = kwargs.pop("position_ids", None)

@@ -266,6 +266,54 @@ class StoppingCriteria:
         return input_ids in self.eos_token_ids
 
 
+class ThinkingBudgetCriteria:
+    """Budget on the tokens generated inside a thinking block (reference utils.py:2252-2335, same constructor, attributes
+    and call protocol).  The generation loop shows it every token (`criteria(token)`, dispatch.py:1016-1018); once more than
+    `thinking_budget` tokens have been produced inside an open block it hands out, one per call, the ids of "\\n" + the end
+    marker, and generate_step feeds the pending id INSTEAD of the sampled token (`pop_forced_token_id`, ar.py:510-513)."""
+
+    def __init__(self, tokenizer, thinking_budget: int, thinking_end_token: str = "</think>",
+                 thinking_start_token: Optional[str] = None, enable_thinking: bool = False,
+                 prompt_preopens_thinking: bool = False):
+        last_id = lambda text: tokenizer.encode(text, add_special_tokens=False)[-1]   # noqa: E731
+        self.tokenizer, self.thinking_budget = tokenizer, thinking_budget
+        self.enable_thinking, self.prompt_preopens_thinking = enable_thinking, prompt_preopens_thinking
+        self.thinking_end_token_id = last_id(thinking_end_token)
+        self.thinking_start_token_id = last_id(thinking_start_token)
+        nl = tokenizer.encode("\n", add_special_tokens=False)
+        self._forced_sequence: List[int] = ([nl[-1]] if nl else []) + [self.thinking_end_token_id]
+        self.forced_token_id = None
+        self.reset_thinking_state()
+
+    def reset_thinking_state(self):
+        """between generations: a prompt that already opened the block starts inside it"""
+        self.in_thinking = bool(self.enable_thinking and self.prompt_preopens_thinking)
+        self.thinking_token_count, self.budget_exceeded, self._forced_index = 0, False, 0
+
+    def __call__(self, token_id: int) -> Optional[int]:
+        if token_id == self.thinking_start_token_id and self.enable_thinking:
+            self.in_thinking = True
+            return None
+        if token_id == self.thinking_end_token_id:          # the block closed (by the model or by the forced sequence)
+            self.in_thinking, self.budget_exceeded, self._forced_index = False, False, 0
+            return None
+        if self.in_thinking:
+            self.thinking_token_count += 1
+            self.budget_exceeded = self.budget_exceeded or self.thinking_token_count > self.thinking_budget
+        pending = None
+        if self.budget_exceeded and self._forced_index < len(self._forced_sequence):
+            pending = self._forced_sequence[self._forced_index]
+            self._forced_index += 1
+        self.forced_token_id = pending
+        return pending
+
+    def pop_forced_token_id(self) -> Optional[int]:
+        if not self.enable_thinking or self.forced_token_id is None:
+            return None
+        forced, self.forced_token_id = self.forced_token_id, None
+        return forced
+
+
 class NaiveStreamingDetokenizer:
     """reference tokenizer_utils.py:19-86 (NaiveStreamingDetokenizer): decode the running token list,
     emit the new text once it no longer ends in an incomplete UTF-8 sequence."""

@@ -206,17 +206,54 @@ def test_rejects_what_the_built_path_does_not_do():
     pool = make_pool()
     with pytest.raises(NotImplementedError):
         MockEngineGenerator(pool, kv_bits=4)
-    with pytest.raises(NotImplementedError):
-        MockEngineGenerator(pool, kv_bits=8, quantized_kv_start=100)
     with pytest.raises(TypeError):
-        MockEngineGenerator(pool, sampler=lambda x: x)
+        MockEngineGenerator(pool, sampler=3)                       # neither a Sampler nor a callable
+    # accepted since round 4 (the reference accepts them): a Python sampler, Python logits processors, quantized_kv_start
+    # (without effect on the uniform scheme in the batch path, ar.py:776-812), thinking budgets
+    MockEngineGenerator(pool, sampler=lambda lp: lp.argmax(-1)).close()
     gen = MockEngineGenerator(pool)
     with pytest.raises(ValueError):
         gen.insert([np.array([], dtype=np.int64)])
-    with pytest.raises(NotImplementedError):
-        gen.insert([np.arange(3)], logits_processors=[[lambda t, l: l]])
+    with pytest.raises(TypeError):
+        gen.insert([np.arange(3)], logits_processors=[[123]])
     with pytest.raises(ValueError):
         gen.insert([np.arange(3)], max_tokens=[1, 2])
+    with pytest.raises(ValueError):
+        gen.insert([np.arange(3)], thinking_budget_criteria=[None, None])
+    assert len(gen.insert([np.arange(1, 4)], logits_processors=[[lambda t, l: l]])) == 1
+    gen.close()
+
+
+def test_thinking_budget_forces_the_next_token_of_its_row_only():
+    """insert(..., thinking_budget_criteria=) (ar.py:1303-1350): every reported token of the row is shown to its criteria; a
+    pending forced id replaces the row's NEXT token (already sampled by the step in flight), the other rows are untouched,
+    and the forced token is what the following step is fed (the mock's chain continues from it)."""
+    from mlx_vlm_amd.utils import ThinkingBudgetCriteria
+
+    class Tok:
+        def encode(self, t, add_special_tokens=False):
+            return {"<think>": [V - 1], "</think>": [V - 2], "\n": [V - 3]}[t]
+
+    pool = make_pool()
+    gen = MockEngineGenerator(pool, completion_batch_size=4, prefill_batch_size=4, max_tokens=12)
+    prompts = [np.arange(1, 8), np.arange(3, 14)]
+    crit = ThinkingBudgetCriteria(Tok(), thinking_budget=3, thinking_start_token="<think>", enable_thinking=True,
+                                  prompt_preopens_thinking=True)          # the prompt opened the block: counting from token 1
+    uids = gen.insert(prompts, thinking_budget_criteria=[crit, None])
+    got, reasons, _, _ = drain(gen)
+    assert [t for t, _ in got[uids[1]]] == stream_alone(prompts[1], 12)       # the row without a budget: its own chain
+    mine = [t for t, _ in got[uids[0]]]
+    # expected: the mock chain, except that after the 4th thinking token the next two tokens are "\n", "</think>"
+    exp, tok, ctx = [], first_token(prompts[0]), len(prompts[0])
+    c2 = ThinkingBudgetCriteria(Tok(), thinking_budget=3, thinking_start_token="<think>", enable_thinking=True,
+                                prompt_preopens_thinking=True)
+    for _ in range(12):
+        exp.append(tok)
+        c2(tok)
+        forced = c2.pop_forced_token_id()
+        nxt = next_token(tok, ctx, ctx)
+        tok, ctx = (forced if forced is not None else nxt), ctx + 1
+    assert mine == exp and exp[4:6] == [V - 3, V - 2] and len(set(exp)) > 4
     gen.close()
 
 

@@ -734,10 +734,145 @@ def test_batch_generator_per_request_logits_processors_equal_single_requests(tin
     _assert_streams_equal_up_to_ties([got[u] for u in uids], singles)
     # the processors really reached the rows: the batch's streams follow the processed singles, not the plain ones
     assert sum([t for t, _ in got[u]] != [t for t, _ in plain[u]] for u in uids) >= 2
-    gen2 = BatchGenerator(model, None)
-    with pytest.raises(NotImplementedError):            # a Python callable cannot run inside the captured step
-        gen2.insert([reqs[2][0].reshape(-1)], logits_processors=[[lambda toks, logits: logits]])
-    gen2.close()
+
+
+def _torch_repetition_penalty(penalty, context_size):
+    """The reference's repetition penalty (sample_utils.py:424-447) written as a Python callable over DEVICE tensors - what a
+    drop-in caller would pass as `logits_processors=[...]`"""
+    def proc(tokens, logits):
+        assert tokens.dtype == torch.int32 and tokens.is_cuda and logits.is_cuda and logits.shape[0] == 1
+        idx = tokens[-context_size:].long().unique()
+        sel = logits[:, idx].float()
+        sel = torch.where(sel < 0, (sel * penalty).to(torch.bfloat16).float(), (sel / penalty).to(torch.bfloat16).float())
+        out = logits.clone()
+        out[:, idx] = sel.to(out.dtype)
+        return out
+    return proc
+
+
+@pytest.mark.parametrize("sizes", [[(56, 84)], []])
+def test_generate_step_python_callables_take_the_eager_step(tiny, sizes):
+    """generate_step(sampler=<callable>, logits_processors=[<callables>]) (reference ar.py:151-193,360-379): the eager step.
+    (1) identity processor + argmax sampler == the captured step, tokens and log-probs bit for bit (same kernels, the host
+    in the middle); (2) a repetition penalty written as a Python callable over the device tensors == the built-in device
+    pass with the same parameters (tokens identical, log-probs 2 ulps): `tokens` really is prompt + every fed token."""
+    from mlx_vlm_amd.generate import generate_step
+
+    cfg, W, model = tiny
+    ids, pix, thw = synth_request(cfg, sizes, n_text=14, seed=33) if sizes else \
+        (np.random.default_rng(34).integers(3, 1000, (1, 19)), None, None)
+    kw = dict(image_grid_thw=thw) if thw is not None else {}
+    pv = (lambda: torch.from_numpy(pix)) if pix is not None else (lambda: None)
+
+    def run(**a):
+        toks, lps = [], []
+        for t, lp in generate_step(ids, model, pv(), None, max_tokens=24, temperature=0.0, **kw, **a):
+            toks.append(t)
+            lps.append(lp.float().cpu())
+        return toks, torch.stack(lps)
+
+    base_t, base_lp = run()
+    seen = []
+
+    def ident(tokens, logits):
+        seen.append(int(tokens.numel()))
+        return logits
+
+    t, lp = run(sampler=lambda logprobs: logprobs.argmax(-1), logits_processors=[ident])
+    assert t == base_t and torch.equal(lp, base_lp)
+    assert seen == [ids.size + i for i in range(24)]                       # the token context grows by one fed token per step
+    rep_t, rep_lp = run(repetition_penalty=1.4, repetition_context_size=16)
+    t, lp = run(logits_processors=[_torch_repetition_penalty(1.4, 16)])
+    assert rep_t != base_t and t == rep_t
+    ok, msg = bf16_close(lp, rep_lp, ulps=2, atol_rms=5e-3)
+    assert ok, msg
+    # a spec and a callable together: spec first (device pass), then the callable
+    t2, _ = run(logits_processors=[__import__("mlx_vlm_amd").sample_utils.make_logits_processors(logit_bias={7: 3.0}), ident])
+    t3, _ = run(logit_bias={7: 3.0})
+    assert t2 == t3
+
+
+def test_generate_step_thinking_budget_forces_the_closing_sequence(tiny):
+    """generate_step(thinking_budget_criteria=) (ar.py:308,510-513) with the caller driving the criteria as stream_generate
+    does (dispatch.py:1016-1018): past the budget the next tokens are "\\n" + the end marker, then decoding continues from
+    them; before that the stream equals the plain one."""
+    from mlx_vlm_amd.generate import generate_step
+    from mlx_vlm_amd.utils import ThinkingBudgetCriteria
+
+    cfg, W, model = tiny
+
+    class Tok:
+        def encode(self, t, add_special_tokens=False):
+            return {"<think>": [990], "</think>": [991], "\n": [992]}[t]
+
+    ids = np.random.default_rng(35).integers(3, 900, (1, 17))
+    plain = [t for t, _ in generate_step(ids, model, None, None, max_tokens=12, temperature=0.0)]
+    crit = ThinkingBudgetCriteria(Tok(), thinking_budget=4, thinking_start_token="<think>", enable_thinking=True,
+                                  prompt_preopens_thinking=True)
+    got = []
+    for t, _ in generate_step(ids, model, None, None, max_tokens=12, temperature=0.0, thinking_budget_criteria=crit):
+        got.append(t)
+        crit(t)
+    assert got[:5] == plain[:5] and got[5:7] == [992, 991] and len(got) == 12
+    # the forced tokens were FED: the continuation equals a plain run over prompt + the tokens so far
+    cont = [t for t, _ in generate_step(np.concatenate([ids, np.asarray([got[:7]])], axis=1), model, None, None, max_tokens=5,
+                                        temperature=0.0)]
+    assert got[7:12] == cont
+
+
+@pytest.mark.parametrize("py_sampler", [False, True])
+def test_batch_generator_python_callables_equal_single_requests(tiny, py_sampler):
+    """BatchGenerator.insert(..., logits_processors=[[callable]], thinking_budget_criteria=[...]) and
+    BatchGenerator(sampler=<callable>) (reference ar.py:1044-1141,1303-1350,2584-2606): 7 requests through 4 rows, some with
+    a Python repetition penalty, one with a thinking budget, the rest plain - eager steps while a callable's row is live,
+    captured steps otherwise.  Each request's tokens equal the ones it produces alone through generate_step with the same
+    callables (up to bf16 ties: a batched step and a one-row step reduce in different orders)."""
+    from mlx_vlm_amd.batch import BatchGenerator
+    from mlx_vlm_amd.generate import generate_step
+    from mlx_vlm_amd.utils import ThinkingBudgetCriteria
+
+    cfg, W, model = tiny
+
+    class Tok:
+        def encode(self, t, add_special_tokens=False):
+            return {"<think>": [990], "</think>": [991], "\n": [992]}[t]
+
+    def budget():
+        return ThinkingBudgetCriteria(Tok(), thinking_budget=3, thinking_start_token="<think>", enable_thinking=True,
+                                      prompt_preopens_thinking=True)
+
+    reqs = _mixed_requests(cfg, 7, seed0=340)
+    max_tokens = [9, 12, 7, 11, 8, 10, 6]
+    procs = [[_torch_repetition_penalty(1.3, 12)], None, None, [_torch_repetition_penalty(1.5, 20)], None, None, None]
+    crits = [None, None, budget(), None, None, None, None]
+    smp = (lambda logprobs: logprobs.float().argmax(-1)) if py_sampler else None
+    singles = []
+    for (ids, pix, thw), m, pr, has_budget in zip(reqs, max_tokens, procs, [c is not None for c in crits]):
+        a = dict(image_grid_thw=thw) if thw is not None else {}
+        c = budget() if has_budget else None
+        row = []
+        for t, lp in generate_step(ids, model, torch.from_numpy(pix) if pix is not None else None, None, max_tokens=m,
+                                   logits_processors=pr, sampler=smp, thinking_budget_criteria=c, **a):
+            row.append((t, float(lp[t])))
+            if c is not None:
+                c(t)
+        singles.append(row)
+    assert [t for t, _ in singles[2]][4:6] == [992, 991]
+    gen = BatchGenerator(model, None, max_tokens=7, completion_batch_size=4, prefill_batch_size=2, sampler=smp)
+    pk = [dict(pixel_values=torch.from_numpy(p), image_grid_thw=g) if p is not None else {} for _, p, g in reqs]
+    uids = gen.insert([r[0].reshape(-1) for r in reqs], list(max_tokens), prompt_kwargs=pk, logits_processors=procs,
+                      thinking_budget_criteria=crits)
+    got = {u: [] for u in uids}
+    while gen.has_work:
+        _, out = gen.next()
+        for r in out:
+            got[r.uid].append((r.token, r.token_logprob))
+    gen.close()
+    # (the forced tokens report the log-prob of the token the model had sampled, as the reference does: compare tokens there)
+    for u, ref in zip(uids, singles):
+        if u == uids[2]:
+            assert [t for t, _ in got[u]] == [t for t, _ in ref]
+    _assert_streams_equal_up_to_ties([got[u] for i, u in enumerate(uids) if i != 2], [s for i, s in enumerate(singles) if i != 2])
 
 
 def test_batch_generator_16_rows_matrix_core_steps_equal_single_requests(tiny):

@@ -517,17 +517,20 @@ def test_model_construction_and_weight_packing_run_without_a_device(family):
 
 
 def test_generate_step_rejects_unbuilt_options():
-    """max_kv_size / draft_model / thinking_budget_criteria / Python logits processors / the KV quantisation schemes other
-    than uniform 8-bit group-64 are outside the built path: they raise instead of being dropped silently (reference
-    signature: ar.py:151-214)."""
+    """max_kv_size / draft_model / the KV quantisation schemes other than uniform 8-bit group-64 are outside the built path:
+    they raise instead of being dropped silently (reference signature: ar.py:151-214).  Python samplers / logits
+    processors and thinking budgets are built since round 4 (the eager step, tests/test_engine_gpu.py); malformed ones raise
+    TypeError."""
     import numpy as np
     from mlx_vlm_amd.generate import generate_step
 
     ids = np.array([[5, 6, 7]])
     for kw in (dict(kv_bits=4), dict(kv_bits=8, kv_group_size=32), dict(kv_bits=3.5), dict(kv_bits=8, kv_quant_scheme="turboquant"),
-               dict(max_kv_size=1024), dict(draft_model=object()), dict(thinking_budget_criteria=object()),
-               dict(logits_processors=[lambda t, l: l])):
+               dict(max_kv_size=1024), dict(draft_model=object())):
         with pytest.raises(NotImplementedError):
+            next(generate_step(ids, None, None, None, max_tokens=2, **kw))
+    for kw in (dict(logits_processors=[123]), dict(sampler=7)):
+        with pytest.raises(TypeError):
             next(generate_step(ids, None, None, None, max_tokens=2, **kw))
 
 
@@ -552,3 +555,26 @@ def test_dp_batch_generate_carries_model_specific_request_fields(monkeypatch):
     assert seen["extras"] == [{k: v for k, v in reqs[i].items() if k not in parallel._REQUEST_KEYS} for i in order]
     assert seen["pix"] == [reqs[i].get("pixel_values") for i in order] and seen["grids"] == [reqs[i].get("image_grid_thw") for i in order]
     assert seen["extras"][order.index(0)] == {"image_sizes": [[336, 336]]} and seen["extras"][order.index(2)] == {"pixel_attention_mask": "pm2"}
+
+
+def test_thinking_budget_criteria_matches_reference_known_answers():
+    """utils.ThinkingBudgetCriteria against the reference class's own outputs (tests/golden/make_golden_thinking.py executes
+    mlx_vlm/utils.py:2252-2335 on seeded token streams): return value, popped forced id and every state field per token."""
+    import json
+
+    from mlx_vlm_amd.utils import ThinkingBudgetCriteria
+
+    class Tok:
+        def encode(self, t, add_special_tokens=False):
+            return {"<think>": [5, 7], "</think>": [8], "\n": [9]}.get(t, [1])
+
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "thinking_ref.json")))
+    assert len(cases) == 60
+    for case in cases:
+        c = ThinkingBudgetCriteria(Tok(), **case["kw"])
+        for i, (t, pop, want) in enumerate(zip(case["tokens"], case["pops"], case["trace"])):
+            ret = c(t)
+            popped = c.pop_forced_token_id() if pop else "-"
+            assert [ret, popped, c.in_thinking, c.thinking_token_count, c.budget_exceeded, c.forced_token_id] == want, (case["kw"], i)
+            if i == 30:
+                c.reset_thinking_state()
