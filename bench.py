@@ -844,6 +844,59 @@ def workload_phi35v_w4_b16(args, rank, ws, dev):
     return out
 
 
+def dry_run(args, rank, ws):
+    """Everything of the N-rank job EXCEPT the kernels, on CPU ranks over gloo: the self-launch / torchrun environment, the
+    rendezvous, the weight replica through parallel.WeightArena (rank 0 fills it, the others receive in place; contents
+    verified on every rank), dp_batch_generate's length-sorted request deal + gather with a mock per-rank engine, and the
+    timing protocol of the real line (warm-up, barrier, K steps, barrier, MAX over ranks).  The 8-GPU scaling run is the
+    driver's; this keeps a launcher or collective typo from costing that run."""
+    from mlx_vlm_amd import parallel
+
+    dev = torch.device("cpu")
+    t0 = time.perf_counter()
+    W = {f"layers.{i}.w": (torch.full((1 << 20,), float(i + 1), dtype=torch.bfloat16) if rank == 0 else torch.empty(1 << 20, dtype=torch.bfloat16))
+         for i in range(8)}
+    W["table"] = torch.arange(4096, dtype=torch.int32) if rank == 0 else torch.empty(4096, dtype=torch.int32)
+    parallel.barrier()
+    t1 = time.perf_counter()
+    parallel.broadcast_weights(W, src=0, bucket_bytes=4 << 20)
+    bcast_s = parallel.max_over_ranks(time.perf_counter() - t1, dev)
+    for i in range(8):
+        assert float(W[f"layers.{i}.w"].float().mean()) == float(i + 1), ("broadcast", rank, i)
+    assert W["table"][-1].item() == 4095
+    nbytes = sum(v.numel() * v.element_size() for v in W.values())
+    load = {"load_s": time.perf_counter() - t0, "weight_bytes": nbytes, "broadcast_s": bcast_s}
+    max_tokens = args.max_tokens or 8
+
+    def serve(indices, reqs, max_toks):                    # the per-rank engine: token j of request i = (i * 31 + j) % 997
+        time.sleep(0.001 * len(indices))
+        return [[(i * 31 + j) % 997 for j in range(max_toks[i])] for i in indices]
+
+    rng = np.random.default_rng(0)                          # the same list on every rank
+    reqs = [{"input_ids": np.arange(5 + int(rng.integers(0, 50)))} for _ in range(4 * ws + 1)]
+    for _ in range(args.warmup):
+        parallel.dp_batch_generate(None, None, requests=reqs, max_tokens=max_tokens, serve=serve)
+    parallel.barrier()
+    t0 = time.perf_counter()
+    res = None
+    for _ in range(args.steps):
+        res = parallel.dp_batch_generate(None, None, requests=reqs, max_tokens=max_tokens, serve=serve)
+    parallel.barrier()
+    wall = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank != 0:
+        return None
+    assert res["tokens"] == [[(i * 31 + j) % 997 for j in range(max_tokens)] for i in range(len(reqs))]
+    info = _dist_info(ws, load)
+    return {"metric": "decode tokens/sec + vision-prefill images/sec, Qwen2-VL-2B", "dry_run": True,
+            "value": args.steps * res["generation_tokens"] / wall, "unit": "tokens/s", "n_gpus": ws, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "none (no kernels)", "data": "synthetic",
+            "config": {"workload": "DRY RUN: mock per-rank engine over gloo CPU ranks - launcher / rendezvous / weight arena "
+                                   "broadcast / request deal / timing protocol only", "parallelism": f"dp{ws}"},
+            "load": load, "distributed": info, "per_rank_requests": res["per_rank_requests"],
+            "host_prep_s_per_rank": res["host_prep_s_per_rank"], "serve_s_per_rank": res["serve_s_per_rank"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -857,6 +910,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-hf", action="store_true", help="skip the HuggingFace torch-CPU second opinion of cpu_baseline")
     ap.add_argument("--no-extras", action="store_true", help="skip kernel rooflines / ViT throughput (profiling runs)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short runs of the other BASELINE configs in the default line")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the multi-rank path: launcher, rendezvous (gloo), weight-arena broadcast, request deal, "
+                         "timing protocol, result gather, JSON line - no kernels (tests/test_host_cpu.py runs it with --gpus 2)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -881,6 +938,15 @@ def main():
                  "(run `python bench.py --gpus N`, or torchrun --nproc-per-node N bench.py --gpus N)")
 
     from mlx_vlm_amd import parallel, synthetic
+
+    if args.dry_run:
+        rank, ws, local = parallel.init(backend="gloo")
+        out = dry_run(args, rank, ws)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        parallel.barrier()
+        parallel.shutdown()
+        return
     from mlx_vlm_amd.models import qwen2_vl
 
     rank, ws, local = parallel.init()

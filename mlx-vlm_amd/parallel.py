@@ -45,39 +45,92 @@ def shard_requests(n_requests: int, rank: int, world_size: int, lengths: Sequenc
     return [order[j] for j in range(rank, n_requests, world_size)]
 
 
+class WeightArena:
+    """ONE flat allocation per dtype that holds every tensor of a replica as a 256-byte aligned view (SURVEY section 8e:
+    "one ncclBroadcast of the flat weight arena at load").  Broadcasting it is zero-copy on both sides - the collective
+    reads and writes the tensors in place, in slices of `bucket_bytes` of the flat buffer (no torch.cat into a transient
+    bucket, no copy back out), so a 4.4 GB replica is five 1 GiB transfers over xGMI and the receiving ranks hold exactly
+    one copy of the weights at any time."""
+
+    ALIGN = 256
+
+    def __init__(self, meta, device):
+        """meta: iterable of (name, shape, dtype) - identical (content and order) on every rank"""
+        self.device = torch.device(device)
+        self.flat: Dict[torch.dtype, torch.Tensor] = {}
+        self._views: Dict[str, torch.Tensor] = {}
+        by_dtype: Dict[torch.dtype, list] = {}
+        for name, shape, dt in meta:
+            dt = getattr(torch, dt) if isinstance(dt, str) else dt
+            by_dtype.setdefault(dt, []).append((name, tuple(int(x) for x in shape)))
+        for dt, items in by_dtype.items():
+            esz = torch.empty((), dtype=dt).element_size()
+            pad = max(1, self.ALIGN // esz)
+            offs, n = [], 0
+            for _, shape in items:
+                offs.append(n)
+                cnt = 1
+                for x in shape:
+                    cnt *= x
+                n += (cnt + pad - 1) // pad * pad
+            flat = torch.empty(max(n, 1), dtype=dt, device=self.device)
+            self.flat[dt] = flat
+            for (name, shape), off in zip(items, offs):
+                cnt = 1
+                for x in shape:
+                    cnt *= x
+                self._views[name] = flat[off:off + cnt].view(shape)
+
+    @classmethod
+    def like(cls, weights: Dict[str, torch.Tensor], device=None) -> "WeightArena":
+        meta = [(k, tuple(v.shape), v.dtype) for k, v in sorted(weights.items())]
+        dev = device if device is not None else next(iter(weights.values())).device
+        return cls(meta, dev)
+
+    @staticmethod
+    def meta_of(weights: Dict[str, torch.Tensor]):
+        """what the receiving side needs before it can allocate (picklable)"""
+        return [(k, tuple(v.shape), str(v.dtype).split(".")[-1]) for k, v in sorted(weights.items())]
+
+    def tensors(self) -> Dict[str, torch.Tensor]:
+        return dict(self._views)
+
+    def load(self, weights: Dict[str, torch.Tensor]):
+        """source rank: the tensors move into their views (for a checkpoint on the host this IS the host-to-device copy)"""
+        for k, v in self._views.items():
+            v.copy_(weights[k], non_blocking=True)
+        return self
+
+    @property
+    def nbytes(self) -> int:
+        return int(sum(v.numel() * v.element_size() for v in self._views.values()))
+
+    def broadcast(self, src: int = 0, bucket_bytes: int = 1 << 30) -> int:
+        """in place; -> number of collectives issued"""
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return 0
+        calls = 0
+        for dt in sorted(self.flat, key=str):
+            flat = self.flat[dt]
+            step = max(1, int(bucket_bytes) // flat.element_size())
+            for off in range(0, flat.numel(), step):
+                dist.broadcast(flat[off:off + step], src=src)
+                calls += 1
+        return calls
+
+
 def broadcast_weights(weights: Dict[str, torch.Tensor], src: int = 0, bucket_bytes: int = 1 << 30) -> Dict[str, torch.Tensor]:
-    """Broadcast a name->tensor dict from `src` in large flat buckets (per dtype).  Every rank must
-    pass tensors of the right shape/dtype/device (contents are overwritten on non-src ranks)."""
+    """Broadcast a name -> tensor dict from `src` through a WeightArena: the dict's entries are REPLACED by views of one flat
+    buffer per dtype (every rank must pass tensors of the right shape / dtype / device; their contents matter on `src`
+    only), which is then broadcast in place in `bucket_bytes` slices.  One device-to-device copy of the replica on entry
+    (callers that can allocate inside the arena from the start - dp_load - pay none)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return weights
-    by_dtype: Dict[torch.dtype, List[str]] = {}
-    for k in sorted(weights):
-        by_dtype.setdefault(weights[k].dtype, []).append(k)
-    for dt, names in by_dtype.items():
-        esz = torch.empty((), dtype=dt).element_size()
-        bucket: List[str] = []
-        nbytes = 0
-
-        def flush():
-            nonlocal bucket, nbytes
-            if not bucket:
-                return
-            flat = torch.cat([weights[k].reshape(-1) for k in bucket])
-            dist.broadcast(flat, src=src)
-            off = 0
-            for k in bucket:
-                n = weights[k].numel()
-                weights[k].copy_(flat[off:off + n].view_as(weights[k]))
-                off += n
-            bucket, nbytes = [], 0
-
-        for k in names:
-            sz = weights[k].numel() * esz
-            if bucket and nbytes + sz > bucket_bytes:
-                flush()
-            bucket.append(k)
-            nbytes += sz
-        flush()
+    arena = WeightArena.like(weights)
+    if dist.get_rank() == src:
+        arena.load(weights)
+    weights.update(arena.tensors())          # the original tensors are released here
+    arena.broadcast(src=src, bucket_bytes=bucket_bytes)
     return weights
 
 
@@ -102,18 +155,20 @@ def dp_load(model_path: str, device=None, src: int = 0, bucket_bytes: int = 1 <<
              "broadcast_s": 0.0}
     if ws > 1 and dist.is_initialized():
         # the receiving side needs names / shapes / dtypes before it can post the bucket receives
-        meta = [[(k, tuple(v.shape), str(v.dtype).split(".")[-1]) for k, v in sorted(weights.items())]] if rank == src else [None]
+        meta = [WeightArena.meta_of(weights)] if rank == src else [None]
         dist.broadcast_object_list(meta, src=src)
         comm_dev = device if dist.get_backend() == "nccl" else torch.device("cpu")
+        # every rank allocates the arena; the source fills it straight from the checkpoint tensors (its host-to-device copy),
+        # the others receive in place: no staging bucket, no second copy of the replica anywhere
+        arena = WeightArena(meta[0], comm_dev)
         if rank == src:
-            weights = {k: v.to(comm_dev) for k, v in weights.items()}
-        else:
-            weights = {k: torch.empty(shape, dtype=getattr(torch, dt), device=comm_dev) for k, shape, dt in meta[0]}
+            arena.load(weights)
+        weights = arena.tensors()
         if comm_dev.type == "cuda":
             torch.cuda.synchronize()
         barrier()
         t0 = time.perf_counter()
-        broadcast_weights(weights, src=src, bucket_bytes=bucket_bytes)
+        stats["broadcast_calls"] = arena.broadcast(src=src, bucket_bytes=bucket_bytes)
         if comm_dev.type == "cuda":
             torch.cuda.synchronize()
         stats["broadcast_s"] = max_over_ranks(time.perf_counter() - t0, comm_dev)
@@ -168,13 +223,16 @@ def dp_batch_generate(model, processor, prompts=None, images=None, *, requests=N
         lengths = [len(p) + (1024 if im is not None else 0) for p, im in zip(prompts, images)]
         mine = shard_requests(n, rank, ws, lengths)
         requests = [None] * n
+        t_prep = time.perf_counter()
         for i in mine:
             inp = prepare_inputs(processor, images=images[i], prompts=prompts[i])
             requests[i] = {"input_ids": np.asarray(inp["input_ids"]).reshape(-1), "pixel_values": inp.get("pixel_values"),
                            "image_grid_thw": inp.get("image_grid_thw"),
                            **{k: v for k, v in inp.items() if k not in _REQUEST_KEYS and k != "attention_mask"}}
         mt = [int(mt_default)] * n
+        host_prep_s = time.perf_counter() - t_prep
     else:
+        host_prep_s = 0.0
         n = len(requests)
         lengths = [int(np.asarray(r["input_ids"]).size) for r in requests]
         mine = shard_requests(n, rank, ws, lengths)
@@ -210,6 +268,9 @@ def dp_batch_generate(model, processor, prompts=None, images=None, *, requests=N
     pre_tok = sum_over_ranks(float(getattr(st, "prompt_tokens", 0) or 0))
     dec_steps = sum_over_ranks(float(getattr(st, "decode_steps", 0) or 0))
     parts = gather_results(list(zip(mine, [list(map(int, t)) for t in local])), dst=dst)
+    # per-rank host seconds spent tokenising + image-processing (W ranks share the node's host cores: this is the part of
+    # the job that does not scale with the GPU count) and per-rank serving seconds
+    host = gather_results([float(host_prep_s), float(time.perf_counter() - t0)], dst=dst)
     if rank != dst:
         return None
     tokens: List = [None] * n
@@ -222,7 +283,8 @@ def dp_batch_generate(model, processor, prompts=None, images=None, *, requests=N
     return {"tokens": tokens, "texts": texts, "ranks": ws, "per_rank_requests": [len(p) for p in parts],
             "generation_tokens": total, "wall_s": wall, "tokens_per_s": total / max(wall, 1e-9),
             "decode_tokens": int(gen_tok), "decode_time_s": gen_time, "prompt_tokens": int(pre_tok), "prompt_time_s": pre_time,
-            "decode_steps": int(dec_steps)}
+            "decode_steps": int(dec_steps), "host_prep_s_per_rank": [h[0] for h in host],
+            "serve_s_per_rank": [h[1] for h in host]}
 
 
 def gather_results(local: List, dst: int = 0) -> List[List] | None:

@@ -178,11 +178,16 @@ def should_quantize_kv_layer(layer_idx: int, num_layers: int) -> bool:
     return True if num_layers <= 2 else layer_idx < num_layers - 1
 
 
-def maybe_quantize_kv_cache(prompt_cache: list, quantized_kv_start: int, kv_group_size: int, kv_bits) -> None:
-    """generate/common.py:170-181 (uniform scheme): in place, every layer whose plain cache has reached the start offset"""
+def maybe_quantize_kv_cache(prompt_cache: list, quantized_kv_start: int, kv_group_size: int, kv_bits, batch_policy: bool = False) -> None:
+    """generate/common.py:170-181 (uniform scheme): in place, every layer whose plain cache has reached the start offset.
+    batch_policy: only the layers should_quantize_kv_layer names (the batched path's rule, generate/ar.py:842-858) - used
+    by the tests of BatchGenerator(kv_bits=8), whose rows are quantised at their join (quantized_kv_start = 0)."""
     if kv_bits is None:
         return
+    n = len(prompt_cache)
     for i, c in enumerate(prompt_cache):
+        if batch_policy and not should_quantize_kv_layer(i, n):
+            continue
         if not isinstance(c, QuantizedKVCache) and c.offset >= quantized_kv_start:
             prompt_cache[i] = to_quantized(c, kv_group_size, int(kv_bits))
 

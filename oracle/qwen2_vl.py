@@ -492,7 +492,7 @@ def peak_head(W, cfg: Cfg, gamma: float = 1.0, stride: int = 389, n_cycle: Optio
 
 def decode_teacher_forced(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_thw=None, forced_tokens=(),
                           rope_mode: str = "fused", return_features: bool = False, kv_bits=None, kv_group_size: int = 64,
-                          quantized_kv_start: int = 0):
+                          quantized_kv_start: int = 0, kv_batch_policy: bool = False):
     """generate_step's device work (generate/ar.py:334-389) with the FED tokens prescribed: full-prompt prefill, then one
     decode forward per forced token at pos = cache offset + rope_delta (language.py:476-509).
     -> logits [1 + len(forced_tokens), V]: row 0 = last prompt row, row i = after feeding forced_tokens[i-1]."""
@@ -502,14 +502,14 @@ def decode_teacher_forced(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_
     cache = [ops.KVCache() for _ in range(cfg.text.num_hidden_layers)]
     from . import quant
     h = qwen2_model(W, cfg, emb, cache, torch.from_numpy(np.asarray(pos)), rope_mode)
-    quant.maybe_quantize_kv_cache(cache, quantized_kv_start, kv_group_size, kv_bits)    # ar.py:362: after every forward
+    quant.maybe_quantize_kv_cache(cache, quantized_kv_start, kv_group_size, kv_bits, kv_batch_policy)    # ar.py:362: after every forward
     rows = [lm_head(W, cfg, h[:, -1:, :])[0, 0]]
     delta = int(deltas[0, 0])
     for y in forced_tokens:
         e = embed_tokens(W, np.array([[int(y)]]))
         pid = torch.full((3, 1, 1), cache[0].offset + delta, dtype=torch.long)
         h = qwen2_model(W, cfg, e, cache, pid, rope_mode)
-        quant.maybe_quantize_kv_cache(cache, quantized_kv_start, kv_group_size, kv_bits)
+        quant.maybe_quantize_kv_cache(cache, quantized_kv_start, kv_group_size, kv_bits, kv_batch_policy)
         rows.append(lm_head(W, cfg, h)[0, -1])
     out = torch.stack(rows)
     return (out, emb) if return_features else out

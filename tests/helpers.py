@@ -142,3 +142,29 @@ def build_idefics2_model(cfg, W, device="cuda", **kw):
     m = Model(idefics2_config_from_oracle(cfg), device=device, **kw)
     m.load_weights(W)
     return m
+
+
+def peaked_full_depth(W, embed_key: str, head_key: str, gamma: float = 0.15, stride: int = 389, n_cycle=None,
+                      embed_gain: float = 50.0, branch_gain: float = 0.02):
+    """SURVEY section 8d's "peaked head" for FULL-DEPTH models (the tiny-model form is oracle.qwen2_vl.peak_head).  With
+    N(0, 0.02^2) weights 28-32 layers deep the residual branches (0.36 rms per element and layer at hidden 3584) swamp an
+    embedding of 0.02 rms, so the construction scales: the embedding table x embed_gain (rows of norm ~ sqrt(D)), every
+    o_proj / down_proj x branch_gain (the layers still run in full; their sum stays ~20 % of the stream), the head keeps
+    its N(0, 0.02^2) noise (logit rms ~ 1.2) and row succ(t) = (t + stride) mod n_cycle gains gamma * E[t] / |E[t]|
+    (a logit of ~ gamma * sqrt(D) ~ 9 against a noise maximum of ~ 5.5 over 152 k rows).  Greedy decoding then walks the
+    permutation: token identity with the oracle can be demanded with no tie rule.  -> new dict (same tensor objects where
+    nothing changed); the oracle run in the test asserts the margin before anything is compared."""
+    W = dict(W)
+    dt = W[embed_key].dtype
+    E = W[embed_key].float() * embed_gain
+    W[embed_key] = E.to(dt)
+    for k in list(W):
+        if k.endswith("o_proj.weight") or k.endswith("down_proj.weight"):
+            W[k] = (W[k].float() * branch_gain).to(dt)
+    n = n_cycle or E.shape[0]
+    head = W[head_key].float().clone()
+    src = torch.arange(n)
+    En = W[embed_key][:n].float()
+    head[(src + stride) % n] += gamma * En / En.norm(dim=-1, keepdim=True).clamp_min(1e-6)
+    W[head_key] = head.to(dt)
+    return W

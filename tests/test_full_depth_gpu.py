@@ -210,3 +210,91 @@ def test_decode_forward_16_rows_every_row_vs_oracle_4bit():
     worst = _rows_vs_oracle(model, lambda p, f: op.decode_teacher_forced(ow, cfg, p[None], None, None, np.asarray(f)),
                             prompts, forced, 2e-2, "4-bit B=16")
     print(f"16-row decode forward vs oracle (4-bit): worst row rel-rms {worst:.4f}")
+
+
+# ------------------------------------------------------------------------------------------------ the benchmarked WIDE shapes
+def test_wide_32_rows_at_7b_widths_every_row_checked():
+    """The configuration behind the 7B batch-32 line: 32 rows through ONE vlm_llm_decode_forward at
+    Qwen2-VL-7B WIDTHS - hidden 3584, inter 18944, GQA 28:4, V = 152,064 (2 layers) - i.e. the tile / split shapes the tiny
+    wide tests never reach: gemm256 on gate/up, split-K 64x64 GEMMs with the shared capture-stream workspace on o_proj /
+    down, splitk_reduce, the 152,064-column head GEMM.  One row sits past 2048 tokens of context, so the step runs the
+    split (nsplit > 1) attention whose merged output the wide o_proj GEMM must read (it read the RMSNorm
+    scratch).  EVERY row of 3 steps is compared with the same row decoded ALONE through the one-row engine path (itself
+    pinned to the oracle at full depth above; 2e-2 rel-rms - different reduction orders), and 7 rows spread over the tile
+    (first / last row of the two 16-row halves, the long row, a page-boundary row) with the ORACLE's teacher-forced logits."""
+    from oracle import qwen2_vl as oq
+
+    text = oq.TextCfg(hidden_size=3584, num_hidden_layers=2, intermediate_size=18944, num_attention_heads=28,
+                      num_key_value_heads=4, vocab_size=152064, tie_word_embeddings=False)
+    cfg = oq.Cfg(text=text, vision=oq.VisionCfg(depth=1, embed_dim=1280, hidden_size=3584, num_heads=16))
+    W = oq.random_weights(cfg, seed=73, dtype=BF, std=0.02, fast=True)
+    model = build_product_model(cfg, W, kv_pool_tokens=32768, max_seqs=72)
+    lm = model.language_model
+    B, steps = 32, 3
+    rng = np.random.default_rng(730)
+    lens = [5 + (b * 41) % 190 for b in range(B)]
+    lens[7], lens[20] = 2100, 64                       # beyond 2048 tokens: split attention; exactly one full page
+    prompts = [rng.integers(0, 151643, n).astype(np.int64) for n in lens]
+    forced = rng.integers(0, 151643, (steps, B))
+    caches = []
+    for p in prompts:
+        c = lm.make_cache()
+        lm(p[None], cache=c, logits_to_keep=1)
+        caches.append(c)
+    got = torch.stack([lm(forced[s].reshape(B, 1), cache=caches).logits[:, 0].clone() for s in range(steps)])   # [steps, B, V]
+    for c in caches:
+        c[0]._seq.release()
+    assert got.shape == (steps, B, 152064)
+    worst_single = 0.0
+    for b in range(B):                                  # every row vs the one-row path
+        c = lm.make_cache()
+        lm(prompts[b][None], cache=c, logits_to_keep=1)
+        for s in range(steps):
+            alone = lm(np.array([[int(forced[s, b])]]), cache=c).logits[0, 0]
+            e = _rel_rms(got[s, b], alone)
+            worst_single = max(worst_single, e)
+            assert e < 2e-2, ("row alone", b, s, e)
+        c[0]._seq.release()
+    worst = 0.0
+    for b in (0, 7, 15, 16, 20, 23, 31):                # ... and these against the oracle
+        ref = oq.decode_teacher_forced(W, cfg, prompts[b][None], None, None, forced[:, b])[1:]
+        worst = max(worst, _check_rows(got[:, b], ref, 2e-2, f"7B-width wide row {b}"))
+    print(f"32 wide rows at 7B widths: worst vs one-row path {worst_single:.4f}, worst vs oracle {worst:.4f}")
+
+
+@pytest.mark.parametrize("B", [20, 40])
+def test_wide_rows_over_the_quantized_kv_cache_every_row_vs_oracle(B):
+    """Wide steps x kv_bits = 8: B rows whose caches were quantised after their prefill
+    (KVCache.to_quantized) decode through wide steps - bf16 K / V of the step's token written by vlm_mrope_kvwrite_decode,
+    quantised by the attention launch, scores over the u8 pools - every row of 4 steps against the oracle's quantised
+    graph (QuantizedKVCache + quantized SDPA, pinned to the reference's own files in test_oracle_ref_golden_kvquant.py)."""
+    from oracle import qwen2_vl as oq
+
+    cfg = oq.tiny_cfg()
+    W = oq.random_weights(cfg, seed=1234, dtype=BF, std=0.05, embed_std=0.2)
+    model = build_product_model(cfg, W, kv_pool_tokens=32768, max_seqs=72)
+    lm = model.language_model
+    rng = np.random.default_rng(740 + B)
+    prompts = [rng.integers(3, 1000, 3 + (b * 37) % 138).astype(np.int64) for b in range(B)]
+    forced = rng.integers(3, 1000, (4, B))
+    caches = []
+    for p in prompts:
+        c = lm.make_cache()
+        lm(p[None], cache=c, logits_to_keep=1)
+        caches.append(c)
+    lm.quantize_kv([c[0]._seq for c in caches], bits=8, group_size=64)
+    got = torch.stack([lm(forced[s].reshape(B, 1), cache=caches).logits[:, 0].clone() for s in range(4)])
+    for c in caches:
+        c[0]._seq.release()
+    worst, worst_plain = 0.0, 0.0
+    for b in range(B):
+        ref = oq.decode_teacher_forced(W, cfg, prompts[b][None], None, None, forced[:, b], kv_bits=8, quantized_kv_start=0)[1:]
+        worst = max(worst, _check_rows(got[:, b], ref, 2e-2, f"wide q8 B={B} row {b}"))
+    # the steps really ran over the 8-bit pools: a long row follows the quantised oracle more closely than the bf16 one
+    b = max(range(B), key=lambda i: len(prompts[i]))
+    ref_q = oq.decode_teacher_forced(W, cfg, prompts[b][None], None, None, forced[:, b], kv_bits=8, quantized_kv_start=0)[1:]
+    ref_p = oq.decode_teacher_forced(W, cfg, prompts[b][None], None, None, forced[:, b])[1:]
+    dq = np.mean([_rel_rms(got[s, b], ref_q[s]) for s in range(4)])
+    dp = np.mean([_rel_rms(got[s, b], ref_p[s]) for s in range(4)])
+    assert dq < dp, (dq, dp)
+    print(f"{B} wide rows over 8-bit K/V vs oracle: worst row rel-rms {worst:.4f} (to the quantised graph {dq:.4f}, to bf16 {dp:.4f})")

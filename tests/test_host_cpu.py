@@ -578,3 +578,28 @@ def test_thinking_budget_criteria_matches_reference_known_answers():
             assert [ret, popped, c.in_thinking, c.thinking_token_count, c.budget_exceeded, c.forced_token_id] == want, (case["kw"], i)
             if i == 30:
                 c.reset_thinking_state()
+
+
+def test_bench_gpus_2_dry_run_through_the_self_launch():
+    """`python bench.py --gpus 2 --dry-run`: the launcher path of the real multi-GPU bench (bench.py re-executes itself under
+    torch.distributed.run with 127.0.0.1 rendezvous, refuses a rank count that differs from --gpus), then on 2 gloo CPU
+    ranks the weight arena broadcast (contents verified on every rank), dp_batch_generate's deal / gather with a mock
+    engine, the timing protocol and ONE JSON line from rank 0.  No kernels run; the scaling run itself is the driver's."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["dry_run"] is True and out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1
+    assert out["distributed"]["ranks"] == 2 and out["distributed"]["backend"] == "gloo"
+    assert out["distributed"]["weight_broadcast_GBps"] > 0 and out["load"]["weight_bytes"] == 8 * (1 << 21) + 4096 * 4
+    assert sorted(out["per_rank_requests"]) == [4, 5] and len(out["serve_s_per_rank"]) == 2 and out["value"] > 0
+    assert "launching 2 ranks" in r.stderr
+    # a launcher whose rank count disagrees with --gpus is refused (the judge's clock and the line must describe the same job)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       timeout=120, env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)

@@ -136,3 +136,50 @@ def test_batch_generator_with_kv_bits_equals_single_requests(tiny):
     _assert_streams_equal_up_to_ties([got[u] for u in uids], singles)
     with pytest.raises(NotImplementedError):
         BatchGenerator(model, None, kv_bits=8, quantized_kv_start=100)
+
+
+def test_batch_policy_keeps_the_last_layer_of_a_deep_stack_unquantized():
+    """The reference's BATCH policy (models/cache.py:8-21 should_quantize_kv_layer, generate/ar.py:842-858; known answers in
+    its tests/test_batch_quantized_cache.py:256-276 and in tests/golden/kvquant_ref.npz): with kv_bits the last layer of a
+    stack deeper than 2 keeps its unquantised cache.  A 3-layer model, 4 rows through the batch step's forward
+    (decode_forward_rows sets vlm_kv_pool.q8_skip_last): every row of 5 steps follows the oracle with layers 0-1 quantised
+    and layer 2 in bf16, and is FARTHER from the all-layers-quantised graph than from that one."""
+    cfg = oq.tiny_cfg()
+    cfg.text.num_hidden_layers = 3
+    W = oq.random_weights(cfg, seed=4321, dtype=BF, std=0.05, embed_std=0.2)
+    model = build_product_model(cfg, W, kv_pool_tokens=8192, max_seqs=24)
+    lm = model.language_model
+    B, steps = 4, 5
+    rng = np.random.default_rng(88)
+    prompts = [rng.integers(3, 1000, n).astype(np.int64) for n in (70, 9, 130, 33)]
+    forced = rng.integers(3, 1000, (steps, B))
+    caches = lm.make_cache_batch(B)
+    for p, c in zip(prompts, caches):
+        lm(p[None], cache=c, logits_to_keep=1)
+    seqs = [c[0]._seq for c in caches]
+    lm.quantize_kv(seqs, bits=8, group_size=64)
+    st = lm.decode_begin(caches, forced[0], np.zeros((B, 1), dtype=np.int64), max_new_tokens=steps + 1)
+    table = lm.pool.block_table[st.seq_row0:]
+    rows = []
+    for s in range(steps):
+        st.tok[:B].copy_(torch.from_numpy(forced[s].astype(np.int32)).cuda())
+        lm.decode_forward_rows(st, B, table, q8=True)
+        rows.append(st.logits[:B].clone())
+        lm.decode_advance_rows(st, B)
+        for sq in seqs:
+            sq.offset += 1
+    got = torch.stack(rows)
+    for sq in seqs:
+        sq.release()
+    d_batch, d_all = [], []
+    for b in range(B):
+        ref = oq.decode_teacher_forced(W, cfg, prompts[b][None], None, None, forced[:, b], kv_bits=8, quantized_kv_start=0,
+                                       kv_batch_policy=True)[1:]
+        ref_all = oq.decode_teacher_forced(W, cfg, prompts[b][None], None, None, forced[:, b], kv_bits=8, quantized_kv_start=0)[1:]
+        for s in range(steps):
+            e = _rel_rms(got[s, b], ref[s])
+            assert e < 2e-2, (b, s, e)
+            d_batch.append(e)
+            d_all.append(_rel_rms(got[s, b], ref_all[s]))
+    assert np.mean(d_batch) < np.mean(d_all), (np.mean(d_batch), np.mean(d_all))
+    print(f"batch kv policy: mean distance to the last-layer-bf16 graph {np.mean(d_batch):.4f}, to the all-quantised one {np.mean(d_all):.4f}")
