@@ -64,10 +64,11 @@ def dequantize(wq, scales, biases, group_size: int = 64, bits: int = 4, dtype=No
     return w.reshape(N, K).to(dtype or scales.dtype)
 
 
-def quantized_linear(x, wq, scales, biases, bias=None, group_size: int = 64, bits: int = 4):
+def quantized_linear(x, wq, scales, biases, bias=None, group_size: int = 64, bits: int = 4, w_f32=None):
     """nn.QuantizedLinear: mx.quantized_matmul(x, w, scales, biases, transpose=True) (+ bias).  fp32 accumulation over
-    x (its dtype) times the fp32 dequantized weight, one rounding to x's dtype; the bias add is a second typed op."""
-    w = dequantize(wq, scales, biases, group_size, bits, dtype=F32)
+    x (its dtype) times the fp32 dequantized weight, one rounding to x's dtype; the bias add is a second typed op.
+    w_f32: the fp32 affine weights if the caller keeps them (QW.keep_f32 - same values, computed once)."""
+    w = w_f32 if w_f32 is not None else dequantize(wq, scales, biases, group_size, bits, dtype=F32)
     y = (x.to(F32) @ w.T).to(x.dtype)
     if bias is not None:
         y = (y.to(F32) + bias.to(F32)).to(x.dtype)
@@ -88,8 +89,16 @@ class QW:
     def shape(self):
         return (self.wq.shape[0], self.wq.shape[1] * 32 // self.bits)
 
+    keep_f32 = False        # class-wide switch for long full-size runs: keep each weight's fp32 affine values after the first
+                            # use instead of unpacking 4-bit words on every call (same values; 4 bytes per weight of host memory)
+
     def linear(self, x, bias=None):
-        return quantized_linear(x, self.wq, self.scales, self.biases, bias, self.group_size, self.bits)
+        w = None
+        if QW.keep_f32:
+            w = self.__dict__.get("_f32")
+            if w is None:
+                w = self._f32 = dequantize(self.wq, self.scales, self.biases, self.group_size, self.bits, dtype=F32)
+        return quantized_linear(x, self.wq, self.scales, self.biases, bias, self.group_size, self.bits, w_f32=w)
 
     def rows(self, idx):
         """nn.QuantizedEmbedding.__call__: mx.dequantize of the gathered rows"""

@@ -298,3 +298,73 @@ def test_wide_rows_over_the_quantized_kv_cache_every_row_vs_oracle(B):
     dp = np.mean([_rel_rms(got[s, b], ref_p[s]) for s in range(4)])
     assert dq < dp, (dq, dp)
     print(f"{B} wide rows over 8-bit K/V vs oracle: worst row rel-rms {worst:.4f} (to the quantised graph {dq:.4f}, to bf16 {dp:.4f})")
+
+
+# ------------------------------------------------------------------------------------------------ greedy token identity at full depth
+def _greedy_identity(tag, model, oracle_greedy, ids, n_new, k_oracle, stride, n_cycle):
+    """32 greedy tokens through the captured decode step must be IDENTICAL to the oracle's - no tie rule (north_star: "token-id
+    bit-exact under greedy").  The oracle decodes the first k_oracle tokens at full depth (seconds per token on the host)
+    and must itself show the construction's margin at every one of them (top-2 gap above half the logit rms) and walk the
+    successor permutation; the engine's whole stream must equal the oracle's prefix and continue the same permutation walk,
+    which the construction makes the unique greedy path."""
+    from mlx_vlm_amd.generate import generate_step
+
+    ref_toks, ref_logits = oracle_greedy(k_oracle)
+    want = [(int(ids[0, -1]) + stride * (i + 1)) % n_cycle for i in range(n_new)]
+    assert ref_toks == want[:k_oracle], (tag, ref_toks, want[:k_oracle])
+    for i in range(k_oracle):
+        r = ref_logits[i].float()
+        top2 = r.topk(2).values
+        assert float(top2[0] - top2[1]) > 0.5 * float(r.pow(2).mean().sqrt()), (tag, i)
+    toks = [t for t, _ in generate_step(ids, model, None, None, max_tokens=n_new, temperature=0.0)]
+    assert toks[:k_oracle] == ref_toks, (tag, toks[:k_oracle], ref_toks)
+    assert toks == want, (tag, toks, want)
+    print(f"{tag}: {n_new} greedy tokens identical ({k_oracle} against the oracle, the rest on the permutation it confirmed)")
+
+
+def test_full_depth_qwen2_vl_7b_greedy_tokens_identical_to_oracle():
+    from oracle import qwen2_vl as oq
+    from tests.helpers import peaked_full_depth
+
+    text = oq.TextCfg(hidden_size=3584, num_hidden_layers=28, intermediate_size=18944, num_attention_heads=28,
+                      num_key_value_heads=4, vocab_size=152064, tie_word_embeddings=False)
+    cfg = oq.Cfg(text=text, vision=oq.VisionCfg(depth=1, embed_dim=1280, hidden_size=3584, num_heads=16))
+    W = oq.random_weights(cfg, seed=74, dtype=BF, std=0.02, fast=True)
+    W = peaked_full_depth(W, "language_model.model.embed_tokens.weight", "language_model.lm_head.weight", gamma=0.2, n_cycle=150000)
+    model = build_product_model(cfg, W, kv_pool_tokens=4096, max_seqs=4)
+    ids = np.random.default_rng(741).integers(3, 150000, (1, 40))
+    _greedy_identity("7B", model, lambda k: oq.generate_greedy(W, cfg, ids, max_tokens=k, return_logits=True), ids, 32, 8, 389, 150000)
+
+
+def test_full_depth_idefics2_8b_greedy_tokens_identical_to_oracle():
+    from oracle import idefics2 as oi
+    from tests.helpers import peaked_full_depth
+
+    cfg = oi.Cfg(text=oi.TextCfg(), vision=oi.VisionCfg(num_hidden_layers=1), perceiver=oi.PerceiverCfg())
+    W = oi.random_weights(cfg, seed=75, dtype=BF, std=0.02, embed_std=0.02, fast=True)
+    W = peaked_full_depth(W, oi.LM + "embed_tokens.weight", oi.LM + "lm_head.weight", gamma=0.2, n_cycle=32000)
+    model = build_idefics2_model(cfg, W, kv_pool_tokens=4096, max_seqs=4)
+    ids = np.random.default_rng(751).integers(3, 32000, (1, 40))
+    _greedy_identity("Idefics2-8B", model, lambda k: oi.generate_greedy(W, cfg, ids, max_tokens=k, return_logits=True), ids, 32, 8,
+                     389, 32000)
+
+
+def test_full_depth_phi35_vision_4bit_greedy_tokens_identical_to_oracle():
+    from oracle import phi3_v as op
+    from oracle import quant as Q
+    from tests.helpers import peaked_full_depth
+
+    short, long = op.su_factors(96, seed=9)
+    cfg = op.Cfg(text=op.TextCfg(short_factor=short, long_factor=long), vision=op.VisionCfg(num_hidden_layers=2))
+    W = op.random_weights(cfg, seed=76, dtype=BF, std=0.02, embed_std=0.02, fast=True)
+    W = peaked_full_depth(W, op.M + "embed_tokens.weight", "lm_head.weight", gamma=0.25, n_cycle=32000)
+    ck, ow = Q.quantize_checkpoint(W, predicate=lambda p, v: not p.startswith("model.vision_embed_tokens."))
+    del W
+    model = build_phi3v_model(cfg, ck, kv_pool_tokens=4096, max_seqs=4)
+    ids = np.random.default_rng(761).integers(3, 32000, (1, 40))
+    Q.QW.keep_f32 = True                 # (5 full-size oracle tokens: unpack each 4-bit matrix once, not per call)
+    try:
+        _greedy_identity("Phi-3.5-vision 4-bit", model, lambda k: op.generate_greedy(ow, cfg, ids, max_tokens=k, return_logits=True),
+                         ids, 32, 5, 389, 32000)
+    finally:
+        Q.QW.keep_f32 = False
