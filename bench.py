@@ -29,6 +29,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+T_PROCESS_START = time.perf_counter()
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak
@@ -108,8 +109,23 @@ def kernel_rooflines(model, cfg):
                                   ("gemv_lm_head", head, 2 * V * D, 1)):
         fn()
         torch.cuda.synchronize()
-        dt = time_events(fn, 4) / per
-        res[name] = {"bytes_per_launch": nbytes, "us_per_launch": dt * 1e6, "GBps": nbytes / dt / 1e9}
+        # timed as ONE captured graph of the launches (HIP events around 6 replays): a Python loop of ctypes calls is
+        # host-dispatch bound below ~10 us per launch (round 3 reported 9.6 us for a 6.1 us kernel this way)
+        side = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+            side.synchronize()
+            with torch.cuda.graph(g, stream=side):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g.replay()
+        torch.cuda.synchronize()
+        dt = time_events(g.replay, 6) / per
+        res[name] = {"bytes_per_launch": nbytes, "us_per_launch": dt * 1e6, "GBps": nbytes / dt / 1e9,
+                     "timing": f"hipGraph of {per} launch(es), HIP events over 6 replays"}
+        del g
     return res
 
 
@@ -523,11 +539,13 @@ def cpu_baseline_nanollava(threads):
                       f"image through the 27-layer SigLIP tower + projector; nothing extrapolated"}
 
 
-def cpu_baseline_lm(kind, threads):
+def cpu_baseline_lm(kind, threads, short=False):
     """cpu_baseline of the non-headline workloads: the oracle (torch-CPU restatement of the reference's graph for that model
     family) at FULL size on the host cores, single-stream decode - a bounded sample (3 or 6 tokens at the workload's context,
     all layers + lm_head + greedy sampling; K / V of the context pre-filled with random values: timing only).  The big
-    matrices of the synthetic checkpoint come from oracle.ops.fast_normal (seconds instead of minutes of setup)."""
+    matrices of the synthetic checkpoint come from oracle.ops.fast_normal (seconds instead of minutes of setup).
+    short (the `configs` block of the default line): 2 timed tokens, and 4-bit checkpoints take RANDOM packed words instead
+    of quantising billions of weights on the host (timing only) - the sample says so."""
     from oracle import ops as O
 
     torch.set_num_threads(threads)
@@ -547,7 +565,8 @@ def cpu_baseline_lm(kind, threads):
         W = oq.random_weights(cfg, seed=0, dtype=BF, fast=True)
         if kind == "qwen2vl-2b-w4":
             from oracle import quant as Q
-            W = Q.quantize_checkpoint(W, predicate=lambda p, v: p.startswith("language_model."))[1]
+            W = (_fast_w4_oracle_weights(W, lambda p, v: p.startswith("language_model.")) if short else
+                 Q.quantize_checkpoint(W, predicate=lambda p, v: p.startswith("language_model."))[1])
         t = cfg.text
         hd, nkv, nl = t.hidden_size // t.num_attention_heads, t.num_key_value_heads, t.num_hidden_layers
         step = lambda e, cache, i: O.argmax_first(O.logprobs_from_logits(  # noqa: E731
@@ -566,7 +585,8 @@ def cpu_baseline_lm(kind, threads):
         short, long = om.su_factors(96, seed=9)
         cfg = om.Cfg(text=om.TextCfg(short_factor=short, long_factor=long), vision=om.VisionCfg(num_hidden_layers=1))
         W = om.random_weights(cfg, seed=0, dtype=BF, std=0.02, embed_std=0.02, fast=True)
-        W = Q.quantize_checkpoint(W, predicate=lambda p, v: not p.startswith("model.vision_embed_tokens."))[1]
+        W = (_fast_w4_oracle_weights(W, lambda p, v: not p.startswith("model.vision_embed_tokens.")) if short else
+             Q.quantize_checkpoint(W, predicate=lambda p, v: not p.startswith("model.vision_embed_tokens."))[1])
         t = cfg.text
         hd, nkv, nl = t.hidden_size // t.num_attention_heads, t.num_key_value_heads, t.num_hidden_layers
         ctx, n_tok, label = 885, 6, "Phi-3.5-vision language model (32 layers of 3072 / 8192) as an MLX affine 4-bit checkpoint"
@@ -578,6 +598,8 @@ def cpu_baseline_lm(kind, threads):
     for c in cache:
         c.update_and_fetch((torch.randn(1, nkv, ctx, hd, generator=g) * 0.5).to(BF), (torch.randn(1, nkv, ctx, hd, generator=g) * 0.5).to(BF))
     e1 = (torch.randn(1, 1, t.hidden_size, generator=g) * 0.02).to(BF)
+    if short:
+        n_tok = 2
     step(e1, cache, 0)                                        # warm-up token
     t0 = time.perf_counter()
     for i in range(n_tok):
@@ -586,7 +608,8 @@ def cpu_baseline_lm(kind, threads):
     return {"value": tok_s, "unit": "tokens/s", "cores": threads, "kind": "port", "setup_s": setup_s,
             "sample": f"oracle (torch-CPU restatement of the reference's typed graph), {label} at full size, {threads} threads: "
                       f"{n_tok} single-stream decode tokens at context {ctx} through all {nl} layers + lm_head + greedy sampling; "
-                      "nothing extrapolated (the CPU path has no batched step: one sequence)"}
+                      "nothing extrapolated (the CPU path has no batched step: one sequence)"
+                      + ("; 4-bit matrices hold random packed words (timing only)" if short and "w4" in kind else "")}
 
 
 def _with_cpu_baseline(out, kind, args, rank, ws):
@@ -844,6 +867,74 @@ def workload_phi35v_w4_b16(args, rank, ws, dev):
     return out
 
 
+def _fast_w4_oracle_weights(W, predicate):
+    """oracle weight dict with the accepted matrices as MLX 4-bit QW objects of RANDOM words / scales / biases (timing only:
+    quantising 3.8 B weights on the host would take minutes; the values do not matter for a tokens/s sample)"""
+    from oracle import quant as Q
+
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    for k, v in W.items():
+        path = k[: -len(".weight")] if k.endswith(".weight") else None
+        if path is not None and v.dim() == 2 and v.shape[1] % 64 == 0 and predicate(path, v):
+            n, kk = v.shape
+            wq = torch.randint(-2 ** 31, 2 ** 31 - 1, (n, kk // 8), dtype=torch.int32, generator=g)
+            sc = torch.full((n, kk // 64), 0.004, dtype=torch.bfloat16)
+            bi = torch.full((n, kk // 64), -0.03, dtype=torch.bfloat16)
+            out[k] = Q.QW(wq, sc, bi, 64, 4)
+        else:
+            out[k] = v
+    return out
+
+
+def other_configs(args, rank, ws, dev, t_start, budget_s=420.0):
+    """The default line's `configs` block (only configs[1] had a driver-run line): a SHORT run of every
+    other BASELINE config on this GPU - value, roofline and, where it fits in ~40 s, the oracle's CPU tokens/s - each in a
+    try / except and under a wall-clock budget so that an extra can never cost the headline.  The full lines (more steps,
+    vision rooflines, batched extras) are `--workload <name>`."""
+    import copy
+    import gc
+
+    from mlx_vlm_amd.utils import cpu_quota
+
+    plan = [("configs[0] nanollava", workload_nanollava, "nanollava", {}),
+            ("configs[2] qwen2vl-7b-b32", workload_7b_b32, "qwen2vl-7b", {}),
+            ("configs[3] idefics2-b8", workload_idefics2_b8, "idefics2-8b", {}),
+            ("configs[4] phi35v-w4-b16", workload_phi35v_w4_b16, "phi35v-w4", {}),
+            ("configs[4] phi35v-w4-b16 kv_bits=8", workload_phi35v_w4_b16, None, {"kv_bits": 8})]
+    keep_keys = ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline", "decode_tokens_per_s",
+                 "decode_us_per_token", "e2e_tokens_per_s", "images_per_s_prefill", "prompt_tps", "kv_bits")
+    block = {}
+    for name, fn, kind, over in plan:
+        if time.perf_counter() - t_start > budget_s:
+            block[name] = {"skipped": f"wall-clock budget of the default line ({budget_s:.0f} s) reached"}
+            continue
+        a = copy.copy(args)
+        a.steps, a.warmup, a.no_extras, a.no_cpu_baseline, a.max_tokens, a.kv_bits = 1, 1, True, True, 0, 0
+        for k, v in over.items():
+            setattr(a, k, v)
+        t0 = time.perf_counter()
+        try:
+            out = fn(a, rank, ws, dev)
+            row = {k: out[k] for k in keep_keys if k in out}
+            row["gpu_wall_s"] = time.perf_counter() - t0
+        except Exception as e:
+            row = {"error": f"{type(e).__name__}: {e}"}
+        gc.collect()
+        torch.cuda.empty_cache()
+        if kind and not args.no_cpu_baseline and "error" not in row and time.perf_counter() - t_start < budget_s:
+            t1 = time.perf_counter()
+            try:
+                threads = min(cpu_quota(), 32)
+                row["cpu_baseline"] = cpu_baseline_nanollava(threads) if kind == "nanollava" else cpu_baseline_lm(kind, threads, short=True)
+                row["cpu_baseline"]["wall_s"] = time.perf_counter() - t1
+            except Exception as e:
+                row["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+            gc.collect()
+        block[name] = row
+    return block
+
+
 def dry_run(args, rank, ws):
     """Everything of the N-rank job EXCEPT the kernels, on CPU ranks over gloo: the self-launch / torchrun environment, the
     rendezvous, the weight replica through parallel.WeightArena (rank 0 fills it, the others receive in place; contents
@@ -1019,6 +1110,16 @@ def main():
     if rank == 0 and ws == 1 and not args.no_cpu_baseline:
         from mlx_vlm_amd.utils import cpu_quota
         cpu = cpu_baseline(min(cpu_quota(), 32), with_hf=not args.no_cpu_hf)          # the cores the container may use
+    configs = None
+    if rank == 0 and ws == 1 and not args.no_extras and not args.no_configs:
+        import gc
+        head_tuning = dict(model.language_model.tuning)
+        del model                                   # the headline engine (weights + 37 GB of identity-layout K/V) makes room
+        gc.collect()
+        torch.cuda.empty_cache()
+        configs = other_configs(args, rank, ws, dev, T_PROCESS_START)
+    else:
+        head_tuning = dict(model.language_model.tuning)
 
     if rank == 0:
         lm_params = 28 * 46797824 + 1536 + 233373696
@@ -1033,7 +1134,7 @@ def main():
             "config": {"workload": "Qwen2-VL-2B-Instruct dims (random-init bf16), batch=1 per GPU, one 448x448 image "
                                    "(1024 patches -> 256 image tokens) + 128 text tokens, greedy 256-token decode, EOS disabled",
                        "prompt_tokens": int(req[0].shape[1]), "max_tokens": args.max_tokens, "parallelism": f"dp{ws}",
-                       "decode_lookahead": args.lookahead, "decode_tuning": dict(model.language_model.tuning)},
+                       "decode_lookahead": args.lookahead, "decode_tuning": head_tuning},
             "decode_us_per_token": us_per_token,
             "prefill_ms_to_first_token": pre_max / args.steps * 1e3,
             "prompt_tps": ws * args.steps * int(req[0].shape[1]) / pre_max,
@@ -1066,6 +1167,8 @@ def main():
             out["vision_single_448_tflops"] = ips448 * VIT_TFLOP_448
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if configs is not None:
+            out["configs"] = configs
         print(json.dumps(out), flush=True)
     parallel.barrier()             # ranks leave together (rank 0 was still measuring the per-kernel rooflines)
     parallel.shutdown()

@@ -22,6 +22,10 @@ struct VlmRopeKv {
   float qk_scale = 1.f;      // q and k times this, rounded to bf16, before the rotation (SuScaledRoPE, rope_utils.py:174-176)
   int long_from = 0;         // > 0: inv_freq = [2][D/2] (short, long); long for the whole step when any row's slot >= long_from
 };
+// vlm_gemm_bf16's dispatcher: tiles of 256 x 256 from which the phased 256-wide kernel is taken (default 120 = it fills the
+// chip alone; vlm_vit_forward_parts lowers it while it enqueues chains that run side by side).  Kernel choice only:
+// every choice gives the same bits.
+VLM_INTERNAL void vlm_gemm_tile256_min_tiles(int tiles);
 // split-K workspace of the bf16 GEMMs for kernels captured on another stream than the one that replays them (gemm_bf16.hip)
 VLM_INTERNAL int vlm_gemm_splitk_share(void* from_stream, void* to_stream);
 VLM_INTERNAL void vlm_gemm_splitk_unshare(void* to_stream);

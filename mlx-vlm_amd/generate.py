@@ -694,8 +694,10 @@ def batch_generate(model, processor, images=None, audios=None, prompts: Optional
         extras.append({k: v for k, v in inp.items() if k not in ("input_ids", "pixel_values", "image_grid_thw", "attention_mask")})
     stop = getattr(tokenizer, "stopping_criteria", None)
     stop_ids = tuple(getattr(stop, "eos_token_ids", ()) or ())
-    smp = _resolve_sampler(kwargs.pop("sampler", None), kwargs.pop("temperature", 0.0), kwargs.pop("top_p", 1.0),
-                           kwargs.pop("min_p", 0.0), kwargs.pop("top_k", 0), kwargs.pop("seed", None))
+    smp, py_smp = _resolve_sampler(kwargs.pop("sampler", None), kwargs.pop("temperature", 0.0), kwargs.pop("top_p", 1.0),
+                                   kwargs.pop("min_p", 0.0), kwargs.pop("top_k", 0), kwargs.pop("seed", None))
+    if py_smp is not None:
+        smp = py_smp               # a Python callable: the generator runs eager steps around it (batch.py)
     # the reference's batch_generate hands its penalty keywords to the generator (ar.py:2890-3096): one spec for every request
     from .sample_utils import make_logits_processors
     procs = make_logits_processors(kwargs.pop("logit_bias", None), kwargs.pop("repetition_penalty", None),
@@ -710,8 +712,9 @@ def batch_generate(model, processor, images=None, audios=None, prompts: Optional
                                                 extras=extras, logits_processors=procs if procs else None,
                                                 **({"batch_size": int(rows)} if rows else {}))
     else:
-        if procs:
-            raise NotImplementedError("static batches (continuous=False) run without logits processors; use the continuous generator")
+        if procs or py_smp is not None:
+            raise NotImplementedError("static batches (continuous=False) run without logits processors / Python samplers; "
+                                      "use the continuous generator")
         toks, stats = batch_generate_ids(model, ids_l, pix_l, grid_l, max_tokens=max_tokens, stop_ids=stop_ids, sampler=smp,
                                          extras=extras)
     texts = [tokenizer.decode(t) if hasattr(tokenizer, "decode") else "" for t in toks]
