@@ -481,11 +481,6 @@ int vlm_vit_destroy(void* handle);
 int vlm_vit_set_block(void* handle, int i, const vlm_vit_block* w);
 int vlm_vit_set_globals(void* handle, const vlm_vit_globals* g);
 int vlm_vit_forward(void* handle, const vlm_vit_args* a, void* stream);
-/* The same forward with the images of the call dealt into `nparts` (1..8) groups of whole images, one vlm_vit_args each
- * (its own rows of every buffer, cu_seqlens / rope tables starting at its first image): the groups are independent launch
- * chains (vision.py:148-158 attends per cu_seqlens segment, everything else is per row) and run on HIP streams of their
- * own, forked from and joined back into `stream`.  Same bits as one vlm_vit_forward over all images. */
-int vlm_vit_forward_parts(void* handle, const vlm_vit_args* parts, int nparts, void* stream);
 
 #ifdef __cplusplus
 }

@@ -158,7 +158,6 @@ SIGNATURES = {
     "vlm_vit_set_block": (c_int, [c_void_p, c_int, P(VitBlock)]),
     "vlm_vit_set_globals": (c_int, [c_void_p, P(VitGlobals)]),
     "vlm_vit_forward": (c_int, [c_void_p, P(VitArgs), c_void_p]),
-    "vlm_vit_forward_parts": (c_int, [c_void_p, P(VitArgs), c_int, c_void_p]),
 }
 
 _lib = None

@@ -100,10 +100,6 @@ struct Vit {
   vlm_vit_config cfg;
   std::vector<vlm_vit_block> blocks;
   vlm_vit_globals g{};
-  // vlm_vit_forward_parts: side streams (part p >= 1 runs on side[p - 1]) and their fork / join events, created on first use
-  std::vector<hipStream_t> side;
-  std::vector<hipEvent_t> joined;
-  hipEvent_t forked = nullptr;
 };
 
 inline char* off(void* p, size_t bytes) { return static_cast<char*>(p) + bytes; }
@@ -520,9 +516,6 @@ extern "C" int vlm_vit_create(const vlm_vit_config* cfg, void** handle) {
 extern "C" int vlm_vit_destroy(void* handle) {
   Vit* v = static_cast<Vit*>(handle);
   if (!v) return 1;
-  for (hipStream_t s : v->side) (void)hipStreamDestroy(s);
-  for (hipEvent_t e : v->joined) (void)hipEventDestroy(e);
-  if (v->forked) (void)hipEventDestroy(v->forked);
   delete v;
   return 0;
 }
@@ -541,61 +534,9 @@ extern "C" int vlm_vit_set_globals(void* handle, const vlm_vit_globals* g) {
   return 0;
 }
 
-static int vit_forward_impl(Vit* v, const vlm_vit_args* a, void* stream);
-
 extern "C" int vlm_vit_forward(void* handle, const vlm_vit_args* a, void* stream) {
   Vit* v = static_cast<Vit*>(handle);
   if (!v || !a || !a->patches || a->N <= 0) return 1;
-  return vit_forward_impl(v, a, stream);
-}
-
-// The images of one call as `nparts` groups of whole images, each group a complete forward on a stream of its own (part 0
-// on the caller's stream, which forks the others and joins them before returning to the caller's order).  Images do not
-// interact anywhere in the tower (vision.py:148-158 attends per cu_seqlens segment; every other op is per row), so the
-// groups are independent launch chains, and the results are bit for bit those of one call (every output element's
-// accumulation order is independent of the row count).  Why: a chain's GEMM launches run in lock step - all workgroups
-// stream, then all write their C tiles at once (an HBM burst with the matrix cores idle), then the launch drains
-// before the next one may start.  Two or three chains out of phase fill each other's bursts, drains, launch gaps and
-// partly filled last rounds (one chain: ~70 us of 445 per block are such fixed costs).  While the parts are
-// being enqueued the GEMM dispatcher takes the 256-wide phased kernel from 120 / nparts tiles (the parts fill the chip
-// together).
-extern "C" int vlm_vit_forward_parts(void* handle, const vlm_vit_args* parts, int nparts, void* stream) {
-  Vit* v = static_cast<Vit*>(handle);
-  if (!v || !parts || nparts <= 0 || nparts > 8) return 1;
-  for (int p = 0; p < nparts; ++p)
-    if (!parts[p].patches || parts[p].N <= 0) return 1;
-  if (nparts == 1) return vit_forward_impl(v, parts, stream);
-  hipStream_t main_st = (hipStream_t)stream;
-  while ((int)v->side.size() < nparts - 1) {
-    hipStream_t s = nullptr;
-    hipEvent_t e = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return 1013;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
-      (void)hipStreamDestroy(s);
-      return 1013;
-    }
-    v->side.push_back(s);
-    v->joined.push_back(e);
-  }
-  if (!v->forked && hipEventCreateWithFlags(&v->forked, hipEventDisableTiming) != hipSuccess) return 1013;
-  if (hipEventRecord(v->forked, main_st) != hipSuccess) return 1014;
-  vlm_gemm_tile256_min_tiles((120 + nparts - 1) / nparts);
-  int rc = 0;
-  // (interleaved enqueue order does not matter: each chain is ordered by its own stream)
-  for (int p = 1; p < nparts && rc == 0; ++p) {
-    if (hipStreamWaitEvent(v->side[p - 1], v->forked, 0) != hipSuccess) rc = 1014;
-    if (rc == 0) rc = vit_forward_impl(v, parts + p, v->side[p - 1]);
-    if (rc == 0 && hipEventRecord(v->joined[p - 1], v->side[p - 1]) != hipSuccess) rc = 1014;
-  }
-  if (rc == 0) rc = vit_forward_impl(v, parts, stream);
-  vlm_gemm_tile256_min_tiles(120);
-  // join whatever was forked, also on an error path (the caller's stream must not run ahead of a side chain)
-  for (int p = 1; p < nparts; ++p)
-    if (hipStreamWaitEvent(main_st, v->joined[p - 1], 0) != hipSuccess && rc == 0) rc = 1014;
-  return rc;
-}
-
-static int vit_forward_impl(Vit* v, const vlm_vit_args* a, void* stream) {
   const vlm_vit_config& c = v->cfg;
   const int E = c.embed_dim, H = c.n_heads, hd = E / H, N = a->N, MH = c.mlp_hidden;
   const int mm = c.merge * c.merge;

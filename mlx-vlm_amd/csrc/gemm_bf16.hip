@@ -36,7 +36,6 @@ namespace {
 
 bool g_force_regstage = false;   // test hook (vlm_gemm_set_staging): exercise the register-staged kernel
 int g_tile256 = 0;               // 0 = automatic, -1 = never use the 256x256 phased kernel, 1 = whenever it is legal
-int g_tile256_min = 120;         // automatic: from this many 256 x 256 tiles (vlm_gemm_tile256_min_tiles)
 
 constexpr int BK = 64;          // k elements per LDS tile
 constexpr int ROWB = BK * 2;    // bytes per tile row (128)
@@ -568,8 +567,6 @@ extern "C" int vlm_gemm_set_staging(int mode) {
 static int gemm_dispatch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
                          int lda, int ldw, int ldc, int ldres, int epilogue, void* stream);
 
-VLM_INTERNAL void vlm_gemm_tile256_min_tiles(int tiles) { g_tile256_min = tiles > 0 ? tiles : 120; }
-
 extern "C" int vlm_gemm_bf16(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N,
                              int K, int lda, int ldw, int ldc, int ldres, int epilogue, void* stream) {
   if (epilogue & ~(VLM_EPI_BIAS | VLM_EPI_GELU_FAST | VLM_EPI_GELU_ERF | VLM_EPI_RESIDUAL | VLM_EPI_SWIGLU)) return VLM_ERR_ARG;
@@ -601,7 +598,7 @@ static int gemm_dispatch(const void* A, const void* W, const void* bias, const v
     // 566 vs 432 TF; 180: 838 vs 772; 540: 869 vs 828; 720: 1073-1087 vs 895-921 TF) and loses below (60 tiles:
     // 326-421 vs 471-530 TF), where the 128x128 kernel spreads the work over more CUs.  (g_tile256 == 1: test hook.)
     const long t256 = (long)vlm_cdiv(M, 256) * vlm_cdiv(N, 256);
-    const bool fills = t256 >= g_tile256_min;
+    const bool fills = t256 >= 120;
     if (g_tile256 == 1 || fills) {
       const int rc = vlm_gemm256_try(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, epilogue, stream);
       if (rc >= 0) return rc;

@@ -589,7 +589,8 @@ static int mfma_try(const void* x, const void* W, const void* Wsb, const void* b
                     void* ws, void* stream);
 
 #ifndef VLM_MFMA_W4_TU
-VLM_INTERNAL size_t vlm_gemv_mfma_ws_bytes(void) { return (size_t)4096 * 256 * 4 + 8192 * 4; }   // 4096 units of partials + tickets
+// 4096 units of partials + tickets + the normalised activation rows of the second form (gemv_mfma2.hip)
+VLM_INTERNAL size_t vlm_gemv_mfma_ws_bytes(void) { return VLM_MFMA_WS_XN_OFFSET + VLM_MFMA_WS_XN_BYTES; }
 
 VLM_INTERNAL int vlm_gemv_mfma_try(const void* x, const void* W, const void* bias, const void* res, const void* norm_w, void* y, int M, int N,
                                    int K, int ldx, int ldw, int ldy, int ldres, float eps, int epilogue, const VlmRopeKv* rk,
@@ -625,6 +626,18 @@ static int mfma_try(const void* x, const void* W, const void* Wsb, const void* b
     return -1;
   if (norm_w && (epilogue & VLM_EPI_RESIDUAL)) return -1;
   if ((epilogue & VLM_EPI_SWIGLU) && (N % 16)) return -1;
+  {
+    // the second form first (gemv_mfma2.hip: activations in registers, two workgroups per CU); VLM_GEMV_MFMA2=0: A/B knob
+    static const bool v2 = [] { const char* e = getenv("VLM_GEMV_MFMA2"); return !e || atoi(e) != 0; }();
+    if (v2) {
+#ifdef VLM_MFMA_W4_TU
+      const int rc2 = Wsb ? vlm_gemv_mfma2_try_w4(x, W, Wsb, bias, res, norm_w, y, M, N, K, ldx, ldw, ldy, ldres, eps, epilogue, rk, ws, stream) : -1;
+#else
+      const int rc2 = Wsb ? -1 : vlm_gemv_mfma2_try_bf16(x, W, Wsb, bias, res, norm_w, y, M, N, K, ldx, ldw, ldy, ldres, eps, epilogue, rk, ws, stream);
+#endif
+      if (rc2 != -1) return rc2;
+    }
+  }
   MfmaArgs a{};
   a.x = (const bf16_t*)x; a.W = (const bf16_t*)W; a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res;
   a.norm_w = (const bf16_t*)norm_w; a.y = (bf16_t*)y; a.Wsb = (const unsigned*)Wsb;

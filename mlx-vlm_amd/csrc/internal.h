@@ -22,10 +22,6 @@ struct VlmRopeKv {
   float qk_scale = 1.f;      // q and k times this, rounded to bf16, before the rotation (SuScaledRoPE, rope_utils.py:174-176)
   int long_from = 0;         // > 0: inv_freq = [2][D/2] (short, long); long for the whole step when any row's slot >= long_from
 };
-// vlm_gemm_bf16's dispatcher: tiles of 256 x 256 from which the phased 256-wide kernel is taken (default 120 = it fills the
-// chip alone; vlm_vit_forward_parts lowers it while it enqueues chains that run side by side).  Kernel choice only:
-// every choice gives the same bits.
-VLM_INTERNAL void vlm_gemm_tile256_min_tiles(int tiles);
 // split-K workspace of the bf16 GEMMs for kernels captured on another stream than the one that replays them (gemm_bf16.hip)
 VLM_INTERNAL int vlm_gemm_splitk_share(void* from_stream, void* to_stream);
 VLM_INTERNAL void vlm_gemm_splitk_unshare(void* to_stream);
@@ -39,6 +35,16 @@ VLM_INTERNAL int vlm_gemv_mfma_try(const void* x, const void* W, const void* bia
 VLM_INTERNAL int vlm_gemv_mfma_try_w4(const void* x, const void* Wq, const void* Wsb, const void* bias, const void* res,
                                       const void* norm_w, void* y, int M, int N, int K, int ldx, int ldy, int ldres, float eps,
                                       int epilogue, const VlmRopeKv* rk, void* ws, void* stream);
+// second form (csrc/gemv_mfma2.hip): activations in registers, two workgroups per CU, coalesced 4-bit loads; the RMSNorm
+// prologue runs as one rows kernel into the workspace scratch at VLM_MFMA_WS_XN_OFFSET.  -1: shape not handled.
+#define VLM_MFMA_WS_XN_OFFSET ((size_t)4096 * 256 * 4 + 8192 * 4)
+#define VLM_MFMA_WS_XN_BYTES ((size_t)16 * 8192 * 2)
+VLM_INTERNAL int vlm_gemv_mfma2_try_bf16(const void* x, const void* W, const void* Wsb, const void* bias, const void* res,
+                                         const void* norm_w, void* y, int M, int N, int K, int ldx, int ldw, int ldy, int ldres,
+                                         float eps, int epilogue, const VlmRopeKv* rk, void* ws, void* stream);
+VLM_INTERNAL int vlm_gemv_mfma2_try_w4(const void* x, const void* W, const void* Wsb, const void* bias, const void* res,
+                                       const void* norm_w, void* y, int M, int N, int K, int ldx, int ldw, int ldy, int ldres,
+                                       float eps, int epilogue, const VlmRopeKv* rk, void* ws, void* stream);
 VLM_INTERNAL void vlm_gemv_set_variant(int bits);   // A/B bits of the batch-1 launch shapes (process-wide; VLM_TUNE_GEMV_VARIANT)
 VLM_INTERNAL int vlm_gemv_bf16_ex(const void* x, const void* W, const void* bias, const void* res, const void* norm_w, void* y,
                                   int M, int N, int K, int ldx, int ldw, int ldy, int ldres, float eps, int epilogue, int mfma,

@@ -153,34 +153,6 @@ class VisionModel:
             self._tab_cache[key] = hit
         return hit
 
-    def _image_groups(self, grid_thw, N):
-        """Contiguous groups of whole images for vlm_vit_forward_parts: [(grid rows, first patch row, patches)].  One
-        group (= the plain forward) for small calls: a chain must still fill a good part of the chip on its own.
-        VLM_VIT_STREAMS = number of chains (default 3 from 12 k patches, 2 from 6 k; 1 = off)."""
-        import os
-        g = np.asarray(grid_thw).reshape(-1, 3)
-        per = (g[:, 0] * g[:, 1] * g[:, 2]).astype(np.int64)
-        want = os.environ.get("VLM_VIT_STREAMS")
-        k = int(want) if want else (2 if N >= 6144 else 1)
-        k = max(1, min(k, 8, len(per)))
-        if k == 1:
-            return [(g, 0, N)]
-        # contiguous split balanced by patches: group i ends at the image where the running count passes (i + 1) N / k
-        bounds, acc, nxt = [0], 0, 1
-        for i, n in enumerate(per.tolist()):
-            acc += n
-            if nxt < k and acc >= nxt * N / k and i + 1 < len(per):
-                bounds.append(i + 1)
-                nxt += 1
-        bounds.append(len(per))
-        out, r0 = [], 0
-        for a, b in zip(bounds[:-1], bounds[1:]):
-            n = int(per[a:b].sum())
-            if n:
-                out.append((g[a:b], r0, n))
-            r0 += n
-        return out
-
     # ------------------------------------------------------------------ forward
     def __call__(self, hidden_states: torch.Tensor, grid_thw, output_hidden_states: Optional[bool] = None):
         """hidden_states: pixel_values [N, C*T*ph*pw] (f32 or bf16, rows as the processor emits them:
@@ -196,6 +168,7 @@ class VisionModel:
         if hidden_states.dtype != torch.float32:
             hidden_states = hidden_states.to(torch.float32)
         x = ops.cast_pad(hidden_states.contiguous(), self.patch_k)
+        cos, sin, cu, nseg, nqb, uniform = self._tables(grid_thw)
         E, dev = c.embed_dim, self.device
         mm = c.spatial_merge_size ** 2
         bf = torch.bfloat16
@@ -203,24 +176,11 @@ class VisionModel:
               (("x", E), ("xn", E), ("qkv", 3 * E), ("attn", E), ("mlp", self.mlp_hidden))}
         mrg = torch.empty(N // mm, E * mm, dtype=bf, device=dev)
         out = torch.empty(N // mm, c.hidden_size, dtype=bf, device=dev)
-
-        def args_of(grid, r0, n):
-            """vlm_vit_args of the images `grid` = rows r0 .. r0 + n of every buffer"""
-            cos, sin, cu, nseg, nqb, uniform = self._tables(grid)
-            row = lambda t, d, k=1: t.data_ptr() + (r0 // k) * d * 2          # noqa: E731  (bf16 rows)
-            return _lib.VitArgs(x.data_ptr() + r0 * self.patch_k * 2, n, cos.data_ptr(), sin.data_ptr(), cu.data_ptr(), nseg, nqb,
-                                row(ws["x"], E), row(ws["xn"], E), row(ws["qkv"], 3 * E), row(ws["attn"], E),
-                                row(ws["mlp"], self.mlp_hidden), row(mrg, E * mm, mm), row(out, c.hidden_size, mm), uniform)
-
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        groups = self._image_groups(grid_thw, N)
-        if len(groups) <= 1:
-            a = args_of(grid_thw, 0, N)
-            check(_lib.lib().vlm_vit_forward(self._handle, C.byref(a), st), "vit_forward")
-        else:
-            # whole images dealt into independent launch chains on streams of their own (vlm_vit_forward_parts)
-            parts = (_lib.VitArgs * len(groups))(*[args_of(g, r0, n) for g, r0, n in groups])
-            check(_lib.lib().vlm_vit_forward_parts(self._handle, parts, len(groups), st), "vit_forward_parts")
+        a = _lib.VitArgs(x.data_ptr(), N, cos.data_ptr(), sin.data_ptr(), cu.data_ptr(), nseg, nqb, ws["x"].data_ptr(),
+                         ws["xn"].data_ptr(), ws["qkv"].data_ptr(), ws["attn"].data_ptr(), ws["mlp"].data_ptr(),
+                         mrg.data_ptr(), out.data_ptr(), uniform)
+        check(_lib.lib().vlm_vit_forward(self._handle, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              "vit_forward")
         return out
 
     # ------------------------------------------------------------------ checkpoint key/layout fixups

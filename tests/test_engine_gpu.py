@@ -46,25 +46,6 @@ def test_vision_tower_vs_oracle(tiny):
     assert e < 2e-2, e      # bf16 through 2 blocks + merger: ~1% rms
 
 
-@pytest.mark.parametrize("streams", [2, 3, 5])
-def test_vision_tower_image_parallel_streams_bit_identical(tiny, streams, monkeypatch):
-    """vlm_vit_forward_parts: whole images dealt into launch chains on streams of their own == one chain, bit for bit
-    (images of different sizes, more streams than some groups can use, a video grid with t > 1 staying in one group)"""
-    cfg, W, model = tiny
-    _, pix, thw = synth_request(cfg, [(56, 84), (112, 56), (56, 56), (84, 84), (28, 56)], seed=31)
-    monkeypatch.setenv("VLM_VIT_STREAMS", "1")
-    one = model.vision_tower(torch.from_numpy(pix), thw)
-    ref = oq.vision_tower(W, cfg, torch.from_numpy(pix).to(BF), thw)
-    assert _rel_rms_err(one, ref) < 2e-2
-    monkeypatch.setenv("VLM_VIT_STREAMS", str(streams))
-    groups = model.vision_tower._image_groups(thw, pix.shape[0])
-    assert 1 < len(groups) <= streams and sum(n for _, _, n in groups) == pix.shape[0]
-    for _ in range(3):
-        many = model.vision_tower(torch.from_numpy(pix), thw)
-        torch.cuda.synchronize()
-        assert torch.equal(one, many)
-
-
 def test_vision_tower_vs_hf_golden_fp32_weights(tiny):
     """HF fp32 features vs the HIP bf16 path: bf16 weights/activations => ~1-2% rms."""
     cfg, _, _ = tiny

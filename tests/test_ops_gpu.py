@@ -1168,7 +1168,7 @@ def test_gemv_mfma_row_trip_prologue_is_bit_identical_to_the_loop_form(vops, tmp
     res = {}
     for knob in ("0", "1"):
         path = str(tmp_path / f"trips{knob}.pt")
-        env = dict(os.environ, VLM_GEMV_MFMA_TRIPS=knob)
+        env = dict(os.environ, VLM_GEMV_MFMA_TRIPS=knob, VLM_GEMV_MFMA2="0")      # the first form (the second has no prologue of its own)
         r = subprocess.run([sys.executable, "-c", _TRIPS_CHILD, root, path], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res[knob] = torch.load(path)
