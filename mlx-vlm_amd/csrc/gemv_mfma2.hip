@@ -34,13 +34,22 @@
 #include "internal.h"
 #include "../../include/vlm_hip.h"
 
+#ifdef MFMA2_STAMPS
+// measurement build only (scripts/mfma2_probe.hip): wall-clock stamps (100 MHz) of wave 0 of workgroup MFMA2_STAMPS
+__device__ unsigned long long g_mfma2_stamps[64];
+#define ST2(i) do { if (blockIdx.x == MFMA2_STAMPS && threadIdx.x == 0 && (i) < 64) g_mfma2_stamps[i] = wall_clock64(); } while (0)
+#else
+#define ST2(i)
+#endif
+
 namespace {
 
 constexpr int MEPI2_ROPE_KV = 1 << 10;
 constexpr int WREG2 = 16 * 272;      // bytes of a wave's private transposition region (4-bit: 16 x 144 + 256 of scales)
 
 struct Mfma2Args {
-  const bf16_t *x, *W, *bias, *res;
+  const bf16_t *x, *W, *bias, *res, *norm_w;
+  float eps;
   const unsigned* Wsb;   // 4-bit: W = q words uint32 [N][K/8], Wsb = (scale | bias << 16) [N][K/64]; else null
   bf16_t* y;
   int M, N, K, ldx, ldw, ldy, ldres;
@@ -63,7 +72,14 @@ __device__ __forceinline__ int tile_row2(const Mfma2Args& a, int tile, int r) {
 // NCH: chunks per wave and unit (the wave's chunk slots).  bf16: chunk = 128 k (4 MFMA steps, 4 weight loads, 16 x VGPRs);
 // 4-bit: chunk = 256 k (8 MFMA steps, 2 weight loads + 1 scale word, 32 x VGPRs).
 // NW: waves per workgroup (4 or 8; 8 halves a wave's x^T fragments: the 4-bit form's 32 VGPRs per chunk).
-template <int EPI, bool W4, int NCH, int NW>
+// NSETS: register sets of weights, i.e. units of the workgroup in flight per wave (a set is refilled for the unit NSETS
+// ahead the moment its chunk has gone to LDS).  With ONE set a wave's next unit is requested when the current one
+// ARRIVES: a unit per memory round trip - the 4-bit form (2.25 KB per chunk) then has 27 KB per CU in flight and runs at
+// 1.2-1.7 TB/s (profiles/r04_mfma2_shapes.txt); its sets cost 9 VGPRs per chunk, so it takes four.
+// NORM: the RMSNorm prologue inside the launch (one K segment only: the workgroup's waves hold ALL of x): every wave takes
+// the sum of squares of its fragments, the partials meet in LDS, the fragments are normalised in registers - behind the
+// weight loads, which are already in flight.  (With K segments the rows are normalised by one rows kernel in front.)
+template <int EPI, bool W4, int NCH, int NW, int NSETS, bool NORM>
 __global__ __launch_bounds__(64 * NW, 2) void gemv_mfma2_kernel(const Mfma2Args a) {
   constexpr int NS = W4 ? 8 : 4;       // MFMA k steps per chunk
   constexpr int NJ = W4 ? 2 : 4;       // weight load instructions per chunk
@@ -71,6 +87,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemv_mfma2_kernel(const Mfma2Args 
   __shared__ __attribute__((aligned(16))) char s_wreg[NW * WREG2];
   __shared__ float part[NW * 256];
   __shared__ int flags[64];
+  __shared__ float red[NORM ? NW * 16 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
   char* wreg = s_wreg + wave * WREG2;
   unsigned* sbw = reinterpret_cast<unsigned*>(wreg + 16 * 144);      // 4-bit: [4 groups][16 rows] (scale | bias) words of a chunk
@@ -79,6 +96,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemv_mfma2_kernel(const Mfma2Args 
   const int c0 = ks * a.cps, c1 = min(a.nchunk, c0 + a.cps);
   const int n_valid = max(0, min(NCH, (c1 - c0 - wave + NW - 1) / NW));     // this wave's chunks c0 + wave + NW i < c1
   const int mrow = min(r16, a.M - 1);
+  ST2(0);
 
   // ---- x^T fragments of the wave's chunks (rows past M alias row M - 1: their columns of D are dropped)
   u32x4_t xf[NCH][NS];
@@ -97,9 +115,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemv_mfma2_kernel(const Mfma2Args 
   }
 
   // weights of (unit, slot): the wave's chunk of the unit's 16 rows, coalesced
-  u32x4_t wv[NCH][NJ];
-  unsigned sbv[NCH];
-  auto load_slot = [&](int u, int i) __attribute__((always_inline)) {
+  u32x4_t wv[NSETS][NCH][NJ];
+  unsigned sbv[NSETS][NCH];
+  auto load_slot = [&](int u, int i, u32x4_t (&wv)[NCH][NJ], unsigned (&sbv)[NCH]) __attribute__((always_inline)) {
     const int tile = u / a.KS;
     const int c = min(c0 + wave + NW * i, c1 - 1);
     if (W4) {
@@ -124,11 +142,53 @@ __global__ __launch_bounds__(64 * NW, 2) void gemv_mfma2_kernel(const Mfma2Args 
 
   int u = blockIdx.x;
   __builtin_amdgcn_sched_barrier(0);      // the activation loads first (vector loads return in issue order), the stream behind
-  if (u < n_units) {
+  // (the further sets go out behind the prologue when it runs here: its temporaries and four sets in flight do not fit)
+  constexpr int PRE = NORM ? 1 : NSETS;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) load_slot(u, i);
-  }
+  for (int s_ = 0; s_ < PRE; ++s_)
+    if (u + s_ * G < n_units) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) load_slot(u + s_ * G, i, wv[s_], sbv[s_]);
+    }
   __builtin_amdgcn_sched_barrier(0);
+
+  if (NORM) {
+    // nn.RMSNorm's typed graph on the fragments: bf16(x * inv) * weight -> bf16 (language.py:130-133); inv from the fp32 sum
+    // of squares of the whole row (this wave's chunks, the four k groups of a row in lanes r16 + 16 g, then the NW waves in
+    // a fixed order)
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (i < n_valid) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const u32x4_t v = xf[i][s];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ss += bf_lo(v[q]) * bf_lo(v[q]) + bf_hi(v[q]) * bf_hi(v[q]);
+        }
+      }
+    ss = col4_sum(ss);
+    if (g == 0) red[wave * 16 + r16] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += red[w * 16 + r16];
+    const float inv = rsqrtf(tot / (float)a.K + a.eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = min(c0 + wave + NW * i, c1 - 1);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int k = c * CK + (W4 ? 64 * (s >> 1) + 16 * g + 8 * (s & 1) : 32 * s + 8 * g);
+        const u32x4_t wu = *reinterpret_cast<const u32x4_t*>(a.norm_w + k);
+        const u32x4_t v = xf[i][s];
+        u32x4_t o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = pack_bf2(bf_lo(wu[q]) * rbf(bf_lo(v[q]) * inv), bf_hi(wu[q]) * rbf(bf_hi(v[q]) * inv));
+        xf[i][s] = o;
+      }
+    }
+  }
 
   // 4-bit: group sums of the wave's activations (per batch row m = r16 and 64-wide group) and the expanded-word order
   float sx[W4 ? NCH : 1][4];
@@ -158,6 +218,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gemv_mfma2_kernel(const Mfma2Args 
       }
     }
   }
+
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s_ = PRE; s_ < NSETS; ++s_)
+    if (u + s_ * G < n_units) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) load_slot(u + s_ * G, i, wv[s_], sbv[s_]);
+    }
+  __builtin_amdgcn_sched_barrier(0);
 
   // epilogue of one finished 16 x 16 tile: thread tid holds element (n_l = tid >> 4, m = tid & 15); whole workgroup
   auto finish = [&](int tile, float v) __attribute__((always_inline)) {
@@ -219,8 +288,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemv_mfma2_kernel(const Mfma2Args 
     }
   };
 
-  while (u < n_units) {
-    const int un = u + G;
+  ST2(1);
+  int st_k = 0;
+  auto unit = [&](int u, u32x4_t (&wv)[NCH][NJ], unsigned (&sbv)[NCH]) __attribute__((always_inline)) {
+    const int un = u + NSETS * G;         // the unit this set is refilled for
     const bool more = un < n_units;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     // chunk slot i: registers -> the wave's private region (same-wave LDS operations execute in order: no barrier), the
@@ -230,7 +301,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemv_mfma2_kernel(const Mfma2Args 
 #pragma unroll
         for (int j = 0; j < NJ; ++j) *reinterpret_cast<u32x4_t*>(wreg + (8 * j + (lane >> 3)) * 144 + (lane & 7) * 16) = wv[i][j];
         sbw[(lane & 3) * 16 + (lane >> 2)] = sbv[W4 ? i : 0];
-        if (more) load_slot(un, i);
+        if (more) load_slot(un, i, wv, sbv);
 #pragma unroll
         for (int Gq = 0; Gq < 4; ++Gq) {
           const uint2 wd = *reinterpret_cast<const uint2*>(wreg + r16 * 144 + Gq * 32 + g * 8);
@@ -251,7 +322,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemv_mfma2_kernel(const Mfma2Args 
       } else {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) *reinterpret_cast<u32x4_t*>(wreg + (4 * j + g) * 272 + r16 * 16) = wv[i][j];
-        if (more) load_slot(un, i);
+        if (more) load_slot(un, i, wv, sbv);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
           const u32x4_t af = *reinterpret_cast<const u32x4_t*>(wreg + r16 * 272 + kb * 64 + g * 16);
@@ -272,7 +343,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemv_mfma2_kernel(const Mfma2Args 
     // D[n = 4 g + q][m = r16]  ->  part[wave][n * 16 + m]
 #pragma unroll
     for (int q = 0; q < 4; ++q) part[wave * 256 + (4 * g + q) * 16 + r16] = acc[q];
+    ST2(2 + 3 * st_k);
     __syncthreads();
+    ST2(3 + 3 * st_k);
     const int te = tid & 255;
     float v = (part[te] + part[256 + te]) + (part[512 + te] + part[768 + te]);
     if (NW == 8) v += (part[1024 + te] + part[1280 + te]) + (part[1536 + te] + part[1792 + te]);
@@ -283,9 +356,18 @@ __global__ __launch_bounds__(64 * NW, 2) void gemv_mfma2_kernel(const Mfma2Args 
       finish(u, v);
     }
     __syncthreads();                      // part[] is rewritten by the next unit
-    u = un;
+    ST2(4 + 3 * st_k);
+    ++st_k;
+  };
+  while (u < n_units) {
+#pragma unroll
+    for (int s_ = 0; s_ < NSETS; ++s_) {
+      if (u < n_units) unit(u, wv[s_], sbv[s_]);      // (uniform)
+      u += G;
+    }
   }
 
+  ST2(62);
   if (a.KS > 1) {
     // deferred hand-off (as gemv_mfma.hip): ONE wait, the tickets of all units of this workgroup at once (thread i: unit
     // blockIdx.x + i G), then the merges of the tiles it arrived last at - partials summed in the fixed order
@@ -312,9 +394,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemv_mfma2_kernel(const Mfma2Args 
   }
 }
 
-template <int EPI, bool W4, int NCH, int NW>
-int launch2(const Mfma2Args& a, int n_units, hipStream_t st) {
-  auto kern = gemv_mfma2_kernel<EPI, W4, NCH, NW>;
+template <int EPI, bool W4, int NCH, int NW, int NSETS, bool NORM>
+int launch2n(const Mfma2Args& a, int n_units, hipStream_t st) {
+  auto kern = gemv_mfma2_kernel<EPI, W4, NCH, NW, NSETS, NORM>;
   static int nb = 0;
   if (nb == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * NW, 0) != hipSuccess || nb < 1)) nb = 1;
   static const int wgs_per_cu = [] { const char* e = getenv("VLM_GEMV_MFMA2_WGS_PER_CU"); return e ? max(1, min(8, atoi(e))) : 3; }();
@@ -327,22 +409,32 @@ int launch2(const Mfma2Args& a, int n_units, hipStream_t st) {
   return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
 }
 
+template <int EPI, bool W4, int NCH, int NW, int NSETS>
+int launch2(const Mfma2Args& a, int n_units, hipStream_t st) {
+  constexpr bool CAN_NORM = (EPI & VLM_EPI_RESIDUAL) == 0;
+  if constexpr (CAN_NORM) {
+    if (a.norm_w) return launch2n<EPI, W4, NCH, NW, NSETS, true>(a, n_units, st);
+  }
+  return launch2n<EPI, W4, NCH, NW, NSETS, false>(a, n_units, st);
+}
+
+
 template <int EPI, bool W4>
 int launch2_nch(const Mfma2Args& a, int nch, int n_units, hipStream_t st) {
   if constexpr (W4) {
     switch (nch) {
-      case 1: return launch2<EPI, true, 1, 8>(a, n_units, st);
-      case 2: return launch2<EPI, true, 2, 8>(a, n_units, st);
+      case 1: return launch2<EPI, true, 1, 8, 4>(a, n_units, st);
+      case 2: return launch2<EPI, true, 2, 8, 4>(a, n_units, st);
       default: return -1;
     }
   } else {
     switch (nch) {
-      case 1: return launch2<EPI, false, 1, 4>(a, n_units, st);
-      case 2: return launch2<EPI, false, 2, 4>(a, n_units, st);
-      case 3: return launch2<EPI, false, 3, 4>(a, n_units, st);
-      case 4: return launch2<EPI, false, 4, 4>(a, n_units, st);
-      case 5: return launch2<EPI, false, 5, 4>(a, n_units, st);
-      case 6: return launch2<EPI, false, 6, 4>(a, n_units, st);
+      case 1: return launch2<EPI, false, 1, 4, 2>(a, n_units, st);
+      case 2: return launch2<EPI, false, 2, 4, 2>(a, n_units, st);
+      case 3: return launch2<EPI, false, 3, 4, 1>(a, n_units, st);
+      case 4: return launch2<EPI, false, 4, 4, 1>(a, n_units, st);
+      case 5: return launch2<EPI, false, 5, 4, 1>(a, n_units, st);
+      case 6: return launch2<EPI, false, 6, 4, 1>(a, n_units, st);
       default: return -1;
     }
   }
@@ -369,7 +461,7 @@ VLM_INTERNAL int VLM_MFMA2_ENTRY(const void* x, const void* W, const void* Wsb, 
   if (M < 1 || M > 16 || K % CK || ldx % 8 || (!kW4 && ldw % 8)) return -1;
   const bool rope = rk != nullptr;
   if (rope && (rk->D % 16 || !bias || !norm_w)) return -1;
-  if (norm_w && (!ws || ldx != K || K > 8192 || (epilogue & VLM_EPI_RESIDUAL))) return -1;
+  if (norm_w && (!ws || ldx != K || K > 8192 || (epilogue & VLM_EPI_RESIDUAL))) return -1;      // (ws: the rows kernel's scratch)
   if (!rope && epilogue != VLM_EPI_NONE && epilogue != VLM_EPI_BIAS && epilogue != VLM_EPI_RESIDUAL && epilogue != VLM_EPI_SWIGLU &&
       epilogue != (VLM_EPI_BIAS | VLM_EPI_RESIDUAL))
     return -1;
@@ -399,6 +491,16 @@ VLM_INTERNAL int VLM_MFMA2_ENTRY(const void* x, const void* W, const void* Wsb, 
   KS = a.KS = vlm_cdiv(a.nchunk, a.cps);            // no empty segment
   const int nch = vlm_cdiv(a.cps, NW);
   if (nch > NCH_MAX) return -1;
+  // Which projections take this form (measured per projection at 16 rows, profiles/r04_mfma2_shapes.txt; VLM_GEMV_MFMA2=2
+  // takes it wherever it is legal): every 4-bit one (Phi-3.5 layer 74.4 -> 53.6 us); bf16 without a norm prologue unless
+  // the registers force a K split the first form does not need (7B o_proj: 28 chunks, 9.6 vs 11.9 us); bf16 with a norm
+  // prologue from K = 4096 (Mistral gate/up 67.8 -> 54.4 us; at 2B / 7B widths the first form's in-launch prologue wins:
+  // 5.9 vs 6.2, 14.3 vs 16.3, 16.4 vs 18.8 us)
+  static const int force = [] { const char* e = getenv("VLM_GEMV_MFMA2"); return e ? atoi(e) : 1; }();
+  if (!kW4 && force != 2) {
+    if (norm_w && K < 4096) return -1;
+    if (!norm_w && a.nchunk <= 28 && vlm_cdiv(a.nchunk, 4) > NCH_MAX) return -1;
+  }
   a.ws = (float*)ws;
   a.tickets = ws ? (unsigned*)((char*)ws + (size_t)4096 * 256 * 4) : nullptr;
   const int n_units = a.n_tiles * KS;
@@ -407,7 +509,14 @@ VLM_INTERNAL int VLM_MFMA2_ENTRY(const void* x, const void* W, const void* Wsb, 
     fprintf(stderr, "[gemv_mfma2] M=%d N=%d K=%d %s epi=%d: tiles=%d KS=%d cps=%d nch=%d units=%d\n", M, N, K, kW4 ? "w4" : "bf16",
             rope ? -1 : epilogue, a.n_tiles, KS, a.cps, nch, n_units);
   hipStream_t st = (hipStream_t)stream;
-  if (norm_w) {
+  // measured (profiles/r04_mfma2_probe_v1.txt): in the launch 6.2 vs 7.4 us (2B qkv), 16.3 vs 16.5 (2B gate/up) - but the 4-bit
+  // form's 8-wave workgroups spend 8.9 us in it (19.9 -> 21.2 us at Phi-3.5 gate/up): rows kernel there
+  static const int norm_env = [] { const char* e = getenv("VLM_GEMV_MFMA2_NORM_IN_KERNEL"); return e ? atoi(e) : -1; }();
+  const bool norm_in_kernel = norm_env >= 0 ? norm_env != 0 : !kW4;
+  if (norm_w && KS == 1 && norm_in_kernel) {
+    a.norm_w = (const bf16_t*)norm_w;      // one K segment: the workgroup holds whole rows, the prologue runs in the launch
+    a.eps = eps;
+  } else if (norm_w) {
     // nn.RMSNorm's typed graph (bf16(x * inv) * weight -> bf16), once for all workgroups: rows [M][K] after the tickets
     bf16_t* xn = reinterpret_cast<bf16_t*>((char*)ws + VLM_MFMA_WS_XN_OFFSET);
     const int rc = vlm_rmsnorm_residual(x, nullptr, norm_w, xn, nullptr, M, K, eps, stream);
