@@ -28,13 +28,14 @@
 #include <string.h>
 
 #include "common.cuh"
+#include "attn_pagesplit.cuh"
 #include "internal.h"
 #include "../../include/vlm_hip.h"
 
 namespace {
 
-constexpr int HD = 128;   // head_dim supported by the decode path
-constexpr int PAGE = 64;
+constexpr int HD = VLM_HD;   // head_dim supported by the decode path
+constexpr int PAGE = VLM_PAGE;
 
 // NW waves per workgroup: 16 (one round covers 1024 tokens of context); 8 when G == 8 (LDS merge buffer <= 64 KB)
 template <int G, int NW, bool STAMPS, bool IDENT>
@@ -365,109 +366,11 @@ __global__ __launch_bounds__(64) void attn_decode_pagesplit_kernel(
   // every kernel argument in ONE scalar-load batch at entry (the tail's arguments would otherwise be fetched lazily,
   // one more round trip on the path to the ticket)
   asm volatile("" ::"s"(part_o), "s"(part_ml), "s"(tickets), "s"(out), "s"(S), "s"(ldo));
-  int pi = s;
-  const int* trow = IDENT ? nullptr : block_table + (size_t)b * max_pages;
-  size_t page = IDENT ? (size_t)b * max_pages + min(pi, max_pages - 1) : (size_t)trow[min(pi, max_pages - 1)];
-  int len_raw;
-  asm volatile("global_load_dword %0, %1, off" : "=v"(len_raw) : "v"(kv_len + b) : "memory");
-  bf16x8_t qf[4];
-  {
-    const bf16_t* qr = q + (size_t)b * ldq + (size_t)(g * G + min(head, G - 1)) * HD + 8 * gq;
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) qf[ds] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(qr + 32 * ds));
-  }
-  __builtin_amdgcn_sched_barrier(0);
   f32x4_t ot[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) ot[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
-  int len = 0, npages = 0;
-  do {
-    if (!IDENT) asm volatile("s_waitcnt vmcnt(0)" : "+v"(len_raw), "+v"(page)::"memory");
-    const bf16_t* kp = kpool + (page * Hkv + g) * (size_t)(HD / 8) * PAGE * 8 + ((size_t)gq * PAGE + head) * 8;
-    const bf16_t* vp = vpool + (page * Hkv + g) * (size_t)HD * PAGE + (size_t)head * PAGE + 8 * gq;
-    u32x4_t kf[4][4], vf[8][2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int ds = 0; ds < 4; ++ds)
-        kf[t][ds] = *reinterpret_cast<const u32x4_t*>(kp + ((size_t)(4 * ds) * PAGE + 16 * t) * 8);
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-        vf[dt][u] = *reinterpret_cast<const u32x4_t*>(vp + (size_t)(16 * dt) * PAGE + 32 * u);
-    const int pc = pi;     // the page being processed
-    pi += S;
-    const size_t next_page = IDENT ? (size_t)b * max_pages + min(pi, max_pages - 1) : (size_t)trow[min(pi, max_pages - 1)];
-    __builtin_amdgcn_sched_barrier(0);
-    if (!IDENT) {
-      len = __builtin_amdgcn_readfirstlane(len_raw) + kv_len_add;
-      npages = (len + PAGE - 1) / PAGE;
-    }
-    f32x4_t st[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      st[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ds = 0; ds < 4; ++ds)
-        st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[t][ds]), qf[ds], st[t], 0, 0, 0);
-    }
-    if (IDENT) {
-      asm volatile("s_waitcnt vmcnt(16)" : "+v"(len_raw)::"memory");
-      len = __builtin_amdgcn_readfirstlane(len_raw) + kv_len_add;
-      npages = (len + PAGE - 1) / PAGE;
-    }
-    float mt = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = pc * PAGE + 16 * t + 4 * gq + r;
-        const float sv = key < len ? st[t][r] * scale_log2 : -INFINITY;
-        st[t][r] = sv;
-        mt = fmaxf(mt, sv);
-      }
-    mt = col4_max(mt);
-    const float m_new = fmaxf(m_run, mt);
-    const float m_use = m_new == -INFINITY ? 0.f : m_new;
-    const float alpha = exp2f(m_run - m_use);
-    float ls = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = exp2f(st[t][r] - m_use);
-        st[t][r] = p;
-        ls += p;
-      }
-    l_run = l_run * alpha + ls;
-    m_run = m_new;
-    bf16x8_t pb[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const u32x4_t pk = {pack_bf2(st[2 * u][0], st[2 * u][1]), pack_bf2(st[2 * u][2], st[2 * u][3]),
-                          pack_bf2(st[2 * u + 1][0], st[2 * u + 1][1]), pack_bf2(st[2 * u + 1][2], st[2 * u + 1][3])};
-      pb[u] = __builtin_bit_cast(bf16x8_t, pk);
-    }
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        u32x4_t vv = vf[dt][u];
-        const int k0 = pc * PAGE + 32 * u + 4 * gq, k1 = k0 + 16;
-        vv[0] = (k0 + 1 < len) ? vv[0] : ((k0 < len) ? (vv[0] & 0xffffu) : 0u);
-        vv[1] = (k0 + 3 < len) ? vv[1] : ((k0 + 2 < len) ? (vv[1] & 0xffffu) : 0u);
-        vv[2] = (k1 + 1 < len) ? vv[2] : ((k1 < len) ? (vv[2] & 0xffffu) : 0u);
-        vv[3] = (k1 + 3 < len) ? vv[3] : ((k1 + 2 < len) ? (vv[3] & 0xffffu) : 0u);
-        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pb[u], ot[dt], 0, 0, 0);
-      }
-    }
-    if (pi >= npages) break;
-    page = next_page;
-  } while (true);
+  float m_run, l_run;
+  int npages;
+  vlm_pagesplit_walk<G, IDENT>(q, kpool, vpool, block_table, kv_len, ldq, max_pages, Hkv, kv_len_add, scale_log2, S, b, g, s, lane, ot,
+                               m_run, l_run, npages);
 
   pagesplit_finish<G, MERGE>(ot, m_run, l_run, npages, bh, b, g, s, S, Hkv, lane, ldo, part_o, part_ml, tickets, out);
 }

@@ -25,6 +25,7 @@
 //     a workgroup split K for RW rows (N / RW workgroups keep all 256 CUs busy),
 //     partial sums meet in LDS.
 #include "common.cuh"
+#include "attn_pagesplit.cuh"
 #include "internal.h"
 #include "../../include/vlm_hip.h"
 
@@ -45,6 +46,8 @@ struct RopeKvArgs {
   int long_from = 0;         // > 0: inv_freq holds [2][D/2] (short, long factors); the LONG row applies to every row of the step
                              // when ANY row's slot (= cache offset) >= long_from: SuScaledRoPE's per-call rule
                              // (rope_utils.py:168-172: position_end = max(offset) + tokens of the call > original_max)
+  unsigned* epoch = nullptr; // the fused decode block that FOLLOWS this launch (decode_block.hip) tags its hand-offs with this
+                             // word: ONE thread of this launch advances it (single writer; the kernel boundary publishes it)
 };
 
 struct AttnProArgs {
@@ -52,7 +55,7 @@ struct AttnProArgs {
   const float* part_ml;      // [M][Hq][S][2]  (PRO_ATTN: m in the natural-log domain; PRO_ATTN_BF16: log2 domain, -inf = no page)
   int S, Hq, D;
 };
-constexpr int AT2_S = 16;    // splits the PRO_ATTN_BF16 prologue reads (all of them, unconditionally)
+constexpr int AT2_S = VLM_MERGE_S;    // splits the PRO_ATTN_BF16 prologue reads (all of them, unconditionally)
 
 __device__ __forceinline__ u32x4_t ntl(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)); }
 
@@ -83,6 +86,9 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nchunk = K >> 3;
   const int gw = blockIdx.x * 4 + wave;
+  if (EPI == EPI_ROPE_KV) {
+    if (rk.epoch && blockIdx.x == 0 && tid == 0) *rk.epoch += 1u;
+  }
 
   // ---- which rows does this wave own?
   int row[R];
@@ -275,31 +281,9 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
       }
     }
   } else if (PRO == PRO_ATTN_BF16) {
-    // x[h*D + d] = sum_s f_s O_s[d] / sum_s f_s l_s,  f_s = 2^(m_s - M)
-    float mm = -INFINITY;
-#pragma unroll
-    for (int sp = 0; sp < AT2_S; ++sp) mm = fmaxf(mm, sp < ap.S ? a2_ml[sp].x : -INFINITY);
-    float ll = 0.f, acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int sp = 0; sp < AT2_S; ++sp) {
-      const bool on = sp < ap.S && a2_ml[sp].x != -INFINITY;
-      const float f = on ? exp2f(a2_ml[sp].x - mm) : 0.f;
-      ll += on ? f * a2_ml[sp].y : 0.f;
-      const u32x4_t o = a2_o[sp];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const unsigned w = o[j];
-        acc8[2 * j] += on ? f * bf_lo(w) : 0.f;
-        acc8[2 * j + 1] += on ? f * bf_hi(w) : 0.f;
-      }
-    }
-    const float il = 1.0f / ll;
-    if (tid < nchunk) {
-      uint4 o;
-      o.x = pack_bf2(acc8[0] * il, acc8[1] * il); o.y = pack_bf2(acc8[2] * il, acc8[3] * il);
-      o.z = pack_bf2(acc8[4] * il, acc8[5] * il); o.w = pack_bf2(acc8[6] * il, acc8[7] * il);
-      reinterpret_cast<uint4*>(smem)[tid] = o;
-    }
+    // x[h*D + d] = sum_s f_s O_s[d] / sum_s f_s l_s,  f_s = 2^(m_s - M)   (attn_pagesplit.cuh: shared with decode_block.hip)
+    const uint4 o = vlm_merge_splits16(a2_ml, a2_o, ap.S);
+    if (tid < nchunk) reinterpret_cast<uint4*>(smem)[tid] = o;
   } else if (PRO == PRO_ATTN) {
     // general form (more splits / rows): three short phases so that every global load of a phase is independent
     // (one memory round trip each)
@@ -618,7 +602,7 @@ extern "C" int vlm_gemv_qkv_rope_kvwrite_ws(const void* h, const void* norm_w, f
                                             const void* slot, const void* inv_freq, const void* block_table, int max_pages,
                                             void* kpool, void* vpool, void* workspace, void* stream) {
   return vlm_gemv_qkv_rope_kvwrite_ex(h, norm_w, eps, Wqkv, bqkv, qkv, ldq, M, hidden, Hq, Hkv, D, pos, slot, inv_freq, block_table,
-                                      max_pages, kpool, vpool, 1, workspace, 1.f, 0, stream);
+                                      max_pages, kpool, vpool, 1, workspace, 1.f, 0, nullptr, stream);
 }
 
 // mfma: 0 = v_dot2c kernels only; ws: the engine's workspace for vlm_gemv_mfma_try (nullptr: no K split over workgroups)
@@ -670,14 +654,14 @@ extern "C" int vlm_gemv_qkv_rope_kvwrite(const void* h, const void* norm_w, floa
                                          const void* block_table, int max_pages, void* kpool, void* vpool,
                                          void* stream) {
   return vlm_gemv_qkv_rope_kvwrite_ex(h, norm_w, eps, Wqkv, bqkv, qkv, ldq, M, hidden, Hq, Hkv, D, pos, slot, inv_freq, block_table,
-                                      max_pages, kpool, vpool, 1, nullptr, 1.f, 0, stream);
+                                      max_pages, kpool, vpool, 1, nullptr, 1.f, 0, nullptr, stream);
 }
 
 VLM_INTERNAL int vlm_gemv_qkv_rope_kvwrite_ex(const void* h, const void* norm_w, float eps, const void* Wqkv,
                                               const void* bqkv, void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D,
                                               const void* pos, const void* slot, const void* inv_freq,
                                               const void* block_table, int max_pages, void* kpool, void* vpool, int mfma,
-                                              void* ws, float qk_scale, int long_from, void* stream) {
+                                              void* ws, float qk_scale, int long_from, void* epoch, void* stream) {
   if (!h || !norm_w || !Wqkv || !bqkv || !qkv || !pos || !slot || !inv_freq || !kpool || !vpool || max_pages <= 0)
     return VLM_ERR_ARG;
   const int N = (Hq + 2 * Hkv) * D;
@@ -691,7 +675,7 @@ VLM_INTERNAL int vlm_gemv_qkv_rope_kvwrite_ex(const void* h, const void* norm_w,
   if (hidden % 8 || D % 16 || hidden > 4096 || (size_t)M * hidden * 2 > 64 * 1024) return VLM_ERR_SHAPE;
   Args a{h, Wqkv, bqkv, nullptr, norm_w, qkv, N, hidden, hidden, hidden, ldq, 0, eps,
          RopeKvArgs{(const int*)pos, (const int*)slot, (const float*)inv_freq, (const int*)block_table, max_pages, Hq, Hkv,
-                    D, (bf16_t*)kpool, (bf16_t*)vpool, qk_scale, long_from},
+                    D, (bf16_t*)kpool, (bf16_t*)vpool, qk_scale, long_from, (unsigned*)epoch},
          AttnProArgs{}, (hipStream_t)stream};
   return launch_rw_m<PRO_RMSNORM, EPI_ROPE_KV>(M, a);
 }

@@ -5,7 +5,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 scripts/decode_probe.cpp -Iinclude -Lmlx-vlm_amd/lib -lvlm_hip \
 //         -Wl,-rpath,'$ORIGIN/../mlx-vlm_amd/lib' -o scripts/bin/decode_probe
-//   scripts/bin/decode_probe [--steps 300] [--ctx 450] [--variant pf,wgs,mask,flags,headmb ...] [--micro]
+//   scripts/bin/decode_probe [--steps 300] [--ctx 450] [--variant flags,psplit,gv,am,fused_block ...] [--micro] [--no-hot]
 //
 // Every variant restarts from the same device state and must reproduce the baseline's tokens bit for bit
 // (prefetch and the fused tail change scheduling only).
@@ -20,7 +20,6 @@
 #include <vector>
 
 #include "vlm_hip.h"
-extern "C" int vlm_llm_debug_fused_stamps(void* handle, float* out16);
 
 #define CK(x)                                                                              \
   do {                                                                                     \
@@ -203,10 +202,10 @@ static void reset_state(const Model& m, State& s, int ctx0, hipStream_t st) {
 }
 
 struct Variant {
-  int pf = 0, wgs = 256, mask = 0x7f, flags = 0, headmb = 96, skip = 0, fmlp = 0, psplit = 16, gv = 0, am = 1, tt = 0;
+  int flags = 1, psplit = 16, gv = 1, am = 1, fb = 1;     // fused greedy tail, page-split width, GEMV variant bits, merge in o_proj, fused block
   std::string name() const {
     char b[160];
-    snprintf(b, sizeof b, "pf=%d flags=%d skip=0x%02x fmlp=%d psplit=%d gv=%d am=%d tt=%d", pf, flags, skip, fmlp, psplit, gv, am, tt);
+    snprintf(b, sizeof b, "flags=%d psplit=%d gv=%d am=%d fused_block=%d", flags, psplit, gv, am, fb);
     return b;
   }
 };
@@ -214,17 +213,10 @@ struct Variant {
 // -> microseconds per step; tokens of the first ring_len steps in `toks`
 static double run_variant(const Model& m, State& s, const Variant& v, int ctx0, int warm, int steps, std::vector<int>* toks,
                           hipStream_t st) {
-  RC(vlm_llm_set_tuning(m.h, VLM_TUNE_PREFETCH, v.pf));
-  RC(vlm_llm_set_tuning(m.h, VLM_TUNE_PREFETCH_WGS, v.wgs));
-  RC(vlm_llm_set_tuning(m.h, VLM_TUNE_PREFETCH_MASK, v.mask));
-  RC(vlm_llm_set_tuning(m.h, VLM_TUNE_PREFETCH_HEAD_MB, v.headmb));
-  RC(vlm_llm_set_tuning(m.h, VLM_TUNE_DEBUG_SKIP, v.skip));
-  RC(vlm_llm_set_tuning(m.h, VLM_TUNE_FUSED_MLP, v.fmlp));
   RC(vlm_llm_set_tuning(m.h, VLM_TUNE_ATTN_PAGESPLIT, v.psplit));
   RC(vlm_llm_set_tuning(m.h, VLM_TUNE_GEMV_VARIANT, v.gv));
   RC(vlm_llm_set_tuning(m.h, VLM_TUNE_ATTN_MERGE, v.am));
-  RC(vlm_llm_set_tuning(m.h, VLM_TUNE_TLB_TOUCH, v.tt));
-  if (v.fmlp && !vlm_llm_get_tuning(m.h, VLM_TUNE_FUSED_MLP)) printf("   (fused MLP not available on this device / shape)\n");
+  RC(vlm_llm_set_tuning(m.h, VLM_TUNE_FUSED_BLOCK, v.fb));
   s.a.flags = v.flags;
   RC(vlm_llm_set_kv(m.h, &m.kv));
   reset_state(m, s, ctx0, st);
@@ -321,28 +313,16 @@ int main(int argc, char** argv) {
     else if (a == "--block-table") use_table = true;
     else if (a == "--variant" && i + 1 < argc) {
       Variant v;
-      sscanf(argv[++i], "%d,%d,%i,%d,%d,%i,%d,%d,%i,%d,%d", &v.pf, &v.wgs, &v.mask, &v.flags, &v.headmb, &v.skip, &v.fmlp, &v.psplit, &v.gv, &v.am, &v.tt);
+      sscanf(argv[++i], "%d,%d,%i,%d,%d", &v.flags, &v.psplit, &v.gv, &v.am, &v.fb);
       variants.push_back(v);
     }
   }
   if (variants.empty()) {
     variants = {
-        {0, 256, 0x7f, 0, 96},   // baseline (round-1 step)
-        {0, 256, 0x7f, 1, 96},   // fused greedy tail
-        {1, 256, 0x7f, 1, 96},   // + event-paced prefetch, everything
-        {2, 256, 0x7f, 1, 96},   // + flag-paced persistent prefetch, everything
-        {1, 256, 0x1f, 1, 96},   // layers only (no head rows, no next-step layer 0)
-        {2, 256, 0x1f, 1, 96},
-        {1, 256, 0x0f, 1, 96},   // weights only (no K/V pages)
-        {1, 256, 0x0c, 1, 96},   // gate/up + down only
-        {1, 256, 0x13, 1, 96},   // qkv + o + K/V only (the latency-bound kernels)
-        {1, 128, 0x7f, 1, 96},
-        {1, 512, 0x7f, 1, 96},
-        {2, 128, 0x7f, 1, 96},
-        {2, 512, 0x7f, 1, 96},
-        {1, 256, 0x7f, 1, 32},
-        {1, 256, 0x7f, 1, 200},
-        {0, 256, 0x7f, 0, 96},   // baseline again (drift check)
+        {1, 16, 1, 1, 0},   // five launches per layer
+        {1, 16, 1, 1, 1},   // fused decode block: three launches per layer
+        {1, 16, 1, 1, 0},
+        {1, 16, 1, 1, 1},
     };
   }
   hipStream_t st;
@@ -370,17 +350,8 @@ int main(int argc, char** argv) {
     int first_diff = -1;
     for (size_t i = 0; i < toks.size() && i < base_toks.size(); ++i)
       if (toks[i] != base_toks[i]) { first_diff = (int)i; break; }
-    if (variants[vi].fmlp && getenv("VLM_FUSED_STAMPS")) {
-      float st[16];
-      if (vlm_llm_debug_fused_stamps(m.h, st) == 0) {
-        printf("   fused launch, workgroup 0 (us): worker: o-published %.2f | past #1 %.2f | gu-published %.2f | past #2 %.2f | down-summed %.2f | end %.2f\n",
-               st[0], st[1], st[2], st[3], st[4], st[5]);
-        printf("                                    gatherer: h-gathered %.2f | past #1 %.2f | act-sentinels %.2f | act-gathered %.2f\n",
-               st[8], st[9], st[10], st[11]);
-      }
-    }
-    const int ferr = vlm_llm_fused_error(m.h);
-    if (ferr) printf("   FUSED HAND-OFF GAVE UP: code %d\n", ferr);
+    const int ferr = vlm_llm_fused_errors(m.h);
+    if (ferr) printf("   FUSED HAND-OFF GAVE UP: %d\n", ferr);
     if (!same) printf("   first differing token at step %d of %zu\n", first_diff, toks.size());
     const double bytes = lm_bytes + 28672.0 * (ctx0 + steps / 2);
     if (getenv("VLM_ATTN_STAMPS")) {   // timeline of the LAST attention launch (library built with -DVLM_ATTN_TIMELINE)
@@ -410,7 +381,7 @@ int main(int argc, char** argv) {
     m2.g = m1.g;
     RC(vlm_llm_set_globals(m2.h, &m2.g));
     State s1 = make_state(dev, d1, B);
-    Variant v0{0, 256, 0x7f, 0, 96};
+    Variant v0{1, 16, 1, 1, 0};
     const double t1 = run_variant(m1, s1, v0, ctx0, warm, steps, nullptr, st);
     const double t2 = run_variant(m2, s1, v0, ctx0, warm, steps, nullptr, st);
     printf("\n== cache-resident bound: 1 layer %.1f us/step, 2 layers %.1f us/step -> one on-die layer %.1f us (HBM-cold: see baseline / 28)\n",
