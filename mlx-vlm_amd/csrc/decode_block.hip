@@ -34,6 +34,8 @@
 // (tests/test_decode_block_gpu.py).
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include "common.cuh"
 #include "attn_pagesplit.cuh"
 #include "internal.h"
@@ -45,6 +47,7 @@ typedef unsigned long long u64;
 constexpr int HD = VLM_HD;
 constexpr int BLK_WGS = 256, BLK_THREADS = 512, GU_WAVES = 7;
 constexpr int RP = 4;                       // o_proj row pairs per wave, at most
+constexpr int RG0 = 10, RG1 = 12;           // gate / up rows per wave: LAYOUT 0 (1792 waves) / LAYOUT 1 (7 (256 - NU) waves)
 constexpr int POLL_LIMIT = 1 << 18;         // bounded waits (a fraction of a second): then the error word, never a hang
 
 // workspace (bytes): epoch word | error word | flags of the attention units | granules of the merged attention vector |
@@ -98,13 +101,15 @@ __device__ __forceinline__ void st4(unsigned* p, unsigned v) { __hip_atomic_stor
 // elements = 4 granules = two 16-byte sc1 loads each), every tag checked, the sweep repeated until all match.  A cheap
 // pre-poll (ONE 8-byte load per lane over a spread sample, with s_sleep) keeps the full sweeps off the memory pipe while
 // the producers are still far away (MI355X_MICROARCH.md: polling-cost).
-template <int KC, typename RS>
+template <int KC, bool PREPOLL, typename RS>
 __device__ __forceinline__ void gather_vec(RS rs, const u64* base, unsigned E, int lane, u32x4_t (&x)[KC], unsigned* err) {
   int it = 0;
-  for (; it < POLL_LIMIT; ++it) {
-    const u64 v = ld8(base + lane * (KC * 4));
-    if (__all((unsigned)(v >> 32) == E)) break;
-    __builtin_amdgcn_s_sleep(4);
+  if (PREPOLL) {
+    for (; it < POLL_LIMIT; ++it) {
+      const u64 v = ld8(base + lane * (KC * 4));
+      if (__all((unsigned)(v >> 32) == E)) break;
+      __builtin_amdgcn_s_sleep(4);
+    }
   }
   for (; it < POLL_LIMIT; ++it) {
     u32x4_t a[KC], b[KC];
@@ -125,160 +130,166 @@ __device__ __forceinline__ void gather_vec(RS rs, const u64* base, unsigned E, i
   if (lane == 0) atomicAdd(err, 1u);
 }
 
-template <int G, bool IDENT, int KC, int RG>
-__global__ __launch_bounds__(BLK_THREADS) void decode_block_kernel(BlockArgs p) {
-  __shared__ __attribute__((aligned(16))) uint4 xs[KC * 64];      // the normalised residual stream, bf16 [K]
+// A wave's weight rows, REQUESTED IN A PACED STREAM: at most DEPTH 1-KiB loads of the wave in flight (s_waitcnt vmcnt(DEPTH - 1)
+// before every further request).  Everything-at-entry (DEPTH >= the wave's loads) puts 60 MB into the memory system's queues
+// in the first two microseconds - a chain hop issued after that waits behind all of it (profiles/r04_decode_block_v1.txt);
+// 7 waves x DEPTH KiB per CU in flight is bandwidth x latency, the queues stay short and the stream runs at the same rate.
+template <int N, int KC, int DEPTH>
+__device__ __forceinline__ void paced_rows(const bf16_t* W, int row0, int row_max, int K, int lane, u32x4_t (&wv)[N][KC]) {
+#pragma unroll
+  for (int i = 0; i < N * KC; ++i) {
+    const int r = i / KC, c = i % KC;
+    if (DEPTH < N * KC && i >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");
+    wv[r][c] = ntl(W + (size_t)min(row0 + r, row_max) * K + (size_t)(lane + 64 * c) * 8);
+  }
+}
+
+struct Sync {                 // the hand-off state of a launch, decoded from the workspace
+  unsigned E;
+  unsigned* err;
+  unsigned* f1;
+  u64* xm;
+  u64* hg;
+};
+__device__ __forceinline__ Sync sync_of(const BlockArgs& p) {
+  return Sync{*reinterpret_cast<const unsigned*>(p.ws + WS_EPOCH), reinterpret_cast<unsigned*>(p.ws + WS_ERR),
+              reinterpret_cast<unsigned*>(p.ws + WS_F1), reinterpret_cast<u64*>(p.ws + WS_XM), reinterpret_cast<u64*>(p.ws + WS_HG)};
+}
+
+// ---- gate / up rows row0 .. row0 + RG - 1 of one wave: every weight load at entry, then the workgroup barrier behind which
+//      the normalised residual stream is in LDS, dots, SwiGLU
+template <int KC, int RG, int DEPTH>
+__device__ __forceinline__ void gateup_rows(const BlockArgs& p, const uint4* xs, int row0, int lane, u64* st) {
   constexpr int K = KC * 512;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wg = blockIdx.x;
-  const bool stamp = p.stamps != nullptr && (wg == 0 || wg == BLK_WGS - 1);
-
-  if (wave < GU_WAVES) {
-    // ------------------------------------------------------------------------------------------------ gate / up rows
-    const int gw = wg * GU_WAVES + wave, row0 = gw * RG;
-    u32x4_t wv[RG][KC];
+  u32x4_t wv[RG][KC];
+  paced_rows<RG, KC, DEPTH>(p.wgu, row0, p.n2 - 1, K, lane, wv);
+  __builtin_amdgcn_sched_barrier(0);
+  if (st) st[8] = wall_clock64();                                                  // weights requested
+  asm volatile("s_barrier" ::: "memory");                                          // the eighth wave has x in LDS
+  if (st) st[9] = wall_clock64();
+  float acc[RG];
 #pragma unroll
-    for (int r = 0; r < RG; ++r) {
-      const bf16_t* wr = p.wgu + (size_t)min(row0 + r, p.n2 - 1) * K;
+  for (int r = 0; r < RG; ++r) acc[r] = 0.f;
 #pragma unroll
-      for (int c = 0; c < KC; ++c) wv[r][c] = ntl(wr + (size_t)(lane + 64 * c) * 8);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (stamp && wg == BLK_WGS - 1 && tid == 0) p.stamps[8] = wall_clock64();       // weights requested
-    asm volatile("s_barrier" ::: "memory");                                        // the eighth wave has x in LDS
-    if (stamp && wg == BLK_WGS - 1 && tid == 0) p.stamps[9] = wall_clock64();
-    float acc[RG];
+  for (int c = 0; c < KC; ++c) {
+    const u32x4_t xv = *reinterpret_cast<const u32x4_t*>(&xs[lane + 64 * c]);
 #pragma unroll
-    for (int r = 0; r < RG; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      const u32x4_t xv = *reinterpret_cast<const u32x4_t*>(&xs[lane + 64 * c]);
-#pragma unroll
-      for (int r = 0; r < RG; ++r) acc[r] = dot8(wv[r][c], xv, acc[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < RG; ++r) acc[r] = wave_sum(acc[r]);
-#pragma unroll
-    for (int r = 0; r < RG; r += 2)
-      if (lane == (r >> 1) && row0 + r + 1 < p.n2) p.act[(row0 + r) >> 1] = f2bf(swiglu_(rbf(acc[r]), rbf(acc[r + 1])));
-    if (stamp && wg == BLK_WGS - 1 && tid == 0) p.stamps[10] = wall_clock64();
-    return;
+    for (int r = 0; r < RG; ++r) acc[r] = dot8(wv[r][c], xv, acc[r]);
   }
+#pragma unroll
+  for (int r = 0; r < RG; ++r) acc[r] = wave_sum(acc[r]);
+#pragma unroll
+  for (int r = 0; r < RG; r += 2)
+    if (lane == (r >> 1) && row0 + r + 1 < p.n2) p.act[(row0 + r) >> 1] = f2bf(swiglu_(rbf(acc[r]), rbf(acc[r + 1])));
+  if (st) st[10] = wall_clock64();
+}
 
-  // ---------------------------------------------------------------------------------------------------- the eighth wave
-  const unsigned E = *reinterpret_cast<const unsigned*>(p.ws + WS_EPOCH);
-  unsigned* const err = reinterpret_cast<unsigned*>(p.ws + WS_ERR);
-  unsigned* const f1 = reinterpret_cast<unsigned*>(p.ws + WS_F1);
-  u64* const xm = reinterpret_cast<u64*>(p.ws + WS_XM);
-  u64* const hg = reinterpret_cast<u64*>(p.ws + WS_HG);
-  const auto rs_xm = VLM_RSRC(xm);
-  const auto rs_hg = VLM_RSRC(hg);
-  const int NU = p.Hkv * p.S;
-  uint4 nwv[KC];
+// ---- attention unit (kv head g, page stride s): page walk, partials out (R1 form), hop 2a, its slice of the merged vector
+template <int G, bool IDENT>
+__device__ __forceinline__ void attention_unit(const BlockArgs& p, const Sync& y, int unit, int lane, u64* st) {
+  const int g = unit / p.S, s = unit % p.S;
+  f32x4_t ot[8];
+  float m_run, l_run;
+  int npages;
+  vlm_pagesplit_walk<G, IDENT>(p.q, p.kpool, p.vpool, p.block_table, p.kv_len, p.ldq, p.max_pages, p.Hkv, p.kv_len_add,
+                               p.scale_log2, p.S, 0, g, s, lane, ot, m_run, l_run, npages);
+  const int head = lane & 15, gq = lane >> 4;
+  l_run = col4_sum(l_run);
+  // partials in the layout of the unfused attention launch (pagesplit_finish, MERGE = false), write-through
+  if (head < G) {
+    const size_t e = (size_t)(g * G + head) * p.S + s;
+    if (gq == 0) st8(reinterpret_cast<u64*>(p.part_ml + e * 2), ((u64)__float_as_uint(l_run) << 32) | __float_as_uint(m_run));
+    if (m_run != -INFINITY) {
+      bf16_t* po = p.part_o + e * HD + 4 * gq;
 #pragma unroll
-  for (int c = 0; c < KC; ++c) nwv[c] = reinterpret_cast<const uint4*>(p.ln2_w)[lane + 64 * c];
-  if (stamp && lane == 0) p.stamps[wg == 0 ? 0 : 4] = wall_clock64();
-
-  if (wg < NU) {
-    // ------------------------------------------------------------------------------------- attention unit (g, s)
-    const int g = wg / p.S, s = wg % p.S;
-    f32x4_t ot[8];
-    float m_run, l_run;
-    int npages;
-    vlm_pagesplit_walk<G, IDENT>(p.q, p.kpool, p.vpool, p.block_table, p.kv_len, p.ldq, p.max_pages, p.Hkv, p.kv_len_add,
-                                 p.scale_log2, p.S, 0, g, s, lane, ot, m_run, l_run, npages);
-    const int head = lane & 15, gq = lane >> 4;
-    l_run = col4_sum(l_run);
-    // partials in the layout of the unfused attention launch (pagesplit_finish, MERGE = false), write-through
-    if (head < G) {
-      const size_t e = (size_t)(g * G + head) * p.S + s;
-      if (gq == 0) st8(reinterpret_cast<u64*>(p.part_ml + e * 2), ((u64)__float_as_uint(l_run) << 32) | __float_as_uint(m_run));
-      if (m_run != -INFINITY) {
-        bf16_t* po = p.part_o + e * HD + 4 * gq;
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt)
-          st8(reinterpret_cast<u64*>(po + 16 * dt), ((u64)pack_bf2(ot[dt][2], ot[dt][3]) << 32) | pack_bf2(ot[dt][0], ot[dt][1]));
-      }
+      for (int dt = 0; dt < 8; ++dt)
+        st8(reinterpret_cast<u64*>(po + 16 * dt), ((u64)pack_bf2(ot[dt][2], ot[dt][3]) << 32) | pack_bf2(ot[dt][0], ot[dt][1]));
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // every store has left (R1) ...
-    if (lane == 0) st4(f1 + wg, E);                                                // ... then the flag
-    if (stamp && lane == 0) p.stamps[1] = wall_clock64();                          // partial published
-    // hop 2a: the S units of this kv head
-    {
-      int it = 0;
-      for (; it < POLL_LIMIT; ++it) {
-        const unsigned v = ld4(f1 + g * p.S + min(lane, p.S - 1));
-        if (__all(v == E)) break;
-        __builtin_amdgcn_s_sleep(2);
-      }
-      if (it == POLL_LIMIT && lane == 0) atomicAdd(err, 1u);
-    }
-    if (stamp && lane == 0) p.stamps[2] = wall_clock64();                          // all partials of the kv head are out
-    // my chunks of the attention output: chunk cj of kv head g = (head g*G + cj / 16, d0 = 8 (cj % 16)); lane j < CPU_ one each
-    const int cpu = G * 16 / p.S, cj = s * cpu + min(lane, cpu - 1);
-    const int mh = g * G + (cj >> 4), d0 = (cj & 15) * 8;
-    const auto rs_po = VLM_RSRC(p.part_o);
-    float2 a2_ml[VLM_MERGE_S];
-    u32x4_t a2_o[VLM_MERGE_S];
-#pragma unroll
-    for (int sp = 0; sp < VLM_MERGE_S; ++sp) {
-      const int e = mh * p.S + min(sp, p.S - 1);
-      const u64 mlv = ld8(reinterpret_cast<const u64*>(p.part_ml) + e);
-      a2_ml[sp] = make_float2(__uint_as_float((unsigned)mlv), __uint_as_float((unsigned)(mlv >> 32)));
-      a2_o[sp] = VLM_LD16(rs_po, (e * HD + d0) * 2);
-    }
-    const uint4 o = vlm_merge_splits16(a2_ml, a2_o, p.S);
-    if (lane < cpu) {
-      const int off = (mh * HD + d0) * 4;                                          // 4 granules of 8 bytes per chunk
-      VLM_ST16((u32x4_t{o.x, E, o.y, E}), rs_xm, off);
-      VLM_ST16((u32x4_t{o.z, E, o.w, E}), rs_xm, off + 16);
-    }
-    if (stamp && lane == 0) p.stamps[3] = wall_clock64();                          // merged slice published
-  } else {
-    // ------------------------------------------------------------------------------------- o_proj rows
-    const int NO = BLK_WGS - NU, wi = wg - NU, pairs = K / 2, base = pairs / NO, rem = pairs % NO;
-    const int cnt = base + (wi < rem ? 1 : 0), p0 = wi * base + min(wi, rem);
-    const unsigned res2 = reinterpret_cast<const unsigned*>(p.h)[min(p0 + lane, pairs - 1)];   // rows 2 (p0 + lane), + 1
-    __builtin_amdgcn_sched_barrier(0);
-    u32x4_t wo[2 * RP][KC];
-#pragma unroll
-    for (int r = 0; r < 2 * RP; ++r) {
-      const bf16_t* wr = p.wo + (size_t)min(2 * p0 + r, K - 1) * K;
-#pragma unroll
-      for (int c = 0; c < KC; ++c) wo[r][c] = ntl(wr + (size_t)(lane + 64 * c) * 8);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // hop 2b: the merged attention vector
-    u32x4_t xa[KC];
-    gather_vec<KC>(rs_xm, xm, E, lane, xa, err);
-    if (stamp && lane == 0) p.stamps[5] = wall_clock64();                          // attention output here
-    float acc[2 * RP];
-#pragma unroll
-    for (int r = 0; r < 2 * RP; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int c = 0; c < KC; ++c)
-#pragma unroll
-      for (int r = 0; r < 2 * RP; ++r) acc[r] = dot8(wo[r][c], xa[c], acc[r]);
-#pragma unroll
-    for (int r = 0; r < 2 * RP; ++r) acc[r] = wave_sum(acc[r]);
-    // lane j < cnt: row pair p0 + j.  h = bf16(bf16(o_proj) + residual) as the o_proj launch's epilogue rounds it
-    float a0 = acc[0], a1 = acc[1];
-#pragma unroll
-    for (int j = 1; j < RP; ++j) {
-      a0 = (lane == j) ? acc[2 * j] : a0;
-      a1 = (lane == j) ? acc[2 * j + 1] : a1;
-    }
-    const unsigned payload = (unsigned)f2bf(rbf(a0) + bf_lo(res2)) | ((unsigned)f2bf(rbf(a1) + bf_hi(res2)) << 16);
-    if (lane < cnt) {
-      st8(hg + p0 + lane, ((u64)E << 32) | payload);
-      reinterpret_cast<unsigned*>(p.h)[p0 + lane] = payload;
-    }
-    if (stamp && lane == 0) p.stamps[6] = wall_clock64();                          // residual rows published
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 // every store has left (R1) ...
+  if (lane == 0) st4(y.f1 + unit, y.E);                                            // ... then the flag
+  if (st) st[1] = wall_clock64();                                                  // partial published
+  // hop 2a: the S units of this kv head
+  {
+    int it = 0;
+    for (; it < POLL_LIMIT; ++it) {
+      const unsigned v = ld4(y.f1 + g * p.S + min(lane, p.S - 1));
+      if (__all(v == y.E)) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (it == POLL_LIMIT && lane == 0) atomicAdd(y.err, 1u);
+  }
+  if (st) st[2] = wall_clock64();                                                  // all partials of the kv head are out
+  // my chunks of the attention output: chunk cj of kv head g = (head g*G + cj / 16, d0 = 8 (cj % 16)); lane j < cpu one each
+  const int cpu = G * 16 / p.S, cj = s * cpu + min(lane, cpu - 1);
+  const int mh = g * G + (cj >> 4), d0 = (cj & 15) * 8;
+  const auto rs_po = VLM_RSRC(p.part_o);
+  const auto rs_xm = VLM_RSRC(y.xm);
+  float2 a2_ml[VLM_MERGE_S];
+  u32x4_t a2_o[VLM_MERGE_S];
+#pragma unroll
+  for (int sp = 0; sp < VLM_MERGE_S; ++sp) {
+    const int e = mh * p.S + min(sp, p.S - 1);
+    const u64 mlv = ld8(reinterpret_cast<const u64*>(p.part_ml) + e);
+    a2_ml[sp] = make_float2(__uint_as_float((unsigned)mlv), __uint_as_float((unsigned)(mlv >> 32)));
+    a2_o[sp] = VLM_LD16(rs_po, (e * HD + d0) * 2);
+  }
+  const uint4 o = vlm_merge_splits16(a2_ml, a2_o, p.S);
+  if (lane < cpu) {
+    const int off = (mh * HD + d0) * 4;                                            // 4 granules of 8 bytes per chunk
+    VLM_ST16((u32x4_t{o.x, y.E, o.y, y.E}), rs_xm, off);
+    VLM_ST16((u32x4_t{o.z, y.E, o.w, y.E}), rs_xm, off + 16);
+  }
+  if (st) st[3] = wall_clock64();                                                  // merged slice published
+}
 
-  // ------------------------------------------------------------------------------------------- hop 3, every workgroup
+// ---- o_proj row pairs of wave wi of NO: weights at entry, hop 2b, dots, + residual, publish
+template <int KC, int DEPTH>
+__device__ __forceinline__ void oproj_rows(const BlockArgs& p, const Sync& y, int wi, int NO, int lane, u64* st) {
+  constexpr int K = KC * 512;
+  const int pairs = K / 2, base = pairs / NO, rem = pairs % NO;
+  const int cnt = base + (wi < rem ? 1 : 0), p0 = wi * base + min(wi, rem);
+  const unsigned res2 = reinterpret_cast<const unsigned*>(p.h)[min(p0 + lane, pairs - 1)];     // rows 2 (p0 + lane), + 1
+  __builtin_amdgcn_sched_barrier(0);
+  u32x4_t wo[2 * RP][KC];
+  paced_rows<2 * RP, KC, DEPTH>(p.wo, 2 * p0, K - 1, K, lane, wo);
+  __builtin_amdgcn_sched_barrier(0);
+  // hop 2b: the merged attention vector
+  u32x4_t xa[KC];
+  gather_vec<KC, true>(VLM_RSRC(y.xm), y.xm, y.E, lane, xa, y.err);
+  if (st) st[5] = wall_clock64();                                                  // attention output here
+  float acc[2 * RP];
+#pragma unroll
+  for (int r = 0; r < 2 * RP; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int c = 0; c < KC; ++c)
+#pragma unroll
+    for (int r = 0; r < 2 * RP; ++r) acc[r] = dot8(wo[r][c], xa[c], acc[r]);
+#pragma unroll
+  for (int r = 0; r < 2 * RP; ++r) acc[r] = wave_sum(acc[r]);
+  // lane j < cnt: row pair p0 + j.  h = bf16(bf16(o_proj) + residual) as the o_proj launch's epilogue rounds it
+  float a0 = acc[0], a1 = acc[1];
+#pragma unroll
+  for (int j = 1; j < RP; ++j) {
+    a0 = (lane == j) ? acc[2 * j] : a0;
+    a1 = (lane == j) ? acc[2 * j + 1] : a1;
+  }
+  const unsigned payload = (unsigned)f2bf(rbf(a0) + bf_lo(res2)) | ((unsigned)f2bf(rbf(a1) + bf_hi(res2)) << 16);
+  if (lane < cnt) {
+    st8(y.hg + p0 + lane, ((u64)y.E << 32) | payload);
+    reinterpret_cast<unsigned*>(p.h)[p0 + lane] = payload;
+  }
+  if (st) st[6] = wall_clock64();                                                  // residual rows published
+}
+
+// ---- hop 3: gather the new residual stream, RMSNorm (the rounding points of the gate/up launch's prologue,
+//      gemv_bf16.hip PRO_RMSNORM) -> LDS -> the workgroup barrier the gate/up waves wait at
+template <int KC, bool PREPOLL>
+__device__ __forceinline__ void norm_to_lds(const BlockArgs& p, const Sync& y, const uint4 (&nwv)[KC], uint4* xs, int lane, u64* st,
+                                            int st_slot) {
+  constexpr int K = KC * 512;
   u32x4_t hv[KC];
-  gather_vec<KC>(rs_hg, hg, E, lane, hv, err);
-  // RMSNorm with the rounding points of the gate/up launch's prologue (gemv_bf16.hip, PRO_RMSNORM)
+  gather_vec<KC, PREPOLL>(VLM_RSRC(y.hg), y.hg, y.E, lane, hv, y.err);
   float ss = 0.f;
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
@@ -300,8 +311,61 @@ __global__ __launch_bounds__(BLK_THREADS) void decode_block_kernel(BlockArgs p) 
     xs[lane + 64 * c] = o;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (stamp && lane == 0) p.stamps[wg == 0 ? 11 : 7] = wall_clock64();             // normalised stream in LDS
+  if (st) st[st_slot] = wall_clock64();                                            // normalised stream in LDS
   asm volatile("s_barrier" ::: "memory");
+}
+
+// LAYOUT 1 (the product): the latency chain runs on CUs of its OWN - workgroups 0 .. NU-1 hold one attention unit (eighth
+// wave) and the o_proj rows (waves 0..6: 768 row pairs over 7 NU waves), nothing else, so their loads never queue behind a
+// weight stream; workgroups NU .. 255 hold the gate/up rows (RG1 per wave, requested at entry) and an eighth wave that
+// gathers the residual stream (first sweep issued right away: it returns when the CU's weight requests have drained).
+// LAYOUT 0 (first cut, kept for the A/B that explains LAYOUT 1: profiles/r04_decode_block_v1.txt): every workgroup = 7
+// gate/up waves + one chain wave on the same CU.
+template <int G, bool IDENT, int KC, int LAYOUT, int DEPTH>
+__global__ __launch_bounds__(BLK_THREADS) void decode_block_kernel(BlockArgs p) {
+  __shared__ __attribute__((aligned(16))) uint4 xs[KC * 64];      // the normalised residual stream, bf16 [K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wg = blockIdx.x;
+  const int NU = p.Hkv * p.S;
+  u64* const st0 = (p.stamps && wg == 0 && lane == 0) ? p.stamps : nullptr;                    // an attention unit's workgroup
+  u64* const st1 = (p.stamps && wg == (LAYOUT ? NU - 1 : BLK_WGS - 1) && wave == (LAYOUT ? 0 : 7) && lane == 0) ? p.stamps : nullptr;  // o_proj rows
+  u64* const st2 = (p.stamps && wg == BLK_WGS - 1 && lane == 0) ? p.stamps : nullptr;          // gate / up rows + hop 3
+
+  if (LAYOUT == 0) {
+    if (wave < GU_WAVES) {
+      gateup_rows<KC, RG0, DEPTH>(p, xs, (wg * GU_WAVES + wave) * RG0, lane, wave == 0 ? st2 : nullptr);
+      return;
+    }
+    const Sync y = sync_of(p);
+    uint4 nwv[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) nwv[c] = reinterpret_cast<const uint4*>(p.ln2_w)[lane + 64 * c];
+    if (st0) st0[0] = wall_clock64();
+    if (st1) st1[4] = wall_clock64();
+    if (wg < NU) attention_unit<G, IDENT>(p, y, wg, lane, st0);
+    else oproj_rows<KC, DEPTH>(p, y, wg - NU, BLK_WGS - NU, lane, st1);
+    norm_to_lds<KC, true>(p, y, nwv, xs, lane, wg == 0 ? st0 : st2, wg == 0 ? 11 : 7);
+    return;
+  }
+  if (wg < NU) {                                                   // ---- chain workgroups
+    const Sync y = sync_of(p);
+    if (wave == 7) {
+      if (st0) st0[0] = wall_clock64();
+      attention_unit<G, IDENT>(p, y, wg, lane, st0);
+    } else {
+      if (st1) st1[4] = wall_clock64();
+      oproj_rows<KC, DEPTH>(p, y, wg * GU_WAVES + wave, NU * GU_WAVES, lane, st1);
+    }
+    return;
+  }
+  if (wave < GU_WAVES) {                                           // ---- streaming workgroups
+    gateup_rows<KC, RG1, DEPTH>(p, xs, ((wg - NU) * GU_WAVES + wave) * RG1, lane, wave == 0 ? st2 : nullptr);
+    return;
+  }
+  const Sync y = sync_of(p);
+  uint4 nwv[KC];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) nwv[c] = reinterpret_cast<const uint4*>(p.ln2_w)[lane + 64 * c];
+  norm_to_lds<KC, false>(p, y, nwv, xs, lane, st2, 7);
 }
 
 __global__ void epoch_bump_kernel(unsigned* e) { *e += 1u; }
@@ -316,18 +380,24 @@ bool resident(Kern kern) {
   return cus >= BLK_WGS && per_cu >= 1;
 }
 
-constexpr int KC_ = 3, RG_ = 10;          // hidden = Hq * 128 = 1536; 10 gate / up rows per wave (2 * inter <= 17920)
+constexpr int KC_ = 3;                    // hidden = Hq * 128 = 1536
+int g_layout = 1;                         // VLM_DECODE_BLOCK_LAYOUT=0: the first cut (A/B)
+int g_depth = 8;                          // VLM_DECODE_BLOCK_DEPTH: loads in flight per wave (A/B: 4, 8, 16, 64 = all at entry)
 
 bool shape_ok(int Hq, int Hkv, int D, int inter, int nsplit) {
   if (D != HD || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 || inter <= 0 || nsplit <= 0 || nsplit > VLM_MERGE_S) return false;
   const int K = Hq * HD, G = Hq / Hkv, NU = Hkv * nsplit;
   if (K != KC_ * 512) return false;
-  if (G != 2 && G != 3 && G != 4 && G != 6) return false;
-  if ((G * 16) % nsplit != 0 || NU > 64) return false;
-  if (2 * inter > BLK_WGS * GU_WAVES * RG_) return false;
-  const int NO = BLK_WGS - NU, pairs = K / 2;
-  if ((pairs + NO - 1) / NO > RP) return false;
-  return true;
+  if (G != 3 && G != 6) return false;
+  if ((G * 16) % nsplit != 0 || NU > 32) return false;
+  if (g_layout == 0) {
+    if (2 * inter > BLK_WGS * GU_WAVES * RG0) return false;
+    const int NO = BLK_WGS - NU, pairs = K / 2;
+    return (pairs + NO - 1) / NO <= RP;
+  }
+  if (2 * inter > (BLK_WGS - NU) * GU_WAVES * RG1) return false;
+  const int NO = NU * GU_WAVES, pairs = K / 2;
+  return (pairs + NO - 1) / NO <= RP;
 }
 
 }  // namespace
@@ -335,9 +405,16 @@ bool shape_ok(int Hq, int Hkv, int D, int inter, int nsplit) {
 extern "C" size_t vlm_decode_block_ws_bytes(void) { return WS_BYTES; }
 
 extern "C" int vlm_decode_block_supported(int Hq, int Hkv, int D, int inter, int nsplit) {
-  if (!shape_ok(Hq, Hkv, D, inter, nsplit)) return 0;
   static int res = -1;                      // (the answer depends on the device and the kernel's registers, not on the shape)
-  if (res < 0) res = resident(decode_block_kernel<6, true, KC_, RG_>) && resident(decode_block_kernel<6, false, KC_, RG_>) ? 1 : 0;
+  if (res < 0) {
+    const char* e = getenv("VLM_DECODE_BLOCK_LAYOUT");
+    if (e) g_layout = atoi(e) ? 1 : 0;
+    e = getenv("VLM_DECODE_BLOCK_DEPTH");
+    if (e) g_depth = atoi(e);
+    res = resident(decode_block_kernel<6, true, KC_, 1, 8>) && resident(decode_block_kernel<6, false, KC_, 1, 8>) &&
+                  resident(decode_block_kernel<6, true, KC_, 1, 64>) && resident(decode_block_kernel<6, true, KC_, 0, 64>) ? 1 : 0;
+  }
+  if (!shape_ok(Hq, Hkv, D, inter, nsplit)) return 0;
   return res;
 }
 
@@ -359,21 +436,28 @@ extern "C" int vlm_decode_block_bf16(const void* q, int ldq, const void* kpool, 
               (const bf16_t*)Wo, (bf16_t*)h, (const bf16_t*)ln2_w, (const bf16_t*)Wgu, (bf16_t*)act, 2 * inter, eps, (char*)ws,
               (bump_epoch & 2) ? reinterpret_cast<u64*>((char*)ws + WS_STAMPS) : nullptr};
   const int G = Hq / Hkv;
-#define GO1(GV, ID) hipLaunchKernelGGL((decode_block_kernel<GV, ID, KC_, RG_>), dim3(BLK_WGS), dim3(BLK_THREADS), 0, st, p)
+#define GO2(GV, ID, LY, DP) hipLaunchKernelGGL((decode_block_kernel<GV, ID, KC_, LY, DP>), dim3(BLK_WGS), dim3(BLK_THREADS), 0, st, p)
+#define GO1(GV, ID)                                                   \
+  do {                                                                \
+    if (g_layout == 0) { if (GV == 6) GO2(6, ID, 0, 64); else return VLM_ERR_SHAPE; } \
+    else if (g_depth <= 4) GO2(GV, ID, 1, 4);                         \
+    else if (g_depth <= 8) GO2(GV, ID, 1, 8);                         \
+    else if (g_depth <= 16) GO2(GV, ID, 1, 16);                       \
+    else GO2(GV, ID, 1, 64);                                          \
+  } while (0)
 #define GO(GV)                     \
   do {                             \
     if (!block_table) GO1(GV, true); \
     else GO1(GV, false);           \
   } while (0)
   switch (G) {
-    case 2: GO(2); break;
     case 3: GO(3); break;
-    case 4: GO(4); break;
     case 6: GO(6); break;
     default: return VLM_ERR_SHAPE;
   }
 #undef GO
 #undef GO1
+#undef GO2
   VLM_CHECK_LAUNCH();
   return VLM_OK;
 }

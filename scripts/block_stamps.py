@@ -8,9 +8,12 @@ and the wall-clock stamps (10 ns ticks) of the last fused launch: workgroup 0 (a
 
     python scripts/block_stamps.py [ctx=450] [reps=20]
 """
+import os
 import sys
 
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from mlx_vlm_amd import ops
 
@@ -87,6 +90,6 @@ t0 = min(x for x in st[:12] if x)
 us = [(x - t0) / 100.0 if x else float("nan") for x in st]
 print(f"workgroup 0 (attention unit g0 s0): start {us[0]:.2f} | partial published {us[1]:.2f} | kv head's partials seen {us[2]:.2f} | "
       f"slice published {us[3]:.2f} | x in LDS {us[11]:.2f}")
-print(f"workgroup 255, wave 7 (o_proj rows): start {us[4]:.2f} | attention vector gathered {us[5]:.2f} | rows published {us[6]:.2f} | "
+print(f"an o_proj wave (layout 1: workgroup NU-1 wave 0; layout 0: workgroup 255 wave 7): start {us[4]:.2f} | attention vector gathered {us[5]:.2f} | rows published {us[6]:.2f} | "
       f"x in LDS {us[7]:.2f}")
-print(f"workgroup 255, wave 0 (gate/up rows): weights requested {us[8]:.2f} | past the barrier {us[9]:.2f} | end {us[10]:.2f}")
+print(f"workgroup 255, wave 0 (gate/up rows; its wave 7's 'x in LDS' is the line above): weights requested {us[8]:.2f} | past the barrier {us[9]:.2f} | end {us[10]:.2f}")

@@ -63,8 +63,8 @@ def _skip_unless_supported(vops, Hq, Hkv, inter, nsplit):
 
 @pytest.mark.parametrize("n,heads,nsplit,inter,identity", [
     (386, (12, 2), 16, 8960, True), (1, (12, 2), 16, 8960, True), (64, (12, 2), 16, 8960, False),
-    (1024, (12, 2), 16, 8960, True), (1500, (12, 2), 16, 8960, False), (700, (12, 4), 16, 8960, True),
-    (130, (12, 6), 8, 4096, False), (450, (12, 3), 16, 8954, True)])
+    (1024, (12, 2), 16, 8960, True), (1500, (12, 2), 16, 8960, False), (700, (12, 4), 8, 8960, True),
+    (130, (12, 4), 8, 4096, False), (450, (12, 2), 16, 8954, True), (2000, (12, 2), 8, 8960, False)])
 def test_decode_block_bit_identical_to_three_launches_and_close_to_oracle(vops, n, heads, nsplit, inter, identity):
     Hq, Hkv = heads
     _skip_unless_supported(vops, Hq, Hkv, inter, nsplit)
