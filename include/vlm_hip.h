@@ -430,34 +430,8 @@ int vlm_llm_decode_launches(void* handle);
 #define VLM_TUNE_ATTN_MERGE 9       /* where the page-split attention of a ONE-row step is merged: 1 (default) = in the o_proj
                                        GEMV's prologue (partial-only attention launch, vlm_gemv_attn_out_bf16; needs bf16 Wo,
                                        Hq * D <= 2048, <= 16 splits), 0 = by the attention launch's last-arriving workgroup */
-#define VLM_TUNE_FUSED_BLOCK 11      /* one-row steps over bf16 weights at Qwen2-VL-2B-class widths (vlm_decode_block_supported):
-                                       1 (default) = [attention] [merge + o_proj] [norm + gate/up] as ONE launch
-                                       (vlm_decode_block_bf16: 3 launches per layer), 0 = five launches per layer.  Results
-                                       are bit-identical either way */
 int vlm_llm_set_tuning(void* handle, int key, int value);
 int vlm_llm_get_tuning(void* handle, int key);
-/* hand-offs of the fused decode block that gave up waiting since the handle was created (0 on a healthy run; a non-zero
- * count means the results of those steps are invalid - the waits are bounded so that a fault can never hang the device) */
-int vlm_llm_fused_errors(void* handle);
-
-/* The fused decode block of a ONE-row step (csrc/decode_block.hip): page-split attention over the paged pools (the new
- * token already written: kv_len = *kv_len + kv_len_add) -> split merge -> h += attn Wo^T -> act = swiglu(RMSNorm(h) Wgu^T)
- * in one launch of 256 co-resident workgroups.  Replaces vlm_attn_decode_paged_split (partial form) +
- * vlm_gemv_attn_out_bf16 + vlm_gemv_bf16(norm_w, VLM_EPI_SWIGLU) bit for bit; reference call sites: base.py:366-373,
- * qwen2_vl/language.py:115-133,149-153.
- * q bf16 [Hq][D] (row stride ldq unused beyond row 0); part_o / part_ml as vlm_attn_decode_paged_split's; Wo [Hq*D][Hq*D];
- * h bf16 [Hq*D] in / out; Wgu [2*inter][Hq*D] gate / up rows interleaved; act bf16 [inter].
- * ws: vlm_decode_block_ws_bytes() of zero-initialised device memory owned by the caller, one per stream of launches (its
- * first word is the launch epoch: advanced by the preceding qkv launch inside the engine, or by this call when
- * bump_epoch & 1; bump_epoch & 2: debug stamps).  VLM_ERR_SHAPE when vlm_decode_block_supported(...) != 1 (shape outside
- * hidden 1536 / 2 * inter <= 17920 / nsplit | 16 G, or a device that cannot hold the 256 x 512-thread grid resident). */
-size_t vlm_decode_block_ws_bytes(void);
-int vlm_decode_block_supported(int Hq, int Hkv, int D, int inter, int nsplit);
-int vlm_decode_block_bf16(const void* q, int ldq, const void* kpool, const void* vpool, const void* block_table, int max_pages,
-                          const void* kv_len, int kv_len_add, int Hq, int Hkv, int D, float scale, int nsplit, void* part_o,
-                          void* part_ml, const void* Wo, void* h, const void* ln2_w, float eps, const void* Wgu, int inter,
-                          void* act, void* ws, int bump_epoch, void* stream);
-int vlm_decode_block_debug(const void* ws, unsigned* err, unsigned long long* stamps16);
 
 /* The encoder-layer loop of the SigLIP / CLIP vision towers (idefics2/vision.py:141-187, llava_bunny/vision.py:139-200,
  * phi3_v/vision.py:117-175: x = x + out_proj(attention(LN1(x))); x = x + fc2(act(fc1(LN2(x)))), biases everywhere, no

@@ -85,7 +85,7 @@ class VitArgs(C.Structure):
 
 
 DECODE_FUSED_TAIL = 1                       # vlm_decode_args.flags
-TUNE_MFMA_GEMV, TUNE_ATTN_PAGESPLIT, TUNE_GEMV_VARIANT, TUNE_ATTN_MERGE, TUNE_FUSED_BLOCK = 6, 7, 8, 9, 11  # vlm_llm_set_tuning keys (include/vlm_hip.h)
+TUNE_MFMA_GEMV, TUNE_ATTN_PAGESPLIT, TUNE_GEMV_VARIANT, TUNE_ATTN_MERGE = 6, 7, 8, 9  # vlm_llm_set_tuning keys (include/vlm_hip.h)
 
 P = C.POINTER
 # name -> (restype, argtypes); every symbol include/vlm_hip.h declares
@@ -140,13 +140,6 @@ SIGNATURES = {
     "vlm_apply_logit_penalties": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, C.POINTER(PenaltyArgs), c_void_p]),
     "vlm_sample_greedy_advance": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "vlm_decode_block_ws_bytes": (c_size_t, []),
-    "vlm_decode_block_supported": (c_int, [c_int] * 5),
-    "vlm_decode_block_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
-                                      c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int,
-                                      c_void_p, c_void_p, c_int, c_void_p]),
-    "vlm_decode_block_debug": (c_int, [c_void_p, C.POINTER(c_uint), C.POINTER(C.c_ulonglong)]),
-    "vlm_llm_fused_errors": (c_int, [c_void_p]),
     "vlm_llm_set_tuning": (c_int, [c_void_p, c_int, c_int]),
     "vlm_llm_get_tuning": (c_int, [c_void_p, c_int]),
     "vlm_llm_create": (c_int, [P(LlmConfig), P(c_void_p)]),

@@ -1,5 +1,6 @@
-// The page walk of the page-split decode attention (attn_decode.hip), shared with the fused decode block
-// (decode_block.hip): ONE wave walks pages s, s + S, s + 2S, ... of (sequence b, kv head g) and leaves the unnormalised
+// The page walk of the page-split decode attention (attn_decode.hip) and the merge of its partials (gemv_bf16.hip) as
+// shared device functions (the rejected fused decode block, scripts/rejected/decode_block.hip.txt, was built from the same
+// sources to be bit-identical with the launches it replaced): ONE wave walks pages s, s + S, s + 2S, ... of (sequence b, kv head g) and leaves the unnormalised
 // O^T[d = 16 dt + 4 gq + r][head = lane & 15] in ot, the running max (log2 domain) in m_run and this lane's share of the row
 // sum in l_run.  Layouts, MFMA operand order and the reasons for them: attn_decode.hip (file header).
 #pragma once
@@ -127,8 +128,8 @@ __device__ __forceinline__ void vlm_pagesplit_walk(const bf16_t* __restrict__ q,
 // mx.fast.scaled_dot_product_attention, reference base.py:366-373):
 //     x[d] = sum_s f_s O_s[d] / sum_s f_s l_s,   f_s = 2^(m_s - M)
 // ml[sp] = (m, l) of split sp (m in the log2 domain of the walk above, -inf = the split owns no page and its O bytes may be
-// anything), o[sp] = its 8 bf16 O values; every split up to NS is passed, the ones >= S are dropped by a select.  ONE source
-// for the o_proj prologue (gemv_bf16.hip, PRO_ATTN_BF16) and the fused decode block (decode_block.hip): identical results.
+// anything), o[sp] = its 8 bf16 O values; every split up to NS is passed, the ones >= S are dropped by a select.  Used by
+// the o_proj prologue (gemv_bf16.hip, PRO_ATTN_BF16).
 constexpr int VLM_MERGE_S = 16;
 template <int NS>
 __device__ __forceinline__ uint4 vlm_merge_splits16(const float2 (&ml)[NS], const u32x4_t (&o)[NS], int S) {

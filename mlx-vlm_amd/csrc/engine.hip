@@ -14,7 +14,6 @@
 
 #include <stdlib.h>
 
-#include <mutex>
 #include <new>
 #include <vector>
 
@@ -40,7 +39,6 @@ struct DecodeGraph {
   hipGraphExec_t exec;
   int launches;
   unsigned long long last_use;
-  bool fused = false;                     // contains fused decode blocks (FusedOrder below)
 };
 constexpr size_t MAX_DECODE_GRAPHS = 16;
 
@@ -50,14 +48,12 @@ struct Tuning {
   int attn_pagesplit = 16;                // vlm_attn_decode_paged_split with up to this many workgroups per (row, kv head)
   int gemv_variant = 0;                   // A/B bits of the batch-1 GEMV launch shapes (VLM_TUNE_GEMV_VARIANT)
   int attn_merge = 1;                     // 1: one-row steps merge the page-split partials in the o_proj prologue
-  int fused_block = 1;                    // 1: attention + o_proj + gate/up of a one-row step as ONE launch (decode_block.hip)
 };
 
 struct Llm {
   Tuning tune;
   void* mfma_ws = nullptr;                // split-K partial tiles + tickets of the skinny-M decode GEMM (gemv_mfma.hip)
   unsigned* attn_tickets = nullptr;       // [4096] arrival words of the page-split decode attention (zero between launches)
-  void* blk_ws = nullptr;                 // epoch / flags / granules of the fused decode block (decode_block.hip), zeroed once
   // bf16 scratch of the prefill GEMMs over 4-bit weights: ONE buffer PER STREAM (an admission prefill on the side stream
   // and a generate_step prefill on the main stream of the same quantized model must not share dequantised weights),
   // each sized once for the largest matrix of the model - never grown, never freed while the engine lives
@@ -69,8 +65,6 @@ struct Llm {
   vlm_kv_pool kv{};
   std::vector<DecodeGraph> graphs;
   hipGraphExec_t exec = nullptr;      // the graph selected by the last vlm_llm_decode_graph_build
-  bool exec_fused = false;            // ... contains fused decode blocks
-  bool step_fused = false;            // the last decode_impl enqueued fused decode blocks
   unsigned long long tick = 0;
   int launches = 0;
 };
@@ -102,44 +96,6 @@ inline void drop_graph(DecodeGraph& g) {
   if (g.graph) (void)hipGraphDestroy(g.graph);
 }
 
-// A fused decode block (decode_block.hip) is a grid of 256 workgroups that wait on each other, one per CU: two such grids
-// dispatched at the same moment from different streams could each get half of the CUs and wait forever (their waits are
-// bounded: an error count, not a hang - but the step is lost).  Steps that contain fused blocks are therefore ordered across
-// the streams of the process: a step enqueued on another stream than the previous one first waits for that one's event.
-// (Other processes on the same GPU are not covered: one process per GPU is the deployment this library is built for.)
-struct FusedOrder {
-  std::mutex mu;
-  hipEvent_t ev = nullptr;
-  hipStream_t last = nullptr;
-  bool multi = false;                     // a second stream has appeared: from then on every fused step records the event
-  bool pending = false;
-  void before(hipStream_t st) {
-    std::lock_guard<std::mutex> lk(mu);
-    if (!multi) {
-      // ONE stream so far (the single-stream generate loop): no event traffic between its graph replays at all
-      if (last == nullptr || st == last) return;
-      (void)hipDeviceSynchronize();       // once per process: everything the first stream enqueued has finished
-      multi = true;
-      return;
-    }
-    if (pending && st != last) (void)hipStreamWaitEvent(st, ev, 0);
-  }
-  void after(hipStream_t st) {
-    std::lock_guard<std::mutex> lk(mu);
-    last = st;
-    if (!multi) return;
-    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ev = nullptr; (void)hipGetLastError(); return; }
-    if (hipEventRecord(ev, st) == hipSuccess) pending = true; else (void)hipGetLastError();
-  }
-};
-FusedOrder g_fused_order;
-
-inline bool capturing(hipStream_t st) {
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
-  return cs != hipStreamCaptureStatusNone;
-}
-
 struct Vit {
   vlm_vit_config cfg;
   std::vector<vlm_vit_block> blocks;
@@ -150,7 +106,7 @@ inline char* off(void* p, size_t bytes) { return static_cast<char*>(p) + bytes; 
 
 }  // namespace
 
-extern "C" int vlm_abi_version(void) { return 6; }
+extern "C" int vlm_abi_version(void) { return 5; }
 
 // ------------------------------------------------------------------ LLM
 extern "C" int vlm_llm_create(const vlm_llm_config* cfg, void** handle) {
@@ -176,15 +132,6 @@ extern "C" int vlm_llm_create(const vlm_llm_config* cfg, void** handle) {
   } else if (hipMemset(m->attn_tickets, 0, 4096 * sizeof(unsigned)) != hipSuccess) {
     return 1013;
   }
-  if (hipMalloc(&m->blk_ws, vlm_decode_block_ws_bytes()) != hipSuccess) {
-    m->blk_ws = nullptr;                  // (no device: the fused block is then not taken)
-    (void)hipGetLastError();
-  } else if (hipMemset(m->blk_ws, 0, vlm_decode_block_ws_bytes()) != hipSuccess) {
-    return 1014;
-  } else {
-    // (the residency query behind this answer runs once per process: here, not inside a stream capture)
-    (void)vlm_decode_block_supported(12, 2, 128, 8960, 16);
-  }
   *handle = m;
   return 0;
 }
@@ -196,7 +143,6 @@ extern "C" int vlm_llm_destroy(void* handle) {
   for (auto& ws : m->wscratch) (void)hipFree(ws.p);
   if (m->mfma_ws) (void)hipFree(m->mfma_ws);
   if (m->attn_tickets) (void)hipFree(m->attn_tickets);
-  if (m->blk_ws) (void)hipFree(m->blk_ws);
   delete m;
   return 0;
 }
@@ -210,7 +156,6 @@ extern "C" int vlm_llm_set_tuning(void* handle, int key, int value) {
     case VLM_TUNE_ATTN_PAGESPLIT: if (value < 0 || value > 32) return 1; slot = &m->tune.attn_pagesplit; break;
     case VLM_TUNE_GEMV_VARIANT: if (value < 0) return 1; slot = &m->tune.gemv_variant; break;
     case VLM_TUNE_ATTN_MERGE: if (value < 0 || value > 1) return 1; slot = &m->tune.attn_merge; break;
-    case VLM_TUNE_FUSED_BLOCK: if (value < 0 || value > 1) return 1; slot = &m->tune.fused_block; break;
     default: return 1;
   }
   if (key == VLM_TUNE_GEMV_VARIANT) vlm_gemv_set_variant(value);
@@ -222,15 +167,6 @@ extern "C" int vlm_llm_set_tuning(void* handle, int key, int value) {
   return 0;
 }
 
-extern "C" int vlm_llm_fused_errors(void* handle) {
-  Llm* m = static_cast<Llm*>(handle);
-  if (!m) return -1;
-  if (!m->blk_ws) return 0;
-  unsigned e = 0;
-  if (vlm_decode_block_debug(m->blk_ws, &e, nullptr) != 0) return -1;
-  return (int)e;
-}
-
 extern "C" int vlm_llm_get_tuning(void* handle, int key) {
   Llm* m = static_cast<Llm*>(handle);
   if (!m) return -1;
@@ -239,7 +175,6 @@ extern "C" int vlm_llm_get_tuning(void* handle, int key) {
     case VLM_TUNE_ATTN_PAGESPLIT: return m->tune.attn_pagesplit;
     case VLM_TUNE_GEMV_VARIANT: return m->tune.gemv_variant;
     case VLM_TUNE_ATTN_MERGE: return m->tune.attn_merge;
-    case VLM_TUNE_FUSED_BLOCK: return m->tune.fused_block;
     default: return -1;
   }
 }
@@ -369,7 +304,6 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
   if (wide && (!m->kv.block_table || Hq * hd < D || B > 64)) return 1;
   void* const xn = a->attn;
   int n = 0;
-  m->step_fused = false;
   // h = embed[tok]
   if (!fused_tail) {
     if (m->g.embed_sb) { TRY(vlm_dequant_w4(m->g.embed, m->g.embed_sb, a->tok, a->h, B, D, D, c.vocab, stream)); }
@@ -382,7 +316,23 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
     const vlm_llm_layer& w = m->layers[i];
     void* kp = off(m->kv.kpool, (size_t)i * m->kv.layer_stride * 2);
     void* vp = off(m->kv.vpool, (size_t)i * m->kv.layer_stride * 2);
-    // ---- the layer's attention policy (decided before the first launch: the fused block changes the qkv launch too)
+    // [RMSNorm + qkv GEMV + bias + M-RoPE at pos[b] + k/v write at slot ctx[b]] in one launch
+    if (wide) {
+      TRY(vlm_rmsnorm_residual(a->h, nullptr, w.ln1_w, xn, nullptr, B, D, c.rms_eps, stream));
+      TRY(lin_gemm(m, xn, w.wqkv, w.wqkv_sb, w.bqkv, nullptr, a->qkv, B, QKV, D, QKV, 0, VLM_EPI_BIAS, stream));
+      TRY(vlm_mrope_kvwrite_decode(a->qkv, QKV, B, Hq, Hkv, hd, a->pos, m->g.inv_freq, c.mrope_sec0, c.mrope_sec1, a->ctx,
+                                   m->kv.block_table, m->kv.max_pages, kp, vp, qk_scale, c.rope_long_from, stream));
+      n += 3;
+    } else if (w.wqkv_sb) {
+      TRY(vlm_gemv_w4_qkv_rope_kvwrite_ex(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.wqkv_sb, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos,
+                                          a->ctx, m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, m->tune.mfma_gemv,
+                                          m->mfma_ws, qk_scale, c.rope_long_from, stream)); ++n;
+    } else {
+      TRY(vlm_gemv_qkv_rope_kvwrite_ex(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos, a->ctx,
+                                       m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, m->tune.mfma_gemv, m->mfma_ws,
+                                       qk_scale, c.rope_long_from, stream)); ++n;
+    }
+    // attention over the pages (the new token is already in the cache: kv_len = ctx + 1)
     // combine: the split partials are merged by the attention side (combine kernel / last arriver) into a->attn - 4-bit Wo,
     // bf16 Wo wider than the row-wave GEMV's prologue, and EVERY wide step (its o_proj is a GEMM over a->attn)
     const bool combine = wide || w.wo_sb != nullptr || Hq * hd > 3584;
@@ -407,36 +357,6 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
     // ... and for ONE row over bf16 Wo the merge moves into the o_proj prologue: the attention launch ends at its partial
     // stores (no ticket, no last-arriver pass)
     const bool merge_in_oproj = psplit && tn.attn_merge && B == 1 && !w.wo_sb && Hq * hd <= 2048 && psplit <= 16;
-    // ONE launch for [attention] [merge + o_proj + residual] [RMSNorm + gate/up + SwiGLU] (decode_block.hip): one-row steps
-    // over bf16 weights where the merge would otherwise sit in the o_proj prologue, at the widths the block is built for
-    const bool fused = tn.fused_block && merge_in_oproj && !q8 && m->blk_ws && D == Hq * hd && !w.wqkv_sb && !w.wgu_sb &&
-                       vlm_decode_block_supported(Hq, Hkv, hd, c.inter, psplit) == 1;
-    // [RMSNorm + qkv GEMV + bias + M-RoPE at pos[b] + k/v write at slot ctx[b]] in one launch
-    if (wide) {
-      TRY(vlm_rmsnorm_residual(a->h, nullptr, w.ln1_w, xn, nullptr, B, D, c.rms_eps, stream));
-      TRY(lin_gemm(m, xn, w.wqkv, w.wqkv_sb, w.bqkv, nullptr, a->qkv, B, QKV, D, QKV, 0, VLM_EPI_BIAS, stream));
-      TRY(vlm_mrope_kvwrite_decode(a->qkv, QKV, B, Hq, Hkv, hd, a->pos, m->g.inv_freq, c.mrope_sec0, c.mrope_sec1, a->ctx,
-                                   m->kv.block_table, m->kv.max_pages, kp, vp, qk_scale, c.rope_long_from, stream));
-      n += 3;
-    } else if (w.wqkv_sb) {
-      TRY(vlm_gemv_w4_qkv_rope_kvwrite_ex(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.wqkv_sb, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos,
-                                          a->ctx, m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, m->tune.mfma_gemv,
-                                          m->mfma_ws, qk_scale, c.rope_long_from, stream)); ++n;
-    } else {
-      // (fused: this launch also advances the epoch word the fused block tags its hand-offs with)
-      TRY(vlm_gemv_qkv_rope_kvwrite_ex(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos, a->ctx,
-                                       m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, m->tune.mfma_gemv, m->mfma_ws,
-                                       qk_scale, c.rope_long_from, fused ? m->blk_ws : nullptr, stream)); ++n;
-    }
-    // attention over the pages (the new token is already in the cache: kv_len = ctx + 1)
-    if (fused) {
-      TRY(vlm_decode_block_bf16(a->qkv, QKV, kp, vp, m->kv.block_table, m->kv.max_pages, a->ctx, 1, Hq, Hkv, hd, scale, psplit,
-                                a->part_o, a->part_ml, w.wo, a->h, w.ln2_w, c.rms_eps, w.wgu, c.inter, a->act, m->blk_ws, 0,
-                                stream)); ++n;
-      m->step_fused = true;
-      TRY(lin_gemv(m, a->act, w.wdown, w.wdown_sb, nullptr, a->h, nullptr, a->h, B, D, c.inter, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
-      continue;
-    }
     if (q8) {
       const size_t lo = (size_t)i * m->kv.layer_stride;                   // elements == bytes of the u8 pools
       TRY(vlm_attn_decode_paged_q8(a->qkv, QKV, kp, vp, off(m->kv.kpool8, lo), off(m->kv.vpool8, lo),
@@ -507,20 +427,10 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
   return 0;
 }
 
-// an eager step (not a capture of the caller's): ordered against the fused steps of other streams (FusedOrder)
-static int decode_eager(Llm* m, const vlm_decode_args* a, void* stream, int* launches, bool sample) {
-  const hipStream_t st = (hipStream_t)stream;
-  const bool may_fuse = m->tune.fused_block && a->B == 1 && m->blk_ws && !capturing(st);
-  if (may_fuse) g_fused_order.before(st);
-  const int rc = decode_impl(m, a, stream, launches, sample);
-  if (may_fuse && m->step_fused) g_fused_order.after(st);
-  return rc;
-}
-
 extern "C" int vlm_llm_decode_step(void* handle, const vlm_decode_args* a, void* stream) {
   Llm* m = static_cast<Llm*>(handle);
   if (!m || !a || a->B <= 0 || !m->kv.kpool) return 1;
-  return decode_eager(m, a, stream, &m->launches, true);
+  return decode_impl(m, a, stream, &m->launches, true);
 }
 
 // embeddings -> logits only (the module-contract path: language_model(y, cache=...) at L == 1;
@@ -528,7 +438,7 @@ extern "C" int vlm_llm_decode_step(void* handle, const vlm_decode_args* a, void*
 extern "C" int vlm_llm_decode_forward(void* handle, const vlm_decode_args* a, void* stream) {
   Llm* m = static_cast<Llm*>(handle);
   if (!m || !a || a->B <= 0 || !m->kv.kpool) return 1;
-  return decode_eager(m, a, stream, nullptr, false);
+  return decode_impl(m, a, stream, nullptr, false);
 }
 
 extern "C" int vlm_llm_decode_graph_build(void* handle, const vlm_decode_args* a, void* stream) {
@@ -542,7 +452,6 @@ extern "C" int vlm_llm_decode_graph_build(void* handle, const vlm_decode_args* a
     if (same_key(g, *a, m->kv)) {
       g.last_use = ++m->tick;
       m->exec = g.exec;
-      m->exec_fused = g.fused;
       m->launches = g.launches;
       return 0;
     }
@@ -561,7 +470,6 @@ extern "C" int vlm_llm_decode_graph_build(void* handle, const vlm_decode_args* a
     (void)hipStreamDestroy(cap); return 1000 + (int)e;
   }
   int rc = decode_impl(m, a, (void*)cap, &ng.launches, true);
-  ng.fused = m->step_fused;
   e = hipStreamEndCapture(cap, &ng.graph);
   if (wide) vlm_gemm_splitk_unshare((void*)cap);
   (void)hipStreamDestroy(cap);
@@ -578,7 +486,6 @@ extern "C" int vlm_llm_decode_graph_build(void* handle, const vlm_decode_args* a
   }
   m->graphs.push_back(ng);
   m->exec = ng.exec;
-  m->exec_fused = ng.fused;
   m->launches = ng.launches;
   return 0;
 }
@@ -586,9 +493,7 @@ extern "C" int vlm_llm_decode_graph_build(void* handle, const vlm_decode_args* a
 extern "C" int vlm_llm_decode_graph_launch(void* handle, void* stream) {
   Llm* m = static_cast<Llm*>(handle);
   if (!m || !m->exec) return 1;
-  if (m->exec_fused) g_fused_order.before((hipStream_t)stream);
   hipError_t e = hipGraphLaunch(m->exec, (hipStream_t)stream);
-  if (m->exec_fused && e == hipSuccess) g_fused_order.after((hipStream_t)stream);
   return e == hipSuccess ? 0 : 1000 + (int)e;
 }
 

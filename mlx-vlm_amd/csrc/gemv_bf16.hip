@@ -46,8 +46,6 @@ struct RopeKvArgs {
   int long_from = 0;         // > 0: inv_freq holds [2][D/2] (short, long factors); the LONG row applies to every row of the step
                              // when ANY row's slot (= cache offset) >= long_from: SuScaledRoPE's per-call rule
                              // (rope_utils.py:168-172: position_end = max(offset) + tokens of the call > original_max)
-  unsigned* epoch = nullptr; // the fused decode block that FOLLOWS this launch (decode_block.hip) tags its hand-offs with this
-                             // word: ONE thread of this launch advances it (single writer; the kernel boundary publishes it)
 };
 
 struct AttnProArgs {
@@ -86,9 +84,6 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nchunk = K >> 3;
   const int gw = blockIdx.x * 4 + wave;
-  if (EPI == EPI_ROPE_KV) {
-    if (rk.epoch && blockIdx.x == 0 && tid == 0) *rk.epoch += 1u;
-  }
 
   // ---- which rows does this wave own?
   int row[R];
@@ -281,7 +276,7 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
       }
     }
   } else if (PRO == PRO_ATTN_BF16) {
-    // x[h*D + d] = sum_s f_s O_s[d] / sum_s f_s l_s,  f_s = 2^(m_s - M)   (attn_pagesplit.cuh: shared with decode_block.hip)
+    // x[h*D + d] = sum_s f_s O_s[d] / sum_s f_s l_s,  f_s = 2^(m_s - M)   (attn_pagesplit.cuh)
     const uint4 o = vlm_merge_splits16(a2_ml, a2_o, ap.S);
     if (tid < nchunk) reinterpret_cast<uint4*>(smem)[tid] = o;
   } else if (PRO == PRO_ATTN) {
@@ -602,7 +597,7 @@ extern "C" int vlm_gemv_qkv_rope_kvwrite_ws(const void* h, const void* norm_w, f
                                             const void* slot, const void* inv_freq, const void* block_table, int max_pages,
                                             void* kpool, void* vpool, void* workspace, void* stream) {
   return vlm_gemv_qkv_rope_kvwrite_ex(h, norm_w, eps, Wqkv, bqkv, qkv, ldq, M, hidden, Hq, Hkv, D, pos, slot, inv_freq, block_table,
-                                      max_pages, kpool, vpool, 1, workspace, 1.f, 0, nullptr, stream);
+                                      max_pages, kpool, vpool, 1, workspace, 1.f, 0, stream);
 }
 
 // mfma: 0 = v_dot2c kernels only; ws: the engine's workspace for vlm_gemv_mfma_try (nullptr: no K split over workgroups)
@@ -654,14 +649,14 @@ extern "C" int vlm_gemv_qkv_rope_kvwrite(const void* h, const void* norm_w, floa
                                          const void* block_table, int max_pages, void* kpool, void* vpool,
                                          void* stream) {
   return vlm_gemv_qkv_rope_kvwrite_ex(h, norm_w, eps, Wqkv, bqkv, qkv, ldq, M, hidden, Hq, Hkv, D, pos, slot, inv_freq, block_table,
-                                      max_pages, kpool, vpool, 1, nullptr, 1.f, 0, nullptr, stream);
+                                      max_pages, kpool, vpool, 1, nullptr, 1.f, 0, stream);
 }
 
 VLM_INTERNAL int vlm_gemv_qkv_rope_kvwrite_ex(const void* h, const void* norm_w, float eps, const void* Wqkv,
                                               const void* bqkv, void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D,
                                               const void* pos, const void* slot, const void* inv_freq,
                                               const void* block_table, int max_pages, void* kpool, void* vpool, int mfma,
-                                              void* ws, float qk_scale, int long_from, void* epoch, void* stream) {
+                                              void* ws, float qk_scale, int long_from, void* stream) {
   if (!h || !norm_w || !Wqkv || !bqkv || !qkv || !pos || !slot || !inv_freq || !kpool || !vpool || max_pages <= 0)
     return VLM_ERR_ARG;
   const int N = (Hq + 2 * Hkv) * D;
@@ -675,7 +670,7 @@ VLM_INTERNAL int vlm_gemv_qkv_rope_kvwrite_ex(const void* h, const void* norm_w,
   if (hidden % 8 || D % 16 || hidden > 4096 || (size_t)M * hidden * 2 > 64 * 1024) return VLM_ERR_SHAPE;
   Args a{h, Wqkv, bqkv, nullptr, norm_w, qkv, N, hidden, hidden, hidden, ldq, 0, eps,
          RopeKvArgs{(const int*)pos, (const int*)slot, (const float*)inv_freq, (const int*)block_table, max_pages, Hq, Hkv,
-                    D, (bf16_t*)kpool, (bf16_t*)vpool, qk_scale, long_from, (unsigned*)epoch},
+                    D, (bf16_t*)kpool, (bf16_t*)vpool, qk_scale, long_from},
          AttnProArgs{}, (hipStream_t)stream};
   return launch_rw_m<PRO_RMSNORM, EPI_ROPE_KV>(M, a);
 }

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemv_mfma2_kernel(const Mfma2Args 
   };
 
   ST2(1);
-  int st_k = 0;
+  [[maybe_unused]] int st_k = 0;     // (phase-stamp index of the -DMFMA2_STAMPS probe build)
   auto unit = [&](int u, u32x4_t (&wv)[NCH][NJ], unsigned (&sbv)[NCH]) __attribute__((always_inline)) {
     const int un = u + NSETS * G;         // the unit this set is refilled for
     const bool more = un < n_units;

@@ -53,7 +53,7 @@ VLM_INTERNAL int vlm_gemv_qkv_rope_kvwrite_ex(const void* h, const void* norm_w,
                                               void* qkv, int ldq, int M, int hidden, int Hq, int Hkv, int D, const void* pos,
                                               const void* slot, const void* inv_freq, const void* block_table, int max_pages,
                                               void* kpool, void* vpool, int mfma, void* ws, float qk_scale, int long_from,
-                                              void* epoch, void* stream);   // epoch: see decode_block.hip (nullptr: none)
+                                              void* stream);
 VLM_INTERNAL int vlm_gemv_w4_ex(const void* x, const void* Wq, const void* Wsb, const void* bias, const void* res, const void* norm_w,
                                 void* y, int M, int N, int K, int ldx, int ldy, int ldres, float eps, int epilogue, int mfma, void* ws,
                                 void* stream);

@@ -319,8 +319,7 @@ class LanguageModel:
 
     # decode-step tuning (results are identical under every setting up to bf16 ties; defaults from the measurements in
     # DESIGN.md, environment overrides VLM_DECODE_<NAME> for A/B runs)
-    TUNING_DEFAULTS = {"fused_tail": 1, "mfma_gemv": 1, "attn_pagesplit": 16, "gemv_variant": 1, "attn_merge": 1,
-                       "fused_block": 1}
+    TUNING_DEFAULTS = {"fused_tail": 1, "mfma_gemv": 1, "attn_pagesplit": 16, "gemv_variant": 1, "attn_merge": 1}
 
     def apply_tuning(self, **over):
         L = _lib.lib()
@@ -332,8 +331,7 @@ class LanguageModel:
         t.update(over)
         self.tuning = t
         for key, name in ((_lib.TUNE_MFMA_GEMV, "mfma_gemv"), (_lib.TUNE_ATTN_PAGESPLIT, "attn_pagesplit"),
-                          (_lib.TUNE_GEMV_VARIANT, "gemv_variant"), (_lib.TUNE_ATTN_MERGE, "attn_merge"),
-                          (_lib.TUNE_FUSED_BLOCK, "fused_block")):
+                          (_lib.TUNE_GEMV_VARIANT, "gemv_variant"), (_lib.TUNE_ATTN_MERGE, "attn_merge")):
             check(L.vlm_llm_set_tuning(self._handle, key, int(t[name])), "llm_set_tuning")
         for st in getattr(self, "_decode_states", {}).values():
             st.graph_key = None          # the engine dropped its captured steps

@@ -257,41 +257,6 @@ def attn_decode_paged_split(q, kpool, vpool, block_table, kv_len, kv_len_add, Hq
     return out
 
 
-def decode_block_supported(Hq, Hkv, D, inter, nsplit) -> bool:
-    """whether the fused decode block (csrc/decode_block.hip) takes this shape on this device"""
-    return _lib.lib().vlm_decode_block_supported(Hq, Hkv, D, inter, nsplit) == 1
-
-
-def decode_block_(q, kpool, vpool, block_table, kv_len, kv_len_add, Hq, Hkv, D, scale, nsplit, wo, h, ln2_w, eps, wgu, act,
-                  ws=None, max_pages=None, stamps=False, part=None):
-    """ONE launch for a decode row: page-split attention over the pools -> split merge -> h += attn @ wo.T (in place) ->
-    act = swiglu(rmsnorm(h, ln2_w) @ wgu.T).  Bit-identical to attn_decode_paged_split(merge=False) + gemv_attn_out_bf16_
-    + gemv_bf16(norm_w, SWIGLU).  Returns (h, act, ws); ws carries the launch epoch between calls (zeroed on first use)."""
-    _dev(q, kpool, vpool, block_table, kv_len, wo, h, ln2_w, wgu, act)
-    L = _lib.lib()
-    if ws is None:
-        ws = torch.zeros(L.vlm_decode_block_ws_bytes(), dtype=torch.uint8, device=q.device)
-    if part is not None:
-        part_o, part_ml = part
-    else:
-        part_o = torch.full((1, Hq, nsplit, D), float("nan"), dtype=torch.bfloat16, device=q.device)
-        part_ml = torch.empty(1, Hq, nsplit, 2, dtype=torch.float32, device=q.device)
-    check(L.vlm_decode_block_bf16(_p(q), q.stride(0), _p(kpool), _p(vpool), _p(block_table),
-                                  block_table.shape[1] if block_table is not None else int(max_pages), _p(kv_len), kv_len_add,
-                                  Hq, Hkv, D, scale, nsplit, _p(part_o), _p(part_ml), _p(wo), _p(h), _p(ln2_w), eps, _p(wgu),
-                                  wgu.shape[0] // 2, _p(act), _p(ws), 3 if stamps else 1, _stream()), "decode_block")
-    return h, act, ws
-
-
-def decode_block_debug(ws):
-    """-> (hand-offs that gave up, the 16 debug stamps in wall-clock ticks of 10 ns)"""
-    import ctypes as C
-    err = C.c_uint(0)
-    st = (C.c_ulonglong * 16)()
-    check(_lib.lib().vlm_decode_block_debug(_p(ws), C.byref(err), st), "decode_block_debug")
-    return int(err.value), list(st)
-
-
 class EncoderLayers:
     """The weights of a SigLIP / CLIP encoder stack as the native layer loop takes them (vlm_enc_layer array, built once at
     load from a tower's `_w` dict: keys "<i>.ln1w", "<i>.ln1b", "<i>.wqkv", "<i>.bqkv", "<i>.wo", "<i>.bo", "<i>.ln2w",

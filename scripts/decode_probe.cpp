@@ -5,7 +5,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 scripts/decode_probe.cpp -Iinclude -Lmlx-vlm_amd/lib -lvlm_hip \
 //         -Wl,-rpath,'$ORIGIN/../mlx-vlm_amd/lib' -o scripts/bin/decode_probe
-//   scripts/bin/decode_probe [--steps 300] [--ctx 450] [--variant flags,psplit,gv,am,fused_block ...] [--micro] [--no-hot]
+//   scripts/bin/decode_probe [--steps 300] [--ctx 450] [--variant flags,psplit,gv,am ...] [--micro] [--no-hot]
 //
 // Every variant restarts from the same device state and must reproduce the baseline's tokens bit for bit
 // (prefetch and the fused tail change scheduling only).
@@ -202,10 +202,10 @@ static void reset_state(const Model& m, State& s, int ctx0, hipStream_t st) {
 }
 
 struct Variant {
-  int flags = 1, psplit = 16, gv = 1, am = 1, fb = 1;     // fused greedy tail, page-split width, GEMV variant bits, merge in o_proj, fused block
+  int flags = 1, psplit = 16, gv = 1, am = 1;     // fused greedy tail, page-split width, GEMV variant bits, merge in o_proj
   std::string name() const {
     char b[160];
-    snprintf(b, sizeof b, "flags=%d psplit=%d gv=%d am=%d fused_block=%d", flags, psplit, gv, am, fb);
+    snprintf(b, sizeof b, "flags=%d psplit=%d gv=%d am=%d", flags, psplit, gv, am);
     return b;
   }
 };
@@ -216,7 +216,6 @@ static double run_variant(const Model& m, State& s, const Variant& v, int ctx0, 
   RC(vlm_llm_set_tuning(m.h, VLM_TUNE_ATTN_PAGESPLIT, v.psplit));
   RC(vlm_llm_set_tuning(m.h, VLM_TUNE_GEMV_VARIANT, v.gv));
   RC(vlm_llm_set_tuning(m.h, VLM_TUNE_ATTN_MERGE, v.am));
-  RC(vlm_llm_set_tuning(m.h, VLM_TUNE_FUSED_BLOCK, v.fb));
   s.a.flags = v.flags;
   RC(vlm_llm_set_kv(m.h, &m.kv));
   reset_state(m, s, ctx0, st);
@@ -313,16 +312,17 @@ int main(int argc, char** argv) {
     else if (a == "--block-table") use_table = true;
     else if (a == "--variant" && i + 1 < argc) {
       Variant v;
-      sscanf(argv[++i], "%d,%d,%i,%d,%d", &v.flags, &v.psplit, &v.gv, &v.am, &v.fb);
+      sscanf(argv[++i], "%d,%d,%i,%d", &v.flags, &v.psplit, &v.gv, &v.am);
       variants.push_back(v);
     }
   }
   if (variants.empty()) {
     variants = {
-        {1, 16, 1, 1, 0},   // five launches per layer
-        {1, 16, 1, 1, 1},   // fused decode block: three launches per layer
-        {1, 16, 1, 1, 0},
-        {1, 16, 1, 1, 1},
+        {1, 16, 1, 1},   // the product's step
+        {0, 16, 1, 1},   // without the fused greedy tail
+        {1, 16, 0, 1},   // down projection at 4 rows per workgroup
+        {1, 16, 1, 0},   // merge by the attention launch's last arriver
+        {1, 16, 1, 1},
     };
   }
   hipStream_t st;
@@ -350,8 +350,6 @@ int main(int argc, char** argv) {
     int first_diff = -1;
     for (size_t i = 0; i < toks.size() && i < base_toks.size(); ++i)
       if (toks[i] != base_toks[i]) { first_diff = (int)i; break; }
-    const int ferr = vlm_llm_fused_errors(m.h);
-    if (ferr) printf("   FUSED HAND-OFF GAVE UP: %d\n", ferr);
     if (!same) printf("   first differing token at step %d of %zu\n", first_diff, toks.size());
     const double bytes = lm_bytes + 28672.0 * (ctx0 + steps / 2);
     if (getenv("VLM_ATTN_STAMPS")) {   // timeline of the LAST attention launch (library built with -DVLM_ATTN_TIMELINE)
@@ -381,7 +379,7 @@ int main(int argc, char** argv) {
     m2.g = m1.g;
     RC(vlm_llm_set_globals(m2.h, &m2.g));
     State s1 = make_state(dev, d1, B);
-    Variant v0{1, 16, 1, 1, 0};
+    Variant v0{1, 16, 1, 1};
     const double t1 = run_variant(m1, s1, v0, ctx0, warm, steps, nullptr, st);
     const double t2 = run_variant(m2, s1, v0, ctx0, warm, steps, nullptr, st);
     printf("\n== cache-resident bound: 1 layer %.1f us/step, 2 layers %.1f us/step -> one on-die layer %.1f us (HBM-cold: see baseline / 28)\n",
