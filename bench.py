@@ -910,7 +910,9 @@ def other_configs(args, rank, ws, dev, t_start, budget_s=420.0):
             block[name] = {"skipped": f"wall-clock budget of the default line ({budget_s:.0f} s) reached"}
             continue
         a = copy.copy(args)
-        a.steps, a.warmup, a.no_extras, a.no_cpu_baseline, a.max_tokens, a.kv_bits = 1, 1, True, True, 0, 0
+        # (3 timed passes after 2 warm ones: one pass right after the previous config's teardown read 20 % low - Phi-3.5 3383 vs
+        #  4182 tok/s for the workload on its own, gpurun sessions 10 / 11 of round 4 - allocator and clock warm-up inside the sample)
+        a.steps, a.warmup, a.no_extras, a.no_cpu_baseline, a.max_tokens, a.kv_bits = 3, 2, True, True, 0, 0
         for k, v in over.items():
             setattr(a, k, v)
         t0 = time.perf_counter()
