@@ -626,6 +626,14 @@ static int mfma_try(const void* x, const void* W, const void* Wsb, const void* b
     return -1;
   if (norm_w && (epilogue & VLM_EPI_RESIDUAL)) return -1;
   if ((epilogue & VLM_EPI_SWIGLU) && (N % 16)) return -1;
+#ifndef VLM_MFMA_W4_TU
+  if (!Wsb && !norm_w && !rope) {
+    // few row tiles x long K (the down projections): one workgroup per tile, K split over its 16 waves, no cross-workgroup
+    // hand-off (gemv_mfma_longk.hip)
+    const int rc3 = vlm_gemv_mfma_longk_try(x, W, bias, res, y, M, N, K, ldx, ldw, ldy, ldres, epilogue, stream);
+    if (rc3 != -1) return rc3;
+  }
+#endif
   {
     // the second form first (gemv_mfma2.hip: activations in registers, two workgroups per CU); VLM_GEMV_MFMA2=0: A/B knob
     static const bool v2 = [] { const char* e = getenv("VLM_GEMV_MFMA2"); return !e || atoi(e) != 0; }();

@@ -45,6 +45,9 @@ VLM_INTERNAL int vlm_gemv_mfma2_try_bf16(const void* x, const void* W, const voi
 VLM_INTERNAL int vlm_gemv_mfma2_try_w4(const void* x, const void* W, const void* Wsb, const void* bias, const void* res,
                                        const void* norm_w, void* y, int M, int N, int K, int ldx, int ldw, int ldy, int ldres,
                                        float eps, int epilogue, const VlmRopeKv* rk, void* ws, void* stream);
+// long-K form (csrc/gemv_mfma_longk.hip): bf16, no norm prologue, few row tiles; -1: shape not handled
+VLM_INTERNAL int vlm_gemv_mfma_longk_try(const void* x, const void* W, const void* bias, const void* res, void* y, int M, int N,
+                                         int K, int ldx, int ldw, int ldy, int ldres, int epilogue, void* stream);
 VLM_INTERNAL void vlm_gemv_set_variant(int bits);   // A/B bits of the batch-1 launch shapes (process-wide; VLM_TUNE_GEMV_VARIANT)
 VLM_INTERNAL int vlm_gemv_bf16_ex(const void* x, const void* W, const void* bias, const void* res, const void* norm_w, void* y,
                                   int M, int N, int K, int ldx, int ldw, int ldy, int ldres, float eps, int epilogue, int mfma,
