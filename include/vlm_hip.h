@@ -225,7 +225,9 @@ int vlm_attn_decode_paged_split(const void* q, int ldq, const void* kpool, const
  * vlm_attn_decode_paged_q8: the page-split decode attention (vlm_attn_decode_paged_split: same nsplit / part_o / part_ml /
  *   tickets / out conventions, out == NULL = partial-only form) over the 8-bit pools; quantize_new != 0: the step's new
  *   token (slot kv_len - 1, already written to the bf16 pools by the qkv epilogue) is quantised first -
- *   QuantizedKVCache.update_and_fetch - by the workgroup that owns its page. */
+ *   QuantizedKVCache.update_and_fetch - by the workgroup that owns its page.  In the merging form (out != NULL) a step of
+ *   128 or more (row, kv head) pairs with nsplit <= 16 runs half-page units: part_o / part_ml must then hold 2 * nsplit
+ *   splits per (row, head). */
 int vlm_kv_quantize_tokens(const void* kpool, const void* vpool, void* kpool8, void* vpool8, void* ksb, void* vsb,
                            size_t layer_stride, int n_layers, const void* kv_seq, const void* kv_slot, int T,
                            const void* block_table, int max_pages, int Hkv, int D, void* stream);

@@ -520,13 +520,20 @@ __device__ __forceinline__ unsigned pack_h2(float lo, float hi) {      // two fp
 // The workgroup whose page holds the step's new token (slot len - 1, written to the bf16 pools by the qkv epilogue)
 // quantises it first - QuantizedKVCache.update_and_fetch - and reads it back with the rest of the page (every page load
 // is non-temporal: served by L2, behind the workgroup's own drained stores).
-template <int G, bool IDENT, bool MERGE>
+// HP ("half pages", the form for many (row, kv head) pairs): a workgroup takes 32 keys of a page instead of 64 - split index
+// s' = 2 s + hh covers keys 32 s' .. 32 s' + 31 of every S-th page, so the active splits are exactly s' < ceil(len / 32) and
+// the hand-off / merge below runs unchanged over 2 S splits - with half the operand registers (145 instead of 209 VGPRs:
+// three waves per SIMD instead of two; the 64-key form of a 512-pair step ran at 3.4 TB/s, latency-bound per wave:
+// profiles/r04_phi35v_kv8_kernel_stats.txt).
+template <int G, bool IDENT, bool MERGE, bool HP>
 __global__ __launch_bounds__(64) void attn_decode_pagesplit_q8_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ kpool16, const bf16_t* __restrict__ vpool16, unsigned char* kpool8,
     unsigned char* vpool8, unsigned* ksb, unsigned* vsb, const int* __restrict__ block_table, const int* __restrict__ kv_len,
     int ldq, int max_pages, int Hkv, int kv_len_add, float scale, int S, int ldo, float* part_o, float* part_ml,
     unsigned* tickets, bf16_t* __restrict__ out, int quantize_new) {
-  const int bh = blockIdx.x, b = bh / Hkv, g = bh % Hkv, s = blockIdx.y;
+  const int bh = blockIdx.x, b = bh / Hkv, g = bh % Hkv, s2 = blockIdx.y, s = HP ? s2 >> 1 : s2, hh = HP ? s2 & 1 : 0;
+  constexpr int NT = HP ? 2 : 4, NU = HP ? 1 : 2;             // key tiles of 16 / 32-key steps per visit
+  const int t0 = NT * hh, u0 = hh;
   const int lane = threadIdx.x, head = lane & 15, gq = lane >> 4;
   const int len = kv_len[b] + kv_len_add, npages = (len + PAGE - 1) / PAGE;
   const int* trow = IDENT ? nullptr : block_table + (size_t)b * max_pages;
@@ -557,9 +564,10 @@ __global__ __launch_bounds__(64) void attn_decode_pagesplit_q8_kernel(
   float m_run = -INFINITY, l_run = 0.f, ob[2] = {0.f, 0.f};
   constexpr float LOG2E = 1.44269504088896340736f;
   for (int pc = s; pc < npages; pc += S) {
+    if (HP && pc * PAGE + 32 * hh >= len) break;          // the last page's second half may be empty
     const size_t page = IDENT ? (size_t)b * max_pages + pc : (size_t)trow[pc];
     const size_t ph = page * Hkv + g;
-    if (quantize_new && pc == (len - 1) / PAGE) {
+    if (quantize_new && pc == (len - 1) / PAGE && (!HP || hh == (((len - 1) & 63) >> 5))) {
       q8_quantize_token(kpool16, vpool16, kpool8, vpool8, ksb, vsb, ph, (len - 1) & 63, lane);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -567,31 +575,31 @@ __global__ __launch_bounds__(64) void attn_decode_pagesplit_q8_kernel(
     const unsigned char* vp = vpool8 + ph * (size_t)HD * PAGE + (size_t)head * PAGE + 8 * gq;
     const unsigned* ks = ksb + (ph * PAGE + 4 * gq) * 2;
     const unsigned* vs = vsb + (ph * PAGE + 4 * gq) * 2;
-    u32x2_t kf[4][4], vf[8][2];
-    u32x4_t kq[4][2], vq[4][2];           // (scale | bias) words of keys 16 t + 4 gq + r: [t][half]: r = 2 half, 2 half + 1 x 2 groups
+    u32x2_t kf[NT][4], vf[8][NU];
+    u32x4_t kq[NT][2], vq[NT][2];         // (scale | bias) words of keys 16 t + 4 gq + r: [t][half]: r = 2 half, 2 half + 1 x 2 groups
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
       for (int ds = 0; ds < 4; ++ds)
-        kf[t][ds] = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(kp + ((size_t)(4 * ds) * PAGE + 16 * t) * 8));
+        kf[tt][ds] = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(kp + ((size_t)(4 * ds) * PAGE + 16 * (t0 + tt)) * 8));
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        kq[t][hf] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(ks + (16 * t) * 2 + 4 * hf));
-        vq[t][hf] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vs + (16 * t) * 2 + 4 * hf));
+        kq[tt][hf] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(ks + (16 * (t0 + tt)) * 2 + 4 * hf));
+        vq[tt][hf] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vs + (16 * (t0 + tt)) * 2 + 4 * hf));
       }
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-        vf[dt][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(vp + (size_t)(16 * dt) * PAGE + 32 * u));
+      for (int uu = 0; uu < NU; ++uu)
+        vf[dt][uu] = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(vp + (size_t)(16 * dt) * PAGE + 32 * (u0 + uu)));
     __builtin_amdgcn_sched_barrier(0);
     // ---- S^T: per key tile two group accumulators, then the affine form per (key, group)
-    float sc[4][4];
+    float sc[NT][4];
     float mt = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NT; ++t) {
       f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
       a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(q8_frag(kf[t][0]), qf[0], a0, 0, 0, 0);
       a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(q8_frag(kf[t][1]), qf[1], a0, 0, 0, 0);
@@ -601,7 +609,7 @@ __global__ __launch_bounds__(64) void attn_decode_pagesplit_q8_kernel(
       for (int r = 0; r < 4; ++r) {
         const u32x4_t w4 = kq[t][r >> 1];
         const unsigned w0 = (r & 1) ? w4[2] : w4[0], w1 = (r & 1) ? w4[3] : w4[1];     // groups 0 / 1 of key 16 t + 4 gq + r
-        const int key = pc * PAGE + 16 * t + 4 * gq + r;
+        const int key = pc * PAGE + 16 * (t0 + t) + 4 * gq + r;
         // quantized_matmul: fp32 sum over the dequantised keys, one rounding to the query dtype
         // (a_j = q . (1024 + n): the constant leaves through the bias factor)
         const float sv = rbf(bf_lo(w0) * a0[r] + (bf_hi(w0) - 1024.f * bf_lo(w0)) * sq[0] +
@@ -614,13 +622,13 @@ __global__ __launch_bounds__(64) void attn_decode_pagesplit_q8_kernel(
     const float m_new = fmaxf(m_run, mt);
     const float alpha = exp2f(m_run - m_new);      // (every page processed holds a valid key: m_new is finite)
     float ls = 0.f, pbias[2] = {0.f, 0.f};
-    u32x4_t pk[2][2];                              // P'^T fragments [group][u]
+    u32x4_t pk[2][NU];                             // P'^T fragments [group][u]
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NT; ++t) {
       float pp[2][4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = pc * PAGE + 16 * t + 4 * gq + r;
+        const int key = pc * PAGE + 16 * (t0 + t) + 4 * gq + r;
         const bool ok = key < len;
         const float pr = ok ? rbf(exp2f(sc[t][r] - m_new)) : 0.f;     // the probabilities are a bf16 tensor in the reference
         ls += pr;
@@ -647,7 +655,7 @@ __global__ __launch_bounds__(64) void attn_decode_pagesplit_q8_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < NU; ++u)
         ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(q8_frag(vf[dt][u]), __builtin_bit_cast(f16x8_t, pk[dt >> 2][u]), ot[dt], 0, 0, 0);
     }
   }
@@ -658,7 +666,9 @@ __global__ __launch_bounds__(64) void attn_decode_pagesplit_q8_kernel(
   for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) ot[dt][r] += ob[dt >> 2];
-  pagesplit_finish<G, MERGE>(ot, m_run, l_run, npages, bh, b, g, s, S, Hkv, lane, ldo, part_o, part_ml, tickets, out);
+  // (HP: 2 S splits of half pages; the active ones are s2 < ceil(len / 32))
+  pagesplit_finish<G, MERGE>(ot, m_run, l_run, HP ? (len + 31) / 32 : npages, bh, b, g, s2, HP ? 2 * S : S, Hkv, lane, ldo, part_o,
+                             part_ml, tickets, out);
 }
 
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ part_o,
@@ -802,7 +812,6 @@ extern "C" int vlm_attn_decode_paged_q8(const void* q, int ldq, const void* kpoo
   if ((size_t)B * Hq * nsplit * HD * 4 >= ((size_t)1 << 31)) return VLM_ERR_SHAPE;
   const int G = Hq / Hkv;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(B * Hkv, nsplit);
   // `queries *= scale` (base.py:272) with a python float: MLX converts the weak scalar to the ARRAY's dtype first, so the
   // typed multiply uses bf16(scale) (128 ** -0.5 -> 0.08837890625) - pinned by tests/golden/kvquant_ref.npz, where the
   // reference's own function runs; round-to-nearest-even on the host
@@ -812,12 +821,22 @@ extern "C" int vlm_attn_decode_paged_q8(const void* q, int ldq, const void* kpoo
     u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
     memcpy(&scale, &u, 4);
   }
-#define GO1(GV, ID, MG)                                                                                                  \
-  hipLaunchKernelGGL((attn_decode_pagesplit_q8_kernel<GV, ID, MG>), grid, dim3(64), 0, st, (const bf16_t*)q,              \
+  // half-page units once the (row, kv head) pairs alone give every SIMD its waves (Phi-3.5 at 16 rows: 512 pairs): the 64-key
+  // form holds 209 registers (2 waves per SIMD); VLM_ATTN_Q8_HALF = 0 / 1 forces (A/B)
+  static const int hp_env = [] { const char* e = getenv("VLM_ATTN_Q8_HALF"); return e ? atoi(e) : -1; }();
+  const bool hp = (hp_env >= 0 ? hp_env != 0 : B * Hkv >= 128) && nsplit <= 16 && out != nullptr;   // (merging form only)
+  dim3 grid_q8(B * Hkv, hp ? 2 * nsplit : nsplit);
+#define GO2(GV, ID, MG, HP)                                                                                              \
+  hipLaunchKernelGGL((attn_decode_pagesplit_q8_kernel<GV, ID, MG, HP>), grid_q8, dim3(64), 0, st, (const bf16_t*)q,       \
                      (const bf16_t*)kpool16, (const bf16_t*)vpool16, (unsigned char*)kpool8, (unsigned char*)vpool8,      \
                      (unsigned*)ksb, (unsigned*)vsb, (const int*)block_table, (const int*)kv_len, ldq, max_pages, Hkv,    \
                      kv_len_add, scale, nsplit, ldo, (float*)part_o, (float*)part_ml, (unsigned*)tickets, (bf16_t*)out,   \
                      quantize_new)
+#define GO1(GV, ID, MG)                  \
+  do {                                   \
+    if (hp) GO2(GV, ID, MG, true);       \
+    else GO2(GV, ID, MG, false);         \
+  } while (0)
 #define GO(GV)                                                                                                           \
   do {                                                                                                                   \
     if (!block_table) { if (out) GO1(GV, true, true); else GO1(GV, true, false); }                                       \
@@ -836,6 +855,7 @@ extern "C" int vlm_attn_decode_paged_q8(const void* q, int ldq, const void* kpoo
   }
 #undef GO
 #undef GO1
+#undef GO2
   VLM_CHECK_LAUNCH();
   return VLM_OK;
 }

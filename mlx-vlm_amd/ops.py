@@ -331,8 +331,9 @@ def attn_decode_paged_q8(q, kpool16, vpool16, kpool8, vpool8, ksb, vsb, block_ta
                                                   nsplit, _p(part_o), _p(part_ml), None, None, 0, int(bool(quantize_new)),
                                                   _stream()), "attn_decode_q8")
         return part_o, part_ml
-    part_o = torch.empty(B, Hq, nsplit, D, dtype=torch.float32, device=q.device)
-    part_ml = torch.empty(B, Hq, nsplit, 2, dtype=torch.float32, device=q.device)
+    # (2 * nsplit: from 128 (row, kv head) pairs the launch runs half-page units, i.e. twice the splits)
+    part_o = torch.empty(B, Hq, 2 * nsplit, D, dtype=torch.float32, device=q.device)
+    part_ml = torch.empty(B, Hq, 2 * nsplit, 2, dtype=torch.float32, device=q.device)
     if tickets is None:
         tickets = torch.zeros(B * Hkv, dtype=torch.int32, device=q.device)
     if out is None:
