@@ -337,7 +337,8 @@ DECODE_KERNELS = ("gemv_rowwave_kernel", "gemv_splitk_kernel", "attn_decode_mfma
                   "embed_gather_kernel", "decode_advance_kernel", "sample_filter_kernel", "logprob_argmax_tail_kernel")
 HEAD_KERNEL = "gemv_rowwave_kernel<4, 3, 1, 1, 0>"         # RMSNorm + lm_head GEMV: exactly one launch per decoded token
 GATE_UP_KERNEL = "gemv_rowwave_kernel<4, 3, 1, 1, 16>"     # name as rocprofv3 prints it (R=4 rows/wave, RMSNorm prologue, SwiGLU)
-DECODE_CSRC = ("gemv_bf16.hip", "attn_decode.hip", "sample.hip", "embed.hip", "engine.hip", "common.cuh", "internal.h")
+DECODE_CSRC = ("gemv_bf16.hip", "attn_decode.hip", "attn_pagesplit.cuh", "sample.hip", "embed.hip", "engine.hip", "common.cuh",
+               "internal.h")
 
 
 def decode_csrc_sha16():
@@ -352,7 +353,7 @@ def decode_csrc_sha16():
 
 
 def pmc_traffic():
-    """HBM bytes per launch from the committed --pmc passes (scripts/r03_final_prof.sh -> profiles/r03_pmc_traffic.json):
+    """HBM bytes per launch from the committed --pmc passes (scripts/r04_final.sh -> profiles/r04_pmc_traffic.json):
     (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of MI355X_MICROARCH.md.  bench.py cannot collect hardware
     counters itself (they need rocprofv3 around the process).  The file records the hash of the decode step's kernel sources
     it was taken on (`_meta.decode_csrc_sha16`, scripts/pmc_summary.py); a file without it or with another hash is STALE and
@@ -366,7 +367,7 @@ def pmc_traffic():
     sha = d.get("_meta", {}).get("decode_csrc_sha16")
     if sha != decode_csrc_sha16():
         return None, None, (f"{cands[0]} is stale: taken on decode sources {sha}, this tree is {decode_csrc_sha16()} "
-                            "(re-run scripts/r03_final_prof.sh)")
+                            "(re-run scripts/r04_final.sh)")
     gu = d.get(GATE_UP_KERNEL, {}).get("hbm_bytes_per_launch")
     steps = d.get(HEAD_KERNEL, {}).get("launches", 0) or d.get("decode_advance_kernel", {}).get("launches", 0)
     per_tok = None
