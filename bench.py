@@ -893,16 +893,16 @@ def other_configs(args, rank, ws, dev, t_start, budget_s=420.0):
     other BASELINE config on this GPU - value, roofline and, where it fits in ~40 s, the oracle's CPU tokens/s - each in a
     try / except and under a wall-clock budget so that an extra can never cost the headline.  The full lines (more steps,
     vision rooflines, batched extras) are `--workload <name>`."""
-    import copy
     import gc
+    import subprocess
 
     from mlx_vlm_amd.utils import cpu_quota
 
-    plan = [("configs[0] nanollava", workload_nanollava, "nanollava", {}),
-            ("configs[2] qwen2vl-7b-b32", workload_7b_b32, "qwen2vl-7b", {}),
-            ("configs[3] idefics2-b8", workload_idefics2_b8, "idefics2-8b", {}),
-            ("configs[4] phi35v-w4-b16", workload_phi35v_w4_b16, "phi35v-w4", {}),
-            ("configs[4] phi35v-w4-b16 kv_bits=8", workload_phi35v_w4_b16, None, {"kv_bits": 8})]
+    plan = [("configs[0] nanollava", "nanollava", "nanollava", {}),
+            ("configs[2] qwen2vl-7b-b32", "qwen2vl-7b-b32", "qwen2vl-7b", {}),
+            ("configs[3] idefics2-b8", "idefics2-b8", "idefics2-8b", {}),
+            ("configs[4] phi35v-w4-b16", "phi35v-w4-b16", "phi35v-w4", {}),
+            ("configs[4] phi35v-w4-b16 kv_bits=8", "phi35v-w4-b16", None, {"kv_bits": 8})]
     keep_keys = ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline", "decode_tokens_per_s",
                  "decode_us_per_token", "e2e_tokens_per_s", "images_per_s_prefill", "prompt_tps", "kv_bits")
     block = {}
@@ -910,15 +910,19 @@ def other_configs(args, rank, ws, dev, t_start, budget_s=420.0):
         if time.perf_counter() - t_start > budget_s:
             block[name] = {"skipped": f"wall-clock budget of the default line ({budget_s:.0f} s) reached"}
             continue
-        a = copy.copy(args)
-        # (3 timed passes after 2 warm ones: one pass right after the previous config's teardown read 20 % low - Phi-3.5 3383 vs
-        #  4182 tok/s for the workload on its own, gpurun sessions 10 / 11 of round 4 - allocator and clock warm-up inside the sample)
-        a.steps, a.warmup, a.no_extras, a.no_cpu_baseline, a.max_tokens, a.kv_bits = 3, 2, True, True, 0, 0
-        for k, v in over.items():
-            setattr(a, k, v)
+        # Each config runs as `bench.py --workload <name>` in a FRESH process (3 timed passes after 2 warm ones) and its JSON line
+        # is read back: inside this process - after the headline model, the extras, the previous configs and the oracle's CPU
+        # legs - the same workload read 17-20 % low (Phi-3.5: 3383-3491 vs 4182-4245 tok/s on its own, gpurun sessions 10 / 11 /
+        # 12 and the first evidence run of round 4).  The CPU baselines stay here.
         t0 = time.perf_counter()
         try:
-            out = fn(a, rank, ws, dev)
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", fn, "--steps", "3", "--warmup", "2", "--no-extras",
+                   "--no-cpu-baseline"] + (["--kv-bits", str(over["kv_bits"])] if over.get("kv_bits") else [])
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=max(60.0, budget_s - (time.perf_counter() - t_start) + 120.0))
+            lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                raise RuntimeError(f"rc={r.returncode}: {r.stderr.strip()[-300:]}")
+            out = json.loads(lines[-1])
             row = {k: out[k] for k in keep_keys if k in out}
             row["gpu_wall_s"] = time.perf_counter() - t0
         except Exception as e:
