@@ -267,6 +267,33 @@ int vlm_sample(const void* logits, int ld, int B, int V, void* logprobs, void* s
                void* workspace, float temperature, float top_p, float min_p, int top_k, unsigned seed,
                const void* step_ptr, void* stream);
 
+/* The whole sampler surface of make_sampler (sample_utils.py:10-89), filters in its order: top_n_sigma (181-212) -> p_less
+ * (215-236) -> typical_p (321-345) -> top_p (289-318) -> min_p with min_tokens_to_keep (239-286) -> xtc (348-376) -> top_k
+ * (169-175) -> categorical(logprobs / temp) (385-387).  The python scalars arrive as doubles and are converted the way MLX's
+ * weak typing converts them (double -> float32 -> the log-probs' dtype) before they meet the bf16 log-probs; every
+ * elementary op of the typed graph rounds to bf16 (pinned by tests/golden/samplers_ref.npz).  A filter is off at the value
+ * make_sampler treats as off: top_p outside (0, 1), min_p == 0, top_k <= 0, top_n_sigma == 0, p_less == 0, typical_p outside
+ * (0, 1), xtc_probability == 0.  After the call `scratch` holds the filtered log-probs (-inf = removed).
+ * typical_p needs sort_workspace (device, vlm_sample_sort_workspace_bytes(B, V)).  xtc: B == 1 only (the reference's minimum
+ * runs over the whole array and its draw is one scalar per call) -> VLM_ERR_SHAPE otherwise; the draw is the counter hash at
+ * (seed, *step_ptr, row, 0xFFFFFFFF); xtc_special_tokens = device int32 [n_xtc_special <= 256]. */
+typedef struct vlm_sampler_params {
+  double temperature, top_p, min_p;
+  int min_tokens_to_keep, top_k;
+  double top_n_sigma;
+  int p_less;
+  double typical_p, xtc_probability, xtc_threshold;
+  const void* xtc_special_tokens;
+  int n_xtc_special;
+  void* sort_workspace;
+  unsigned seed;
+  int input_is_logprobs; /* temperature > 0: `logits` already holds log-probs (what the reference hands a sampler closure,
+                            ar.py:368-379): no logsumexp pass, `logprobs` may be NULL */
+} vlm_sampler_params;
+size_t vlm_sample_sort_workspace_bytes(int B, int V);
+int vlm_sample_ex(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok, void* workspace,
+                  const vlm_sampler_params* p, const void* step_ptr, void* stream);
+
 /* Logits processors of generate_step (make_logits_processors, sample_utils.py:92-146, applied at ar.py:360-364) as ONE
  * device pass over the logits row(s), in the reference's order: logit_bias (129-134) -> repetition penalty (390-422:
  * x < 0 ? x * p : x / p, once per distinct token of the last rep_ctx fed tokens) -> presence penalty (425-450: - p once

@@ -63,6 +63,14 @@ class DecodeArgs(C.Structure):
                 ("flags", c_int), ("penalties", C.POINTER(PenaltyArgs))]
 
 
+class SamplerParams(C.Structure):
+    """vlm_sampler_params (include/vlm_hip.h): make_sampler's arguments as C doubles / ints"""
+    _fields_ = [("temperature", C.c_double), ("top_p", C.c_double), ("min_p", C.c_double), ("min_tokens_to_keep", c_int),
+                ("top_k", c_int), ("top_n_sigma", C.c_double), ("p_less", c_int), ("typical_p", C.c_double),
+                ("xtc_probability", C.c_double), ("xtc_threshold", C.c_double), ("xtc_special_tokens", c_void_p),
+                ("n_xtc_special", c_int), ("sort_workspace", c_void_p), ("seed", c_uint), ("input_is_logprobs", c_int)]
+
+
 class VitConfig(C.Structure):
     _fields_ = [("depth", c_int), ("embed_dim", c_int), ("n_heads", c_int), ("mlp_hidden", c_int), ("patch_k", c_int),
                 ("merge", c_int), ("out_dim", c_int), ("ln_eps", c_float), ("qk_interleaved", c_int)]
@@ -137,6 +145,9 @@ SIGNATURES = {
     "vlm_sample_workspace_bytes": (c_size_t, [c_int]),
     "vlm_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float,
                            c_float, c_float, c_int, c_uint, c_void_p, c_void_p]),
+    "vlm_sample_sort_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "vlm_sample_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                              C.POINTER(SamplerParams), c_void_p, c_void_p]),
     "vlm_apply_logit_penalties": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, C.POINTER(PenaltyArgs), c_void_p]),
     "vlm_sample_greedy_advance": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

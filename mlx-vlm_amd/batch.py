@@ -185,7 +185,9 @@ class BatchGenerator:
         # a sample_utils.Sampler samples on the device inside the captured step; any other callable is the reference's
         # `sampler(logprobs [n, V]) -> tokens [n]` contract and makes every step eager
         self._py_sampler = None
-        if sampler is not None and not isinstance(sampler, Sampler):
+        if sampler is not None and (not isinstance(sampler, Sampler) or sampler.extended):
+            # (a Sampler with the filters the captured step does not carry - sample_utils.Sampler.extended - is called on the
+            # rows' log-probs like any callable: the same HIP kernel through vlm_sample_ex)
             if not callable(sampler):
                 raise TypeError("sampler must be a mlx_vlm_amd.sample_utils.Sampler or a callable logprobs -> tokens")
             self._py_sampler, sampler = sampler, None

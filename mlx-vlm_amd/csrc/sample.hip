@@ -10,6 +10,9 @@
 // Because logprobs are bf16 there are only 65,536 distinct keys: top-k and top-p
 // are done EXACTLY with a 64 Ki-bin histogram (count and probability mass per
 // key) instead of a sort - a radix-select that fits the LDS-less L2-resident row.
+#include <math.h>
+#include <string.h>
+
 #include "common.cuh"
 #include "internal.h"
 #include "../../include/vlm_hip.h"
@@ -319,80 +322,308 @@ __device__ __forceinline__ T block_excl_scan(T v, T* lds /* >= 17 */, T* total) 
 
 constexpr bf16_t NEG_INF_BF = 0xff80u;
 
-// Among the elements whose key == tk (in index order) keep ranks [keep_lo, keep_hi), mask the rest.
+constexpr uint32_t KEY_NEG_INF = 0x007fu;   // bf_key(-inf)
+
+// Among the elements whose key == tk (in index order) keep ranks [keep_lo, keep_hi), mask the rest.  Wave w owns a contiguous
+// range of the row and walks it 64 elements at a time (coalesced); an element's rank = matches in the waves before + in this
+// wave's earlier iterations + in the lower lanes of this one (ballot).  (The first version gave every thread a contiguous
+// chunk: 64 cache lines per load instruction, 150 us of a 500 us top-p call at V = 151,936.)
 __device__ __forceinline__ void mask_equal_by_rank(bf16_t* lp, int V, uint32_t tk, uint32_t keep_lo, uint32_t keep_hi,
                                                    uint32_t* lds) {
-  const int chunk = (V + 1023) / 1024;
-  const int lo = threadIdx.x * chunk, hi = min(V, lo + chunk);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per = (((V + 15) >> 4) + 63) & ~63;
+  const int w_lo = min(V, wave * per), w_hi = min(V, w_lo + per);
   uint32_t cnt = 0;
-  for (int i = lo; i < hi; ++i) cnt += (bf_key(lp[i]) == tk);
-  uint32_t total;
-  uint32_t rank = block_excl_scan<uint32_t>(cnt, lds, &total);
-  for (int i = lo; i < hi; ++i)
-    if (bf_key(lp[i]) == tk) {
-      if (rank < keep_lo || rank >= keep_hi) lp[i] = NEG_INF_BF;
-      ++rank;
+  for (int i0 = w_lo; i0 < w_hi; i0 += 64) {
+    const int i = i0 + lane;
+    cnt += (uint32_t)__popcll(__ballot(i < w_hi && bf_key(lp[min(i, V - 1)]) == tk));
+  }
+  __syncthreads();
+  if (lane == 0) lds[wave] = cnt;
+  __syncthreads();
+  uint32_t rank = 0;
+  for (int w = 0; w < wave; ++w) rank += lds[w];
+  for (int i0 = w_lo; i0 < w_hi; i0 += 64) {
+    const int i = i0 + lane;
+    const bool hit = i < w_hi && bf_key(lp[min(i, V - 1)]) == tk;
+    const unsigned long long m = __ballot(hit);
+    if (hit) {
+      const uint32_t r = rank + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (r < keep_lo || r >= keep_hi) lp[i] = NEG_INF_BF;
     }
+    rank += (uint32_t)__popcll(m);
+  }
   __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __restrict__ lp_in, bf16_t* __restrict__ lp_all,
-                                                             int ldlp, int V, uint32_t* __restrict__ hist_all,
-                                                             float top_p, float min_p, int top_k, float temp,
-                                                             uint32_t seed, const int* __restrict__ step_ptr,
+// What the filters need on the device: the python scalars of the reference's closures already converted the way MLX's weak
+// typing converts them (double -> float32 -> the log-probs' dtype, on the host: make_params below)
+struct SamplerK {
+  int use_top_p;
+  float thr_top_p;      // T(1 - top_p)
+  int use_min_p, min_keep;
+  float log_min_p;      // T(log(min_p))
+  int top_k;
+  float temp;
+  uint32_t seed;
+  float n_sigma;        // > 0: on (fp32 statistics: the filter casts to float32 itself)
+  int p_less;
+  float inv_temp_t;     // T(1 / temp)
+  int use_typical;
+  float typical_thr;    // T(typical_p)
+  float xtc_prob, xtc_thr;   // xtc_prob > 0: on; xtc_thr = T(xtc_threshold)
+  const int* xtc_special;
+  int n_special;
+  uint32_t* sort_ws;    // typical_p: per row [2][Vp] u32 index arrays
+  size_t sort_stride;   // u32 words per row
+  int Vp;
+};
+
+constexpr int XTC_MAX_SPECIAL = 256;
+constexpr int LH_WORDS = 32768 + 512;   // LDS histogram of the keys below 0x8000, one pad word per 64 keys
+
+__global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __restrict__ lp_in, int ld_in,
+                                                             bf16_t* __restrict__ lp_all, int ldlp, int V,
+                                                             uint32_t* __restrict__ hist_all,
+                                                             const SamplerK p, const int* __restrict__ step_ptr,
                                                              int* __restrict__ tok) {
   __shared__ float red[32];
   __shared__ int redi[32];
   __shared__ uint32_t s_thr_key, s_thr_keep;
-  __shared__ float s_f;
+  __shared__ unsigned long long s_best;
   __shared__ uint32_t scan_u[17];
   __shared__ float scan_f[17];
+  __shared__ bf16_t s_special[XTC_MAX_SPECIAL];
+  __shared__ uint32_t s_dig[16 * 256];
+  __shared__ int s_anypos;
+  extern __shared__ uint32_t lh[];               // [LH_WORDS] the lower half of the key histogram (see build_hist)           // typical-p: per-wave digit counters of the radix passes
   const int b = blockIdx.x, tid = threadIdx.x;
   bf16_t* lp = lp_all + (size_t)b * ldlp;           // scratch copy that the filters mask in place
   uint32_t* hist = hist_all + (size_t)b * 65536;
-  for (int i = tid; i < V; i += 1024) lp[i] = lp_in[(size_t)b * ldlp + i];
+  const uint32_t step = (uint32_t)(step_ptr ? *step_ptr : 0);
+  for (int i = tid; i < V; i += 1024) lp[i] = lp_in[(size_t)b * ld_in + i];
   __syncthreads();
 
+  // The count per bf16 key.  Log-probs are <= 0: their keys are the lower 32 Ki, and that half of the histogram lives in LDS
+  // (padded one word per 64 keys: a thread walks 64 CONSECUTIVE keys, lanes 65 words apart land in different banks).  Keys
+  // of positive values (a caller may hand any row to a sampler) go to the global histogram - built, zeroed and read only
+  // when such a value exists.  (In global memory alone: 150,000 atomics into a few hundred words of one L2, and a thread's 64
+  // keys 64 cache lines apart for every lane of a load - most of a 500 us top-p call.)
+  bool any_pos = false;
   auto build_hist = [&]() {
-    for (int i = tid; i < 65536; i += 1024) hist[i] = 0;
+    for (int i = tid; i < LH_WORDS; i += 1024) lh[i] = 0;
+    if (tid == 0) s_anypos = 0;
     __syncthreads();
-    for (int i = tid; i < V; i += 1024) atomicAdd(&hist[bf_key(lp[i])], 1u);
+    // (-inf - every token an earlier filter removed - is counted in registers: 150,000 atomics on ONE word serialise)
+    uint32_t ninf = 0;
+    bool pos = false;
+    for (int i = tid; i < V; i += 1024) {
+      const uint32_t k = bf_key(lp[i]);
+      if (k == KEY_NEG_INF) ++ninf;
+      else if (k < 0x8000u) atomicAdd(&lh[k + (k >> 6)], 1u);
+      else pos = true;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ninf += __shfl_xor(ninf, o, 64);
+    if ((tid & 63) == 0 && ninf) atomicAdd(&lh[KEY_NEG_INF + (KEY_NEG_INF >> 6)], ninf);
+    if (pos) s_anypos = 1;
     __syncthreads();
+    any_pos = s_anypos != 0;
+    if (any_pos) {
+      for (int i = 32768 + tid; i < 65536; i += 1024) hist[i] = 0;
+      __syncthreads();
+      for (int i = tid; i < V; i += 1024) {
+        const uint32_t k = bf_key(lp[i]);
+        if (k >= 0x8000u) atomicAdd(&hist[k], 1u);
+      }
+      __syncthreads();
+    }
+  };
+  auto H = [&](uint32_t k) -> uint32_t { return k < 0x8000u ? lh[k + (k >> 6)] : (any_pos ? hist[k] : 0u); };
+  auto bmax = [&](float v) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float m = red[0];
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    return m;
   };
 
-  // ---- top-p (sample_utils.py:289-318): keep x_i iff cumulative prob (ascending, inclusive) > 1 - top_p
-  if (top_p > 0.f && top_p < 1.f) {
+  // ---- top-n-sigma (sample_utils.py:181-212): statistics of the float32 copy; keep x >= max - n_sigma * std (ddof 0)
+  if (p.n_sigma > 0.f) {
+    float m = -INFINITY, s = 0.f;
+    for (int i = tid; i < V; i += 1024) { const float f = bf2f(lp[i]); m = fmaxf(m, f); s += f; }
+    const float top = bmax(m);
+    const float mean = block_sum(s, red) / (float)V;
+    float q = 0.f;
+    for (int i = tid; i < V; i += 1024) { const float d = bf2f(lp[i]) - mean; q += d * d; }
+    const float sd = sqrtf(block_sum(q, red) / (float)V);
+    const float thr = top - p.n_sigma * sd;          // (a row that already holds -inf: NaN statistics, nothing removed - as MLX)
+    for (int i = tid; i < V; i += 1024)
+      if (bf2f(lp[i]) < thr) lp[i] = NEG_INF_BF;
+    __syncthreads();
+  }
+
+  // ---- p-less (sample_utils.py:215-236): keep p >= sum p^2 of softmax(x * T(1 / temp)); every op rounds to T
+  if (p.p_less) {
+    float m = -INFINITY;
+    for (int i = tid; i < V; i += 1024) m = fmaxf(m, rbf(bf2f(lp[i]) * p.inv_temp_t));
+    m = bmax(m);
+    float s = 0.f;
+    for (int i = tid; i < V; i += 1024) s += expf(rbf(bf2f(lp[i]) * p.inv_temp_t) - m);
+    const float den = block_sum(s, red);
+    float q = 0.f;
+    for (int i = tid; i < V; i += 1024) {
+      const float pr = rbf(expf(rbf(bf2f(lp[i]) * p.inv_temp_t) - m) / den);
+      q += rbf(pr * pr);
+    }
+    const float thr = rbf(block_sum(q, red));
+    for (int i = tid; i < V; i += 1024) {
+      const float pr = rbf(expf(rbf(bf2f(lp[i]) * p.inv_temp_t) - m) / den);
+      if (pr < thr) lp[i] = NEG_INF_BF;
+    }
+    __syncthreads();
+  }
+
+  // ---- typical-p (sample_utils.py:321-345): tokens in ascending order of |-logp - entropy| (stable: equal keys in index
+  // order), kept while the cumulative probability BEFORE them is below typical_p.  The order is a real sort here (the key is
+  // not monotone in logp and equal keys hold different probabilities): an LSD radix sort of the indices by the 15-bit key of
+  // the non-negative bf16 value, two stable 8-bit passes.  Wave w owns a contiguous range of positions and walks it 64 at a
+  // time (coalesced index loads); digit counters per wave in LDS; stability comes from the (digit, wave) order of the counter
+  // scan, the iteration order inside a wave and the lane order inside an iteration (the lanes that share a digit find each
+  // other with 8 ballots).  (First version: a contiguous chunk and 256 global counters per THREAD - 1.7 ms per call.)
+  if (p.use_typical) {
+    float acc = 0.f;
+    for (int i = tid; i < V; i += 1024) {
+      const float lf = bf2f(lp[i]);
+      acc += rbf(rbf(expf(lf)) * lf);                 // (0 * -inf = NaN on a row that was already filtered: as MLX)
+    }
+    const float ent = rbf(-rbf(block_sum(acc, red)));
+    auto tkey = [&](int i) -> uint32_t { return (uint32_t)f2bf(fabsf(rbf(-bf2f(lp[i]) - ent))) & 0x7fffu; };
+    uint32_t* idxA = p.sort_ws + (size_t)b * p.sort_stride;
+    uint32_t* idxB = idxA + p.Vp;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int per = (((V + 15) >> 4) + 63) & ~63;                 // positions per wave: contiguous, walked 64 at a time
+    const int w_lo = min(V, wave * per), w_hi = min(V, w_lo + per);
+    uint32_t* my_dig = s_dig + wave * 256;
+    for (int d = 0; d < 2; ++d) {
+      const uint32_t* src = d == 0 ? nullptr : idxB;
+      uint32_t* dst = d == 0 ? idxB : idxA;
+      for (int j = lane; j < 256; j += 64) my_dig[j] = 0;
+      for (int q0 = w_lo; q0 < w_hi; q0 += 64) {
+        const int q = q0 + lane;
+        if (q < w_hi) atomicAdd(&my_dig[(tkey(src ? (int)src[q] : q) >> (8 * d)) & 255u], 1u);
+      }
+      __syncthreads();
+      // exclusive prefix in (digit, wave) order = the stable order: thread t owns the flattened entries 4 t .. 4 t + 3
+      uint32_t v[4], mine = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const int f = 4 * tid + e; v[e] = s_dig[(f & 15) * 256 + (f >> 4)]; mine += v[e]; }
+      uint32_t total;
+      uint32_t run = block_excl_scan<uint32_t>(mine, scan_u, &total);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const int f = 4 * tid + e; s_dig[(f & 15) * 256 + (f >> 4)] = run; run += v[e]; }
+      __syncthreads();
+      for (int q0 = w_lo; q0 < w_hi; q0 += 64) {
+        const int q = q0 + lane;
+        const bool valid = q < w_hi;
+        const int i = valid ? (src ? (int)src[q] : q) : 0;
+        const uint32_t dg = valid ? (tkey(i) >> (8 * d)) & 255u : 0u;
+        // the lanes of this iteration that hold the same digit (8 ballots): rank inside the group by lane = by position
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+          const unsigned long long bb = __ballot((dg >> bit) & 1u);
+          same &= ((dg >> bit) & 1u) ? bb : ~bb;
+        }
+        if (valid) {
+          const uint32_t base = my_dig[dg];
+          dst[base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = (uint32_t)i;
+          // (the wave's LDS operations execute in order: every lane has read before the group's last lane writes)
+          if (lane == 63 - __clzll(same)) my_dig[dg] = base + (uint32_t)__popcll(same);
+        }
+      }
+      __syncthreads();
+    }
+    // the running sum of T(exp(logp)) in sorted order: wave totals, then an inclusive scan over the lanes of each iteration
+    float wsum = 0.f;
+    for (int q0 = w_lo; q0 < w_hi; q0 += 64) {
+      const int q = q0 + lane;
+      wsum += q < w_hi ? rbf(expf(bf2f(lp[idxA[q]]))) : 0.f;
+    }
+    wsum = wave_sum(wsum);
+    __syncthreads();
+    if (lane == 0) scan_f[wave] = wsum;
+    __syncthreads();
+    float run = 0.f;
+    for (int w = 0; w < wave; ++w) run += scan_f[w];
+    for (int q0 = w_lo; q0 < w_hi; q0 += 64) {
+      const int q = q0 + lane;
+      const bool valid = q < w_hi;
+      const int i = valid ? (int)idxA[q] : 0;
+      const float pe = valid ? rbf(expf(bf2f(lp[i]))) : 0.f;
+      float inc = pe;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const float n = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += n;
+      }
+      const float before = rbf(rbf(run + inc) - pe);
+      const float tot = __shfl(inc, 63, 64);
+      // (position q is this lane's alone and every lane has loaded its lp[i] above: nobody reads what is written here)
+      if (valid && !(before < p.typical_thr)) lp[i] = NEG_INF_BF;
+      run += tot;
+    }
+    __syncthreads();
+  }
+
+  // ---- top-p (sample_utils.py:289-318): ascending stable sort, keep x_i iff T(cumulative prob, inclusive) > T(1 - top_p);
+  // probabilities are T(exp(x)) (typed graph: for bf16 log-probs every step rounds, tests/golden/samplers_ref.npz)
+  if (p.use_top_p) {
     build_hist();
     // each thread owns 64 consecutive keys (ascending); prefix of the probability mass over threads
     float mass = 0.f;
     for (int j = 0; j < 64; ++j) {
-      const uint32_t k = tid * 64 + j, c = hist[k];
-      if (c) mass += (float)c * expf(bf2f(key_bf(k)));
+      const uint32_t k = tid * 64 + j, c = H(k);
+      if (c) mass += (float)c * rbf(expf(bf2f(key_bf(k))));
     }
     float total;
     float cum = block_excl_scan<float>(mass, scan_f, &total);
-    const float thr = 1.f - top_p;
-    if (tid == 0) { s_thr_key = 65536; s_thr_keep = 0; }
+    const float thr = p.thr_top_p;
+    if (tid == 0) s_best = ~0ull;
     __syncthreads();
-    if (cum <= thr && cum + mass > thr) {   // the crossing is inside this thread's keys (first such thread only)
+    // The first element (ascending key, then index) whose rounded inclusive prefix exceeds the threshold: every thread walks
+    // its own keys from its exclusive prefix and proposes (key, elements of the bin left below the threshold); the smallest
+    // proposal wins.  (The walk re-associates the sum the scan made; letting every thread speak - a thread that starts above
+    // the threshold proposes its first key - keeps a crossing that falls between two threads.)
+    {
+      bool above = rbf(cum) > thr;
       for (int j = 0; j < 64; ++j) {
-        const uint32_t k = tid * 64 + j, c = hist[k];
+        const uint32_t k = tid * 64 + j, c = H(k);
         if (!c) continue;
-        const float pk = expf(bf2f(key_bf(k)));
+        const float pk = rbf(expf(bf2f(key_bf(k))));
         if (pk == 0.f) continue;
-        if (cum + (float)c * pk > thr) {
+        if (above) { atomicMin(&s_best, (unsigned long long)k << 32); break; }
+        if (rbf(cum + (float)c * pk) > thr) {
+          // inside the bin: one addition per element, as the cumulative sum runs
+          float c2 = cum;
           uint32_t r = 0;
-          while (r < c && !(cum + (float)(r + 1) * pk > thr)) ++r;
-          s_thr_key = k; s_thr_keep = c - r;
-          break;
+          for (; r < c; ++r) { c2 += pk; if (rbf(c2) > thr) break; }
+          if (r < c) { atomicMin(&s_best, ((unsigned long long)k << 32) | r); break; }
+          cum = c2;
+        } else {
+          cum += (float)c * pk;
         }
-        cum += (float)c * pk;
       }
     }
     __syncthreads();
-    const uint32_t tk = s_thr_key, keep = s_thr_keep;
+    const uint32_t tk = s_best == ~0ull ? 65536u : (uint32_t)(s_best >> 32);
+    const uint32_t keep = tk < 65536 ? H(tk) - (uint32_t)(s_best & 0xffffffffu) : 0;
+    // (no crossing at all - T(1 - top_p) rounds to 1 for top_p < 2^-9 in bf16 and the reference then removes EVERY token;
+    // a row of -inf has no sample: left unfiltered here)
     if (tk < 65536) {
-      const uint32_t c = hist[tk];
+      const uint32_t c = H(tk);
       // ascending stable sort: equal keys are in index order and the cumulative grows with the index,
       // so the LAST `keep` of the bin survive
       if (keep < c) mask_equal_by_rank(lp, V, tk, c - keep, c, scan_u);
@@ -402,38 +633,84 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
     __syncthreads();
   }
 
-  // ---- min-p (sample_utils.py:266-286): drop x < max + log(min_p)
-  if (min_p > 0.f) {
+  // ---- min-p (sample_utils.py:266-286): drop x < T(max + T(log(min_p))); min_tokens_to_keep > 1: the k largest are never
+  // dropped (argpartition(kth=-k)[-k:]; ties at the k-th value: the HIGHEST indices - oracle/ops.py::apply_min_p)
+  if (p.use_min_p) {
     float m = -INFINITY;
     for (int i = tid; i < V; i += 1024) m = fmaxf(m, bf2f(lp[i]));
-    m = wave_max(m);
-    if ((tid & 63) == 0) red[tid >> 6] = m;
-    __syncthreads();
-    if (tid == 0) {
-      float mm = red[0];
-      for (int w = 1; w < 16; ++w) mm = fmaxf(mm, red[w]);
-      s_f = mm + logf(min_p);
+    const float thr = rbf(bmax(m) + p.log_min_p);
+    bool by_rank = false;
+    if (p.min_keep > 1 && p.min_keep < V) {
+      build_hist();
+      uint32_t cnt = 0;
+      for (int j = 0; j < 64; ++j) cnt += H(65535 - (tid * 64 + j));
+      uint32_t total;
+      uint32_t acc = block_excl_scan<uint32_t>(cnt, scan_u, &total);
+      if (tid == 0) { s_thr_key = 0; s_thr_keep = 0xffffffffu; }
+      __syncthreads();
+      if (acc < (uint32_t)p.min_keep && acc + cnt >= (uint32_t)p.min_keep) {
+        for (int j = 0; j < 64; ++j) {
+          const uint32_t k = 65535 - (tid * 64 + j), c = H(k);
+          if (acc + c >= (uint32_t)p.min_keep) { s_thr_key = k; s_thr_keep = (uint32_t)p.min_keep - acc; break; }
+          acc += c;
+        }
+      }
+      __syncthreads();
+      const uint32_t tk = s_thr_key, need = s_thr_keep;
+      // the k-th largest value is below the threshold: the survivors are exactly the k largest
+      if (need != 0xffffffffu && bf2f(key_bf(tk)) < thr) {
+        by_rank = true;
+        const uint32_t c = H(tk);
+        if (need < c) mask_equal_by_rank(lp, V, tk, c - need, c, scan_u);
+        for (int i = tid; i < V; i += 1024)
+          if (bf_key(lp[i]) < tk) lp[i] = NEG_INF_BF;
+      }
     }
+    if (!by_rank)
+      for (int i = tid; i < V; i += 1024)
+        if (bf2f(lp[i]) < thr) lp[i] = NEG_INF_BF;
     __syncthreads();
-    const float thr = s_f;
+  }
+
+  // ---- XTC (sample_utils.py:348-376), one row: with probability xtc_probability remove every token whose probability is
+  // above the SMALLEST probability that exceeds the threshold, except the special tokens.  The draw is the counter hash at
+  // an index no vocabulary entry has.
+  if (p.xtc_prob > 0.f && !(hash_uniform(p.seed, step, (uint32_t)b, 0xFFFFFFFFu) > p.xtc_prob)) {
+    float m = -INFINITY;
+    for (int i = tid; i < V; i += 1024) m = fmaxf(m, bf2f(lp[i]));
+    m = bmax(m);
+    float s = 0.f;
+    for (int i = tid; i < V; i += 1024) s += expf(bf2f(lp[i]) - m);
+    const float den = block_sum(s, red);
+    float cand = INFINITY;
+    for (int i = tid; i < V; i += 1024) {
+      const float pr = rbf(expf(bf2f(lp[i]) - m) / den);
+      if (pr > p.xtc_thr) cand = fminf(cand, pr);
+    }
+    cand = -bmax(-cand);
+    if (tid < p.n_special) { const int t = p.xtc_special[tid]; s_special[tid] = (t >= 0 && t < V) ? lp[t] : (bf16_t)0; }
+    __syncthreads();
     for (int i = tid; i < V; i += 1024)
-      if (bf2f(lp[i]) < thr) lp[i] = NEG_INF_BF;
+      if (rbf(expf(bf2f(lp[i]) - m) / den) > cand) lp[i] = NEG_INF_BF;
+    __syncthreads();
+    if (tid < p.n_special) { const int t = p.xtc_special[tid]; if (t >= 0 && t < V) lp[t] = s_special[tid]; }
     __syncthreads();
   }
 
   // ---- top-k (sample_utils.py:169-175): keep the k largest (ties at the k-th value: lowest indices)
+  const int top_k = p.top_k;
   if (top_k > 0 && top_k < V) {
     build_hist();
     // descending walk: thread t owns keys 65535 - 64 t - j
     uint32_t cnt = 0;
-    for (int j = 0; j < 64; ++j) cnt += hist[65535 - (tid * 64 + j)];
+    for (int j = 0; j < 64; ++j) cnt += H(65535 - (tid * 64 + j));
     uint32_t total;
     uint32_t acc = block_excl_scan<uint32_t>(cnt, scan_u, &total);
     if (tid == 0) { s_thr_key = 0; s_thr_keep = 0xffffffffu; }
     __syncthreads();
     if (acc < (uint32_t)top_k && acc + cnt >= (uint32_t)top_k) {
       for (int j = 0; j < 64; ++j) {
-        const uint32_t k = 65535 - (tid * 64 + j), c = hist[k];
+        const uint32_t k = 65535 - (tid * 64 + j), c = H(k);
         if (acc + c >= (uint32_t)top_k) { s_thr_key = k; s_thr_keep = (uint32_t)top_k - acc; break; }
         acc += c;
       }
@@ -441,7 +718,7 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
     __syncthreads();
     const uint32_t tk = s_thr_key, keep = s_thr_keep;
     if (keep != 0xffffffffu) {
-      if (keep < hist[tk]) mask_equal_by_rank(lp, V, tk, 0, keep, scan_u);
+      if (keep < H(tk)) mask_equal_by_rank(lp, V, tk, 0, keep, scan_u);
       for (int i = tid; i < V; i += 1024)
         if (bf_key(lp[i]) < tk) lp[i] = NEG_INF_BF;
     }
@@ -449,13 +726,12 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
   }
 
   // ---- categorical(logprobs / temp) via Gumbel-max with the counter hash RNG
-  const uint32_t step = (uint32_t)(step_ptr ? *step_ptr : 0);
-  const float it = 1.0f / temp;
+  const float it = 1.0f / p.temp;
   float best = -INFINITY;
   int besti = 0x7fffffff;
   for (int i = tid; i < V; i += 1024) {
     const float x = bf2f(lp[i]) * it;
-    const float u = hash_uniform(seed, step, (uint32_t)b, (uint32_t)i);
+    const float u = hash_uniform(p.seed, step, (uint32_t)b, (uint32_t)i);
     const float z = x + (-logf(-logf(u)));
     if (z > best || (z == best && i < besti)) { best = z; besti = i; }
   }
@@ -465,6 +741,7 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
     const int oi = __shfl_xor(besti, o, 64);
     if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
   }
+  __syncthreads();
   if ((tid & 63) == 0) { red[tid >> 6] = best; redi[tid >> 6] = besti; }
   __syncthreads();
   if (tid == 0) {
@@ -474,37 +751,118 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
   }
 }
 
+// float32 -> bf16 value, round to nearest even (host side of the weak-typed scalars)
+inline float host_rbf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return f;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  u &= 0xffff0000u;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
 }  // namespace
 
 extern "C" size_t vlm_sample_workspace_bytes(int B) { return (size_t)B * (NBLK * 4 * sizeof(float) + 65536 * sizeof(uint32_t)) + 256; }
 
+// typical_p's sort: per row two index arrays of Vp = V rounded up to 1024 entries (the digit counters live in LDS)
+extern "C" size_t vlm_sample_sort_workspace_bytes(int B, int V) {
+  if (B <= 0 || V <= 0) return 0;
+  const size_t Vp = ((size_t)V + 1023) & ~(size_t)1023;
+  return (size_t)B * 2 * Vp * sizeof(uint32_t);
+}
+
 // workspace layout: 256 B arrival ticket of the fused greedy tail (must be zero at allocation; the kernel re-arms it; at a
 // fixed offset so that a step over the first B' < B rows of a state finds the same word) |
 // [B][NBLK][2] f32 lse partials | [B][NBLK] f32 cand_v | [B][NBLK] i32 cand_i | [B][65536] u32 hist
-extern "C" int vlm_sample(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
-                          void* workspace, float temperature, float top_p, float min_p, int top_k, unsigned seed,
-                          const void* step_ptr, void* stream) {
-  if (!logits || !tok || !workspace || B <= 0 || V <= 0) return VLM_ERR_ARG;
-  if (temperature < 0.f) return VLM_ERR_ARG;
-  if (temperature > 0.f && (!logprobs || !scratch)) return VLM_ERR_ARG;
+extern "C" int vlm_sample_ex(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
+                             void* workspace, const vlm_sampler_params* sp, const void* step_ptr, void* stream) {
+  if (!logits || !tok || !workspace || !sp || B <= 0 || V <= 0) return VLM_ERR_ARG;
+  const double temperature = sp->temperature;
+  if (!(temperature >= 0.0)) return VLM_ERR_ARG;
+  const bool lp_given = temperature > 0.0 && sp->input_is_logprobs;     // the sampler closure's own contract: log-probs in
+  if (temperature > 0.0 && (!scratch || (!logprobs && !lp_given))) return VLM_ERR_ARG;
+  SamplerK k{};
+  if (temperature > 0.0) {
+    // the checks of the reference's closures (sample_utils.py:160-165, 200-203, 253-260, 323-326, 363-370)
+    if (sp->min_p < 0.0 || sp->min_p > 1.0 || sp->min_tokens_to_keep < 1 || sp->top_n_sigma < 0.0 || sp->top_k < 0) return VLM_ERR_ARG;
+    if (sp->xtc_probability < 0.0 || sp->xtc_probability > 1.0) return VLM_ERR_ARG;
+    k.use_top_p = sp->top_p > 0.0 && sp->top_p < 1.0;
+    k.thr_top_p = host_rbf((float)(1.0 - sp->top_p));
+    k.use_min_p = sp->min_p != 0.0;
+    k.min_keep = sp->min_tokens_to_keep;
+    k.log_min_p = k.use_min_p ? host_rbf((float)log(sp->min_p)) : 0.f;
+    k.top_k = sp->top_k;
+    k.temp = (float)temperature;
+    k.seed = sp->seed;
+    k.n_sigma = (float)sp->top_n_sigma;
+    k.p_less = sp->p_less != 0;
+    k.inv_temp_t = host_rbf((float)(1.0 / temperature));
+    k.use_typical = sp->typical_p > 0.0 && sp->typical_p < 1.0;
+    k.typical_thr = host_rbf((float)sp->typical_p);
+    k.xtc_prob = (float)sp->xtc_probability;
+    if (k.xtc_prob > 0.f) {
+      if (sp->xtc_threshold < 0.0 || sp->xtc_threshold > 0.5) return VLM_ERR_ARG;
+      // apply_xtc's minimum runs over the WHOLE array and its draw is one scalar per call (sample_utils.py:371-376): built for
+      // the one-row call of generate_step
+      if (B != 1) return VLM_ERR_SHAPE;
+      if (sp->n_xtc_special < 0 || sp->n_xtc_special > XTC_MAX_SPECIAL || (sp->n_xtc_special > 0 && !sp->xtc_special_tokens))
+        return VLM_ERR_ARG;
+      k.xtc_thr = host_rbf((float)sp->xtc_threshold);
+      k.xtc_special = (const int*)sp->xtc_special_tokens;
+      k.n_special = sp->n_xtc_special;
+    }
+    if (k.use_typical) {
+      if (!sp->sort_workspace) return VLM_ERR_ARG;
+      k.Vp = (V + 1023) & ~1023;
+      k.sort_stride = 2 * (size_t)k.Vp;
+      k.sort_ws = (uint32_t*)sp->sort_workspace;
+    }
+  }
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)((char*)workspace + 256);
   float* cand_v = ws + (size_t)B * NBLK * 2;
   int* cand_i = (int*)(cand_v + (size_t)B * NBLK);
   uint32_t* hist = (uint32_t*)(cand_i + (size_t)B * NBLK);
-  hipLaunchKernelGGL(lse_partial_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws);
-  VLM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(logprob_argmax_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws,
-                     (bf16_t*)logprobs, ldlp, cand_v, cand_i);
-  VLM_CHECK_LAUNCH();
-  if (temperature == 0.f) {
+  if (!lp_given) {
+    hipLaunchKernelGGL(lse_partial_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws);
+    VLM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(logprob_argmax_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws,
+                       (bf16_t*)logprobs, ldlp, cand_v, cand_i);
+    VLM_CHECK_LAUNCH();
+  }
+  if (temperature == 0.0) {
     hipLaunchKernelGGL(argmax_final_kernel, dim3(B), dim3(64), 0, st, cand_v, cand_i, (int*)tok);
   } else {
-    hipLaunchKernelGGL(sample_filter_kernel, dim3(B), dim3(1024), 0, st, (const bf16_t*)logprobs, (bf16_t*)scratch, ldlp,
-                       V, hist, top_p, min_p, top_k, temperature, seed, (const int*)step_ptr, (int*)tok);
+    constexpr int LDS = LH_WORDS * (int)sizeof(uint32_t);       // 130 KB of the CU's 160 (one workgroup per CU)
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_filter_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (attr != hipSuccess) return VLM_ERR_HIP + (int)attr;
+    if (lp_given)
+      hipLaunchKernelGGL(sample_filter_kernel, dim3(B), dim3(1024), LDS, st, (const bf16_t*)logits, ld, (bf16_t*)scratch, ldlp,
+                         V, hist, k, (const int*)step_ptr, (int*)tok);
+    else
+      hipLaunchKernelGGL(sample_filter_kernel, dim3(B), dim3(1024), LDS, st, (const bf16_t*)logprobs, ldlp, (bf16_t*)scratch,
+                         ldlp, V, hist, k, (const int*)step_ptr, (int*)tok);
   }
   VLM_CHECK_LAUNCH();
   return VLM_OK;
+}
+
+extern "C" int vlm_sample(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
+                          void* workspace, float temperature, float top_p, float min_p, int top_k, unsigned seed,
+                          const void* step_ptr, void* stream) {
+  if (temperature < 0.f) return VLM_ERR_ARG;
+  vlm_sampler_params sp{};
+  sp.temperature = temperature;
+  sp.top_p = top_p;
+  sp.min_p = min_p;
+  sp.min_tokens_to_keep = 1;
+  sp.top_k = top_k;
+  sp.typical_p = 1.0;
+  sp.seed = seed;
+  return vlm_sample_ex(logits, ld, B, V, logprobs, scratch, ldlp, tok, workspace, &sp, step_ptr, stream);
 }
 
 /* greedy tail of the decode step in two launches: vlm_sample (temperature 0) + vlm_decode_advance + the next step's

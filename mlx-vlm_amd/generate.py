@@ -136,14 +136,17 @@ class _TokenPipe:
         return self.buf[idx % self.cap].numpy().copy()
 
 
-def _resolve_sampler(sampler, temperature, top_p, min_p, top_k, seed):
-    """-> (device Sampler, python callable or None).  A `sample_utils.Sampler` runs inside the captured step; any other
-    callable is the reference's `sampler(logprobs) -> token` contract (ar.py:151-193,369-379) and runs on the host side of
-    an EAGER step (logits come back from the engine, the callable gets the log-probs as a device tensor)."""
+def _resolve_sampler(sampler, temperature, top_p, min_p, top_k, seed, **more):
+    """-> (device Sampler, python callable or None).  A `sample_utils.Sampler` with top-p / min-p / top-k runs inside the
+    captured step; one with the other filters of make_sampler (top_n_sigma, p_less, typical_p, xtc, min_tokens_to_keep - the
+    reference's generate_step takes the first three as keywords, ar.py:168-170,279-288) is called on the step's log-probs
+    (the same HIP kernel through vlm_sample_ex) around an EAGER step, like any other callable: the reference's
+    `sampler(logprobs) -> token` contract (ar.py:151-193,369-379), which gets the log-probs as a device tensor."""
     if sampler is None:
-        return make_sampler(temp=temperature, top_p=top_p, min_p=min_p, top_k=top_k, seed=seed), None
+        sampler = make_sampler(temp=temperature, top_p=top_p, min_p=min_p, top_k=top_k, seed=seed,
+                               **{k: v for k, v in more.items() if v is not None})
     if isinstance(sampler, Sampler):
-        return sampler, None
+        return (make_sampler(temp=0.0), sampler) if sampler.extended else (sampler, None)
     if callable(sampler):
         return make_sampler(temp=0.0), sampler
     raise TypeError("sampler must be a mlx_vlm_amd.sample_utils.Sampler or a callable logprobs -> token")
@@ -214,7 +217,8 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
                                       "8-bit / group-64 quantized KV cache is built (TurboQuant / other widths: SURVEY section 2 out of scope)")
     for k in ("verbose", "prompt_cache_checkpoint", "prompt_cache_checkpoint_len"):
         kwargs.pop(k, None)
-    smp, py_sampler = _resolve_sampler(sampler, temperature, top_p, min_p, top_k, seed)
+    smp, py_sampler = _resolve_sampler(sampler, temperature, top_p, min_p, top_k, seed, top_n_sigma=kwargs.pop("top_n_sigma", None),
+                                       p_less=kwargs.pop("p_less", None), typical_p=kwargs.pop("typical_p", None))
     sargs = smp.engine_args()
     eager = bool(py_procs) or py_sampler is not None or thinking_budget_criteria is not None
     lm = model.language_model
@@ -610,6 +614,9 @@ def batch_generate_ids(model, input_ids_list: List[np.ndarray], pixel_values_lis
     pixel_attention_mask), as `generate_batch_continuous` takes them."""
     lm = model.language_model
     smp = sampler or make_sampler()
+    if smp.extended:
+        raise NotImplementedError("static batches sample inside the captured step (top-p / min-p / top-k); the other filters of "
+                                  "make_sampler run through the continuous generator")
     sargs = smp.engine_args()
     stats = BatchStats()
     outs: List[List[int]] = [[] for _ in input_ids_list]
@@ -695,7 +702,9 @@ def batch_generate(model, processor, images=None, audios=None, prompts: Optional
     stop = getattr(tokenizer, "stopping_criteria", None)
     stop_ids = tuple(getattr(stop, "eos_token_ids", ()) or ())
     smp, py_smp = _resolve_sampler(kwargs.pop("sampler", None), kwargs.pop("temperature", 0.0), kwargs.pop("top_p", 1.0),
-                                   kwargs.pop("min_p", 0.0), kwargs.pop("top_k", 0), kwargs.pop("seed", None))
+                                   kwargs.pop("min_p", 0.0), kwargs.pop("top_k", 0), kwargs.pop("seed", None),
+                                   top_n_sigma=kwargs.pop("top_n_sigma", None), p_less=kwargs.pop("p_less", None),
+                                   typical_p=kwargs.pop("typical_p", None))
     if py_smp is not None:
         smp = py_smp               # a Python callable: the generator runs eager steps around it (batch.py)
     # the reference's batch_generate hands its penalty keywords to the generator (ar.py:2890-3096): one spec for every request

@@ -375,19 +375,40 @@ def sample_workspace(B, device):
     return torch.zeros(_lib.lib().vlm_sample_workspace_bytes(B), dtype=torch.uint8, device=device)
 
 
-def sample(logits, temperature=0.0, top_p=1.0, min_p=0.0, top_k=0, seed=0, step=None, want_logprobs=True, ws=None):
-    """-> (tokens int32 [B], logprobs bf16 [B,V] or None)"""
+def sample(logits, temperature=0.0, top_p=1.0, min_p=0.0, top_k=0, seed=0, step=None, want_logprobs=True, ws=None,
+           min_tokens_to_keep=1, top_n_sigma=0.0, p_less=False, typical_p=1.0, xtc_probability=0.0, xtc_threshold=0.0,
+           xtc_special_tokens=None, return_filtered=False, input_is_logprobs=False):
+    """-> (tokens int32 [B], logprobs bf16 [B,V] or None[, filtered logprobs bf16 [B,V] when return_filtered]).
+    vlm_sample_ex: the whole make_sampler surface (sample_utils.py:10-89), scalars handed over as python floats (doubles).
+    input_is_logprobs (temperature > 0): `logits` already holds log-probs - the contract of the reference's sampler closures -
+    and is filtered as it is."""
     _dev(logits)
     B, V = logits.shape
     tok = torch.empty(B, dtype=torch.int32, device=logits.device)
-    lp = torch.empty(B, V, dtype=torch.bfloat16, device=logits.device) if (want_logprobs or temperature > 0) else None
+    lp_given = bool(input_is_logprobs) and temperature > 0
+    lp = torch.empty(B, V, dtype=torch.bfloat16, device=logits.device) if ((want_logprobs or temperature > 0) and not lp_given) else None
     scratch = torch.empty(B, V, dtype=torch.bfloat16, device=logits.device) if temperature > 0 else None
     if ws is None:
         ws = sample_workspace(B, logits.device)
-    check(_lib.lib().vlm_sample(_p(logits), logits.stride(0), B, V, _p(lp), _p(scratch), V, _p(tok), _p(ws),
-                                float(temperature), float(top_p), float(min_p), int(top_k), int(seed) & 0xFFFFFFFF,
-                                _p(step), _stream()), "sample")
-    return tok, lp
+    sp = _lib.SamplerParams(input_is_logprobs=int(lp_given), temperature=float(temperature), top_p=float(top_p), min_p=float(min_p),
+                            min_tokens_to_keep=int(min_tokens_to_keep), top_k=int(top_k), top_n_sigma=float(top_n_sigma),
+                            p_less=int(bool(p_less)), typical_p=float(typical_p), xtc_probability=float(xtc_probability),
+                            xtc_threshold=float(xtc_threshold), seed=int(seed) & 0xFFFFFFFF)
+    keep = []
+    if temperature > 0 and xtc_probability > 0 and xtc_special_tokens is not None and len(xtc_special_tokens):
+        sp_tok = torch.as_tensor([int(t) for t in xtc_special_tokens], dtype=torch.int32).to(logits.device)
+        keep.append(sp_tok)
+        sp.xtc_special_tokens, sp.n_xtc_special = _p(sp_tok), sp_tok.numel()
+    if temperature > 0 and 0.0 < typical_p < 1.0:
+        sort_ws = torch.empty(_lib.lib().vlm_sample_sort_workspace_bytes(B, V), dtype=torch.uint8, device=logits.device)
+        keep.append(sort_ws)
+        sp.sort_workspace = _p(sort_ws)
+    check(_lib.lib().vlm_sample_ex(_p(logits), logits.stride(0), B, V, _p(lp), _p(scratch), V, _p(tok), _p(ws), sp, _p(step),
+                                   _stream()), "sample")
+    del keep                           # (allocated and freed on the launch's own stream: the caching allocator orders reuse)
+    if lp_given:
+        lp = logits
+    return (tok, lp, scratch) if return_filtered else (tok, lp)
 
 
 def sample_greedy_advance(logits, tok, ctx, pos, step, embed, h, out_ring=None, want_logprobs=True, ws=None):

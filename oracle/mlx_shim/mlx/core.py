@@ -731,6 +731,11 @@ def var(a, axis=None, keepdims=False, ddof=0, stream=None):
     return array(t.to(torch.float32).var(_axes(axis), correction=ddof, keepdim=keepdims).to(t.dtype))
 
 
+def std(a, axis=None, keepdims=False, ddof=0, stream=None):
+    t = _a(a)._t
+    return array(t.to(torch.float32).var(_axes(axis), correction=ddof, keepdim=keepdims).sqrt().to(t.dtype))
+
+
 def logsumexp(a, axis=None, keepdims=False, stream=None):
     t = _a(a)._t
     ax = _axes(axis)

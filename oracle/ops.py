@@ -321,27 +321,121 @@ def apply_top_k(logprobs, top_k: int):
 
 def apply_top_p(logprobs, top_p: float):
     """apply_top_p (sample_utils.py:289-318): ascending sort, cumulative probs,
-    keep tokens whose cumulative prob (inclusive) > 1 - top_p."""
+    keep tokens whose cumulative prob (inclusive) > 1 - top_p.  Typed graph (matters for bf16 log-probs, which is what
+    generate_step passes: tests/golden/samplers_ref.npz): exp -> T, cumsum -> T (fp32 accumulate, every prefix rounded), and the
+    python scalar 1 - top_p is converted to T before the comparison."""
+    T = logprobs.dtype
     xf = logprobs.to(F32)
-    probs = torch.exp(xf)
+    probs = torch.exp(xf).to(T).to(F32)
     order = torch.sort(xf, dim=-1, stable=True).indices
     sp = torch.gather(probs, -1, order)
-    cum = torch.cumsum(sp, dim=-1)
+    cum = torch.cumsum(sp, dim=-1).to(T).to(F32)
     inv = torch.empty_like(order)
     inv.scatter_(-1, order, torch.arange(order.shape[-1]).expand_as(order))
     cum = torch.gather(cum, -1, inv)
-    return torch.where(cum > 1 - top_p, xf, torch.full_like(xf, float("-inf"))).to(logprobs.dtype)
+    return torch.where(cum > _c(1 - top_p, T), xf, torch.full_like(xf, float("-inf"))).to(T)
 
 
 def apply_min_p(logprobs, min_p: float, min_tokens_to_keep: int = 1):
-    """_apply_min_p (sample_utils.py:266-286)."""
+    """_apply_min_p (sample_utils.py:266-286).  min_tokens_to_keep > 1: the k largest are never removed
+    (mx.argpartition(kth=-k)[-k:]; ties at the k-th value: the shim's stable ascending sort keeps the HIGHEST indices)."""
+    T = logprobs.dtype
     xf = logprobs.to(F32)
     top = xf.max(dim=-1, keepdim=True).values
-    remove = xf < (top + math.log(min_p))
+    # typed graph: `top_logprobs + math.log(min_p)` is an op of the logprobs dtype - the python scalar is converted to T first
+    # and the sum is rounded to T (found with bf16 inputs in tests/golden/samplers_ref.npz; fp32 inputs cannot tell)
+    remove = xf < (top + _c(math.log(min_p), T)).to(T).to(F32)
     if min_tokens_to_keep > 1:
-        keep = torch.topk(xf, min_tokens_to_keep, dim=-1).indices
+        keep = torch.sort(xf, dim=-1, stable=True).indices[..., -min_tokens_to_keep:]
         remove.scatter_(-1, keep, False)
     return torch.where(remove, torch.full_like(xf, float("-inf")), xf).to(logprobs.dtype)
+
+
+def apply_top_n_sigma(logits, n_sigma: float):
+    """_top_n_sigma (sample_utils.py:181-212): keep x >= max - n_sigma * std, statistics of the float32 copy (ddof 0)."""
+    f = logits.to(F32)
+    top = f.max(dim=-1, keepdim=True).values
+    std = f.var(dim=-1, correction=0, keepdim=True).sqrt()
+    thr = top - n_sigma * std
+    return torch.where(f < thr, torch.full_like(f, float("-inf")), f).to(logits.dtype)
+
+
+def apply_p_less(logits, temp: float):
+    """apply_p_less (sample_utils.py:215-236): keep tokens whose probability under softmax(logits / temp) is at least the
+    collision probability sum p^2.  Typed graph: logits * T(1 / temp) -> T, softmax -> T, p * p -> T, sum -> T."""
+    T = logits.dtype
+    s = (logits.to(F32) * _c(1.0 / temp, T)).to(T)
+    probs = torch.softmax(s.to(F32), dim=-1).to(T)
+    sq = (probs.to(F32) * probs.to(F32)).to(T)
+    thr = sq.to(F32).sum(dim=-1, keepdim=True).to(T)
+    lf = logits.to(F32)
+    return torch.where(probs.to(F32) < thr.to(F32), torch.full_like(lf, float("-inf")), lf).to(T)
+
+
+def apply_typical_p(logprobs, typical_p: float):
+    """_typical_p (sample_utils.py:321-345): tokens in ascending order of |-logp - entropy| (stable), kept while the
+    cumulative probability BEFORE them is below typical_p.  Typed graph: every elementary op rounds to T."""
+    T = logprobs.dtype
+    lf = logprobs.to(F32)
+    p = torch.exp(lf).to(T)
+    pl = (p.to(F32) * lf).to(T)
+    ent = (-(pl.to(F32).sum(dim=-1, keepdim=True).to(T)).to(F32)).to(T)
+    shifted = ((-lf) - ent.to(F32)).to(T).to(F32).abs()
+    order = torch.sort(shifted, dim=-1, stable=True).indices
+    sp = torch.gather(p.to(F32), -1, order)
+    cum = torch.cumsum(sp, dim=-1).to(T)
+    inv = torch.empty_like(order)
+    inv.scatter_(-1, order, torch.arange(order.shape[-1]).expand_as(order))
+    cum = torch.gather(cum, -1, inv)
+    before = (cum.to(F32) - p.to(F32)).to(T)
+    return torch.where(before.to(F32) < _c(typical_p, T), lf, torch.full_like(lf, float("-inf"))).to(T)
+
+
+def apply_xtc(logits, apply: bool, xtc_threshold: float, special_tokens=()):
+    """apply_xtc (sample_utils.py:348-376) for ONE row: when the draw says so (`apply`), every token whose probability is
+    strictly above the SMALLEST probability that exceeds the threshold is removed - i.e. of the tokens above the threshold
+    only the least likely survives - except the special tokens."""
+    if not apply:
+        return logits
+    T = logits.dtype
+    lf = logits.to(F32)
+    probs = torch.softmax(lf, dim=-1).to(T).to(F32)
+    cand = torch.where(probs > _c(xtc_threshold, T), probs, torch.full_like(probs, float("inf"))).min()
+    mask = probs > cand
+    if len(special_tokens):
+        mask[..., list(special_tokens)] = False
+    return torch.where(mask, torch.full_like(lf, float("-inf")), lf).to(T)
+
+
+def xtc_draw(seed: int, step: int, row: int = 0) -> float:
+    """The uniform draw of OUR xtc (the reference's is mx.random.uniform, sample_utils.py:374 - MLX's stream is not
+    reproducible outside MLX): the counter hash at an index no vocabulary entry has (csrc/sample.hip)."""
+    return float(hash_uniform(seed, step, row, np.array([0xFFFFFFFF], dtype=np.uint64))[0])
+
+
+def sampler_filters(logprobs, temp: float, top_p: float = 0.0, min_p: float = 0.0, min_tokens_to_keep: int = 1, top_k: int = 0,
+                    top_n_sigma: float = 0.0, p_less: bool = False, typical_p: float = 1.0, xtc_probability: float = 0.0,
+                    xtc_threshold: float = 0.0, xtc_special_tokens=(), seed: int = 0, step: int = 0):
+    """The filter chain of make_sampler's closure (sample_utils.py:66-89) in its order, on [B, V] log-probs -> the filtered
+    log-probs that categorical_sampling receives.  xtc: one row (its minimum runs over the whole array)."""
+    x = logprobs
+    if top_n_sigma > 0.0:
+        x = apply_top_n_sigma(x, top_n_sigma)
+    if p_less:
+        x = apply_p_less(x, temp)
+    if 0.0 < typical_p < 1.0:
+        x = apply_typical_p(x, typical_p)
+    if 0.0 < top_p < 1.0:
+        x = apply_top_p(x, top_p)
+    if min_p != 0.0:
+        x = apply_min_p(x, min_p, min_tokens_to_keep)
+    if xtc_probability > 0.0:
+        assert x.shape[0] == 1
+        # np.float32 comparison: the kernel compares the fp32 draw with float32(xtc_probability)
+        x = apply_xtc(x, not (np.float32(xtc_draw(seed, step, 0)) > np.float32(xtc_probability)), xtc_threshold, xtc_special_tokens)
+    if top_k > 0:
+        x = apply_top_k(x, top_k)
+    return x
 
 
 def apply_logits_processors(logits, tokens, logit_bias=None, repetition_penalty=None, repetition_context_size=20,

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES)
     for s in declared:
         assert hasattr(L, s), s
-    assert L.vlm_abi_version() == 5
+    assert L.vlm_abi_version() == 6
     # ... and NOTHING else: the dynamic symbol table of the .so is exactly the header (debug hooks and library-internal
     # entry points have hidden visibility)
     import subprocess
@@ -603,3 +603,32 @@ def test_bench_gpus_2_dry_run_through_the_self_launch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
                        timeout=120, env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
+
+
+def test_make_sampler_takes_the_whole_reference_surface():
+    """make_sampler's arguments (reference sample_utils.py:10-89) all land in the spec; the filters the captured step does not
+    carry mark it `extended`, which routes it around an eager step as the sampler callable (generate._resolve_sampler); the
+    argument checks of the reference's closures are made at construction."""
+    from mlx_vlm_amd.generate import _resolve_sampler
+    from mlx_vlm_amd.sample_utils import Sampler, make_sampler
+
+    s = make_sampler(temp=0.7, top_p=0.9, min_p=0.05, top_k=40, seed=3)
+    assert not s.extended and s.engine_args() == dict(temperature=0.7, top_p=0.9, min_p=0.05, top_k=40, seed=3)
+    assert _resolve_sampler(s, 0.0, 1.0, 0.0, 0, None) == (s, None)
+    for kw in (dict(min_tokens_to_keep=4, min_p=0.1), dict(top_n_sigma=1.0), dict(p_less=True), dict(typical_p=0.5),
+               dict(xtc_probability=0.3, xtc_threshold=0.1, xtc_special_tokens=[1, 2])):
+        e = make_sampler(temp=0.7, seed=1, **kw)
+        assert e.extended, kw
+        dev, py = _resolve_sampler(e, 0.0, 1.0, 0.0, 0, None)
+        assert dev.greedy and py is e
+        a = e.sample_args()
+        for k, v in kw.items():
+            assert a[k] == v, (k, a[k])
+        assert not make_sampler(temp=0.0, **kw).extended            # greedy ignores every filter (sample_utils.py:63-64)
+    # generate_step's keywords (ar.py:168-170) reach make_sampler
+    dev, py = _resolve_sampler(None, 0.8, 0.9, 0.0, 0, 5, top_n_sigma=1.5, p_less=None, typical_p=0.4)
+    assert isinstance(py, Sampler) and py.top_n_sigma == 1.5 and py.typical_p == 0.4 and py.top_p == 0.9 and not py.p_less
+    for bad in (dict(min_p=1.5), dict(min_tokens_to_keep=0), dict(top_n_sigma=-1.0), dict(typical_p=1.5),
+                dict(xtc_probability=0.5, xtc_threshold=0.7), dict(xtc_probability=1.5)):
+        with pytest.raises(ValueError):
+            make_sampler(temp=0.5, **bad)

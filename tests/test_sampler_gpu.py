@@ -1,0 +1,222 @@
+"""The whole make_sampler surface (reference mlx_vlm/sample_utils.py:10-89) on MI355X through vlm_sample_ex: top-n-sigma,
+p-less, locally typical, top-p, min-p with min_tokens_to_keep, XTC, top-k - the FILTERED log-probs the kernel leaves in its
+scratch row against
+
+  * the reference's own functions' outputs (tests/golden/samplers_ref.npz: its sample_utils.py executed over the shim) on
+    the golden bf16 rows, bit for bit;
+  * the oracle's typed restatement (oracle/ops.py::sampler_filters, pinned to the same vectors on the CPU side) on rows of
+    real vocabulary sizes (32,003 ragged / 151,936) and on chains of filters in make_sampler's order.
+
+Agreement is EXACT (which tokens survive, and their values) except where a float32 sum taken in another order lands on the
+other side of a bf16 rounding edge: a survivor set may differ by elements whose deciding quantity sits on the filter's
+threshold - the tests name that quantity per filter and accept nothing else.  The draw (Gumbel-max over the filtered row
+with the counter hash) is checked against oracle.categorical_gumbel on the kernel's own filtered row."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "samplers_ref.npz"))
+
+
+@pytest.fixture(scope="module")
+def vops():
+    from mlx_vlm_amd import ops
+    return ops
+
+
+def _rows(B, V, seed, scales=(1.5, 5.0, 2.0)):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, V, generator=g) * torch.tensor([[scales[b % len(scales)]] for b in range(B)])
+    if B > 2:
+        x[2] = torch.round(x[2] * 2) / 2            # exact ties
+    return (x - torch.logsumexp(x, -1, keepdim=True)).to(BF)
+
+
+def _filtered(vops, lp, temp=0.8, seed=11, step=0, **kw):
+    st = torch.tensor([step], dtype=torch.int32, device="cuda")
+    tok, _, filt = vops.sample(lp.cuda(), temperature=temp, seed=seed, step=st, want_logprobs=False, input_is_logprobs=True,
+                               return_filtered=True, **kw)
+    torch.cuda.synchronize()
+    return tok.cpu(), filt.cpu()
+
+
+def _kept(x):
+    return torch.isfinite(x.float())
+
+
+def _assert_same(got, ref, lp, what=""):
+    """got / ref: filtered rows [B, V].  Survivors keep their values; the survivor sets are equal, or differ only in EDGE
+    elements: an element the two sides disagree on has, within one bf16 step of its own log-prob, an element the reference puts
+    in the other class (every filter here cuts in log-prob order, or - typical-p - in a band of it whose two ends are such
+    edges).  -> number of elements on the other side of an edge."""
+    kg, kr = _kept(got), _kept(ref)
+    assert torch.equal(got.float()[kg], lp.float()[kg]), what          # a filter never changes a survivor
+    if torch.equal(kg, kr):
+        return 0
+    q = lp.float()
+    n_bad = 0
+    for b in range(lp.shape[0]):
+        diff = torch.nonzero(kg[b] != kr[b]).flatten()
+        if diff.numel() == 0:
+            continue
+        assert diff.numel() <= max(4, int(0.01 * int(kr[b].sum()))), (what, b, int(diff.numel()), int(kg[b].sum()), int(kr[b].sum()))
+        for i in diff.tolist():
+            v = float(q[b, i])
+            other = q[b, ~kr[b] & torch.isfinite(q[b])] if bool(kr[b, i]) else q[b, kr[b]]
+            d = float((other - v).abs().min()) if other.numel() else float("inf")
+            assert d <= 2.0 ** -7 * abs(v) + 1e-30, (what, b, i, v, d, int(kg[b].sum()), int(kr[b].sum()))
+        n_bad += int(diff.numel())
+    return n_bad
+
+
+def test_filters_equal_the_reference_on_its_golden_rows(vops):
+    """Kernel output vs the reference's own apply_* outputs (bf16 inputs), every golden case."""
+    lp = torch.from_numpy(G["bf16.logprobs"]).to(BF)
+    sp = [int(v) for v in G["xtc_special"]]
+    cases = []
+    for ns in (0.5, 1.5):
+        cases.append((f"top_n_sigma_{ns}", dict(top_n_sigma=ns), 0.8))
+    for temp in (0.7, 1.3):
+        cases.append((f"p_less_{temp}", dict(p_less=True), temp))
+    for tp in (0.3, 0.9):
+        cases.append((f"typical_p_{tp}", dict(typical_p=tp), 0.8))
+    for mp, keep in ((0.3, 4), (0.05, 1), (0.9, 7)):
+        cases.append((f"min_p_{mp}_keep_{keep}", dict(min_p=mp, min_tokens_to_keep=keep), 0.8))
+    for tp in (0.5, 0.9, 0.99):
+        cases.append((f"top_p_{tp}", dict(top_p=tp), 0.8))
+    cases.append(("top_k_5", dict(top_k=5), 0.8))
+    total = 0
+    for name, kw, temp in cases:
+        ref = torch.from_numpy(G[f"bf16.{name}"])
+        _, got = _filtered(vops, lp, temp=temp, **kw)
+        n = int((_kept(got) != _kept(ref)).sum())
+        total += n
+        assert n == 0, (name, n, [int(_kept(got[b]).sum()) for b in range(3)], [int(_kept(ref[b]).sum()) for b in range(3)])
+        assert torch.equal(got.float()[_kept(ref)], ref[_kept(ref)]), name
+    # xtc: one row per call; probability 1.0 = always (any draw), 0.0 = the filter is off (make_sampler adds it only when > 0)
+    for thr in (0.02, 0.08):
+        ref = torch.from_numpy(G[f"bf16.xtc_{thr}"])
+        for r in range(3):
+            _, got = _filtered(vops, lp[r:r + 1], xtc_probability=1.0, xtc_threshold=thr, xtc_special_tokens=sp)
+            assert torch.equal(_kept(got[0]), _kept(ref[r])), (thr, r, int(_kept(got[0]).sum()), int(_kept(ref[r]).sum()))
+            assert all(bool(_kept(got[0])[t]) for t in sp)
+    print(f"golden rows: {len(cases)} filter cases + 6 xtc calls, survivor sets identical")
+
+
+@pytest.mark.parametrize("V", [32003, 151936])
+@pytest.mark.parametrize("name,kw,temp", [
+    ("top_n_sigma", dict(top_n_sigma=1.0), 0.8),
+    ("p_less", dict(p_less=True), 0.7),
+    ("p_less_hot", dict(p_less=True), 1.6),
+    ("typical_p", dict(typical_p=0.5), 0.8),
+    ("typical_p_wide", dict(typical_p=0.95), 0.8),
+    ("top_p", dict(top_p=0.9), 0.8),
+    ("top_p_low", dict(top_p=0.25), 0.8),
+    ("min_p", dict(min_p=0.05), 0.8),
+    ("min_p_keep", dict(min_p=0.6, min_tokens_to_keep=300), 0.8),
+    ("top_k", dict(top_k=50), 0.8),
+    ("chain_classic", dict(top_p=0.95, min_p=0.02, top_k=64), 1.0),
+    ("chain_typical", dict(typical_p=0.9, top_p=0.9, top_k=40), 0.9),
+    ("chain_sigma", dict(top_n_sigma=2.0, min_p=0.1, min_tokens_to_keep=3, top_k=16), 1.1),
+])
+def test_filters_equal_the_oracle_at_vocabulary_size(vops, V, name, kw, temp):
+    lp = _rows(3, V, seed=200 + len(name))
+    _, got = _filtered(vops, lp, temp=temp, **kw)
+    ref = O.sampler_filters(lp, temp, **kw)
+    n = _assert_same(got, ref, lp, what=name)
+    print(f"{name} V={V}: kept {[int(_kept(ref[b]).sum()) for b in range(3)]}, elements on the other side of an edge: {n}")
+
+
+@pytest.mark.parametrize("kw", [dict(top_p=0.9), dict(top_k=33), dict(min_p=0.5, min_tokens_to_keep=200),
+                                dict(top_p=0.95, min_p=0.01, top_k=100)])
+def test_filters_on_rows_with_positive_values(vops, kw):
+    """A sampler closure takes whatever row it is handed (the reference's make_sampler documents top-n-sigma / p-less on raw
+    logits): rows with positive entries - keys the LDS half of the histogram does not hold - through the same filters."""
+    g = torch.Generator().manual_seed(321)
+    x = (torch.randn(2, 40000, generator=g) * 3.0 + 1.0).to(BF)       # unnormalised: about 60 % positive
+    x[1] = (x[1].float() - 10.5).to(BF)                               # second row: only a handful above zero
+    _, got = _filtered(vops, x, **kw)
+    ref = O.sampler_filters(x, 0.8, **kw)
+    n = _assert_same(got, ref, x, what=str(kw))
+    print(f"{kw}: kept {[int(_kept(ref[b]).sum()) for b in range(2)]}, on the other side of an edge: {n}")
+
+
+def test_xtc_draw_and_special_tokens(vops):
+    """xtc_probability = 0.5 over 24 steps: applied exactly on the steps where the counter hash says so (oracle.xtc_draw),
+    removing everything above the weakest above-threshold token except the special ones."""
+    V = 32003
+    lp = _rows(1, V, seed=77, scales=(4.0,))
+    sp = [int(i) for i in torch.topk(lp[0].float(), 3).indices[:2]] + [5]
+    applied = 0
+    for step in range(24):
+        _, got = _filtered(vops, lp, seed=1234, step=step, xtc_probability=0.5, xtc_threshold=0.01, xtc_special_tokens=sp)
+        ref = O.sampler_filters(lp, 0.8, xtc_probability=0.5, xtc_threshold=0.01, xtc_special_tokens=sp, seed=1234, step=step)
+        _assert_same(got, ref, lp, what=f"xtc step {step}")
+        on = not (np.float32(O.xtc_draw(1234, step)) > np.float32(0.5))
+        assert (int(_kept(got).sum()) < V) == on, step
+        applied += on
+    assert 4 < applied < 20
+    with pytest.raises(Exception):       # the reference's minimum runs over the whole array: one row per call
+        _filtered(vops, _rows(2, 1024, seed=3), xtc_probability=1.0, xtc_threshold=0.05)
+
+
+def test_typical_p_after_a_filter_follows_the_reference_into_its_nan_order(vops):
+    """The reference's typical-p on a row that already holds -inf: p * logp = 0 * -inf = NaN, the entropy is NaN, every sort
+    key is NaN, the (stable) order is the index order and tokens are kept in INDEX order until the mass before them reaches
+    typical_p.  Not a useful filter - but it is what make_sampler(top_n_sigma=, typical_p=) computes, and IEEE arithmetic in
+    the kernel arrives at the same survivors (up to the float32 order of the running sum at the cut)."""
+    lp = _rows(2, 32003, seed=41)
+    _, got = _filtered(vops, lp, top_n_sigma=1.5, typical_p=0.9)
+    ref = O.sampler_filters(lp, 0.8, top_n_sigma=1.5, typical_p=0.9)
+    for b in range(2):
+        kg, kr = _kept(got[b]), _kept(ref[b])
+        assert int((kg != kr).sum()) <= 2, (b, int(kg.sum()), int(kr.sum()))
+        assert 0 < int(kr.sum()) < 2000
+
+
+def test_the_draw_runs_over_the_filtered_row(vops):
+    """tokens = Gumbel-max over (filtered log-probs / temp) with the counter hash at (seed, step, row, index)."""
+    V = 32003
+    lp = _rows(2, V, seed=91)
+    agree = 0
+    for step in range(30):
+        tok, filt = _filtered(vops, lp, temp=0.9, seed=5, step=step, typical_p=0.9, top_k=50)
+        for b in range(2):
+            assert bool(_kept(filt[b])[int(tok[b])])
+            agree += int(int(tok[b]) == O.categorical_gumbel(filt[b], 0.9, seed=5, step=step, row=b))
+    assert agree >= 58, agree
+
+
+def test_sampler_spec_is_callable_on_logprobs_and_generate_step_takes_the_keywords(vops):
+    """make_sampler(...) with the extra filters: callable on a log-probs tensor (the reference's closure contract), and
+    generate_step(top_n_sigma= / p_less= / typical_p=) routes to it (ar.py:168-170,279-288) - every token drawn is a
+    survivor of the oracle's filter chain on that step's log-probs."""
+    from mlx_vlm_amd.generate import generate_step
+    from mlx_vlm_amd.sample_utils import make_sampler
+    from oracle import qwen2_vl as oq
+    from tests.helpers import build_product_model
+
+    smp = make_sampler(temp=0.8, typical_p=0.6, min_p=0.05, min_tokens_to_keep=3, seed=9)
+    assert smp.extended
+    lp = _rows(2, 4096, seed=17)
+    ref = O.sampler_filters(lp, 0.8, typical_p=0.6, min_p=0.05, min_tokens_to_keep=3)
+    for _ in range(20):
+        tok = smp(lp.cuda()).cpu()
+        assert all(bool(_kept(ref[b])[int(tok[b])]) for b in range(2))
+    cfg = oq.tiny_cfg()
+    W = oq.random_weights(cfg, seed=1234, dtype=BF, std=0.05, embed_std=0.2)
+    model = build_product_model(cfg, W, kv_pool_tokens=4096, max_seqs=8)
+    ids = np.random.default_rng(5).integers(3, 1000, (1, 21))
+    out = list(generate_step(ids, model, None, None, max_tokens=12, temperature=0.9, typical_p=0.8, top_k=30, seed=3))
+    assert len(out) == 12
+    for t, lpv in out:
+        row = lpv.reshape(1, -1).cpu()
+        keep = _kept(O.sampler_filters(row, 0.9, typical_p=0.8, top_k=30))[0]
+        near = row.float()[0, t] >= row.float()[0][keep].min() - 2.0 ** -6 * abs(float(row.float()[0][keep].min()))
+        assert bool(keep[t]) or bool(near), t
