@@ -273,7 +273,9 @@ int vlm_sample(const void* logits, int ld, int B, int V, void* logprobs, void* s
  * weak typing converts them (double -> float32 -> the log-probs' dtype) before they meet the bf16 log-probs; every
  * elementary op of the typed graph rounds to bf16 (pinned by tests/golden/samplers_ref.npz).  A filter is off at the value
  * make_sampler treats as off: top_p outside (0, 1), min_p == 0, top_k <= 0, top_n_sigma == 0, p_less == 0, typical_p outside
- * (0, 1), xtc_probability == 0.  After the call `scratch` holds the filtered log-probs (-inf = removed).
+ * (0, 1), xtc_probability == 0.  After the call `scratch` holds the filtered log-probs (-inf = removed) when at least one filter
+ * is on; with none the draw reads the log-probs themselves.  Launches: logsumexp partials, log-probs, [filters: one workgroup
+ * per row], the Gumbel-max partials (64 workgroups per row), the final pick.
  * typical_p needs sort_workspace (device, vlm_sample_sort_workspace_bytes(B, V)).  xtc: B == 1 only (the reference's minimum
  * runs over the whole array and its draw is one scalar per call) -> VLM_ERR_SHAPE otherwise; the draw is the counter hash at
  * (seed, *step_ptr, row, 0xFFFFFFFF); xtc_special_tokens = device int32 [n_xtc_special <= 256]. */

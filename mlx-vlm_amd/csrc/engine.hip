@@ -419,7 +419,9 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
                                     a->out_ring, a->ring_len, a->step, m->g.embed, a->h, D, D, stream)); n += 2;
     } else {
       TRY(vlm_sample(a->logits, VL, B, c.vocab, a->logprobs, a->scratch, VL, a->tok, a->sample_ws, a->temperature, a->top_p,
-                     a->min_p, a->top_k, a->seed, a->step, stream)); n += 3;
+                     a->min_p, a->top_k, a->seed, a->step, stream));
+      // (greedy: partials, log-probs + candidates, pick; sampling: + the draw's partials, + the filter kernel when one is on)
+      n += a->temperature == 0.f ? 3 : ((a->top_p > 0.f && a->top_p < 1.f) || a->min_p != 0.f || a->top_k > 0 ? 5 : 4);
       TRY(vlm_decode_advance(a->ctx, a->pos, a->tok, a->out_ring, a->ring_len, a->step, B, stream)); ++n;
     }
   }

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restric
     const int oi = __shfl_xor(besti, o, 64);
     if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
   }
-  if (threadIdx.x == 0) tok[b] = besti;
+  if (threadIdx.x == 0) tok[b] = besti == 0x7fffffff ? 0 : besti;   // (sampling over a row with every token removed: a valid index anyway)
 }
 
 
@@ -325,35 +325,132 @@ constexpr bf16_t NEG_INF_BF = 0xff80u;
 constexpr uint32_t KEY_NEG_INF = 0x007fu;   // bf_key(-inf)
 
 // Among the elements whose key == tk (in index order) keep ranks [keep_lo, keep_hi), mask the rest.  Wave w owns a contiguous
-// range of the row and walks it 64 elements at a time (coalesced); an element's rank = matches in the waves before + in this
-// wave's earlier iterations + in the lower lanes of this one (ballot).  (The first version gave every thread a contiguous
-// chunk: 64 cache lines per load instruction, 150 us of a 500 us top-p call at V = 151,936.)
-__device__ __forceinline__ void mask_equal_by_rank(bf16_t* lp, int V, uint32_t tk, uint32_t keep_lo, uint32_t keep_hi,
+// range of the row; an element's rank = matches in the waves before + in this wave's earlier iterations + in the lower lanes
+// of this one (ballots).  Aligned rows: a lane takes 8 consecutive elements per iteration (one 16-byte load, 19 iterations for
+// V = 151,936) and the lanes' match counts (0..8: four bits) are prefixed with four ballots; otherwise one element per lane.
+// (History, profiles/r04_sampler_*: a contiguous chunk per THREAD cost 150 us of a top-p call - 64 cache lines per load;
+// one element per lane with a ballot behind every load 59 us - 149 exposed load latencies per pass.)
+__device__ __forceinline__ void mask_equal_by_rank(bf16_t* lp, int V, bool vec, uint32_t tk, uint32_t keep_lo, uint32_t keep_hi,
                                                    uint32_t* lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int per = (((V + 15) >> 4) + 63) & ~63;
-  const int w_lo = min(V, wave * per), w_hi = min(V, w_lo + per);
-  uint32_t cnt = 0;
-  for (int i0 = w_lo; i0 < w_hi; i0 += 64) {
-    const int i = i0 + lane;
-    cnt += (uint32_t)__popcll(__ballot(i < w_hi && bf_key(lp[min(i, V - 1)]) == tk));
-  }
-  __syncthreads();
-  if (lane == 0) lds[wave] = cnt;
-  __syncthreads();
-  uint32_t rank = 0;
-  for (int w = 0; w < wave; ++w) rank += lds[w];
-  for (int i0 = w_lo; i0 < w_hi; i0 += 64) {
-    const int i = i0 + lane;
-    const bool hit = i < w_hi && bf_key(lp[min(i, V - 1)]) == tk;
-    const unsigned long long m = __ballot(hit);
-    if (hit) {
-      const uint32_t r = rank + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      if (r < keep_lo || r >= keep_hi) lp[i] = NEG_INF_BF;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint32_t cnt = 0, rank = 0;
+  if (vec && (V & 7) == 0) {
+    const uint32_t tb = key_bf(tk);
+    const int per = (((V + 15) >> 4) + 511) & ~511;
+    const int w_lo = min(V, wave * per), w_hi = min(V, w_lo + per);
+    auto hits = [&](const u32x4_t& w) -> uint32_t {
+      const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+      return (uint32_t)((w0 & 0xffffu) == tb) | (uint32_t)((w0 >> 16) == tb) << 1 | (uint32_t)((w1 & 0xffffu) == tb) << 2 |
+             (uint32_t)((w1 >> 16) == tb) << 3 | (uint32_t)((w2 & 0xffffu) == tb) << 4 | (uint32_t)((w2 >> 16) == tb) << 5 |
+             (uint32_t)((w3 & 0xffffu) == tb) << 6 | (uint32_t)((w3 >> 16) == tb) << 7;
+    };
+    for (int i0 = w_lo; i0 < w_hi; i0 += 512) {
+      const int base = i0 + lane * 8;
+      if (base < w_hi) cnt += (uint32_t)__popc(hits(*reinterpret_cast<const u32x4_t*>(lp + base)));
     }
-    rank += (uint32_t)__popcll(m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    __syncthreads();
+    if (lane == 0) lds[wave] = cnt;
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) rank += lds[w];
+    for (int i0 = w_lo; i0 < w_hi; i0 += 512) {
+      const int base = i0 + lane * 8;
+      u32x4_t w = {0u, 0u, 0u, 0u};
+      uint32_t m = 0;
+      if (base < w_hi) { w = *reinterpret_cast<const u32x4_t*>(lp + base); m = hits(w); }
+      const uint32_t n = (uint32_t)__popc(m);
+      uint32_t before = 0, tot = 0;
+#pragma unroll
+      for (int bit = 0; bit < 4; ++bit) {
+        const unsigned long long bb = __ballot((n >> bit) & 1u);
+        before += (uint32_t)__popcll(bb & lt) << bit;
+        tot += (uint32_t)__popcll(bb) << bit;
+      }
+      if (m) {
+        uint32_t r = rank + before, wv[4] = {w[0], w[1], w[2], w[3]};
+        bool changed = false;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if ((m >> e) & 1u) {
+            if (r < keep_lo || r >= keep_hi) {
+              wv[e >> 1] = (e & 1) ? (wv[e >> 1] & 0x0000ffffu) | ((uint32_t)NEG_INF_BF << 16) : (wv[e >> 1] & 0xffff0000u) | NEG_INF_BF;
+              changed = true;
+            }
+            ++r;
+          }
+        if (changed) { u32x4_t o; o[0] = wv[0]; o[1] = wv[1]; o[2] = wv[2]; o[3] = wv[3]; *reinterpret_cast<u32x4_t*>(lp + base) = o; }
+      }
+      rank += tot;
+    }
+  } else {
+    const int per = (((V + 15) >> 4) + 63) & ~63;
+    const int w_lo = min(V, wave * per), w_hi = min(V, w_lo + per);
+    for (int i0 = w_lo; i0 < w_hi; i0 += 64) {
+      const int i = i0 + lane;
+      cnt += (uint32_t)__popcll(__ballot(i < w_hi && bf_key(lp[min(i, V - 1)]) == tk));
+    }
+    __syncthreads();
+    if (lane == 0) lds[wave] = cnt;
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) rank += lds[w];
+    for (int i0 = w_lo; i0 < w_hi; i0 += 64) {
+      const int i = i0 + lane;
+      const bool hit = i < w_hi && bf_key(lp[min(i, V - 1)]) == tk;
+      const unsigned long long m = __ballot(hit);
+      if (hit) {
+        const uint32_t r = rank + (uint32_t)__popcll(m & lt);
+        if (r < keep_lo || r >= keep_hi) lp[i] = NEG_INF_BF;
+      }
+      rank += (uint32_t)__popcll(m);
+    }
   }
   __syncthreads();
+}
+
+// Row passes of the one-workgroup-per-row sampler: 8 elements (one 16-byte load) per lane per iteration when the row is 16-byte
+// aligned (the engine's rows and every vocabulary that is a multiple of 8), one element otherwise.  A pass of 2-byte loads
+// is 149 dependent-latency iterations for V = 151,936 - 12 us each, ten of them in a top-p call.
+template <typename F>
+__device__ __forceinline__ void row_read(const bf16_t* row, int V, bool vec, F f) {
+  const int tid = threadIdx.x;
+  if (vec) {
+    const int V8 = V >> 3;
+    for (int c = tid; c < V8; c += 1024) {
+      const u32x4_t w = *reinterpret_cast<const u32x4_t*>(row + (size_t)c * 8);
+      const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+      f(c * 8 + 0, (bf16_t)(w0 & 0xffffu)); f(c * 8 + 1, (bf16_t)(w0 >> 16));
+      f(c * 8 + 2, (bf16_t)(w1 & 0xffffu)); f(c * 8 + 3, (bf16_t)(w1 >> 16));
+      f(c * 8 + 4, (bf16_t)(w2 & 0xffffu)); f(c * 8 + 5, (bf16_t)(w2 >> 16));
+      f(c * 8 + 6, (bf16_t)(w3 & 0xffffu)); f(c * 8 + 7, (bf16_t)(w3 >> 16));
+    }
+    for (int i = (V8 << 3) + tid; i < V; i += 1024) f(i, row[i]);
+  } else {
+    for (int i = tid; i < V; i += 1024) f(i, row[i]);
+  }
+}
+// f(i, bits) -> the element's new bits
+template <typename F>
+__device__ __forceinline__ void row_update(bf16_t* row, int V, bool vec, F f) {
+  const int tid = threadIdx.x;
+  if (vec) {
+    const int V8 = V >> 3;
+    for (int c = tid; c < V8; c += 1024) {
+      u32x4_t* ptr = reinterpret_cast<u32x4_t*>(row + (size_t)c * 8);
+      const u32x4_t w = *ptr;
+      const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+      u32x4_t o;
+      o[0] = (uint32_t)f(c * 8 + 0, (bf16_t)(w0 & 0xffffu)) | ((uint32_t)f(c * 8 + 1, (bf16_t)(w0 >> 16)) << 16);
+      o[1] = (uint32_t)f(c * 8 + 2, (bf16_t)(w1 & 0xffffu)) | ((uint32_t)f(c * 8 + 3, (bf16_t)(w1 >> 16)) << 16);
+      o[2] = (uint32_t)f(c * 8 + 4, (bf16_t)(w2 & 0xffffu)) | ((uint32_t)f(c * 8 + 5, (bf16_t)(w2 >> 16)) << 16);
+      o[3] = (uint32_t)f(c * 8 + 6, (bf16_t)(w3 & 0xffffu)) | ((uint32_t)f(c * 8 + 7, (bf16_t)(w3 >> 16)) << 16);
+      if (o[0] != w0 || o[1] != w1 || o[2] != w2 || o[3] != w3) *ptr = o;
+    }
+    for (int i = (V8 << 3) + tid; i < V; i += 1024) row[i] = f(i, row[i]);
+  } else {
+    for (int i = tid; i < V; i += 1024) { const bf16_t x = row[i], y = f(i, x); if (y != x) row[i] = y; }
+  }
 }
 
 // What the filters need on the device: the python scalars of the reference's closures already converted the way MLX's weak
@@ -385,8 +482,7 @@ constexpr int LH_WORDS = 32768 + 512;   // LDS histogram of the keys below 0x800
 __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __restrict__ lp_in, int ld_in,
                                                              bf16_t* __restrict__ lp_all, int ldlp, int V,
                                                              uint32_t* __restrict__ hist_all,
-                                                             const SamplerK p, const int* __restrict__ step_ptr,
-                                                             int* __restrict__ tok) {
+                                                             const SamplerK p, const int* __restrict__ step_ptr) {
   __shared__ float red[32];
   __shared__ int redi[32];
   __shared__ uint32_t s_thr_key, s_thr_keep;
@@ -401,7 +497,23 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
   bf16_t* lp = lp_all + (size_t)b * ldlp;           // scratch copy that the filters mask in place
   uint32_t* hist = hist_all + (size_t)b * 65536;
   const uint32_t step = (uint32_t)(step_ptr ? *step_ptr : 0);
-  for (int i = tid; i < V; i += 1024) lp[i] = lp_in[(size_t)b * ld_in + i];
+#ifdef VLM_SAMPLE_STAMPS
+  // probe build (scripts/sampler_stamps.py): phase stamps of the 100 MHz wall clock in the words of the global histogram that
+  // the LDS half has made free
+  int n_stamp = 0;
+#define STAMP() do { __syncthreads(); if (tid == 0) hist[n_stamp] = (uint32_t)wall_clock64(); ++n_stamp; } while (0)
+#else
+#define STAMP() do { } while (0)
+#endif
+  const bf16_t* src_row = lp_in + (size_t)b * ld_in;
+  const bool vec = ((uintptr_t)lp & 15) == 0;
+  STAMP();   // 0
+  if (vec && ((uintptr_t)src_row & 15) == 0) {
+    for (int c = tid; c < (V >> 3); c += 1024) reinterpret_cast<u32x4_t*>(lp)[c] = reinterpret_cast<const u32x4_t*>(src_row)[c];
+    for (int i = (V & ~7) + tid; i < V; i += 1024) lp[i] = src_row[i];
+  } else {
+    for (int i = tid; i < V; i += 1024) lp[i] = src_row[i];
+  }
   __syncthreads();
 
   // The count per bf16 key.  Log-probs are <= 0: their keys are the lower 32 Ki, and that half of the histogram lives in LDS
@@ -417,12 +529,12 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
     // (-inf - every token an earlier filter removed - is counted in registers: 150,000 atomics on ONE word serialise)
     uint32_t ninf = 0;
     bool pos = false;
-    for (int i = tid; i < V; i += 1024) {
-      const uint32_t k = bf_key(lp[i]);
+    row_read(lp, V, vec, [&](int, bf16_t xb) {
+      const uint32_t k = bf_key(xb);
       if (k == KEY_NEG_INF) ++ninf;
       else if (k < 0x8000u) atomicAdd(&lh[k + (k >> 6)], 1u);
       else pos = true;
-    }
+    });
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ninf += __shfl_xor(ninf, o, 64);
     if ((tid & 63) == 0 && ninf) atomicAdd(&lh[KEY_NEG_INF + (KEY_NEG_INF >> 6)], ninf);
@@ -432,10 +544,10 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
     if (any_pos) {
       for (int i = 32768 + tid; i < 65536; i += 1024) hist[i] = 0;
       __syncthreads();
-      for (int i = tid; i < V; i += 1024) {
-        const uint32_t k = bf_key(lp[i]);
+      row_read(lp, V, vec, [&](int, bf16_t xb) {
+        const uint32_t k = bf_key(xb);
         if (k >= 0x8000u) atomicAdd(&hist[k], 1u);
-      }
+      });
       __syncthreads();
     }
   };
@@ -453,36 +565,34 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
   // ---- top-n-sigma (sample_utils.py:181-212): statistics of the float32 copy; keep x >= max - n_sigma * std (ddof 0)
   if (p.n_sigma > 0.f) {
     float m = -INFINITY, s = 0.f;
-    for (int i = tid; i < V; i += 1024) { const float f = bf2f(lp[i]); m = fmaxf(m, f); s += f; }
+    row_read(lp, V, vec, [&](int, bf16_t xb) { const float f = bf2f(xb); m = fmaxf(m, f); s += f; });
     const float top = bmax(m);
     const float mean = block_sum(s, red) / (float)V;
     float q = 0.f;
-    for (int i = tid; i < V; i += 1024) { const float d = bf2f(lp[i]) - mean; q += d * d; }
+    row_read(lp, V, vec, [&](int, bf16_t xb) { const float d = bf2f(xb) - mean; q += d * d; });
     const float sd = sqrtf(block_sum(q, red) / (float)V);
     const float thr = top - p.n_sigma * sd;          // (a row that already holds -inf: NaN statistics, nothing removed - as MLX)
-    for (int i = tid; i < V; i += 1024)
-      if (bf2f(lp[i]) < thr) lp[i] = NEG_INF_BF;
+    row_update(lp, V, vec, [&](int, bf16_t xb) -> bf16_t { return bf2f(xb) < thr ? NEG_INF_BF : xb; });
     __syncthreads();
   }
 
   // ---- p-less (sample_utils.py:215-236): keep p >= sum p^2 of softmax(x * T(1 / temp)); every op rounds to T
   if (p.p_less) {
     float m = -INFINITY;
-    for (int i = tid; i < V; i += 1024) m = fmaxf(m, rbf(bf2f(lp[i]) * p.inv_temp_t));
+    row_read(lp, V, vec, [&](int, bf16_t xb) { m = fmaxf(m, rbf(bf2f(xb) * p.inv_temp_t)); });
     m = bmax(m);
     float s = 0.f;
-    for (int i = tid; i < V; i += 1024) s += expf(rbf(bf2f(lp[i]) * p.inv_temp_t) - m);
+    row_read(lp, V, vec, [&](int, bf16_t xb) { s += expf(rbf(bf2f(xb) * p.inv_temp_t) - m); });
     const float den = block_sum(s, red);
     float q = 0.f;
-    for (int i = tid; i < V; i += 1024) {
-      const float pr = rbf(expf(rbf(bf2f(lp[i]) * p.inv_temp_t) - m) / den);
+    row_read(lp, V, vec, [&](int, bf16_t xb) {
+      const float pr = rbf(expf(rbf(bf2f(xb) * p.inv_temp_t) - m) / den);
       q += rbf(pr * pr);
-    }
+    });
     const float thr = rbf(block_sum(q, red));
-    for (int i = tid; i < V; i += 1024) {
-      const float pr = rbf(expf(rbf(bf2f(lp[i]) * p.inv_temp_t) - m) / den);
-      if (pr < thr) lp[i] = NEG_INF_BF;
-    }
+    row_update(lp, V, vec, [&](int, bf16_t xb) -> bf16_t {
+      return rbf(expf(rbf(bf2f(xb) * p.inv_temp_t) - m) / den) < thr ? NEG_INF_BF : xb;
+    });
     __syncthreads();
   }
 
@@ -495,10 +605,10 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
   // other with 8 ballots).  (First version: a contiguous chunk and 256 global counters per THREAD - 1.7 ms per call.)
   if (p.use_typical) {
     float acc = 0.f;
-    for (int i = tid; i < V; i += 1024) {
-      const float lf = bf2f(lp[i]);
+    row_read(lp, V, vec, [&](int, bf16_t xb) {
+      const float lf = bf2f(xb);
       acc += rbf(rbf(expf(lf)) * lf);                 // (0 * -inf = NaN on a row that was already filtered: as MLX)
-    }
+    });
     const float ent = rbf(-rbf(block_sum(acc, red)));
     auto tkey = [&](int i) -> uint32_t { return (uint32_t)f2bf(fabsf(rbf(-bf2f(lp[i]) - ent))) & 0x7fffu; };
     uint32_t* idxA = p.sort_ws + (size_t)b * p.sort_stride;
@@ -580,19 +690,22 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
 
   // ---- top-p (sample_utils.py:289-318): ascending stable sort, keep x_i iff T(cumulative prob, inclusive) > T(1 - top_p);
   // probabilities are T(exp(x)) (typed graph: for bf16 log-probs every step rounds, tests/golden/samplers_ref.npz)
+  STAMP();   // 1: row copied, earlier filters done
   if (p.use_top_p) {
     build_hist();
+    STAMP();   // 2: histogram
     // each thread owns 64 consecutive keys (ascending); prefix of the probability mass over threads
     float mass = 0.f;
     for (int j = 0; j < 64; ++j) {
       const uint32_t k = tid * 64 + j, c = H(k);
-      if (c) mass += (float)c * rbf(expf(bf2f(key_bf(k))));
+      if (c) mass = fmaf((float)c, rbf(expf(bf2f(key_bf(k)))), mass);
     }
     float total;
     float cum = block_excl_scan<float>(mass, scan_f, &total);
     const float thr = p.thr_top_p;
     if (tid == 0) s_best = ~0ull;
     __syncthreads();
+    STAMP();   // 3: mass per thread + scan
     // The first element (ascending key, then index) whose rounded inclusive prefix exceeds the threshold: every thread walks
     // its own keys from its exclusive prefix and proposes (key, elements of the bin left below the threshold); the smallest
     // proposal wins.  (The walk re-associates the sum the scan made; letting every thread speak - a thread that starts above
@@ -605,19 +718,24 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
         const float pk = rbf(expf(bf2f(key_bf(k))));
         if (pk == 0.f) continue;
         if (above) { atomicMin(&s_best, (unsigned long long)k << 32); break; }
-        if (rbf(cum + (float)c * pk) > thr) {
-          // inside the bin: one addition per element, as the cumulative sum runs
-          float c2 = cum;
-          uint32_t r = 0;
-          for (; r < c; ++r) { c2 += pk; if (rbf(c2) > thr) break; }
-          if (r < c) { atomicMin(&s_best, ((unsigned long long)k << 32) | r); break; }
-          cum = c2;
-        } else {
-          cum += (float)c * pk;
+        if (rbf(fmaf((float)c, pk, cum)) > thr) {
+          // inside the bin the prefix after n elements is cum + n pk (one rounding - closer to the wide accumulator of a
+          // library cumsum than n float32 additions, and monotone in n): the smallest n that crosses, by bisection.  (One
+          // addition per element on a single lane was 96 us of a 250 us call: 1900 elements share the crossing key.)
+          uint32_t lo_n = 1, hi_n = c;                      // invariant: n = hi_n crosses
+          while (lo_n < hi_n) {
+            const uint32_t mid = (lo_n + hi_n) >> 1;
+            if (rbf(fmaf((float)mid, pk, cum)) > thr) hi_n = mid;
+            else lo_n = mid + 1;
+          }
+          atomicMin(&s_best, ((unsigned long long)k << 32) | (hi_n - 1));     // hi_n - 1 elements stay below
+          break;
         }
+        cum = fmaf((float)c, pk, cum);
       }
     }
     __syncthreads();
+    STAMP();   // 4: crossing found
     const uint32_t tk = s_best == ~0ull ? 65536u : (uint32_t)(s_best >> 32);
     const uint32_t keep = tk < 65536 ? H(tk) - (uint32_t)(s_best & 0xffffffffu) : 0;
     // (no crossing at all - T(1 - top_p) rounds to 1 for top_p < 2^-9 in bf16 and the reference then removes EVERY token;
@@ -626,18 +744,19 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
       const uint32_t c = H(tk);
       // ascending stable sort: equal keys are in index order and the cumulative grows with the index,
       // so the LAST `keep` of the bin survive
-      if (keep < c) mask_equal_by_rank(lp, V, tk, c - keep, c, scan_u);
-      for (int i = tid; i < V; i += 1024)
-        if (bf_key(lp[i]) < tk) lp[i] = NEG_INF_BF;
+      if (keep < c) mask_equal_by_rank(lp, V, vec, tk, c - keep, c, scan_u);
+      STAMP(); // 5: ranks inside the crossing bin
+      row_update(lp, V, vec, [&](int, bf16_t xb) -> bf16_t { return bf_key(xb) < tk ? NEG_INF_BF : xb; });
     }
     __syncthreads();
+    STAMP();   // 6: masked
   }
 
   // ---- min-p (sample_utils.py:266-286): drop x < T(max + T(log(min_p))); min_tokens_to_keep > 1: the k largest are never
   // dropped (argpartition(kth=-k)[-k:]; ties at the k-th value: the HIGHEST indices - oracle/ops.py::apply_min_p)
   if (p.use_min_p) {
     float m = -INFINITY;
-    for (int i = tid; i < V; i += 1024) m = fmaxf(m, bf2f(lp[i]));
+    row_read(lp, V, vec, [&](int, bf16_t xb) { m = fmaxf(m, bf2f(xb)); });
     const float thr = rbf(bmax(m) + p.log_min_p);
     bool by_rank = false;
     if (p.min_keep > 1 && p.min_keep < V) {
@@ -661,14 +780,12 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
       if (need != 0xffffffffu && bf2f(key_bf(tk)) < thr) {
         by_rank = true;
         const uint32_t c = H(tk);
-        if (need < c) mask_equal_by_rank(lp, V, tk, c - need, c, scan_u);
-        for (int i = tid; i < V; i += 1024)
-          if (bf_key(lp[i]) < tk) lp[i] = NEG_INF_BF;
+        if (need < c) mask_equal_by_rank(lp, V, vec, tk, c - need, c, scan_u);
+        row_update(lp, V, vec, [&](int, bf16_t xb) -> bf16_t { return bf_key(xb) < tk ? NEG_INF_BF : xb; });
       }
     }
     if (!by_rank)
-      for (int i = tid; i < V; i += 1024)
-        if (bf2f(lp[i]) < thr) lp[i] = NEG_INF_BF;
+      row_update(lp, V, vec, [&](int, bf16_t xb) -> bf16_t { return bf2f(xb) < thr ? NEG_INF_BF : xb; });
     __syncthreads();
   }
 
@@ -677,21 +794,20 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
   // an index no vocabulary entry has.
   if (p.xtc_prob > 0.f && !(hash_uniform(p.seed, step, (uint32_t)b, 0xFFFFFFFFu) > p.xtc_prob)) {
     float m = -INFINITY;
-    for (int i = tid; i < V; i += 1024) m = fmaxf(m, bf2f(lp[i]));
+    row_read(lp, V, vec, [&](int, bf16_t xb) { m = fmaxf(m, bf2f(xb)); });
     m = bmax(m);
     float s = 0.f;
-    for (int i = tid; i < V; i += 1024) s += expf(bf2f(lp[i]) - m);
+    row_read(lp, V, vec, [&](int, bf16_t xb) { s += expf(bf2f(xb) - m); });
     const float den = block_sum(s, red);
     float cand = INFINITY;
-    for (int i = tid; i < V; i += 1024) {
-      const float pr = rbf(expf(bf2f(lp[i]) - m) / den);
+    row_read(lp, V, vec, [&](int, bf16_t xb) {
+      const float pr = rbf(expf(bf2f(xb) - m) / den);
       if (pr > p.xtc_thr) cand = fminf(cand, pr);
-    }
+    });
     cand = -bmax(-cand);
     if (tid < p.n_special) { const int t = p.xtc_special[tid]; s_special[tid] = (t >= 0 && t < V) ? lp[t] : (bf16_t)0; }
     __syncthreads();
-    for (int i = tid; i < V; i += 1024)
-      if (rbf(expf(bf2f(lp[i]) - m) / den) > cand) lp[i] = NEG_INF_BF;
+    row_update(lp, V, vec, [&](int, bf16_t xb) -> bf16_t { return rbf(expf(bf2f(xb) - m) / den) > cand ? NEG_INF_BF : xb; });
     __syncthreads();
     if (tid < p.n_special) { const int t = p.xtc_special[tid]; if (t >= 0 && t < V) lp[t] = s_special[tid]; }
     __syncthreads();
@@ -718,20 +834,40 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
     __syncthreads();
     const uint32_t tk = s_thr_key, keep = s_thr_keep;
     if (keep != 0xffffffffu) {
-      if (keep < H(tk)) mask_equal_by_rank(lp, V, tk, 0, keep, scan_u);
-      for (int i = tid; i < V; i += 1024)
-        if (bf_key(lp[i]) < tk) lp[i] = NEG_INF_BF;
+      if (keep < H(tk)) mask_equal_by_rank(lp, V, vec, tk, 0, keep, scan_u);
+      row_update(lp, V, vec, [&](int, bf16_t xb) -> bf16_t { return bf_key(xb) < tk ? NEG_INF_BF : xb; });
     }
     __syncthreads();
   }
 
-  // ---- categorical(logprobs / temp) via Gumbel-max with the counter hash RNG
-  const float it = 1.0f / p.temp;
+  STAMP();     // 7 (2 without top-p): filters done
+#ifdef VLM_SAMPLE_STAMPS
+  if (tid == 0) hist[31] = (uint32_t)n_stamp;
+#endif
+}
+
+// categorical(logprobs / temp) (sample_utils.py:385-387) by Gumbel-max with the counter hash RNG over the (filtered) row:
+// z_i = x_i / temp - log(-log(u_i)), u_i = hash(seed, step, row, i); the token is argmax z (lowest index on a tie).  NBLK
+// workgroups per row leave their best (z, i) where the greedy path leaves its candidates and argmax_final_kernel picks the
+// winner.  (Inside the one-workgroup-per-row filter kernel this pass was 45-52 us of hash + two logs per element on ONE CU.)
+__global__ __launch_bounds__(256) void gumbel_partial_kernel(const bf16_t* __restrict__ lp_all, int ldlp, int V, float temp,
+                                                             uint32_t seed, const int* __restrict__ step_ptr,
+                                                             float* __restrict__ cand_v, int* __restrict__ cand_i) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+  const uint32_t step = (uint32_t)(step_ptr ? *step_ptr : 0);
+  const int per = ((V + NBLK - 1) / NBLK + 7) & ~7;
+  const int lo = blk * per, hi = min(V, lo + per);
+  const bf16_t* row = lp_all + (size_t)b * ldlp;
+  const float it = 1.0f / temp;
   float best = -INFINITY;
   int besti = 0x7fffffff;
-  for (int i = tid; i < V; i += 1024) {
-    const float x = bf2f(lp[i]) * it;
-    const float u = hash_uniform(p.seed, step, (uint32_t)b, (uint32_t)i);
+  for (int i = lo + tid; i < hi; i += 256) {
+    const bf16_t xb = row[i];
+    if (xb == NEG_INF_BF) continue;                     // (a removed token cannot win: -inf + gumbel = -inf)
+    const float x = bf2f(xb) * it;
+    const float u = hash_uniform(seed, step, (uint32_t)b, (uint32_t)i);
     const float z = x + (-logf(-logf(u)));
     if (z > best || (z == best && i < besti)) { best = z; besti = i; }
   }
@@ -741,13 +877,13 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
     const int oi = __shfl_xor(besti, o, 64);
     if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
   }
-  __syncthreads();
-  if ((tid & 63) == 0) { red[tid >> 6] = best; redi[tid >> 6] = besti; }
+  if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = besti; }
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < 16; ++w)
-      if (red[w] > best || (red[w] == best && redi[w] < besti)) { best = red[w]; besti = redi[w]; }
-    tok[b] = besti;
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < besti)) { best = sv[w]; besti = si[w]; }
+    cand_v[(size_t)b * NBLK + blk] = best;
+    cand_i[(size_t)b * NBLK + blk] = besti;
   }
 }
 
@@ -839,12 +975,21 @@ extern "C" int vlm_sample_ex(const void* logits, int ld, int B, int V, void* log
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_filter_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (attr != hipSuccess) return VLM_ERR_HIP + (int)attr;
-    if (lp_given)
-      hipLaunchKernelGGL(sample_filter_kernel, dim3(B), dim3(1024), LDS, st, (const bf16_t*)logits, ld, (bf16_t*)scratch, ldlp,
-                         V, hist, k, (const int*)step_ptr, (int*)tok);
-    else
-      hipLaunchKernelGGL(sample_filter_kernel, dim3(B), dim3(1024), LDS, st, (const bf16_t*)logprobs, ldlp, (bf16_t*)scratch,
-                         ldlp, V, hist, k, (const int*)step_ptr, (int*)tok);
+    const bf16_t* row_in = lp_given ? (const bf16_t*)logits : (const bf16_t*)logprobs;
+    int ld_in = lp_given ? ld : ldlp;
+    const bool any_filter = k.use_top_p || k.use_min_p || k.top_k > 0 || k.n_sigma > 0.f || k.p_less || k.use_typical || k.xtc_prob > 0.f;
+    if (any_filter) {
+      hipLaunchKernelGGL(sample_filter_kernel, dim3(B), dim3(1024), LDS, st, row_in, ld_in, (bf16_t*)scratch, ldlp, V, hist, k,
+                         (const int*)step_ptr);
+      VLM_CHECK_LAUNCH();
+      row_in = (const bf16_t*)scratch;
+      ld_in = ldlp;
+    }
+    // (no filter: the draw runs over the log-probs themselves; `scratch` is left untouched)
+    hipLaunchKernelGGL(gumbel_partial_kernel, dim3(NBLK, B), dim3(256), 0, st, row_in, ld_in, V, k.temp, k.seed,
+                       (const int*)step_ptr, cand_v, cand_i);
+    VLM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(B), dim3(64), 0, st, cand_v, cand_i, (int*)tok);
   }
   VLM_CHECK_LAUNCH();
   return VLM_OK;

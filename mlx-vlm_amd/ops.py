@@ -408,7 +408,12 @@ def sample(logits, temperature=0.0, top_p=1.0, min_p=0.0, top_k=0, seed=0, step=
     del keep                           # (allocated and freed on the launch's own stream: the caching allocator orders reuse)
     if lp_given:
         lp = logits
-    return (tok, lp, scratch) if return_filtered else (tok, lp)
+    if return_filtered:
+        # (no filter on: the kernel draws from the log-probs themselves and leaves the scratch row alone)
+        any_filter = temperature > 0 and (0.0 < top_p < 1.0 or min_p != 0.0 or top_k > 0 or top_n_sigma > 0.0 or p_less
+                                          or 0.0 < typical_p < 1.0 or xtc_probability > 0.0)
+        return tok, lp, (scratch if any_filter else lp)
+    return tok, lp
 
 
 def sample_greedy_advance(logits, tok, ctx, pos, step, embed, h, out_ring=None, want_logprobs=True, ws=None):

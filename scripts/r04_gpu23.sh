@@ -27,6 +27,6 @@ for name, kw in (("top_p", dict(top_p=0.9)), ("classic chain", dict(top_p=0.9, m
     for _ in range(10):
         ops.sample(x, temperature=0.8, step=step, want_logprobs=False, **kw)
     b.record(); torch.cuda.synchronize()
-    print(f"{name:16s} {a.elapsed_time(b) * 100:.1f} us per vlm_sample_ex call (V = {V}, 1 row, 3 launches + allocations)")
+    print(f"{name:16s} {a.elapsed_time(b) * 100:.1f} us per vlm_sample_ex call (V = {V}, 1 row, 4-5 launches + allocations)")
 P
 cat $O/timing.log
