@@ -68,6 +68,30 @@ def run_step(model, req, max_tokens, lookahead):
     return t_first - t0, t1 - t_first, toks
 
 
+def sampled_decode_throughput(model, req, max_tokens, lookahead):
+    """The same request decoded with a SAMPLER in the captured step instead of the greedy tail (reference make_sampler,
+    sample_utils.py:10-89: temperature 0.7 alone, + top_p 0.9, + the top-p / min-p / top-k chain) - what csrc/sample.hip's
+    filter + Gumbel launches add to a decode step.  One warm pass, one timed pass each."""
+    from mlx_vlm_amd.generate import generate_step
+
+    ids, pix, thw = req
+    out = {}
+    for name, kw in (("temperature_0.7", {}), ("top_p_0.9", dict(top_p=0.9)), ("top_p_0.9_min_p_0.02_top_k_50", dict(top_p=0.9, min_p=0.02, top_k=50))):
+        dec = 0.0
+        for rep in range(2):
+            gen = generate_step(ids, model, pix, None, max_tokens=max_tokens, temperature=0.7, seed=1234, image_grid_thw=thw,
+                                return_logprobs=False, lookahead=lookahead, **kw)
+            n, t_first = 0, None
+            for _tok, _ in gen:
+                if t_first is None:
+                    t_first = time.perf_counter()
+                n += 1
+            torch.cuda.synchronize()
+            dec = time.perf_counter() - t_first
+        out[name] = {"generation_tps": (n - 1) / dec, "decode_us_per_token": dec / (n - 1) * 1e6}
+    return out
+
+
 def time_events(fn, reps):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
@@ -1105,7 +1129,8 @@ def main():
         for key, fn in (("batch8", lambda: batch_decode_throughput(model, cfg, 8, 64)),
                         ("batch16", lambda: batch_decode_throughput(model, cfg, 16, 64)),
                         ("wide64", lambda: wide_decode_throughput(model, cfg, 64, 48)),
-                        ("continuous", lambda: continuous_batch_throughput(model, cfg))):
+                        ("continuous", lambda: continuous_batch_throughput(model, cfg)),
+                        ("sampled", lambda: sampled_decode_throughput(model, req, 128, args.lookahead))):
             if ws > 1:
                 extras[key] = None
                 continue
@@ -1170,6 +1195,7 @@ def main():
             out["batch16_decode"] = extras.get("batch16")
             out["wide64_decode"] = extras.get("wide64")
             out["continuous_batching"] = extras["continuous"]
+            out["sampled_decode"] = extras.get("sampled")
             out["vision_single_448_images_per_s"] = ips448
             out["vision_single_448_tflops"] = ips448 * VIT_TFLOP_448
         if cpu is not None:
