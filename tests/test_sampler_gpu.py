@@ -220,3 +220,52 @@ def test_sampler_spec_is_callable_on_logprobs_and_generate_step_takes_the_keywor
         keep = _kept(O.sampler_filters(row, 0.9, typical_p=0.8, top_k=30))[0]
         near = row.float()[0, t] >= row.float()[0][keep].min() - 2.0 ** -6 * abs(float(row.float()[0][keep].min()))
         assert bool(keep[t]) or bool(near), t
+
+
+def test_batch_generator_runs_a_sampler_with_the_extra_filters(vops):
+    """BatchGenerator(sampler=make_sampler(top_n_sigma=..., min_tokens_to_keep=...)) (reference ar.py:2584-2606 takes any
+    sampler): the filters the captured step does not carry run through vlm_sample_ex around an eager step, all rows in one
+    call; every token drawn is a survivor of the oracle's chain on that row's log-probs (or sits on its edge)."""
+    import dataclasses
+
+    from mlx_vlm_amd.batch import BatchGenerator
+    from mlx_vlm_amd.sample_utils import Sampler, make_sampler
+    from oracle import qwen2_vl as oq
+    from tests.helpers import build_product_model
+
+    seen = []
+
+    class Recording(Sampler):
+        def __call__(self, logprobs):
+            tok = super().__call__(logprobs)
+            seen.append((logprobs.detach().to(BF).cpu(), tok.cpu()))
+            return tok
+
+    cfg = oq.tiny_cfg()
+    W = oq.random_weights(cfg, seed=1234, dtype=BF, std=0.05, embed_std=0.2)
+    model = build_product_model(cfg, W, kv_pool_tokens=8192, max_seqs=24)
+    kw = dict(top_n_sigma=1.5, min_p=0.3, min_tokens_to_keep=5)
+    smp = Recording(**dataclasses.asdict(make_sampler(temp=0.9, seed=21, **kw)))
+    assert smp.extended
+    gen = BatchGenerator(model, None, max_tokens=6, completion_batch_size=4, prefill_batch_size=2, sampler=smp)
+    rng = np.random.default_rng(8)
+    uids = gen.insert([rng.integers(3, 1000, n) for n in (9, 17, 30, 12, 25)], [6, 5, 6, 4, 6])
+    got = {u: [] for u in uids}
+    while gen.has_work:
+        _, out = gen.next()
+        for r in out:
+            got[r.uid].append(r.token)
+    gen.close()
+    assert [len(got[u]) for u in uids] == [6, 5, 6, 4, 6]
+    assert len(seen) >= 5
+    n = 0
+    for lp, tok in seen:
+        lp2 = lp.reshape(-1, lp.shape[-1])
+        ref = O.sampler_filters(lp2, 0.9, **kw)
+        for b in range(lp2.shape[0]):
+            keep = _kept(ref[b])
+            lo = float(lp2[b].float()[keep].min())
+            t = int(tok.reshape(-1)[b])
+            assert bool(keep[t]) or float(lp2[b, t]) >= lo - 2.0 ** -6 * abs(lo), (b, t)
+            n += 1
+    assert n >= 20
