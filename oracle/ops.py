@@ -289,6 +289,83 @@ class KVCache:
         return n
 
 
+class RotatingKVCache:
+    """RotatingKVCache (cache.py:442-625) as make_prompt_cache builds it for `max_kv_size` (cache.py:65-68: keep = 4): the
+    first `keep` tokens stay for ever; a multi-token update (the prompt) is kept WHOLE (_update_concat on an empty cache; a later
+    one would first put the buffer in temporal order and trim it to max_size - 1 + S); a one-token update (_update_in_place)
+    grows the buffer up to max_size, cuts a longer buffer down to keep + the most recent max_size - keep, and once the write
+    index reaches max_size wraps it to `keep` - the new token overwrites the oldest entry that is not a sink.
+    `_idx` (the write index) is what the language models read as the cache offset (qwen2_vl/language.py:430: `c0._idx if
+    hasattr(c0, "_idx")`): after the first wrap the rope position of a decoded token is its RING index, not its count."""
+
+    def __init__(self, max_size: int, keep: int = 0):
+        self.keep, self.max_size = keep, max_size
+        self.keys = self.values = None
+        self.offset = 0
+        self._idx = 0
+
+    def _temporal(self, v):
+        if self._idx == v.shape[2]:
+            return v
+        if self._idx < self.offset:
+            return torch.cat([v[..., :self.keep, :], v[..., self._idx:, :], v[..., self.keep:self._idx, :]], dim=2)
+        return v[..., :self._idx, :]
+
+    def _cut(self, n, v, append=None):
+        parts = [v[..., :self.keep, :], v[..., n + self.keep:, :]] if n > 0 else [v]
+        if append is not None:
+            parts.append(append)
+        return torch.cat(parts, dim=2)
+
+    def update_and_fetch(self, keys, values):
+        S = keys.shape[2]
+        if S != 1:                                                      # _update_concat (cache.py:486-505)
+            if self.keys is None:
+                self.keys, self.values = keys, values
+            else:
+                self.keys, self.values = self._temporal(self.keys), self._temporal(self.values)
+                self._idx = self.keys.shape[2]
+                n = self._idx - self.max_size + 1
+                self.keys, self.values = self._cut(n, self.keys, keys), self._cut(n, self.values, values)
+            self.offset += S
+            self._idx = self.keys.shape[2]
+            return self.keys, self.values
+        prev = self.offset                                              # _update_in_place (cache.py:507-547)
+        if self.keys is None or (prev >= self.keys.shape[2] and self.keys.shape[2] < self.max_size):
+            B, H, _, D = keys.shape
+            grow = min(256, self.max_size - prev)
+            zk = torch.zeros(B, H, grow, D, dtype=keys.dtype)
+            zv = torch.zeros(B, H, grow, values.shape[3], dtype=values.dtype)
+            self.keys = zk if self.keys is None else torch.cat([self.keys, zk], dim=2)
+            self.values = zv if self.values is None else torch.cat([self.values, zv], dim=2)
+            self._idx = prev
+        n = self.keys.shape[2] - self.max_size
+        if n > 0:
+            self.keys, self.values = self._cut(n, self.keys), self._cut(n, self.values)
+            self._idx = self.max_size
+        if self._idx == self.max_size:
+            self._idx = self.keep
+        self.keys[..., self._idx:self._idx + 1, :] = keys
+        self.values[..., self._idx:self._idx + 1, :] = values
+        self.offset += 1
+        self._idx += 1
+        if self.offset < self.max_size:
+            return self.keys[..., :self.offset, :], self.values[..., :self.offset, :]
+        return self.keys, self.values
+
+    def size(self):
+        return min(self.offset, self.max_size)
+
+    def is_trimmable(self):
+        return self.offset < self.max_size
+
+    def trim(self, n):
+        n = min(self.offset, n)
+        self.offset -= n
+        self._idx -= n
+        return n
+
+
 # --------------------------------------------------------------------------
 # sampling (generate/ar.py:368; sample_utils.py)
 # --------------------------------------------------------------------------

@@ -424,12 +424,25 @@ def get_input_embeddings(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_t
     return emb, pos, deltas
 
 
+def _make_prompt_cache(cfg: Cfg, max_kv_size: Optional[int] = None):
+    """make_prompt_cache (cache.py:45-70): the built families define no make_cache, so `max_kv_size` gives every layer a
+    RotatingKVCache(max_size, keep=4)"""
+    n = cfg.text.num_hidden_layers
+    return [ops.RotatingKVCache(max_kv_size, keep=4) for _ in range(n)] if max_kv_size is not None else [ops.KVCache() for _ in range(n)]
+
+
+def _cache_offset(c0) -> int:
+    """what LanguageModel.__call__ reads as the cache offset (language.py:426-431): the WRITE INDEX of a rotating cache"""
+    return c0._idx if hasattr(c0, "_idx") else c0.offset
+
+
 # --------------------------------------------------------------------------
 # generate_step, greedy (generate/ar.py:151-515)
 # --------------------------------------------------------------------------
 def generate_greedy(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_thw=None,
                     max_tokens: int = 16, rope_mode: str = "fused", return_logits: bool = False, processors=None,
-                    kv_bits=None, kv_group_size: int = 64, quantized_kv_start: int = 0, return_logprobs: bool = False):
+                    kv_bits=None, kv_group_size: int = 64, quantized_kv_start: int = 0, return_logprobs: bool = False,
+                    max_kv_size: Optional[int] = None):
     """generate_step with temperature 0: embeds -> full-prompt prefill ->
     logits[:, -1] -> logprobs = logits - logsumexp -> argmax -> decode loop with
     pos = cache offset + rope_delta (language.py:476-509)."""
@@ -437,7 +450,7 @@ def generate_greedy(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_thw=No
     assert input_ids.shape[0] == 1
     emb, pos, deltas = get_input_embeddings(W, cfg, input_ids, pixel_values, image_grid_thw)
     pos_t = torch.from_numpy(np.asarray(pos))
-    cache = [ops.KVCache() for _ in range(cfg.text.num_hidden_layers)]
+    cache = _make_prompt_cache(cfg, max_kv_size)
     from . import quant
     h = qwen2_model(W, cfg, emb, cache, pos_t, rope_mode)
     logits = lm_head(W, cfg, h)[:, -1, :]
@@ -457,7 +470,7 @@ def generate_greedy(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_thw=No
             break
         e = embed_tokens(W, np.array([[y]]))
         fed.append(y)
-        p = cache[0].offset + delta
+        p = _cache_offset(cache[0]) + delta
         pid = torch.full((3, 1, 1), p, dtype=torch.long)
         h = qwen2_model(W, cfg, e, cache, pid, rope_mode)
         logits = lm_head(W, cfg, h)[:, -1, :]
@@ -492,14 +505,14 @@ def peak_head(W, cfg: Cfg, gamma: float = 1.0, stride: int = 389, n_cycle: Optio
 
 def decode_teacher_forced(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_thw=None, forced_tokens=(),
                           rope_mode: str = "fused", return_features: bool = False, kv_bits=None, kv_group_size: int = 64,
-                          quantized_kv_start: int = 0, kv_batch_policy: bool = False):
+                          quantized_kv_start: int = 0, kv_batch_policy: bool = False, max_kv_size: Optional[int] = None):
     """generate_step's device work (generate/ar.py:334-389) with the FED tokens prescribed: full-prompt prefill, then one
     decode forward per forced token at pos = cache offset + rope_delta (language.py:476-509).
     -> logits [1 + len(forced_tokens), V]: row 0 = last prompt row, row i = after feeding forced_tokens[i-1]."""
     input_ids = np.asarray(input_ids)
     assert input_ids.shape[0] == 1
     emb, pos, deltas = get_input_embeddings(W, cfg, input_ids, pixel_values, image_grid_thw)
-    cache = [ops.KVCache() for _ in range(cfg.text.num_hidden_layers)]
+    cache = _make_prompt_cache(cfg, max_kv_size)
     from . import quant
     h = qwen2_model(W, cfg, emb, cache, torch.from_numpy(np.asarray(pos)), rope_mode)
     quant.maybe_quantize_kv_cache(cache, quantized_kv_start, kv_group_size, kv_bits, kv_batch_policy)    # ar.py:362: after every forward
@@ -507,7 +520,7 @@ def decode_teacher_forced(W, cfg: Cfg, input_ids, pixel_values=None, image_grid_
     delta = int(deltas[0, 0])
     for y in forced_tokens:
         e = embed_tokens(W, np.array([[int(y)]]))
-        pid = torch.full((3, 1, 1), cache[0].offset + delta, dtype=torch.long)
+        pid = torch.full((3, 1, 1), _cache_offset(cache[0]) + delta, dtype=torch.long)
         h = qwen2_model(W, cfg, e, cache, pid, rope_mode)
         quant.maybe_quantize_kv_cache(cache, quantized_kv_start, kv_group_size, kv_bits, kv_batch_policy)
         rows.append(lm_head(W, cfg, h)[0, -1])
