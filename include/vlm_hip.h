@@ -386,6 +386,13 @@ typedef struct vlm_kv_pool {
   int q8_skip_last;
 } vlm_kv_pool;
 
+/* max_kv_size (RotatingKVCache, models/cache.py:442-625; make_prompt_cache cache.py:45-70 builds it with keep = 4): entry i
+ * moves the cached token of sequence seq[i] at slot src_slot[i] to slot dst_slot[i] in EVERY layer (bf16 pools).  The source
+ * and destination SETS of one call must be disjoint.  The host keeps the ring (which slot holds which token); the engine's
+ * rule stays "write at slot = entries held, attend over entries held + 1" (csrc/kv_rotate.hip).  int32 device arrays [T]. */
+int vlm_kv_move_tokens(void* kpool, void* vpool, size_t layer_stride, int n_layers, const void* seq, const void* src_slot,
+                       const void* dst_slot, int T, const void* block_table, int max_pages, int Hkv, int D, void* stream);
+
 /* prefill over T tokens (all sequences concatenated).  h [T][hidden] holds the input
  * embeddings and is the residual stream (overwritten).  Workspaces are caller-owned:
  * xn [T][hidden], qkv [T][(Hq+2Hkv)*D], attn [T][Hq*D], act [T][inter].

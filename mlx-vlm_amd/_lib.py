@@ -145,6 +145,8 @@ SIGNATURES = {
     "vlm_sample_workspace_bytes": (c_size_t, [c_int]),
     "vlm_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float,
                            c_float, c_float, c_int, c_uint, c_void_p, c_void_p]),
+    "vlm_kv_move_tokens": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                   c_int, c_int, c_void_p]),
     "vlm_sample_sort_workspace_bytes": (c_size_t, [c_int, c_int]),
     "vlm_sample_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                               C.POINTER(SamplerParams), c_void_p, c_void_p]),

@@ -160,6 +160,9 @@ class BatchGenerator:
             # token; accepted and, as there, without effect
             if getattr(self.lm if hasattr(self, "lm") else model.language_model, "head_dim", 128) != 128:
                 raise NotImplementedError("BatchGenerator(kv_bits=8): the 8-bit KV kernels are built for 128-wide heads")
+        if kwargs.get("max_kv_size"):
+            # reference ar.py:831-834 (to_batch_cache): make_prompt_cache's RotatingKVCache has keep = 4
+            raise ValueError("RotatingKVCache with keep tokens is not supported.")
         unsupported = {k: v for k, v in kwargs.items() if v not in (None, False, 0, [], ())
                        and k not in ("prefill_step_size", "greedy_sampling", "stream")}
         if unsupported:

@@ -199,11 +199,13 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
             raise NotImplementedError("penalty keyword arguments and a make_logits_processors spec: pass one of them")
         procs = extra_specs[0]
     thinking_budget_criteria = kwargs.pop("thinking_budget_criteria", None)
-    for k in ("max_kv_size", "draft_model"):
-        if kwargs.pop(k, None):
-            # the reference would switch cache class / decoding scheme (RotatingKVCache, speculative): dropping the request
-            # silently would change results without telling the caller
-            raise NotImplementedError(f"{k} is outside the built hot path (SURVEY section 8f.4)")
+    if kwargs.pop("draft_model", None):
+        # the reference would switch the decoding scheme (speculative): dropping the request silently would change results
+        # without telling the caller
+        raise NotImplementedError("draft_model is outside the built hot path (SURVEY section 8f.4)")
+    # reference ar.py:173,310-315: make_prompt_cache(model.language_model, max_kv_size) - a RotatingKVCache(max_kv_size, keep=4)
+    # per layer when the caller brings no prompt_cache.  Here: a bound on the paged sequence, served by eager steps
+    max_kv_size = kwargs.pop("max_kv_size", None)
     # uniform quantized KV cache (reference ar.py:174-181,249-260,362: maybe_quantize_kv_cache after EVERY forward): from the
     # first forward that leaves the cache at quantized_kv_start tokens or more, the cache is a QuantizedKVCache
     kv_bits = kwargs.pop("kv_bits", None)
@@ -220,7 +222,7 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
     smp, py_sampler = _resolve_sampler(sampler, temperature, top_p, min_p, top_k, seed, top_n_sigma=kwargs.pop("top_n_sigma", None),
                                        p_less=kwargs.pop("p_less", None), typical_p=kwargs.pop("typical_p", None))
     sargs = smp.engine_args()
-    eager = bool(py_procs) or py_sampler is not None or thinking_budget_criteria is not None
+    eager = bool(py_procs) or py_sampler is not None or thinking_budget_criteria is not None or max_kv_size is not None
     lm = model.language_model
 
     ids = input_ids.detach().cpu().numpy() if isinstance(input_ids, torch.Tensor) else np.asarray(input_ids)
@@ -239,7 +241,17 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
         f.rope_deltas = np.asarray(delta_override)
     own_cache = prompt_cache is None
     if own_cache:
-        prompt_cache = cache_mod.make_prompt_cache(lm)
+        prompt_cache = cache_mod.make_prompt_cache(lm, max_kv_size=max_kv_size)
+    if prompt_cache[0]._seq.rotating:
+        eager = True                                   # (also a caller's own make_prompt_cache(lm, max_kv_size=...))
+        if kv_bits is not None:
+            raise NotImplementedError("RotatingKVCache Quantization NYI")          # the reference's words (cache.py:583-584)
+        # the reference prefills prompts beyond prefill_step_size in chunks (ar.py:425-470) and a rotating cache trims its
+        # window between chunks (cache.py:486-505): only the single-chunk prompt is built
+        if prefill_step_size is not None and ids.shape[1] > int(prefill_step_size):
+            raise NotImplementedError(f"max_kv_size with a prompt of {ids.shape[1]} tokens > prefill_step_size {prefill_step_size}: "
+                                      "the reference feeds such a prompt in chunks and its rotating cache re-orders / trims the "
+                                      "window between them; pass a larger prefill_step_size (one chunk) ")
     emb = f.inputs_embeds
     L = emb.shape[1]
     pos = np.asarray(f.position_ids)

@@ -178,8 +178,91 @@ class PagedSequence:
         self.offset = 0          # tokens stored (== the reference's KVCache.offset)
         self.released = False
         self.q8 = False          # True once the sequence's cache has become a QuantizedKVCache (LanguageModel.quantize_kv)
+        # max_kv_size (reference RotatingKVCache, cache.py:442-625): None = unbounded.  `held` = entries the pool holds for this
+        # sequence (== offset until the window is full), `ring` = the non-sink slots in the age order of their tokens
+        self.max_size: Optional[int] = None
+        self.keep = 0
+        self.held = 0
+        self.ring = None
+        self.ring_idx = 0        # the reference's `_idx` (what its Qwen2-VL reads as the cache offset, language.py:426-431)
+
+    # ------------------------------------------------------------------ max_kv_size
+    def set_rotating(self, max_size: int, keep: int = 4):
+        if self.offset:
+            raise ValueError("max_kv_size is set on an empty cache")
+        if int(max_size) <= keep + 1:
+            raise ValueError(f"max_kv_size has to exceed keep + 1 = {keep + 1} (the window holds the sinks, the staging slot and "
+                             f"at least one more token), got {max_size}")
+        self.max_size, self.keep = int(max_size), int(keep)
+
+    @property
+    def rotating(self) -> bool:
+        return self.max_size is not None
+
+    @property
+    def kv_entries(self) -> int:
+        """entries a decode step finds in the pool (the engine writes its token at this slot and attends over one more)"""
+        return self.held if self.rotating else self.offset
+
+    @property
+    def rope_offset(self) -> int:
+        """the offset a family that reads `cache._idx` adds its rope delta to (Qwen2-VL); the others use `offset`"""
+        return self.ring_idx if self.rotating else self.offset
+
+    def note_prefill(self, n_tokens: int):
+        """after a prompt of n_tokens landed at slots [held, held + n): the reference's _update_concat keeps a first prompt whole
+        (cache.py:486-505); a SECOND multi-token update would trim the buffer to max_size - 1 + S first - not built"""
+        if not self.rotating:
+            return
+        if self.held:
+            raise NotImplementedError("max_kv_size: a second multi-token update of the rotating cache (chunked prefill / a "
+                                      "prompt-cache continuation) trims the window in the reference; only the first prompt is built")
+        self.held = self.ring_idx = n_tokens
+
+    def rotate_plan(self):
+        """What has to move before the next ONE-token step so that the pool holds what the reference's _update_in_place leaves
+        (cache.py:507-547) minus the token about to be written: -> (src_slots, dst_slots) or None.  Updates held / ring /
+        ring_idx as the reference's trim + wrap do."""
+        if not self.rotating:
+            return None
+        M, K = self.max_size, self.keep
+        plan = None
+        if self.held > M:
+            # a prompt longer than the window: the reference cuts the buffer to keep + the most recent M - keep and then
+            # overwrites the oldest of those: sinks + the last M - keep - 1 tokens stay; survivors beyond slot M - 2 move into
+            # the holes below it (disjoint sets, any pairing)
+            L = self.held
+            first = L - (M - K - 1)                                   # oldest surviving non-sink token (slot == token index)
+            stay = [t for t in range(first, L) if t < M - 1]
+            src = [t for t in range(first, L) if t >= M - 1]
+            holes = [sl for sl in range(K, M - 1) if sl < first]
+            assert len(src) == len(holes), (len(src), len(holes))
+            where = {t: t for t in stay}
+            where.update(dict(zip(src, holes)))
+            self.ring = [where[t] for t in range(first, L)]           # age order
+            self.held = M - 1
+            self.ring_idx = K                                         # trim -> _idx = max_size -> wraps to keep
+            plan = (src, holes)
+        elif self.held == M:
+            if self.ring is None:                                     # first time full: slot == token index
+                self.ring = list(range(K, M - 1))
+            oldest = self.ring.pop(0)
+            self.ring.append(oldest)                                  # the newest token (staging slot M - 1) moves there
+            self.held = M - 1
+            if self.ring_idx >= M:
+                self.ring_idx = K
+            plan = ([M - 1], [oldest])
+        return plan
+
+    def note_decode_step(self):
+        """one token was written at slot `held` (ring position ring_idx) and the offset grew"""
+        if self.rotating:
+            self.held += 1
+            self.ring_idx += 1
 
     def reserve(self, n_total_tokens: int):
+        if self.rotating and self.held:          # (decode: the window never grows past max_size; the prompt itself is kept whole)
+            n_total_tokens = min(n_total_tokens, max(self.held, self.max_size) + 1)
         self.pool.ensure(self.seq, self.pages, n_total_tokens)
 
     def release(self):
@@ -213,20 +296,37 @@ class KVCache:
         self._seq.offset = int(v)
 
     def size(self):
-        return self._seq.offset
+        s = self._seq
+        return min(s.offset, s.max_size) if s.rotating else s.offset      # RotatingKVCache.size (cache.py:554-555)
 
     def empty(self):
         return self._seq.offset == 0
 
+    @property
+    def max_size(self):
+        return self._seq.max_size
+
+    @property
+    def keep(self):
+        return self._seq.keep
+
     def is_trimmable(self):
-        return True
+        s = self._seq
+        return s.offset < s.max_size if s.rotating else True              # cache.py:574-575
 
     def trim(self, n):
         # all layer views share the sequence: only layer 0 moves the offset so that
         # `for c in cache: c.trim(n)` (reference dispatch.py:868-870) trims once
-        n = min(self._seq.offset, n)
+        s = self._seq
+        n = min(s.offset, n)
         if self._layer == 0:
-            self._seq.offset -= n
+            if s.rotating and n and s.ring is not None:
+                raise NotImplementedError("trim of a rotating cache whose window has wrapped (the reference moves offset and _idx "
+                                          "only, cache.py:577-581: its buffer then holds tokens the offset no longer counts)")
+            s.offset -= n
+            if s.rotating:
+                s.held -= n
+                s.ring_idx -= n
         return n
 
     @property
@@ -254,7 +354,12 @@ class KVCache:
 
 
 def make_prompt_cache(model, max_kv_size: Optional[int] = None):
-    """reference cache.py:45-70: defer to model.make_cache() when present."""
-    if hasattr(model, "make_cache"):
-        return model.make_cache()
-    raise ValueError("make_prompt_cache: the language model must provide make_cache() (paged pool owner)")
+    """reference cache.py:45-70.  There the built families define no `make_cache`, so `max_kv_size` gives every layer a
+    RotatingKVCache(max_size=max_kv_size, keep=4); here `make_cache` is the paged pool's allocator and the bound becomes a
+    property of the sequence all layer facades share (PagedSequence.set_rotating)."""
+    if not hasattr(model, "make_cache"):
+        raise ValueError("make_prompt_cache: the language model must provide make_cache() (paged pool owner)")
+    caches = model.make_cache()
+    if max_kv_size is not None:
+        caches[0]._seq.set_rotating(int(max_kv_size), keep=4)
+    return caches

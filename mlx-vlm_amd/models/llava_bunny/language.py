@@ -31,6 +31,7 @@ ENGINE_HEAD_DIM = 128
 
 
 class LanguageModel(_Engine):
+    ROTATING_POS_FROM_RING = False     # rope offset of a decode step over a rotating cache = cache.offset (the reference's own read)
     def __init__(self, args: TextConfig, config: ModelConfig, device="cuda", **engine_kwargs):
         hd = args.hidden_size // args.num_attention_heads
         if hd > ENGINE_HEAD_DIM or hd % 2:

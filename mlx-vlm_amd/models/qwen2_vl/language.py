@@ -494,10 +494,14 @@ class LanguageModel:
               "llm_prefill")
         for n, s in zip(lengths, seqs):
             s.offset += n
+            s.note_prefill(n)
         self._keep = (h, xn, qkv, attn, act, xlast, pos_d, meta, rows_d)  # keep alive until the stream has run
         return logits
 
     def _prefill_onto_cache(self, inputs_embeds, position_ids, caches, lengths, logits_rows, reserve_extra):
+        if any(c[0]._seq.rotating for c in caches):
+            raise NotImplementedError("max_kv_size: a multi-token update of a non-empty rotating cache (the reference first trims "
+                                      "the window to max_size - 1 + S, cache.py:486-505) is not built; only the first prompt")
         """A prompt chunk appended to a NON-EMPTY cache: chunked prefill (reference ar.py:426-472) and `prompt_cache=`
         continuation across calls, i.e. multi-turn (dispatch.py:861-882, common.py:243-263).  The chunk's queries attend
         to [cached tokens | the chunk] (cache.py:345-367 + base.py:366-373 with the causal mask offset by the cache
@@ -587,6 +591,8 @@ class LanguageModel:
         caches = [cache] if isinstance(cache[0], KVCache) else cache
         if B not in (1, 2, 4, 8) or len(caches) != B or any(c[0].offset == 0 for c in caches):
             return None
+        if any(c[0]._seq.rotating for c in caches):       # max_kv_size: the host makes room before every step (the module call)
+            return None
         deltas = self._rope_deltas if self._rope_deltas is not None else np.zeros((B, 1), dtype=np.int64)
         deltas = np.broadcast_to(np.asarray(deltas).reshape(-1, 1), (B, 1)) if np.asarray(deltas).size == 1 else np.asarray(deltas)
         try:
@@ -604,7 +610,37 @@ class LanguageModel:
             self._decode_states[B] = st
         return st
 
-    def decode_begin(self, caches: List[List[KVCache]], first_tokens, rope_deltas, max_new_tokens: int) -> DecodeState:
+    # max_kv_size: the family's rule for the rope offset of a decode step over a RotatingKVCache.  The reference's Qwen2-VL reads
+    # `cache[0]._idx` - the ring's WRITE INDEX - where the cache has one (qwen2_vl/language.py:426-431), so after the first wrap
+    # a token's rope position is its ring index; the plain-rope families read `cache.offset` (llava_bunny/language.py:65-66,
+    # idefics2/language.py:54-55, phi3_v/phi3_v.py:82-83)
+    ROTATING_POS_FROM_RING = True
+
+    def _rotate_windows(self, seqs) -> np.ndarray:
+        """Before a one-token step over sequences with max_kv_size: read each one's rope offset (BEFORE the ring wraps, as the
+        reference's forward does), then make room as RotatingKVCache._update_in_place would (cache.py:507-547) - the moves of
+        PagedSequence.rotate_plan in one vlm_kv_move_tokens launch.  -> rope offsets int32 [B]"""
+        if any(s.q8 for s in seqs if s.rotating):
+            raise NotImplementedError("RotatingKVCache Quantization NYI")          # (the reference's own words, cache.py:583-584)
+        rope_pos = np.array([(s.rope_offset if self.ROTATING_POS_FROM_RING else s.offset) for s in seqs], dtype=np.int32)
+        rows, src, dst = [], [], []
+        for s in seqs:
+            plan = s.rotate_plan()
+            if plan:
+                rows += [s.seq] * len(plan[0])
+                src += list(plan[0])
+                dst += list(plan[1])
+        if rows:
+            pool = self.pool
+            dev = _lib.h2d(np.array([rows, src, dst], dtype=np.int32), self.device)
+            check(_lib.lib().vlm_kv_move_tokens(pool.kpool.data_ptr(), pool.vpool.data_ptr(), pool.layer_stride, pool.n_layers,
+                                                dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), len(rows),
+                                                pool.block_table.data_ptr(), pool.max_pages, pool.n_kv_heads, pool.head_dim,
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "kv_move_tokens")
+            self._keep_rot = dev
+        return rope_pos
+
+    def decode_begin(self, caches: List[List[KVCache]], first_tokens, rope_deltas, max_new_tokens: int, rope_pos=None) -> DecodeState:
         """Bind B sequences (B in {1,2,4,8}) to the device decode state: tok = first sampled tokens,
         ctx = cache offsets, pos = offset + rope_delta (reference language.py:476-509)."""
         B = len(caches)
@@ -615,7 +651,7 @@ class LanguageModel:
         # attention decomposition for this generation: up to 2048 tokens one workgroup per (sequence, kv head)
         # walks the pages itself (nsplit = 1, no merge pass); beyond that, split-K with one workgroup per
         # page-stride (<= 32 splits) merged in the o_proj prologue
-        max_total = max(s.offset for s in seqs) + max_new_tokens + 1
+        max_total = max(s.kv_entries for s in seqs) + max_new_tokens + 1
         st.nsplit = 1 if max_total <= 2048 else max(2, min(32, (max_total + 16 * PAGE - 1) // (16 * PAGE)))
         if os.environ.get("VLM_DECODE_NSPLIT"):     # A/B knob for measurements
             st.nsplit = max(1, min(32, int(os.environ["VLM_DECODE_NSPLIT"])))
@@ -624,8 +660,11 @@ class LanguageModel:
         if rows != list(range(rows[0], rows[0] + B)):
             raise RuntimeError("decode batch needs consecutive KV sequence slots")
         st.seq_row0 = rows[0]
-        ctx = np.array([s.offset for s in seqs], dtype=np.int32)
-        pos = ctx + np.asarray(rope_deltas, dtype=np.int64).reshape(-1).astype(np.int32)
+        # (a rotating window: entries held, not tokens seen; the rope offset is the family's - `rope_pos` when the caller read it
+        # before the window wrapped, LanguageModel.__call__)
+        ctx = np.array([s.kv_entries for s in seqs], dtype=np.int32)
+        base = np.array([s.offset for s in seqs], dtype=np.int32) if rope_pos is None else np.asarray(rope_pos, dtype=np.int32)
+        pos = base + np.asarray(rope_deltas, dtype=np.int64).reshape(-1).astype(np.int32)
         host = np.concatenate([pos, ctx, np.zeros(1, np.int32)])
         dev = _lib.h2d(host, self.device)
         st.pos.copy_(dev[:B]); st.ctx.copy_(dev[B:2 * B]); st.step.copy_(dev[2 * B:])
@@ -684,6 +723,9 @@ class LanguageModel:
     def decode_run(self, st: DecodeState, n_steps: int, sampler_args: dict, use_graph: bool = True, penalties=None):
         """Enqueue n_steps decode steps (graph replays when use_graph).  penalties: sample_utils.LogitsProcessors."""
         L = _lib.lib()
+        if any(s.rotating for s in st.seqs):
+            raise NotImplementedError("max_kv_size: the captured step writes at slot = tokens seen; a rotating window runs "
+                                      "through the module call (LanguageModel.__call__), one step at a time")
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         q8 = self._seqs_q8(st.seqs)
         kv = self._kv_struct(st.seq_row0, decode=True, q8=q8)
@@ -789,7 +831,10 @@ class LanguageModel:
             # decode: pos = cache offset + rope delta (language.py:476-509); logits only
             deltas = self._rope_deltas if self._rope_deltas is not None else np.zeros((B, 1), dtype=np.int64)
             deltas = np.broadcast_to(np.asarray(deltas).reshape(-1, 1), (B, 1)) if np.asarray(deltas).size == 1 else deltas
-            st = self.decode_begin(caches, ids.reshape(-1), deltas[:B], max_new_tokens=1)
+            rope_pos = None
+            if any(c[0]._seq.rotating for c in caches):
+                rope_pos = self._rotate_windows([c[0]._seq for c in caches])
+            st = self.decode_begin(caches, ids.reshape(-1), deltas[:B], max_new_tokens=1, rope_pos=rope_pos)
             kv = self._kv_struct(st.seq_row0, decode=B <= 16, q8=self._seqs_q8(st.seqs))
             check(_lib.lib().vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
             args = st.args()
@@ -797,6 +842,7 @@ class LanguageModel:
                                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "decode_forward")
             for s in st.seqs:
                 s.offset += 1
+                s.note_decode_step()
             return LanguageModelOutput(logits=st.logits.clone().view(B, 1, -1))
 
         # prefill path

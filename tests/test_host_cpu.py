@@ -517,7 +517,8 @@ def test_model_construction_and_weight_packing_run_without_a_device(family):
 
 
 def test_generate_step_rejects_unbuilt_options():
-    """max_kv_size / draft_model / the KV quantisation schemes other than uniform 8-bit group-64 are outside the built path:
+    """draft_model / the KV quantisation schemes other than uniform 8-bit group-64 are outside the built path (max_kv_size is
+    built since round 4: tests/test_rotating_*.py):
     they raise instead of being dropped silently (reference signature: ar.py:151-214).  Python samplers / logits
     processors and thinking budgets are built since round 4 (the eager step, tests/test_engine_gpu.py); malformed ones raise
     TypeError."""
@@ -526,7 +527,7 @@ def test_generate_step_rejects_unbuilt_options():
 
     ids = np.array([[5, 6, 7]])
     for kw in (dict(kv_bits=4), dict(kv_bits=8, kv_group_size=32), dict(kv_bits=3.5), dict(kv_bits=8, kv_quant_scheme="turboquant"),
-               dict(max_kv_size=1024), dict(draft_model=object())):
+               dict(draft_model=object())):
         with pytest.raises(NotImplementedError):
             next(generate_step(ids, None, None, None, max_tokens=2, **kw))
     for kw in (dict(logits_processors=[123]), dict(sampler=7)):
