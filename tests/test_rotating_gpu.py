@@ -174,5 +174,5 @@ def test_what_the_window_does_not_cover_is_refused(tiny):
     cache = cache_mod.make_prompt_cache(lm, max_kv_size=16)
     lm(ids, cache=cache, logits_to_keep=1)
     with pytest.raises(NotImplementedError):                  # a second multi-token update of the window
-        lm(ids[:, :5], cache=cache, logits_to_keep=1)
+        lm(ids[:, :5], cache=cache, logits_to_keep=1, position_ids=np.broadcast_to(np.arange(40, 45), (3, 1, 5)))
     cache[0]._seq.release()
