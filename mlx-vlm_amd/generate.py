@@ -438,7 +438,9 @@ def stream_generate(model, processor, prompt: Optional[str] = None, image=None, 
         media = {getattr(cfgm, n, None) for n in ("image_token_id", "video_token_id", "image_token_index")} - {None}
         suffix_text_only = not any(t in media for t in full_ids[prefix:])
         lm = model.language_model
-        if 0 < prefix < len(full_ids) and suffix_text_only and hasattr(lm, "get_rope_index"):
+        # (a rotating window - max_kv_size - is not continued: the reference reuses one only until it wraps, dispatch.py:656-690,
+        # and a multi-token update of it re-orders and trims the window; the turn is prefilled cold)
+        if 0 < prefix < len(full_ids) and suffix_text_only and hasattr(lm, "get_rope_index") and not kv[0]._seq.rotating:
             pos, deltas = lm.get_rope_index(ids, kwargs.get("image_grid_thw"), kwargs.get("video_grid_thw"), None)
             pos = np.asarray(pos)
             if pos.ndim == 2:
@@ -454,7 +456,7 @@ def stream_generate(model, processor, prompt: Optional[str] = None, image=None, 
         if prompt_cache_state.cache is not None:
             prompt_cache_state.cache[0]._seq.release()        # cold prefill: the old turn's pages go back to the pool
             prompt_cache_state.cache = None
-        kwargs["prompt_cache"] = _cm.make_prompt_cache(model.language_model)
+        kwargs["prompt_cache"] = _cm.make_prompt_cache(model.language_model, max_kv_size=kwargs.get("max_kv_size"))
     detok = make_streaming_detokenizer(processor) if processor is not None else None
     stop = getattr(tokenizer, "stopping_criteria", None) if tokenizer is not None else None
     # thinking budget (reference dispatch.py:930-947,1016-1018): the criteria watches every token; past the budget inside a
