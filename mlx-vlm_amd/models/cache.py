@@ -331,8 +331,9 @@ class KVCache:
 
     @property
     def state(self):
-        """Materialise contiguous (keys, values) [1, Hkv, S, D] from the pages (debug / interop)."""
-        pool, S = self._seq.pool, self._seq.offset
+        """Materialise contiguous (keys, values) [1, Hkv, S, D] from the pages (debug / interop).  A rotating window: the
+        entries held, in SLOT order (the reference's buffer is in ring order; attention sees the same set either way)."""
+        pool, S = self._seq.pool, self._seq.kv_entries
         kp, vp = pool.layer_views(self._layer)
         H, D = pool.n_kv_heads, pool.head_dim
         if S == 0:
