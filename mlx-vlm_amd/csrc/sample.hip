@@ -1,15 +1,19 @@
 // Sampler kernels for gfx950 over the vocabulary row (V = 151,936 for Qwen2-VL):
 //   logprobs = logits - logsumexp(logits)          (reference mlx_vlm/generate/ar.py:368)
 //   greedy   = argmax(logprobs), lowest index wins  (reference mlx_vlm/sample_utils.py:63-64)
-//   top-p / min-p / top-k filters                   (sample_utils.py:289-318, 266-286, 169-175)
+//   the filters of make_sampler in its order         (sample_utils.py:10-89: top-n-sigma 181-212, p-less 215-236,
+//                                                     typical-p 321-345, top-p 289-318, min-p 239-286, xtc 348-376, top-k 169-175)
 //   categorical(logprobs / temp) by Gumbel-max      (sample_utils.py:385-387)
 // The row is 300 KB: everything is a couple of passes of 16-byte loads with
 // wavefront-shuffle reductions; logprobs are produced in the logits dtype (bf16)
-// exactly as the reference does (lse rounded to bf16, then the difference rounded).
+// exactly as the reference does (lse rounded to bf16, then the difference rounded),
+// and the filters follow MLX's TYPED graph over bf16 (every elementary op rounds; python
+// scalars are converted to bf16 first): pinned by tests/golden/samplers_ref.npz.
 //
-// Because logprobs are bf16 there are only 65,536 distinct keys: top-k and top-p
-// are done EXACTLY with a 64 Ki-bin histogram (count and probability mass per
-// key) instead of a sort - a radix-select that fits the LDS-less L2-resident row.
+// Because logprobs are bf16 there are only 65,536 distinct keys: top-k, top-p and
+// min_tokens_to_keep are done EXACTLY with a histogram over the keys (the half that
+// holds values <= 0 in LDS) instead of a sort; typical-p, whose order is not the
+// log-prob's, sorts the indices with a stable in-kernel radix sort.
 #include <math.h>
 #include <string.h>
 
@@ -471,7 +475,7 @@ struct SamplerK {
   float xtc_prob, xtc_thr;   // xtc_prob > 0: on; xtc_thr = T(xtc_threshold)
   const int* xtc_special;
   int n_special;
-  uint32_t* sort_ws;    // typical_p: per row [2][Vp] u32 index arrays
+  uint32_t* sort_ws;    // typical_p: per row [2][Vp] u32 index arrays + [2][Vp] u32 payloads (sort key | log-prob bits)
   size_t sort_stride;   // u32 words per row
   int Vp;
 };
@@ -484,7 +488,6 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
                                                              uint32_t* __restrict__ hist_all,
                                                              const SamplerK p, const int* __restrict__ step_ptr) {
   __shared__ float red[32];
-  __shared__ int redi[32];
   __shared__ uint32_t s_thr_key, s_thr_keep;
   __shared__ unsigned long long s_best;
   __shared__ uint32_t scan_u[17];
@@ -610,20 +613,37 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
       acc += rbf(rbf(expf(lf)) * lf);                 // (0 * -inf = NaN on a row that was already filtered: as MLX)
     });
     const float ent = rbf(-rbf(block_sum(acc, red)));
-    auto tkey = [&](int i) -> uint32_t { return (uint32_t)f2bf(fabsf(rbf(-bf2f(lp[i]) - ent))) & 0x7fffu; };
+    // what the later passes need of a token travels WITH its index - the 15-bit sort key and the log-prob's own bits in one
+    // word - so that no pass gathers from the row, and every loop has the next iteration's loads in flight before it touches
+    // the counters / stores of this one (a gather + a dependent load chain per iteration was 576 us per call)
+    auto payload = [&](bf16_t xb) -> uint32_t { return (((uint32_t)f2bf(fabsf(rbf(-bf2f(xb) - ent))) & 0x7fffu) << 16) | (uint32_t)xb; };
     uint32_t* idxA = p.sort_ws + (size_t)b * p.sort_stride;
     uint32_t* idxB = idxA + p.Vp;
+    uint32_t* payA = idxB + p.Vp;
+    uint32_t* payB = payA + p.Vp;
     const int lane = tid & 63, wave = tid >> 6;
     const int per = (((V + 15) >> 4) + 63) & ~63;                 // positions per wave: contiguous, walked 64 at a time
     const int w_lo = min(V, wave * per), w_hi = min(V, w_lo + per);
     uint32_t* my_dig = s_dig + wave * 256;
     for (int d = 0; d < 2; ++d) {
-      const uint32_t* src = d == 0 ? nullptr : idxB;
-      uint32_t* dst = d == 0 ? idxB : idxA;
+      const uint32_t *si = d == 0 ? nullptr : idxB, *sp = d == 0 ? nullptr : payB;
+      uint32_t *di = d == 0 ? idxB : idxA, *dp = d == 0 ? payB : payA;
+      const int sh = 16 + 8 * d;
+      auto fetch = [&](int q, uint32_t& i, uint32_t& pay) {
+        i = 0; pay = 0;
+        if (q < w_hi) {
+          if (si) { i = si[q]; pay = sp[q]; }
+          else { i = (uint32_t)q; pay = payload(lp[q]); }
+        }
+      };
       for (int j = lane; j < 256; j += 64) my_dig[j] = 0;
+      uint32_t ci, cp;
+      fetch(w_lo + lane, ci, cp);
       for (int q0 = w_lo; q0 < w_hi; q0 += 64) {
-        const int q = q0 + lane;
-        if (q < w_hi) atomicAdd(&my_dig[(tkey(src ? (int)src[q] : q) >> (8 * d)) & 255u], 1u);
+        uint32_t ni, np;
+        fetch(q0 + 64 + lane, ni, np);
+        if (q0 + lane < w_hi) atomicAdd(&my_dig[(cp >> sh) & 255u], 1u);
+        ci = ni; cp = np;
       }
       __syncthreads();
       // exclusive prefix in (digit, wave) order = the stable order: thread t owns the flattened entries 4 t .. 4 t + 3
@@ -635,11 +655,12 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const int f = 4 * tid + e; s_dig[(f & 15) * 256 + (f >> 4)] = run; run += v[e]; }
       __syncthreads();
+      fetch(w_lo + lane, ci, cp);
       for (int q0 = w_lo; q0 < w_hi; q0 += 64) {
-        const int q = q0 + lane;
-        const bool valid = q < w_hi;
-        const int i = valid ? (src ? (int)src[q] : q) : 0;
-        const uint32_t dg = valid ? (tkey(i) >> (8 * d)) & 255u : 0u;
+        uint32_t ni, np;
+        fetch(q0 + 64 + lane, ni, np);
+        const bool valid = q0 + lane < w_hi;
+        const uint32_t dg = valid ? (cp >> sh) & 255u : 0u;
         // the lanes of this iteration that hold the same digit (8 ballots): rank inside the group by lane = by position
         unsigned long long same = __ballot(valid);
 #pragma unroll
@@ -649,10 +670,13 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
         }
         if (valid) {
           const uint32_t base = my_dig[dg];
-          dst[base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = (uint32_t)i;
+          const uint32_t at = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+          di[at] = ci;
+          dp[at] = cp;
           // (the wave's LDS operations execute in order: every lane has read before the group's last lane writes)
           if (lane == 63 - __clzll(same)) my_dig[dg] = base + (uint32_t)__popcll(same);
         }
+        ci = ni; cp = np;
       }
       __syncthreads();
     }
@@ -660,7 +684,7 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
     float wsum = 0.f;
     for (int q0 = w_lo; q0 < w_hi; q0 += 64) {
       const int q = q0 + lane;
-      wsum += q < w_hi ? rbf(expf(bf2f(lp[idxA[q]]))) : 0.f;
+      wsum += q < w_hi ? rbf(expf(bf2f((bf16_t)(payA[q] & 0xffffu)))) : 0.f;
     }
     wsum = wave_sum(wsum);
     __syncthreads();
@@ -668,11 +692,13 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
     __syncthreads();
     float run = 0.f;
     for (int w = 0; w < wave; ++w) run += scan_f[w];
+    uint32_t ci = 0, cp = 0;
+    if (w_lo + lane < w_hi) { ci = idxA[w_lo + lane]; cp = payA[w_lo + lane]; }
     for (int q0 = w_lo; q0 < w_hi; q0 += 64) {
-      const int q = q0 + lane;
-      const bool valid = q < w_hi;
-      const int i = valid ? (int)idxA[q] : 0;
-      const float pe = valid ? rbf(expf(bf2f(lp[i]))) : 0.f;
+      uint32_t ni = 0, np = 0;
+      if (q0 + 64 + lane < w_hi) { ni = idxA[q0 + 64 + lane]; np = payA[q0 + 64 + lane]; }
+      const bool valid = q0 + lane < w_hi;
+      const float pe = valid ? rbf(expf(bf2f((bf16_t)(cp & 0xffffu)))) : 0.f;
       float inc = pe;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
@@ -681,9 +707,10 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
       }
       const float before = rbf(rbf(run + inc) - pe);
       const float tot = __shfl(inc, 63, 64);
-      // (position q is this lane's alone and every lane has loaded its lp[i] above: nobody reads what is written here)
-      if (valid && !(before < p.typical_thr)) lp[i] = NEG_INF_BF;
+      // (token ci is this lane's alone: nobody else reads or writes lp[ci] now)
+      if (valid && !(before < p.typical_thr)) lp[ci] = NEG_INF_BF;
       run += tot;
+      ci = ni; cp = np;
     }
     __syncthreads();
   }
@@ -902,11 +929,11 @@ inline float host_rbf(float f) {
 
 extern "C" size_t vlm_sample_workspace_bytes(int B) { return (size_t)B * (NBLK * 4 * sizeof(float) + 65536 * sizeof(uint32_t)) + 256; }
 
-// typical_p's sort: per row two index arrays of Vp = V rounded up to 1024 entries (the digit counters live in LDS)
+// typical_p's sort: per row two (index, payload) array pairs of Vp = V rounded up to 1024 entries (the digit counters live in LDS)
 extern "C" size_t vlm_sample_sort_workspace_bytes(int B, int V) {
   if (B <= 0 || V <= 0) return 0;
   const size_t Vp = ((size_t)V + 1023) & ~(size_t)1023;
-  return (size_t)B * 2 * Vp * sizeof(uint32_t);
+  return (size_t)B * 4 * Vp * sizeof(uint32_t);
 }
 
 // workspace layout: 256 B arrival ticket of the fused greedy tail (must be zero at allocation; the kernel re-arms it; at a
@@ -952,7 +979,7 @@ extern "C" int vlm_sample_ex(const void* logits, int ld, int B, int V, void* log
     if (k.use_typical) {
       if (!sp->sort_workspace) return VLM_ERR_ARG;
       k.Vp = (V + 1023) & ~1023;
-      k.sort_stride = 2 * (size_t)k.Vp;
+      k.sort_stride = 4 * (size_t)k.Vp;
       k.sort_ws = (uint32_t*)sp->sort_workspace;
     }
   }
