@@ -83,10 +83,8 @@ def make_sampler(temp: float = 0.0, top_p: float = 0.0, min_p: float = 0.0, min_
             raise ValueError(f"`min_p` has to be a float in the [0, 1] interval, but is {min_p}")
         if not isinstance(min_tokens_to_keep, int) or min_tokens_to_keep < 1:
             raise ValueError(f"`min_tokens_to_keep` has to be a positive integer, but is {min_tokens_to_keep}")
-        if top_n_sigma < 0:
-            raise ValueError(f"`top_n_sigma` has to be a non-negative float, but is {top_n_sigma}")
-        if not (0.0 < typical_p <= 1.0) and typical_p != 0.0:
-            raise ValueError(f"`typical_p` has to be a float in the (0, 1] interval, but is {typical_p}")
+        # (top_n_sigma <= 0 and typical_p outside (0, 1) never reach their closures in the reference - make_sampler's own
+        # conditions, sample_utils.py:69-74 - and are ignored here the same way)
         if xtc_probability > 0.0:
             if not (0 <= xtc_threshold <= 0.5):
                 raise ValueError(f"`threshold` has to be a float in the [0, 0.5] interval, but is {xtc_threshold}")

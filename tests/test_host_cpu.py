@@ -629,7 +629,8 @@ def test_make_sampler_takes_the_whole_reference_surface():
     # generate_step's keywords (ar.py:168-170) reach make_sampler
     dev, py = _resolve_sampler(None, 0.8, 0.9, 0.0, 0, 5, top_n_sigma=1.5, p_less=None, typical_p=0.4)
     assert isinstance(py, Sampler) and py.top_n_sigma == 1.5 and py.typical_p == 0.4 and py.top_p == 0.9 and not py.p_less
-    for bad in (dict(min_p=1.5), dict(min_tokens_to_keep=0), dict(top_n_sigma=-1.0), dict(typical_p=1.5),
-                dict(xtc_probability=0.5, xtc_threshold=0.7), dict(xtc_probability=1.5)):
+    for bad in (dict(min_p=1.5), dict(min_tokens_to_keep=0), dict(xtc_probability=0.5, xtc_threshold=0.7), dict(xtc_probability=1.5)):
         with pytest.raises(ValueError):
             make_sampler(temp=0.5, **bad)
+    # values make_sampler itself treats as "off" (sample_utils.py:69-74): ignored, as there
+    assert not make_sampler(temp=0.5, top_n_sigma=-1.0, typical_p=1.5).extended
