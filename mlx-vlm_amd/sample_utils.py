@@ -53,7 +53,8 @@ class Sampler:
     def sample_args(self) -> dict:
         """keyword arguments of ops.sample (vlm_sample_ex) - python floats, converted on the other side of the C ABI"""
         return dict(self.engine_args(), top_p=float(self.top_p), min_tokens_to_keep=int(self.min_tokens_to_keep),
-                    top_n_sigma=float(self.top_n_sigma), p_less=bool(self.p_less), typical_p=float(self.typical_p),
+                    top_n_sigma=float(self.top_n_sigma) if self.top_n_sigma > 0 else 0.0, p_less=bool(self.p_less),
+                    typical_p=float(self.typical_p) if 0.0 < self.typical_p < 1.0 else 1.0,
                     xtc_probability=float(self.xtc_probability), xtc_threshold=float(self.xtc_threshold),
                     xtc_special_tokens=list(self.xtc_special_tokens))
 
