@@ -193,6 +193,10 @@ class BatchGenerator:
             # rows' log-probs like any callable: the same HIP kernel through vlm_sample_ex)
             if not callable(sampler):
                 raise TypeError("sampler must be a mlx_vlm_amd.sample_utils.Sampler or a callable logprobs -> tokens")
+            if isinstance(sampler, Sampler) and sampler.xtc_probability > 0.0:
+                # the reference's apply_xtc takes its minimum over the WHOLE [rows, V] array and draws once per call
+                # (sample_utils.py:371-376): across requests that is not a per-request filter; vlm_sample_ex serves one row
+                raise NotImplementedError("xtc in the batch generator: the reference's filter mixes the rows of a batch; one row per call is built")
             self._py_sampler, sampler = sampler, None
         self.sampler = sampler or make_sampler()
         self._sargs = self.sampler.engine_args()
