@@ -86,3 +86,43 @@ def test_rotating_facade_known_answers_and_refusals():
     pc = C.make_prompt_cache(LM(), max_kv_size=33)
     assert pc[0]._seq.rotating and pc[2].max_size == 33 and pc[1].keep == 4
     assert not C.make_prompt_cache(LM())[0]._seq.rotating
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_rotate_plans_against_the_oracle_for_many_windows(seed):
+    """Property check over window sizes and prompt lengths the golden file does not hold (the oracle's RotatingKVCache is
+    pinned to the reference on the golden cases): the tokens the pool holds for the step, and the ring index, at every step."""
+    import torch
+
+    from oracle import ops as O
+
+    rng = np.random.default_rng(100 + seed)
+    for _ in range(12):
+        M = int(rng.integers(6, 200))
+        L = int(rng.integers(1, 3 * M))
+        steps = int(rng.integers(1, 2 * M + 20))
+        oc = O.RotatingKVCache(M, keep=4)
+        tag = lambda a, b: torch.arange(a, b, dtype=torch.float32).reshape(1, 1, b - a, 1)     # noqa: E731
+        oc.update_and_fetch(tag(0, L), tag(0, L)) if L > 1 else oc.update_and_fetch(tag(0, 1), tag(0, 1))
+        s = _seq(max_tokens=65536)
+        s.set_rotating(M, keep=4)
+        s.reserve(L + 2)
+        slots = {i: i for i in range(L)}
+        s.offset += L
+        s.note_prefill(L)
+        if L == 1:
+            # (a one-token "prompt" goes through the reference's in-place path: same state - one entry, index 1)
+            assert oc._idx == 1 and oc.offset == 1
+        for t in range(L, L + steps):
+            assert s.rope_offset == oc._idx, (M, L, t)
+            plan = s.rotate_plan()
+            if plan:
+                assert not (set(plan[0]) & set(plan[1]))
+                slots.update({d: slots[a] for a, d in zip(*plan)})
+            slots[s.kv_entries] = t
+            seen = sorted(slots[i] for i in range(s.kv_entries + 1))
+            s.offset += 1
+            s.note_decode_step()
+            k, _ = oc.update_and_fetch(tag(t, t + 1), tag(t, t + 1))
+            assert seen == sorted(int(x) for x in k.reshape(-1)), (M, L, t)
+            assert s.kv_entries <= M
