@@ -37,3 +37,20 @@ def test_exotic_sampler_filters_match_the_reference(tag):
         _same(O.apply_min_p(x, mp, keep), G[f"{tag}.min_p_{mp}_keep_{keep}"])
     for tp in (0.5, 0.9, 0.99):
         _same(O.apply_top_p(x, tp), G[f"{tag}.top_p_{tp}"])
+
+
+@pytest.mark.parametrize("tag", ["bf16", "f32"])
+def test_filter_chains_follow_make_samplers_own_order(tag):
+    """`chain_<i>`: the row the reference's make_sampler closure hands to its draw (the draw replaced by the identity in
+    make_golden_samplers.py) - the oracle's sampler_filters applies the same filters in the same order."""
+    import json
+
+    chains = json.loads(str(G["chains_json"]))
+    dt = torch.bfloat16 if tag == "bf16" else torch.float32
+    x = torch.from_numpy(G[f"{tag}.logprobs"]).to(dt)
+    for ci, kw in enumerate(chains):
+        if kw.get("xtc_probability"):
+            got = torch.cat([O.sampler_filters(x[r:r + 1], 0.8, **kw) for r in range(x.shape[0])])
+        else:
+            got = O.sampler_filters(x, 0.8, **kw)
+        _same(got, G[f"{tag}.chain_{ci}"])

@@ -106,7 +106,17 @@ def test_filters_equal_the_reference_on_its_golden_rows(vops):
             _, got = _filtered(vops, lp[r:r + 1], xtc_probability=1.0, xtc_threshold=thr, xtc_special_tokens=sp)
             assert torch.equal(_kept(got[0]), _kept(ref[r])), (thr, r, int(_kept(got[0]).sum()), int(_kept(ref[r]).sum()))
             assert all(bool(_kept(got[0])[t]) for t in sp)
-    print(f"golden rows: {len(cases)} filter cases + 6 xtc calls, survivor sets identical")
+    # the CHAINS: what the reference's make_sampler closure hands to its draw (filters in ITS order)
+    import json
+    chains = json.loads(str(G["chains_json"]))
+    for ci, kw in enumerate(chains):
+        ref = torch.from_numpy(G[f"bf16.chain_{ci}"])
+        if kw.get("xtc_probability"):
+            got = torch.cat([_filtered(vops, lp[r:r + 1], **kw)[1] for r in range(3)])
+        else:
+            _, got = _filtered(vops, lp, **kw)
+        assert torch.equal(_kept(got), _kept(ref)), (ci, kw, [int(_kept(got[b]).sum()) for b in range(3)], [int(_kept(ref[b]).sum()) for b in range(3)])
+    print(f"golden rows: {len(cases)} filter cases + 6 xtc calls + {len(chains)} make_sampler chains, survivor sets identical")
 
 
 @pytest.mark.parametrize("V", [32003, 151936])
