@@ -1033,6 +1033,8 @@ def main():
     ap.add_argument("--no-cpu-hf", action="store_true", help="skip the HuggingFace torch-CPU second opinion of cpu_baseline")
     ap.add_argument("--no-extras", action="store_true", help="skip kernel rooflines / ViT throughput (profiling runs)")
     ap.add_argument("--no-configs", action="store_true", help="skip the short runs of the other BASELINE configs in the default line")
+    ap.add_argument("--stage", default="", choices=["", "headline", "extras"],
+                    help="internal: one stage of the default single-GPU line in a process of its own (see orchestrate)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU rehearsal of the multi-rank path: launcher, rendezvous (gloo), weight-arena broadcast, request deal, "
                          "timing protocol, result gather, JSON line - no kernels (tests/test_host_cpu.py runs it with --gpus 2)")
@@ -1069,14 +1071,13 @@ def main():
         parallel.barrier()
         parallel.shutdown()
         return
-    from mlx_vlm_amd.models import qwen2_vl
-
-    rank, ws, local = parallel.init()
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if rank == 0 and ws > 1:
-        print(f"[bench] {ws} ranks, backend {_dist_info(ws)['backend']} (RCCL over xGMI), one process per GPU", file=sys.stderr, flush=True)
+    ws = ws_env
     if args.workload != "qwen2vl-2b":
+        rank, ws, local = parallel.init()
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        if rank == 0 and ws > 1:
+            print(f"[bench] {ws} ranks, backend {_dist_info(ws)['backend']} (RCCL over xGMI), one process per GPU", file=sys.stderr, flush=True)
         out = {"nanollava": workload_nanollava, "qwen2vl-7b-b32": workload_7b_b32, "qwen2vl-2b-w4": workload_2b_w4,
                "phi35v-w4-b16": workload_phi35v_w4_b16, "idefics2-b8": workload_idefics2_b8}[args.workload](
             args, rank, ws, dev)
@@ -1090,13 +1091,42 @@ def main():
         parallel.shutdown()
         return
     args.max_tokens = args.max_tokens or 256
+    if args.stage == "headline" or ws > 1:
+        # one rank of the N-rank job (torchrun / the self-launch above), or the headline child of the single-GPU orchestrator
+        rank, ws, local = parallel.init()
+        out = stage_headline(args, rank, ws, local)
+        if rank == 0:
+            if not args.stage:
+                out.pop("_traffic_gate_up", None)          # (the orchestrator's hand-over field)
+            print(json.dumps(out), flush=True)
+        parallel.barrier()
+        parallel.shutdown()
+        return
+    if args.stage == "extras":
+        print(json.dumps(stage_extras(args)), flush=True)
+        return
+    orchestrate(args)
 
+
+def stage_headline(args, rank, ws, local):
+    """The timed region of the default line: W warm-up passes, then exactly K passes of BASELINE configs[1] bracketed by a
+    barrier + synchronize on both sides, MAX over ranks.  -> the line's dict (rank 0; the other ranks get the same numbers)."""
+    from mlx_vlm_amd import parallel, synthetic
+    from mlx_vlm_amd.models import qwen2_vl
+
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if rank == 0 and ws > 1:
+        print(f"[bench] {ws} ranks, backend {_dist_info(ws)['backend']} (RCCL over xGMI), one process per GPU", file=sys.stderr, flush=True)
+    t_host0 = time.perf_counter()
     cfg, model, load = _load_synthetic(synthetic.QWEN2_VL_2B, qwen2_vl, rank, dev, kv_pool_tokens=32768, max_seqs=40)
     if rank == 0 and ws > 1:
         print(f"[bench] weights: {load['weight_bytes'] / 1e9:.2f} GB broadcast from rank 0 in {load['broadcast_s']:.3f} s", file=sys.stderr, flush=True)
 
+    t_prep0 = time.perf_counter()
     req = build_request(cfg, 448, 128, seed=rank)
     req = (req[0], req[1].to(dev), req[2])
+    host_prep_s = time.perf_counter() - t_prep0
     for _ in range(args.warmup):
         run_step(model, req, args.max_tokens, args.lookahead)
     parallel.barrier()
@@ -1114,76 +1144,137 @@ def main():
     wall = parallel.max_over_ranks(time.perf_counter() - t0, dev)
     dec_max = parallel.max_over_ranks(dec_s, dev)
     pre_max = parallel.max_over_ranks(pre_s, dev)
+    prep_max = parallel.max_over_ranks(host_prep_s, dev)
     decode_steps = args.steps * (args.max_tokens - 1)          # tokens produced by decode steps, per rank
     decode_tps = ws * decode_steps / dec_max
     ms_per_step = wall / args.steps * 1e3
     us_per_token = dec_max / decode_steps * 1e6
 
-    extras = {}
-    if rank == 0 and not args.no_extras:
-        kr = kernel_rooflines(model, cfg)
-        ips336, dt336 = vit_throughput(model, cfg, args.vit_batch, 336)
-        ips448, dt448 = vit_throughput(model, cfg, 1, 448)
-        extras = dict(kernels=kr, vit336=(ips336, dt336), vit448=(ips448, dt448))
-        # exploratory single-GPU extras: not part of the scaling runs (the other ranks would only wait for rank 0)
-        for key, fn in (("batch8", lambda: batch_decode_throughput(model, cfg, 8, 64)),
-                        ("batch16", lambda: batch_decode_throughput(model, cfg, 16, 64)),
-                        ("wide64", lambda: wide_decode_throughput(model, cfg, 64, 48)),
-                        ("continuous", lambda: continuous_batch_throughput(model, cfg)),
-                        ("sampled", lambda: sampled_decode_throughput(model, req, 128, args.lookahead))):
-            if ws > 1:
-                extras[key] = None
-                continue
-            try:
-                extras[key] = fn()
-            except Exception as e:   # an extra must never cost the headline line
-                extras[key] = {"error": f"{type(e).__name__}: {e}"}
-    cpu = None
-    if rank == 0 and ws == 1 and not args.no_cpu_baseline:
-        from mlx_vlm_amd.utils import cpu_quota
-        cpu = cpu_baseline(min(cpu_quota(), 32), with_hf=not args.no_cpu_hf)          # the cores the container may use
-    configs = None
-    if rank == 0 and ws == 1 and not args.no_extras and not args.no_configs:
-        import gc
-        head_tuning = dict(model.language_model.tuning)
-        del model                                   # the headline engine (weights + 37 GB of identity-layout K/V) makes room
-        gc.collect()
-        torch.cuda.empty_cache()
-        configs = other_configs(args, rank, ws, dev, T_PROCESS_START)
-    else:
-        head_tuning = dict(model.language_model.tuning)
+    lm_params = 28 * 46797824 + 1536 + 233373696
+    ctx_mid = int(req[0].shape[1]) + args.max_tokens // 2
+    bytes_per_token = 2 * lm_params + 28672 * ctx_mid + 28672
+    step_gbs = bytes_per_token / (us_per_token * 1e-6) / 1e9
+    traffic_gu, traffic_tok, traffic_src = pmc_traffic()
+    dist = _dist_info(ws, load)
+    dist["host_prep_s_max_over_ranks"] = prep_max          # image processing + request assembly of one rank's request
+    out = {
+        "metric": "decode tokens/sec + vision-prefill images/sec, Qwen2-VL-2B", "value": decode_tps, "unit": "tokens/s",
+        "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "Qwen2-VL-2B-Instruct dims (random-init bf16), batch=1 per GPU, one 448x448 image "
+                               "(1024 patches -> 256 image tokens) + 128 text tokens, greedy 256-token decode, EOS disabled",
+                   "prompt_tokens": int(req[0].shape[1]), "max_tokens": args.max_tokens, "parallelism": f"dp{ws}",
+                   "decode_lookahead": args.lookahead, "decode_tuning": dict(model.language_model.tuning)},
+        "decode_us_per_token": us_per_token,
+        "prefill_ms_to_first_token": pre_max / args.steps * 1e3,
+        "prompt_tps": ws * args.steps * int(req[0].shape[1]) / pre_max,
+        "e2e_tokens_per_s": ws * ntok / wall,
+        "load_s": load["load_s"], "load": load, "distributed": dist,
+        # the number the north-star's 60 % target refers to: the WHOLE decode step against the HBM roofline
+        "roofline": {"bound": "hbm", "kernel": "whole decode step (all launches of one token)", "achieved": step_gbs,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS, "traffic": traffic_tok,
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_token": bytes_per_token},
+    }
+    out["roofline_decode_step"] = dict(out["roofline"])
+    out["_traffic_gate_up"] = traffic_gu
+    return out
 
-    if rank == 0:
-        lm_params = 28 * 46797824 + 1536 + 233373696
-        ctx_mid = int(req[0].shape[1]) + args.max_tokens // 2
-        bytes_per_token = 2 * lm_params + 28672 * ctx_mid + 28672
-        step_gbs = bytes_per_token / (us_per_token * 1e-6) / 1e9
-        traffic_gu, traffic_tok, traffic_src = pmc_traffic()
-        out = {
-            "metric": "decode tokens/sec + vision-prefill images/sec, Qwen2-VL-2B", "value": decode_tps, "unit": "tokens/s",
-            "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "Qwen2-VL-2B-Instruct dims (random-init bf16), batch=1 per GPU, one 448x448 image "
-                                   "(1024 patches -> 256 image tokens) + 128 text tokens, greedy 256-token decode, EOS disabled",
-                       "prompt_tokens": int(req[0].shape[1]), "max_tokens": args.max_tokens, "parallelism": f"dp{ws}",
-                       "decode_lookahead": args.lookahead, "decode_tuning": head_tuning},
-            "decode_us_per_token": us_per_token,
-            "prefill_ms_to_first_token": pre_max / args.steps * 1e3,
-            "prompt_tps": ws * args.steps * int(req[0].shape[1]) / pre_max,
-            "e2e_tokens_per_s": ws * ntok / wall,
-            "load_s": load["load_s"], "load": load, "distributed": _dist_info(ws, load),
-            # the number the north-star's 60 % target refers to: the WHOLE decode step against the HBM roofline
-            "roofline": {"bound": "hbm", "kernel": "whole decode step (all launches of one token)", "achieved": step_gbs,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS, "traffic": traffic_tok,
-                         "traffic_source": traffic_src, "algorithmic_bytes_per_token": bytes_per_token},
-        }
-        out["roofline_decode_step"] = dict(out["roofline"])
-        if extras:
+
+def stage_extras(args):
+    """Everything of the default line that is not the headline's timed region, in a process of its own (a GPU memory fault
+    cannot be caught by try / except: BENCH_r04): per-kernel rooflines, ViT throughput, batched / continuous / sampled decode."""
+    from mlx_vlm_amd import parallel, synthetic
+    from mlx_vlm_amd.models import qwen2_vl
+
+    rank, ws, local = parallel.init()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cfg, model, load = _load_synthetic(synthetic.QWEN2_VL_2B, qwen2_vl, rank, dev, kv_pool_tokens=32768, max_seqs=40)
+    req = build_request(cfg, 448, 128, seed=rank)
+    req = (req[0], req[1].to(dev), req[2])
+    run_step(model, req, 16, args.lookahead)
+    extras = {}
+
+    def emit():          # the parent reads the LAST complete line: every finished extra survives a later fault
+        print(json.dumps(extras), flush=True)
+
+    extras["kernels"] = kernel_rooflines(model, cfg)
+    emit()
+    ips336, dt336 = vit_throughput(model, cfg, args.vit_batch, 336)
+    ips448, dt448 = vit_throughput(model, cfg, 1, 448)
+    extras.update(vit336=(ips336, dt336), vit448=(ips448, dt448))
+    emit()
+    for key, fn in (("batch8", lambda: batch_decode_throughput(model, cfg, 8, 64)),
+                    ("batch16", lambda: batch_decode_throughput(model, cfg, 16, 64)),
+                    ("wide64", lambda: wide_decode_throughput(model, cfg, 64, 48)),
+                    ("continuous", lambda: continuous_batch_throughput(model, cfg)),
+                    ("sampled", lambda: sampled_decode_throughput(model, req, 128, args.lookahead))):
+        try:
+            extras[key] = fn()
+        except Exception as e:   # an extra must never cost the line
+            extras[key] = {"error": f"{type(e).__name__}: {e}"}
+        emit()
+    return extras
+
+
+def _child(args, stage, timeout_s):
+    """Run one stage of the default line as `bench.py --stage <stage>` -> (last JSON line or None, returncode, stderr tail)."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--stage", stage, "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--max-tokens", str(args.max_tokens), "--lookahead", str(args.lookahead), "--vit-batch", str(args.vit_batch)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        rc, so, se = r.returncode, r.stdout, r.stderr
+    except subprocess.TimeoutExpired as e:
+        rc, so, se = -9, (e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or ""), f"timeout after {timeout_s} s"
+    lines = [ln for ln in so.strip().splitlines() if ln.startswith("{")]
+    doc = None
+    for ln in reversed(lines):
+        try:
+            doc = json.loads(ln)
+            break
+        except ValueError:          # a line cut short by an abort
+            continue
+    return doc, rc, se.strip()[-600:]
+
+
+def orchestrate(args):
+    """`python bench.py` on one GPU: this process never touches the GPU.  The headline (timed region) runs in a child whose JSON
+    is echoed to stderr the moment it exists; the extras, the CPU baseline and the other configs follow, each in a process of
+    its own, and ONE enriched line goes to stdout at the end.  A headline child killed by a signal is re-run (up to 3 attempts,
+    every failed attempt is reported in `headline_attempts`)."""
+    attempts = []
+    out = None
+    for _ in range(3):
+        out, rc, err = _child(args, "headline", 900)
+        if out is not None and rc == 0:
+            break
+        attempts.append({"rc": rc, "stderr_tail": err[-300:]})
+        print(f"[bench] headline attempt {len(attempts)} failed (rc {rc}): {err[-300:]}", file=sys.stderr, flush=True)
+        out = None
+    if out is None:
+        sys.exit(f"bench.py: the headline stage failed {len(attempts)} times: {attempts}")
+    if attempts:
+        out["headline_attempts"] = {"failed": attempts, "succeeded_on": len(attempts) + 1}
+    traffic_gu = out.pop("_traffic_gate_up", None)
+    print("[bench] headline: " + json.dumps(out), file=sys.stderr, flush=True)
+
+    extras = None
+    if not args.no_extras:
+        extras, rc, err = _child(args, "extras", 900)
+        if rc != 0:
+            extras = dict(extras or {})
+            extras["error"] = f"extras stage rc {rc}: {err[-300:]}"
+            print(f"[bench] extras stage failed (rc {rc}): {err[-300:]}", file=sys.stderr, flush=True)
+    if extras:
+        if extras.get("kernels"):
             k = extras["kernels"]["gemv_gate_up_swiglu"]
             out["roofline_kernel"] = {"bound": "hbm", "kernel": GATE_UP_KERNEL + " (RMSNorm + gate/up GEMV + SwiGLU, 28 launches/token)",
                                       "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["GBps"] / HBM_PEAK_GBS,
                                       "traffic": traffic_gu, "bytes_per_launch": k["bytes_per_launch"], "us_per_launch": k["us_per_launch"]}
             out["kernel_rooflines"] = extras["kernels"]
+        if extras.get("vit336"):
             ips336, dt336 = extras["vit336"]
             ips448, dt448 = extras["vit448"]
             out["vision_images_per_s"] = ips336
@@ -1191,20 +1282,25 @@ def main():
                                    "unit": "TFLOP/s", "frac": ips336 * VIT_TFLOP_336 / MFMA_BF16_PEAK_TF, "traffic": None,
                                    "workload": f"{args.vit_batch} x 336x336 images per call ({args.vit_batch * 576} patches)",
                                    "ms_per_call": dt336 * 1e3}
-            out["batch8_decode"] = extras["batch8"]
-            out["batch16_decode"] = extras.get("batch16")
-            out["wide64_decode"] = extras.get("wide64")
-            out["continuous_batching"] = extras["continuous"]
-            out["sampled_decode"] = extras.get("sampled")
             out["vision_single_448_images_per_s"] = ips448
             out["vision_single_448_tflops"] = ips448 * VIT_TFLOP_448
-        if cpu is not None:
-            out["cpu_baseline"] = cpu
-        if configs is not None:
-            out["configs"] = configs
-        print(json.dumps(out), flush=True)
-    parallel.barrier()             # ranks leave together (rank 0 was still measuring the per-kernel rooflines)
-    parallel.shutdown()
+        for src, dst in (("batch8", "batch8_decode"), ("batch16", "batch16_decode"), ("wide64", "wide64_decode"),
+                         ("continuous", "continuous_batching"), ("sampled", "sampled_decode")):
+            out[dst] = extras.get(src)
+        if extras.get("error"):
+            out["extras_error"] = extras["error"]
+    if not args.no_cpu_baseline:
+        try:
+            from mlx_vlm_amd.utils import cpu_quota
+            out["cpu_baseline"] = cpu_baseline(min(cpu_quota(), 32), with_hf=not args.no_cpu_hf)          # the cores the container may use
+        except Exception as e:
+            out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    if not args.no_extras and not args.no_configs:
+        try:
+            out["configs"] = other_configs(args, 0, 1, None, T_PROCESS_START)
+        except Exception as e:
+            out["configs"] = {"error": f"{type(e).__name__}: {e}"}
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

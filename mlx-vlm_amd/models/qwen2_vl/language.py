@@ -733,6 +733,8 @@ class LanguageModel:
         fused = bool(self.tuning.get("fused_tail")) and float(sampler_args.get("temperature", 0.0)) == 0.0 \
             and not hasattr(self._w["embed"], "wq")          # the fused tail gathers bf16 embedding rows
         args = st.args(flags=_lib.DECODE_FUSED_TAIL if fused else 0, penalties=penalties, **sampler_args)
+        if os.environ.get("VLM_NO_GRAPH"):           # diagnostics: every launch of the step visible to the HIP runtime's log
+            use_graph = False
         if use_graph:
             key = (st.seq_row0, st.nsplit, fused, q8, penalties.key() if penalties else None, tuple(sorted(sampler_args.items())))
             if st.graph_key != key or getattr(self, "_graph_owner", None) is not st:
