@@ -1127,6 +1127,8 @@ def stage_headline(args, rank, ws, local):
     req = build_request(cfg, 448, 128, seed=rank)
     req = (req[0], req[1].to(dev), req[2])
     host_prep_s = time.perf_counter() - t_prep0
+    if os.environ.get("VLM_DEBUG_ADDR"):
+        _dump_address_map(model, "after load")
     for _ in range(args.warmup):
         run_step(model, req, args.max_tokens, args.lookahead)
     parallel.barrier()
@@ -1176,8 +1178,29 @@ def stage_headline(args, rank, ws, local):
                      "traffic_source": traffic_src, "algorithmic_bytes_per_token": bytes_per_token},
     }
     out["roofline_decode_step"] = dict(out["roofline"])
+    from mlx_vlm_amd import ops as _ops
+    # rows whose logits held no finite value in any greedy tail of this process (0 on a healthy run; csrc/sample.hip)
+    out["decode_nan_rows"] = sum(_ops.bad_argmax_rows(st.sample_ws) for st in model.language_model._decode_states.values())
     out["_traffic_gate_up"] = traffic_gu
     return out
+
+
+def _dump_address_map(model, when):
+    """diagnostics (VLM_DEBUG_ADDR=1): where everything lives, so that the address of a GPU memory fault can be attributed"""
+    from mlx_vlm_amd import _lib
+
+    lm = model.language_model
+    rows = [(seg["address"], seg["address"] + seg["total_size"], f"torch segment ({seg['segment_type']})") for seg in torch.cuda.memory_snapshot()]
+    for name, t in (("weight arena", lm.warena.buf if lm.warena is not None else None), ("small arena", lm.arena.buf),
+                    ("kpool", lm.pool.kpool), ("vpool", lm.pool.vpool)):
+        if t is not None:
+            rows.append((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size(), name))
+    if _lib._ring is not None:
+        rows.append((_lib._ring.buf.data_ptr(), _lib._ring.buf.data_ptr() + _lib._ring.buf.numel(), "pinned upload ring (host)"))
+    print(f"[bench] address map {when}:", file=sys.stderr)
+    for a, b, name in sorted(rows):
+        print(f"[bench]   {a:#x} .. {b:#x}  {(b - a) / 2**20:10.2f} MiB  {name}", file=sys.stderr)
+    sys.stderr.flush()
 
 
 def stage_extras(args):

@@ -176,7 +176,16 @@ __global__ __launch_bounds__(256) void logprob_argmax_tail_kernel(
       const int oi = __shfl_xor(bi, o, 64);
       if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
-    if (li == 0) s_tok[r] = bi;
+    if (li == 0) {
+      // a row with no candidate (every logit NaN: `lp > best` never holds and the index stays 0x7fffffff) must not become an
+      // address: the embedding gather below would read 6.6 TB past the table - a GPU memory fault instead of a wrong token.
+      // Token 0 as argmax_final_kernel gives, and the event is counted in the word behind the ticket (ops.bad_argmax_rows)
+      if ((unsigned)bi >= (unsigned)V) {
+        bi = 0;
+        __hip_atomic_fetch_add(ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      s_tok[r] = bi;
+    }
   }
   __syncthreads();
   const int st = *step;
@@ -936,8 +945,9 @@ extern "C" size_t vlm_sample_sort_workspace_bytes(int B, int V) {
   return (size_t)B * 4 * Vp * sizeof(uint32_t);
 }
 
-// workspace layout: 256 B arrival ticket of the fused greedy tail (must be zero at allocation; the kernel re-arms it; at a
-// fixed offset so that a step over the first B' < B rows of a state finds the same word) |
+// workspace layout: 256 B = arrival ticket of the fused greedy tail (must be zero at allocation; the kernel re-arms it; at a
+// fixed offset so that a step over the first B' < B rows of a state finds the same word) + at byte 4 the count of rows whose
+// argmax found no candidate (an all-NaN logits row; the token is then 0) |
 // [B][NBLK][2] f32 lse partials | [B][NBLK] f32 cand_v | [B][NBLK] i32 cand_i | [B][65536] u32 hist
 extern "C" int vlm_sample_ex(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
                              void* workspace, const vlm_sampler_params* sp, const void* step_ptr, void* stream) {

@@ -375,6 +375,12 @@ def sample_workspace(B, device):
     return torch.zeros(_lib.lib().vlm_sample_workspace_bytes(B), dtype=torch.uint8, device=device)
 
 
+def bad_argmax_rows(ws) -> int:
+    """rows of fused greedy tails run over this workspace whose logits held no finite candidate (all NaN): csrc/sample.hip
+    counts them behind the ticket and hands out token 0 instead of turning the sentinel into an address"""
+    return int(ws[4:8].view(torch.int32).item())
+
+
 def sample(logits, temperature=0.0, top_p=1.0, min_p=0.0, top_k=0, seed=0, step=None, want_logprobs=True, ws=None,
            min_tokens_to_keep=1, top_n_sigma=0.0, p_less=False, typical_p=1.0, xtc_probability=0.0, xtc_threshold=0.0,
            xtc_special_tokens=None, return_filtered=False, input_is_logprobs=False):

@@ -842,6 +842,33 @@ def test_sample_greedy_advance_equals_sample_plus_advance_plus_gather(vops, B, V
     assert int(a["step"][0]) == 6
 
 
+def test_sample_greedy_advance_nan_row_gives_token_zero_not_a_fault(vops):
+    """A logits row without a finite candidate (all NaN) must not turn the argmax sentinel into an embedding address (BENCH_r04:
+    a GPU memory fault kills the process): token 0 as the unfused kernels give, the event counted, the other rows and the
+    next call unaffected."""
+    dev = "cuda"
+    B, V, D = 3, 4099, 64
+    torch.manual_seed(7)
+    embed = torch.randn(V, D, device=dev).to(BF)
+    ws = vops.sample_workspace(B, dev)
+    ctx = torch.arange(10, 10 + B, dtype=torch.int32, device=dev)
+    pos = torch.arange(20, 20 + B, dtype=torch.int32, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    tok = torch.full((B,), -7, dtype=torch.int32, device=dev)
+    h = torch.zeros(B, D, dtype=BF, device=dev)
+    logits = (torch.randn(B, V, device=dev) * 3).to(BF)
+    good = logits.clone()
+    logits[1] = float("nan")
+    vops.sample_greedy_advance(logits, tok, ctx, pos, step, embed, h, ws=ws)
+    torch.cuda.synchronize()
+    ref, _ = vops.sample(good, step=torch.zeros(1, dtype=torch.int32, device=dev))
+    assert int(tok[1]) == 0 and int(tok[0]) == int(ref[0]) and int(tok[2]) == int(ref[2])
+    assert torch.equal(h[1], embed[0]) and torch.equal(h[0], embed[int(ref[0])])
+    assert vops.bad_argmax_rows(ws) == 1
+    vops.sample_greedy_advance(good, tok, ctx, pos, step, embed, h, ws=ws)          # the ticket re-armed itself
+    assert torch.equal(tok, ref) and vops.bad_argmax_rows(ws) == 1 and int(step[0]) == 2
+
+
 def test_logit_penalties_kernel_bit_exact_vs_oracle_and_reference_golden(vops):
     """vlm_apply_logit_penalties (bias -> repetition -> presence -> frequency over the device token history) against the
     oracle on the reference-generated cases (bit-exact bf16), then the push path: tokens appended one by one, ring
