@@ -16,6 +16,9 @@ def ev(fn, reps=10):
 
 shapes = [(4096, 4096, 4096), (8192, 8192, 8192), (9216, 3840, 1280), (9216, 1280, 1280), (9216, 5120, 1280), (9216, 1280, 5120),
           (1024, 3840, 1280), (1024, 5120, 1280), (1024, 1280, 5120), (386, 17920, 1536), (386, 1536, 8960)]
+if os.environ.get("GEMM_SHAPES") == "vit":      # the ViT block's GEMMs at 16 and 64 images of 336 x 336 per call
+    shapes = [(9216, 3840, 1280), (9216, 5120, 1280), (36864, 3840, 1280), (36864, 5120, 1280), (36864, 1280, 1280), (36864, 1280, 5120)]
+EPI = {"none": 0, "bias": ops.EPI_BIAS, "gelu": ops.EPI_BIAS | ops.EPI_GELU_FAST}[os.environ.get("GEMM_EPI", "none")]
 modes = [int(x) for x in sys.argv[1:]] or [0]
 for M, N, K in shapes:
     a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
@@ -24,7 +27,8 @@ for M, N, K in shapes:
     line = f"{M:6d} {N:6d} {K:6d}"
     for mode in modes:
         ops.gemm_set_staging(mode)
-        dt = ev(lambda: ops.gemm(a, w, out=out))
+        bias = torch.randn(N, device="cuda").to(torch.bfloat16) if EPI else None
+        dt = ev(lambda: ops.gemm(a, w, out=out, bias=bias, epilogue=EPI) if EPI else ops.gemm(a, w, out=out))
         line += f"  mode{mode}: {dt*1e6:8.1f} us {2*M*N*K/dt/1e12:7.1f} TF"
     print(line)
 ops.gemm_set_staging(0)
