@@ -1026,7 +1026,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--max-tokens", type=int, default=0, help="0 = the workload's own (256 / 64 / 64)")
     ap.add_argument("--lookahead", type=int, default=8)
-    ap.add_argument("--vit-batch", type=int, default=16)
+    ap.add_argument("--vit-batch", type=int, default=68,
+                    help="336x336 images per vision-tower call of the ViT throughput line.  68 images = 39168 patches = 153 row tiles of "
+                         "256: every GEMM of a block then fills its last round of 256 workgroups (3060 / 3060 / 765 / 765 tiles = 11.95 / "
+                         "11.95 / 2.99 / 2.99 rounds; at 64 images the rounds are 11.25 -> 12 and 2.81 -> 3).  16 images (round 1-4's "
+                         "workload) is reported next to it")
     ap.add_argument("--workload", default="qwen2vl-2b", choices=["qwen2vl-2b", "nanollava", "qwen2vl-7b-b32", "qwen2vl-2b-w4", "phi35v-w4-b16", "idefics2-b8"])
     ap.add_argument("--kv-bits", type=int, default=0, help="phi35v-w4-b16: 8 = uniform 8-bit KV cache (kv_bits of the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1227,6 +1231,13 @@ def stage_extras(args):
     ips448, dt448 = vit_throughput(model, cfg, 1, 448)
     extras.update(vit336=(ips336, dt336), vit448=(ips448, dt448))
     emit()
+    sweep = {}
+    for nb in (16, 32, 64):                      # the same tower at other batch sizes (16 = the workload of rounds 1-4)
+        if nb != args.vit_batch:
+            ips, dt = vit_throughput(model, cfg, nb, 336)
+            sweep[str(nb)] = {"images_per_s": ips, "ms_per_call": dt * 1e3, "frac_of_mfma_peak": ips * VIT_TFLOP_336 / MFMA_BF16_PEAK_TF}
+    extras["vit336_sweep"] = sweep
+    emit()
     for key, fn in (("batch8", lambda: batch_decode_throughput(model, cfg, 8, 64)),
                     ("batch16", lambda: batch_decode_throughput(model, cfg, 16, 64)),
                     ("wide64", lambda: wide_decode_throughput(model, cfg, 64, 48)),
@@ -1307,6 +1318,7 @@ def orchestrate(args):
                                    "ms_per_call": dt336 * 1e3}
             out["vision_single_448_images_per_s"] = ips448
             out["vision_single_448_tflops"] = ips448 * VIT_TFLOP_448
+            out["vision_batch_sweep_336"] = extras.get("vit336_sweep")
         for src, dst in (("batch8", "batch8_decode"), ("batch16", "batch16_decode"), ("wide64", "wide64_decode"),
                          ("continuous", "continuous_batching"), ("sampled", "sampled_decode")):
             out[dst] = extras.get(src)
