@@ -393,6 +393,15 @@ typedef struct vlm_kv_pool {
 int vlm_kv_move_tokens(void* kpool, void* vpool, size_t layer_stride, int n_layers, const void* seq, const void* src_slot,
                        const void* dst_slot, int T, const void* block_table, int max_pages, int Hkv, int D, void* stream);
 
+/* KVCache.update_and_fetch (models/cache.py:345-367; BatchKVCache.update_and_fetch cache.py:1002-1025 calls it per row): the S
+ * tokens of `keys` / `values` - bf16 [Hkv][S][D] views, strides in ELEMENTS (multiples of 8 for the keys, whose rows are read
+ * as 16-byte pieces; base 16-byte aligned) - become the cached tokens slot0 .. slot0 + S - 1 of sequence `seq` in ONE layer:
+ * kpool_layer / vpool_layer = that layer's pools (vlm_kv_pool.kpool + layer * layer_stride elements).  block_table NULL =
+ * identity layout (page = seq * max_pages + index).  The pages must already belong to the sequence. */
+int vlm_kv_append_tokens(void* kpool_layer, void* vpool_layer, const void* keys, const void* values, int S, long k_head_stride,
+                         long k_tok_stride, long v_head_stride, long v_tok_stride, int seq, int slot0, const void* block_table,
+                         int max_pages, int Hkv, int D, void* stream);
+
 /* prefill over T tokens (all sequences concatenated).  h [T][hidden] holds the input
  * embeddings and is the residual stream (overwritten).  Workspaces are caller-owned:
  * xn [T][hidden], qkv [T][(Hq+2Hkv)*D], attn [T][Hq*D], act [T][inter].

@@ -147,6 +147,7 @@ SIGNATURES = {
                            c_float, c_float, c_int, c_uint, c_void_p, c_void_p]),
     "vlm_kv_move_tokens": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                    c_int, c_int, c_void_p]),
+    "vlm_kv_append_tokens": (c_int, [c_void_p] * 4 + [c_int] + [C.c_long] * 4 + [c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "vlm_sample_sort_workspace_bytes": (c_size_t, [c_int, c_int]),
     "vlm_sample_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                               C.POINTER(SamplerParams), c_void_p, c_void_p]),

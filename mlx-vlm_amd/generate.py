@@ -19,7 +19,7 @@ from __future__ import annotations
 
 import time
 from dataclasses import dataclass, field
-from typing import Any, Callable, Generator, List, Optional, Tuple, Union
+from typing import Any, Callable, Dict, Generator, List, Optional, Tuple, TypedDict, Union
 
 import numpy as np
 import torch
@@ -115,6 +115,80 @@ class PromptCacheState:
 
 def _peak_gb():
     return torch.cuda.max_memory_allocated() / 1e9 if torch.cuda.is_available() else 0.0
+
+
+class GenerateKwargs(TypedDict, total=False):
+    """reference generate/types.py:20-63: the keyword arguments generate / stream_generate / generate_step accept.  The same
+    names; array-typed entries are torch tensors or numpy arrays here.  Options outside the built path are accepted by the
+    type and REFUSED at the call (NotImplementedError) rather than ignored: kv_key_bits / kv_value_bits / kv_*_scheme
+    (TurboQuant), apc_manager / apc_tenant (automatic prefix caching), video."""
+    max_tokens: int
+    temperature: float
+    repetition_penalty: Optional[float]
+    repetition_context_size: Optional[int]
+    presence_penalty: Optional[float]
+    presence_context_size: Optional[int]
+    frequency_penalty: Optional[float]
+    frequency_context_size: Optional[int]
+    top_p: float
+    min_p: float
+    top_k: int
+    logit_bias: Optional[Dict[int, float]]
+    prompt_cache: Optional[List[Any]]
+    max_kv_size: Optional[int]
+    kv_bits: Optional[float]
+    kv_key_bits: Optional[float]
+    kv_value_bits: Optional[float]
+    kv_key_scheme: Optional[str]
+    kv_value_scheme: Optional[str]
+    kv_group_size: int
+    kv_quant_scheme: str
+    quantized_kv_start: int
+    sampler: Optional[Callable[[Any], Any]]
+    logits_processors: Optional[List[Callable[[Any, Any], Any]]]
+    prefill_step_size: Optional[int]
+    input_ids: Any
+    pixel_values: Any
+    mask: Any
+    resize_shape: Optional[Tuple[int, int]]
+    eos_tokens: Optional[List[Any]]
+    stopping_criteria: Any
+    thinking_budget: Optional[int]
+    thinking_end_token: str
+    thinking_start_token: Optional[str]
+    enable_thinking: bool
+    skip_special_tokens: bool
+    vision_cache: Any
+    prompt_cache_state: Any
+    apc_manager: Any
+    apc_tenant: Optional[str]
+    seed: Optional[int]
+    verbose: bool
+    video: Any
+
+
+def _policy_enabled(policy) -> bool:
+    return bool(getattr(policy, "enabled", policy))
+
+
+def _chunked_prefill_enabled(model, *, input_ids=None, inputs_embeds=None, prompt_cache=None, draft_model=None, draft_kind=None,
+                             prefill_kwargs=None) -> bool:
+    """reference generate/common.py:39-74: may the prompt be fed in `prefill_step_size` chunks?  The model (or its language
+    model) decides with a callable `chunked_prefill_policy(...)` -> bool or an object with `.enabled`; a truthy
+    `no_chunked_prefill` attribute on either forbids it; otherwise chunking is on unless a draft model is involved."""
+    prefill_kwargs = prefill_kwargs or {}
+    candidates = [model]
+    language_model = getattr(model, "language_model", None)
+    if language_model is not None and language_model is not model:
+        candidates.append(language_model)
+    for candidate in candidates:
+        policy = getattr(candidate, "chunked_prefill_policy", None)
+        if callable(policy):
+            return _policy_enabled(policy(input_ids=input_ids, inputs_embeds=inputs_embeds, prompt_cache=prompt_cache,
+                                          draft_model=draft_model, draft_kind=draft_kind, prefill_kwargs=prefill_kwargs))
+    if any(getattr(candidate, "no_chunked_prefill", False) for candidate in candidates):
+        return False
+    return draft_model is None
 
 
 class _TokenPipe:
@@ -222,6 +296,10 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
     smp, py_sampler = _resolve_sampler(sampler, temperature, top_p, min_p, top_k, seed, top_n_sigma=kwargs.pop("top_n_sigma", None),
                                        p_less=kwargs.pop("p_less", None), typical_p=kwargs.pop("typical_p", None))
     sargs = smp.engine_args()
+    if isinstance(py_sampler, Sampler):
+        # an extended Sampler runs through its __call__, whose RNG step is a counter of the object: like the captured path
+        # (step 0 at the start of every generation) a seeded sampler reused across two generations draws the same stream
+        py_sampler._calls = 0
     eager = bool(py_procs) or py_sampler is not None or thinking_budget_criteria is not None or max_kv_size is not None
     lm = model.language_model
 
@@ -257,12 +335,29 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
     pos = np.asarray(f.position_ids)
     if pos.ndim == 2:
         pos = np.broadcast_to(pos[None], (3,) + pos.shape)
-    logits = lm.prefill(emb.reshape(L, -1), pos.reshape(3, L), [prompt_cache], [L], "last", reserve_extra=max_tokens + 2)
 
     def maybe_quantize_kv_cache():      # generate/common.py:170-181 on the paged cache: all layers share one offset
         sq = prompt_cache[0]._seq
         if kv_bits is not None and not sq.q8 and sq.offset >= quantized_kv_start:
             lm.quantize_kv([sq], bits=int(kv_bits), group_size=int(kv_group_size))
+
+    # chunked prefill (reference ar.py:409-470): a prompt longer than prefill_step_size is fed in chunks of that many tokens -
+    # every chunk attends to the cached tokens and itself (LanguageModel._prefill_onto_cache) - until ONE token is left, which
+    # the final call turns into the first logits.  The model may forbid it (generate/common.py:39-74: chunked_prefill_policy /
+    # no_chunked_prefill); a rotating window takes its first prompt whole (refused above).
+    E, P = emb.reshape(L, -1), pos.reshape(3, L)
+    step_size = None if prefill_step_size is None else int(prefill_step_size)
+    if step_size is not None and not _chunked_prefill_enabled(model, input_ids=ids, inputs_embeds=emb, prompt_cache=prompt_cache,
+                                                              draft_model=None, draft_kind=None, prefill_kwargs=kwargs):
+        step_size = None
+    done = 0
+    if step_size is not None and step_size > 0 and L > step_size and not prompt_cache[0]._seq.rotating:
+        while L - done > 1:
+            n = min(step_size, L - done - 1)
+            lm.prefill(E[done:done + n], P[:, done:done + n], [prompt_cache], [n], "last", reserve_extra=L - done - n + max_tokens + 2)
+            maybe_quantize_kv_cache()
+            done += n
+    logits = lm.prefill(E[done:], P[:, done:], [prompt_cache], [L - done], "last", reserve_extra=max_tokens + 2)
 
     if eager:
         yield from _generate_step_eager(lm, ids, logits, prompt_cache, f, procs, py_procs, smp, sargs, py_sampler,

@@ -176,6 +176,10 @@ class PagedSequence:
         self.seq = pool.new_seq() if seq is None else seq
         self.pages: List[int] = []
         self.offset = 0          # tokens stored (== the reference's KVCache.offset)
+        # KVCache.update_and_fetch appends to ONE layer (the reference's caches are per-layer objects, cache.py:345-367): while a
+        # forward walks the layers their counts differ; `offset` (what the engine's own paths use) moves when every layer has the
+        # token (advance_layer).  None = all layers level with `offset`.
+        self._layer_off: Optional[List[int]] = None
         self.released = False
         self.q8 = False          # True once the sequence's cache has become a QuantizedKVCache (LanguageModel.quantize_kv)
         # max_kv_size (reference RotatingKVCache, cache.py:442-625): None = unbounded.  `held` = entries the pool holds for this
@@ -185,6 +189,24 @@ class PagedSequence:
         self.held = 0
         self.ring = None
         self.ring_idx = 0        # the reference's `_idx` (what its Qwen2-VL reads as the cache offset, language.py:426-431)
+
+    # ------------------------------------------------------------------ per-layer appends (update_and_fetch)
+    def layer_offset(self, layer: int) -> int:
+        return self.offset if self._layer_off is None else self._layer_off[layer]
+
+    def advance_layer(self, layer: int, n: int):
+        if self._layer_off is None:
+            self._layer_off = [self.offset] * self.pool.n_layers
+        self._layer_off[layer] += n
+        lo = min(self._layer_off)
+        self.offset = lo
+        if lo == max(self._layer_off):
+            self._layer_off = None
+
+    def set_offset(self, v: int):
+        """every layer at `v` tokens (trim, a caller's `cache.offset = n`)"""
+        self.offset = int(v)
+        self._layer_off = None
 
     # ------------------------------------------------------------------ max_kv_size
     def set_rotating(self, max_size: int, keep: int = 4):
@@ -261,7 +283,8 @@ class PagedSequence:
             self.ring_idx += 1
 
     def reserve(self, n_total_tokens: int):
-        if self.rotating and self.held:          # (decode: the window never grows past max_size; the prompt itself is kept whole)
+        if self.rotating and self.held:          # (decode: the window never grows past max_size; the prompt itself is kept whole -
+            # the prefill call reserves max(prompt, max_size) + 1 itself, LanguageModel.prefill)
             n_total_tokens = min(n_total_tokens, max(self.held, self.max_size) + 1)
         self.pool.ensure(self.seq, self.pages, n_total_tokens)
 
@@ -289,18 +312,70 @@ class KVCache:
 
     @property
     def offset(self):
-        return self._seq.offset
+        return self._seq.layer_offset(self._layer)
 
     @offset.setter
     def offset(self, v):
-        self._seq.offset = int(v)
+        self._seq.set_offset(int(v))
 
     def size(self):
         s = self._seq
-        return min(s.offset, s.max_size) if s.rotating else s.offset      # RotatingKVCache.size (cache.py:554-555)
+        return min(s.offset, s.max_size) if s.rotating else self.offset      # RotatingKVCache.size (cache.py:554-555)
 
     def empty(self):
-        return self._seq.offset == 0
+        return self.offset == 0
+
+    def update_and_fetch(self, keys: torch.Tensor, values: torch.Tensor):
+        """reference cache.py:345-367: append `keys` / `values` [1, Hkv, S, D] (device tensors) to THIS layer's cache and return
+        what attention sees, (keys[..., :offset, :], values[..., :offset, :]).  The engine's own paths (prefill / decode
+        launches) write K / V themselves; this is the module-contract entry for code that computes k and v on its own - a
+        reference-side model file, a test.  The rows go into the sequence's pages (vlm_kv_append_tokens); the return value is
+        materialised from the pages as `state` is."""
+        from .. import _lib
+        from .._lib import check
+        import ctypes as C
+
+        s = self._seq
+        if s.rotating or s.q8:
+            raise NotImplementedError("update_and_fetch on a rotating / quantized cache: the engine's decode step maintains those")
+        pool = s.pool
+        if keys.dim() != 4 or values.shape != keys.shape or keys.shape[0] != 1 or keys.shape[1] != pool.n_kv_heads \
+                or keys.shape[3] != pool.head_dim:
+            raise ValueError(f"update_and_fetch: keys / values [1, {pool.n_kv_heads}, S, {pool.head_dim}], got {tuple(keys.shape)} / "
+                             f"{tuple(values.shape)}")
+        if keys.device.type != "cuda":
+            raise RuntimeError("update_and_fetch: device tensors (the K / V pools live in HBM; there is no host path)")
+        S = int(keys.shape[2])
+        prev = self.offset
+        if S:
+            k = keys[0].to(pool.kpool.dtype)
+            v = values[0].to(pool.vpool.dtype)
+            if k.stride(2) != 1 or k.stride(0) % 8 or k.stride(1) % 8 or k.data_ptr() % 16:
+                k = k.contiguous()
+            if v.stride(2) != 1:
+                v = v.contiguous()
+            s.reserve(prev + S)
+            esz = pool.kpool.element_size()
+            lo = self._layer * pool.layer_stride * esz
+            bt = None if pool.identity else pool.block_table.data_ptr()
+            check(_lib.lib().vlm_kv_append_tokens(pool.kpool.data_ptr() + lo, pool.vpool.data_ptr() + lo, k.data_ptr(), v.data_ptr(), S,
+                                                  k.stride(0), k.stride(1), v.stride(0), v.stride(1), s.seq, prev, bt, pool.max_pages,
+                                                  pool.n_kv_heads, pool.head_dim,
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "kv_append_tokens")
+            self._keep_uaf = (k, v)             # alive until the stream has run
+            s.advance_layer(self._layer, S)
+        return self.state
+
+    def extract(self, idx: int):
+        """reference cache.py:395-413: row `idx` of a (one-row) cache as a KVCache of its own.  The reference copies the row; here
+        the result shares the sequence's pages (a facade over the same PagedSequence)."""
+        if idx not in (0, -1):
+            raise IndexError(f"KVCache row index {idx} out of range for batch size 1")
+        return KVCache(self._seq, self._layer)
+
+    @classmethod
+    def merge(cls, caches):
+        return BatchKVCache.merge(caches)
 
     @property
     def max_size(self):
@@ -323,7 +398,7 @@ class KVCache:
             if s.rotating and n and s.ring is not None:
                 raise NotImplementedError("trim of a rotating cache whose window has wrapped (the reference moves offset and _idx "
                                           "only, cache.py:577-581: its buffer then holds tokens the offset no longer counts)")
-            s.offset -= n
+            s.set_offset(s.offset - n)
             if s.rotating:
                 s.held -= n
                 s.ring_idx -= n
@@ -333,7 +408,8 @@ class KVCache:
     def state(self):
         """Materialise contiguous (keys, values) [1, Hkv, S, D] from the pages (debug / interop).  A rotating window: the
         entries held, in SLOT order (the reference's buffer is in ring order; attention sees the same set either way)."""
-        pool, S = self._seq.pool, self._seq.kv_entries
+        pool = self._seq.pool
+        S = self._seq.kv_entries if self._seq.rotating else self.offset
         kp, vp = pool.layer_views(self._layer)
         H, D = pool.n_kv_heads, pool.head_dim
         if S == 0:
@@ -352,6 +428,193 @@ class KVCache:
 
     def make_mask(self, N, return_array=False, window_size=None):
         return None if N == 1 else "causal"
+
+
+class BatchKVCache:
+    """The reference's BatchKVCache (cache.py:972-1201) for ONE layer, over rows of the paged pool.
+
+    The reference keeps a left-padded [B, Hkv, S, D] tensor per layer and its batch operations copy it: `filter` gathers rows,
+    `extend` pads and concatenates, `merge` builds a padded tensor from single caches, `finalize` rolls right padding to the
+    left.  Here a row IS a sequence of the pool (its pages are named by a block-table row) and no padding is ever stored, so
+    the same operations are bookkeeping: `filter` / `extend` / `merge` re-list the rows, `finalize` drops the padded tail
+    of a row, `prepare(left_padding=)` only records the numbers the reference's masks would use.  The numbers the reference
+    exposes keep their meaning - `_idx` (length of the padded window), `left_padding[i]`, `offset[i] = _idx - left_padding[i]`
+    (tokens row i really holds) - and are pinned to the reference's own class run over the shim
+    (tests/golden/make_golden_batchcache.py).  All layers of a row share one PagedSequence; like `KVCache.trim`, the
+    operations that change how many tokens a row holds act on the sequence once (layer 0's object).
+    """
+
+    step = 256
+
+    def __init__(self, left_padding: List[int], pool: Optional[KVPool] = None, layer: int = 0, rows: Optional[List[PagedSequence]] = None):
+        """left_padding as the reference (cache.py:975-1000); `pool` (or `rows`) names the paged pool the rows live in - the
+        reference's constructor needs no such thing because its tensors appear at the first update."""
+        self.left_padding = np.asarray(list(left_padding), dtype=np.int64)
+        self.offset = -self.left_padding.copy()
+        self._idx = 0
+        self._right_padding = None
+        self._layer = int(layer)
+        self._pool = pool if pool is not None else (rows[0].pool if rows else None)
+        self._rows: List[Optional[PagedSequence]] = list(rows) if rows is not None else [None] * len(self.left_padding)
+        if len(self._rows) != len(self.left_padding):
+            raise ValueError("BatchKVCache: one row per left_padding entry")
+
+    @classmethod
+    def for_layers(cls, pool: KVPool, left_padding: List[int]) -> List["BatchKVCache"]:
+        """one BatchKVCache per layer over the SAME rows (what a model's per-layer cache list is for a batch)"""
+        rows = [PagedSequence(pool) for _ in left_padding]
+        return [cls(left_padding, rows=rows, layer=l) for l in range(pool.n_layers)]
+
+    # ------------------------------------------------------------------ rows
+    def _row(self, i: int) -> PagedSequence:
+        if self._rows[i] is None:
+            if self._pool is None:
+                raise RuntimeError("BatchKVCache: no pool (construct it with pool= / rows=, or through merge / the model's make_cache)")
+            self._rows[i] = PagedSequence(self._pool)
+        return self._rows[i]
+
+    def _kept(self, i: int) -> int:
+        """tokens row i holds in THIS layer"""
+        r = self._rows[i]
+        return 0 if r is None else r.layer_offset(self._layer)
+
+    # ------------------------------------------------------------------ reference interface
+    def update_and_fetch(self, keys: torch.Tensor, values: torch.Tensor):
+        """cache.py:1002-1025: keys / values [B, Hkv, S, D] land at window positions [_idx, _idx + S).  Positions left of a
+        row's left padding hold padding in the reference (masked out of every attention): they are not stored.  -> the
+        padded (keys, values) [B, Hkv, _idx, D] as the reference returns them (zeros where it holds padding)."""
+        B, S = int(keys.shape[0]), int(keys.shape[2])
+        if B != len(self._rows):
+            raise ValueError(f"update_and_fetch: {B} rows for a cache of {len(self._rows)}")
+        for i in range(B):
+            first = max(0, int(self.left_padding[i]) - self._idx)          # leading positions of this call that are padding
+            if first < S:
+                KVCache(self._row(i), self._layer).update_and_fetch(keys[i:i + 1, :, first:], values[i:i + 1, :, first:])
+        self._advance(S)
+        return self.state[:2]
+
+    def _advance(self, S: int):
+        self.offset = self.offset + S
+        self._idx += S
+
+    def prepare(self, *, left_padding=None, lengths=None, right_padding=None):
+        """cache.py:1027-1040"""
+        if left_padding is not None:
+            if self._idx != 0 or any(self._kept(i) for i in range(len(self._rows))):
+                raise ValueError("Left padding can only be added to an empty BatchKVCache")
+            lp = np.asarray(list(left_padding), dtype=np.int64)
+            self.left_padding = self.left_padding + lp
+            self.offset = self.offset - lp
+        if right_padding is not None and max(right_padding) > 0:
+            self._right_padding = np.asarray(list(right_padding), dtype=np.int64)
+
+    def finalize(self):
+        """cache.py:1042-1049: the reference rolls every row right by its right padding (the padded tail wraps to the front and
+        becomes left padding).  Unpadded rows: the tail tokens of the right-padded call are dropped from the row."""
+        if self._right_padding is not None:
+            pad = self._right_padding
+            if self._layer == 0:
+                for i, r in enumerate(self._rows):
+                    if r is not None and pad[i]:
+                        r.set_offset(max(0, r.offset - int(pad[i])))
+            self.offset = self.offset - pad
+            self.left_padding = self.left_padding + pad
+            self._right_padding = None
+
+    @property
+    def state(self):
+        """(keys, values, offset, left_padding): keys / values padded [B, Hkv, _idx, D], zeros in the padding"""
+        B = len(self._rows)
+        pool = self._pool
+        if pool is None or self._idx == 0:
+            return None, None, self.offset, self.left_padding
+        H, D = pool.n_kv_heads, pool.head_dim
+        k = torch.zeros(B, H, self._idx, D, dtype=pool.kpool.dtype, device=pool.kpool.device)
+        v = torch.zeros_like(k)
+        for i, r in enumerate(self._rows):
+            n = min(self._kept(i), self._idx - int(self.left_padding[i]))
+            if r is not None and n > 0:
+                kk, vv = KVCache(r, self._layer).state
+                k[i, :, int(self.left_padding[i]): int(self.left_padding[i]) + n] = kk[0, :, :n]
+                v[i, :, int(self.left_padding[i]): int(self.left_padding[i]) + n] = vv[0, :, :n]
+        return k, v, self.offset, self.left_padding
+
+    def is_trimmable(self):
+        return True
+
+    def trim(self, n):
+        """cache.py:1065-1069"""
+        n = min(self._idx, n)
+        if self._layer == 0:
+            for r in self._rows:
+                if r is not None:
+                    r.set_offset(max(0, r.offset - n))
+        self._idx -= n
+        self.offset = self.offset - n
+        return n
+
+    def make_mask(self, N: int, return_array: bool = False, **kwargs):
+        # (no padding is stored: the engine's kernels take the rows' own lengths; cache.py:1071-1074 builds an array mask)
+        return None if N == 1 else "causal"
+
+    def filter(self, batch_indices):
+        """cache.py:1076-1098: keep the given rows (in that order), then shift the window left by the smallest left padding"""
+        idx = [int(i) for i in np.asarray(batch_indices).reshape(-1)]
+        self._rows = [self._rows[i] for i in idx]
+        self.offset = self.offset[idx]
+        self.left_padding = self.left_padding[idx]
+        if self._right_padding is not None:
+            self._right_padding = self._right_padding[idx]
+        min_left_pad = int(self.left_padding.min()) if len(idx) else 0
+        if min_left_pad > 0:
+            self._idx -= min_left_pad
+            self.left_padding = self.left_padding - min_left_pad
+
+    def extend(self, other: "BatchKVCache"):
+        """cache.py:1100-1146: the rows of `other` join; both windows are right-justified at max(_idx)"""
+        if self._pool is None:
+            self._pool = other._pool
+        max_idx = max(self._idx, other._idx)
+        self.left_padding = np.concatenate([self.left_padding + (max_idx - self._idx), other.left_padding + (max_idx - other._idx)])
+        self.offset = np.concatenate([self.offset, other.offset])
+        self._rows = self._rows + other._rows
+        self._idx = max_idx
+
+    def extract(self, idx: int) -> "KVCache":
+        """cache.py:1148-1154: row idx as a KVCache (sharing the row's pages; the reference copies)"""
+        return KVCache(self._row(int(idx)), self._layer)
+
+    @classmethod
+    def merge(cls, caches: List["KVCache"]):
+        """cache.py:1156-1188: single caches become the rows of a batch, right-justified at the longest.  The reference copies
+        them into one padded tensor and its callers drop the singles (ar.py:743-746); here the singles' sequences BECOME the
+        rows - no K / V bytes move, and a single cache kept by the caller aliases its row from then on."""
+        lengths = [c.size() for c in caches]
+        max_length = max(lengths)
+        padding = [max_length - n for n in lengths]
+        layer = caches[0]._layer
+        out = cls(padding, rows=[c._seq for c in caches], layer=layer)
+        if max_length:
+            out.offset = out.offset + max_length
+            out._idx = max_length
+        return out
+
+    def size(self):
+        return self._idx
+
+    def empty(self):
+        return self._idx == 0 and not any(self._kept(i) for i in range(len(self._rows)))
+
+    @property
+    def batch_size(self):
+        return len(self._rows)
+
+    def is_single_row(self):
+        return self.batch_size == 1
+
+    @property
+    def nbytes(self):
+        return sum(len(r.pages) * PAGE * r.pool.n_kv_heads * r.pool.head_dim * 2 * 2 for r in self._rows if r is not None)
 
 
 def make_prompt_cache(model, max_kv_size: Optional[int] = None):

@@ -52,6 +52,7 @@ def su_scale(max_pos: int, orig_max_pos: int) -> float:
 
 class LanguageModel(_Engine):
     ROTATING_POS_FROM_RING = False     # rope offset of a decode step over a rotating cache = cache.offset (the reference's own read)
+    ROTATING_PROMPT_WINDOW_MASK = True # phi3_v.py:163 passes cache[0] to create_attention_mask: a prompt > max_kv_size is windowed
     MAX_DECODE_ROWS = 64      # wide steps too: SuScaledRoPE's per-call regime is decided on the device in every rope site
                               # (the fused qkv kernels of the <= 16-row steps, vlm_mrope_kvwrite_decode of the wide ones)
 

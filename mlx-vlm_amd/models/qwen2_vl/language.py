@@ -464,7 +464,15 @@ class LanguageModel:
         kv_seq = np.concatenate([np.full(n, s.seq, dtype=np.int32) for n, s in zip(lengths, seqs)])
         kv_slot = np.concatenate([np.arange(n, dtype=np.int32) for n in lengths])
         for n, s in zip(lengths, seqs):
-            s.reserve(n + reserve_extra)
+            if s.rotating and n > s.max_size and self.ROTATING_PROMPT_WINDOW_MASK:
+                # the reference's Phi-3.5-V hands cache[0] to create_attention_mask (phi3_v.py:163): for a first prompt longer
+                # than max_kv_size RotatingKVCache.make_mask returns a causal mask WINDOWED to max_size (cache.py:586-596);
+                # Qwen2-VL and Bunny pass the cache list and attend causally.  The windowed prefill is not built
+                raise NotImplementedError(f"max_kv_size={s.max_size} with a prompt of {n} tokens: this family's reference prefills "
+                                          "such a prompt under a sliding-window mask (RotatingKVCache.make_mask); only prompts "
+                                          "up to max_kv_size are built for it")
+            # (a rotating window never holds more than max(prompt, max_size) + 1 entries: max_kv_size bounds the reservation)
+            s.reserve(max(n, s.max_size) + 1 if s.rotating else n + reserve_extra)
         kv = self._kv_struct(0)   # prefill addresses block-table rows by absolute sequence id
         check(_lib.lib().vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
         nqb = int(sum((n + 127) // 128 for n in lengths))
@@ -499,15 +507,15 @@ class LanguageModel:
         return logits
 
     def _prefill_onto_cache(self, inputs_embeds, position_ids, caches, lengths, logits_rows, reserve_extra):
-        if any(c[0]._seq.rotating for c in caches):
-            raise NotImplementedError("max_kv_size: a multi-token update of a non-empty rotating cache (the reference first trims "
-                                      "the window to max_size - 1 + S, cache.py:486-505) is not built; only the first prompt")
         """A prompt chunk appended to a NON-EMPTY cache: chunked prefill (reference ar.py:426-472) and `prompt_cache=`
         continuation across calls, i.e. multi-turn (dispatch.py:861-882, common.py:243-263).  The chunk's queries attend
         to [cached tokens | the chunk] (cache.py:345-367 + base.py:366-373 with the causal mask offset by the cache
         length).  Rare path, kept simple: the layer loop runs here over the C-ABI operators; per layer the cached k / v
         rows are fetched back into a full-length token-major buffer (vlm_kv_gather) and the varlen causal attention runs
         over the whole sequence - the prefix rows carry zero queries and their outputs are dropped."""
+        if any(c[0]._seq.rotating for c in caches):
+            raise NotImplementedError("max_kv_size: a multi-token update of a non-empty rotating cache (the reference first trims "
+                                      "the window to max_size - 1 + S, cache.py:486-505) is not built; only the first prompt")
         t, dev = self.args, self.device
         hd, Hq, Hkv = self.head_dim, t.num_attention_heads, t.num_key_value_heads
         D, QKV = t.hidden_size, (Hq + 2 * Hkv) * self.head_dim
@@ -615,6 +623,9 @@ class LanguageModel:
     # a token's rope position is its ring index; the plain-rope families read `cache.offset` (llava_bunny/language.py:65-66,
     # idefics2/language.py:54-55, phi3_v/phi3_v.py:82-83)
     ROTATING_POS_FROM_RING = True
+    # does the family's reference prefill a prompt longer than max_kv_size under the rotating cache's WINDOWED mask (it passes
+    # cache[0] to create_attention_mask: phi3_v.py:163) instead of the plain causal one (cache list: Qwen2-VL, Bunny)?
+    ROTATING_PROMPT_WINDOW_MASK = False
 
     def _rotate_windows(self, seqs) -> np.ndarray:
         """Before a one-token step over sequences with max_kv_size: read each one's rope offset (BEFORE the ring wraps, as the
@@ -834,14 +845,23 @@ class LanguageModel:
             deltas = self._rope_deltas if self._rope_deltas is not None else np.zeros((B, 1), dtype=np.int64)
             deltas = np.broadcast_to(np.asarray(deltas).reshape(-1, 1), (B, 1)) if np.asarray(deltas).size == 1 else deltas
             rope_pos = None
-            if any(c[0]._seq.rotating for c in caches):
-                rope_pos = self._rotate_windows([c[0]._seq for c in caches])
-            st = self.decode_begin(caches, ids.reshape(-1), deltas[:B], max_new_tokens=1, rope_pos=rope_pos)
-            kv = self._kv_struct(st.seq_row0, decode=B <= 16, q8=self._seqs_q8(st.seqs))
-            check(_lib.lib().vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
-            args = st.args()
-            check(_lib.lib().vlm_llm_decode_forward(self._handle, C.byref(args),
-                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), "decode_forward")
+            rot = [c[0]._seq for c in caches if c[0]._seq.rotating]
+            saved = [(s, s.held, None if s.ring is None else list(s.ring), s.ring_idx) for s in rot]
+            try:
+                if rot:
+                    rope_pos = self._rotate_windows([c[0]._seq for c in caches])
+                st = self.decode_begin(caches, ids.reshape(-1), deltas[:B], max_new_tokens=1, rope_pos=rope_pos)
+                kv = self._kv_struct(st.seq_row0, decode=B <= 16, q8=self._seqs_q8(st.seqs))
+                check(_lib.lib().vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
+                args = st.args()
+                check(_lib.lib().vlm_llm_decode_forward(self._handle, C.byref(args),
+                                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)), "decode_forward")
+            except Exception:
+                # the step did not get enqueued (slot rows, pool exhaustion, ...): the ring goes back to what it was, so a retry
+                # plans the SAME move again (newest entry -> the slot of the token that leaves: idempotent on the pool)
+                for s, held, ring, ring_idx in saved:
+                    s.held, s.ring, s.ring_idx = held, ring, ring_idx
+                raise
             for s in st.seqs:
                 s.offset += 1
                 s.note_decode_step()

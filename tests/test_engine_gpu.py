@@ -306,6 +306,45 @@ def test_prefill_onto_non_empty_cache_chunked_and_multi_turn(tiny):
     cache[0]._seq.release(); one[0]._seq.release()
 
 
+def test_generate_step_prefill_step_size_chunks_and_the_models_veto(tiny, monkeypatch):
+    """generate_step(prefill_step_size=16) feeds a longer prompt in chunks of 16 until one token is left (reference
+    ar.py:409-470) - same greedy tokens as the one-shot prefill, log-probs of the first token within the chunk-vs-one-shot
+    distance - unless the model forbids it (`no_chunked_prefill`, or a `chunked_prefill_policy` that says no:
+    generate/common.py:39-74), in which case the prompt goes in whole."""
+    from mlx_vlm_amd.generate import generate_step
+
+    cfg, W, model = tiny
+    lm = model.language_model
+    ids, pix, thw = synth_request(cfg, [(56, 84)], n_text=30, seed=71)
+    L = ids.shape[1]
+    calls = []
+    real = lm.prefill
+
+    def spy(emb, pos, caches, lengths, *a, **k):
+        calls.append(list(lengths))
+        return real(emb, pos, caches, lengths, *a, **k)
+
+    monkeypatch.setattr(lm, "prefill", spy)
+    run = lambda **kw: list(generate_step(ids, model, torch.from_numpy(pix), None, max_tokens=8, image_grid_thw=thw, **kw))     # noqa: E731
+    one = run(prefill_step_size=None)
+    assert calls == [[L]]
+    calls.clear()
+    chunked = run(prefill_step_size=16)
+    want = [[16]] * ((L - 1) // 16) + ([[(L - 1) % 16]] if (L - 1) % 16 else []) + [[1]]
+    assert calls == want, (calls, want)
+    as_pairs = lambda st: [[(t, float(lp[t])) for t, lp in st]]       # noqa: E731
+    _assert_streams_equal_up_to_ties(as_pairs(chunked), as_pairs(one), min_equal=0.5)
+    for veto in ("attr", "policy"):
+        calls.clear()
+        if veto == "attr":
+            monkeypatch.setattr(lm, "no_chunked_prefill", True, raising=False)
+        else:
+            monkeypatch.delattr(lm, "no_chunked_prefill")
+            monkeypatch.setattr(model, "chunked_prefill_policy", lambda **kw: False, raising=False)
+        assert [t for t, _ in run(prefill_step_size=16)] == [t for t, _ in one]
+        assert calls == [[L]], (veto, calls)
+
+
 def test_stream_generate_multi_turn_prompt_cache_state_and_vision_cache(tiny):
     """Two conversation turns through stream_generate with a PromptCacheState and a VisionFeatureCache (reference
     dispatch.py:800-809,861-882): turn 2's prompt = turn 1's prompt + its answer + new text; the cached KV prefix is reused

@@ -52,7 +52,7 @@ def vops():
 def test_library_loaded_is_in_tree():
     import mlx_vlm_amd._lib as L
 
-    assert L.lib().vlm_abi_version() == 6
+    assert L.lib().vlm_abi_version() == 7
     assert "mlx-vlm_amd/lib/libvlm_hip.so" in L.LIB_PATH
 
 
