@@ -214,6 +214,8 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void attn_prefill_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
     const bf16_t* krow = &Ks[(lane & 31) * K_LD + 8 * h];
+    if (D > 80) __builtin_amdgcn_s_setprio(1);      // (two waves per SIMD: measured 139.7 -> 128.6 us on a 4096-token causal prompt;
+                                                    //  the three-wave instances lose 1-3 % with it, profiles/r05_attn_prefill_ab.txt)
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
@@ -221,6 +223,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void attn_prefill_kernel(
         const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(krow + kb * 32 * K_LD + ks * 16);
         st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
       }
+    if (D > 80) __builtin_amdgcn_s_setprio(0);
 
     // ---- online softmax (q = lane&31 is lane-local; lane^32 holds the other keys) ----
     // The loop is VALU-bound (22 MFMAs per tile vs the element-wise work on 32 scores per lane), so the
@@ -289,6 +292,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void attn_prefill_kernel(
     // lane (i = lane & 15, g = lane >> 4): d = db * 32 + 16 (g & 1) + i, keys K0 + {0..3} and K0 + 8 + {0..3} with
     // K0 = kb * 32 + 16 mm + 4 h; it passes the address of row K0 + i / 4, columns (its group's 16 d) + 4 (i % 4)
     const bf16_t* vlane = &Vs[(4 * h + ((lane & 15) >> 2)) * V_LD + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)];
+    if (D > 80) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void attn_prefill_kernel(
                                                       5, 6, 7);
           ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][mm], ot[db], 0, 0, 0);
         }
+    if (D > 80) __builtin_amdgcn_s_setprio(0);
     }   // wave_rows
 
     // hipcc otherwise hoists the register-only part of lstore (the V^T pair packing) up between the QK^T MFMAs - with
