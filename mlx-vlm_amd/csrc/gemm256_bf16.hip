@@ -59,11 +59,19 @@ __device__ __forceinline__ void epilogue256(f32x4_t (&acc)[8][NF], char* smem, c
                                             int ldres, int m0, int n0, int wr, int wc, int fr, int fs, int tid) {
   // ---- epilogue (as gemm_bf16.hip): lane holds D^T[n = nb + fs*4 + r][m = mb + fr]; bias / activation in registers
   //      with the reference's rounding points, tile transposed through LDS, coalesced 16-byte stores (+ residual).
+  //      In TWO halves (round 5): fragment rows mi = 0..3 of every wave are converted and written first; while mi = 4..7
+  //      are converted (the GELU epilogue is ~1770 VALU per lane and tile, 12 % of fc1) the 16-byte stores of the first
+  //      half's rows are issued between the fragments - the store issue of one half runs under the arithmetic of the
+  //      other instead of behind it.  Same values, same addresses.
   constexpr int TN = 64 * NF;          // tile width: 256 or 192 columns
   constexpr int C_LDN = TN + 8;
+  constexpr bool SWI = (EPI & VLM_EPI_SWIGLU) != 0;
+  constexpr int CPR = (SWI ? TN / 2 : TN) / 8;   // 16-byte chunks per output tile row
+  constexpr int PER_HALF = 128 * CPR / 512;      // store chunks of one half per thread: 8 / 6 / 4 / 3
+  static_assert(128 * CPR % 512 == 0, "a half tile's chunks must divide over the 512 threads");
   bf16_t* cs = reinterpret_cast<bf16_t*>(smem);
-#pragma unroll
-  for (int mi = 0; mi < 8; ++mi) {
+  const int n_out = SWI ? (N >> 1) : N, n0o = SWI ? (n0 >> 1) : n0;
+  auto convert = [&](int mi) {
     const int ml = wr * 128 + mi * 16 + fr;
 #pragma unroll
     for (int ni = 0; ni < NF; ++ni) {
@@ -93,14 +101,12 @@ __device__ __forceinline__ void epilogue256(f32x4_t (&acc)[8][NF], char* smem, c
       o.y = pack_bf2(v[2], v[3]);
       *reinterpret_cast<uint2*>(cs + ml * C_LDN + nl) = o;
     }
-  }
-  __syncthreads();
-  constexpr bool SWI = (EPI & VLM_EPI_SWIGLU) != 0;
-  constexpr int CPR = (SWI ? TN / 2 : TN) / 8;   // 16-byte chunks per output tile row
-  const int n_out = SWI ? (N >> 1) : N, n0o = SWI ? (n0 >> 1) : n0;
-#pragma unroll 2
-  for (int c = tid; c < TB * CPR; c += 512) {
-    const int row = c / CPR, cc = c % CPR;
+  };
+  // chunk j (0 .. PER_HALF-1) of this thread in half hf: rows [0, 64) + [128, 192) (hf = 0) or [64, 128) + [192, 256)
+  auto store = [&](int hf, int j) {
+    const int c = tid + 512 * j;
+    const int hr = c / CPR, cc = c % CPR;                       // row inside the half (0 .. 127), chunk inside the row
+    const int row = (hr >> 6) * 128 + hf * 64 + (hr & 63);
     const int m = m0 + row, n = n0o + cc * 8;
     if (m < M && n < n_out) {
       uint4 u = *reinterpret_cast<const uint4*>(cs + row * C_LDN + cc * 8);
@@ -114,7 +120,19 @@ __device__ __forceinline__ void epilogue256(f32x4_t (&acc)[8][NF], char* smem, c
       }
       *reinterpret_cast<uint4*>(C + (size_t)m * ldc + n) = u;
     }
+  };
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) convert(mi);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    convert(4 + k);
+#pragma unroll
+    for (int j = PER_HALF * k / 4; j < PER_HALF * (k + 1) / 4; ++j) store(0, j);
   }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PER_HALF; ++j) store(1, j);
 }
 
 // ABL (ablation builds, scripts/gemm_bench.py): 1 = no DMA in the K loop, 2 = no ds_reads in the K loop,
