@@ -140,6 +140,24 @@ __device__ __forceinline__ float gelu_fast_(float x) {
   const float t = rbf(1.703125f * x);
   return x * rbf(sigmoidf_(t));
 }
+// The same typed graph on TWO elements at once (the GEMM epilogues, where this is 1770 VALU instructions per lane and
+// 256-wide tile: profiles/r05_gemm256_workgroup_timeline.txt - 8.8 of a workgroup's 40.6 us): every rounding to bf16 is ONE
+// v_cvt_pk_bf16_f32 for the pair (the scalar form spent a convert on each element), the multiplies and the add are
+// v_pk_mul_f32 / v_pk_add_f32; the two v_exp_f32 + two v_rcp_f32 stay.  Bit-identical to gelu_fast_ per element (same
+// operations, same rounding points, IEEE multiply / add either way).  x0, x1: the bf16-rounded linear outputs.
+typedef float vlm_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ vlm_f32x2_t rbf2(vlm_f32x2_t v) {
+  const uint32_t p = pack_bf2(v[0], v[1]);
+  return vlm_f32x2_t{bf_lo(p), bf_hi(p)};
+}
+__device__ __forceinline__ vlm_f32x2_t gelu_fast2_(vlm_f32x2_t x) {
+  const vlm_f32x2_t t = rbf2(x * 1.703125f);
+  const vlm_f32x2_t y = t * -1.44269504088896340736f;
+  vlm_f32x2_t e = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
+  e = e + 1.0f;
+  const vlm_f32x2_t sg = rbf2(vlm_f32x2_t{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])});
+  return x * sg;
+}
 // nn.GELU() : x * (1 + erf(x / sqrt(2))) / 2            (reference vision.py:112)
 __device__ __forceinline__ float gelu_erf_(float x) {
   const float t = rbf(x / 1.4140625f);

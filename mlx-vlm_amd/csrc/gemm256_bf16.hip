@@ -31,6 +31,18 @@
 #include "common.cuh"
 #include "../../include/vlm_hip.h"
 
+#ifdef GEMM_STAMPS
+// measurement build only (scripts/r05_gemm_stamps.py): wall-clock stamps (100 MHz s_memrealtime) of every workgroup of the
+// 4-phase kernel - entry, first K tile landed, K loop done, epilogue converted, end - and the CU it ran on
+__device__ unsigned long long g_gemm_stamps[16384][8];
+extern "C" int vlm_debug_gemm_stamps(void* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * 8 * (size_t)n);
+}
+#define GST(i) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_gemm_stamps[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GST(i)
+#endif
+
 namespace {
 
 constexpr int TB = 256;                 // tile edge (M and N)
@@ -89,8 +101,8 @@ __device__ __forceinline__ void epilogue256(f32x4_t (&acc)[8][NF], char* smem, c
         continue;
       }
       if (EPI & VLM_EPI_GELU_FAST) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_fast_(rbf(v[r]));
+        const vlm_f32x2_t g0 = gelu_fast2_(rbf2(vlm_f32x2_t{v[0], v[1]})), g1 = gelu_fast2_(rbf2(vlm_f32x2_t{v[2], v[3]}));
+        v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
       }
       if (EPI & VLM_EPI_GELU_ERF) {
 #pragma unroll
@@ -124,6 +136,7 @@ __device__ __forceinline__ void epilogue256(f32x4_t (&acc)[8][NF], char* smem, c
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) convert(mi);
   __syncthreads();
+  GST(3);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     convert(4 + k);
@@ -131,6 +144,7 @@ __device__ __forceinline__ void epilogue256(f32x4_t (&acc)[8][NF], char* smem, c
     for (int j = PER_HALF * k / 4; j < PER_HALF * (k + 1) / 4; ++j) store(0, j);
   }
   __syncthreads();
+  GST(6);
 #pragma unroll
   for (int j = 0; j < PER_HALF; ++j) store(1, j);
 }
@@ -146,6 +160,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
                                                       bf16_t* __restrict__ C, int M, int N, int K, int lda, int ldw,
                                                       int ldc, int ldres, int tiles_n, int nwg, int group_m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  GST(0);
+#ifdef GEMM_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 16384) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_gemm_stamps[blockIdx.x][5] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
   // XCD-aware bijective remap: blocks with the same (bid % 8) share an L2.
   int bid = blockIdx.x;
   {
@@ -221,6 +244,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
   issue_w(1); issue_a(1, 0); issue_a(1, 1);
   WAIT_A();
   BARRIER();
+  GST(1);
   if (wr == 1) BARRIER();   // the second wave row runs half a phase behind
 
   bf16x8_t wf[NF][2], af[2][2];
@@ -305,8 +329,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
   if (wr == 0) BARRIER();   // barrier counts must match across the workgroup
   VMCNT(0);                 // the clamped reloads past the last K tile still target LDS
   BARRIER();
+  GST(2);
 
   epilogue256<EPI, NF>(acc, smem, bias, res, C, M, N, ldc, ldres, m0, n0, wr, wc, fr, fs, tid);
+  GST(4);
 }
 
 // ---- persistent form of the 4-phase kernel: min(tiles, 256) workgroups walk the tiles (tile = b, b + grid, ...: the same
