@@ -13,6 +13,7 @@ mkdir -p $O
 cd $R
 ( time timeout 1500 python3 -m pytest tests -q -m gpu --tb=line -p no:cacheprovider 2>&1 | grep -v "^$" | tail -15 ) > $O/t_all.log 2>&1; tail -6 $O/t_all.log
 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+( timeout 600 python3 -m pytest tests/test_rotating_gpu.py tests/test_cache_contract_gpu.py tests/test_bench_gpu.py -v -m gpu -p no:cacheprovider 2>&1 | grep -E "PASSED|FAILED|ERROR|passed|failed" ) > $O/r05_rotating_cache_bench_gpu_tests.txt 2>&1; tail -1 $O/r05_rotating_cache_bench_gpu_tests.txt
 SHORT="python3 $R/bench.py --stage headline --gpus 1 --steps 1 --warmup 0 --max-tokens 12"
 cd /tmp
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f -- $SHORT > $O/pmc_fetch.log 2>&1; echo "fetch rc=$?"

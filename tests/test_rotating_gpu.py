@@ -176,3 +176,50 @@ def test_what_the_window_does_not_cover_is_refused(tiny):
     with pytest.raises(NotImplementedError):                  # a second multi-token update of the window
         lm(ids[:, :5], cache=cache, logits_to_keep=1, position_ids=np.broadcast_to(np.arange(40, 45), (3, 1, 5)))
     cache[0]._seq.release()
+
+
+def test_max_kv_size_bounds_the_kv_reservation():
+    """the prefill of a rotating sequence reserved prompt + max_tokens + 2 tokens of pages, so a long generation
+    ran out of pages where the reference runs in max_size entries.  A pool whose sequences hold at most 2 pages (128 tokens):
+    a 40-token prompt decodes 300 tokens under max_kv_size=24, and the sequence never owns more than one page."""
+    from mlx_vlm_amd.generate import generate_step
+    from mlx_vlm_amd.models import cache as cache_mod
+
+    cfg = oq.tiny_cfg()
+    W = oq.random_weights(cfg, seed=1234, dtype=BF, std=0.05, embed_std=0.2)
+    model = build_product_model(cfg, W, kv_pool_tokens=1024, max_seqs=4)
+    lm = model.language_model
+    lm.pool.max_pages = 2                               # (the block table is wider; the allocator refuses a third page)
+    ids = np.random.default_rng(11).integers(3, 1000, (1, 40))
+    cache = cache_mod.make_prompt_cache(lm, max_kv_size=24)
+    toks = [t for t, _ in generate_step(ids, model, None, None, max_tokens=300, temperature=0.0, prompt_cache=cache)]
+    assert len(toks) == 300 and len(cache[0]._seq.pages) == 1 and cache[0].offset == 40 + 299
+    with pytest.raises(RuntimeError, match="max_pages_per_seq"):          # the unbounded cache does need the pages
+        list(generate_step(ids, model, None, None, max_tokens=300, temperature=0.0))
+
+
+def test_phi3v_refuses_a_rotating_prompt_longer_than_the_window():
+    """the reference's Phi-3.5-V passes cache[0] to create_attention_mask (phi3_v.py:163), so a first prompt longer
+    than max_kv_size is prefilled under RotatingKVCache.make_mask's WINDOWED causal mask (cache.py:586-596); this engine's prefill
+    is plain causal - the case is refused, the prompt that fits the window runs."""
+    from mlx_vlm_amd.models.phi3_v.language import LanguageModel as PhiLM
+    from mlx_vlm_amd.models.qwen2_vl.language import LanguageModel as QwenLM
+
+    assert PhiLM.ROTATING_PROMPT_WINDOW_MASK is True and QwenLM.ROTATING_PROMPT_WINDOW_MASK is False
+    from oracle import phi3_v as op
+    from tests.helpers import build_phi3v_model
+    from tests.test_vlm_family_phi3v_gpu import SCALES
+    from mlx_vlm_amd.models import cache as cache_mod
+
+    cfg = op.tiny_cfg()
+    model = build_phi3v_model(cfg, op.random_weights(cfg, seed=4321, dtype=BF, **SCALES), kv_pool_tokens=4096, max_seqs=4)
+    lm = model.language_model
+    ids = np.random.default_rng(5).integers(3, 200, (1, 40))
+    cache = cache_mod.make_prompt_cache(lm, max_kv_size=16)
+    with pytest.raises(NotImplementedError, match="sliding-window mask"):
+        lm(ids, cache=cache, logits_to_keep=1)
+    cache[0]._seq.release()
+    cache = cache_mod.make_prompt_cache(lm, max_kv_size=64)
+    out = lm(ids, cache=cache, logits_to_keep=1)
+    assert out.logits.shape[1] == 1 and cache[0].offset == 40
+    cache[0]._seq.release()
