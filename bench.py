@@ -1260,7 +1260,9 @@ def _child(args, stage, timeout_s):
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
         rc, so, se = r.returncode, r.stdout, r.stderr
     except subprocess.TimeoutExpired as e:
-        rc, so, se = -9, (e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or ""), f"timeout after {timeout_s} s"
+        def _txt(x):
+            return x.decode(errors="replace") if isinstance(x, bytes) else (x or "")
+        rc, so, se = -9, _txt(e.stdout), _txt(e.stderr) + f"\n[bench] stage {stage}: timeout after {timeout_s} s"
     lines = [ln for ln in so.strip().splitlines() if ln.startswith("{")]
     doc = None
     for ln in reversed(lines):
