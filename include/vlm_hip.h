@@ -261,7 +261,12 @@ int vlm_decode_advance(void* ctx, void* pos, const void* tok, void* out_ring, in
  * temperature == 0: argmax, lowest index on ties (sample_utils.py:63-64);
  * else top_p (289-318) -> min_p (266-286) -> top_k (169-175) -> categorical(logprobs/temp) (385-387)
  * by Gumbel-max with a counter-hash RNG keyed by (seed, *step_ptr, row, index).
- * scratch bf16 [B][ldlp] is required when temperature > 0. */
+ * scratch bf16 [B][ldlp] is required when temperature > 0.
+ * workspace: vlm_sample_workspace_bytes(B) bytes, zero-filled ONCE at allocation and then owned by the sampler: an arrival
+ * ticket, the per-block argmax partials, a 65 536-bin key histogram per row (every call leaves it all-zero again) and 128
+ * control words per row for the top-p path that is split over several workgroups (crossing key, per-slice counts, the
+ * populated key range - re-armed by the last launch of a call; the first call after the zero fill sees range [0, kmax],
+ * takes the unwindowed route and gives the same row).  One workspace serves one stream at a time. */
 size_t vlm_sample_workspace_bytes(int B);
 int vlm_sample(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
                void* workspace, float temperature, float top_p, float min_p, int top_k, unsigned seed,

@@ -15,6 +15,7 @@
 // holds values <= 0 in LDS) instead of a sort; typical-p, whose order is not the
 // log-prob's, sorts the indices with a stable in-kernel radix sort.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.cuh"
@@ -533,7 +534,8 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
   // of positive values (a caller may hand any row to a sampler) go to the global histogram - built, zeroed and read only
   // when such a value exists.  (In global memory alone: 150,000 atomics into a few hundred words of one L2, and a thread's 64
   // keys 64 cache lines apart for every lane of a load - most of a 500 us top-p call.)
-  bool any_pos = false;
+  bool any_pos = false, dirty_hist = false;      // dirty_hist: the global half of the histogram holds counts (zeroed again at the end:
+                                                 // between calls the workspace's histogram is all zero - the split top-p path adds into it)
   auto build_hist = [&]() {
     for (int i = tid; i < LH_WORDS; i += 1024) lh[i] = 0;
     if (tid == 0) s_anypos = 0;
@@ -561,6 +563,7 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
         if (k >= 0x8000u) atomicAdd(&hist[k], 1u);
       });
       __syncthreads();
+      dirty_hist = true;
     }
   };
   auto H = [&](uint32_t k) -> uint32_t { return k < 0x8000u ? lh[k + (k >> 6)] : (any_pos ? hist[k] : 0u); };
@@ -879,7 +882,337 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
   STAMP();     // 7 (2 without top-p): filters done
 #ifdef VLM_SAMPLE_STAMPS
   if (tid == 0) hist[31] = (uint32_t)n_stamp;
+#else
+  if (dirty_hist) {        // (uniform: set behind a barrier)
+    __syncthreads();
+    for (int i = 32768 + tid; i < 65536; i += 1024) hist[i] = 0;
+  }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------
+// top-p ALONE (the common nucleus sampler: make_sampler(temp, top_p)), a row split over SPLIT_G workgroups (round 5).  The
+// one-workgroup kernel above spends 60 of its 88 us at V = 151,936 in four passes over the 300 KB row on ONE CU (copy, histogram,
+// ranks inside the crossing bin, mask) and 27 in 64-iteration loops of dependent LDS reads; here
+//   A  topp_hist_kernel   (G x B workgroups)  each slice counts its keys in a private LDS histogram and adds the non-empty bins to
+//                                             the row's global histogram (all zero between calls: D re-zeroes it);
+//   B  topp_cross_kernel  (B workgroups)      the SAME mass / scan / crossing walk as above on the merged histogram - same thread
+//                                             -> key ownership, same float operations in the same order, hence the same crossing
+//                                             (key, rank) bit for bit - with a thread's 64 counts read up front;
+//   C  topp_count_kernel  (G x B)             elements with the crossing key per slice;
+//   D  topp_mask_kernel   (G x B)             writes the filtered row (reads the log-probs directly: no copy pass): below the
+//                                             crossing key -> -inf, the crossing key's elements by their rank in index order
+//                                             (prefix over the slices' counts + ballots inside the slice), re-zeroes the histogram.
+// Four short launches instead of one long one; tests/test_sampler_gpu.py compares the survivors with the one-workgroup kernel,
+// the oracle and the reference's golden rows.
+// ------------------------------------------------------------------------------------------
+constexpr int SPLIT_G = 64;
+constexpr int CTL_WORDS = 128;       // per row: [0] crossing key (65536: none), [1] ranks below this are masked, [2] bin count,
+                                     // [3] a positive key exists, [4] / [5] smallest / largest finite key below 0x8000 (reset to
+                                     // 0xffffffff / 0 by the mask kernel), [8 + s] elements with the crossing key in slice s
+constexpr int PW_MAX = 7424;         // keys in the cross kernel's probability window (29 KB of LDS behind the 130 KB histogram)
+
+__device__ __forceinline__ void slice_bounds(int V, int s, int& c_lo, int& c_hi) {     // in 8-element chunks
+  const int V8 = V >> 3, cps = (V8 + SPLIT_G - 1) / SPLIT_G;
+  c_lo = min(V8, s * cps);
+  c_hi = min(V8, c_lo + cps);
+}
+
+__global__ __launch_bounds__(256) void topp_hist_kernel(const bf16_t* __restrict__ lp_in, int ld_in, int V,
+                                                        uint32_t* __restrict__ hist_all, uint32_t* __restrict__ ctl_all) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lh[];       // [32768] counts of the keys below 0x8000 (no padding here:
+                                                                      // zeroed and flushed as 16-byte pieces)
+  const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const bf16_t* row = lp_in + (size_t)b * ld_in;
+  uint32_t* hist = hist_all + (size_t)b * 65536;
+  const u32x4_t z = {0u, 0u, 0u, 0u};
+#pragma unroll 8
+  for (int i = tid; i < 8192; i += 256) reinterpret_cast<u32x4_t*>(lh)[i] = z;
+  __syncthreads();
+  int c_lo, c_hi;
+  slice_bounds(V, s, c_lo, c_hi);
+  uint32_t ninf = 0, kmin = 0xffffffffu, kmax = 0u;
+  bool pos = false;
+  for (int c = c_lo + tid; c < c_hi; c += 256) {
+    const u32x4_t w = *reinterpret_cast<const u32x4_t*>(row + (size_t)c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t k = bf_key((bf16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu)));
+      if (k == KEY_NEG_INF) ++ninf;
+      else if (k < 0x8000u) { atomicAdd(&lh[k], 1u); kmin = min(kmin, k); kmax = max(kmax, k); }
+      else { atomicAdd(&hist[k], 1u); pos = true; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ninf += __shfl_xor(ninf, o, 64);
+    kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
+    kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+  }
+  if ((tid & 63) == 0) {
+    if (ninf) atomicAdd(&lh[KEY_NEG_INF], ninf);
+    if (kmin <= kmax) {      // the populated range of the finite non-positive keys (the cross kernel's probability window)
+      atomicMin(&ctl_all[(size_t)b * CTL_WORDS + 4], kmin);
+      atomicMax(&ctl_all[(size_t)b * CTL_WORDS + 5], kmax);
+    }
+  }
+  if (pos) ctl_all[(size_t)b * CTL_WORDS + 3] = 1u;
+  __syncthreads();
+  // flush: 4 bins per 16-byte read, 4 reads in flight; a slice of 2400 elements touches a few hundred bins
+#pragma unroll 1
+  for (int i0 = tid; i0 < 8192; i0 += 1024) {
+    u32x4_t q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) q[u] = reinterpret_cast<const u32x4_t*>(lh)[i0 + 256 * u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (q[u][e]) atomicAdd(&hist[4 * (i0 + 256 * u) + e], q[u][e]);
+  }
+}
+
+__global__ __launch_bounds__(1024) void topp_cross_kernel(const uint32_t* __restrict__ hist_all, uint32_t* __restrict__ ctl_all,
+                                                          float thr) {
+  __shared__ float scan_f[17];
+  __shared__ unsigned long long s_best;
+  extern __shared__ uint32_t lh[];               // [LH_WORDS] the lower half of the merged histogram, padded as above
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const uint32_t* hist = hist_all + (size_t)b * 65536;
+  uint32_t* ctl = ctl_all + (size_t)b * CTL_WORDS;
+#ifdef VLM_TOPP_STAMPS
+  int n_st = 0;
+#define XST() do { __syncthreads(); if (tid == 0) ctl[80 + n_st] = (uint32_t)wall_clock64(); ++n_st; } while (0)
+#else
+#define XST() do { } while (0)
+#endif
+  XST();
+#pragma unroll 1
+  for (int k0 = tid; k0 < 32768; k0 += 8192) {        // 8 independent loads per trip (a dependent loop of 32 L2 round trips
+    uint32_t v[8];                                     // was most of this launch)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = hist[k0 + 1024 * u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int k = k0 + 1024 * u; lh[k + (k >> 6)] = v[u]; }
+  }
+  const bool any_pos = ctl[3] != 0;
+  // p(k) = T(exp(value of key k)) is needed for every non-empty bin, twice, by the thread that owns the bin - 64 consecutive keys
+  // per thread, so the few hundred populated bins of a row of log-probs sit in a handful of threads and their exps ran one after
+  // the other (most of this launch).  The populated range [kmin, kmax] (topp_hist_kernel) almost always fits the LDS left beside
+  // the histogram (PW_MAX keys = 58 binades): every thread computes the p of a few keys of that window first.  Same expf, same
+  // rounding - the walk below reads the value instead of computing it.  A row with positive keys, or a wider range, computes on
+  // the fly as the one-workgroup kernel does.
+  float* pw = reinterpret_cast<float*>(lh + LH_WORDS);
+  const uint32_t kmin = ctl[4] & ~63u, kmax = ctl[5] | 63u;      // whole 64-key blocks: a thread's keys are all inside or all outside
+  const bool windowed = !any_pos && ctl[4] <= ctl[5] && kmax - kmin < (uint32_t)PW_MAX;
+  if (tid == 0) s_best = ~0ull;
+  __syncthreads();
+  XST();
+  if (windowed) {
+    for (uint32_t k = kmin + tid; k <= kmax; k += 1024) pw[k - kmin] = lh[k + (k >> 6)] ? rbf(expf(bf2f(key_bf(k)))) : 0.f;
+    __syncthreads();
+  }
+  XST();
+  auto prob = [&](uint32_t k) -> float {
+    return (windowed && k >= kmin && k <= kmax) ? pw[k - kmin] : rbf(expf(bf2f(key_bf(k))));
+  };
+  // This thread's 64 consecutive keys (ascending): mass = sum of count x p in key order, then (after the scan over the threads)
+  // the walk to the first key whose rounded inclusive prefix exceeds the threshold.  The one-workgroup kernel does both with a
+  // dependent LDS read and a branch per key (27 of its 88 us).  In a windowed row a thread's block of keys lies wholly inside
+  // the window - counts and probabilities are read 16 at a time and every key takes the same few instructions: an empty bin has
+  // p = 0 in the window and fmaf(c, 0, x) = x exactly, so the sums are the ones the skipping loops make - or wholly outside,
+  // where only the -inf bin can be populated (p = 0): nothing to add, nothing to propose.
+  auto H = [&](uint32_t k) -> uint32_t { return k < 0x8000u ? lh[k + (k >> 6)] : (any_pos ? hist[k] : 0u); };
+  const uint32_t k0 = (uint32_t)tid * 64u;
+  const bool mine = windowed && k0 >= kmin && k0 <= kmax;
+  float mass = 0.f;
+  XST();
+  if (windowed) {
+    if (mine) {
+#pragma unroll 1
+      for (int j0 = 0; j0 < 64; j0 += 16) {
+        uint32_t cc[16];
+        float pp[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { cc[j] = lh[k0 + (k0 >> 6) + j0 + j]; pp[j] = pw[k0 - kmin + j0 + j]; }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) mass = fmaf((float)cc[j], pp[j], mass);
+      }
+    }
+  } else {
+    for (int j = 0; j < 64; ++j) {
+      const uint32_t k = k0 + j, c = H(k);
+      if (c) mass = fmaf((float)c, prob(k), mass);
+    }
+  }
+  XST();
+  float total;
+  float cum = block_excl_scan<float>(mass, scan_f, &total);
+  XST();
+  {
+    const bool above = rbf(cum) > thr;
+    auto cross_in_bin = [&](uint32_t k, uint32_t c, float pk, float base) {     // the smallest n with T(base + n pk) > thr, by bisection
+      uint32_t lo_n = 1, hi_n = c;                        // invariant: n = hi_n crosses
+      while (lo_n < hi_n) {
+        const uint32_t mid = (lo_n + hi_n) >> 1;
+        if (rbf(fmaf((float)mid, pk, base)) > thr) hi_n = mid;
+        else lo_n = mid + 1;
+      }
+      atomicMin(&s_best, ((unsigned long long)k << 32) | (hi_n - 1));     // hi_n - 1 elements stay below
+    };
+    if (windowed) {
+      if (mine) {
+        // branch-free over the block: the first key with c != 0 and p != 0 (the proposal of a thread that starts above the
+        // threshold), and the first key whose inclusive prefix crosses, with the prefix it started from
+        uint32_t first_any = 64u, first_x = 64u, c_x = 0u;
+        float p_x = 0.f, base_x = 0.f;
+#pragma unroll 1
+        for (int j0 = 0; j0 < 64; j0 += 16) {
+          uint32_t cc[16];
+          float pp[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) { cc[j] = lh[k0 + (k0 >> 6) + j0 + j]; pp[j] = pw[k0 - kmin + j0 + j]; }
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const bool live = cc[j] != 0u && pp[j] != 0.f;
+            const float nxt = fmaf((float)cc[j], pp[j], cum);
+            const bool x = live && first_x == 64u && rbf(nxt) > thr;
+            first_any = (live && first_any == 64u) ? (uint32_t)(j0 + j) : first_any;
+            if (x) { first_x = (uint32_t)(j0 + j); c_x = cc[j]; p_x = pp[j]; base_x = cum; }
+            cum = (first_x == 64u) ? nxt : cum;            // (the walk stops at its crossing)
+          }
+        }
+        if (above) {
+          if (first_any != 64u) atomicMin(&s_best, (unsigned long long)(k0 + first_any) << 32);
+        } else if (first_x != 64u) {
+          cross_in_bin(k0 + first_x, c_x, p_x, base_x);
+        }
+      }
+    } else {
+      for (int j = 0; j < 64; ++j) {
+        const uint32_t k = k0 + j, c = H(k);
+        if (!c) continue;
+        const float pk = prob(k);
+        if (pk == 0.f) continue;
+        if (above) { atomicMin(&s_best, (unsigned long long)k << 32); break; }
+        if (rbf(fmaf((float)c, pk, cum)) > thr) { cross_in_bin(k, c, pk, cum); break; }
+        cum = fmaf((float)c, pk, cum);
+      }
+    }
+  }
+  __syncthreads();
+  XST();
+  if (tid == 0) {
+    const unsigned long long best = s_best;
+    const uint32_t tk = best == ~0ull ? 65536u : (uint32_t)(best >> 32);
+    uint32_t c = 0, drop = 0;
+    if (tk < 65536u) {
+      c = tk < 0x8000u ? lh[tk + (tk >> 6)] : (any_pos ? hist[tk] : 0u);
+      drop = (uint32_t)(best & 0xffffffffu);              // ascending stable sort: the FIRST `drop` of the bin (index order) go
+    }
+    ctl[0] = tk; ctl[1] = drop; ctl[2] = c;
+  }
+}
+
+__device__ __forceinline__ uint32_t hits8(const u32x4_t& w, uint32_t tb) {
+  const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+  return (uint32_t)((w0 & 0xffffu) == tb) | (uint32_t)((w0 >> 16) == tb) << 1 | (uint32_t)((w1 & 0xffffu) == tb) << 2 |
+         (uint32_t)((w1 >> 16) == tb) << 3 | (uint32_t)((w2 & 0xffffu) == tb) << 4 | (uint32_t)((w2 >> 16) == tb) << 5 |
+         (uint32_t)((w3 & 0xffffu) == tb) << 6 | (uint32_t)((w3 >> 16) == tb) << 7;
+}
+
+__global__ __launch_bounds__(256) void topp_count_kernel(const bf16_t* __restrict__ lp_in, int ld_in, int V,
+                                                         uint32_t* __restrict__ ctl_all) {
+  __shared__ uint32_t red[4];
+  const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  uint32_t* ctl = ctl_all + (size_t)b * CTL_WORDS;
+  const uint32_t tk = ctl[0], drop = ctl[1];
+  uint32_t cnt = 0;
+  if (tk < 65536u && drop > 0) {
+    const bf16_t* row = lp_in + (size_t)b * ld_in;
+    const uint32_t tb = key_bf(tk);
+    int c_lo, c_hi;
+    slice_bounds(V, s, c_lo, c_hi);
+    for (int c = c_lo + tid; c < c_hi; c += 256) cnt += (uint32_t)__popc(hits8(*reinterpret_cast<const u32x4_t*>(row + (size_t)c * 8), tb));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = cnt;
+  __syncthreads();
+  if (tid == 0) ctl[8 + s] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void topp_mask_kernel(const bf16_t* __restrict__ lp_in, int ld_in, bf16_t* __restrict__ out_all,
+                                                        int ldo, int V, uint32_t* __restrict__ hist_all, uint32_t* __restrict__ ctl_all) {
+  __shared__ uint32_t wcnt[4];
+  const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* ctl = ctl_all + (size_t)b * CTL_WORDS;
+  const bf16_t* row = lp_in + (size_t)b * ld_in;
+  bf16_t* out = out_all + (size_t)b * ldo;
+  const uint32_t tk = ctl[0], drop = ctl[1];
+  const bool ranked = tk < 65536u && drop > 0;
+  const uint32_t tb = key_bf(min(tk, 65535u));
+  int c_lo, c_hi;
+  slice_bounds(V, s, c_lo, c_hi);
+  // wave w owns a contiguous quarter of the slice's chunks (index order: slices, then waves, then iterations, then lanes)
+  const int per = ((c_hi - c_lo + 3) >> 2), w_lo = min(c_hi, c_lo + wave * per), w_hi = min(c_hi, w_lo + per);
+  uint32_t rank = 0;
+  if (ranked) {
+    for (int sp = 0; sp < s; ++sp) rank += ctl[8 + sp];
+    uint32_t cnt = 0;
+    for (int c = w_lo + lane; c < w_hi; c += 64) cnt += (uint32_t)__popc(hits8(*reinterpret_cast<const u32x4_t*>(row + (size_t)c * 8), tb));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) wcnt[wave] = cnt;
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) rank += wcnt[w];
+  }
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int c0 = w_lo; c0 < w_hi; c0 += 64) {
+    const int c = c0 + lane;
+    const bool in = c < w_hi;
+    u32x4_t w = {0u, 0u, 0u, 0u};
+    if (in) w = *reinterpret_cast<const u32x4_t*>(row + (size_t)c * 8);
+    uint32_t wv[4] = {w[0], w[1], w[2], w[3]};
+    uint32_t m = 0;
+    if (ranked) {
+      m = in ? hits8(w, tb) : 0u;
+      const uint32_t n = (uint32_t)__popc(m);
+      uint32_t before = 0, tot = 0;
+#pragma unroll
+      for (int bit = 0; bit < 4; ++bit) {
+        const unsigned long long bb = __ballot((n >> bit) & 1u);
+        before += (uint32_t)__popcll(bb & lt) << bit;
+        tot += (uint32_t)__popcll(bb) << bit;
+      }
+      uint32_t r = rank + before;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if ((m >> e) & 1u) {
+          if (r < drop) wv[e >> 1] = (e & 1) ? (wv[e >> 1] & 0x0000ffffu) | ((uint32_t)NEG_INF_BF << 16) : (wv[e >> 1] & 0xffff0000u) | NEG_INF_BF;
+          ++r;
+        }
+      rank += tot;
+    }
+    if (in) {
+      if (tk < 65536u) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t bits = (e & 1) ? (wv[e >> 1] >> 16) : (wv[e >> 1] & 0xffffu);
+          if (bf_key((bf16_t)bits) < tk)
+            wv[e >> 1] = (e & 1) ? (wv[e >> 1] & 0x0000ffffu) | ((uint32_t)NEG_INF_BF << 16) : (wv[e >> 1] & 0xffff0000u) | NEG_INF_BF;
+        }
+      }
+      u32x4_t o;
+      o[0] = wv[0]; o[1] = wv[1]; o[2] = wv[2]; o[3] = wv[3];
+      *reinterpret_cast<u32x4_t*>(out + (size_t)c * 8) = o;
+    }
+  }
+  // the row's histogram goes back to all-zero for the next call (1024 words per slice), the positive-key flag with it
+  uint32_t* hist = hist_all + (size_t)b * 65536 + (size_t)s * 1024;
+  const u32x4_t z = {0u, 0u, 0u, 0u};
+  reinterpret_cast<u32x4_t*>(hist)[tid] = z;
+  if (s == 0 && tid == 0) { ctl[3] = 0u; ctl[4] = 0xffffffffu; ctl[5] = 0u; }
 }
 
 // categorical(logprobs / temp) (sample_utils.py:385-387) by Gumbel-max with the counter hash RNG over the (filtered) row:
@@ -936,7 +1269,9 @@ inline float host_rbf(float f) {
 
 }  // namespace
 
-extern "C" size_t vlm_sample_workspace_bytes(int B) { return (size_t)B * (NBLK * 4 * sizeof(float) + 65536 * sizeof(uint32_t)) + 256; }
+extern "C" size_t vlm_sample_workspace_bytes(int B) {
+  return (size_t)B * (NBLK * 4 * sizeof(float) + 65536 * sizeof(uint32_t) + CTL_WORDS * sizeof(uint32_t)) + 256;
+}
 
 // typical_p's sort: per row two (index, payload) array pairs of Vp = V rounded up to 1024 entries (the digit counters live in LDS)
 extern "C" size_t vlm_sample_sort_workspace_bytes(int B, int V) {
@@ -948,7 +1283,8 @@ extern "C" size_t vlm_sample_sort_workspace_bytes(int B, int V) {
 // workspace layout: 256 B = arrival ticket of the fused greedy tail (must be zero at allocation; the kernel re-arms it; at a
 // fixed offset so that a step over the first B' < B rows of a state finds the same word) + at byte 4 the count of rows whose
 // argmax found no candidate (an all-NaN logits row; the token is then 0) |
-// [B][NBLK][2] f32 lse partials | [B][NBLK] f32 cand_v | [B][NBLK] i32 cand_i | [B][65536] u32 hist
+// [B][NBLK][2] f32 lse partials | [B][NBLK] f32 cand_v | [B][NBLK] i32 cand_i | [B][65536] u32 hist (all zero between calls) |
+// [B][128] u32 control words of the split top-p path (zero at allocation)
 extern "C" int vlm_sample_ex(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
                              void* workspace, const vlm_sampler_params* sp, const void* step_ptr, void* stream) {
   if (!logits || !tok || !workspace || !sp || B <= 0 || V <= 0) return VLM_ERR_ARG;
@@ -1015,7 +1351,30 @@ extern "C" int vlm_sample_ex(const void* logits, int ld, int B, int V, void* log
     const bf16_t* row_in = lp_given ? (const bf16_t*)logits : (const bf16_t*)logprobs;
     int ld_in = lp_given ? ld : ldlp;
     const bool any_filter = k.use_top_p || k.use_min_p || k.top_k > 0 || k.n_sigma > 0.f || k.p_less || k.use_typical || k.xtc_prob > 0.f;
-    if (any_filter) {
+    // top-p alone over a 16-byte-aligned row of a real vocabulary: the row split over SPLIT_G workgroups (four short launches)
+    static const bool split_env = [] { const char* e = getenv("VLM_SAMPLE_SPLIT"); return !e || atoi(e) != 0; }();   // A/B knob
+    const bool split = split_env && k.use_top_p && !k.use_min_p && k.top_k == 0 && !(k.n_sigma > 0.f) && !k.p_less && !k.use_typical &&
+                       !(k.xtc_prob > 0.f) && V % 8 == 0 && V >= 8192 && ld_in % 8 == 0 && ldlp % 8 == 0 &&
+                       ((uintptr_t)row_in & 15) == 0 && ((uintptr_t)scratch & 15) == 0;
+    if (split) {
+      static const hipError_t attr_a = hipFuncSetAttribute(reinterpret_cast<const void*>(&topp_hist_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      constexpr int LDS_B = LDS + PW_MAX * (int)sizeof(float);       // histogram + probability window: 159.7 KB of the CU's 160
+      static const hipError_t attr_b = hipFuncSetAttribute(reinterpret_cast<const void*>(&topp_cross_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+      if (attr_a != hipSuccess || attr_b != hipSuccess) return VLM_ERR_HIP + (int)(attr_a != hipSuccess ? attr_a : attr_b);
+      uint32_t* ctl = hist + (size_t)B * 65536;
+      hipLaunchKernelGGL(topp_hist_kernel, dim3(SPLIT_G, B), dim3(256), LDS, st, row_in, ld_in, V, hist, ctl);
+      VLM_CHECK_LAUNCH();
+      hipLaunchKernelGGL(topp_cross_kernel, dim3(B), dim3(1024), LDS_B, st, (const uint32_t*)hist, ctl, k.thr_top_p);
+      VLM_CHECK_LAUNCH();
+      hipLaunchKernelGGL(topp_count_kernel, dim3(SPLIT_G, B), dim3(256), 0, st, row_in, ld_in, V, ctl);
+      VLM_CHECK_LAUNCH();
+      hipLaunchKernelGGL(topp_mask_kernel, dim3(SPLIT_G, B), dim3(256), 0, st, row_in, ld_in, (bf16_t*)scratch, ldlp, V, hist, ctl);
+      VLM_CHECK_LAUNCH();
+      row_in = (const bf16_t*)scratch;
+      ld_in = ldlp;
+    } else if (any_filter) {
       hipLaunchKernelGGL(sample_filter_kernel, dim3(B), dim3(1024), LDS, st, row_in, ld_in, (bf16_t*)scratch, ldlp, V, hist, k,
                          (const int*)step_ptr);
       VLM_CHECK_LAUNCH();

@@ -1,0 +1,17 @@
+import torch, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mlx_vlm_amd import ops, _lib
+torch.manual_seed(0)
+x = torch.randn(1, 151936, device="cuda") * 2
+lp = (x - torch.logsumexp(x, -1, keepdim=True)).to(torch.bfloat16)
+ws = ops.sample_workspace(1, "cuda")
+st = torch.zeros(1, dtype=torch.int32, device="cuda")
+for _ in range(5):
+    ops.sample(lp, temperature=0.7, seed=1, step=st, want_logprobs=False, input_is_logprobs=True, ws=ws, top_p=0.9)
+torch.cuda.synchronize()
+ctl = ws[256 + 64 * 16 + 65536 * 4:].view(torch.int32)
+t = ctl[80:88].cpu().numpy().astype("int64")
+print("ctl[0..6]", ctl[:6].tolist())
+names = ["hist -> LDS", "probability window", "(nothing)", "mass pass", "scan", "crossing walk"]
+for i, n in enumerate(names):
+    print(f"{n:34s} {(t[i + 1] - t[i]) * 0.01:6.2f} us")

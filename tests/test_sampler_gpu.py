@@ -279,3 +279,74 @@ def test_batch_generator_runs_a_sampler_with_the_extra_filters(vops):
             assert bool(keep[t]) or float(lp2[b, t]) >= lo - 2.0 ** -6 * abs(lo), (b, t)
             n += 1
     assert n >= 20
+
+
+_SPLIT_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from mlx_vlm_amd import ops
+from tests.test_sampler_gpu import _split_cases, _filtered
+out = {}
+for name, lp, kw in _split_cases():
+    tok, filt = _filtered(ops, lp, **kw)
+    out[name] = filt.view(torch.int16).numpy(); out[name + ".tok"] = tok.numpy()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def _split_cases():
+    """rows for the split top-p path (csrc/sample.hip: top-p alone, V % 8 == 0, V >= 8192): random rows at three temperatures of
+    the distribution, a row of exact ties (hundreds of elements share the crossing key: the rank inside the bin decides), a row
+    with removed (-inf) tokens, rows with positive values (the global half of the histogram), a top_p so small that nothing
+    crosses, a 3-row call (one launch, three rows)"""
+    cases = []
+    lp = _rows(3, 151936, seed=901)
+    for p in (0.9, 0.5, 0.999, 0.05):
+        cases.append((f"v151936_p{p}", lp, dict(top_p=p)))
+    ties = torch.round(torch.randn(2, 65536, generator=torch.Generator().manual_seed(5)) * 1.5) * 0.25
+    cases.append(("ties", (ties - torch.logsumexp(ties, -1, keepdim=True)).to(BF), dict(top_p=0.8)))
+    holes = _rows(2, 32768, seed=77).clone()
+    holes[:, ::3] = float("-inf")
+    cases.append(("holes", holes, dict(top_p=0.7)))
+    g = torch.Generator().manual_seed(321)
+    pos = (torch.randn(2, 40000, generator=g) * 3.0 + 1.0).to(BF)
+    pos[1] = (pos[1].float() - 10.5).to(BF)
+    cases.append(("positive", pos, dict(top_p=0.9)))
+    cases.append(("no_crossing", _rows(1, 16384, seed=3), dict(top_p=0.001)))
+    return cases
+
+
+def test_split_top_p_equals_the_one_workgroup_kernel(vops, tmp_path):
+    """The row-split top-p path (four short launches over 64 workgroups) against the one-workgroup kernel it replaces
+    (VLM_SAMPLE_SPLIT=0, run in a child process: the knob is read once): filtered rows AND drawn tokens bit for bit; then the
+    split path again on a REUSED workspace with a top-k call (the one-workgroup kernel, which touches the global histogram when
+    a row holds positive values) between two top-p calls - the histogram must be all zero between calls."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref_path = str(tmp_path / "single.npz")
+    env = dict(os.environ, VLM_SAMPLE_SPLIT="0")
+    r = subprocess.run([sys.executable, "-c", _SPLIT_CHILD, root, ref_path], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = np.load(ref_path)
+    for name, lp, kw in _split_cases():
+        tok, filt = _filtered(vops, lp, **kw)
+        assert np.array_equal(filt.view(torch.int16).numpy(), ref[name]), (name, int((filt.view(torch.int16).numpy() != ref[name]).sum()))
+        assert np.array_equal(tok.numpy(), ref[name + ".tok"]), name
+    # reused workspace, interleaved with the other kernel on rows with positive values
+    pos = [lp for name, lp, _ in _split_cases() if name == "positive"][0].cuda()
+    ws = vops.sample_workspace(2, "cuda")
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    outs = []
+    for kw in (dict(top_p=0.9), dict(top_k=33), dict(top_p=0.9), dict(top_p=0.9)):
+        _, _, filt = vops.sample(pos, temperature=0.8, seed=11, step=st, want_logprobs=False, input_is_logprobs=True,
+                                 return_filtered=True, ws=ws, **kw)
+        outs.append(filt.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16)) and torch.equal(outs[2].view(torch.int16), outs[3].view(torch.int16))
+    assert np.array_equal(outs[0].cpu().view(torch.int16).numpy(), ref["positive"])
+    n_hist = 65536 * 2
+    hist = ws[256 + 2 * 64 * 16: 256 + 2 * 64 * 16 + n_hist * 4].view(torch.int32)
+    assert int(hist.abs().sum()) == 0                      # all zero between calls
