@@ -35,6 +35,8 @@ remains unpinned.
   * Pin 2 - an independent implementation (tests/golden/make_golden.py -> qwen2_vl_tiny_hf.npz): HuggingFace
     transformers 5.15 `Qwen2VLForConditionalGeneration` in fp32 (same checkpoint format).  The reference-over-
     shim vectors agree with it to 1.3e-5, which validates the stand-in.
+    The other families (llava_bunny, idefics2, phi3_v) have the same second pin against HF's SigLIP / Qwen2 /
+    Idefics2 / CLIP / Phi-3 classes (tests/golden/make_golden_hf_families.py -> families_hf.npz, <= 2.2e-5).
   * Pin 3 - the reference's own M-RoPE contract (tests/test_rope_utils.py:366-407): fused Metal kernel ==
     pure-MLX path within atol 1e-4 in fp32.  The Metal kernel cannot run off-Metal (the reference itself takes
     the pure-MLX path there); the oracle carries both modes and is held to the same contract.
