@@ -912,6 +912,91 @@ def _fast_w4_oracle_weights(W, predicate):
     return out
 
 
+class ClockSampler:
+    """GPU clocks while a config's child process runs (the Phi-3.5 4-bit line read 3450 vs 4200 tok/s in two
+    contexts - clock / thermal state or the process?).  A thread samples the current shader and memory clock levels from the
+    amdgpu sysfs tables (`pp_dpm_sclk` / `pp_dpm_mclk`: the line with the `*`), falling back to one `rocm-smi -c --json` call
+    before and after when the tables are not there.  The parent never opens the device for this."""
+
+    def __init__(self, period_s=0.25):
+        import glob
+        self.period = period_s
+        self.paths = {}
+        # which card is ours: a node's sysfs lists all eight, rocm-smi only the one this container was given
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        if cards:
+            mine = [k for k in (self._smi_once() or {}).get("_cards", []) if os.path.isdir(f"/sys/class/drm/{k}/device")]
+            for card in ([f"/sys/class/drm/{mine[0]}/device"] if mine else cards):
+                if os.path.exists(os.path.join(card, "pp_dpm_sclk")):
+                    self.paths = {"sclk": os.path.join(card, "pp_dpm_sclk"), "mclk": os.path.join(card, "pp_dpm_mclk")}
+                    break
+        self.samples = {"sclk": [], "mclk": []}
+        self.smi = []
+        self._stop = None
+        self._thread = None
+
+    @staticmethod
+    def _current_mhz(path):
+        try:
+            for ln in open(path).read().splitlines():
+                if ln.rstrip().endswith("*"):
+                    return int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
+        except Exception:
+            return None
+        return None
+
+    @staticmethod
+    def _smi_once():
+        import subprocess
+        try:
+            r = subprocess.run(["/opt/rocm/bin/rocm-smi", "-c", "--json"], capture_output=True, text=True, timeout=15)
+            d = json.loads(r.stdout)
+            card = d[sorted(d)[0]]
+            out = {k.strip(" :"): v for k, v in card.items() if "sclk" in k or "mclk" in k}
+            out["_cards"] = sorted(d)
+            return out
+        except Exception as e:
+            return {"error": f"{type(e).__name__}: {e}"}
+
+    def __enter__(self):
+        import threading
+        if not self.paths:
+            self.smi.append(self._smi_once())
+            return self
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                for k, pth in self.paths.items():
+                    v = self._current_mhz(pth)
+                    if v is not None:
+                        self.samples[k].append(v)
+                self._stop.wait(self.period)
+
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join(timeout=2)
+        else:
+            self.smi.append(self._smi_once())
+        return False
+
+    def summary(self):
+        if self._thread is None:
+            return {"source": "rocm-smi -c --json, before / after", "before": self.smi[0] if self.smi else None,
+                    "after": self.smi[1] if len(self.smi) > 1 else None}
+        out = {"source": "%s, sampled every %.2f s" % (self.paths.get("sclk", ""), self.period)}
+        for k, v in self.samples.items():
+            if v:
+                sv = sorted(v)
+                out[k + "_mhz"] = {"min": sv[0], "median": sv[len(sv) // 2], "max": sv[-1], "n": len(sv)}
+        return out
+
+
 def other_configs(args, rank, ws, dev, t_start, budget_s=420.0):
     """The default line's `configs` block (only configs[1] had a driver-run line): a SHORT run of every
     other BASELINE config on this GPU - value, roofline and, where it fits in ~40 s, the oracle's CPU tokens/s - each in a
@@ -942,13 +1027,15 @@ def other_configs(args, rank, ws, dev, t_start, budget_s=420.0):
         try:
             cmd = [sys.executable, os.path.abspath(__file__), "--workload", fn, "--steps", "3", "--warmup", "2", "--no-extras",
                    "--no-cpu-baseline"] + (["--kv-bits", str(over["kv_bits"])] if over.get("kv_bits") else [])
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=max(60.0, budget_s - (time.perf_counter() - t_start) + 120.0))
+            with ClockSampler() as clk:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=max(60.0, budget_s - (time.perf_counter() - t_start) + 120.0))
             lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not lines:
                 raise RuntimeError(f"rc={r.returncode}: {r.stderr.strip()[-300:]}")
             out = json.loads(lines[-1])
             row = {k: out[k] for k in keep_keys if k in out}
             row["gpu_wall_s"] = time.perf_counter() - t0
+            row["gpu_clocks"] = clk.summary()
         except Exception as e:
             row = {"error": f"{type(e).__name__}: {e}"}
         gc.collect()
@@ -1282,7 +1369,8 @@ def orchestrate(args):
     attempts = []
     out = None
     for _ in range(3):
-        out, rc, err = _child(args, "headline", 900)
+        with ClockSampler() as clk:
+            out, rc, err = _child(args, "headline", 900)
         if out is not None and rc == 0:
             break
         attempts.append({"rc": rc, "stderr_tail": err[-300:]})
@@ -1293,6 +1381,7 @@ def orchestrate(args):
     if attempts:
         out["headline_attempts"] = {"failed": attempts, "succeeded_on": len(attempts) + 1}
     traffic_gu = out.pop("_traffic_gate_up", None)
+    out["gpu_clocks"] = clk.summary()
     print("[bench] headline: " + json.dumps(out), file=sys.stderr, flush=True)
 
     extras = None

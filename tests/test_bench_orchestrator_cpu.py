@@ -76,3 +76,28 @@ def test_three_dead_headline_children_end_the_run(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.orchestrate(_args(no_extras=True))
     assert "failed 3 times" in str(e.value)
+
+
+def test_clock_sampler_reads_the_starred_level_and_degrades_without_sysfs(tmp_path):
+    """bench.ClockSampler: the current level of an amdgpu `pp_dpm_*` table is the line that ends with `*`; without the tables
+    (this container) the summary says so instead of raising."""
+    import time
+
+    import bench
+
+    sclk = tmp_path / "pp_dpm_sclk"
+    sclk.write_text("S: 95Mhz\n0: 500Mhz\n1: 2100Mhz *\n2: 2400Mhz\n")
+    mclk = tmp_path / "pp_dpm_mclk"
+    mclk.write_text("0: 900Mhz\n1: 2000Mhz *\n")
+    assert bench.ClockSampler._current_mhz(str(sclk)) == 2100
+    c = bench.ClockSampler(period_s=0.01)
+    c.paths = {"sclk": str(sclk), "mclk": str(mclk)}
+    with c:
+        time.sleep(0.05)
+    s = c.summary()
+    assert s["sclk_mhz"]["median"] == 2100 and s["mclk_mhz"]["max"] == 2000 and s["sclk_mhz"]["n"] >= 1
+    d = bench.ClockSampler()
+    d.paths = {}
+    with d:
+        pass
+    assert "before" in d.summary() and "after" in d.summary()
