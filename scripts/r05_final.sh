@@ -2,7 +2,7 @@
 # Round-5 end-of-round evidence run on the GPU box (ONE gpurun call, and the LAST one of the round - VERDICT r04: the final .so must
 # not ship unbenched): the whole GPU suite (incl. tests/test_bench_gpu.py = the driver's command), smoke, the two --pmc passes
 # (FETCH_SIZE, WRITE_SIZE: separate runs, kernel-trace only) behind roofline.traffic, rocprofv3 kernel summaries (headline stage,
-# ViT at 16 and 64 images), then the driver's command itself THREE times.  Everything lands in gpurun_out/r05_final/; the
+# ViT at 16 and 64 images, the 4-bit model at one row), then the driver's command itself and two shorter repeats of its headline.  Everything lands in gpurun_out/r05_final/; the
 # summaries worth keeping are copied into profiles/ afterwards (the PMC file right away, so that the bench lines of this run
 # carry the traffic).
 set -u
@@ -11,9 +11,10 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r05_final
 mkdir -p $O
 cd $R
-( time timeout 1500 python3 -m pytest tests -q -m gpu --tb=line -p no:cacheprovider 2>&1 | grep -v "^$" | tail -15 ) > $O/t_all.log 2>&1; tail -6 $O/t_all.log
+( time timeout 1800 python3 -m pytest tests -v -m gpu --tb=line -p no:cacheprovider 2>&1 | grep -v "^$" ) > $O/t_all_verbose.log 2>&1
+tail -15 $O/t_all_verbose.log > $O/t_all.log; tail -6 $O/t_all.log
+grep -E "test_rotating_gpu|test_cache_contract_gpu|test_bench_gpu|test_sampler_gpu.*split| passed| failed" $O/t_all_verbose.log > $O/r05_rotating_cache_bench_gpu_tests.txt; tail -1 $O/r05_rotating_cache_bench_gpu_tests.txt
 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
-( timeout 600 python3 -m pytest tests/test_rotating_gpu.py tests/test_cache_contract_gpu.py tests/test_bench_gpu.py -v -m gpu -p no:cacheprovider 2>&1 | grep -E "PASSED|FAILED|ERROR|passed|failed" ) > $O/r05_rotating_cache_bench_gpu_tests.txt 2>&1; tail -1 $O/r05_rotating_cache_bench_gpu_tests.txt
 SHORT="python3 $R/bench.py --stage headline --gpus 1 --steps 1 --warmup 0 --max-tokens 12"
 cd /tmp
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f -- $SHORT > $O/pmc_fetch.log 2>&1; echo "fetch rc=$?"
@@ -25,14 +26,20 @@ cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o b -- python3 $R/bench.py --stage headline --gpus 1 --steps 2 --warmup 1 > $O/prof_bench.log 2>&1; echo "prof rc=$?"
 timeout 250 rocprofv3 --kernel-trace --stats -d $O/prof_vit -o v -- python3 $R/scripts/vit_prof.py 16 > $O/prof_vit.log 2>&1; echo "vitprof16 rc=$?"
 timeout 250 rocprofv3 --kernel-trace --stats -d $O/prof_vit64 -o v -- python3 $R/scripts/vit_prof.py 64 > $O/prof_vit64.log 2>&1; echo "vitprof64 rc=$?"
+# the 4-bit language model at ONE row, launch by launch, beside the bf16 step's launches
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_w4 -o q -- python3 $R/bench.py --workload qwen2vl-2b-w4 --steps 1 --warmup 1 --no-extras --no-cpu-baseline > $O/prof_w4.log 2>&1; echo "w4prof rc=$?"
 cd $R
 python3 scripts/prof_summary.py $(find $O/prof_bench -name "*.db" | head -1) $O/r05_bench_kernel_stats.txt | head -10
 python3 scripts/r05_decode_gaps.py $(find $O/prof_bench -name "*.db" | head -1) $O/r05_decode_launch_durations.txt | head -12
 python3 scripts/prof_summary.py $(find $O/prof_vit -name "*.db" | head -1) $O/r05_vit16_kernel_stats.txt | head -8
 python3 scripts/prof_summary.py $(find $O/prof_vit64 -name "*.db" | head -1) $O/r05_vit64_kernel_stats.txt | head -8
-rm -rf $O/pmc_fetch $O/pmc_write $O/prof_bench $O/prof_vit $O/prof_vit64
-for i in 1 2 3; do
-  /usr/bin/time -f "wall %e s" timeout 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/r05_bench_line_$i.json 2> $O/bench_$i.err; echo "bench $i rc=$?"; tail -c 200 $O/bench_$i.err
+python3 scripts/prof_summary.py $(find $O/prof_w4 -name "*.db" | head -1) $O/r05_w4_onerow_kernel_stats.txt | head -10
+rm -rf $O/pmc_fetch $O/pmc_write $O/prof_bench $O/prof_vit $O/prof_vit64 $O/prof_w4
+# the driver's command (line 1: everything, as the driver runs it), then the same headline + extras twice more without the CPU legs
+# and the other configs (lines 2, 3: run-to-run spread of the numbers that are quoted)
+/usr/bin/time -f "wall %e s" timeout 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/r05_bench_line_1.json 2> $O/bench_1.err; echo "bench 1 rc=$?"; tail -c 200 $O/bench_1.err
+for i in 2 3; do
+  /usr/bin/time -f "wall %e s" timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-configs --no-cpu-baseline > $O/r05_bench_line_$i.json 2> $O/bench_$i.err; echo "bench $i rc=$?"; tail -c 200 $O/bench_$i.err
 done
 python3 - <<'P'
 import json
