@@ -1318,7 +1318,8 @@ def stage_extras(args):
     extras.update(vit336=(ips336, dt336), vit448=(ips448, dt448))
     emit()
     sweep = {}
-    for nb in (16, 32, 64, 128):                      # the same tower at other batch sizes (16 = the workload of rounds 1-4)
+    for nb in (16, 32, 64, 128, 136):                 # the same tower at other batch sizes (16 = the workload of rounds 1-4;
+                                                      # 136 x 576 patches = 306 row tiles of 256: whole rounds of the 256 CUs)
         if nb != args.vit_batch:
             ips, dt = vit_throughput(model, cfg, nb, 336)
             sweep[str(nb)] = {"images_per_s": ips, "ms_per_call": dt * 1e3, "frac_of_mfma_peak": ips * VIT_TFLOP_336 / MFMA_BF16_PEAK_TF}
