@@ -23,7 +23,7 @@ cd $R
 python3 scripts/pmc_summary.py $O/r05_pmc_traffic.json $(find $O/pmc_fetch -name "*.db" | head -1) $(find $O/pmc_write -name "*.db" | head -1) | head -8
 cp $O/r05_pmc_traffic.json $R/profiles/r05_pmc_traffic.json
 # the driver's command, as the driver runs it (line 1: everything) - before the profiles, so that a long run cannot cost it
-/usr/bin/time -f "wall %e s" timeout 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/r05_bench_line_1.json 2> $O/bench_1.err; echo "bench 1 rc=$?"; tail -c 200 $O/bench_1.err
+timeout 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/r05_bench_line_1.json 2> $O/bench_1.err; echo "bench 1 rc=$?"; tail -c 200 $O/bench_1.err
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o b -- python3 $R/bench.py --stage headline --gpus 1 --steps 2 --warmup 1 > $O/prof_bench.log 2>&1; echo "prof rc=$?"
 timeout 250 rocprofv3 --kernel-trace --stats -d $O/prof_vit -o v -- python3 $R/scripts/vit_prof.py 16 > $O/prof_vit.log 2>&1; echo "vitprof16 rc=$?"
@@ -39,7 +39,7 @@ python3 scripts/prof_summary.py $(find $O/prof_w4 -name "*.db" | head -1) $O/r05
 rm -rf $O/pmc_fetch $O/pmc_write $O/prof_bench $O/prof_vit $O/prof_vit64 $O/prof_w4
 # the same headline + extras twice more without the CPU legs and the other configs (lines 2, 3: run-to-run spread)
 for i in 2 3; do
-  /usr/bin/time -f "wall %e s" timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-configs --no-cpu-baseline > $O/r05_bench_line_$i.json 2> $O/bench_$i.err; echo "bench $i rc=$?"; tail -c 200 $O/bench_$i.err
+  timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-configs --no-cpu-baseline > $O/r05_bench_line_$i.json 2> $O/bench_$i.err; echo "bench $i rc=$?"; tail -c 200 $O/bench_$i.err
 done
 python3 - <<'P'
 import json
