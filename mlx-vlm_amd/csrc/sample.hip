@@ -903,8 +903,11 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
 //   D  topp_mask_kernel   (G x B)             writes the filtered row (reads the log-probs directly: no copy pass): below the
 //                                             crossing key -> -inf, the crossing key's elements by their rank in index order
 //                                             (prefix over the slices' counts + ballots inside the slice), re-zeroes the histogram.
-// Four short launches instead of one long one; tests/test_sampler_gpu.py compares the survivors with the one-workgroup kernel,
-// the oracle and the reference's golden rows.
+// Four short launches instead of one long one, and the two passes around the filter ride in them: from logits, launch A also
+// computes and writes the log-probs (topp_hist_kernel<true>: the work of logprob_argmax_kernel); launch D also makes the Gumbel
+// draw over the survivors (the work of gumbel_partial_kernel).  A sampled top-p step is lse partials -> A -> B -> C -> D -> final
+// argmax: six launches where the first split form had eight.  tests/test_sampler_gpu.py compares rows and tokens with the
+// one-workgroup kernel (log-prob input and logits input), the oracle and the reference's golden rows.
 // ------------------------------------------------------------------------------------------
 constexpr int SPLIT_G = 64;
 constexpr int CTL_WORDS = 128;       // per row: [0] crossing key (65536: none), [1] ranks below this are masked, [2] bin count,
@@ -918,13 +921,27 @@ __device__ __forceinline__ void slice_bounds(int V, int s, int& c_lo, int& c_hi)
   c_hi = min(V8, c_lo + cps);
 }
 
+// FROM_LOGITS: the launch also IS the log-prob pass of the sampled step - lp_in holds the logits, `lse_ws` the NBLK (max, sum)
+// partials of lse_partial_kernel, and the slice's log-probs (bf16(logit - bf16(logsumexp)), ar.py:368: what logprob_argmax_kernel
+// writes) go to `lp_out` on their way into the histogram.  A slice is exactly a block of that kernel (8 ceil(V / 512) elements),
+// so the sampled step loses a launch and a second read of the row.
+template <bool FROM_LOGITS>
 __global__ __launch_bounds__(256) void topp_hist_kernel(const bf16_t* __restrict__ lp_in, int ld_in, int V,
-                                                        uint32_t* __restrict__ hist_all, uint32_t* __restrict__ ctl_all) {
+                                                        uint32_t* __restrict__ hist_all, uint32_t* __restrict__ ctl_all,
+                                                        const float* __restrict__ lse_ws, bf16_t* __restrict__ lp_out, int ld_out) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lh[];       // [32768] counts of the keys below 0x8000 (no padding here:
                                                                       // zeroed and flushed as 16-byte pieces)
   const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const bf16_t* row = lp_in + (size_t)b * ld_in;
   uint32_t* hist = hist_all + (size_t)b * 65536;
+  float lse = 0.f;
+  if (FROM_LOGITS) {      // (the merge of logprob_argmax_kernel: lane i takes partial i, every wave redundantly)
+    const int li = tid & 63;
+    const float pm = lse_ws[((size_t)b * NBLK + li) * 2], ps = lse_ws[((size_t)b * NBLK + li) * 2 + 1];
+    const float m = wave_max(pm);
+    const float sm = wave_sum(pm > -INFINITY ? ps * expf(pm - m) : 0.f);
+    lse = rbf(m + logf(sm));
+  }
   const u32x4_t z = {0u, 0u, 0u, 0u};
 #pragma unroll 8
   for (int i = tid; i < 8192; i += 256) reinterpret_cast<u32x4_t*>(lh)[i] = z;
@@ -934,7 +951,15 @@ __global__ __launch_bounds__(256) void topp_hist_kernel(const bf16_t* __restrict
   uint32_t ninf = 0, kmin = 0xffffffffu, kmax = 0u;
   bool pos = false;
   for (int c = c_lo + tid; c < c_hi; c += 256) {
-    const u32x4_t w = *reinterpret_cast<const u32x4_t*>(row + (size_t)c * 8);
+    u32x4_t w = *reinterpret_cast<const u32x4_t*>(row + (size_t)c * 8);
+    if (FROM_LOGITS) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t lo16 = f2bf(bf2f((bf16_t)(w[q] & 0xffffu)) - lse), hi16 = f2bf(bf2f((bf16_t)(w[q] >> 16)) - lse);
+        w[q] = lo16 | (hi16 << 16);
+      }
+      *reinterpret_cast<u32x4_t*>(lp_out + (size_t)b * ld_out + (size_t)c * 8) = w;
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const uint32_t k = bf_key((bf16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu)));
@@ -1142,9 +1167,20 @@ __global__ __launch_bounds__(256) void topp_count_kernel(const bf16_t* __restric
   if (tid == 0) ctl[8 + s] = red[0] + red[1] + red[2] + red[3];
 }
 
+// ... and the draw: z_i = x_i / temp - log(-log(u_i)) over the survivors as they are written (gumbel_partial_kernel's arithmetic,
+// its index-keyed RNG and its lowest-index tie rule; the best (z, i) of the slice lands where that kernel's block would leave
+// it), so the filtered row is not read back by a launch of its own.
 __global__ __launch_bounds__(256) void topp_mask_kernel(const bf16_t* __restrict__ lp_in, int ld_in, bf16_t* __restrict__ out_all,
-                                                        int ldo, int V, uint32_t* __restrict__ hist_all, uint32_t* __restrict__ ctl_all) {
+                                                        int ldo, int V, uint32_t* __restrict__ hist_all, uint32_t* __restrict__ ctl_all,
+                                                        float temp, uint32_t seed, const int* __restrict__ step_ptr,
+                                                        float* __restrict__ cand_v, int* __restrict__ cand_i) {
   __shared__ uint32_t wcnt[4];
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const uint32_t step = (uint32_t)(step_ptr ? *step_ptr : 0);
+  const float it = 1.0f / temp;
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
   const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   uint32_t* ctl = ctl_all + (size_t)b * CTL_WORDS;
   const bf16_t* row = lp_in + (size_t)b * ld_in;
@@ -1206,7 +1242,30 @@ __global__ __launch_bounds__(256) void topp_mask_kernel(const bf16_t* __restrict
       u32x4_t o;
       o[0] = wv[0]; o[1] = wv[1]; o[2] = wv[2]; o[3] = wv[3];
       *reinterpret_cast<u32x4_t*>(out + (size_t)c * 8) = o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bf16_t xb = (bf16_t)((e & 1) ? (wv[e >> 1] >> 16) : (wv[e >> 1] & 0xffffu));
+        if (xb == NEG_INF_BF) continue;                     // (a removed token cannot win: -inf + gumbel = -inf)
+        const int i = c * 8 + e;
+        const float zg = __builtin_fmaf(bf2f(xb), it, -logf(-logf(hash_uniform(seed, step, (uint32_t)b, (uint32_t)i))));      // (one fma,
+                                                                                  // as hipcc contracts gumbel_partial_kernel's x * it + g)
+        if (zg > best || (zg == best && i < besti)) { best = zg; besti = i; }
+      }
     }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(besti, o, 64);
+    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+  }
+  if (lane == 0) { sv[wave] = best; si[wave] = besti; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < besti)) { best = sv[w]; besti = si[w]; }
+    cand_v[(size_t)b * NBLK + s] = best;
+    cand_i[(size_t)b * NBLK + s] = besti;
   }
   // the row's histogram goes back to all-zero for the next call (1024 words per slice), the positive-key flag with it
   uint32_t* hist = hist_all + (size_t)b * 65536 + (size_t)s * 1024;
@@ -1235,9 +1294,10 @@ __global__ __launch_bounds__(256) void gumbel_partial_kernel(const bf16_t* __res
   for (int i = lo + tid; i < hi; i += 256) {
     const bf16_t xb = row[i];
     if (xb == NEG_INF_BF) continue;                     // (a removed token cannot win: -inf + gumbel = -inf)
-    const float x = bf2f(xb) * it;
     const float u = hash_uniform(seed, step, (uint32_t)b, (uint32_t)i);
-    const float z = x + (-logf(-logf(u)));
+    const float z = __builtin_fmaf(bf2f(xb), it, -logf(-logf(u)));      // x / temp + g as ONE fma (what hipcc's contraction made of the
+                                                                        // two statements before; written out so that topp_mask_kernel's copy
+                                                                        // of the draw cannot drift from it)
     if (z > best || (z == best && i < besti)) { best = z; besti = i; }
   }
 #pragma unroll
@@ -1334,12 +1394,21 @@ extern "C" int vlm_sample_ex(const void* logits, int ld, int B, int V, void* log
   float* cand_v = ws + (size_t)B * NBLK * 2;
   int* cand_i = (int*)(cand_v + (size_t)B * NBLK);
   uint32_t* hist = (uint32_t*)(cand_i + (size_t)B * NBLK);
+  // top-p alone over a 16-byte-aligned row of a real vocabulary: the row split over SPLIT_G workgroups
+  static const bool split_env = [] { const char* e = getenv("VLM_SAMPLE_SPLIT"); return !e || atoi(e) != 0; }();   // A/B knob
+  const bool split = temperature != 0.0 && split_env && (lp_given || logprobs) && k.use_top_p && !k.use_min_p && k.top_k == 0 && !(k.n_sigma > 0.f) && !k.p_less &&
+                     !k.use_typical && !(k.xtc_prob > 0.f) && V % 8 == 0 && V >= 8192 && (lp_given ? ld : ldlp) % 8 == 0 && ldlp % 8 == 0 &&
+                     ((uintptr_t)(lp_given ? logits : logprobs) & 15) == 0 && ((uintptr_t)scratch & 15) == 0;
+  // ... and from logits: the log-prob pass runs inside the histogram launch (topp_hist_kernel<true>)
+  const bool fused_lp = split && !lp_given && ld % 8 == 0 && ((uintptr_t)logits & 15) == 0;
   if (!lp_given) {
     hipLaunchKernelGGL(lse_partial_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws);
     VLM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(logprob_argmax_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws,
-                       (bf16_t*)logprobs, ldlp, cand_v, cand_i);
-    VLM_CHECK_LAUNCH();
+    if (!fused_lp) {
+      hipLaunchKernelGGL(logprob_argmax_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws,
+                         (bf16_t*)logprobs, ldlp, cand_v, cand_i);
+      VLM_CHECK_LAUNCH();
+    }
   }
   if (temperature == 0.0) {
     hipLaunchKernelGGL(argmax_final_kernel, dim3(B), dim3(64), 0, st, cand_v, cand_i, (int*)tok);
@@ -1351,29 +1420,34 @@ extern "C" int vlm_sample_ex(const void* logits, int ld, int B, int V, void* log
     const bf16_t* row_in = lp_given ? (const bf16_t*)logits : (const bf16_t*)logprobs;
     int ld_in = lp_given ? ld : ldlp;
     const bool any_filter = k.use_top_p || k.use_min_p || k.top_k > 0 || k.n_sigma > 0.f || k.p_less || k.use_typical || k.xtc_prob > 0.f;
-    // top-p alone over a 16-byte-aligned row of a real vocabulary: the row split over SPLIT_G workgroups (four short launches)
-    static const bool split_env = [] { const char* e = getenv("VLM_SAMPLE_SPLIT"); return !e || atoi(e) != 0; }();   // A/B knob
-    const bool split = split_env && k.use_top_p && !k.use_min_p && k.top_k == 0 && !(k.n_sigma > 0.f) && !k.p_less && !k.use_typical &&
-                       !(k.xtc_prob > 0.f) && V % 8 == 0 && V >= 8192 && ld_in % 8 == 0 && ldlp % 8 == 0 &&
-                       ((uintptr_t)row_in & 15) == 0 && ((uintptr_t)scratch & 15) == 0;
     if (split) {
-      static const hipError_t attr_a = hipFuncSetAttribute(reinterpret_cast<const void*>(&topp_hist_kernel),
+      static const hipError_t attr_a = hipFuncSetAttribute(reinterpret_cast<const void*>(&topp_hist_kernel<false>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      static const hipError_t attr_a2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&topp_hist_kernel<true>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (attr_a2 != hipSuccess) return VLM_ERR_HIP + (int)attr_a2;
       constexpr int LDS_B = LDS + PW_MAX * (int)sizeof(float);       // histogram + probability window: 159.7 KB of the CU's 160
       static const hipError_t attr_b = hipFuncSetAttribute(reinterpret_cast<const void*>(&topp_cross_kernel),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
       if (attr_a != hipSuccess || attr_b != hipSuccess) return VLM_ERR_HIP + (int)(attr_a != hipSuccess ? attr_a : attr_b);
       uint32_t* ctl = hist + (size_t)B * 65536;
-      hipLaunchKernelGGL(topp_hist_kernel, dim3(SPLIT_G, B), dim3(256), LDS, st, row_in, ld_in, V, hist, ctl);
+      if (fused_lp)
+        hipLaunchKernelGGL(topp_hist_kernel<true>, dim3(SPLIT_G, B), dim3(256), LDS, st, (const bf16_t*)logits, ld, V, hist, ctl,
+                           (const float*)ws, (bf16_t*)logprobs, ldlp);
+      else
+        hipLaunchKernelGGL(topp_hist_kernel<false>, dim3(SPLIT_G, B), dim3(256), LDS, st, row_in, ld_in, V, hist, ctl,
+                           (const float*)nullptr, (bf16_t*)nullptr, 0);
       VLM_CHECK_LAUNCH();
       hipLaunchKernelGGL(topp_cross_kernel, dim3(B), dim3(1024), LDS_B, st, (const uint32_t*)hist, ctl, k.thr_top_p);
       VLM_CHECK_LAUNCH();
       hipLaunchKernelGGL(topp_count_kernel, dim3(SPLIT_G, B), dim3(256), 0, st, row_in, ld_in, V, ctl);
       VLM_CHECK_LAUNCH();
-      hipLaunchKernelGGL(topp_mask_kernel, dim3(SPLIT_G, B), dim3(256), 0, st, row_in, ld_in, (bf16_t*)scratch, ldlp, V, hist, ctl);
+      hipLaunchKernelGGL(topp_mask_kernel, dim3(SPLIT_G, B), dim3(256), 0, st, row_in, ld_in, (bf16_t*)scratch, ldlp, V, hist, ctl,
+                         k.temp, k.seed, (const int*)step_ptr, cand_v, cand_i);
       VLM_CHECK_LAUNCH();
-      row_in = (const bf16_t*)scratch;
-      ld_in = ldlp;
+      hipLaunchKernelGGL(argmax_final_kernel, dim3(B), dim3(64), 0, st, cand_v, cand_i, (int*)tok);
+      VLM_CHECK_LAUNCH();
+      return VLM_OK;
     } else if (any_filter) {
       hipLaunchKernelGGL(sample_filter_kernel, dim3(B), dim3(1024), LDS, st, row_in, ld_in, (bf16_t*)scratch, ldlp, V, hist, k,
                          (const int*)step_ptr);

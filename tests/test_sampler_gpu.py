@@ -285,13 +285,34 @@ _SPLIT_CHILD = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1])
 from mlx_vlm_amd import ops
-from tests.test_sampler_gpu import _split_cases, _filtered
+from tests.test_sampler_gpu import _split_cases, _filtered, _split_logit_cases, _from_logits
 out = {}
 for name, lp, kw in _split_cases():
     tok, filt = _filtered(ops, lp, **kw)
     out[name] = filt.view(torch.int16).numpy(); out[name + ".tok"] = tok.numpy()
+for name, logits, kw in _split_logit_cases():
+    tok, lp, filt = _from_logits(ops, logits, **kw)
+    out[name] = filt.view(torch.int16).numpy(); out[name + ".tok"] = tok.numpy(); out[name + ".lp"] = lp.view(torch.int16).numpy()
 np.savez(sys.argv[2], **out)
 """
+
+
+def _split_logit_cases():
+    """LOGITS in (the captured decode step's form): the log-prob pass rides in the histogram launch and the draw in the mask
+    launch.  A 3-row call at the real vocabulary, a row with -inf logits, an odd leading dimension handled by the fallback."""
+    g = torch.Generator().manual_seed(77)
+    big = (torch.randn(3, 151936, generator=g) * 2.5 + 3.0).to(BF)
+    holes = (torch.randn(2, 32768, generator=g) * 2.0).to(BF)
+    holes[:, 5::7] = float("-inf")
+    return [("logits_v151936_p0.9", big, dict(top_p=0.9)), ("logits_v151936_p0.3", big, dict(top_p=0.3, temp=1.3, seed=5, step=9)),
+            ("logits_holes", holes, dict(top_p=0.8))]
+
+
+def _from_logits(vops, logits, temp=0.8, seed=11, step=0, **kw):
+    st = torch.tensor([step], dtype=torch.int32, device="cuda")
+    tok, lp, filt = vops.sample(logits.cuda(), temperature=temp, seed=seed, step=st, want_logprobs=True, return_filtered=True, **kw)
+    torch.cuda.synchronize()
+    return tok.cpu(), lp.cpu(), filt.cpu()
 
 
 def _split_cases():
@@ -335,6 +356,11 @@ def test_split_top_p_equals_the_one_workgroup_kernel(vops, tmp_path):
         tok, filt = _filtered(vops, lp, **kw)
         assert np.array_equal(filt.view(torch.int16).numpy(), ref[name]), (name, int((filt.view(torch.int16).numpy() != ref[name]).sum()))
         assert np.array_equal(tok.numpy(), ref[name + ".tok"]), name
+    for name, logits, kw in _split_logit_cases():
+        tok, lp, filt = _from_logits(vops, logits, **kw)
+        assert np.array_equal(lp.view(torch.int16).numpy(), ref[name + ".lp"]), name          # the log-prob pass inside launch A
+        assert np.array_equal(filt.view(torch.int16).numpy(), ref[name]), (name, int((filt.view(torch.int16).numpy() != ref[name]).sum()))
+        assert np.array_equal(tok.numpy(), ref[name + ".tok"]), name                           # the draw inside launch D
     # reused workspace, interleaved with the other kernel on rows with positive values
     pos = [lp for name, lp, _ in _split_cases() if name == "positive"][0].cuda()
     ws = vops.sample_workspace(2, "cuda")
