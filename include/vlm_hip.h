@@ -446,10 +446,11 @@ typedef struct vlm_decode_args {
 } vlm_decode_args;
 
 /* vlm_decode_args.flags */
-#define VLM_DECODE_FUSED_TAIL 1 /* greedy only: the step does not start with the embedding gather - h already holds
-                                   embed[tok] (the caller gathers it once after the prefill, vlm_embed_gather) and the
-                                   sampler tail (vlm_sample_greedy_advance) leaves the next step's h behind.  The host
-                                   must not rewrite tok between steps. */
+#define VLM_DECODE_FUSED_TAIL 1 /* the step does not start with the embedding gather - h already holds embed[tok] (the
+                                   caller gathers it once after the prefill, vlm_embed_gather) and the sampler tail leaves
+                                   the next step's h behind: vlm_sample_greedy_advance at temperature 0; with a temperature
+                                   the sampler's last launch (final pick) also does vlm_decode_advance and the gather.
+                                   bf16 embedding tables only.  The host must not rewrite tok between steps. */
 
 int vlm_llm_create(const vlm_llm_config* cfg, void** handle);          /* (host) */
 int vlm_llm_destroy(void* handle);

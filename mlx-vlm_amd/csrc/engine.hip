@@ -289,8 +289,12 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
   const int QKV = (Hq + 2 * Hkv) * hd;
   const float scale = c.attn_scale > 0.f ? c.attn_scale : 1.0f / sqrtf((float)hd);
   const float qk_scale = c.rope_qk_scale > 0.f ? c.rope_qk_scale : 1.f;
-  const bool fused_tail = sample && (a->flags & VLM_DECODE_FUSED_TAIL) && a->temperature == 0.f;
-  if ((a->flags & VLM_DECODE_FUSED_TAIL) && !fused_tail) return 1;   // the flag promises h == embed[tok] at entry
+  // VLM_DECODE_FUSED_TAIL: the step starts from h == embed[tok] and its sampler tail leaves the next step's h behind - the greedy
+  // tail (vlm_sample_greedy_advance) or, with a temperature, the sampled one (vlm_sample_advance: final pick + advance + gather)
+  const bool fused_flag = sample && (a->flags & VLM_DECODE_FUSED_TAIL);
+  const bool fused_tail = fused_flag && a->temperature == 0.f;
+  const bool fused_sampled = fused_flag && a->temperature > 0.f;
+  if ((a->flags & VLM_DECODE_FUSED_TAIL) && !fused_flag) return 1;   // the flag promises h == embed[tok] at entry
   const Tuning& tn = m->tune;
   // WIDE steps (more than 16 rows): beyond one N tile of the skinny-M MFMA GEMM the projections run on the prefill GEMMs,
   // i.e. a layer is the prefill's launch sequence (vlm_llm_prefill above) with the paged decode attention in place of
@@ -305,7 +309,7 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
   void* const xn = a->attn;
   int n = 0;
   // h = embed[tok]
-  if (!fused_tail) {
+  if (!fused_flag) {
     if (m->g.embed_sb) { TRY(vlm_dequant_w4(m->g.embed, m->g.embed_sb, a->tok, a->h, B, D, D, c.vocab, stream)); }
     else { TRY(vlm_embed_gather(a->tok, m->g.embed, a->h, B, D, D, c.vocab, stream)); }
     ++n;
@@ -417,6 +421,11 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
     if (fused_tail) {
       TRY(vlm_sample_greedy_advance(a->logits, VL, B, c.vocab, a->logprobs, VL, a->tok, a->sample_ws, a->ctx, a->pos,
                                     a->out_ring, a->ring_len, a->step, m->g.embed, a->h, D, D, stream)); n += 2;
+    } else if (fused_sampled) {
+      TRY(vlm_sample_advance(a->logits, VL, B, c.vocab, a->logprobs, a->scratch, VL, a->tok, a->sample_ws, a->temperature, a->top_p,
+                             a->min_p, a->top_k, a->seed, a->ctx, a->pos, a->out_ring, a->ring_len, a->step, m->g.embed, a->h, D, D,
+                             stream));
+      n += ((a->top_p > 0.f && a->top_p < 1.f) || a->min_p != 0.f || a->top_k > 0) ? 5 : 4;
     } else {
       TRY(vlm_sample(a->logits, VL, B, c.vocab, a->logprobs, a->scratch, VL, a->tok, a->sample_ws, a->temperature, a->top_p,
                      a->min_p, a->top_k, a->seed, a->step, stream));

@@ -105,6 +105,51 @@ __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restric
   if (threadIdx.x == 0) tok[b] = besti == 0x7fffffff ? 0 : besti;   // (sampling over a row with every token removed: a valid index anyway)
 }
 
+// The SAMPLED step's tail in one launch (the greedy step has logprob_argmax_tail_kernel): the pick of argmax_final_kernel for every
+// row, then vlm_decode_advance's bookkeeping (cache.py:362 offset += 1, language.py:476-509 pos, token ring, step counter) and the
+// embedding gather of the NEXT step (nn.Embedding, language.py:164,179) - the two launches a sampled step used to spend around
+// the sampler.  One workgroup; B <= TAIL_MAX_B.
+struct SampleTail {
+  int *ctx, *pos, *out_ring, *step;
+  int ring_len;
+  const bf16_t* embed;
+  bf16_t* h;
+  int D, ldh;
+};
+
+__global__ __launch_bounds__(256) void argmax_final_advance_kernel(const float* __restrict__ cand_v, const int* __restrict__ cand_i,
+                                                                   int* __restrict__ tok, int B, int V, SampleTail t) {
+  __shared__ int s_tok[64];
+  const int tid = threadIdx.x, li = tid & 63, wave = tid >> 6;
+  for (int r = wave; r < B; r += 4) {
+    float bv = cand_v[(size_t)r * NBLK + li];
+    int bi = cand_i[(size_t)r * NBLK + li];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (li == 0) s_tok[r] = (unsigned)bi >= (unsigned)V ? 0 : bi;      // (every token removed / no candidate: a valid index anyway)
+  }
+  __syncthreads();
+  const int st = *t.step;
+  if (tid < B) {
+    const int y = s_tok[tid];
+    tok[tid] = y;
+    t.ctx[tid] += 1;
+    t.pos[tid] += 1;
+    if (t.out_ring) t.out_ring[(size_t)(st % t.ring_len) * B + tid] = y;
+  }
+  const int cpr = t.D >> 3;
+  for (int i = tid; i < B * cpr; i += 256) {
+    const int r = i / cpr, c = i % cpr;
+    reinterpret_cast<uint4*>(t.h + (size_t)r * t.ldh)[c] = reinterpret_cast<const uint4*>(t.embed + (size_t)s_tok[r] * t.D)[c];
+  }
+  __syncthreads();
+  if (tid == 0) *t.step = st + 1;
+}
+
 
 // ------------------------------------------------------------------------------------------
 // Greedy tail of a decode step in ONE launch: logprobs + per-block argmax candidates as logprob_argmax_kernel, then the
@@ -1345,8 +1390,8 @@ extern "C" size_t vlm_sample_sort_workspace_bytes(int B, int V) {
 // argmax found no candidate (an all-NaN logits row; the token is then 0) |
 // [B][NBLK][2] f32 lse partials | [B][NBLK] f32 cand_v | [B][NBLK] i32 cand_i | [B][65536] u32 hist (all zero between calls) |
 // [B][128] u32 control words of the split top-p path (zero at allocation)
-extern "C" int vlm_sample_ex(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
-                             void* workspace, const vlm_sampler_params* sp, const void* step_ptr, void* stream) {
+static int sample_ex_impl(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
+                          void* workspace, const vlm_sampler_params* sp, const void* step_ptr, void* stream, const SampleTail* tail) {
   if (!logits || !tok || !workspace || !sp || B <= 0 || V <= 0) return VLM_ERR_ARG;
   const double temperature = sp->temperature;
   if (!(temperature >= 0.0)) return VLM_ERR_ARG;
@@ -1445,7 +1490,8 @@ extern "C" int vlm_sample_ex(const void* logits, int ld, int B, int V, void* log
       hipLaunchKernelGGL(topp_mask_kernel, dim3(SPLIT_G, B), dim3(256), 0, st, row_in, ld_in, (bf16_t*)scratch, ldlp, V, hist, ctl,
                          k.temp, k.seed, (const int*)step_ptr, cand_v, cand_i);
       VLM_CHECK_LAUNCH();
-      hipLaunchKernelGGL(argmax_final_kernel, dim3(B), dim3(64), 0, st, cand_v, cand_i, (int*)tok);
+      if (tail) hipLaunchKernelGGL(argmax_final_advance_kernel, dim3(1), dim3(256), 0, st, cand_v, cand_i, (int*)tok, B, V, *tail);
+      else hipLaunchKernelGGL(argmax_final_kernel, dim3(B), dim3(64), 0, st, cand_v, cand_i, (int*)tok);
       VLM_CHECK_LAUNCH();
       return VLM_OK;
     } else if (any_filter) {
@@ -1459,10 +1505,35 @@ extern "C" int vlm_sample_ex(const void* logits, int ld, int B, int V, void* log
     hipLaunchKernelGGL(gumbel_partial_kernel, dim3(NBLK, B), dim3(256), 0, st, row_in, ld_in, V, k.temp, k.seed,
                        (const int*)step_ptr, cand_v, cand_i);
     VLM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(argmax_final_kernel, dim3(B), dim3(64), 0, st, cand_v, cand_i, (int*)tok);
+    if (tail) hipLaunchKernelGGL(argmax_final_advance_kernel, dim3(1), dim3(256), 0, st, cand_v, cand_i, (int*)tok, B, V, *tail);
+    else hipLaunchKernelGGL(argmax_final_kernel, dim3(B), dim3(64), 0, st, cand_v, cand_i, (int*)tok);
   }
   VLM_CHECK_LAUNCH();
   return VLM_OK;
+}
+
+extern "C" int vlm_sample_ex(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
+                             void* workspace, const vlm_sampler_params* sp, const void* step_ptr, void* stream) {
+  return sample_ex_impl(logits, ld, B, V, logprobs, scratch, ldlp, tok, workspace, sp, step_ptr, stream, nullptr);
+}
+
+// vlm_sample (temperature > 0) + vlm_decode_advance + the next step's vlm_embed_gather, for the engine's captured step (internal.h)
+VLM_INTERNAL int vlm_sample_advance(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
+                                    void* workspace, float temperature, float top_p, float min_p, int top_k, unsigned seed,
+                                    void* ctx, void* pos, void* out_ring, int ring_len, void* step, const void* embed, void* h,
+                                    int D, int ldh, void* stream) {
+  if (!(temperature > 0.f) || !ctx || !pos || !step || !embed || !h) return VLM_ERR_ARG;
+  if (B > 64 || D % 8 || ldh % 8 || (out_ring && ring_len <= 0)) return VLM_ERR_SHAPE;
+  vlm_sampler_params sp{};
+  sp.temperature = temperature;
+  sp.top_p = top_p;
+  sp.min_p = min_p;
+  sp.min_tokens_to_keep = 1;
+  sp.top_k = top_k;
+  sp.typical_p = 1.0;
+  sp.seed = seed;
+  const SampleTail t{(int*)ctx, (int*)pos, (int*)out_ring, (int*)step, ring_len, (const bf16_t*)embed, (bf16_t*)h, D, ldh};
+  return sample_ex_impl(logits, ld, B, V, logprobs, scratch, ldlp, tok, workspace, &sp, step, stream, &t);
 }
 
 extern "C" int vlm_sample(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,

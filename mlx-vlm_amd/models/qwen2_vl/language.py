@@ -741,8 +741,9 @@ class LanguageModel:
         q8 = self._seqs_q8(st.seqs)
         kv = self._kv_struct(st.seq_row0, decode=True, q8=q8)
         check(L.vlm_llm_set_kv(self._handle, C.byref(kv)), "llm_set_kv")
-        fused = bool(self.tuning.get("fused_tail")) and float(sampler_args.get("temperature", 0.0)) == 0.0 \
-            and not hasattr(self._w["embed"], "wq")          # the fused tail gathers bf16 embedding rows
+        # the fused tails (greedy: vlm_sample_greedy_advance; with a temperature: the sampler's last launch also advances and
+        # gathers) read bf16 embedding rows
+        fused = bool(self.tuning.get("fused_tail")) and not hasattr(self._w["embed"], "wq")
         args = st.args(flags=_lib.DECODE_FUSED_TAIL if fused else 0, penalties=penalties, **sampler_args)
         if os.environ.get("VLM_NO_GRAPH"):           # diagnostics: every launch of the step visible to the HIP runtime's log
             use_graph = False

@@ -409,6 +409,37 @@ def test_fused_greedy_decode_hook_matches_module_call(tiny):
     c1[0]._seq.release(); c2[0]._seq.release()
 
 
+@pytest.mark.parametrize("sampler", [dict(temperature=0.8), dict(temperature=1.0, top_p=0.9), dict(temperature=0.7, top_p=0.9, min_p=0.02, top_k=50)])
+def test_sampled_fused_tail_equals_gather_sample_advance(tiny, sampler):
+    """The sampled step's fused tail (vlm_sample_advance: the sampler's last launch also advances ctx / pos / step, writes the
+    token ring and gathers the next step's embedding row) against the three-launch form it replaces (embedding gather, vlm_sample,
+    vlm_decode_advance): the same tokens and log-prob rows over 70 steps - across the 64-token page boundary and with a lookahead
+    of 5 steps enqueued ahead."""
+    from mlx_vlm_amd.generate import generate_step
+
+    cfg, W, model = tiny
+    lm = model.language_model
+    ids = np.random.default_rng(33).integers(3, 1000, (1, 21))
+
+    def run():
+        toks, lps = [], []
+        for t, lp in generate_step(ids, model, None, None, max_tokens=70, seed=9, lookahead=5, **sampler):
+            toks.append(t)
+            lps.append(lp.clone())
+        return toks, torch.stack(lps)
+
+    try:
+        lm.apply_tuning(fused_tail=0)
+        base_t, base_lp = run()
+        lm.apply_tuning(fused_tail=1)
+        t, lp = run()
+        assert t == base_t
+        assert torch.equal(lp, base_lp)
+        assert len(set(t)) >= 2                     # (a sampled stream, not one repeated token)
+    finally:
+        lm.apply_tuning()
+
+
 def test_sampling_temperature_reproducible_and_varied(tiny):
     from mlx_vlm_amd.generate import generate_step
 
