@@ -1237,6 +1237,7 @@ def stage_headline(args, rank, ws, local):
     dec_max = parallel.max_over_ranks(dec_s, dev)
     pre_max = parallel.max_over_ranks(pre_s, dev)
     prep_max = parallel.max_over_ranks(host_prep_s, dev)
+    prep_ranks, dec_ranks = parallel.per_rank(host_prep_s, dev), parallel.per_rank(dec_s, dev)
     decode_steps = args.steps * (args.max_tokens - 1)          # tokens produced by decode steps, per rank
     decode_tps = ws * decode_steps / dec_max
     ms_per_step = wall / args.steps * 1e3
@@ -1249,6 +1250,8 @@ def stage_headline(args, rank, ws, local):
     traffic_gu, traffic_tok, traffic_src = pmc_traffic()
     dist = _dist_info(ws, load)
     dist["host_prep_s_max_over_ranks"] = prep_max          # image processing + request assembly of one rank's request
+    dist["host_prep_s_per_rank"] = prep_ranks              # (the first real 8-GPU run answers "is a rank's host side the tail?" from
+    dist["decode_s_per_rank"] = dec_ranks                  #  this line alone; weight_broadcast_GBps sits beside them when ranks > 1)
     out = {
         "metric": "decode tokens/sec + vision-prefill images/sec, Qwen2-VL-2B", "value": decode_tps, "unit": "tokens/s",
         "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

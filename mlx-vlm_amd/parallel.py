@@ -304,6 +304,17 @@ def max_over_ranks(x: float, device=None) -> float:
     return float(t[0])
 
 
+def per_rank(x: float, device=None) -> list:
+    """every rank's value of `x`, in rank order, on every rank - one all-reduce (SUM) of a vector in which a rank fills only its own
+    slot: the same collective as max_over_ranks / sum_over_ranks (no object gather on a path that has not seen hardware)"""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(x)]
+    t = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    t[dist.get_rank()] = float(x)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]
+
+
 def sum_over_ranks(x: float, device=None) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return x

@@ -221,6 +221,7 @@ assert W["ids"].tolist() == list(range(10))
 mine = parallel.shard_requests(7, rank, ws)
 res = parallel.gather_results([(i, i * i) for i in mine])
 assert abs(parallel.max_over_ranks(float(rank)) - 1.0) < 1e-9 and abs(parallel.sum_over_ranks(1.0) - 2.0) < 1e-9
+assert parallel.per_rank(10.0 + rank) == [10.0, 11.0]
 parallel.barrier()
 if rank == 0:
     flat = sorted(sum(res, []))
