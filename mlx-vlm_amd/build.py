@@ -27,6 +27,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # GEMM loses its 5472 accumulator moves.  Results are bit-identical (profiles/r02_attn_prefill_probe.txt).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-pass-failed", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+# measurement builds only (e.g. VLM_BUILD_DEFINES="VLM_GEMM_ABLATION GEMM_STAMPS"): never set for the shipped library
+FLAGS += ["-D" + d for d in os.environ.get("VLM_BUILD_DEFINES", "").split()]
 
 
 def sources():

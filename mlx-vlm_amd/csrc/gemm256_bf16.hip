@@ -162,6 +162,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
   extern __shared__ __attribute__((aligned(16))) char smem[];
   GST(0);
 #ifdef GEMM_STAMPS
+  const unsigned long long mt0 = __builtin_amdgcn_s_memtime();   // shader cycles: slot 7 = cycles entry -> end (effective clock)
   if (threadIdx.x == 0 && blockIdx.x < 16384) {
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -333,6 +334,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
 
   epilogue256<EPI, NF>(acc, smem, bias, res, C, M, N, ldc, ldres, m0, n0, wr, wc, fr, fs, tid);
   GST(4);
+#ifdef GEMM_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 16384) g_gemm_stamps[blockIdx.x][7] = __builtin_amdgcn_s_memtime() - mt0;
+#endif
 }
 
 // ---- persistent form of the 4-phase kernel: min(tiles, 256) workgroups walk the tiles (tile = b, b + grid, ...: the same
