@@ -27,6 +27,9 @@ def world() -> tuple:
 def init(backend: str | None = None):
     """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
     rank, ws, local = world()
+    if ws > 1:
+        from . import utils
+        utils.fit_host_threads()          # the ranks of a node share one CPU quota: each sizes its pool for its share
     if ws > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -144,6 +147,7 @@ def dp_load(model_path: str, device=None, src: int = 0, bucket_bytes: int = 1 <<
     from . import utils
 
     rank, ws, local = world()
+    utils.fit_host_threads()          # this rank's share of the node's CPU quota (quota // LOCAL_WORLD_SIZE), before any CPU tensor op
     if device is None:
         device = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
     config = utils.load_config(model_path)
@@ -296,10 +300,16 @@ def gather_results(local: List, dst: int = 0) -> List[List] | None:
     return out
 
 
+def _scalar_dtype():
+    """dtype of the scalar all-reduces below: fp32 over RCCL (the dtype every NCCL-family reduction kernel is built and
+    exercised for; timings of seconds and counts below 2^24 are exact enough in it), fp64 on the gloo CPU path."""
+    return torch.float32 if dist.get_backend() == "nccl" else torch.float64
+
+
 def max_over_ranks(x: float, device=None) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return x
-    t = torch.tensor([x], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    t = torch.tensor([x], dtype=_scalar_dtype(), device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])
 
@@ -309,7 +319,7 @@ def per_rank(x: float, device=None) -> list:
     slot: the same collective as max_over_ranks / sum_over_ranks (no object gather on a path that has not seen hardware)"""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [float(x)]
-    t = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    t = torch.zeros(dist.get_world_size(), dtype=_scalar_dtype(), device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
     t[dist.get_rank()] = float(x)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [float(v) for v in t.tolist()]
@@ -318,7 +328,7 @@ def per_rank(x: float, device=None) -> list:
 def sum_over_ranks(x: float, device=None) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return x
-    t = torch.tensor([x], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    t = torch.tensor([x], dtype=_scalar_dtype(), device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t[0])
 

@@ -129,16 +129,27 @@ def cpu_quota() -> int:
     return n
 
 
+def host_threads_per_rank() -> int:
+    """This rank's share of the CPU quota: the ranks of one node (LOCAL_WORLD_SIZE, set by torchrun; WORLD_SIZE as the
+    single-node fallback) share ONE cgroup budget, so eight ranks each sizing a pool for the whole quota is the CFS-throttle
+    stall of profiles/r02_continuous_diag.txt times eight."""
+    try:
+        local_ws = int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1)
+    except ValueError:
+        local_ws = 1
+    return max(1, cpu_quota() // max(1, local_ws))
+
+
 def fit_host_threads():
     """torch sizes its CPU thread pool from the cores it SEES (256 on an MI355X host); inside a container with a CFS quota
     (16 cores on the boxes measured) any CPU tensor op then wakes ~128 OpenMP workers that keep spinning after the region,
     the cgroup's budget is gone within milliseconds and the whole process - the decode loop included - is frozen for the
     rest of the 100 ms period (profiles/r02_continuous_diag.txt: 80-90 ms stalls in a 2.7 MB copy).  The engine's own host
-    path uses no parallel CPU ops; this caps torch's pool at the quota for whatever else runs in the process.
-    VLM_FIT_HOST_THREADS=0 opts out."""
+    path uses no parallel CPU ops; this caps torch's pool at this rank's share of the quota (quota // LOCAL_WORLD_SIZE, at
+    least 1) for whatever else runs in the process.  VLM_FIT_HOST_THREADS=0 opts out."""
     if os.environ.get("VLM_FIT_HOST_THREADS", "1") == "0":
         return
-    q = cpu_quota()
+    q = host_threads_per_rank()
     if torch.get_num_threads() > q:
         torch.set_num_threads(q)
 

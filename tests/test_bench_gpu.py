@@ -29,10 +29,16 @@ def test_driver_command_default_line():
     out, err = _run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-configs"])
     assert out["metric"].startswith("decode tokens/sec") and out["unit"] == "tokens/s" and out["n_gpus"] == 1
     assert out["steps"] == 2 and out["warmup"] == 1 and out["value"] > 100.0
-    assert "headline_attempts" not in out, out.get("headline_attempts")
+    assert "headline_attempts" not in out, out.get("headline_attempts")          # ANY retry of the headline child fails the suite
+    assert out["config"]["headline_retries"] == 0 and out["config"]["vit_batch"] == 64
     assert "extras_error" not in out, out.get("extras_error")
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and 0.05 < rf["frac"] < 1.0 and rf["peak"] == 8000.0
+    # the images/s half of the metric sits inside `roofline` (the object the driver's record keeps), like for like
+    for key, batch in (("vit", 64), ("vit_16", 16), ("vit_single_448", 1)):
+        v = rf[key]
+        assert v["batch"] == batch and v["images_per_s"] > 10.0 and 0.02 < v["frac"] < 1.0 and v["peak_tflops"] == 2500.0, (key, v)
+    assert abs(rf["vit"]["frac"] - out["roofline_vit"]["frac"]) < 1e-12
     assert 0.05 < out["roofline_vit"]["frac"] < 1.0 and out["roofline_kernel"]["us_per_launch"] > 1.0
     for k in ("batch8_decode", "batch16_decode", "wide64_decode", "continuous_batching", "sampled_decode"):
         assert out[k] and "error" not in out[k], (k, out[k])
@@ -46,3 +52,12 @@ def test_headline_configuration_under_both_kv_layouts(layout):
     out, _ = _run(["--stage", "headline", "--steps", "1", "--warmup", "1"], env={"VLM_KV_LAYOUT": layout})
     assert out["config"]["max_tokens"] == 256 and out["config"]["decode_lookahead"] == 8 and out["config"]["prompt_tokens"] == 386
     assert out["value"] > 100.0 and 0.05 < out["roofline"]["frac"] < 1.0
+
+
+def test_headline_canary_with_one_hipmalloc_per_tensor():
+    """The headline child once per suite with torch's caching allocator and the HSA fragment allocator off: every tensor is
+    its own hipMalloc, so an out-of-bounds access of any kernel in the timed region lands on an unmapped page and kills the
+    process instead of reading a neighbour (the canary for the unexplained memory fault of BENCH_r04)."""
+    out, _ = _run(["--stage", "headline", "--steps", "1", "--warmup", "1"],
+                  env={"PYTORCH_NO_CUDA_MEMORY_CACHING": "1", "HSA_DISABLE_FRAGMENT_ALLOCATOR": "1"})
+    assert out["value"] > 100.0 and out["decode_nan_rows"] == 0 and out["config"]["prompt_tokens"] == 386

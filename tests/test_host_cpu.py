@@ -607,6 +607,46 @@ def test_bench_gpus_2_dry_run_through_the_self_launch():
     assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
 
 
+def test_bench_gpus_8_dry_run_has_one_entry_per_rank():
+    """`python bench.py --gpus 8 --dry-run`: the driver's 8-rank shape on gloo CPU ranks - eight ranks come up through the
+    self-launch, every per-rank vector of the line has eight entries, the requests are dealt over all eight, and every rank
+    sized torch's CPU pool for ITS share of the cgroup quota (utils.host_threads_per_rank: quota // LOCAL_WORLD_SIZE)."""
+    import json
+
+    from mlx_vlm_amd.utils import cpu_quota
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "64"          # (torchrun would set 1: make the fit do the work)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["distributed"]["ranks"] == 8 and out["config"]["parallelism"] == "dp8"
+    for key in ("host_prep_s_per_rank", "decode_s_per_rank", "serve_s_per_rank", "per_rank_requests", "torch_threads_per_rank"):
+        assert len(out[key]) == 8, (key, out[key])
+    assert sum(out["per_rank_requests"]) == 4 * 8 + 1 and min(out["per_rank_requests"]) >= 4
+    assert all(v > 0 for v in out["decode_s_per_rank"])
+    share = max(1, cpu_quota() // 8)
+    assert all(t <= share for t in out["torch_threads_per_rank"]), (out["torch_threads_per_rank"], share)
+
+
+def test_host_threads_per_rank_divides_the_quota(monkeypatch):
+    from mlx_vlm_amd import utils
+
+    q = utils.cpu_quota()
+    for k in ("LOCAL_WORLD_SIZE", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    assert utils.host_threads_per_rank() == q
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    assert utils.host_threads_per_rank() == max(1, q // 2)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")          # torchrun's per-node count wins over the job's
+    assert utils.host_threads_per_rank() == max(1, q // 8)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4096")
+    assert utils.host_threads_per_rank() == 1
+
+
 def test_make_sampler_takes_the_whole_reference_surface():
     """make_sampler's arguments (reference sample_utils.py:10-89) all land in the spec; the filters the captured step does not
     carry mark it `extended`, which routes it around an eager step as the sampler callable (generate._resolve_sampler); the
