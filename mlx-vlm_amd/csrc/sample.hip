@@ -25,6 +25,16 @@
 namespace {
 
 constexpr int NBLK = 64;  // blocks per vocabulary row
+// Workspace row: every per-row array of the workspace lives in ONE block of ROW_W 4-byte words per batch row, at the same offset
+// for every call - [NBLK][2] f32 lse partials | [NBLK] f32 cand_v | [NBLK] i32 cand_i | [65536] u32 key histogram | [CTL_WORDS] u32
+// control words of the split top-p path.  Row b of array X is X_base + b * ROW_W whatever the call's B: a state whose workspace
+// was sized for 8 rows and that steps at 8, then 4, then 8 rows finds the persistent arrays (histogram and control words, zero /
+// re-armed between calls) of row b in the same words every time.  (Rounds 4-5 laid the arrays out [B][...] back to back: a
+// narrower step then found another step's Gumbel candidates where its histogram should be zero - ADVICE r05.)
+constexpr int CTL_WORDS = 128;
+constexpr int ROW_LSE = 0, ROW_CV = 2 * NBLK, ROW_CI = 3 * NBLK, ROW_HIST = 4 * NBLK, ROW_CTL = ROW_HIST + 65536;
+constexpr int ROW_W = ROW_CTL + CTL_WORDS;
+static_assert(ROW_HIST % 4 == 0 && ROW_W % 4 == 0, "the histogram of every row is cleared with 16-byte stores");
 
 // order-preserving map bf16 bits -> uint16 (ascending)
 __device__ __forceinline__ uint32_t bf_key(bf16_t b) { return (b & 0x8000u) ? (uint32_t)(~b & 0xffffu) : (uint32_t)(b | 0x8000u); }
@@ -47,7 +57,7 @@ __global__ __launch_bounds__(256) void lse_partial_kernel(const bf16_t* __restri
   if (m > -INFINITY)
     for (int i = lo + threadIdx.x; i < hi; i += 256) s += expf(bf2f(row[i]) - m);
   s = block_sum(s, red + 4);
-  if (threadIdx.x == 0) { ws[((size_t)b * NBLK + blk) * 2] = m; ws[((size_t)b * NBLK + blk) * 2 + 1] = s; }
+  if (threadIdx.x == 0) { ws[(size_t)b * ROW_W + blk * 2] = m; ws[(size_t)b * ROW_W + blk * 2 + 1] = s; }
 }
 
 // logprobs (bf16) + per-block argmax candidate
@@ -60,7 +70,7 @@ __global__ __launch_bounds__(256) void logprob_argmax_kernel(const bf16_t* __res
   // merge the NBLK (= 64 = one wavefront) partials: lane i takes partial i, shuffle reductions - every wave
   // does it redundantly (a serial loop of 128 dependent L2 loads cost ~10 us here)
   const int li = threadIdx.x & 63;
-  const float pm = ws[((size_t)b * NBLK + li) * 2], ps = ws[((size_t)b * NBLK + li) * 2 + 1];
+  const float pm = ws[(size_t)b * ROW_W + li * 2], ps = ws[(size_t)b * ROW_W + li * 2 + 1];
   const float m = wave_max(pm);
   const float s = wave_sum(pm > -INFINITY ? ps * expf(pm - m) : 0.f);
   const float lse = rbf(m + logf(s));          // logsumexp materialised in the logits dtype
@@ -86,16 +96,16 @@ __global__ __launch_bounds__(256) void logprob_argmax_kernel(const bf16_t* __res
   if (threadIdx.x == 0) {
     for (int w = 1; w < 4; ++w)
       if (sv[w] > best || (sv[w] == best && si[w] < besti)) { best = sv[w]; besti = si[w]; }
-    cand_v[(size_t)b * NBLK + blk] = best;
-    cand_i[(size_t)b * NBLK + blk] = besti;
+    cand_v[(size_t)b * ROW_W + blk] = best;
+    cand_i[(size_t)b * ROW_W + blk] = besti;
   }
 }
 
 __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restrict__ cand_v, const int* __restrict__ cand_i,
                                                           int* __restrict__ tok) {
   const int b = blockIdx.x;
-  float best = cand_v[(size_t)b * NBLK + threadIdx.x];
-  int besti = cand_i[(size_t)b * NBLK + threadIdx.x];
+  float best = cand_v[(size_t)b * ROW_W + threadIdx.x];
+  int besti = cand_i[(size_t)b * ROW_W + threadIdx.x];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float ov = __shfl_xor(best, o, 64);
@@ -122,8 +132,8 @@ __global__ __launch_bounds__(256) void argmax_final_advance_kernel(const float* 
   __shared__ int s_tok[64];
   const int tid = threadIdx.x, li = tid & 63, wave = tid >> 6;
   for (int r = wave; r < B; r += 4) {
-    float bv = cand_v[(size_t)r * NBLK + li];
-    int bi = cand_i[(size_t)r * NBLK + li];
+    float bv = cand_v[(size_t)r * ROW_W + li];
+    int bi = cand_i[(size_t)r * ROW_W + li];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ov = __shfl_xor(bv, o, 64);
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(256) void logprob_argmax_tail_kernel(
   __shared__ int s_tok[TAIL_MAX_B];
   const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
   const int li = tid & 63;
-  const float pm = ws[((size_t)b * NBLK + li) * 2], ps = ws[((size_t)b * NBLK + li) * 2 + 1];
+  const float pm = ws[(size_t)b * ROW_W + li * 2], ps = ws[(size_t)b * ROW_W + li * 2 + 1];
   const float m = wave_max(pm);
   const float s = wave_sum(pm > -INFINITY ? ps * expf(pm - m) : 0.f);
   const float lse = rbf(m + logf(s));          // logsumexp materialised in the logits dtype (ar.py:368)
@@ -198,8 +208,8 @@ __global__ __launch_bounds__(256) void logprob_argmax_tail_kernel(
   if (tid == 0) {
     for (int w = 1; w < 4; ++w)
       if (sv[w] > best || (sv[w] == best && si[w] < besti)) { best = sv[w]; besti = si[w]; }
-    cand_v[(size_t)b * NBLK + blk] = best;
-    cand_i[(size_t)b * NBLK + blk] = besti;
+    cand_v[(size_t)b * ROW_W + blk] = best;
+    cand_i[(size_t)b * ROW_W + blk] = besti;
     // publish: release, then the ticket (this order; the asm wait restates the fence's own wait where the compiler
     // cannot drop it)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -214,8 +224,8 @@ __global__ __launch_bounds__(256) void logprob_argmax_tail_kernel(
   // ---- last block: final argmax per row (64 candidates = one wavefront), lowest index on ties (sample_utils.py:63-64)
   const int wave = tid >> 6;
   for (int r = wave; r < B; r += 4) {
-    float bv = __hip_atomic_load(cand_v + (size_t)r * NBLK + li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int bi = __hip_atomic_load(cand_i + (size_t)r * NBLK + li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float bv = __hip_atomic_load(cand_v + (size_t)r * ROW_W + li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int bi = __hip_atomic_load(cand_i + (size_t)r * ROW_W + li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ov = __shfl_xor(bv, o, 64);
@@ -553,7 +563,7 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
   extern __shared__ uint32_t lh[];               // [LH_WORDS] the lower half of the key histogram (see build_hist)           // typical-p: per-wave digit counters of the radix passes
   const int b = blockIdx.x, tid = threadIdx.x;
   bf16_t* lp = lp_all + (size_t)b * ldlp;           // scratch copy that the filters mask in place
-  uint32_t* hist = hist_all + (size_t)b * 65536;
+  uint32_t* hist = hist_all + (size_t)b * ROW_W;
   const uint32_t step = (uint32_t)(step_ptr ? *step_ptr : 0);
 #ifdef VLM_SAMPLE_STAMPS
   // probe build (scripts/sampler_stamps.py): phase stamps of the 100 MHz wall clock in the words of the global histogram that
@@ -955,7 +965,7 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
 // one-workgroup kernel (log-prob input and logits input), the oracle and the reference's golden rows.
 // ------------------------------------------------------------------------------------------
 constexpr int SPLIT_G = 64;
-constexpr int CTL_WORDS = 128;       // per row: [0] crossing key (65536: none), [1] ranks below this are masked, [2] bin count,
+// CTL_WORDS (= 128, defined with the workspace row at the top) per row: [0] crossing key (65536: none), [1] ranks below this are masked, [2] bin count,
                                      // [3] a positive key exists, [4] / [5] smallest / largest finite key below 0x8000 (reset to
                                      // 0xffffffff / 0 by the mask kernel), [8 + s] elements with the crossing key in slice s
 constexpr int PW_MAX = 7424;         // keys in the cross kernel's probability window (29 KB of LDS behind the 130 KB histogram)
@@ -978,11 +988,11 @@ __global__ __launch_bounds__(256) void topp_hist_kernel(const bf16_t* __restrict
                                                                       // zeroed and flushed as 16-byte pieces)
   const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const bf16_t* row = lp_in + (size_t)b * ld_in;
-  uint32_t* hist = hist_all + (size_t)b * 65536;
+  uint32_t* hist = hist_all + (size_t)b * ROW_W;
   float lse = 0.f;
   if (FROM_LOGITS) {      // (the merge of logprob_argmax_kernel: lane i takes partial i, every wave redundantly)
     const int li = tid & 63;
-    const float pm = lse_ws[((size_t)b * NBLK + li) * 2], ps = lse_ws[((size_t)b * NBLK + li) * 2 + 1];
+    const float pm = lse_ws[(size_t)b * ROW_W + li * 2], ps = lse_ws[(size_t)b * ROW_W + li * 2 + 1];
     const float m = wave_max(pm);
     const float sm = wave_sum(pm > -INFINITY ? ps * expf(pm - m) : 0.f);
     lse = rbf(m + logf(sm));
@@ -1022,11 +1032,11 @@ __global__ __launch_bounds__(256) void topp_hist_kernel(const bf16_t* __restrict
   if ((tid & 63) == 0) {
     if (ninf) atomicAdd(&lh[KEY_NEG_INF], ninf);
     if (kmin <= kmax) {      // the populated range of the finite non-positive keys (the cross kernel's probability window)
-      atomicMin(&ctl_all[(size_t)b * CTL_WORDS + 4], kmin);
-      atomicMax(&ctl_all[(size_t)b * CTL_WORDS + 5], kmax);
+      atomicMin(&ctl_all[(size_t)b * ROW_W + 4], kmin);
+      atomicMax(&ctl_all[(size_t)b * ROW_W + 5], kmax);
     }
   }
-  if (pos) ctl_all[(size_t)b * CTL_WORDS + 3] = 1u;
+  if (pos) ctl_all[(size_t)b * ROW_W + 3] = 1u;
   __syncthreads();
   // flush: 4 bins per 16-byte read, 4 reads in flight; a slice of 2400 elements touches a few hundred bins
 #pragma unroll 1
@@ -1048,8 +1058,8 @@ __global__ __launch_bounds__(1024) void topp_cross_kernel(const uint32_t* __rest
   __shared__ unsigned long long s_best;
   extern __shared__ uint32_t lh[];               // [LH_WORDS] the lower half of the merged histogram, padded as above
   const int b = blockIdx.x, tid = threadIdx.x;
-  const uint32_t* hist = hist_all + (size_t)b * 65536;
-  uint32_t* ctl = ctl_all + (size_t)b * CTL_WORDS;
+  const uint32_t* hist = hist_all + (size_t)b * ROW_W;
+  uint32_t* ctl = ctl_all + (size_t)b * ROW_W;
 #ifdef VLM_TOPP_STAMPS
   int n_st = 0;
 #define XST() do { __syncthreads(); if (tid == 0) ctl[80 + n_st] = (uint32_t)wall_clock64(); ++n_st; } while (0)
@@ -1195,7 +1205,7 @@ __global__ __launch_bounds__(256) void topp_count_kernel(const bf16_t* __restric
                                                          uint32_t* __restrict__ ctl_all) {
   __shared__ uint32_t red[4];
   const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  uint32_t* ctl = ctl_all + (size_t)b * CTL_WORDS;
+  uint32_t* ctl = ctl_all + (size_t)b * ROW_W;
   const uint32_t tk = ctl[0], drop = ctl[1];
   uint32_t cnt = 0;
   if (tk < 65536u && drop > 0) {
@@ -1227,7 +1237,7 @@ __global__ __launch_bounds__(256) void topp_mask_kernel(const bf16_t* __restrict
   float best = -INFINITY;
   int besti = 0x7fffffff;
   const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint32_t* ctl = ctl_all + (size_t)b * CTL_WORDS;
+  uint32_t* ctl = ctl_all + (size_t)b * ROW_W;
   const bf16_t* row = lp_in + (size_t)b * ld_in;
   bf16_t* out = out_all + (size_t)b * ldo;
   const uint32_t tk = ctl[0], drop = ctl[1];
@@ -1309,11 +1319,11 @@ __global__ __launch_bounds__(256) void topp_mask_kernel(const bf16_t* __restrict
   if (tid == 0) {
     for (int w = 1; w < 4; ++w)
       if (sv[w] > best || (sv[w] == best && si[w] < besti)) { best = sv[w]; besti = si[w]; }
-    cand_v[(size_t)b * NBLK + s] = best;
-    cand_i[(size_t)b * NBLK + s] = besti;
+    cand_v[(size_t)b * ROW_W + s] = best;
+    cand_i[(size_t)b * ROW_W + s] = besti;
   }
   // the row's histogram goes back to all-zero for the next call (1024 words per slice), the positive-key flag with it
-  uint32_t* hist = hist_all + (size_t)b * 65536 + (size_t)s * 1024;
+  uint32_t* hist = hist_all + (size_t)b * ROW_W + (size_t)s * 1024;
   const u32x4_t z = {0u, 0u, 0u, 0u};
   reinterpret_cast<u32x4_t*>(hist)[tid] = z;
   if (s == 0 && tid == 0) { ctl[3] = 0u; ctl[4] = 0xffffffffu; ctl[5] = 0u; }
@@ -1356,8 +1366,8 @@ __global__ __launch_bounds__(256) void gumbel_partial_kernel(const bf16_t* __res
   if (tid == 0) {
     for (int w = 1; w < 4; ++w)
       if (sv[w] > best || (sv[w] == best && si[w] < besti)) { best = sv[w]; besti = si[w]; }
-    cand_v[(size_t)b * NBLK + blk] = best;
-    cand_i[(size_t)b * NBLK + blk] = besti;
+    cand_v[(size_t)b * ROW_W + blk] = best;
+    cand_i[(size_t)b * ROW_W + blk] = besti;
   }
 }
 
@@ -1375,7 +1385,7 @@ inline float host_rbf(float f) {
 }  // namespace
 
 extern "C" size_t vlm_sample_workspace_bytes(int B) {
-  return (size_t)B * (NBLK * 4 * sizeof(float) + 65536 * sizeof(uint32_t) + CTL_WORDS * sizeof(uint32_t)) + 256;
+  return (size_t)B * ROW_W * sizeof(uint32_t) + 256;
 }
 
 // typical_p's sort: per row two (index, payload) array pairs of Vp = V rounded up to 1024 entries (the digit counters live in LDS)
@@ -1388,8 +1398,8 @@ extern "C" size_t vlm_sample_sort_workspace_bytes(int B, int V) {
 // workspace layout: 256 B = arrival ticket of the fused greedy tail (must be zero at allocation; the kernel re-arms it; at a
 // fixed offset so that a step over the first B' < B rows of a state finds the same word) + at byte 4 the count of rows whose
 // argmax found no candidate (an all-NaN logits row; the token is then 0) |
-// [B][NBLK][2] f32 lse partials | [B][NBLK] f32 cand_v | [B][NBLK] i32 cand_i | [B][65536] u32 hist (all zero between calls) |
-// [B][128] u32 control words of the split top-p path (zero at allocation)
+// then one ROW_W-word block per row (see ROW_W at the top): lse partials | cand_v | cand_i | hist (all zero between calls) |
+// control words of the split top-p path (zero at allocation) - every array at a fixed offset inside the row's block
 static int sample_ex_impl(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
                           void* workspace, const vlm_sampler_params* sp, const void* step_ptr, void* stream, const SampleTail* tail) {
   if (!logits || !tok || !workspace || !sp || B <= 0 || V <= 0) return VLM_ERR_ARG;
@@ -1436,9 +1446,9 @@ static int sample_ex_impl(const void* logits, int ld, int B, int V, void* logpro
   }
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)((char*)workspace + 256);
-  float* cand_v = ws + (size_t)B * NBLK * 2;
-  int* cand_i = (int*)(cand_v + (size_t)B * NBLK);
-  uint32_t* hist = (uint32_t*)(cand_i + (size_t)B * NBLK);
+  float* cand_v = ws + ROW_CV;
+  int* cand_i = (int*)(ws + ROW_CI);
+  uint32_t* hist = (uint32_t*)(ws + ROW_HIST);
   // top-p alone over a 16-byte-aligned row of a real vocabulary: the row split over SPLIT_G workgroups
   static const bool split_env = [] { const char* e = getenv("VLM_SAMPLE_SPLIT"); return !e || atoi(e) != 0; }();   // A/B knob
   const bool split = temperature != 0.0 && split_env && (lp_given || logprobs) && k.use_top_p && !k.use_min_p && k.top_k == 0 && !(k.n_sigma > 0.f) && !k.p_less &&
@@ -1475,7 +1485,7 @@ static int sample_ex_impl(const void* logits, int ld, int B, int V, void* logpro
       static const hipError_t attr_b = hipFuncSetAttribute(reinterpret_cast<const void*>(&topp_cross_kernel),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
       if (attr_a != hipSuccess || attr_b != hipSuccess) return VLM_ERR_HIP + (int)(attr_a != hipSuccess ? attr_a : attr_b);
-      uint32_t* ctl = hist + (size_t)B * 65536;
+      uint32_t* ctl = (uint32_t*)(ws + ROW_CTL);
       if (fused_lp)
         hipLaunchKernelGGL(topp_hist_kernel<true>, dim3(SPLIT_G, B), dim3(256), LDS, st, (const bf16_t*)logits, ld, V, hist, ctl,
                            (const float*)ws, (bf16_t*)logprobs, ldlp);
@@ -1562,8 +1572,8 @@ extern "C" int vlm_sample_greedy_advance(const void* logits, int ld, int B, int 
   hipStream_t st = (hipStream_t)stream;
   unsigned* ticket = (unsigned*)workspace;
   float* ws = (float*)((char*)workspace + 256);
-  float* cand_v = ws + (size_t)B * NBLK * 2;
-  int* cand_i = (int*)(cand_v + (size_t)B * NBLK);
+  float* cand_v = ws + ROW_CV;
+  int* cand_i = (int*)(ws + ROW_CI);
   hipLaunchKernelGGL(lse_partial_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws);
   VLM_CHECK_LAUNCH();
   hipLaunchKernelGGL(logprob_argmax_tail_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws,

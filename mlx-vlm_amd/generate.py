@@ -355,7 +355,10 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
         while L - done > 1:
             n = min(step_size, L - done - 1)
             lm.prefill(E[done:done + n], P[:, done:done + n], [prompt_cache], [n], "last", reserve_extra=L - done - n + max_tokens + 2)
-            maybe_quantize_kv_cache()
+            # (the reference quantises between chunks, common.py:170-181; here the cache turns 8-bit AFTER the last prefill call:
+            #  the chunk path attends over the bf16 pages - LanguageModel._prefill_onto_cache - and the whole-prompt path always
+            #  quantised behind the prefill.  The chunks after quantized_kv_start so see unrounded K / V: a deviation of the
+            #  PROMPT pass only, the decode steps attend over the same 8-bit pools either way)
             done += n
     logits = lm.prefill(E[done:], P[:, done:], [prompt_cache], [L - done], "last", reserve_extra=max_tokens + 2)
 

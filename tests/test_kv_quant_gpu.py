@@ -110,6 +110,29 @@ def test_generate_step_with_kv_bits_switches_where_the_reference_does(tiny):
         next(generate_step(ids, model, None, None, max_tokens=2, kv_bits=4))
 
 
+def test_generate_step_with_kv_bits_and_a_chunked_prompt(tiny):
+    """prefill_step_size (default 2048) feeds a long prompt in chunks; with kv_bits the cache must not turn 8-bit
+    between the chunks (the chunk path attends over bf16 pages).  kv_bits = 8, quantized_kv_start = 0 and a prompt of several
+    small chunks: the run completes, the cache IS 8-bit afterwards, and the tokens / log-probs equal the one-chunk prompt's
+    (the prompt pass sees unrounded K / V either way; every decode step attends over the same 8-bit pools)."""
+    from mlx_vlm_amd.generate import generate_step
+
+    cfg, W, model = tiny
+    ids = np.random.default_rng(72).integers(3, 1000, (1, 90))
+    kw = dict(max_tokens=8, temperature=0.0, kv_bits=8, quantized_kv_start=0)
+    whole = [(t, lp.float().cpu()) for t, lp in generate_step(ids, model, None, None, prefill_step_size=4096, **kw)]
+    chunked = [(t, lp.float().cpu()) for t, lp in generate_step(ids, model, None, None, prefill_step_size=32, **kw)]
+    assert model.language_model.pool.kpool8 is not None and len(chunked) == len(whole) == 8
+    # tokens equal up to the first bf16 tie (chunked attention sums in another order), the chosen tokens' log-probs close
+    n_equal = 0
+    for (ta, la), (tb, lb) in zip(whole, chunked):
+        assert abs(float(la[ta]) - float(lb[ta])) <= 0.13
+        if ta != tb:
+            break
+        n_equal += 1
+    assert n_equal >= 4, (n_equal, [t for t, _ in whole], [t for t, _ in chunked])
+
+
 def test_batch_generator_with_kv_bits_equals_single_requests(tiny):
     from mlx_vlm_amd.batch import BatchGenerator
     from mlx_vlm_amd.generate import generate_step

@@ -373,6 +373,33 @@ def test_split_top_p_equals_the_one_workgroup_kernel(vops, tmp_path):
     torch.cuda.synchronize()
     assert torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16)) and torch.equal(outs[2].view(torch.int16), outs[3].view(torch.int16))
     assert np.array_equal(outs[0].cpu().view(torch.int16).numpy(), ref["positive"])
-    n_hist = 65536 * 2
-    hist = ws[256 + 2 * 64 * 16: 256 + 2 * 64 * 16 + n_hist * 4].view(torch.int32)
-    assert int(hist.abs().sum()) == 0                      # all zero between calls
+    row_w, row_hist = 4 * 64 + 65536 + 128, 4 * 64       # csrc/sample.hip ROW_W / ROW_HIST: one block of 4-byte words per row
+    for b in range(2):
+        hist = ws[256 + 4 * (b * row_w + row_hist): 256 + 4 * (b * row_w + row_hist + 65536)].view(torch.int32)
+        assert int(hist.abs().sum()) == 0                  # all zero between calls
+
+
+def test_split_top_p_on_a_workspace_stepped_at_changing_widths(vops):
+    """batch.py steps ONE DecodeState.sample_ws at varying widths.  The workspace is laid out in per-row blocks at
+    fixed offsets (csrc/sample.hip ROW_W), so a step over the first 4 rows of a workspace that just served 8 finds its
+    histograms zero and its control words re-armed: top-p at B = 8, then 4, then 8 on one workspace gives the rows and tokens of
+    fresh workspaces, and between the calls a top-k step (the one-workgroup kernel) runs at yet another width."""
+    lp8 = _rows(8, 32768, seed=21).cuda()
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    kw = dict(temperature=0.8, seed=5, step=st, want_logprobs=False, input_is_logprobs=True, return_filtered=True, top_p=0.9)
+
+    def fresh(rows):
+        tok, _, filt = vops.sample(lp8[:rows], ws=vops.sample_workspace(rows, "cuda"), **kw)
+        return tok.clone(), filt.clone()
+
+    want8, want4 = fresh(8), fresh(4)
+    ws = vops.sample_workspace(8, "cuda")
+    for rows, want in ((8, want8), (4, want4), (8, want8), (4, want4)):
+        tok, _, filt = vops.sample(lp8[:rows], ws=ws, **kw)
+        assert torch.equal(tok, want[0]), rows
+        assert torch.equal(filt.view(torch.int16), want[1].view(torch.int16)), rows
+        # another filter combination at another width in between (sample_filter_kernel: its own use of the histogram words)
+        vops.sample(lp8[:6], ws=ws, **dict(kw, top_p=1.0, top_k=17))
+    torch.cuda.synchronize()
+    kept = (want4[1].float() > -float("inf")).sum(-1)
+    assert int(kept.min()) >= 1 and int(kept.max()) < 32768      # top-p did filter (the failure mode was: silently not applied)
