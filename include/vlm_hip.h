@@ -206,8 +206,9 @@ int vlm_attn_decode_paged(const void* q, int ldq, const void* kpool, const void*
  * it zero again.  Launches that share part_o / part_ml / tickets must be stream-ordered. */
 /* out == NULL: the partial-only form.  Nothing is merged and no ticket is taken (tickets may be NULL): every split s
  * of every head writes (m, l) - m in the log2 domain, (-inf, 0) for a split with no page - to part_ml fp32
- * [B][Hq][nsplit][2] and, when it has pages, its unnormalised O as bf16 to part_o [B][Hq][nsplit][D]; the launch ends
- * at those (plain) stores and vlm_gemv_attn_out_bf16 merges them in the o_proj prologue. */
+ * [B][Hq][nsplit][2] and, when it has pages, its unnormalised O as fp32 to part_o [B][Hq][nsplit][D] (ABI v8; bf16 before -
+ * a rounding point the reference's fused attention does not have); the launch ends at those (plain) stores and
+ * vlm_gemv_attn_out_bf16 merges them in the o_proj prologue. */
 int vlm_attn_decode_paged_split(const void* q, int ldq, const void* kpool, const void* vpool, const void* block_table,
                                 int max_pages, const void* kv_len, int kv_len_add, int B, int Hq, int Hkv, int D,
                                 float scale, int nsplit, void* part_o, void* part_ml, void* tickets, void* out, int ldo,
@@ -237,8 +238,8 @@ int vlm_attn_decode_paged_q8(const void* q, int ldq, const void* kpool16, const 
                              void* part_ml, void* tickets, void* out, int ldo, int quantize_new, void* stream);
 
 /* h[0][0:N] += merge(partials of vlm_attn_decode_paged_split's partial-only form) Wo^T for ONE decode row
- * (language.py:115-120,151): every thread of the o_proj GEMV loads one 8-element chunk of all nsplit <= 16 bf16 partials
- * and their (m, l) ahead of its weight stream and merges them in registers.  Hq * D <= 2048. */
+ * (language.py:115-120,151): every thread of the o_proj GEMV loads one 8-element chunk of all nsplit <= 16 fp32 partials
+ * and their (m, l) ahead of its weight stream and merges them in registers (bf16 Wo: the name).  Hq * D <= 2048. */
 int vlm_gemv_attn_out_bf16(const void* part_o, const void* part_ml, int nsplit, const void* Wo, void* h, int ldh, int N,
                            int Hq, int D, void* stream);
 

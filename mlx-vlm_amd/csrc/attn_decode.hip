@@ -173,13 +173,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
     m_run = m_new;
     stamp(4);
     // ---- P^T fragments: k-slot 8gq + j of step u  <-  tile 2u (j < 4) / tile 2u+1 (j >= 4), register j & 3
-    bf16x8_t pb[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const u32x4_t pk = {pack_bf2(st[2 * u][0], st[2 * u][1]), pack_bf2(st[2 * u][2], st[2 * u][3]),
-                          pack_bf2(st[2 * u + 1][0], st[2 * u + 1][1]), pack_bf2(st[2 * u + 1][2], st[2 * u + 1][3])};
-      pb[u] = __builtin_bit_cast(bf16x8_t, pk);
-    }
+    bf16x8_t pb[2], pl[2];          // hi + lo: 16 mantissa bits of p (attn_pagesplit.cuh)
+    vlm_pack_p_hilo(st, pb, pl);
     // ---- O^T += V^T . P^T ; never-written V slots are multiplied by p == 0 but may hold NaN patterns -> zeroed
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) {
@@ -195,6 +190,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
         vv[2] = (k1 + 1 < len) ? vv[2] : ((k1 < len) ? (vv[2] & 0xffffu) : 0u);
         vv[3] = (k1 + 3 < len) ? vv[3] : ((k1 + 2 < len) ? (vv[3] & 0xffffu) : 0u);
         ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pb[u], ot[dt], 0, 0, 0);
+        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pl[u], ot[dt], 0, 0, 0);
       }
     }
     if (pi >= npages) break;
@@ -266,16 +262,15 @@ __device__ __forceinline__ void pagesplit_finish(f32x4_t (&ot)[8], float m_run, 
   l_run = col4_sum(l_run);
   if (!MERGE) {
     // partials for the o_proj prologue (vlm_gemv_attn_out_bf16): EVERY split writes (m, l) - a split with no page writes
-    // (-inf, 0) and is skipped there - and the splits with pages their O^T as bf16 [b][head][s][d] (plain stores: the
-    // kernel boundary publishes them).  m stays in the log2 domain of this kernel.
+    // (-inf, 0) and is skipped there - and the splits with pages their O^T as fp32 [b][head][s][d] (plain stores: the
+    // kernel boundary publishes them; fp32 since round 6 - a bf16 partial is a rounding point the reference does not have).  m stays in the log2 domain of this kernel.
     if (head < G) {
       const size_t e = ((size_t)b * (Hkv * G) + (g * G + head)) * S + s;
       if (gq == 0) *reinterpret_cast<float2*>(part_ml + e * 2) = make_float2(m_run, l_run);
       if (m_run != -INFINITY) {
-        bf16_t* po = reinterpret_cast<bf16_t*>(part_o) + e * HD + 4 * gq;
+        float* po = part_o + e * HD + 4 * gq;
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt)
-          *reinterpret_cast<uint2*>(po + 16 * dt) = make_uint2(pack_bf2(ot[dt][0], ot[dt][1]), pack_bf2(ot[dt][2], ot[dt][3]));
+        for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4_t*>(po + 16 * dt) = ot[dt];
       }
     }
     return;

@@ -9,6 +9,28 @@
 constexpr int VLM_HD = 128;    // head_dim supported by the decode path
 constexpr int VLM_PAGE = 64;
 
+// P as TWO bf16 MFMA operands: hi = bf16(p), lo = bf16(p - hi).  The reference's fused attention keeps P in fp32
+// (mx.fast.scaled_dot_product_attention, reference base.py:366); a single bf16 P was the one rounding point of the engine that the
+// typed graph does not have (profiles/r05_engine_noise_by_depth_and_op.txt: 1.8e-3 from the exactly rounded result where every
+// GEMM is at 1e-5).  hi + lo carries 16 mantissa bits of p into O^T += V^T . P^T at the price of a second MFMA per fragment - free
+// in the decode kernels, whose launch is one memory round trip long whatever the matrix pipe does.  st[t][r] = p(key 16 t + 4 gq + r);
+// k-slot 8 gq + j of step u <- tile 2u (j < 4) / tile 2u + 1 (j >= 4), register j & 3.
+__device__ __forceinline__ void vlm_pack_p_hilo(const f32x4_t (&st)[4], bf16x8_t (&ph)[2], bf16x8_t (&pl)[2]) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    u32x4_t hi, lo;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float a = st[2 * u + (w >> 1)][2 * (w & 1)], b = st[2 * u + (w >> 1)][2 * (w & 1) + 1];
+      const uint32_t h = pack_bf2(a, b);
+      hi[w] = h;
+      lo[w] = pack_bf2(a - bf_lo(h), b - bf_hi(h));
+    }
+    ph[u] = __builtin_bit_cast(bf16x8_t, hi);
+    pl[u] = __builtin_bit_cast(bf16x8_t, lo);
+  }
+}
+
 template <int G, bool IDENT>
 __device__ __forceinline__ void vlm_pagesplit_walk(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kpool,
                                                    const bf16_t* __restrict__ vpool, const int* __restrict__ block_table,
@@ -96,13 +118,8 @@ __device__ __forceinline__ void vlm_pagesplit_walk(const bf16_t* __restrict__ q,
       }
     l_run = l_run * alpha + ls;
     m_run = m_new;
-    bf16x8_t pb[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const u32x4_t pk = {pack_bf2(st[2 * u][0], st[2 * u][1]), pack_bf2(st[2 * u][2], st[2 * u][3]),
-                          pack_bf2(st[2 * u + 1][0], st[2 * u + 1][1]), pack_bf2(st[2 * u + 1][2], st[2 * u + 1][3])};
-      pb[u] = __builtin_bit_cast(bf16x8_t, pk);
-    }
+    bf16x8_t pb[2], pl[2];
+    vlm_pack_p_hilo(st, pb, pl);
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) {
 #pragma unroll
@@ -116,6 +133,7 @@ __device__ __forceinline__ void vlm_pagesplit_walk(const bf16_t* __restrict__ q,
         vv[2] = (k1 + 1 < len) ? vv[2] : ((k1 < len) ? (vv[2] & 0xffffu) : 0u);
         vv[3] = (k1 + 3 < len) ? vv[3] : ((k1 + 2 < len) ? (vv[3] & 0xffffu) : 0u);
         ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pb[u], ot[dt], 0, 0, 0);
+        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pl[u], ot[dt], 0, 0, 0);
       }
     }
     if (pi >= npages) break;
@@ -128,11 +146,12 @@ __device__ __forceinline__ void vlm_pagesplit_walk(const bf16_t* __restrict__ q,
 // mx.fast.scaled_dot_product_attention, reference base.py:366-373):
 //     x[d] = sum_s f_s O_s[d] / sum_s f_s l_s,   f_s = 2^(m_s - M)
 // ml[sp] = (m, l) of split sp (m in the log2 domain of the walk above, -inf = the split owns no page and its O bytes may be
-// anything), o[sp] = its 8 bf16 O values; every split up to NS is passed, the ones >= S are dropped by a select.  Used by
-// the o_proj prologue (gemv_bf16.hip, PRO_ATTN_BF16).
+// anything), o[sp] = its 8 fp32 O values (round 6: fp32 - bf16 partials were a second rounding point the reference's fused
+// attention does not have, 2.4e-3 from the exactly rounded result with everything else at 1e-5: tests/test_op_noise_gpu.py);
+// every split up to NS is passed, the ones >= S are dropped by a select.  Used by the o_proj prologue (gemv_bf16.hip, PRO_ATTN_PS).
 constexpr int VLM_MERGE_S = 16;
 template <int NS>
-__device__ __forceinline__ uint4 vlm_merge_splits16(const float2 (&ml)[NS], const u32x4_t (&o)[NS], int S) {
+__device__ __forceinline__ uint4 vlm_merge_splits16(const float2 (&ml)[NS], const f32x4_t (&o)[NS][2], int S) {
   float mm = -INFINITY;
 #pragma unroll
   for (int sp = 0; sp < NS; ++sp) mm = fmaxf(mm, sp < S ? ml[sp].x : -INFINITY);
@@ -142,13 +161,8 @@ __device__ __forceinline__ uint4 vlm_merge_splits16(const float2 (&ml)[NS], cons
     const bool on = sp < S && ml[sp].x != -INFINITY;
     const float f = on ? exp2f(ml[sp].x - mm) : 0.f;
     ll += on ? f * ml[sp].y : 0.f;
-    const u32x4_t ov = o[sp];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned w = ov[j];
-      acc8[2 * j] += on ? f * bf_lo(w) : 0.f;
-      acc8[2 * j + 1] += on ? f * bf_hi(w) : 0.f;
-    }
+    for (int j = 0; j < 8; ++j) acc8[j] += on ? f * o[sp][j >> 2][j & 3] : 0.f;
   }
   const float il = 1.0f / ll;
   uint4 r;

@@ -27,6 +27,8 @@
 // 32-lane half reads fall on disjoint banks).  The next K/V tile's global loads are issued before the
 // MFMAs of the current one (register staging, T14-style) and written to LDS after
 // the barrier.  Output is stored as 8-byte bf16x4 pieces (4 consecutive d).
+#include <stdlib.h>
+
 #include "common.cuh"
 #include "../../include/vlm_hip.h"
 
@@ -49,7 +51,9 @@ constexpr int BKV = 64;   // keys per tile
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 
-template <int D, bool CAUSAL>
+template <int D, bool CAUSAL, bool HILO = false>
+// HILO: P as two bf16 MFMA operands (hi = bf16(p), lo = bf16(p - hi)): 16 mantissa bits of p reach O^T, as in the decode kernels
+// (attn_pagesplit.cuh) - here at the price of a second P.V MFMA per fragment in a kernel whose matrix pipe is half busy.
 // (D <= 80: three waves per SIMD = three workgroups per CU - 168 registers, the only spills are epilogue values saved before
 //  the loop; the D = 64 form had three waves all along and ran at 516 TF where this one ran at 440)
 __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void attn_prefill_kernel(
@@ -286,6 +290,20 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void attn_prefill_kernel(
                            pack_bf2(st[kb][8 * mm + 4], st[kb][8 * mm + 5]), pack_bf2(st[kb][8 * mm + 6], st[kb][8 * mm + 7])};
         pf[kb][mm] = __builtin_bit_cast(bf16x8_t, u);
       }
+    bf16x8_t pl[2][2];
+    if (HILO) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+          const u32x4_t hi = __builtin_bit_cast(u32x4_t, pf[kb][mm]);
+          u32x4_t lo;
+#pragma unroll
+          for (int w = 0; w < 4; ++w)
+            lo[w] = pack_bf2(st[kb][8 * mm + 2 * w] - bf_lo(hi[w]), st[kb][8 * mm + 2 * w + 1] - bf_hi(hi[w]));
+          pl[kb][mm] = __builtin_bit_cast(bf16x8_t, lo);
+        }
+    }
 
     ST_MARK(2);                          // softmax + P pack (waits for the QK^T results)
     // ---- O^T += V^T . P^T ----
@@ -305,6 +323,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void attn_prefill_kernel(
           const bf16x8_t vf = __builtin_shufflevector(__builtin_bit_cast(bf16x4_t, lo), __builtin_bit_cast(bf16x4_t, hi), 0, 1, 2, 3, 4,
                                                       5, 6, 7);
           ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][mm], ot[db], 0, 0, 0);
+          if (HILO) ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pl[kb][mm], ot[db], 0, 0, 0);
         }
     if (D > 80) __builtin_amdgcn_s_setprio(0);
     }   // wave_rows
@@ -364,10 +383,25 @@ extern "C" int vlm_attn_prefill(const void* q, const void* k, const void* v, voi
   const bool uniform = (causal & 2) != 0 && total_qblocks % nseg == 0 && ((long)nseg * Hq) % 8 == 0;
   const int uniform_nqb = uniform ? total_qblocks / nseg : 0;
   causal &= 1;
+  // P as hi + lo bf16 operands (16 mantissa bits into P.V; the reference's fused attention keeps P in fp32).  Measured on MI355X
+  // (profiles/r06_attention_p_hilo.txt): distance to the exactly rounded result 1.8e-3 -> 7e-5; launch time +25 % (ViT, D = 80:
+  // 52.5 -> 66 us at 16 images) / +28 % (LLM prompt, D = 128 causal, 4096 tokens: 130 -> 167 us).  Default: ON for D = 128 - the
+  // language model, where the prompt's attention is a small share of the time to the first token and its rounding walks through 28
+  // layers of logits - and OFF for the vision towers (D = 64 / 80), where the launch is 11 % of the images/s metric's block.
+  // VLM_ATTN_PREFILL_HILO=0 / 1 forces every instance.
+  static const int hilo_env = [] { const char* e = getenv("VLM_ATTN_PREFILL_HILO"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  const bool hilo = hilo_env >= 0 ? hilo_env == 1 : D == 128;
 #define GO(DV, CV)                                                                                                    \
-  hipLaunchKernelGGL((attn_prefill_kernel<DV, CV>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,            \
-                     (const bf16_t*)v, (bf16_t*)out, q_stride, k_stride, v_stride, o_stride, (const int*)cu_seqlens,  \
-                     nseg, Hq, Hkv, sl2, uniform_nqb)
+  do {                                                                                                                \
+    if (hilo)                                                                                                         \
+      hipLaunchKernelGGL((attn_prefill_kernel<DV, CV, true>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,  \
+                         (const bf16_t*)v, (bf16_t*)out, q_stride, k_stride, v_stride, o_stride, (const int*)cu_seqlens, \
+                         nseg, Hq, Hkv, sl2, uniform_nqb);                                                             \
+    else                                                                                                              \
+      hipLaunchKernelGGL((attn_prefill_kernel<DV, CV, false>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k, \
+                         (const bf16_t*)v, (bf16_t*)out, q_stride, k_stride, v_stride, o_stride, (const int*)cu_seqlens, \
+                         nseg, Hq, Hkv, sl2, uniform_nqb);                                                             \
+  } while (0)
   if (D == 80 && !causal) GO(80, false);
   else if (D == 80 && causal) GO(80, true);
   else if (D == 128 && !causal) GO(128, false);

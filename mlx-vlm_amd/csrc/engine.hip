@@ -106,7 +106,7 @@ inline char* off(void* p, size_t bytes) { return static_cast<char*>(p) + bytes; 
 
 }  // namespace
 
-extern "C" int vlm_abi_version(void) { return 7; }
+extern "C" int vlm_abi_version(void) { return 8; }
 
 // ------------------------------------------------------------------ LLM
 extern "C" int vlm_llm_create(const vlm_llm_config* cfg, void** handle) {
@@ -425,12 +425,12 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
       TRY(vlm_sample_advance(a->logits, VL, B, c.vocab, a->logprobs, a->scratch, VL, a->tok, a->sample_ws, a->temperature, a->top_p,
                              a->min_p, a->top_k, a->seed, a->ctx, a->pos, a->out_ring, a->ring_len, a->step, m->g.embed, a->h, D, D,
                              stream));
-      n += ((a->top_p > 0.f && a->top_p < 1.f) || a->min_p != 0.f || a->top_k > 0) ? 5 : 4;
+      n += vlm_sample_last_launches();          // (the split top-p route issues more launches than the one-workgroup filter)
     } else {
       TRY(vlm_sample(a->logits, VL, B, c.vocab, a->logprobs, a->scratch, VL, a->tok, a->sample_ws, a->temperature, a->top_p,
                      a->min_p, a->top_k, a->seed, a->step, stream));
-      // (greedy: partials, log-probs + candidates, pick; sampling: + the draw's partials, + the filter kernel when one is on)
-      n += a->temperature == 0.f ? 3 : ((a->top_p > 0.f && a->top_p < 1.f) || a->min_p != 0.f || a->top_k > 0 ? 5 : 4);
+      // (greedy: partials, log-probs + candidates, pick; sampling: + the draw's partials, + the filter kernel(s) when one is on)
+      n += vlm_sample_last_launches();
       TRY(vlm_decode_advance(a->ctx, a->pos, a->tok, a->out_ring, a->ring_len, a->step, B, stream)); ++n;
     }
   }

@@ -31,7 +31,7 @@
 
 namespace {
 
-enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_ATTN = 2, PRO_ATTN_BF16 = 3 };
+enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_ATTN = 2, PRO_ATTN_PS = 3 };
 constexpr int EPI_ROPE_KV = 1 << 10;   // internal epilogue id (qkv projection)
 
 struct RopeKvArgs {
@@ -49,11 +49,11 @@ struct RopeKvArgs {
 };
 
 struct AttnProArgs {
-  const float* part_o;       // [M][Hq][S][D]  (PRO_ATTN_BF16: bf16 elements, the page-split attention's partials)
-  const float* part_ml;      // [M][Hq][S][2]  (PRO_ATTN: m in the natural-log domain; PRO_ATTN_BF16: log2 domain, -inf = no page)
+  const float* part_o;       // [M][Hq][S][D]  fp32 (PRO_ATTN_PS: the page-split attention's partials)
+  const float* part_ml;      // [M][Hq][S][2]  (PRO_ATTN: m in the natural-log domain; PRO_ATTN_PS: log2 domain, -inf = no page)
   int S, Hq, D;
 };
-constexpr int AT2_S = VLM_MERGE_S;    // splits the PRO_ATTN_BF16 prologue reads (all of them, unconditionally)
+constexpr int AT2_S = VLM_MERGE_S;    // splits the PRO_ATTN_PS prologue reads (all of them, unconditionally)
 
 __device__ __forceinline__ u32x4_t ntl(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)); }
 
@@ -150,22 +150,23 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
       }
     }
   }
-  // PRO_ATTN_BF16 (M == 1, K <= 2048, S <= 16): the merge of the page-split decode attention (attn_decode.hip, MERGE =
-  // false) - one 8-element chunk of x per thread, EVERY split's (m, l) and bf16 O chunk loaded unconditionally (a split
+  // PRO_ATTN_PS (M == 1, K <= 2048, S <= 16): the merge of the page-split decode attention (attn_decode.hip, MERGE =
+  // false) - one 8-element chunk of x per thread, EVERY split's (m, l) and fp32 O chunk loaded unconditionally (a split
   // without a page carries m = -inf and is dropped by a select; its O bytes may be anything), all of it issued here, ahead
   // of the weight stream: the attention launch ends at its partial stores (no ticket, no last-arriver pass), and this
-  // kernel pays S * 24 B per thread of L2 reads in front of its weights
-  float2 a2_ml[PRO == PRO_ATTN_BF16 ? AT2_S : 1];
-  u32x4_t a2_o[PRO == PRO_ATTN_BF16 ? AT2_S : 1];
-  if (PRO == PRO_ATTN_BF16) {
+  // kernel pays S * 40 B per thread of L2 reads in front of its weights
+  float2 a2_ml[PRO == PRO_ATTN_PS ? AT2_S : 1];
+  f32x4_t a2_o[PRO == PRO_ATTN_PS ? AT2_S : 1][2];
+  if (PRO == PRO_ATTN_PS) {
     const int ch = min(tid, nchunk - 1), hd0 = ch * 8;
     const size_t base = (size_t)(hd0 / ap.D) * ap.S;
-    const bf16_t* po = reinterpret_cast<const bf16_t*>(ap.part_o);
+    const float* po = ap.part_o;
 #pragma unroll
     for (int sp = 0; sp < AT2_S; ++sp) {
       const size_t e = base + min(sp, ap.S - 1);
       a2_ml[sp] = *reinterpret_cast<const float2*>(ap.part_ml + e * 2);
-      a2_o[sp] = *reinterpret_cast<const u32x4_t*>(po + e * ap.D + hd0 % ap.D);
+      a2_o[sp][0] = *reinterpret_cast<const f32x4_t*>(po + e * ap.D + hd0 % ap.D);
+      a2_o[sp][1] = *reinterpret_cast<const f32x4_t*>(po + e * ap.D + hd0 % ap.D + 4);
     }
   }
   // epilogue operands (bias / residual / rope position, slot, page) for the lane that will store
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
         reinterpret_cast<uint4*>(xs)[item] = o;     // item = m * nchunk + chunk: xs is [MB][K]
       }
     }
-  } else if (PRO == PRO_ATTN_BF16) {
+  } else if (PRO == PRO_ATTN_PS) {
     // x[h*D + d] = sum_s f_s O_s[d] / sum_s f_s l_s,  f_s = 2^(m_s - M)   (attn_pagesplit.cuh)
     const uint4 o = vlm_merge_splits16(a2_ml, a2_o, ap.S);
     if (tid < nchunk) reinterpret_cast<uint4*>(smem)[tid] = o;
@@ -682,7 +683,7 @@ extern "C" int vlm_gemv_attn_out_bf16(const void* part_o, const void* part_ml, i
   if (K % 8 || K > 2048 || D % 8) return VLM_ERR_SHAPE;     // one x chunk per thread
   Args a{nullptr, Wo, nullptr, h, nullptr, h, N, K, K, K, ldh, ldh, 0.f, RopeKvArgs{},
          AttnProArgs{(const float*)part_o, (const float*)part_ml, nsplit, Hq, D}, (hipStream_t)stream};
-  return launch_rw_k<1, PRO_ATTN_BF16, VLM_EPI_RESIDUAL>(a);
+  return launch_rw_k<1, PRO_ATTN_PS, VLM_EPI_RESIDUAL>(a);
 }
 
 extern "C" int vlm_gemv_attn_out(const void* part_o, const void* part_ml, int nsplit, const void* Wo, void* h, int ldh,

@@ -66,6 +66,8 @@ VLM_INTERNAL int vlm_gemv_w4_qkv_rope_kvwrite_ex(const void* h, const void* norm
                                                  int max_pages, void* kpool, void* vpool, int mfma, void* ws, float qk_scale,
                                                  int long_from, void* stream);
 
+VLM_INTERNAL int vlm_sample_last_launches(void);   /* sample.hip: kernels the last vlm_sample / vlm_sample_advance of this thread enqueued */
+
 /* sample.hip: the sampled step's tail for the engine's captured step - vlm_sample (temperature > 0; top_p / min_p / top_k) with the
  * final pick, vlm_decode_advance and the next step's embedding gather in ONE last launch */
 VLM_INTERNAL int vlm_sample_advance(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,

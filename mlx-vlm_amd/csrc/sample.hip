@@ -1400,6 +1400,9 @@ extern "C" size_t vlm_sample_sort_workspace_bytes(int B, int V) {
 // argmax found no candidate (an all-NaN logits row; the token is then 0) |
 // then one ROW_W-word block per row (see ROW_W at the top): lse partials | cand_v | cand_i | hist (all zero between calls) |
 // control words of the split top-p path (zero at allocation) - every array at a fixed offset inside the row's block
+static thread_local int t_last_launches = 0;   // kernels enqueued by the last sample_ex_impl of this thread (engine statistics)
+VLM_INTERNAL int vlm_sample_last_launches(void) { return t_last_launches; }
+
 static int sample_ex_impl(const void* logits, int ld, int B, int V, void* logprobs, void* scratch, int ldlp, void* tok,
                           void* workspace, const vlm_sampler_params* sp, const void* step_ptr, void* stream, const SampleTail* tail) {
   if (!logits || !tok || !workspace || !sp || B <= 0 || V <= 0) return VLM_ERR_ARG;
@@ -1445,6 +1448,7 @@ static int sample_ex_impl(const void* logits, int ld, int B, int V, void* logpro
     }
   }
   hipStream_t st = (hipStream_t)stream;
+  t_last_launches = 0;
   float* ws = (float*)((char*)workspace + 256);
   float* cand_v = ws + ROW_CV;
   int* cand_i = (int*)(ws + ROW_CI);
@@ -1458,11 +1462,11 @@ static int sample_ex_impl(const void* logits, int ld, int B, int V, void* logpro
   const bool fused_lp = split && !lp_given && ld % 8 == 0 && ((uintptr_t)logits & 15) == 0;
   if (!lp_given) {
     hipLaunchKernelGGL(lse_partial_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws);
-    VLM_CHECK_LAUNCH();
+    VLM_CHECK_LAUNCH(); ++t_last_launches;
     if (!fused_lp) {
       hipLaunchKernelGGL(logprob_argmax_kernel, dim3(NBLK, B), dim3(256), 0, st, (const bf16_t*)logits, ld, V, ws,
                          (bf16_t*)logprobs, ldlp, cand_v, cand_i);
-      VLM_CHECK_LAUNCH();
+      VLM_CHECK_LAUNCH(); ++t_last_launches;
     }
   }
   if (temperature == 0.0) {
@@ -1492,33 +1496,33 @@ static int sample_ex_impl(const void* logits, int ld, int B, int V, void* logpro
       else
         hipLaunchKernelGGL(topp_hist_kernel<false>, dim3(SPLIT_G, B), dim3(256), LDS, st, row_in, ld_in, V, hist, ctl,
                            (const float*)nullptr, (bf16_t*)nullptr, 0);
-      VLM_CHECK_LAUNCH();
+      VLM_CHECK_LAUNCH(); ++t_last_launches;
       hipLaunchKernelGGL(topp_cross_kernel, dim3(B), dim3(1024), LDS_B, st, (const uint32_t*)hist, ctl, k.thr_top_p);
-      VLM_CHECK_LAUNCH();
+      VLM_CHECK_LAUNCH(); ++t_last_launches;
       hipLaunchKernelGGL(topp_count_kernel, dim3(SPLIT_G, B), dim3(256), 0, st, row_in, ld_in, V, ctl);
-      VLM_CHECK_LAUNCH();
+      VLM_CHECK_LAUNCH(); ++t_last_launches;
       hipLaunchKernelGGL(topp_mask_kernel, dim3(SPLIT_G, B), dim3(256), 0, st, row_in, ld_in, (bf16_t*)scratch, ldlp, V, hist, ctl,
                          k.temp, k.seed, (const int*)step_ptr, cand_v, cand_i);
-      VLM_CHECK_LAUNCH();
+      VLM_CHECK_LAUNCH(); ++t_last_launches;
       if (tail) hipLaunchKernelGGL(argmax_final_advance_kernel, dim3(1), dim3(256), 0, st, cand_v, cand_i, (int*)tok, B, V, *tail);
       else hipLaunchKernelGGL(argmax_final_kernel, dim3(B), dim3(64), 0, st, cand_v, cand_i, (int*)tok);
-      VLM_CHECK_LAUNCH();
+      VLM_CHECK_LAUNCH(); ++t_last_launches;
       return VLM_OK;
     } else if (any_filter) {
       hipLaunchKernelGGL(sample_filter_kernel, dim3(B), dim3(1024), LDS, st, row_in, ld_in, (bf16_t*)scratch, ldlp, V, hist, k,
                          (const int*)step_ptr);
-      VLM_CHECK_LAUNCH();
+      VLM_CHECK_LAUNCH(); ++t_last_launches;
       row_in = (const bf16_t*)scratch;
       ld_in = ldlp;
     }
     // (no filter: the draw runs over the log-probs themselves; `scratch` is left untouched)
     hipLaunchKernelGGL(gumbel_partial_kernel, dim3(NBLK, B), dim3(256), 0, st, row_in, ld_in, V, k.temp, k.seed,
                        (const int*)step_ptr, cand_v, cand_i);
-    VLM_CHECK_LAUNCH();
+    VLM_CHECK_LAUNCH(); ++t_last_launches;
     if (tail) hipLaunchKernelGGL(argmax_final_advance_kernel, dim3(1), dim3(256), 0, st, cand_v, cand_i, (int*)tok, B, V, *tail);
     else hipLaunchKernelGGL(argmax_final_kernel, dim3(B), dim3(64), 0, st, cand_v, cand_i, (int*)tok);
   }
-  VLM_CHECK_LAUNCH();
+  VLM_CHECK_LAUNCH(); ++t_last_launches;
   return VLM_OK;
 }
 

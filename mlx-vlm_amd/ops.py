@@ -228,7 +228,7 @@ def gemv_attn_out_bf16_(part_o, part_ml, wo, h, Hq, D):
 def attn_decode_paged_split(q, kpool, vpool, block_table, kv_len, kv_len_add, Hq, Hkv, D, scale, nsplit, out=None,
                             max_pages=None, tickets=None, merge=True, part=None):
     """page-split decode attention (one wave per page stride).  merge=True: the last arriver merges -> bf16 [B, Hq*D];
-    merge=False: the partial-only form -> (part_o bf16 [B, Hq, nsplit, D], part_ml fp32 [B, Hq, nsplit, 2]) for
+    merge=False: the partial-only form -> (part_o fp32 [B, Hq, nsplit, D], part_ml fp32 [B, Hq, nsplit, 2]) for
     gemv_attn_out_bf16_."""
     _dev(q, kpool, vpool, block_table, kv_len)
     B = q.shape[0]
@@ -236,7 +236,7 @@ def attn_decode_paged_split(q, kpool, vpool, block_table, kv_len, kv_len_add, Hq
         if part is not None:
             part_o, part_ml = part
         else:
-            part_o = torch.full((B, Hq, nsplit, D), float("nan"), dtype=torch.bfloat16, device=q.device)   # unwritten = NaN on purpose
+            part_o = torch.full((B, Hq, nsplit, D), float("nan"), dtype=torch.float32, device=q.device)   # unwritten = NaN on purpose
             part_ml = torch.empty(B, Hq, nsplit, 2, dtype=torch.float32, device=q.device)
         check(_lib.lib().vlm_attn_decode_paged_split(_p(q), q.stride(0), _p(kpool), _p(vpool), _p(block_table),
                                                      block_table.shape[1] if block_table is not None else int(max_pages),

@@ -694,7 +694,7 @@ def _insert_all(gen, reqs, max_tokens):
 
 
 # A request decoded inside a batch and the same request decoded alone run DIFFERENT reduction structures since round 3 (one
-# row: page-split attention merged in the o_proj prologue from bf16 partials; 2..8 rows: merged by the attention launch's last
+# row: page-split attention merged in the o_proj prologue; 2..8 rows: merged by the attention launch's last
 # arriver from fp32 partials; 9..16 rows: projections on the matrix cores): every step's hidden state may differ by a bf16 ulp.
 # A token log-prob is bf16(logit - bf16(logsumexp)): one ulp of a logsumexp in [8, 16) is 0.0625, the logit adds its own, so
 # two correct runs agree to LP_ATOL; greedy tokens agree until a step whose top two candidates lie inside that noise.

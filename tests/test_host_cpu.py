@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES)
     for s in declared:
         assert hasattr(L, s), s
-    assert L.vlm_abi_version() == 7
+    assert L.vlm_abi_version() == 8
     # ... and NOTHING else: the dynamic symbol table of the .so is exactly the header (debug hooks and library-internal
     # entry points have hidden visibility)
     import subprocess

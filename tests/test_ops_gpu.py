@@ -52,7 +52,7 @@ def vops():
 def test_library_loaded_is_in_tree():
     import mlx_vlm_amd._lib as L
 
-    assert L.lib().vlm_abi_version() == 7
+    assert L.lib().vlm_abi_version() == 8
     assert "mlx-vlm_amd/lib/libvlm_hip.so" in L.LIB_PATH
 
 
@@ -336,10 +336,10 @@ def test_attn_decode_paged_split_vs_oracle(vops, lens, nsplit, heads, identity):
 @pytest.mark.parametrize("n,nsplit,heads", [(386, 16, (12, 2)), (1, 16, (12, 2)), (64, 8, (12, 2)), (1024, 16, (12, 2)),
                                             (1500, 16, (16, 8)), (700, 4, (8, 1)), (130, 16, (14, 2))])
 def test_attn_decode_partial_only_plus_oproj_prologue_merge(vops, n, nsplit, heads):
-    """the one-row decode path of the engine: vlm_attn_decode_paged_split without merge (bf16 partials + (m, l), splits
+    """the one-row decode path of the engine: vlm_attn_decode_paged_split without merge (fp32 partials + (m, l), splits
     without a page flagged (-inf, 0); unwritten partial slots hold NaN on purpose) -> vlm_gemv_attn_out_bf16 (merge in
-    the o_proj prologue + residual) against the oracle's SDPA -> Linear -> residual.  The partials are rounded to bf16
-    before the merge (the one-launch forms merge fp32 partials): 3 ulps + 2 % of the rms of the o_proj output."""
+    the o_proj prologue + residual) against the oracle's SDPA -> Linear -> residual.  3 ulps + 2 % of the
+    rms of the o_proj output (tests/test_op_noise_gpu.py holds the attention itself to 5e-4 of the exactly rounded result)."""
     Hq, Hkv = heads
     D = 128
     scale = D ** -0.5
