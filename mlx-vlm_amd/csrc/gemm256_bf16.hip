@@ -43,6 +43,10 @@ extern "C" int vlm_debug_gemm_stamps(void* host_out, int n) {
 #define GST(i)
 #endif
 
+#ifndef GEMM_DMA_AUX
+#define GEMM_DMA_AUX 0      // cache-policy bits of the LDS-DMA loads (measurement builds: -DGEMM_DMA_AUX=1 sc0, 2 nt, 16 sc1, ...)
+#endif
+
 namespace {
 
 constexpr int TB = 256;                 // tile edge (M and N)
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
     if (ABL == 1 && kt >= 2) return;
     const int ktc = min(kt, nk - 1);   // past the end: a harmless reload (keeps the vmcnt arithmetic uniform)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)ktc * BK),
-                                     (__attribute__((address_space(3))) void*)(smem + lds_byte), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(smem + lds_byte), 16, 0, GEMM_DMA_AUX);
   };
   auto issue_w = [&](int kt) {
     const int base = (kt & 1) * STAGE;
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const bf16_t* __restrict_
   auto dma = [&](const bf16_t* src, int kt, int lds_byte) {
     const int ktc = min(kt, nk - 1);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)ktc * BK),
-                                     (__attribute__((address_space(3))) void*)(smem + lds_byte), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(smem + lds_byte), 16, 0, GEMM_DMA_AUX);
   };
   auto issue_w = [&](int kt) {
     const int base = (kt & 1) * STAGE;
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(512) void gemm256b_kernel(const bf16_t* __restrict_
   auto dma = [&](const bf16_t* src, int kt, int lds_byte) {
     const int ktc = min(kt, nk - 1);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)ktc * BK),
-                                     (__attribute__((address_space(3))) void*)(smem + lds_byte), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(smem + lds_byte), 16, 0, GEMM_DMA_AUX);
   };
   auto issue_w = [&](int kt) {
     const int base = (kt & 1) * STAGE + 2 * HALF + (g >> 1) * HALF + (g & 1) * 8 * 8 * ROWB;
