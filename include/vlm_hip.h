@@ -37,6 +37,14 @@ extern "C" {
 #define VLM_EPI_GELU_ERF 4   /* exact erf GELU                      vision.py:112        */
 #define VLM_EPI_RESIDUAL 8   /* + res[m][n]                         vision.py:188-193, language.py:151-153 */
 #define VLM_EPI_SWIGLU 16    /* W rows interleaved (gate_j, up_j): out[j] = silu(g)*u   mlp.py:6-14, activations.py:7-9 */
+/* vlm_gemv_bf16_ws only, batched decode steps of 5..16 rows (ABI v8): the activations BETWEEN two projections in the tiled layout
+ * t[K / 8][16][8] bf16 (k group, batch row, 8 consecutive k) instead of row-major [M][K] - what the matrix cores' B fragments read
+ * as whole cache lines.  Y_TILED: y is written tiled (ldy ignored; y holds 16 * N_out elements, rows M..15 are not written);
+ * X_TILED: x is read tiled (ldx ignored) - the row-slice form of the skinny decode GEMM (csrc/gemv_mfma_rows.hip), for projections
+ * with at most 16 output rows per compute unit and K >= 4096, K % 128 == 0 (the SwiGLU MLP's down projection, mlp.py:6-14).
+ * A shape the flagged kernel does not take is refused (return 2) and nothing is enqueued. */
+#define VLM_EPI_X_TILED 64
+#define VLM_EPI_Y_TILED 128
 
 int vlm_abi_version(void);
 
@@ -452,6 +460,9 @@ typedef struct vlm_decode_args {
                                    the next step's h behind: vlm_sample_greedy_advance at temperature 0; with a temperature
                                    the sampler's last launch (final pick) also does vlm_decode_advance and the gather.
                                    bf16 embedding tables only.  The host must not rewrite tok between steps. */
+#define VLM_DECODE_ACT16 2      /* `act` holds 16 x intermediate_size elements (not B x): a step of 5..16 rows over bf16 weights
+                                   may then hand the SwiGLU output to the down projection in the tiled layout of
+                                   VLM_EPI_Y_TILED / VLM_EPI_X_TILED (rows padded to the MFMA tile's 16).  ABI v8. */
 
 int vlm_llm_create(const vlm_llm_config* cfg, void** handle);          /* (host) */
 int vlm_llm_destroy(void* handle);

@@ -93,6 +93,7 @@ class VitArgs(C.Structure):
 
 
 DECODE_FUSED_TAIL = 1                       # vlm_decode_args.flags
+DECODE_ACT16 = 2                            # `act` holds 16 x intermediate_size elements (tiled hand-over to the down projection)
 TUNE_MFMA_GEMV, TUNE_ATTN_PAGESPLIT, TUNE_GEMV_VARIANT, TUNE_ATTN_MERGE = 6, 7, 8, 9  # vlm_llm_set_tuning keys (include/vlm_hip.h)
 
 P = C.POINTER

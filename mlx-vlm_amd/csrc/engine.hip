@@ -397,10 +397,21 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
     } else {
       TRY(vlm_gemv_attn_out(a->part_o, a->part_ml, a->nsplit, w.wo, a->h, D, B, D, Hq, hd, stream)); ++n;
     }
-    // act = swiglu(RMSNorm(h) Wgu^T)
-    TRY(lin_gemv(m, a->h, w.wgu, w.wgu_sb, nullptr, nullptr, w.ln2_w, a->act, B, 2 * c.inter, D, c.inter, 0, c.rms_eps, VLM_EPI_SWIGLU, stream)); ++n;
-    // h = h + act Wdown^T
-    TRY(lin_gemv(m, a->act, w.wdown, w.wdown_sb, nullptr, a->h, nullptr, a->h, B, D, c.inter, D, D, 0.f, VLM_EPI_RESIDUAL, stream)); ++n;
+    // act = swiglu(RMSNorm(h) Wgu^T);  h = h + act Wdown^T.  Batched steps over bf16 weights hand `act` over in the TILED layout
+    // when the down projection takes the row-slice form (one workgroup per CU owns N / 256 output rows and their whole K: no K
+    // split across workgroups; csrc/gemv_mfma_rows.hip) - the gate/up launch then writes that layout (refused -> the plain pair)
+    bool tiled = false;
+    if ((a->flags & VLM_DECODE_ACT16) && B >= 5 && tn.mfma_gemv && !w.wgu_sb && !w.wdown_sb && vlm_gemv_mfma_rows_ok(B, D, c.inter) &&
+        c.inter % 8 == 0) {
+      const int rc = lin_gemv(m, a->h, w.wgu, nullptr, nullptr, nullptr, w.ln2_w, a->act, B, 2 * c.inter, D, c.inter, 0, c.rms_eps,
+                              VLM_EPI_SWIGLU | VLM_EPI_Y_TILED, stream);
+      if (rc == 0) tiled = true;
+      else if (rc != 2) return rc;
+    }
+    if (!tiled) TRY(lin_gemv(m, a->h, w.wgu, w.wgu_sb, nullptr, nullptr, w.ln2_w, a->act, B, 2 * c.inter, D, c.inter, 0, c.rms_eps, VLM_EPI_SWIGLU, stream));
+    ++n;
+    TRY(lin_gemv(m, a->act, w.wdown, w.wdown_sb, nullptr, a->h, nullptr, a->h, B, D, c.inter, D, D, 0.f,
+                 VLM_EPI_RESIDUAL | (tiled ? VLM_EPI_X_TILED : 0), stream)); ++n;
   }
   // logits = RMSNorm(h) lm_head^T
   const int VL = (c.vocab + 7) & ~7;      // row pitch of logits / logprobs / scratch (see vlm_llm_prefill)

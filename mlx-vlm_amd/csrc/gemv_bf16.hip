@@ -610,10 +610,18 @@ VLM_INTERNAL int vlm_gemv_bf16_ex(const void* x, const void* W, const void* bias
   if ((epilogue & VLM_EPI_RESIDUAL) && !res) return VLM_ERR_ARG;
   if (K % 8 != 0 || ldx % 8 != 0 || ldw % 8 != 0) return VLM_ERR_SHAPE;
   if ((epilogue & VLM_EPI_SWIGLU) && (N % 2 != 0)) return VLM_ERR_SHAPE;
+  // activations in the tiled layout between two projections of a batched decode step (include/vlm_hip.h VLM_EPI_X_TILED / Y_TILED):
+  // only the matrix-core forms know it - a shape they do not take is refused, nothing is enqueued
+  if (epilogue & VLM_EPI_X_TILED) {
+    if (!mfma || norm_w || (epilogue & VLM_EPI_Y_TILED)) return VLM_ERR_SHAPE;
+    const int rc = vlm_gemv_mfma_rows_try(x, W, bias, res, y, M, N, K, ldw, ldy, ldres, epilogue & ~VLM_EPI_X_TILED, stream);
+    return rc >= 0 ? rc : VLM_ERR_SHAPE;
+  }
   if (mfma) {   // (M >= 3 by default) batch rows as the N dimension of the matrix cores (gemv_mfma.hip); -1: shape not handled there
     const int rc = vlm_gemv_mfma_try(x, W, bias, res, norm_w, y, M, N, K, ldx, ldw, ldy, ldres, eps, epilogue, nullptr, ws, stream);
     if (rc >= 0) return rc;
   }
+  if (epilogue & VLM_EPI_Y_TILED) return VLM_ERR_SHAPE;
   if ((size_t)M * K * 2 > 64 * 1024 && (norm_w || K <= 3584)) return VLM_ERR_SHAPE;
   Args a{x, W, bias, res, norm_w, y, N, K, ldx, ldw, ldy, ldres, eps, RopeKvArgs{}, AttnProArgs{}, (hipStream_t)stream};
   if (K <= 3584 || (norm_w && K <= 4096)) {

@@ -56,6 +56,7 @@ struct MfmaArgs {
   float* ws;            // [n_tiles * KS][256] fp32 partial tiles (KS > 1)
   unsigned* tickets;    // [n_tiles] arrivals of the current launch (zero between launches)
   int n_tiles, KS, nblk, bpk;   // row tiles, K segments, 128-wide chunks of K, chunks per segment
+  int y_tiled;                  // 1: y in the tiled layout [N_out / 8][16][8] the row-slice form reads (gemv_mfma_rows.hip; VLM_EPI_Y_TILED)
 };
 
 template <int EPI>
@@ -384,11 +385,11 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const MfmaArgs a) {
       }
     } else if (EPI & VLM_EPI_SWIGLU) {
       if (m < a.M && !(n_l & 1) && n + 1 < a.N)
-        a.y[(size_t)m * a.ldy + (n >> 1)] = f2bf(swiglu_(rbf(v), rbf(part[tid + 16])));
+        a.y[a.y_tiled ? ((size_t)(n >> 4) * 16 + m) * 8 + ((n >> 1) & 7) : (size_t)m * a.ldy + (n >> 1)] = f2bf(swiglu_(rbf(v), rbf(part[tid + 16])));
     } else if (m < a.M && n < a.N) {
       if (EPI & VLM_EPI_BIAS) v = (W4 ? rbf(v) : v) + bf2f(a.bias[n]);
       if (EPI & VLM_EPI_RESIDUAL) v = rbf(v) + bf2f(a.res[(size_t)m * a.ldres + n]);
-      a.y[(size_t)m * a.ldy + n] = f2bf(v);
+      a.y[a.y_tiled ? ((size_t)(n >> 3) * 16 + m) * 8 + (n & 7) : (size_t)m * a.ldy + n] = f2bf(v);
     }
   };
 
@@ -618,8 +619,11 @@ static int mfma_try(const void* x, const void* W, const void* Wsb, const void* b
   // 4, 1.8 ms at 8): profiles/r02_mfma_gemv.txt.  The qkv + RoPE + KV-write form starts at 9 rows (6.2 vs 7.2 us at 8).
   static const bool enabled = [] { const char* e = getenv("VLM_GEMV_MFMA"); return !e || atoi(e) != 0; }();
   static const int min_m = [] { const char* e = getenv("VLM_GEMV_MFMA_MIN_M"); return e ? atoi(e) : 5; }();
+  const bool y_tiled = (epilogue & VLM_EPI_Y_TILED) != 0;      // (this form's epilogue writes it; the other forms are skipped)
+  epilogue &= ~VLM_EPI_Y_TILED;
   if (!enabled || M < (rk ? max(min_m, 9) : min_m) || M > 16 || K % 128 || ldx % 8 || ldw % 8) return -1;
   const bool rope = rk != nullptr;
+  if (y_tiled && (rope || Wsb)) return -1;
   if (rope && (rk->D % 16 || !norm_w || !bias)) return -1;
   if (!rope && epilogue != VLM_EPI_NONE && epilogue != VLM_EPI_BIAS && epilogue != VLM_EPI_RESIDUAL && epilogue != VLM_EPI_SWIGLU &&
       epilogue != (VLM_EPI_BIAS | VLM_EPI_RESIDUAL))
@@ -627,7 +631,7 @@ static int mfma_try(const void* x, const void* W, const void* Wsb, const void* b
   if (norm_w && (epilogue & VLM_EPI_RESIDUAL)) return -1;
   if ((epilogue & VLM_EPI_SWIGLU) && (N % 16)) return -1;
 #ifndef VLM_MFMA_W4_TU
-  if (!Wsb && !norm_w && !rope) {
+  if (!Wsb && !norm_w && !rope && !y_tiled) {
     // few row tiles x long K (the down projections): one workgroup per tile, K split over its 16 waves, no cross-workgroup
     // hand-off (gemv_mfma_longk.hip)
     const int rc3 = vlm_gemv_mfma_longk_try(x, W, bias, res, y, M, N, K, ldx, ldw, ldy, ldres, epilogue, stream);
@@ -637,7 +641,7 @@ static int mfma_try(const void* x, const void* W, const void* Wsb, const void* b
   {
     // the second form first (gemv_mfma2.hip: activations in registers, two workgroups per CU); VLM_GEMV_MFMA2=0: A/B knob
     static const bool v2 = [] { const char* e = getenv("VLM_GEMV_MFMA2"); return !e || atoi(e) != 0; }();
-    if (v2) {
+    if (v2 && !y_tiled) {
 #ifdef VLM_MFMA_W4_TU
       const int rc2 = Wsb ? vlm_gemv_mfma2_try_w4(x, W, Wsb, bias, res, norm_w, y, M, N, K, ldx, ldw, ldy, ldres, eps, epilogue, rk, ws, stream) : -1;
 #else
@@ -650,6 +654,7 @@ static int mfma_try(const void* x, const void* W, const void* Wsb, const void* b
   a.x = (const bf16_t*)x; a.W = (const bf16_t*)W; a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res;
   a.norm_w = (const bf16_t*)norm_w; a.y = (bf16_t*)y; a.Wsb = (const unsigned*)Wsb;
   a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldres = ldres; a.eps = eps;
+  a.y_tiled = y_tiled ? 1 : 0;
   if (rope) {
     a.rk = *rk;
     if (N != (rk->Hq + 2 * rk->Hkv) * rk->D) return -1;

@@ -66,6 +66,11 @@ VLM_INTERNAL int vlm_gemv_w4_qkv_rope_kvwrite_ex(const void* h, const void* norm
                                                  int max_pages, void* kpool, void* vpool, int mfma, void* ws, float qk_scale,
                                                  int long_from, void* stream);
 
+// row-slice form of the skinny-M decode GEMM (csrc/gemv_mfma_rows.hip): x in the tiled layout [K / 8][16][8]; -1: shape not handled
+VLM_INTERNAL int vlm_gemv_mfma_rows_ok(int M, int N, int K);      // 1: vlm_gemv_mfma_rows_try takes this projection
+VLM_INTERNAL int vlm_gemv_mfma_rows_try(const void* xt, const void* W, const void* bias, const void* res, void* y, int M, int N, int K,
+                                        int ldw, int ldy, int ldres, int epilogue, void* stream);
+
 VLM_INTERNAL int vlm_sample_last_launches(void);   /* sample.hip: kernels the last vlm_sample / vlm_sample_advance of this thread enqueued */
 
 /* sample.hip: the sampled step's tail for the engine's captured step - vlm_sample (temperature > 0; top_p / min_p / top_k) with the

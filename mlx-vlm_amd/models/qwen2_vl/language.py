@@ -56,7 +56,9 @@ class DecodeState:
         self.h = A((B, D), bf)
         self.qkv = A((B, (Hq + 2 * Hkv) * hd), bf)
         self.attn = A((B, Hq * hd), bf)
-        self.act = A((B, t.intermediate_size), bf)
+        # (16 rows even for a narrower state: a 5..16-row step hands the SwiGLU output to the down projection in the MFMA tile's
+        #  layout [inter / 8][16][8] - vlm_decode_args.flags VLM_DECODE_ACT16, csrc/gemv_mfma_rows.hip)
+        self.act = A((max(B, 16), t.intermediate_size), bf)
         self.part_ml = A((B, Hq, nsplit, 2), torch.float32)
         self.out_ring = A((ring_len, B), i32, zero=True)
         # rows at pitch VL = vocab rounded up to 8 (the engine's pitch: 16-byte aligned rows for any vocabulary, e.g. 32003)
@@ -151,7 +153,7 @@ class DecodeState:
                                p(self.logprobs) if (with_logprobs or temperature > 0) else None, p(self.scratch),
                                p(self.part_o), p(self.part_ml), p(self.sample_ws), p(self.out_ring), self.ring_len,
                                self.nsplit, float(temperature), float(top_p), float(min_p), int(top_k),
-                               int(seed) & 0xFFFFFFFF, int(flags),
+                               int(seed) & 0xFFFFFFFF, int(flags) | _lib.DECODE_ACT16,       # (self.act holds 16 rows)
                                C.pointer(pa) if (pa := self.penalty_args(penalties)) is not None else None)
 
 

@@ -82,16 +82,40 @@ def gemv_workspace(device):
     return _gemv_ws[key]
 
 
-def gemv_ws(x, w, bias=None, res=None, norm_w=None, out=None, eps=1e-6, epilogue=EPI_NONE):
-    """gemv for a batched decode step (up to 16 rows), K split over workgroups through the workspace where it pays"""
-    _dev(x, w, bias, res, norm_w, out)
+EPI_X_TILED, EPI_Y_TILED = 64, 128      # include/vlm_hip.h: activations in the MFMA tile's layout [K / 8][16][8] between two projections
+
+
+def tile_rows(x):
+    """[M <= 16, K] row-major -> the tiled layout [K / 8, 16, 8] (rows M..15 zero): what EPI_X_TILED reads / EPI_Y_TILED writes"""
     M, K = x.shape
+    t = torch.zeros(K // 8, 16, 8, dtype=x.dtype, device=x.device)
+    t[:, :M] = x.view(M, K // 8, 8).permute(1, 0, 2)
+    return t
+
+
+def untile_rows(t, M):
+    """inverse of tile_rows: [K / 8, 16, 8] -> [M, K]"""
+    return t[:, :M].permute(1, 0, 2).reshape(M, -1).contiguous()
+
+
+def gemv_ws(x, w, bias=None, res=None, norm_w=None, out=None, eps=1e-6, epilogue=EPI_NONE, M=None):
+    """gemv for a batched decode step (up to 16 rows), K split over workgroups through the workspace where it pays.
+    epilogue | EPI_Y_TILED: out is the tiled [N_out / 8, 16, 8] tensor; epilogue | EPI_X_TILED: x is one (pass M = rows)."""
+    _dev(x, w, bias, res, norm_w, out)
     N = w.shape[0]
     n_out = N // 2 if epilogue & EPI_SWIGLU else N
+    if epilogue & EPI_X_TILED:
+        K, ldx = x.shape[0] * 8, 0
+        assert M is not None and x.shape[1:] == (16, 8)
+    else:
+        M, K = x.shape
+        ldx = x.stride(0)
     if out is None:
-        out = torch.empty(M, n_out, dtype=torch.bfloat16, device=x.device)
-    check(_lib.lib().vlm_gemv_bf16_ws(_p(x), _p(w), _p(bias), _p(res), _p(norm_w), _p(out), M, N, K, x.stride(0),
-                                      w.stride(0), out.stride(0), res.stride(0) if res is not None else 0, eps, epilogue,
+        out = (torch.full((n_out // 8, 16, 8), float("nan"), dtype=torch.bfloat16, device=x.device) if epilogue & EPI_Y_TILED
+               else torch.empty(M, n_out, dtype=torch.bfloat16, device=x.device))
+    ldy = 0 if epilogue & EPI_Y_TILED else out.stride(0)
+    check(_lib.lib().vlm_gemv_bf16_ws(_p(x), _p(w), _p(bias), _p(res), _p(norm_w), _p(out), M, N, K, ldx,
+                                      w.stride(0), ldy, res.stride(0) if res is not None else 0, eps, epilogue,
                                       _p(gemv_workspace(x.device)), _stream()), "gemv_ws")
     return out
 

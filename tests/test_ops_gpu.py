@@ -1086,6 +1086,54 @@ def test_gemv_w4_qkv_rope_kvwrite_fused(vops, M):
 
 # ------------------------------------------------------------------ batched decode rows on the matrix cores (csrc/gemv_mfma.hip)
 @pytest.mark.parametrize("M", [5, 8, 13, 16])
+@pytest.mark.parametrize("H,I", [(1536, 8960), (1024, 4096), (2048, 5632), (896, 4864)])
+def test_gemv_tiled_mlp_pair_equals_the_plain_pair(vops, M, H, I):
+    """The MLP of a batched decode step with the activations handed over in the MFMA tile's layout (VLM_EPI_Y_TILED on the
+    [RMSNorm + gate/up + SwiGLU] launch, VLM_EPI_X_TILED on the down projection = its row-slice form, csrc/gemv_mfma_rows.hip:
+    one workgroup per CU owns N / 256 output rows and their whole K) against the plain pair and the oracle: the SwiGLU output is
+    the SAME values at other addresses (bit-exact, rows M..15 never written), the down projection sums in another fp32 order
+    (2 ulps vs the oracle, as every form), repeats are bit-identical, ragged slices (N = 896: 4 rows per CU, the last ones short)."""
+    x, nw = rnd(M, H, seed=70), (1 + 0.1 * torch.randn(H, generator=torch.Generator().manual_seed(71))).to(BF)
+    wg, wu, wd = rnd(I, H, seed=72, scale=0.05), rnd(I, H, seed=73, scale=0.05), rnd(H, I, seed=74, scale=0.03)
+    wil = torch.stack([wg, wu], dim=1).reshape(2 * I, H).contiguous().cuda()
+    xd, nwd, wdd = x.cuda(), nw.cuda(), wd.cuda()
+    act = vops.gemv_ws(xd, wil, norm_w=nwd, epilogue=vops.EPI_SWIGLU)
+    act_t = vops.gemv_ws(xd, wil, norm_w=nwd, epilogue=vops.EPI_SWIGLU | vops.EPI_Y_TILED)
+    assert act_t.shape == (I // 8, 16, 8)
+    assert torch.equal(vops.untile_rows(act_t, M), act)
+    if M < 16:
+        assert bool(torch.isnan(act_t[:, M:].float()).all())          # rows past M are not written
+    r = rnd(M, H, seed=75)
+    want = vops.gemv_ws(act, wdd, res=r.cuda(), epilogue=vops.EPI_RESIDUAL)
+    got = vops.gemv_ws(act_t, wdd, res=r.cuda(), epilogue=vops.EPI_RESIDUAL | vops.EPI_X_TILED, M=M)
+    ref = O.add(r, O.linear(act.cpu(), wd))
+    ok, rep = bf16_close(got, ref, ulps=2)
+    assert ok, rep
+    ok, rep = bf16_close(got, want.cpu(), ulps=2)
+    assert ok, rep
+    for _ in range(3):
+        assert torch.equal(vops.gemv_ws(act_t, wdd, res=r.cuda(), epilogue=vops.EPI_RESIDUAL | vops.EPI_X_TILED, M=M), got)
+    # bias + residual, no epilogue; a tiled x built by hand
+    b = rnd(H, seed=76, scale=0.3)
+    a2 = rnd(M, I, seed=77, scale=0.3)
+    ok, rep = bf16_close(vops.gemv_ws(vops.tile_rows(a2.cuda()), wdd, bias=b.cuda(), epilogue=vops.EPI_BIAS | vops.EPI_X_TILED, M=M),
+                         O.linear(a2, wd, b), ulps=2)
+    assert ok, rep
+    ok, rep = bf16_close(vops.gemv_ws(vops.tile_rows(a2.cuda()), wdd, epilogue=vops.EPI_X_TILED, M=M), O.linear(a2, wd), ulps=2)
+    assert ok, rep
+
+
+def test_gemv_tiled_flags_refuse_what_the_tiled_kernels_do_not_take(vops):
+    """a flagged call whose shape the matrix-core forms do not take is refused (VLM_ERR_SHAPE) and enqueues nothing"""
+    x, w = rnd(8, 1536, seed=78).cuda(), rnd(1536, 1536, seed=79, scale=0.05).cuda()
+    with pytest.raises(RuntimeError):
+        vops.gemv_ws(vops.tile_rows(x), w, epilogue=vops.EPI_X_TILED, M=8)            # K < 4096: not the row-slice form's
+    x2 = rnd(2, 1536, seed=80).cuda()
+    with pytest.raises(RuntimeError):
+        vops.gemv_ws(x2, w, epilogue=vops.EPI_Y_TILED)                                # 2 rows: the v_dot2c kernels, which do not tile
+
+
+@pytest.mark.parametrize("M", [5, 8, 13, 16])
 @pytest.mark.parametrize("N,K", [(2048, 1536), (1536, 8960), (1000, 3584), (152, 256), (3584, 18944)])
 def test_gemv_mfma_rows_plain_bias_residual(vops, M, N, K):
     """5..16 batch rows as the N dimension of the MFMA (vlm_gemv_bf16_ws): every K-split form (one segment; 6 segments of
