@@ -162,7 +162,7 @@ int vlm_rope2d_vision(void* qkv, const void* cos_tab, const void* sin_tab, int N
  * k and the v of token t are written to slot kv_slot[t] of sequence kv_seq[t] (NULL: seq = t) in
  * the paged pools (page = block_table[seq][slot / 64]).  pos_* int32 [T] (t, h, w axes; pass the
  * same pointer three times for text).  sec0 / sec1 = mrope_section[0..1].  kpool == NULL: rope only.
- * K pool [page][Hkv][D/8][64][8], V pool [page][Hkv][D][64 key slots] (bf16; slot order: see csrc/common.cuh
+ * K pool [page][Hkv][D/8][64][8], V pool [page][Hkv][D][64 key slots] (bf16; slot order: see csrc/common.hpp
  * vlm_vslot - the k-slot order of the decode P.V MFMA). */
 int vlm_mrope_kvwrite(void* qkv, int ld, int T, int Hq, int Hkv, int D, const void* pos_t, const void* pos_h,
                       const void* pos_w, const void* inv_freq, int sec0, int sec1, const void* kv_seq,

@@ -36,7 +36,7 @@ def sources():
 
 
 def _deps_mtime():
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cuh", ".h"))]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "vlm_hip.h"))
     return max(os.path.getmtime(h) for h in hdrs)
 

@@ -27,8 +27,8 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "common.cuh"
-#include "attn_pagesplit.cuh"
+#include "common.hpp"
+#include "attn_pagesplit.hpp"
 #include "internal.h"
 #include "../../include/vlm_hip.h"
 
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(
     m_run = m_new;
     stamp(4);
     // ---- P^T fragments: k-slot 8gq + j of step u  <-  tile 2u (j < 4) / tile 2u+1 (j >= 4), register j & 3
-    bf16x8_t pb[2], pl[2];          // hi + lo: 16 mantissa bits of p (attn_pagesplit.cuh)
+    bf16x8_t pb[2], pl[2];          // hi + lo: 16 mantissa bits of p (attn_pagesplit.hpp)
     vlm_pack_p_hilo(st, pb, pl);
     // ---- O^T += V^T . P^T ; never-written V slots are multiplied by p == 0 but may hold NaN patterns -> zeroed
 #pragma unroll

@@ -4,7 +4,7 @@
 // O^T[d = 16 dt + 4 gq + r][head = lane & 15] in ot, the running max (log2 domain) in m_run and this lane's share of the row
 // sum in l_run.  Layouts, MFMA operand order and the reasons for them: attn_decode.hip (file header).
 #pragma once
-#include "common.cuh"
+#include "common.hpp"
 
 constexpr int VLM_HD = 128;    // head_dim supported by the decode path
 constexpr int VLM_PAGE = 64;

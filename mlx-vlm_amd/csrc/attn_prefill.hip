@@ -29,7 +29,7 @@
 // the barrier.  Output is stored as 8-byte bf16x4 pieces (4 consecutive d).
 #include <stdlib.h>
 
-#include "common.cuh"
+#include "common.hpp"
 #include "../../include/vlm_hip.h"
 
 #ifdef ATTN_STAMPS
@@ -53,7 +53,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 
 template <int D, bool CAUSAL, bool HILO = false>
 // HILO: P as two bf16 MFMA operands (hi = bf16(p), lo = bf16(p - hi)): 16 mantissa bits of p reach O^T, as in the decode kernels
-// (attn_pagesplit.cuh) - here at the price of a second P.V MFMA per fragment in a kernel whose matrix pipe is half busy.
+// (attn_pagesplit.hpp) - here at the price of a second P.V MFMA per fragment in a kernel whose matrix pipe is half busy.
 // (D <= 80: three waves per SIMD = three workgroups per CU - 168 registers, the only spills are epilogue values saved before
 //  the loop; the D = 64 form had three waves all along and ran at 516 TF where this one ran at 440)
 __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void attn_prefill_kernel(

@@ -10,7 +10,7 @@
 // vlm_decode_advance      per-step bookkeeping of the decode loop: KVCache.offset += 1
 //                         (reference mlx_vlm/models/cache.py:362) and pos = offset + rope_delta
 //                         (language.py:476-509) kept in device memory so a step can be graph-replayed
-#include "common.cuh"
+#include "common.hpp"
 #include "../../include/vlm_hip.h"
 
 namespace {

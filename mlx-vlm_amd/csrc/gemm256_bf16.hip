@@ -28,7 +28,7 @@
 // = 1, 1, 5, 1 wave-instructions of 1 KiB; the waits are vmcnt(9), (9), (13), (9) (derivation in DESIGN.md).
 #include <stdlib.h>
 
-#include "common.cuh"
+#include "common.hpp"
 #include "../../include/vlm_hip.h"
 
 #ifdef GEMM_STAMPS

@@ -20,7 +20,7 @@
 // L2) walks a contiguous range of tiles.
 #include <algorithm>
 
-#include "common.cuh"
+#include "common.hpp"
 #include "internal.h"
 #include "../../include/vlm_hip.h"
 

@@ -24,8 +24,8 @@
 //   * split-K kernel (large K, e.g. the 8960-wide down projection): the 4 waves of
 //     a workgroup split K for RW rows (N / RW workgroups keep all 256 CUs busy),
 //     partial sums meet in LDS.
-#include "common.cuh"
-#include "attn_pagesplit.cuh"
+#include "common.hpp"
+#include "attn_pagesplit.hpp"
 #include "internal.h"
 #include "../../include/vlm_hip.h"
 
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void gemv_rowwave_kernel(const bf16_t* __restr
       }
     }
   } else if (PRO == PRO_ATTN_PS) {
-    // x[h*D + d] = sum_s f_s O_s[d] / sum_s f_s l_s,  f_s = 2^(m_s - M)   (attn_pagesplit.cuh)
+    // x[h*D + d] = sum_s f_s O_s[d] / sum_s f_s l_s,  f_s = 2^(m_s - M)   (attn_pagesplit.hpp)
     const uint4 o = vlm_merge_splits16(a2_ml, a2_o, ap.S);
     if (tid < nchunk) reinterpret_cast<uint4*>(smem)[tid] = o;
   } else if (PRO == PRO_ATTN) {

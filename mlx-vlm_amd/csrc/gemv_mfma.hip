@@ -35,7 +35,7 @@
 
 #include <type_traits>
 
-#include "common.cuh"
+#include "common.hpp"
 #include "internal.h"
 #include "../../include/vlm_hip.h"
 

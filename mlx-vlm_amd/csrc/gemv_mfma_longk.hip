@@ -17,7 +17,7 @@
 // 0..15) differs from the general kernel's: same fp32 bounds, tolerance-level agreement (tests/test_ops_gpu.py).
 #include <stdlib.h>
 
-#include "common.cuh"
+#include "common.hpp"
 #include "internal.h"
 #include "../../include/vlm_hip.h"
 

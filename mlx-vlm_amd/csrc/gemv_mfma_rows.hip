@@ -19,7 +19,7 @@
 // (gemv_mfma.hip's SwiGLU epilogue with MfmaArgs.y_tiled: the gate/up launch in front of the down projection).
 #include <stdlib.h>
 
-#include "common.cuh"
+#include "common.hpp"
 #include "internal.h"
 #include "../../include/vlm_hip.h"
 

@@ -17,7 +17,7 @@
 // stored in LDS in the matching pair order, v_dot2c_f32_bf16 accumulates sum (128 + q_k) x_k in fp32; per 32-element
 // chunk   scale * (dot - 128 * sum x) + bias * sum x   is the group's exact affine form (fp32; sum x is computed once per
 // lane and chunk, shared by all rows).  No weight is ever rounded to bf16.
-#include "common.cuh"
+#include "common.hpp"
 #include "internal.h"
 #include "../../include/vlm_hip.h"
 

@@ -7,7 +7,7 @@
 // and once, after a prompt longer than the window, the survivors beyond the window are moved into the holes inside it.  One
 // launch moves a list of tokens in every layer; a token is Hkv x D keys in the [page][Hkv][D/8][64][8] pool (D/8 16-byte
 // pieces) and Hkv x D values in the [page][Hkv][D][64] pool (D 2-byte pieces 128 B apart) - kilobytes per step.
-#include "common.cuh"
+#include "common.hpp"
 #include "internal.h"
 #include "../../include/vlm_hip.h"
 

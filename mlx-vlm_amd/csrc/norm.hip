@@ -7,7 +7,7 @@
 //           nn.RMSNorm -> mx.fast.rms_norm
 //             (reference mlx_vlm/models/qwen2_vl/language.py:130-133,168)
 //           and the residual adds of language.py:151-153 (fused variant).
-#include "common.cuh"
+#include "common.hpp"
 #include "../../include/vlm_hip.h"
 
 namespace {

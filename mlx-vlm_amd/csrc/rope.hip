@@ -14,7 +14,7 @@
 //           64 keys of a page issues one contiguous 1 KiB load (lane = key)
 //   V pool: [page][Hkv][D][64 slots] - transposed, key slots in the k-slot order of the decode P.V MFMA
 //           (vlm_vslot), so a V^T operand fragment (d = lane&15, 8 key slots) is one 16-byte load
-#include "common.cuh"
+#include "common.hpp"
 #include "../../include/vlm_hip.h"
 
 namespace {

@@ -18,7 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "common.cuh"
+#include "common.hpp"
 #include "internal.h"
 #include "../../include/vlm_hip.h"
 

@@ -23,7 +23,7 @@ import torch
 from .._lib import h2d
 
 PAGE = 64
-# V key-slot order inside a page (csrc/common.cuh vlm_vslot): slot of token `w` of the page
+# V key-slot order inside a page (csrc/common.hpp vlm_vslot): slot of token `w` of the page
 VSLOT = [(w & 32) + 8 * (((w & 31) & 15) >> 2) + 4 * ((w & 31) >> 4) + (w & 3) for w in range(PAGE)]
 
 

@@ -54,7 +54,7 @@ __device__ __forceinline__ float dot8(u32x4_t w, u32x4_t x, float a) {
     a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w[i]), __builtin_bit_cast(bf16x2_t, x[i]), a, false);
   return a;
 }
-// wave-wide sum on the DPP data path (csrc/common.cuh: __shfl_xor is ds_bpermute, ~100 cycles per step - six dependent steps per
+// wave-wide sum on the DPP data path (csrc/common.hpp: __shfl_xor is ds_bpermute, ~100 cycles per step - six dependent steps per
 // reduction made the first version of this probe's consumers the bottleneck)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp(float old, float v) {

@@ -50,6 +50,11 @@ def test_headline_child_is_retried_and_one_line_is_printed(monkeypatch, capsys):
     assert "Memory access fault" in d["headline_attempts"]["failed"][0]["stderr_tail"]
     assert d["roofline_kernel"]["traffic"] == 55e6 and d["roofline_vit"]["workload"].startswith("64 x 336x336")
     assert abs(d["roofline_vit"]["frac"] - 1240.0 * bench.VIT_TFLOP_336 / 2500.0) < 1e-12
+    # the images/s half of the metric inside `roofline` (what the driver's record keeps whole), and a retry impossible to miss
+    assert d["roofline"]["vit"]["batch"] == 64 and abs(d["roofline"]["vit"]["frac"] - d["roofline_vit"]["frac"]) < 1e-12
+    assert d["roofline"]["vit_16"]["batch"] == 16 and abs(d["roofline"]["vit_16"]["images_per_s"] - 1150.0) < 1e-9
+    assert d["roofline"]["vit_single_448"]["batch"] == 1 and d["roofline"]["vit_single_448"]["images_per_s"] == 210.0
+    assert d["config"]["headline_retries"] == 1 and d["config"]["vit_batch"] == 64
     assert d["batch8_decode"] == {"generation_tps": 5800.0} and d["wide64_decode"] is None
     assert "[bench] headline: {" in err and "headline attempt 1 failed" in err
 

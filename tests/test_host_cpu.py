@@ -52,7 +52,7 @@ def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "mlx-vlm_amd")
     for dp, _, fs in os.walk(pkg):
         for f in fs:
-            if f.endswith((".py", ".hip", ".cuh", ".h")):
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dp, f)
 

@@ -17,7 +17,7 @@ import torch
 from oracle import ops as O
 from tests.helpers import bf16_close
 
-# V pool key-slot order inside a page (csrc/common.cuh vlm_vslot)
+# V pool key-slot order inside a page (csrc/common.hpp vlm_vslot)
 VSLOT = [(w & 32) + 8 * (((w & 31) & 15) >> 2) + 4 * ((w & 31) >> 4) + (w & 3) for w in range(64)]
 
 
