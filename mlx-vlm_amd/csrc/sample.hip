@@ -946,7 +946,8 @@ __global__ __launch_bounds__(1024) void sample_filter_kernel(const bf16_t* __res
 }
 
 // ------------------------------------------------------------------------------------------
-// top-p ALONE (the common nucleus sampler: make_sampler(temp, top_p)), a row split over SPLIT_G workgroups (round 5).  The
+// top-p (round 5) and, since round 6, any subset of top-p / min-p / top-k (make_sampler's common chain), a row split over SPLIT_G
+// workgroups.  The
 // one-workgroup kernel above spends 60 of its 88 us at V = 151,936 in four passes over the 300 KB row on ONE CU (copy, histogram,
 // ranks inside the crossing bin, mask) and 27 in 64-iteration loops of dependent LDS reads; here
 //   A  topp_hist_kernel   (G x B workgroups)  each slice counts its keys in a private LDS histogram and adds the non-empty bins to
@@ -1052,9 +1053,18 @@ __global__ __launch_bounds__(256) void topp_hist_kernel(const bf16_t* __restrict
   }
 }
 
+// Round 6: the launch also folds min-p (min_tokens_to_keep = 1) and top-k into the rule it leaves for the mask launch.  The three
+// filters run in the reference's order top-p -> min-p -> top-k (sample_utils.py:69-76), each on the row the previous one left, and each
+// is monotone in (value, then index): after any prefix of them the survivors are "every element above a key, plus a window of ranks
+// (index order) inside that key's bin".  So the chain is evaluated ON THE HISTOGRAM - top-p's crossing as before; min-p = the smallest
+// key whose value reaches T(max + T(log min_p)) (sample_utils.py:266-286); top-k = a descending count over the surviving bins
+// (sample_utils.py:169-175: ties at the k-th value keep the LOWEST indices of what is left of that bin) - and ctl carries the final
+// (key, [lo, hi)) for the count / mask launches.  Same survivors, bit for bit, as sample_filter_kernel's three passes over the row.
 __global__ __launch_bounds__(1024) void topp_cross_kernel(const uint32_t* __restrict__ hist_all, uint32_t* __restrict__ ctl_all,
-                                                          float thr) {
+                                                          float thr, int use_top_p, int use_min_p, float log_min_p, int top_k, int V) {
   __shared__ float scan_f[17];
+  __shared__ uint32_t scan_u2[17];
+  __shared__ uint32_t s_kmax, s_k2, s_keep2;
   __shared__ unsigned long long s_best;
   extern __shared__ uint32_t lh[];               // [LH_WORDS] the lower half of the merged histogram, padded as above
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -1085,10 +1095,10 @@ __global__ __launch_bounds__(1024) void topp_cross_kernel(const uint32_t* __rest
   float* pw = reinterpret_cast<float*>(lh + LH_WORDS);
   const uint32_t kmin = ctl[4] & ~63u, kmax = ctl[5] | 63u;      // whole 64-key blocks: a thread's keys are all inside or all outside
   const bool windowed = !any_pos && ctl[4] <= ctl[5] && kmax - kmin < (uint32_t)PW_MAX;
-  if (tid == 0) s_best = ~0ull;
+  if (tid == 0) { s_best = ~0ull; s_kmax = 0u; s_k2 = 65536u; s_keep2 = 0u; }
   __syncthreads();
   XST();
-  if (windowed) {
+  if (windowed && use_top_p) {
     for (uint32_t k = kmin + tid; k <= kmax; k += 1024) pw[k - kmin] = lh[k + (k >> 6)] ? rbf(expf(bf2f(key_bf(k)))) : 0.f;
     __syncthreads();
   }
@@ -1107,7 +1117,9 @@ __global__ __launch_bounds__(1024) void topp_cross_kernel(const uint32_t* __rest
   const bool mine = windowed && k0 >= kmin && k0 <= kmax;
   float mass = 0.f;
   XST();
-  if (windowed) {
+  if (!use_top_p) {
+    // (no nucleus filter in the chain: nothing to sum)
+  } else if (windowed) {
     if (mine) {
 #pragma unroll 1
       for (int j0 = 0; j0 < 64; j0 += 16) {
@@ -1129,7 +1141,7 @@ __global__ __launch_bounds__(1024) void topp_cross_kernel(const uint32_t* __rest
   float total;
   float cum = block_excl_scan<float>(mass, scan_f, &total);
   XST();
-  {
+  if (use_top_p) {
     const bool above = rbf(cum) > thr;
     auto cross_in_bin = [&](uint32_t k, uint32_t c, float pk, float base) {     // the smallest n with T(base + n pk) > thr, by bisection
       uint32_t lo_n = 1, hi_n = c;                        // invariant: n = hi_n crosses
@@ -1182,15 +1194,71 @@ __global__ __launch_bounds__(1024) void topp_cross_kernel(const uint32_t* __rest
   }
   __syncthreads();
   XST();
-  if (tid == 0) {
-    const unsigned long long best = s_best;
-    const uint32_t tk = best == ~0ull ? 65536u : (uint32_t)(best >> 32);
-    uint32_t c = 0, drop = 0;
-    if (tk < 65536u) {
-      c = tk < 0x8000u ? lh[tk + (tk >> 6)] : (any_pos ? hist[tk] : 0u);
-      drop = (uint32_t)(best & 0xffffffffu);              // ascending stable sort: the FIRST `drop` of the bin (index order) go
+  // The rule after top-p, in registers (every thread the same): key, window [lo, hi) of ranks inside its bin.  No nucleus filter /
+  // no crossing (the reference then removes EVERY token; a row of -inf has no sample: left unfiltered): key 0 with its whole bin =
+  // nothing is removed.
+  const unsigned long long best = s_best;
+  const bool crossed = use_top_p && best != ~0ull;
+  uint32_t r_key = crossed ? (uint32_t)(best >> 32) : 0u;
+  uint32_t r_lo = crossed ? (uint32_t)(best & 0xffffffffu) : 0u;       // ascending stable sort: the FIRST `lo` of the bin go
+  uint32_t r_hi = H(r_key);
+  // every finite value of the row has a key below 0x8000 and topp_hist_kernel left their exact range: the chain needs no search
+  const bool finite_neg = !any_pos && ctl[4] <= ctl[5];
+  const uint32_t f_lo = ctl[4], f_hi = ctl[5];
+  // what is left of bin k under the current rule
+  auto A = [&](uint32_t k) -> uint32_t { return k < r_key ? 0u : (k == r_key ? r_hi - r_lo : H(k)); };
+  if (use_min_p) {
+    // the row's maximum = the largest bin with a survivor (top-p never empties the top bin); thr = T(max + T(log(min_p))) is a
+    // T value: the smallest key whose value is not below it is the key of thr itself (-0 / +0: neither is below 0)
+    uint32_t top = f_hi;
+    if (!finite_neg) {
+      for (int j = 63; j >= 0; --j)
+        if (A(k0 + j)) { atomicMax(&s_kmax, k0 + j); break; }
+      __syncthreads();
+      top = s_kmax;
     }
-    ctl[0] = tk; ctl[1] = drop; ctl[2] = c;
+    const float thr_m = rbf(bf2f(key_bf(top)) + log_min_p);
+    if (thr_m == thr_m) {
+      const uint32_t km = thr_m == 0.f ? 0x7fffu : bf_key((bf16_t)(__float_as_uint(thr_m) >> 16));
+      if (km > r_key) { r_key = km; r_lo = 0u; r_hi = H(km); }
+    }
+  }
+  if (top_k > 0 && top_k < V) {
+    // descending count over what is left: thread t owns the 64 keys from kb + 63 down to kb (as the one-workgroup kernel).  In a
+    // finite_neg row only the blocks between the rule's key and the largest populated key can hold a survivor (the -inf bin can
+    // only be the k-th value when fewer than k tokens are left, where the filter removes nothing).
+    const uint32_t kb = (1023u - (uint32_t)tid) * 64u;
+    const bool live = !finite_neg || (kb + 63u >= max(r_key, f_lo) && kb <= f_hi);
+    uint32_t cnt = 0;
+    if (live) {
+#pragma unroll 16
+      for (int j = 0; j < 64; ++j) cnt += A(kb + 63u - j);
+    }
+    uint32_t tot_u;
+    uint32_t acc = block_excl_scan<uint32_t>(cnt, scan_u2, &tot_u);
+    if (live && acc < (uint32_t)top_k && acc + cnt >= (uint32_t)top_k) {
+      uint32_t found = 64u, keep = 0u;
+#pragma unroll 16
+      for (int j = 0; j < 64; ++j) {
+        const uint32_t c = A(kb + 63u - j);
+        const bool x = found == 64u && acc + c >= (uint32_t)top_k;
+        if (x) { found = (uint32_t)j; keep = (uint32_t)top_k - acc; }
+        acc += c;
+      }
+      s_k2 = kb + 63u - found; s_keep2 = keep;
+    }
+    __syncthreads();
+    const uint32_t k2 = s_k2, keep2 = s_keep2;
+    if (k2 < 65536u) {
+      // ties at the k-th value: the lowest indices of what is left of that bin
+      if (k2 == r_key) r_hi = r_lo + keep2;
+      else { r_key = k2; r_lo = 0u; r_hi = keep2; }
+    }
+  }
+  if (tid == 0) {
+    const uint32_t c = H(r_key);
+    ctl[0] = r_key; ctl[1] = r_lo; ctl[2] = c; ctl[6] = r_hi;
+    ctl[7] = (r_lo > 0u || r_hi < c) ? 1u : 0u;            // the bin is cut: the count / mask launches rank its elements
   }
 }
 
@@ -1206,9 +1274,9 @@ __global__ __launch_bounds__(256) void topp_count_kernel(const bf16_t* __restric
   __shared__ uint32_t red[4];
   const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   uint32_t* ctl = ctl_all + (size_t)b * ROW_W;
-  const uint32_t tk = ctl[0], drop = ctl[1];
+  const uint32_t tk = ctl[0];
   uint32_t cnt = 0;
-  if (tk < 65536u && drop > 0) {
+  if (ctl[7]) {
     const bf16_t* row = lp_in + (size_t)b * ld_in;
     const uint32_t tb = key_bf(tk);
     int c_lo, c_hi;
@@ -1240,8 +1308,8 @@ __global__ __launch_bounds__(256) void topp_mask_kernel(const bf16_t* __restrict
   uint32_t* ctl = ctl_all + (size_t)b * ROW_W;
   const bf16_t* row = lp_in + (size_t)b * ld_in;
   bf16_t* out = out_all + (size_t)b * ldo;
-  const uint32_t tk = ctl[0], drop = ctl[1];
-  const bool ranked = tk < 65536u && drop > 0;
+  const uint32_t tk = ctl[0], drop = ctl[1], keep_hi = ctl[6];      // elements of bin tk survive with rank in [drop, keep_hi)
+  const bool ranked = ctl[7] != 0u;
   const uint32_t tb = key_bf(min(tk, 65535u));
   int c_lo, c_hi;
   slice_bounds(V, s, c_lo, c_hi);
@@ -1280,7 +1348,7 @@ __global__ __launch_bounds__(256) void topp_mask_kernel(const bf16_t* __restrict
 #pragma unroll
       for (int e = 0; e < 8; ++e)
         if ((m >> e) & 1u) {
-          if (r < drop) wv[e >> 1] = (e & 1) ? (wv[e >> 1] & 0x0000ffffu) | ((uint32_t)NEG_INF_BF << 16) : (wv[e >> 1] & 0xffff0000u) | NEG_INF_BF;
+          if (r < drop || r >= keep_hi) wv[e >> 1] = (e & 1) ? (wv[e >> 1] & 0x0000ffffu) | ((uint32_t)NEG_INF_BF << 16) : (wv[e >> 1] & 0xffff0000u) | NEG_INF_BF;
           ++r;
         }
       rank += tot;
@@ -1453,9 +1521,11 @@ static int sample_ex_impl(const void* logits, int ld, int B, int V, void* logpro
   float* cand_v = ws + ROW_CV;
   int* cand_i = (int*)(ws + ROW_CI);
   uint32_t* hist = (uint32_t*)(ws + ROW_HIST);
-  // top-p alone over a 16-byte-aligned row of a real vocabulary: the row split over SPLIT_G workgroups
+  // top-p / min-p / top-k over a 16-byte-aligned row of a real vocabulary: the row split over SPLIT_G workgroups
   static const bool split_env = [] { const char* e = getenv("VLM_SAMPLE_SPLIT"); return !e || atoi(e) != 0; }();   // A/B knob
-  const bool split = temperature != 0.0 && split_env && (lp_given || logprobs) && k.use_top_p && !k.use_min_p && k.top_k == 0 && !(k.n_sigma > 0.f) && !k.p_less &&
+  // (round 6: any subset of top-p / min-p with min_tokens_to_keep = 1 / top-k - the chain is folded into the crossing launch)
+  const bool split = temperature != 0.0 && split_env && (lp_given || logprobs) && (k.use_top_p || k.use_min_p || (k.top_k > 0 && k.top_k < V)) &&
+                     (!k.use_min_p || k.min_keep == 1) && !(k.n_sigma > 0.f) && !k.p_less &&
                      !k.use_typical && !(k.xtc_prob > 0.f) && V % 8 == 0 && V >= 8192 && (lp_given ? ld : ldlp) % 8 == 0 && ldlp % 8 == 0 &&
                      ((uintptr_t)(lp_given ? logits : logprobs) & 15) == 0 && ((uintptr_t)scratch & 15) == 0;
   // ... and from logits: the log-prob pass runs inside the histogram launch (topp_hist_kernel<true>)
@@ -1497,7 +1567,8 @@ static int sample_ex_impl(const void* logits, int ld, int B, int V, void* logpro
         hipLaunchKernelGGL(topp_hist_kernel<false>, dim3(SPLIT_G, B), dim3(256), LDS, st, row_in, ld_in, V, hist, ctl,
                            (const float*)nullptr, (bf16_t*)nullptr, 0);
       VLM_CHECK_LAUNCH(); ++t_last_launches;
-      hipLaunchKernelGGL(topp_cross_kernel, dim3(B), dim3(1024), LDS_B, st, (const uint32_t*)hist, ctl, k.thr_top_p);
+      hipLaunchKernelGGL(topp_cross_kernel, dim3(B), dim3(1024), LDS_B, st, (const uint32_t*)hist, ctl, k.thr_top_p, k.use_top_p, k.use_min_p,
+                         k.log_min_p, k.top_k, V);
       VLM_CHECK_LAUNCH(); ++t_last_launches;
       hipLaunchKernelGGL(topp_count_kernel, dim3(SPLIT_G, B), dim3(256), 0, st, row_in, ld_in, V, ctl);
       VLM_CHECK_LAUNCH(); ++t_last_launches;

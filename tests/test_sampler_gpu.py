@@ -305,7 +305,8 @@ def _split_logit_cases():
     holes = (torch.randn(2, 32768, generator=g) * 2.0).to(BF)
     holes[:, 5::7] = float("-inf")
     return [("logits_v151936_p0.9", big, dict(top_p=0.9)), ("logits_v151936_p0.3", big, dict(top_p=0.3, temp=1.3, seed=5, step=9)),
-            ("logits_holes", holes, dict(top_p=0.8))]
+            ("logits_holes", holes, dict(top_p=0.8)), ("logits_chain", big, dict(top_p=0.9, min_p=0.02, top_k=50)),
+            ("logits_holes_chain", holes, dict(min_p=0.05, top_k=11))]
 
 
 def _from_logits(vops, logits, temp=0.8, seed=11, step=0, **kw):
@@ -316,7 +317,7 @@ def _from_logits(vops, logits, temp=0.8, seed=11, step=0, **kw):
 
 
 def _split_cases():
-    """rows for the split top-p path (csrc/sample.hip: top-p alone, V % 8 == 0, V >= 8192): random rows at three temperatures of
+    """rows for the split path (csrc/sample.hip: top-p / min-p / top-k, V % 8 == 0, V >= 8192): random rows at three temperatures of
     the distribution, a row of exact ties (hundreds of elements share the crossing key: the rank inside the bin decides), a row
     with removed (-inf) tokens, rows with positive values (the global half of the histogram), a top_p so small that nothing
     crosses, a 3-row call (one launch, three rows)"""
@@ -334,6 +335,23 @@ def _split_cases():
     pos[1] = (pos[1].float() - 10.5).to(BF)
     cases.append(("positive", pos, dict(top_p=0.9)))
     cases.append(("no_crossing", _rows(1, 16384, seed=3), dict(top_p=0.001)))
+    # round 6: the chain top-p -> min-p -> top-k folded into the crossing launch (any subset, min_tokens_to_keep = 1)
+    cases.append(("chain", lp, dict(top_p=0.9, min_p=0.02, top_k=50)))
+    cases.append(("chain_small_k", lp, dict(top_p=0.95, min_p=0.001, top_k=3)))
+    cases.append(("min_p", lp, dict(min_p=0.05)))
+    cases.append(("top_k", lp, dict(top_k=40)))
+    cases.append(("min_p_top_k", lp, dict(min_p=0.01, top_k=1000)))
+    cases.append(("top_p_top_k", lp, dict(top_p=0.5, top_k=7)))
+    tl = (ties - torch.logsumexp(ties, -1, keepdim=True)).to(BF)
+    for k in (1, 100, 1000, 5000, 30000):                  # the k-th value inside bins of hundreds: top-p's bin, another, none
+        cases.append((f"ties_chain_k{k}", tl, dict(top_p=0.8, min_p=0.1, top_k=k)))
+        cases.append((f"ties_top_k{k}", tl, dict(top_k=k)))
+    cases.append(("ties_min_p", tl, dict(min_p=0.3, top_p=0.99)))
+    cases.append(("holes_k_beyond", holes, dict(top_k=30000)))      # more than the finite tokens: nothing to remove
+    cases.append(("holes_chain", holes, dict(top_p=0.7, min_p=0.05, top_k=20)))
+    cases.append(("positive_chain", pos, dict(top_p=0.9, min_p=0.02, top_k=64)))
+    cases.append(("positive_min_p", pos, dict(min_p=0.1)))
+    cases.append(("no_crossing_chain", _rows(1, 16384, seed=3), dict(top_p=0.001, min_p=0.05, top_k=9)))
     return cases
 
 
@@ -366,7 +384,7 @@ def test_split_top_p_equals_the_one_workgroup_kernel(vops, tmp_path):
     ws = vops.sample_workspace(2, "cuda")
     st = torch.zeros(1, dtype=torch.int32, device="cuda")
     outs = []
-    for kw in (dict(top_p=0.9), dict(top_k=33), dict(top_p=0.9), dict(top_p=0.9)):
+    for kw in (dict(top_p=0.9), dict(top_k=33, min_p=0.01, min_tokens_to_keep=2), dict(top_p=0.9), dict(top_p=0.9)):
         _, _, filt = vops.sample(pos, temperature=0.8, seed=11, step=st, want_logprobs=False, input_is_logprobs=True,
                                  return_filtered=True, ws=ws, **kw)
         outs.append(filt.clone())
@@ -399,7 +417,7 @@ def test_split_top_p_on_a_workspace_stepped_at_changing_widths(vops):
         assert torch.equal(tok, want[0]), rows
         assert torch.equal(filt.view(torch.int16), want[1].view(torch.int16)), rows
         # another filter combination at another width in between (sample_filter_kernel: its own use of the histogram words)
-        vops.sample(lp8[:6], ws=ws, **dict(kw, top_p=1.0, top_k=17))
+        vops.sample(lp8[:6], ws=ws, **dict(kw, top_p=1.0, top_k=17, min_p=0.01, min_tokens_to_keep=2))
     torch.cuda.synchronize()
     kept = (want4[1].float() > -float("inf")).sum(-1)
     assert int(kept.min()) >= 1 and int(kept.max()) < 32768      # top-p did filter (the failure mode was: silently not applied)
