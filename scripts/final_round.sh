@@ -10,5 +10,5 @@ timeout 420 python $R/bench.py --steps 3 --warmup 1 > $O/bench_$TAG.log 2> $O/be
 python $R/scripts/prof_summary.py $(find /tmp/p1 -name "*.db" | head -1) $O/${TAG}_bench_kernel_stats.txt > /dev/null 2>&1
 (cd /tmp && rm -rf /tmp/p2 && timeout 250 rocprofv3 --kernel-trace --stats -d /tmp/p2 -o v -- python $R/scripts/vit_prof.py 16 > $O/vitprof_$TAG.log 2>&1); echo "vitprof rc=$?"
 python $R/scripts/prof_summary.py $(find /tmp/p2 -name "*.db" | head -1) $O/${TAG}_vit16_kernel_stats.txt > /dev/null 2>&1
-(cd /tmp && rm -rf /tmp/p3 && timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE WRITE_SIZE -d /tmp/p3 -o c -- python $R/bench.py --steps 1 --warmup 0 --max-tokens 24 --no-cpu-baseline --no-extras > $O/pmc_$TAG.log 2>&1); echo "pmc rc=$?"
-python $R/scripts/pmc_summary.py $(find /tmp/p3 -name "*.db" | head -1) $O/${TAG}_pmc_traffic.json 2>&1 | head -12
+# FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950 (and the refused run hangs until its timeout): one pass each
+bash $R/scripts/r06/evidence_pmc.sh
