@@ -226,6 +226,17 @@ static int lin_gemm(Llm* m, const void* A, const void* W, const void* Wsb, const
   }
   return vlm_gemm_bf16(A, W, bias, res, C, M, N, K, K, K, ldc, ldres, epi, stream);
 }
+// lin_gemm whose split-K reduce launch may carry the caller's next launch (VlmGemmTail, internal.h): *done = 1 when it did
+static int lin_gemm_tail(Llm* m, const void* A, const void* W, const void* Wsb, const void* bias, const void* res, void* C, int M,
+                         int N, int K, int ldc, int ldres, int epi, const VlmGemmTail* tail, int* done, void* stream) {
+  static const bool off = [] { const char* e = getenv("VLM_WIDE_TAILS"); return e && atoi(e) == 0; }();   // A/B knob
+  *done = 0;
+  if (off) return lin_gemm(m, A, W, Wsb, bias, res, C, M, N, K, ldc, ldres, epi, stream);
+  if (Wsb && M <= 2048 && K % 64 == 0)
+    return vlm_gemm_w4_tail(A, W, Wsb, bias, res, C, M, N, K, K, ldc, ldres, epi, tail, done, stream);
+  if (Wsb) return lin_gemm(m, A, W, Wsb, bias, res, C, M, N, K, ldc, ldres, epi, stream);
+  return vlm_gemm_bf16_tail(A, W, bias, res, C, M, N, K, K, K, ldc, ldres, epi, tail, done, stream);
+}
 // decode: y = epi(x . W^T) for B rows
 static int lin_gemv(Llm* m, const void* x, const void* W, const void* Wsb, const void* bias, const void* res, const void* norm_w,
                     void* y, int B, int N, int K, int ldy, int ldres, float eps, int epi, void* stream) {
@@ -307,6 +318,7 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
   const bool wide = B > 16;
   if (wide && (!m->kv.block_table || Hq * hd < D || B > 64)) return 1;
   void* const xn = a->attn;
+  bool xn_ready = false;      // wide steps: xn already holds RMSNorm(h) of the coming layer (the previous down GEMM's reduce launch wrote it)
   int n = 0;
   // h = embed[tok]
   if (!fused_flag) {
@@ -322,11 +334,24 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
     void* vp = off(m->kv.vpool, (size_t)i * m->kv.layer_stride * 2);
     // [RMSNorm + qkv GEMV + bias + M-RoPE at pos[b] + k/v write at slot ctx[b]] in one launch
     if (wide) {
-      TRY(vlm_rmsnorm_residual(a->h, nullptr, w.ln1_w, xn, nullptr, B, D, c.rms_eps, stream));
-      TRY(lin_gemm(m, xn, w.wqkv, w.wqkv_sb, w.bqkv, nullptr, a->qkv, B, QKV, D, QKV, 0, VLM_EPI_BIAS, stream));
-      TRY(vlm_mrope_kvwrite_decode(a->qkv, QKV, B, Hq, Hkv, hd, a->pos, m->g.inv_freq, c.mrope_sec0, c.mrope_sec1, a->ctx,
-                                   m->kv.block_table, m->kv.max_pages, kp, vp, qk_scale, c.rope_long_from, stream));
-      n += 3;
+      // (round 6) the three small GEMMs of a wide layer are split-K: their reduce launches also do the launch that would read
+      // the reduced rows straight back - M-RoPE + KV write here, RMSNorm(ln2) after o_proj, the NEXT layer's RMSNorm(ln1) (or
+      // the final norm) after down.  Same values (csrc/gemm_bf16.hip); a GEMM that does not take the split-K route reports
+      // done = 0 and the follower is launched as before.
+      if (!xn_ready) { TRY(vlm_rmsnorm_residual(a->h, nullptr, w.ln1_w, xn, nullptr, B, D, c.rms_eps, stream)); ++n; }
+      VlmGemmTail rt{};
+      rt.kind = VLM_TAIL_ROPE_KV;
+      rt.Hq = Hq; rt.Hkv = Hkv; rt.D = hd;
+      rt.pos = (const int*)a->pos; rt.inv_freq = (const float*)m->g.inv_freq; rt.slot = (const int*)a->ctx;
+      rt.block_table = (const int*)m->kv.block_table; rt.max_pages = m->kv.max_pages;
+      rt.kpool = (unsigned short*)kp; rt.vpool = (unsigned short*)vp; rt.qk_scale = qk_scale; rt.long_from = c.rope_long_from;
+      int done = 0;
+      TRY(lin_gemm_tail(m, xn, w.wqkv, w.wqkv_sb, w.bqkv, nullptr, a->qkv, B, QKV, D, QKV, 0, w.bqkv ? VLM_EPI_BIAS : VLM_EPI_NONE,
+                        &rt, &done, stream)); ++n;
+      if (!done) {
+        TRY(vlm_mrope_kvwrite_decode(a->qkv, QKV, B, Hq, Hkv, hd, a->pos, m->g.inv_freq, c.mrope_sec0, c.mrope_sec1, a->ctx,
+                                     m->kv.block_table, m->kv.max_pages, kp, vp, qk_scale, c.rope_long_from, stream)); ++n;
+      }
     } else if (w.wqkv_sb) {
       TRY(vlm_gemv_w4_qkv_rope_kvwrite_ex(a->h, w.ln1_w, c.rms_eps, w.wqkv, w.wqkv_sb, w.bqkv, a->qkv, QKV, B, D, Hq, Hkv, hd, a->pos,
                                           a->ctx, m->g.inv_freq, m->kv.block_table, m->kv.max_pages, kp, vp, m->tune.mfma_gemv,
@@ -383,11 +408,16 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
                                 stream)); ++n;
     }
     if (wide) {
-      TRY(lin_gemm(m, a->attn, w.wo, w.wo_sb, nullptr, a->h, a->h, B, D, Hq * hd, D, D, VLM_EPI_RESIDUAL, stream));
-      TRY(vlm_rmsnorm_residual(a->h, nullptr, w.ln2_w, xn, nullptr, B, D, c.rms_eps, stream));
-      TRY(lin_gemm(m, xn, w.wgu, w.wgu_sb, nullptr, nullptr, a->act, B, 2 * c.inter, D, c.inter, 0, VLM_EPI_SWIGLU, stream));
-      TRY(lin_gemm(m, a->act, w.wdown, w.wdown_sb, nullptr, a->h, a->h, B, D, c.inter, D, D, VLM_EPI_RESIDUAL, stream));
-      n += 4;
+      VlmGemmTail nt{};
+      nt.kind = VLM_TAIL_RMSNORM;
+      nt.norm_w = w.ln2_w; nt.eps = c.rms_eps; nt.xn = xn; nt.ldxn = D;
+      int done = 0;
+      TRY(lin_gemm_tail(m, a->attn, w.wo, w.wo_sb, nullptr, a->h, a->h, B, D, Hq * hd, D, D, VLM_EPI_RESIDUAL, &nt, &done, stream)); ++n;
+      if (!done) { TRY(vlm_rmsnorm_residual(a->h, nullptr, w.ln2_w, xn, nullptr, B, D, c.rms_eps, stream)); ++n; }
+      TRY(lin_gemm(m, xn, w.wgu, w.wgu_sb, nullptr, nullptr, a->act, B, 2 * c.inter, D, c.inter, 0, VLM_EPI_SWIGLU, stream)); ++n;
+      nt.norm_w = i + 1 < NL ? m->layers[i + 1].ln1_w : m->g.final_norm_w;
+      TRY(lin_gemm_tail(m, a->act, w.wdown, w.wdown_sb, nullptr, a->h, a->h, B, D, c.inter, D, D, VLM_EPI_RESIDUAL, &nt, &done, stream)); ++n;
+      xn_ready = done != 0;
       continue;
     }
     if (merge_in_oproj) {
@@ -417,9 +447,8 @@ static int decode_impl(Llm* m, const vlm_decode_args* a, void* stream, int* laun
   const int VL = (c.vocab + 7) & ~7;      // row pitch of logits / logprobs / scratch (see vlm_llm_prefill)
   if (wide) {
     // (the head matrix has VL rows: the loader pads a vocabulary that is not a multiple of 8 with zero rows, as in the prefill)
-    TRY(vlm_rmsnorm_residual(a->h, nullptr, m->g.final_norm_w, xn, nullptr, B, D, c.rms_eps, stream));
-    TRY(lin_gemm(m, xn, m->g.lm_head, m->g.lm_head_sb, nullptr, nullptr, a->logits, B, VL, D, VL, 0, VLM_EPI_NONE, stream));
-    n += 2;
+    if (!xn_ready) { TRY(vlm_rmsnorm_residual(a->h, nullptr, m->g.final_norm_w, xn, nullptr, B, D, c.rms_eps, stream)); ++n; }
+    TRY(lin_gemm(m, xn, m->g.lm_head, m->g.lm_head_sb, nullptr, nullptr, a->logits, B, VL, D, VL, 0, VLM_EPI_NONE, stream)); ++n;
   } else {
     TRY(lin_gemv(m, a->h, m->g.lm_head, m->g.lm_head_sb, nullptr, nullptr, m->g.final_norm_w, a->logits, B, c.vocab, D, VL, 0,
                  c.rms_eps, VLM_EPI_NONE, stream)); ++n;
@@ -460,7 +489,7 @@ extern "C" int vlm_llm_decode_step(void* handle, const vlm_decode_args* a, void*
 extern "C" int vlm_llm_decode_forward(void* handle, const vlm_decode_args* a, void* stream) {
   Llm* m = static_cast<Llm*>(handle);
   if (!m || !a || a->B <= 0 || !m->kv.kpool) return 1;
-  return decode_impl(m, a, stream, nullptr, false);
+  return decode_impl(m, a, stream, &m->launches, false);
 }
 
 extern "C" int vlm_llm_decode_graph_build(void* handle, const vlm_decode_args* a, void* stream) {

@@ -364,6 +364,227 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   *reinterpret_cast<uint4*>(C + (size_t)m * ldc + n) = u;
 }
 
+// the fp32 partials of TWO 8-wide chunks (row m, columns n0.. and n1..) summed over the splits in the fixed order 0 .. splits - 1
+// (splitk_reduce_kernel's sum), with every load of both chunks issued before the first add: up to 8 splits x 2 chunks x 32 bytes
+// in flight per thread instead of one dependent round trip per split
+__device__ __forceinline__ void reduce_two_chunks(const float* __restrict__ part, int splits, int M, int N, int m, int n0, int n1,
+                                                  float (&v0)[8], float (&v1)[8]) {
+  // (ext_vector loads from a CLAMPED split index, the absent splits' values replaced by +0 afterwards: written with float4 and
+  // a conditional load, hipcc emitted one dword load + branch per element)
+  f32x4_t a0[8], b0[8], a1[8], b1[8];
+#pragma unroll
+  for (int sp = 0; sp < 8; ++sp) {
+    const size_t base = ((size_t)min(sp, splits - 1) * M + m) * N;
+    const f32x4_t* p0 = reinterpret_cast<const f32x4_t*>(part + base + n0);
+    const f32x4_t* p1 = reinterpret_cast<const f32x4_t*>(part + base + n1);
+    a0[sp] = p0[0]; b0[sp] = p0[1];
+    a1[sp] = p1[0]; b1[sp] = p1[1];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { v0[j] = 0.f; v1[j] = 0.f; }
+#pragma unroll
+  for (int sp = 0; sp < 8; ++sp) {
+    if (sp < splits) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v0[j] += a0[sp][j]; v0[4 + j] += b0[sp][j]; v1[j] += a1[sp][j]; v1[4 + j] += b1[sp][j]; }
+    }
+  }
+  for (int sp = 8; sp < splits; ++sp) {                    // (only the forced-split test hook goes past 8)
+    const f32x4_t* p0 = reinterpret_cast<const f32x4_t*>(part + ((size_t)sp * M + m) * N + n0);
+    const f32x4_t* p1 = reinterpret_cast<const f32x4_t*>(part + ((size_t)sp * M + m) * N + n1);
+    const f32x4_t a = p0[0], bq = p0[1], c = p1[0], d = p1[1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v0[j] += a[j]; v0[4 + j] += bq[j]; v1[j] += c[j]; v1[4 + j] += d[j]; }
+  }
+}
+
+// ---- split-K reduce launches that also do the NEXT launch's work (round 6: the wide decode steps, csrc/engine.hip).  A layer of a
+// 17..64-row step is the prefill's launch sequence; its three small GEMMs (qkv, o_proj, down) are split-K, so each is already
+// followed by a reduce launch - and then by a launch that reads the reduced rows straight back: RMSNorm (after o_proj and after
+// down) or M-RoPE + KV write (after qkv).  These kernels are the reduce AND that follower, arithmetic and order of both kept
+// (the reduce's fixed split order, bias, one rounding to bf16, residual in bf16; then the follower on the rounded values), so
+// the rows they write equal the two-launch sequence bit for bit (tests/test_ops_gpu.py).  6.7 + 6.7 + 6.3 us of 152 per 7B layer.
+
+// reduce + epilogue -> C, then y = w * T(h * rsqrt(mean(h^2) + eps)) of the row just written (rmsnorm_kernel of norm.hip: one
+// wave per row there, lane -> chunks lane + 64 i, one running sum of squares in (i, j) order, wave_sum).  Here a row has the whole
+// workgroup: wave w reduces chunks i = w, w + 4 (the loads are the cost), the rounded row meets in LDS, then EVERY wave takes the
+// sum of squares over ALL chunks in that same order - the same inv in all four - and normalises its own chunks.
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __restrict__ part, int splits,
+                                                                 const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                                 bf16_t* __restrict__ C, int M, int N, int ldc, int ldres,
+                                                                 const bf16_t* __restrict__ norm_w, float eps,
+                                                                 bf16_t* __restrict__ xn, int ldxn) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* rowbuf = reinterpret_cast<uint4*>(smem);                 // the row as written to C: N / 8 chunks of 8 bf16
+  const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nchunk = N >> 3;
+  // this wave's chunks: i = wave and wave + 4 (N <= 4096: at most two); a lane past the row's end reduces chunk 0 again, unused
+  const int c0 = lane + wave * 64, c1 = lane + (wave + 4) * 64;
+  const bool in0 = c0 < nchunk, in1 = c1 < nchunk;
+  uint4 mine[2];
+  {
+    float v[2][8];
+    reduce_two_chunks(part, splits, M, N, m, in0 ? c0 * 8 : 0, in1 ? c1 * 8 : 0, v[0], v[1]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c = q ? c1 : c0, n = c * 8;
+      if (!(q ? in1 : in0)) continue;
+      if (EPI & VLM_EPI_BIAS) {
+        const uint4 bb = *reinterpret_cast<const uint4*>(bias + n);
+        v[q][0] += bf_lo(bb.x); v[q][1] += bf_hi(bb.x); v[q][2] += bf_lo(bb.y); v[q][3] += bf_hi(bb.y);
+        v[q][4] += bf_lo(bb.z); v[q][5] += bf_hi(bb.z); v[q][6] += bf_lo(bb.w); v[q][7] += bf_hi(bb.w);
+      }
+      uint4 u;
+      u.x = pack_bf2(v[q][0], v[q][1]); u.y = pack_bf2(v[q][2], v[q][3]); u.z = pack_bf2(v[q][4], v[q][5]); u.w = pack_bf2(v[q][6], v[q][7]);
+      if (EPI & VLM_EPI_RESIDUAL) {
+        const uint4 r = *reinterpret_cast<const uint4*>(res + (size_t)m * ldres + n);
+        u.x = pack_bf2(bf_lo(u.x) + bf_lo(r.x), bf_hi(u.x) + bf_hi(r.x));
+        u.y = pack_bf2(bf_lo(u.y) + bf_lo(r.y), bf_hi(u.y) + bf_hi(r.y));
+        u.z = pack_bf2(bf_lo(u.z) + bf_lo(r.z), bf_hi(u.z) + bf_hi(r.z));
+        u.w = pack_bf2(bf_lo(u.w) + bf_lo(r.w), bf_hi(u.w) + bf_hi(r.w));
+      }
+      *reinterpret_cast<uint4*>(C + (size_t)m * ldc + n) = u;
+      rowbuf[c] = u;
+      mine[q] = u;
+    }
+  }
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i * 64 < nchunk; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+      const uint4 u = rowbuf[c];
+      const float f[8] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y), bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += f[j] * f[j];
+    }
+  }
+  const float inv = rsqrtf(wave_sum(s) / (float)N + eps);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int c = q ? c1 : c0;
+    if (!(q ? in1 : in0)) continue;
+    const uint4 u = mine[q], wu = reinterpret_cast<const uint4*>(norm_w)[c];
+    const float f[8] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y), bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
+    const float wv[8] = {bf_lo(wu.x), bf_hi(wu.x), bf_lo(wu.y), bf_hi(wu.y), bf_lo(wu.z), bf_hi(wu.z), bf_lo(wu.w), bf_hi(wu.w)};
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = wv[j] * rbf(f[j] * inv);
+    uint4 o;
+    o.x = pack_bf2(r[0], r[1]); o.y = pack_bf2(r[2], r[3]); o.z = pack_bf2(r[4], r[5]); o.w = pack_bf2(r[6], r[7]);
+    *reinterpret_cast<uint4*>(xn + (size_t)m * ldxn + c * 8) = o;
+  }
+}
+
+// reduce + bias -> the qkv rows, rotated (q, k) and written to the paged cache (k, v): mrope_kvwrite_kernel of rope.hip in its decode
+// form (row b = one token at text position pos[b], slot[b] of block-table row b) on the values the reduce would have stored.
+// One thread = one 8-wide chunk of the low half of a q / k head + its partner in the high half, or one chunk of a v head.
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_rope_kernel(const float* __restrict__ part, int splits,
+                                                                 const bf16_t* __restrict__ bias, bf16_t* __restrict__ C, int M,
+                                                                 int N, int ldc, const VlmGemmTail t) {
+  const int D = t.D, Hq = t.Hq, Hkv = t.Hkv, half = D >> 1, cph = half >> 3;
+  const float* inv_freq = t.inv_freq;
+  if (t.long_from > 0) {
+    bool any_long = false;
+    for (int r = 0; r < M; ++r) any_long |= t.slot[r] >= t.long_from;
+    if (any_long) inv_freq += half;
+  }
+  const int rot_items = (Hq + Hkv) * cph, v_items = Hkv * (D >> 3), per_tok = rot_items + v_items;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)M * per_tok) return;
+  const int tok = (int)(idx / per_tok), it = (int)(idx % per_tok);
+  auto finish = [&](float (&v)[8], int n) -> uint4 {       // what splitk_reduce_kernel<EPI> stores at (tok, n .. n + 7)
+    if (EPI & VLM_EPI_BIAS) {
+      const uint4 b = *reinterpret_cast<const uint4*>(bias + n);
+      v[0] += bf_lo(b.x); v[1] += bf_hi(b.x); v[2] += bf_lo(b.y); v[3] += bf_hi(b.y);
+      v[4] += bf_lo(b.z); v[5] += bf_hi(b.z); v[6] += bf_lo(b.w); v[7] += bf_hi(b.w);
+    }
+    uint4 u;
+    u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
+    return u;
+  };
+  bf16_t* row = C + (size_t)tok * ldc;
+  const int slot = t.slot[tok];
+  const long page = t.block_table[(size_t)tok * t.max_pages + (slot >> 6)];
+  const int within = slot & 63;
+  if (it < rot_items) {
+    const int head = it / cph, c = it % cph;
+    const int n = head * D + c * 8;
+    float va[8], vb[8];
+    reduce_two_chunks(part, splits, M, N, tok, n, n + half, va, vb);
+    const uint4 ua = finish(va, n), ub = finish(vb, n + half);
+    const float a[8] = {bf_lo(ua.x), bf_hi(ua.x), bf_lo(ua.y), bf_hi(ua.y), bf_lo(ua.z), bf_hi(ua.z), bf_lo(ua.w), bf_hi(ua.w)};
+    const float b[8] = {bf_lo(ub.x), bf_hi(ub.x), bf_lo(ub.y), bf_hi(ub.y), bf_lo(ub.z), bf_hi(ub.z), bf_lo(ub.w), bf_hi(ub.w)};
+    float oa[8], ob[8];
+    const float p = (float)t.pos[tok];                     // decode rows: all three M-RoPE axes at the text position
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f = c * 8 + j;
+      const float ang = p * inv_freq[f];
+      float sn, co;
+      sincosf(ang, &sn, &co);
+      const float za = rbf(a[j] * t.qk_scale), zb = rbf(b[j] * t.qk_scale);
+      oa[j] = za * co - zb * sn;
+      ob[j] = zb * co + za * sn;
+    }
+    uint4 lo, hi;
+    lo.x = pack_bf2(oa[0], oa[1]); lo.y = pack_bf2(oa[2], oa[3]); lo.z = pack_bf2(oa[4], oa[5]); lo.w = pack_bf2(oa[6], oa[7]);
+    hi.x = pack_bf2(ob[0], ob[1]); hi.y = pack_bf2(ob[2], ob[3]); hi.z = pack_bf2(ob[4], ob[5]); hi.w = pack_bf2(ob[6], ob[7]);
+    *reinterpret_cast<uint4*>(row + n) = lo;
+    *reinterpret_cast<uint4*>(row + n + half) = hi;
+    if (head >= Hq) {
+      const int g = head - Hq;
+      const size_t kb = ((size_t)page * Hkv + g) * (size_t)(D >> 3);
+      *reinterpret_cast<uint4*>(t.kpool + ((kb + c) * 64 + within) * 8) = lo;
+      *reinterpret_cast<uint4*>(t.kpool + ((kb + c + cph) * 64 + within) * 8) = hi;
+    }
+  } else {
+    const int vi = it - rot_items;
+    const int g = vi / (D >> 3), c = vi % (D >> 3);
+    const int n = (Hq + Hkv + g) * D + c * 8;
+    float va[8], vdup[8];
+    reduce_two_chunks(part, splits, M, N, tok, n, n, va, vdup);      // (one chunk: the second slot re-reads it)
+    const uint4 v = finish(va, n);
+    *reinterpret_cast<uint4*>(row + n) = v;
+    bf16_t* vb = t.vpool + (((size_t)page * Hkv + g) * D + c * 8) * 64 + vlm_vslot(within);   // [D][64 slots]
+    vb[0 * 64] = (bf16_t)(v.x & 0xffffu); vb[1 * 64] = (bf16_t)(v.x >> 16);
+    vb[2 * 64] = (bf16_t)(v.y & 0xffffu); vb[3 * 64] = (bf16_t)(v.y >> 16);
+    vb[4 * 64] = (bf16_t)(v.z & 0xffffu); vb[5 * 64] = (bf16_t)(v.z >> 16);
+    vb[6 * 64] = (bf16_t)(v.w & 0xffffu); vb[7 * 64] = (bf16_t)(v.w >> 16);
+  }
+}
+
+// The tail request of the calling thread's next split-K GEMM (vlm_gemm_bf16_tail / vlm_gemm_w4_tail set and clear it around
+// gemm_dispatch: the templates between the entry point and the reduce launch stay as they are).
+thread_local const VlmGemmTail* t_tail = nullptr;
+thread_local bool t_tail_done = false;
+
+// the reduce launch of a split-K GEMM: the plain one, or - when the caller asked for a tail this launch can carry - the fused one
+template <int EPI>
+void launch_reduce(const float* ws, int splits, const void* bias, const void* res, void* C, int M, int N, int ldc, int ldres,
+                   hipStream_t st) {
+  const VlmGemmTail* t = t_tail;
+  if (t && !(EPI & (VLM_EPI_GELU_FAST | VLM_EPI_GELU_ERF | VLM_EPI_SWIGLU | VLM_EPI_ROPE2D))) {
+    if (t->kind == VLM_TAIL_RMSNORM && N <= 4096 && t->norm_w && t->xn && t->ldxn % 8 == 0) {
+      hipLaunchKernelGGL((splitk_reduce_norm_kernel<EPI>), dim3(M), dim3(256), (size_t)N * 2, st, ws, splits, (const bf16_t*)bias,
+                         (const bf16_t*)res, (bf16_t*)C, M, N, ldc, ldres, (const bf16_t*)t->norm_w, t->eps, (bf16_t*)t->xn, t->ldxn);
+      t_tail_done = true;
+      return;
+    }
+    if (t->kind == VLM_TAIL_ROPE_KV && !(EPI & VLM_EPI_RESIDUAL) && M <= 64 && t->D % 16 == 0 && N == (t->Hq + 2 * t->Hkv) * t->D) {
+      const long total = (long)M * ((t->Hq + t->Hkv) * (t->D / 16) + t->Hkv * (t->D / 8));
+      hipLaunchKernelGGL((splitk_reduce_rope_kernel<EPI>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, splits,
+                         (const bf16_t*)bias, (bf16_t*)C, M, N, ldc, *t);
+      t_tail_done = true;
+      return;
+    }
+  }
+  const long items = (long)M * (N >> 3);
+  hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, ws, splits,
+                     (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, ldc, ldres);
+}
+
 // per-process fp32 workspace of the split-K path (grown on demand; never (re)allocated while the stream is capturing)
 // Split-K partials: one workspace PER STREAM (a prefill on a side stream may run under another one), sized once for
 // everything the automatic policy can ask for: split-K is taken only when M*N < 256 tiles of 64x64 = 2^20 outputs and
@@ -379,6 +600,7 @@ constexpr size_t SPLITK_WS_BYTES = 34u << 20;
 constexpr int MAX_SPLITK_WS = 8;
 SplitkWs g_splitk_ws[MAX_SPLITK_WS];
 int g_n_splitk_ws = 0;
+const bool g_skinny64 = [] { const char* e = getenv("VLM_GEMM_SKINNY64"); return !e || atoi(e) != 0; }();   // A/B knob: 0 = the tile policy of rounds 1-5
 int g_splitk = 0;   // 0 = automatic, -1 = never (vlm_gemm_set_staging mode 8), n > 1 = forced split count (test hook, 9: 4)
 
 float* splitk_workspace(size_t bytes, hipStream_t st) {
@@ -446,9 +668,7 @@ int launch_splitk(const void* A, const void* W, const void* bias, const void* re
   hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, VLM_EPI_NONE, true, true>), dim3(nwg, splits), dim3(256), lds, st,
                      (const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
                      reinterpret_cast<bf16_t*>(ws), M, N, K, lda, ldw, N, 0, tiles_n, nwg, kchunk);
-  const long items = (long)M * (N >> 3);
-  hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
-                     (const float*)ws, splits, (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, ldc, ldres);
+  launch_reduce<EPI>((const float*)ws, splits, bias, res, C, M, N, ldc, ldres, st);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
 }
@@ -475,9 +695,7 @@ int launch_splitk_w4(const void* A, const void* Wq, const void* Wsb, const void*
   hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, VLM_EPI_NONE, false, true, true>), dim3(nwg, splits), dim3(256), lds, st,
                      (const bf16_t*)A, (const bf16_t*)Wq, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
                      reinterpret_cast<bf16_t*>(ws), M, N, K, lda, K, N, 0, tiles_n, nwg, kchunk, (const unsigned*)Wsb);
-  const long items = (long)M * (N >> 3);
-  hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st,
-                     (const float*)ws, splits, (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, ldc, ldres);
+  launch_reduce<EPI>((const float*)ws, splits, bias, res, C, M, N, ldc, ldres, st);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e;
 }
@@ -508,6 +726,7 @@ int launch_epi_w4(const void* A, const void* Wq, const void* Wsb, const void* bi
         return launch_splitk_w4<EPI>(A, Wq, Wsb, bias, res, C, M, N, K, lda, ldc, ldres, splits, ws, st);
     }
   }
+  if (M <= 64 && g_skinny64) return launch_cfg_w4<64, 64, EPI>(A, Wq, Wsb, bias, res, C, M, N, K, lda, ldc, ldres, st);   // (see launch_epi)
   if (t128 >= 200) return launch_cfg_w4<128, 128, EPI>(A, Wq, Wsb, bias, res, C, M, N, K, lda, ldc, ldres, st);
   if (t64n >= 200) return launch_cfg_w4<64, 128, EPI>(A, Wq, Wsb, bias, res, C, M, N, K, lda, ldc, ldres, st);
   return launch_cfg_w4<64, 64, EPI>(A, Wq, Wsb, bias, res, C, M, N, K, lda, ldc, ldres, st);
@@ -534,6 +753,10 @@ int launch_epi(const void* A, const void* W, const void* bias, const void* res, 
 #define CFG(BMV, BNV)                                                                                            \
   (glds ? launch_cfg<BMV, BNV, EPI, true>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st)                \
         : launch_cfg<BMV, BNV, EPI, false>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st))
+  // up to 64 rows (the wide decode steps, short prompts) the launch is a WEIGHT STREAM: what counts is bytes in flight, i.e.
+  // workgroups - 7B gate/up at 32 rows: 148 tiles of 256 rows 65.9 us, 296 of 128 ~58, 592 of 64 ~50 (the one-row GEMV: 42.8);
+  // whole 32-row 7B step 0.425 -> 0.469 of HBM (profiles/r06_wide_step.txt)
+  if (M <= 64 && g_skinny64) return CFG(64, 64);
   if (t128 >= 200) return CFG(128, 128);
   if (t64n >= 200) return CFG(64, 128);
   return CFG(64, 64);
@@ -598,7 +821,7 @@ static int gemm_dispatch(const void* A, const void* W, const void* bias, const v
     // 566 vs 432 TF; 180: 838 vs 772; 540: 869 vs 828; 720: 1073-1087 vs 895-921 TF) and loses below (60 tiles:
     // 326-421 vs 471-530 TF), where the 128x128 kernel spreads the work over more CUs.  (g_tile256 == 1: test hook.)
     const long t256 = (long)vlm_cdiv(M, 256) * vlm_cdiv(N, 256);
-    const bool fills = t256 >= 120;
+    const bool fills = t256 >= 120 && !(g_skinny64 && M <= 64);      // (<= 64 rows: 64 x 64 tiles, see launch_epi)
     if (g_tile256 == 1 || fills) {
       const int rc = vlm_gemm256_try(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, epilogue, stream);
       if (rc >= 0) return rc;
@@ -640,3 +863,31 @@ extern "C" int vlm_gemm_w4(const void* A, const void* Wq, const void* Wsb, const
   }
 #undef GO
 }
+
+// vlm_gemm_bf16 / vlm_gemm_w4 with a TAIL: when the GEMM takes the split-K route, its reduce launch also does what the caller
+// would launch next on the reduced rows (VlmGemmTail, internal.h) and *tail_done = 1; otherwise the GEMM runs as usual,
+// *tail_done = 0 and the caller launches the follower itself.
+VLM_INTERNAL int vlm_gemm_bf16_tail(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
+                                    int lda, int ldw, int ldc, int ldres, int epilogue, const VlmGemmTail* tail, int* tail_done,
+                                    void* stream) {
+  if (epilogue & ~(VLM_EPI_BIAS | VLM_EPI_RESIDUAL)) return VLM_ERR_ARG;
+  t_tail = tail;
+  t_tail_done = false;
+  const int rc = gemm_dispatch(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, epilogue, stream);
+  t_tail = nullptr;
+  if (tail_done) *tail_done = t_tail_done ? 1 : 0;
+  return rc;
+}
+
+VLM_INTERNAL int vlm_gemm_w4_tail(const void* A, const void* Wq, const void* Wsb, const void* bias, const void* res, void* C, int M,
+                                  int N, int K, int lda, int ldc, int ldres, int epilogue, const VlmGemmTail* tail, int* tail_done,
+                                  void* stream) {
+  if (epilogue & ~(VLM_EPI_BIAS | VLM_EPI_RESIDUAL)) return VLM_ERR_ARG;
+  t_tail = tail;
+  t_tail_done = false;
+  const int rc = vlm_gemm_w4(A, Wq, Wsb, bias, res, C, M, N, K, lda, ldc, ldres, epilogue, stream);
+  t_tail = nullptr;
+  if (tail_done) *tail_done = t_tail_done ? 1 : 0;
+  return rc;
+}
+

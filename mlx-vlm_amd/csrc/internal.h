@@ -80,3 +80,33 @@ VLM_INTERNAL int vlm_sample_advance(const void* logits, int ld, int B, int V, vo
                                     void* ctx, void* pos, void* out_ring, int ring_len, void* step, const void* embed, void* h,
                                     int D, int ldh, void* stream);
 
+
+/* gemm_bf16.hip: what the reduce launch of a split-K GEMM does ON TOP of its epilogue (the wide decode steps of engine.hip): the
+ * launch the caller would otherwise issue next on the reduced rows.  Bit-identical to the two-launch sequence. */
+enum { VLM_TAIL_NONE = 0, VLM_TAIL_RMSNORM = 1, VLM_TAIL_ROPE_KV = 2 };
+struct VlmGemmTail {
+  int kind;
+  /* VLM_TAIL_RMSNORM: xn[m] = norm_w * T(C[m] * rsqrt(mean(C[m]^2) + eps)) (vlm_rmsnorm_residual on the rows just written) */
+  const void* norm_w;
+  float eps;
+  void* xn;
+  int ldxn;
+  /* VLM_TAIL_ROPE_KV: vlm_mrope_kvwrite_decode on the qkv rows just written (row b at text position pos[b], slot[b] of
+   * block-table row b) */
+  int Hq, Hkv, D;
+  const int* pos;
+  const float* inv_freq;
+  const int* slot;
+  const int* block_table;
+  int max_pages;
+  unsigned short* kpool;
+  unsigned short* vpool;
+  float qk_scale;
+  int long_from;
+};
+VLM_INTERNAL int vlm_gemm_bf16_tail(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
+                                    int lda, int ldw, int ldc, int ldres, int epilogue, const VlmGemmTail* tail, int* tail_done,
+                                    void* stream);
+VLM_INTERNAL int vlm_gemm_w4_tail(const void* A, const void* Wq, const void* Wsb, const void* bias, const void* res, void* C, int M,
+                                  int N, int K, int lda, int ldc, int ldres, int epilogue, const VlmGemmTail* tail, int* tail_done,
+                                  void* stream);

@@ -262,6 +262,69 @@ def test_wide_32_rows_at_7b_widths_every_row_checked():
     print(f"32 wide rows at 7B widths: worst vs one-row path {worst_single:.4f}, worst vs oracle {worst:.4f}")
 
 
+_TAILS_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from tests.test_full_depth_gpu import _wide_tail_logits
+got, launches = _wide_tail_logits()
+np.savez(sys.argv[2], logits=got.view(__import__("torch").int16).cpu().numpy(), launches=launches)
+"""
+
+
+def _wide_tail_logits():
+    """32 rows x 2 wide steps at 7B widths (2 layers; one row on split attention) -> (logits [steps, B, V], launches of a step)"""
+    import ctypes as C
+
+    from mlx_vlm_amd import _lib
+    from oracle import qwen2_vl as oq
+
+    text = oq.TextCfg(hidden_size=3584, num_hidden_layers=2, intermediate_size=18944, num_attention_heads=28,
+                      num_key_value_heads=4, vocab_size=152064, tie_word_embeddings=False)
+    cfg = oq.Cfg(text=text, vision=oq.VisionCfg(depth=1, embed_dim=1280, hidden_size=3584, num_heads=16))
+    W = oq.random_weights(cfg, seed=74, dtype=BF, std=0.02, fast=True)
+    model = build_product_model(cfg, W, kv_pool_tokens=32768, max_seqs=72)
+    lm = model.language_model
+    B, steps = 32, 2
+    rng = np.random.default_rng(731)
+    lens = [5 + (b * 43) % 150 for b in range(B)]
+    lens[9] = 2100
+    prompts = [rng.integers(0, 151643, n).astype(np.int64) for n in lens]
+    forced = rng.integers(0, 151643, (steps, B))
+    caches = []
+    for p in prompts:
+        c = lm.make_cache()
+        lm(p[None], cache=c, logits_to_keep=1)
+        caches.append(c)
+    got = torch.stack([lm(forced[s].reshape(B, 1), cache=caches).logits[:, 0].clone() for s in range(steps)])
+    torch.cuda.synchronize()
+    launches = int(_lib.lib().vlm_llm_decode_launches(lm._handle))
+    for c in caches:
+        c[0]._seq.release()
+    return got, launches
+
+
+def test_wide_step_reduce_tails_equal_the_separate_launches(tmp_path):
+    """Round 6: in a wide step the reduce launch of each split-K GEMM also does its follower - M-RoPE + KV write after qkv, RMSNorm
+    after o_proj and after down (csrc/gemm_bf16.hip splitk_reduce_rope_kernel / splitk_reduce_norm_kernel).  Same arithmetic in
+    the same order, so the logits of 32 rows x 2 steps at 7B widths (the second step reads the K / V the first one's fused launch
+    wrote) equal the separate-launch sequence (VLM_WIDE_TAILS=0, a child process: the knob is read once) BIT FOR BIT, in 13
+    launches per step instead of 19."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref_path = str(tmp_path / "separate.npz")
+    r = subprocess.run([sys.executable, "-c", _TAILS_CHILD, root, ref_path], env=dict(os.environ, VLM_WIDE_TAILS="0"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = np.load(ref_path)
+    got, launches = _wide_tail_logits()
+    assert int(ref["launches"]) == 19 and launches == 13, (int(ref["launches"]), launches)
+    g = got.view(torch.int16).cpu().numpy()
+    assert np.array_equal(g, ref["logits"]), int((g != ref["logits"]).sum())
+
+
 @pytest.mark.parametrize("B", [20, 40])
 def test_wide_rows_over_the_quantized_kv_cache_every_row_vs_oracle(B):
     """Wide steps x kv_bits = 8: B rows whose caches were quantised after their prefill
