@@ -721,6 +721,10 @@ int launch_epi_w4(const void* A, const void* Wq, const void* Wsb, const void* bi
     const long t64 = (long)vlm_cdiv(M, 64) * vlm_cdiv(N, 64);
     int splits = g_splitk > 1 ? g_splitk : 0;
     if (!splits && t64 < 256 && K >= 2048) splits = (int)std::min<long>(8, std::max<long>(2, (512 + t64 - 1) / t64));
+    if (!splits && t64 < 256 && M <= 64 && g_skinny64 && K >= 1024) {        // (see launch_epi)
+      splits = (int)std::min<long>(8, std::max<long>(2, (512 + t64 - 1) / t64));
+      while (splits > 1 && K / splits < 4 * BK) --splits;
+    }
     if (splits > 1 && K / splits >= 4 * BK) {
       if (float* ws = splitk_workspace((size_t)splits * M * N * sizeof(float), st))
         return launch_splitk_w4<EPI>(A, Wq, Wsb, bias, res, C, M, N, K, lda, ldc, ldres, splits, ws, st);
@@ -745,6 +749,12 @@ int launch_epi(const void* A, const void* W, const void* bias, const void* res, 
     const long t64 = (long)vlm_cdiv(M, 64) * vlm_cdiv(N, 64);
     int splits = g_splitk > 1 ? g_splitk : 0;
     if (!splits && t64 < 256 && K >= 2048) splits = (int)std::min<long>(8, std::max<long>(2, (512 + t64 - 1) / t64));
+    // ... and up to 64 rows (a weight stream: the 2B model's qkv / o_proj at a 64-row step are 32 / 24 tiles of K = 1536, 10 us
+    // each for 6 / 5 MB) from K = 1024, with as many splits as leave 4 K tiles per workgroup
+    if (!splits && t64 < 256 && M <= 64 && g_skinny64 && K >= 1024) {
+      splits = (int)std::min<long>(8, std::max<long>(2, (512 + t64 - 1) / t64));
+      while (splits > 1 && K / splits < 4 * BK) --splits;
+    }
     if (splits > 1 && K / splits >= 4 * BK) {
       if (float* ws = splitk_workspace((size_t)splits * M * N * sizeof(float), st))
         return launch_splitk<EPI>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, splits, ws, st);

@@ -266,21 +266,20 @@ _TAILS_CHILD = r"""
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
 from tests.test_full_depth_gpu import _wide_tail_logits
-got, launches = _wide_tail_logits()
+got, launches = _wide_tail_logits(sys.argv[3])
 np.savez(sys.argv[2], logits=got.view(__import__("torch").int16).cpu().numpy(), launches=launches)
 """
 
 
-def _wide_tail_logits():
-    """32 rows x 2 wide steps at 7B widths (2 layers; one row on split attention) -> (logits [steps, B, V], launches of a step)"""
-    import ctypes as C
-
+def _wide_tail_logits(widths):
+    """32 rows x 2 wide steps at 7B / 2B widths (2 layers; one row on split attention) -> (logits [steps, B, V], launches of a step)"""
     from mlx_vlm_amd import _lib
     from oracle import qwen2_vl as oq
 
-    text = oq.TextCfg(hidden_size=3584, num_hidden_layers=2, intermediate_size=18944, num_attention_heads=28,
-                      num_key_value_heads=4, vocab_size=152064, tie_word_embeddings=False)
-    cfg = oq.Cfg(text=text, vision=oq.VisionCfg(depth=1, embed_dim=1280, hidden_size=3584, num_heads=16))
+    H, I, NH, NKV, V = {"7b": (3584, 18944, 28, 4, 152064), "2b": (1536, 8960, 12, 2, 151936)}[widths]
+    text = oq.TextCfg(hidden_size=H, num_hidden_layers=2, intermediate_size=I, num_attention_heads=NH,
+                      num_key_value_heads=NKV, vocab_size=V, tie_word_embeddings=False)
+    cfg = oq.Cfg(text=text, vision=oq.VisionCfg(depth=1, embed_dim=1280, hidden_size=H, num_heads=16))
     W = oq.random_weights(cfg, seed=74, dtype=BF, std=0.02, fast=True)
     model = build_product_model(cfg, W, kv_pool_tokens=32768, max_seqs=72)
     lm = model.language_model
@@ -303,23 +302,24 @@ def _wide_tail_logits():
     return got, launches
 
 
-def test_wide_step_reduce_tails_equal_the_separate_launches(tmp_path):
+@pytest.mark.parametrize("widths", ["7b", "2b"])
+def test_wide_step_reduce_tails_equal_the_separate_launches(tmp_path, widths):
     """Round 6: in a wide step the reduce launch of each split-K GEMM also does its follower - M-RoPE + KV write after qkv, RMSNorm
     after o_proj and after down (csrc/gemm_bf16.hip splitk_reduce_rope_kernel / splitk_reduce_norm_kernel).  Same arithmetic in
     the same order, so the logits of 32 rows x 2 steps at 7B widths (the second step reads the K / V the first one's fused launch
     wrote) equal the separate-launch sequence (VLM_WIDE_TAILS=0, a child process: the knob is read once) BIT FOR BIT, in 13
-    launches per step instead of 19."""
+    launches per step instead of 19.  At 2B widths (K = 1536) the qkv / o_proj GEMMs are split-K only under the <= 64-row policy."""
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ref_path = str(tmp_path / "separate.npz")
-    r = subprocess.run([sys.executable, "-c", _TAILS_CHILD, root, ref_path], env=dict(os.environ, VLM_WIDE_TAILS="0"),
+    r = subprocess.run([sys.executable, "-c", _TAILS_CHILD, root, ref_path, widths], env=dict(os.environ, VLM_WIDE_TAILS="0"),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     ref = np.load(ref_path)
-    got, launches = _wide_tail_logits()
+    got, launches = _wide_tail_logits(widths)
     assert int(ref["launches"]) == 19 and launches == 13, (int(ref["launches"]), launches)
     g = got.view(torch.int16).cpu().numpy()
     assert np.array_equal(g, ref["logits"]), int((g != ref["logits"]).sum())
