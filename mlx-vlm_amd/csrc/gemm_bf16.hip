@@ -601,6 +601,7 @@ constexpr int MAX_SPLITK_WS = 8;
 SplitkWs g_splitk_ws[MAX_SPLITK_WS];
 int g_n_splitk_ws = 0;
 const bool g_skinny64 = [] { const char* e = getenv("VLM_GEMM_SKINNY64"); return !e || atoi(e) != 0; }();   // A/B knob: 0 = the tile policy of rounds 1-5
+int g_force_cfg = 0;   // tile of the plain kernels forced (vlm_gemm_set_staging mode 100 + 10 * splits + cfg): 1 = 64 x 64, 2 = 64 x 128, 3 = 128 x 128
 int g_splitk = 0;   // 0 = automatic, -1 = never (vlm_gemm_set_staging mode 8), n > 1 = forced split count (test hook, 9: 4)
 
 float* splitk_workspace(size_t bytes, hipStream_t st) {
@@ -766,6 +767,9 @@ int launch_epi(const void* A, const void* W, const void* bias, const void* res, 
   // up to 64 rows (the wide decode steps, short prompts) the launch is a WEIGHT STREAM: what counts is bytes in flight, i.e.
   // workgroups - 7B gate/up at 32 rows: 148 tiles of 256 rows 65.9 us, 296 of 128 ~58, 592 of 64 ~50 (the one-row GEMV: 42.8);
   // whole 32-row 7B step 0.425 -> 0.469 of HBM (profiles/r06_wide_step.txt)
+  if (g_force_cfg == 1) return CFG(64, 64);
+  if (g_force_cfg == 2) return CFG(64, 128);
+  if (g_force_cfg == 3) return CFG(128, 128);
   if (M <= 64 && g_skinny64) return CFG(64, 64);
   if (t128 >= 200) return CFG(128, 128);
   if (t64n >= 200) return CFG(64, 128);
@@ -782,6 +786,15 @@ int launch_epi(const void* A, const void* W, const void* bias, const void* res, 
 // 8 = LDS-DMA 128 kernel, never split-K; 9 = 128 kernel with split-K x4 forced (modes 1 / 2 also disable split-K).
 // Test / A-B knob only.
 extern "C" int vlm_gemm_set_staging(int mode) {
+  g_force_cfg = 0;
+  if (mode >= 100 && mode < 200) {       // tuning hook: plain kernels only, tile cfg = mode % 10, forced split count = (mode - 100) / 10 (0: never)
+    g_force_regstage = false;
+    g_tile256 = -1;
+    g_force_cfg = mode % 10;
+    const int sp = (mode - 100) / 10;
+    g_splitk = sp > 1 ? sp : -1;
+    return VLM_OK;
+  }
   g_force_regstage = (mode == 1);
   g_tile256 = (mode == 3 || mode == 4 || mode == 6 || mode == 7 || mode == 10) ? 1 : (mode == 1 || mode == 2 || mode == 8 || mode == 9) ? -1 : 0;
   g_splitk = (mode == 1 || mode == 2 || mode == 8) ? -1 : mode == 9 ? 4 : 0;   // 8: no split-K, 9: split-K x4 forced

@@ -12,10 +12,12 @@ vt = VisionModel(cfg.vision_config)
 vt.load_weights({k[len("vision_tower."):]: v for k, v in W.items() if k.startswith("vision_tower.")})
 del W
 nimg = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-pix = torch.randn(nimg * 576, 1176, device="cuda")
-thw = np.array([[1, 24, 24]] * nimg)
+side = int(sys.argv[2]) // 14 if len(sys.argv) > 2 else 24      # argv[2]: image side in pixels (336 -> 24 x 24 patches, 448 -> 32 x 32)
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+pix = torch.randn(nimg * side * side, 1176, device="cuda")
+thw = np.array([[1, side, side]] * nimg)
 for _ in range(2): vt(pix, thw)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(3): vt(pix, thw)
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+for _ in range(reps): vt(pix, thw)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
 print(f"{nimg} images: {dt*1e3:.2f} ms/call, {nimg/dt:.1f} img/s, {nimg/dt*0.791:.1f} TFLOP/s")
