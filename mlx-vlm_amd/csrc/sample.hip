@@ -32,6 +32,7 @@ constexpr int NBLK = 64;  // blocks per vocabulary row
 // re-armed between calls) of row b in the same words every time.  (Rounds 4-5 laid the arrays out [B][...] back to back: a
 // narrower step then found another step's Gumbel candidates where its histogram should be zero - ADVICE r05.)
 constexpr int CTL_WORDS = 128;
+constexpr int CTL_ROW_TICKET = 120;   // control word of a row's block: arrivals of the row's blocks in the fused greedy tail (zero between launches)
 constexpr int ROW_LSE = 0, ROW_CV = 2 * NBLK, ROW_CI = 3 * NBLK, ROW_HIST = 4 * NBLK, ROW_CTL = ROW_HIST + 65536;
 constexpr int ROW_W = ROW_CTL + CTL_WORDS;
 static_assert(ROW_HIST % 4 == 0 && ROW_W % 4 == 0, "the histogram of every row is cleared with 16-byte stores");
@@ -127,6 +128,26 @@ struct SampleTail {
   int D, ldh;
 };
 
+// the next step's input rows h[r] = embed[tok[r]] by ONE workgroup (the last block of a fused tail): 8 loads of a thread in flight
+// before the first store - one dependent HBM round trip per 16-byte piece made the 16-row greedy tail 27-32 us long (12 trips)
+__device__ __forceinline__ void gather_rows_256(const bf16_t* __restrict__ embed, bf16_t* __restrict__ h, const int* s_tok, int B,
+                                                int D, int ldh, int tid) {
+  const int cpr = D >> 3, total = B * cpr;
+  for (int i0 = tid; i0 < total; i0 += 256 * 8) {
+    u32x4_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(i0 + 256 * u, total - 1), r = i / cpr, c = i % cpr;
+      v[u] = reinterpret_cast<const u32x4_t*>(embed + (size_t)s_tok[r] * D)[c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 256 * u;
+      if (i < total) reinterpret_cast<u32x4_t*>(h + (size_t)(i / cpr) * ldh)[i % cpr] = v[u];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void argmax_final_advance_kernel(const float* __restrict__ cand_v, const int* __restrict__ cand_i,
                                                                    int* __restrict__ tok, int B, int V, SampleTail t) {
   __shared__ int s_tok[64];
@@ -151,11 +172,7 @@ __global__ __launch_bounds__(256) void argmax_final_advance_kernel(const float* 
     t.pos[tid] += 1;
     if (t.out_ring) t.out_ring[(size_t)(st % t.ring_len) * B + tid] = y;
   }
-  const int cpr = t.D >> 3;
-  for (int i = tid; i < B * cpr; i += 256) {
-    const int r = i / cpr, c = i % cpr;
-    reinterpret_cast<uint4*>(t.h + (size_t)r * t.ldh)[c] = reinterpret_cast<const uint4*>(t.embed + (size_t)s_tok[r] * t.D)[c];
-  }
+  gather_rows_256(t.embed, t.h, s_tok, B, t.D, t.ldh, tid);
   __syncthreads();
   if (tid == 0) *t.step = st + 1;
 }
@@ -208,14 +225,23 @@ __global__ __launch_bounds__(256) void logprob_argmax_tail_kernel(
   if (tid == 0) {
     for (int w = 1; w < 4; ++w)
       if (sv[w] > best || (sv[w] == best && si[w] < besti)) { best = sv[w]; besti = si[w]; }
-    cand_v[(size_t)b * ROW_W + blk] = best;
-    cand_i[(size_t)b * ROW_W + blk] = besti;
-    // publish: release, then the ticket (this order; the asm wait restates the fence's own wait where the compiler
-    // cannot drop it)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // publish: the candidates as agent-scope atomic stores (written through to where every XCD reads them), their completion,
+    // then the ticket.  (Rounds 2-5 used plain stores + an agent-scope RELEASE fence: on this part that fence writes the XCD's
+    // L2 back - every dirty line in it, i.e. the log-probs all its blocks are storing - once per block; 1024 of them made the
+    // 16-row launch 32 us long, round 6.  The last block reads the candidates with agent-scope atomic loads, as before.)
+    __hip_atomic_store(cand_v + (size_t)b * ROW_W + blk, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(cand_i + (size_t)b * ROW_W + blk, besti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = t == (unsigned)(gridDim.x * gridDim.y) - 1u;
+    // Two levels (round 6): the row's own ticket (a control word of the row's workspace block, 260 KB from its neighbours'),
+    // then the last block of each row on the launch's ticket.  One ticket for all NBLK x B blocks serialises 1024 agent-scope
+    // fetch_adds on ONE address at a 16-row step: the launch took 32 us, against 8.8 at one row (64 arrivals).
+    unsigned* row_ticket = reinterpret_cast<unsigned*>(const_cast<float*>(ws)) + (size_t)b * ROW_W + ROW_CTL + CTL_ROW_TICKET;
+    int last = 0;
+    if (__hip_atomic_fetch_add(row_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+      __hip_atomic_store(row_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // every block of the row has arrived: re-arm
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.y - 1u;
+    }
     if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     s_last = last;
   }
@@ -253,11 +279,7 @@ __global__ __launch_bounds__(256) void logprob_argmax_tail_kernel(
     if (out_ring) out_ring[(size_t)(st % ring_len) * B + tid] = t;
   }
   // next step's input embeddings
-  const int cpr = D >> 3;
-  for (int i = tid; i < B * cpr; i += 256) {
-    const int r = i / cpr, c = i % cpr;
-    reinterpret_cast<uint4*>(h + (size_t)r * ldh)[c] = reinterpret_cast<const uint4*>(embed + (size_t)s_tok[r] * D)[c];
-  }
+  gather_rows_256(embed, h, s_tok, B, D, ldh, tid);
   __syncthreads();
   if (tid == 0) {
     *step = st + 1;
