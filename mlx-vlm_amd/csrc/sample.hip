@@ -208,7 +208,24 @@ __global__ __launch_bounds__(256) void logprob_argmax_tail_kernel(
   const bf16_t* row = logits + (size_t)b * ld;
   float best = -INFINITY;
   int besti = 0x7fffffff;
-  for (int i = lo + tid; i < hi; i += 256) {
+  // 8 elements per thread and trip where rows and pitches allow 16-byte accesses (elementwise + an order-free argmax with the
+  // index tie rule: the same log-probs and candidate as the scalar loop); the ragged end of the last block stays scalar
+  const bool vec = ((ld | ldlp) & 7) == 0 && (((uintptr_t)logits | (uintptr_t)logprobs) & 15) == 0;
+  const int hi8 = vec ? lo + ((hi - lo) & ~7) : lo;
+  for (int i = lo + tid * 8; i < hi8; i += 256 * 8) {
+    const u32x4_t w = *reinterpret_cast<const u32x4_t*>(row + i);
+    u32x4_t o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bf16_t l0 = f2bf(bf_lo(w[q]) - lse), l1 = f2bf(bf_hi(w[q]) - lse);
+      o[q] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+      const float p0 = bf2f(l0), p1 = bf2f(l1);
+      if (p0 > best || (p0 == best && i + 2 * q < besti)) { best = p0; besti = i + 2 * q; }
+      if (p1 > best || (p1 == best && i + 2 * q + 1 < besti)) { best = p1; besti = i + 2 * q + 1; }
+    }
+    if (logprobs) *reinterpret_cast<u32x4_t*>(logprobs + (size_t)b * ldlp + i) = o;
+  }
+  for (int i = hi8 + tid; i < hi; i += 256) {
     const bf16_t lpb = f2bf(bf2f(row[i]) - lse);
     if (logprobs) logprobs[(size_t)b * ldlp + i] = lpb;
     const float lp = bf2f(lpb);

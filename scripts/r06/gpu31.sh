@@ -11,3 +11,6 @@ python3 scripts/batch_prof.py 16 64 | grep "^B="; python3 scripts/batch_prof.py 
 python3 bench.py --stage headline --steps 3 --warmup 1 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('headline', d['value'], d['decode_us_per_token'])"
+(cd /tmp && rm -rf /tmp/p1 && timeout -k 15 400 rocprofv3 --kernel-trace --stats -d /tmp/p1 -o p -- python3 $R/bench.py --stage headline --steps 3 --warmup 1 > $O/prof.log 2>&1); echo "prof rc=$?"
+python3 $R/scripts/prof_summary.py $(find /tmp/p1 -name "*.db" | head -1) $O/headline_stats.txt > /dev/null 2>&1
+grep "logprob_argmax_tail\|lse_partial" $O/headline_stats.txt
