@@ -202,25 +202,29 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + (size_t)kt * BK),
                                          (__attribute__((address_space(3))) void*)(ws + (uw * W_IT + j) * 1024), 16, 0, 0);
     };
-    if constexpr (BM == 64 && BN == 64) {
+    if constexpr ((BM == 64 || BM == 32) && BN == 64) {
       // 64x64 tiles carry ~100 cycles of MFMA per K tile: with one tile of prefetch every iteration waited a full
       // memory latency (~0.8 us per K tile measured on the M = 386 prefill GEMMs).  Four 16 KiB stages, three tiles in
       // flight, COUNTED waits (4 DMA instructions per wave and tile; tile indices clamped at the end so the count
       // never changes), raw barriers (__syncthreads would drain vmcnt(0)).  Stage kt % 4 is refilled with tile kt + 4
       // in iteration kt + 1, after the barrier that ends its last read.
+      // (round 6) BM = 32, for GEMMs of <= 32 rows: half the A tile, 12 KiB stages - three workgroups per CU instead of two
+      // (a weight stream wants bytes in flight) and 3 DMA instructions per wave and tile.
       constexpr int NS = 4, PER = A_IT + W_IT;
-      static_assert(PER == 4, "vmcnt immediates below assume 4 DMA instructions per wave and tile");
+      static_assert(PER == 4 || PER == 3, "vmcnt immediates below: 4 or 3 DMA instructions per wave and tile");
       issue(0, 0);
       issue(min(1, nk - 1), 1);
       issue(min(2, nk - 1), 2);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 landed (tiles 1, 2 may be in flight)
+      if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 landed (tiles 1, 2 may be in flight)
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       for (int kt = 0; kt < nk; ++kt) {
         issue(min(kt + 3, nk - 1), (kt + 3) % NS);
         __builtin_amdgcn_sched_barrier(0);
         compute(kt % NS);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile kt + 1 landed (this wave's pieces) ...
+        if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile kt + 1 landed (this wave's pieces) ...
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // ... and everybody's; stage kt % 4 is free again
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // clamped reloads still target LDS
@@ -600,6 +604,7 @@ constexpr size_t SPLITK_WS_BYTES = 34u << 20;
 constexpr int MAX_SPLITK_WS = 8;
 SplitkWs g_splitk_ws[MAX_SPLITK_WS];
 int g_n_splitk_ws = 0;
+const bool g_skinny32 = [] { const char* e = getenv("VLM_GEMM_SKINNY32"); return !e || atoi(e) != 0; }();   // A/B knob: 0 = 64-row A tiles for <= 32 rows too
 const bool g_skinny64 = [] { const char* e = getenv("VLM_GEMM_SKINNY64"); return !e || atoi(e) != 0; }();   // A/B knob: 0 = the tile policy of rounds 1-5
 int g_force_cfg = 0;   // tile of the plain kernels forced (vlm_gemm_set_staging mode 100 + 10 * splits + cfg): 1 = 64 x 64, 2 = 64 x 128, 3 = 128 x 128
 int g_splitk = 0;   // 0 = automatic, -1 = never (vlm_gemm_set_staging mode 8), n > 1 = forced split count (test hook, 9: 4)
@@ -664,6 +669,15 @@ int launch_splitk(const void* A, const void* W, const void* bias, const void* re
                   int ldw, int ldc, int ldres, int splits, float* ws, hipStream_t st) {
   const int kchunk = vlm_cdiv(vlm_cdiv(K, splits), BK) * BK;
   splits = vlm_cdiv(K, kchunk);
+  if (M <= 32 && g_skinny32) {                       // (<= 32 rows: 32 x 64 tiles, see launch_epi)
+    const int tiles_n = vlm_cdiv(N, 64), nwg = tiles_n;
+    hipLaunchKernelGGL((gemm_bf16_kernel<32, 64, VLM_EPI_NONE, true, true>), dim3(nwg, splits), dim3(256), 4 * (size_t)(32 + 64) * ROWB, st,
+                       (const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
+                       reinterpret_cast<bf16_t*>(ws), M, N, K, lda, ldw, N, 0, tiles_n, nwg, kchunk);
+    launch_reduce<EPI>((const float*)ws, splits, bias, res, C, M, N, ldc, ldres, st);
+    hipError_t e32 = hipGetLastError();
+    return e32 == hipSuccess ? VLM_OK : VLM_ERR_HIP + (int)e32;
+  }
   const int tiles_m = vlm_cdiv(M, 64), tiles_n = vlm_cdiv(N, 64), nwg = tiles_m * tiles_n;
   const size_t lds = 4 * (size_t)(64 + 64) * ROWB;   // four stages (see the 64x64 K loop)
   hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, VLM_EPI_NONE, true, true>), dim3(nwg, splits), dim3(256), lds, st,
@@ -678,7 +692,7 @@ template <int BM, int BN, int EPI, bool GLDS>
 int launch_cfg(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
                int ldw, int ldc, int ldres, hipStream_t st) {
   const int tiles_m = vlm_cdiv(M, BM), tiles_n = vlm_cdiv(N, BN), nwg = tiles_m * tiles_n;
-  const size_t lds = ((BM == 64 && BN == 64 && GLDS) ? 4 : 2) * (size_t)(BM + BN) * ROWB;
+  const size_t lds = (((BM == 64 || BM == 32) && BN == 64 && GLDS) ? 4 : 2) * (size_t)(BM + BN) * ROWB;
   hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, GLDS>), dim3(nwg), dim3(256), lds, st, (const bf16_t*)A, (const bf16_t*)W,
                      (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg, 0);
   hipError_t e = hipGetLastError();
@@ -770,6 +784,7 @@ int launch_epi(const void* A, const void* W, const void* bias, const void* res, 
   if (g_force_cfg == 1) return CFG(64, 64);
   if (g_force_cfg == 2) return CFG(64, 128);
   if (g_force_cfg == 3) return CFG(128, 128);
+  if (M <= 32 && g_skinny64 && g_skinny32 && glds) return launch_cfg<32, 64, EPI, true>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
   if (M <= 64 && g_skinny64) return CFG(64, 64);
   if (t128 >= 200) return CFG(128, 128);
   if (t64n >= 200) return CFG(64, 128);
