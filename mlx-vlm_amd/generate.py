@@ -35,6 +35,7 @@ DEFAULT_TOP_K = 0
 DEFAULT_MIN_P = 0.0
 DEFAULT_QUANTIZED_KV_START = 5000      # reference generate/common.py:17
 DEFAULT_PREFILL_STEP_SIZE = 2048
+ONE_SHOT_PREFILL_TOKENS = 32768    # with the default step size, prompts up to this many tokens prefill in one shot (generate_step)
 
 
 @dataclass
@@ -349,6 +350,13 @@ def generate_step(input_ids, model, pixel_values, mask, *, max_tokens: int = DEF
     step_size = None if prefill_step_size is None else int(prefill_step_size)
     if step_size is not None and not _chunked_prefill_enabled(model, input_ids=ids, inputs_embeds=emb, prompt_cache=prompt_cache,
                                                               draft_model=None, draft_kind=None, prefill_kwargs=kwargs):
+        step_size = None
+    # The reference chunks to bound MLX's prompt memory; here the one-shot prefill kernels take any prompt the workspaces hold
+    # and the chunk path re-attends over the gathered prefix (LanguageModel._prefill_onto_cache): measured on the 2B, first token
+    # of a 4096 / 8192 / 16384-token prompt 37 / 88 / 276 ms in chunks of 2048 against 22 / 38 / 90 ms in one shot
+    # (scripts/r06/long_prompt.py).  So the DEFAULT step size means "the engine decides": prompts up to
+    # ONE_SHOT_PREFILL_TOKENS go in one shot (same logits up to summation order); any other value is honoured as given.
+    if step_size == DEFAULT_PREFILL_STEP_SIZE and L <= ONE_SHOT_PREFILL_TOKENS:
         step_size = None
     done = 0
     if step_size is not None and step_size > 0 and L > step_size and not prompt_cache[0]._seq.rotating:

@@ -345,6 +345,34 @@ def test_generate_step_prefill_step_size_chunks_and_the_models_veto(tiny, monkey
         assert calls == [[L]], (veto, calls)
 
 
+def test_generate_step_default_step_size_prefills_a_long_prompt_in_one_shot(tiny, monkeypatch):
+    """with the DEFAULT prefill_step_size the engine decides - a 2500-token prompt (beyond the reference's 2048)
+    goes through ONE prefill call (the one-shot kernels: 2.3 x faster than chunks at 8k tokens, scripts/r06/long_prompt.py),
+    an explicit step size is honoured, and beyond ONE_SHOT_PREFILL_TOKENS the default chunks again."""
+    from mlx_vlm_amd import generate as G
+
+    cfg, W, model = tiny
+    lm = model.language_model
+    ids = np.random.default_rng(5).integers(3, 1000, (1, 2500))
+    calls = []
+    real = lm.prefill
+
+    def spy(emb, pos, caches, lengths, *a, **k):
+        calls.append(list(lengths))
+        return real(emb, pos, caches, lengths, *a, **k)
+
+    monkeypatch.setattr(lm, "prefill", spy)
+    toks = [t for t, _ in G.generate_step(ids, model, None, None, max_tokens=3)]
+    assert calls == [[2500]] and len(toks) == 3
+    calls.clear()
+    list(G.generate_step(ids, model, None, None, max_tokens=3, prefill_step_size=1024))
+    assert calls == [[1024], [1024], [451], [1]], calls
+    calls.clear()
+    monkeypatch.setattr(G, "ONE_SHOT_PREFILL_TOKENS", 2000)
+    list(G.generate_step(ids, model, None, None, max_tokens=3))
+    assert calls == [[2048], [451], [1]], calls
+
+
 def test_stream_generate_multi_turn_prompt_cache_state_and_vision_cache(tiny):
     """Two conversation turns through stream_generate with a PromptCacheState and a VisionFeatureCache (reference
     dispatch.py:800-809,861-882): turn 2's prompt = turn 1's prompt + its answer + new text; the cached KV prefix is reused
