@@ -331,6 +331,12 @@ class KVCache:
         launches) write K / V themselves; this is the module-contract entry for code that computes k and v on its own - a
         reference-side model file, a test.  The rows go into the sequence's pages (vlm_kv_append_tokens); the return value is
         materialised from the pages as `state` is."""
+        self._append(keys, values)
+        return self.state
+
+    def _append(self, keys: torch.Tensor, values: torch.Tensor):
+        """the write half of update_and_fetch (no materialisation of the row's K / V: BatchKVCache appends row by row and
+        builds the padded batch state once)"""
         from .. import _lib
         from .._lib import check
         import ctypes as C
@@ -364,7 +370,6 @@ class KVCache:
                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "kv_append_tokens")
             self._keep_uaf = (k, v)             # alive until the stream has run
             s.advance_layer(self._layer, S)
-        return self.state
 
     def extract(self, idx: int):
         """reference cache.py:395-413: row `idx` of a (one-row) cache as a KVCache of its own.  The reference copies the row; here
@@ -489,7 +494,7 @@ class BatchKVCache:
         for i in range(B):
             first = max(0, int(self.left_padding[i]) - self._idx)          # leading positions of this call that are padding
             if first < S:
-                KVCache(self._row(i), self._layer).update_and_fetch(keys[i:i + 1, :, first:], values[i:i + 1, :, first:])
+                KVCache(self._row(i), self._layer)._append(keys[i:i + 1, :, first:], values[i:i + 1, :, first:])
         self._advance(S)
         return self.state[:2]
 
