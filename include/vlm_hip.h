@@ -189,7 +189,11 @@ int vlm_kv_gather(void* qkv, int ld, int T, int Hq, int Hkv, int D, const void* 
  * q/k/v/out are token-major with the given token strides; head h of token t at ptr + t*stride + h*D.
  * total_qblocks = sum_s ceil(len_s / 128) (host).  D in {64, 80, 128}.
  * causal: bit 0 = causal mask; bit 1 = hint "all segments have the same length" (enables an XCD-local
- * placement of the query blocks of one (segment, head); results are identical with or without it). */
+ * placement of the query blocks of one (segment, head); results are identical with or without it);
+ * bit 2 = cu_seqlens is followed by q_start int32 [nseg]: rows of segment s before q_start[s] are KEYS ONLY (the
+ * cached prefix of a prompt chunk appended to a non-empty cache, ar.py:426-472 / dispatch.py:861-882 - the causal
+ * mask stays on absolute rows, i.e. offset by the cache length as base.py:366-373 builds it); their rows of `out`
+ * are not written and total_qblocks = sum_s ceil((len_s - q_start_s) / 128).  Not with bit 1. */
 int vlm_attn_prefill(const void* q, const void* k, const void* v, void* out, int q_stride, int k_stride, int v_stride,
                      int o_stride, const void* cu_seqlens, int nseg, int total_qblocks, int Hq, int Hkv, int D,
                      float scale, int causal, void* stream);

@@ -59,7 +59,7 @@ template <int D, bool CAUSAL, bool HILO = false>
 __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void attn_prefill_kernel(
     const bf16_t* __restrict__ qp, const bf16_t* __restrict__ kp, const bf16_t* __restrict__ vp, bf16_t* __restrict__ op,
     int q_stride, int k_stride, int v_stride, int o_stride, const int* __restrict__ cu, int nseg, int Hq, int Hkv,
-    float scale_log2, int uniform_nqb) {
+    float scale_log2, int uniform_nqb, const int* __restrict__ qstart) {
   constexpr int DP = (D + 31) / 32 * 32;   // padded head dim for the O^T tiles
   constexpr int NKS = D / 16;              // k-steps of the S^T product
   constexpr int NDB = DP / 32;             // 32-wide d blocks of O^T
@@ -88,21 +88,25 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void attn_prefill_kernel(
     seg = pair / Hq;
     head = pair % Hq;
   } else {
+    // qstart (round 6): rows of segment s before qstart[s] are KEYS ONLY - the cached prefix of a prompt chunk appended to a
+    // non-empty cache (LanguageModel._prefill_onto_cache).  The segment's query blocks start at that row; masks and the causal
+    // end work on absolute rows, so nothing else changes (the prefix rows used to carry zero queries: O(Tf^2) for a chunk).
     int bid = blockIdx.x;
     for (; seg < nseg; ++seg) {
-      const int nb = (cu[seg + 1] - cu[seg] + BQ - 1) / BQ;
+      const int nb = (cu[seg + 1] - cu[seg] - (qstart ? qstart[seg] : 0) + BQ - 1) / BQ;
       if (bid < nb) { qb = bid; break; }
       bid -= nb;
     }
     if (seg >= nseg) return;
   }
   const int seg_start = cu[seg], seg_len = cu[seg + 1] - seg_start;
+  const int qbase = (qstart ? qstart[seg] : 0) + qb * BQ;        // first row of this query block inside the segment
   const int kvh = head / (Hq / Hkv);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   __builtin_assume(tid >= 0 && tid < 256);
-  const int qrow = qb * BQ + wave * 32 + (lane & 31);          // row inside the segment
+  const int qrow = qbase + wave * 32 + (lane & 31);            // row inside the segment
   const int qrow_c = min(qrow, seg_len - 1);
-  const bool wave_rows = qb * BQ + wave * 32 < seg_len;          // wave-uniform
+  const bool wave_rows = qbase + wave * 32 < seg_len;            // wave-uniform
 
   // ---- Q fragments (B operand of S^T): q = lane&31, d = ks*16 + 8h .. +8 ----
   bf16x8_t qf[NKS];
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void attn_prefill_kernel(
     for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qr + ks * 16);
   }
 
-  const int kv_end = CAUSAL ? min(seg_len, qb * BQ + BQ) : seg_len;
+  const int kv_end = CAUSAL ? min(seg_len, qbase + BQ) : seg_len;
   const int ntiles = (kv_end + BKV - 1) / BKV;
   const bf16_t* kbase = kp + (size_t)seg_start * k_stride + (size_t)kvh * D;
   const bf16_t* vbase = vp + (size_t)seg_start * v_stride + (size_t)kvh * D;
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 3 : 2)) void attn_prefill_kernel(
     //     than 2^8 (log2 domain) - P stays <= 256, exact in the normalised result, and the O / l rescale
     //     (48 accumulator registers) runs on a few tiles per query block instead of every tile.
     ST_MARK(1);                          // QK^T MFMAs issued
-    const bool need_mask = (j0 + BKV > seg_len) || (CAUSAL && j0 + BKV - 1 > qb * BQ + wave * 32);
+    const bool need_mask = (j0 + BKV > seg_len) || (CAUSAL && j0 + BKV - 1 > qbase + wave * 32);
     if (need_mask) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -382,6 +386,9 @@ extern "C" int vlm_attn_prefill(const void* q, const void* k, const void* v, voi
   // bit 1 of `causal`: the caller asserts that all segments have the same length -> XCD-local placement
   const bool uniform = (causal & 2) != 0 && total_qblocks % nseg == 0 && ((long)nseg * Hq) % 8 == 0;
   const int uniform_nqb = uniform ? total_qblocks / nseg : 0;
+  // bit 2 (round 6): cu_seqlens is followed by q_start int32 [nseg] (see the header); total_qblocks counts the query rows only
+  const int* qstart = (causal & 4) ? (const int*)cu_seqlens + nseg + 1 : nullptr;
+  if ((causal & 4) && (causal & 2)) return VLM_ERR_ARG;
   causal &= 1;
   // P as hi + lo bf16 operands (16 mantissa bits into P.V; the reference's fused attention keeps P in fp32).  Measured on MI355X
   // (profiles/r06_attention_p_hilo.txt): distance to the exactly rounded result 1.8e-3 -> 7e-5; launch time +25 % (ViT, D = 80:
@@ -396,11 +403,11 @@ extern "C" int vlm_attn_prefill(const void* q, const void* k, const void* v, voi
     if (hilo)                                                                                                         \
       hipLaunchKernelGGL((attn_prefill_kernel<DV, CV, true>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,  \
                          (const bf16_t*)v, (bf16_t*)out, q_stride, k_stride, v_stride, o_stride, (const int*)cu_seqlens, \
-                         nseg, Hq, Hkv, sl2, uniform_nqb);                                                             \
+                         nseg, Hq, Hkv, sl2, uniform_nqb, qstart);                                                             \
     else                                                                                                              \
       hipLaunchKernelGGL((attn_prefill_kernel<DV, CV, false>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k, \
                          (const bf16_t*)v, (bf16_t*)out, q_stride, k_stride, v_stride, o_stride, (const int*)cu_seqlens, \
-                         nseg, Hq, Hkv, sl2, uniform_nqb);                                                             \
+                         nseg, Hq, Hkv, sl2, uniform_nqb, qstart);                                                             \
   } while (0)
   if (D == 80 && !causal) GO(80, false);
   else if (D == 80 && causal) GO(80, true);

@@ -512,9 +512,10 @@ class LanguageModel:
         """A prompt chunk appended to a NON-EMPTY cache: chunked prefill (reference ar.py:426-472) and `prompt_cache=`
         continuation across calls, i.e. multi-turn (dispatch.py:861-882, common.py:243-263).  The chunk's queries attend
         to [cached tokens | the chunk] (cache.py:345-367 + base.py:366-373 with the causal mask offset by the cache
-        length).  Rare path, kept simple: the layer loop runs here over the C-ABI operators; per layer the cached k / v
-        rows are fetched back into a full-length token-major buffer (vlm_kv_gather) and the varlen causal attention runs
-        over the whole sequence - the prefix rows carry zero queries and their outputs are dropped."""
+        length).  Kept simple: the layer loop runs here over the C-ABI operators; per layer the cached k / v rows are fetched
+        back into a full-length token-major buffer (vlm_kv_gather) and the varlen causal attention runs with the segment's
+        query rows starting at the cache length (vlm_attn_prefill's q_start, round 6: the prefix rows are keys only - they used
+        to carry zero queries, O(Tf^2) per chunk)."""
         if any(c[0]._seq.rotating for c in caches):
             raise NotImplementedError("max_kv_size: a multi-token update of a non-empty rotating cache (the reference first trims "
                                       "the window to max_size - 1 + S, cache.py:486-505) is not built; only the first prompt")
@@ -546,7 +547,10 @@ class LanguageModel:
         seq_d, slot_d, cu_d = _lib.h2d(full_seq, dev), _lib.h2d(full_slot, dev), _lib.h2d(cu_full, dev)
         new_seq_d, new_slot_d = seq_d[new_rows_d], slot_d[new_rows_d]
         old_seq_d, old_slot_d = seq_d[old_rows_d].contiguous(), slot_d[old_rows_d].contiguous()
-        nqb = int(sum((n + 127) // 128 for n in tot))
+        nqb = int(sum((n + 127) // 128 for n in lengths))      # query blocks: the chunk rows only
+        qstart_d = _lib.h2d(np.asarray(offs, dtype=np.int32), dev)
+        if os.environ.get("VLM_ONTO_CACHE_QSTART") == "0":     # A/B knob: the form of rounds 3-5 (the prefix rows carry zero queries)
+            nqb, qstart_d = int(sum((n + 127) // 128 for n in tot)), None
         scale = float(getattr(t, "attn_scale", 0.0) or 0.0) or hd ** -0.5
         h = inputs_embeds.contiguous().clone()
         sec = self.mrope_section
@@ -564,13 +568,14 @@ class LanguageModel:
             ops.mrope_kvwrite_(qkv, Hq, Hkv, hd, pos_d[0], pos_d[1], pos_d[2], inv_tab, int(sec[0]), int(sec[1]),
                                kv_seq=new_seq_d.contiguous(), kv_slot=new_slot_d.contiguous(), block_table=bt, kpool=kp, vpool=vp,
                                qk_scale=getattr(t, "rope_qk_scale", None))
-            full = torch.zeros(Tf, QKV, dtype=bf, device=dev)
+            full = (torch.empty if qstart_d is not None else torch.zeros)(Tf, QKV, dtype=bf, device=dev)       # (q_start: the q columns of the prefix rows are never read)
             full[new_rows_d] = qkv
             if old_rows.size:
-                prefix = torch.zeros(old_rows.size, QKV, dtype=bf, device=dev)
+                prefix = (torch.empty if qstart_d is not None else torch.zeros)(old_rows.size, QKV, dtype=bf, device=dev)
                 ops.kv_gather_(prefix, Hq, Hkv, hd, old_slot_d, bt, kp, vp, kv_seq=old_seq_d)
                 full[old_rows_d] = prefix
-            attn = ops.attn_prefill(full, full[:, Hq * hd:], full[:, (Hq + Hkv) * hd:], cu_d, nqb, Hq, Hkv, hd, scale, True)
+            attn = ops.attn_prefill(full, full[:, Hq * hd:], full[:, (Hq + Hkv) * hd:], cu_d, nqb, Hq, Hkv, hd, scale, True,
+                                    q_start=qstart_d)
             h = ops.gemm(attn[new_rows_d].contiguous(), w[f"{i}.wo"], res=h, epilogue=ops.EPI_RESIDUAL)
             xn = ops.rmsnorm(h, w[f"{i}.ln2"], t.rms_norm_eps)
             act = ops.gemm(xn, w[f"{i}.wgu"], epilogue=ops.EPI_SWIGLU)

@@ -210,16 +210,22 @@ def kv_gather_(qkv, Hq, Hkv, D, kv_slot, block_table, kpool, vpool, kv_seq=None)
     return qkv
 
 
-def attn_prefill(q, k, v, cu_seqlens, total_qblocks, Hq, Hkv, D, scale, causal, out=None, uniform_segments=False):
+def attn_prefill(q, k, v, cu_seqlens, total_qblocks, Hq, Hkv, D, scale, causal, out=None, uniform_segments=False, q_start=None):
     """q/k/v: 2-D views [T, *] whose data_ptr points at head 0 of token 0 and stride(0) is the token stride.
-    uniform_segments: placement hint (all segments the same length); results are identical."""
-    _dev(q, k, v, cu_seqlens)
+    uniform_segments: placement hint (all segments the same length); results are identical.
+    q_start (int32 [nseg], device): rows of segment s before q_start[s] are keys only (a cached prefix) - their rows of `out`
+    are not written; total_qblocks then counts sum ceil((len_s - q_start_s) / 128)."""
+    _dev(q, k, v, cu_seqlens, q_start)
     T = q.shape[0]
     if out is None:
         out = torch.empty(T, Hq * D, dtype=torch.bfloat16, device=q.device)
+    nseg = cu_seqlens.numel() - 1
+    flags = (1 if causal else 0) | (2 if uniform_segments else 0)
+    if q_start is not None:
+        cu_seqlens = torch.cat([cu_seqlens.reshape(-1).to(torch.int32), q_start.reshape(-1).to(torch.int32)])     # [cu | q_start]
+        flags |= 4
     check(_lib.lib().vlm_attn_prefill(_p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
-                                      _p(cu_seqlens), cu_seqlens.numel() - 1, total_qblocks, Hq, Hkv, D, scale,
-                                      (1 if causal else 0) | (2 if uniform_segments else 0), _stream()), "attn_prefill")
+                                      _p(cu_seqlens), nseg, total_qblocks, Hq, Hkv, D, scale, flags, _stream()), "attn_prefill")
     return out
 
 

@@ -241,6 +241,39 @@ def test_attn_prefill(vops, D, Hq, Hkv, causal, lens):
     assert ok, rep
 
 
+@pytest.mark.parametrize("D,Hq,Hkv,causal,lens,starts", [
+    (128, 12, 2, True, [300, 64, 700], [257, 0, 699]),        # a prefix past two query blocks, none, all but one row
+    (128, 4, 4, True, [130, 2049], [1, 2000]),
+    (80, 4, 4, False, [200, 576], [100, 575]),
+])
+def test_attn_prefill_query_start_rows_before_it_are_keys_only(vops, D, Hq, Hkv, causal, lens, starts):
+    """causal bit 2 / ops.attn_prefill(q_start=...) (round 6: a prompt chunk onto a non-empty cache - the cached prefix rows are
+    keys only, the causal mask stays on absolute rows): the query rows equal the oracle's attention over the whole segment
+    (same tolerance as test_attn_prefill) and the launch's other rows - the prefix - are left untouched."""
+    T = sum(lens)
+    q, k, v = rnd(T, Hq, D, seed=31), rnd(T, Hkv, D, seed=32), rnd(T, Hkv, D, seed=33)
+    scale = D ** -0.5
+    ref = _ref_attn_varlen(q, k, v, lens, scale, causal)
+    qkv = torch.cat([q.reshape(T, -1), k.reshape(T, -1), v.reshape(T, -1)], dim=1).cuda()
+    off = np.concatenate([[0], np.cumsum(lens)])
+    is_q = np.zeros(T, dtype=bool)
+    for i, (n, s0) in enumerate(zip(lens, starts)):
+        is_q[off[i] + s0: off[i + 1]] = True
+    qkv[torch.from_numpy(~is_q).cuda(), : Hq * D] = float("nan")          # the prefix rows' queries must never be read
+    cu = torch.tensor(off, dtype=torch.int32).cuda()
+    nqb = sum((n - s0 + 127) // 128 for n, s0 in zip(lens, starts))
+    out = torch.full((T, Hq * D), 7.0, dtype=BF, device="cuda")
+    vops.attn_prefill(qkv, qkv[:, Hq * D:], qkv[:, (Hq + Hkv) * D:], cu, nqb, Hq, Hkv, D, scale, causal, out=out,
+                      q_start=torch.tensor(starts, dtype=torch.int32).cuda())
+    o = out.cpu().view(T, Hq, D)
+    ok, rep = bf16_close(o[is_q], ref[is_q], ulps=2, atol_rms=2e-2)
+    assert ok, rep
+    assert bool((o[~is_q].float() == 7.0).all())
+    with pytest.raises(Exception):                            # not together with the uniform-placement hint
+        vops.attn_prefill(qkv, qkv[:, Hq * D:], qkv[:, (Hq + Hkv) * D:], cu, nqb, Hq, Hkv, D, scale, causal, out=out,
+                          q_start=torch.tensor(starts, dtype=torch.int32).cuda(), uniform_segments=True)
+
+
 def test_attn_prefill_forced_rescale_spike(vops):
     """online-softmax rescale branch: one key per tile spikes the running max (guide rule 26)."""
     T, H, D = 400, 2, 128
