@@ -571,9 +571,9 @@ class LanguageModel:
             full = (torch.empty if qstart_d is not None else torch.zeros)(Tf, QKV, dtype=bf, device=dev)       # (q_start: the q columns of the prefix rows are never read)
             full[new_rows_d] = qkv
             if old_rows.size:
-                prefix = (torch.empty if qstart_d is not None else torch.zeros)(old_rows.size, QKV, dtype=bf, device=dev)
-                ops.kv_gather_(prefix, Hq, Hkv, hd, old_slot_d, bt, kp, vp, kv_seq=old_seq_d)
-                full[old_rows_d] = prefix
+                # ONE gather over every row of the buffer, straight into it: the chunk's rows re-read from the pages what
+                # mrope_kvwrite_ just stored there (the same bits) - no prefix buffer, no second copy of Tf rows
+                ops.kv_gather_(full, Hq, Hkv, hd, slot_d, bt, kp, vp, kv_seq=seq_d)
             attn = ops.attn_prefill(full, full[:, Hq * hd:], full[:, (Hq + Hkv) * hd:], cu_d, nqb, Hq, Hkv, hd, scale, True,
                                     q_start=qstart_d)
             h = ops.gemm(attn[new_rows_d].contiguous(), w[f"{i}.wo"], res=h, epilogue=ops.EPI_RESIDUAL)
