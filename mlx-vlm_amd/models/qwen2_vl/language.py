@@ -552,6 +552,18 @@ class LanguageModel:
         if os.environ.get("VLM_ONTO_CACHE_QSTART") == "0":     # A/B knob: the form of rounds 3-5 (the prefix rows carry zero queries)
             nqb, qstart_d = int(sum((n + 127) // 128 for n in tot)), None
         scale = float(getattr(t, "attn_scale", 0.0) or 0.0) or hd ** -0.5
+        # A SHORT chunk (a conversation turn of up to 64 tokens in all) takes the paged DECODE attention instead: every new token is
+        # a decode row over its sequence's pages with kv_len = cache length + its index + 1 (its K / V are in the pages by then:
+        # mrope_kvwrite_ below) - no gather of the prefix at all, and the keys are split over workgroups as in a decode step
+        # (one 64-row query block per head walking 16k keys took ~0.4 ms per layer; profiles/r06_long_prompt_prefill.txt).
+        short = T <= 64 and os.environ.get("VLM_ONTO_CACHE_DECODE_ATTN") != "0"
+        if short:
+            row_seq = np.concatenate([np.full(n, s.seq, np.int64) for n, s in zip(lengths, seqs)])
+            row_len = np.concatenate([o + 1 + np.arange(n) for o, n in zip(offs, lengths)]).astype(np.int32)
+            bt_rows = bt[_lib.h2d(row_seq, dev)].contiguous()
+            row_len_d = _lib.h2d(row_len, dev)
+            longest = int(row_len.max())
+            dec_nsplit = 1 if longest <= 2048 else max(2, min(32, (longest + 16 * PAGE - 1) // (16 * PAGE)))
         h = inputs_embeds.contiguous().clone()
         sec = self.mrope_section
         def dense(x):        # 4-bit matrices are materialised as bf16 for the GEMMs of this (rare) path
@@ -568,6 +580,13 @@ class LanguageModel:
             ops.mrope_kvwrite_(qkv, Hq, Hkv, hd, pos_d[0], pos_d[1], pos_d[2], inv_tab, int(sec[0]), int(sec[1]),
                                kv_seq=new_seq_d.contiguous(), kv_slot=new_slot_d.contiguous(), block_table=bt, kpool=kp, vpool=vp,
                                qk_scale=getattr(t, "rope_qk_scale", None))
+            if short:
+                attn = ops.attn_decode_paged(qkv, kp, vp, bt_rows, row_len_d, 0, Hq, Hkv, hd, scale, dec_nsplit)
+                h = ops.gemm(attn, w[f"{i}.wo"], res=h, epilogue=ops.EPI_RESIDUAL)
+                xn = ops.rmsnorm(h, w[f"{i}.ln2"], t.rms_norm_eps)
+                act = ops.gemm(xn, w[f"{i}.wgu"], epilogue=ops.EPI_SWIGLU)
+                h = ops.gemm(act, w[f"{i}.wdown"], res=h, epilogue=ops.EPI_RESIDUAL)
+                continue
             full = (torch.empty if qstart_d is not None else torch.zeros)(Tf, QKV, dtype=bf, device=dev)       # (q_start: the q columns of the prefix rows are never read)
             full[new_rows_d] = qkv
             if old_rows.size:

@@ -306,6 +306,40 @@ def test_prefill_onto_non_empty_cache_chunked_and_multi_turn(tiny):
     cache[0]._seq.release(); one[0]._seq.release()
 
 
+@pytest.mark.parametrize("prefix,n", [(300, 1), (300, 64), (2100, 37), (130, 65), (700, 200)])
+def test_prompt_chunk_onto_a_cache_three_attention_forms_agree(tiny, monkeypatch, prefix, n):
+    """LanguageModel._prefill_onto_cache (chunked prefill / a conversation turn) has three attention forms since round 6: up to
+    64 new tokens run the paged DECODE attention (every new token a decode row over the pages, no gather of the prefix); longer
+    chunks gather the prefix and run the prompt kernel with the query blocks starting at the cache length (q_start); the form of
+    rounds 3-5 gave the prefix rows zero queries (VLM_ONTO_CACHE_QSTART=0).  All three against the one-shot prefill of the whole
+    sequence: the chunk's last-row logits and the NEXT decode step's logits (which reads the K / V the chunk wrote)."""
+    cfg, W, model = tiny
+    lm = model.language_model
+    L = prefix + n
+    rng = np.random.default_rng(prefix * 131 + n)
+    emb = lm._w["embed"][torch.from_numpy(rng.integers(3, 1000, L)).cuda()]
+    pos = np.broadcast_to(np.arange(L, dtype=np.int64)[None], (3, L)).copy()
+    lm._rope_deltas = np.zeros((1, 1), dtype=np.int64)
+    one = lm.make_cache()
+    want = lm.prefill(emb.clone(), pos, [one], [L], "last")
+    want_next = lm(np.array([[77]]), cache=one).logits[0, -1].clone()
+    one[0]._seq.release()
+    for form, env in (("decode", {}), ("q_start", {"VLM_ONTO_CACHE_DECODE_ATTN": "0"}),
+                      ("zero_queries", {"VLM_ONTO_CACHE_DECODE_ATTN": "0", "VLM_ONTO_CACHE_QSTART": "0"})):
+        for k in ("VLM_ONTO_CACHE_DECODE_ATTN", "VLM_ONTO_CACHE_QSTART"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = lm.make_cache()
+        lm.prefill(emb[:prefix].clone(), pos[:, :prefix], [c], [prefix], "last", reserve_extra=n + 4)
+        got = lm.prefill(emb[prefix:].clone(), pos[:, prefix:], [c], [n], "last", reserve_extra=4)
+        assert c[0].offset == L
+        assert _rel_rms_err(got[0], want[0]) < 1e-2, (form, _rel_rms_err(got[0], want[0]))
+        nxt = lm(np.array([[77]]), cache=c).logits[0, -1]
+        assert _rel_rms_err(nxt, want_next) < 1e-2, (form, "next step", _rel_rms_err(nxt, want_next))
+        c[0]._seq.release()
+
+
 def test_generate_step_prefill_step_size_chunks_and_the_models_veto(tiny, monkeypatch):
     """generate_step(prefill_step_size=16) feeds a longer prompt in chunks of 16 until one token is left (reference
     ar.py:409-470) - same greedy tokens as the one-shot prefill, log-probs of the first token within the chunk-vs-one-shot
