@@ -9,12 +9,16 @@ import torch
 from tests.cache_contract_replay import replay
 
 
-def _dry_update(self, keys, values):
+def _dry_append(self, keys, values):
     s = self._seq
     S = int(keys.shape[2])
     if S:
         s.reserve(self.offset + S)
         s.advance_layer(self._layer, S)
+
+
+def _dry_update(self, keys, values):
+    _dry_append(self, keys, values)
     return self.state
 
 
@@ -23,6 +27,7 @@ def test_cache_facades_bookkeeping_matches_reference_classes(monkeypatch, layout
     from mlx_vlm_amd.models import cache as C
 
     monkeypatch.setattr(C.KVCache, "update_and_fetch", _dry_update)
+    monkeypatch.setattr(C.KVCache, "_append", _dry_append)          # (BatchKVCache appends row by row without materialising the state)
     pool = C.KVPool(2, 2, 128, max_tokens=1024, max_seqs=32, max_pages_per_seq=4, device="cpu", layout=layout)
     _, n_ops = replay(pool, "cpu", check_contents=False)
     assert n_ops >= 35
