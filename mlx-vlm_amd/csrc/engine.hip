@@ -253,10 +253,11 @@ extern "C" int vlm_llm_prefill(void* handle, const vlm_prefill_args* a, void* st
   const int QKV = (Hq + 2 * Hkv) * hd, T = a->T;
   const float scale = c.attn_scale > 0.f ? c.attn_scale : 1.0f / sqrtf((float)hd);
   const float qk_scale = c.rope_qk_scale > 0.f ? c.rope_qk_scale : 1.f;
+  bool xn_ready = false;      // xn already holds RMSNorm(h) of the coming layer (the previous down GEMM's split-K reduce launch wrote it)
   for (int i = 0; i < c.n_layers; ++i) {
     const vlm_llm_layer& w = m->layers[i];
     // xn = RMSNorm(h)
-    TRY(vlm_rmsnorm_residual(a->h, nullptr, w.ln1_w, a->xn, nullptr, T, D, c.rms_eps, stream));
+    if (!xn_ready) TRY(vlm_rmsnorm_residual(a->h, nullptr, w.ln1_w, a->xn, nullptr, T, D, c.rms_eps, stream));
     // qkv = xn Wqkv^T + b
     TRY(lin_gemm(m, a->xn, w.wqkv, w.wqkv_sb, w.bqkv, nullptr, a->qkv, T, QKV, D, QKV, 0, VLM_EPI_BIAS, stream));
     // M-RoPE on q, k in place + paged KV write
@@ -277,7 +278,18 @@ extern "C" int vlm_llm_prefill(void* handle, const vlm_prefill_args* a, void* st
     // xn = RMSNorm(h); act = swiglu(xn Wgu^T); h = h + act Wdown^T
     TRY(vlm_rmsnorm_residual(a->h, nullptr, w.ln2_w, a->xn, nullptr, T, D, c.rms_eps, stream));
     TRY(lin_gemm(m, a->xn, w.wgu, w.wgu_sb, nullptr, nullptr, a->act, T, 2 * c.inter, D, c.inter, 0, VLM_EPI_SWIGLU, stream));
-    TRY(lin_gemm(m, a->act, w.wdown, w.wdown_sb, nullptr, a->h, a->h, T, D, c.inter, D, D, VLM_EPI_RESIDUAL, stream));
+    // (round 6) a split-K down GEMM's reduce launch also writes the NEXT layer's RMSNorm(h) (VlmGemmTail: the wide decode steps'
+    // mechanism, same bits as the separate launch; the last layer's rows go through the gather below instead)
+    int done = 0;
+    if (i + 1 < c.n_layers) {
+      VlmGemmTail nt{};
+      nt.kind = VLM_TAIL_RMSNORM;
+      nt.norm_w = m->layers[i + 1].ln1_w; nt.eps = c.rms_eps; nt.xn = a->xn; nt.ldxn = D;
+      TRY(lin_gemm_tail(m, a->act, w.wdown, w.wdown_sb, nullptr, a->h, a->h, T, D, c.inter, D, D, VLM_EPI_RESIDUAL, &nt, &done, stream));
+    } else {
+      TRY(lin_gemm(m, a->act, w.wdown, w.wdown_sb, nullptr, a->h, a->h, T, D, c.inter, D, D, VLM_EPI_RESIDUAL, stream));
+    }
+    xn_ready = done != 0;
   }
   if (a->n_last > 0) {
     if (!a->last_rows || !a->xlast || !a->logits) return 1;
