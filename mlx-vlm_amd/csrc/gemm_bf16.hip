@@ -55,6 +55,26 @@ __device__ __forceinline__ int lds_off(int row, int slot) { return row * ROWB + 
 // vlm_dequant_w4's output (same fp32 scale * q + bias, one rounding: mx.dequantize), so the fused GEMM equals
 // dequantise-then-GEMM bit for bit while reading 4.5 instead of 16 + 16 + 16 bits per weight (nn.QuantizedLinear /
 // mx.quantized_matmul at L > 1, reference utils.py:918-967).
+// LDS stages of the LDS-DMA K loop per tile shape (2 = the plain double buffer) and the counted wait it needs
+template <int BM, int BN>
+constexpr int gemm_stages() {
+  if ((BM == 64 || BM == 32) && BN == 64) return 4;
+#ifndef VLM_GEMM_NS128
+#define VLM_GEMM_NS128 2      // measured (profiles/r06_wide_step.txt, item 5): 3 / 4 stages on the 128-wide tiles LOSE - one workgroup per CU instead of two
+#endif
+  if (BM == 128 && BN == 128) return VLM_GEMM_NS128;
+  if (BM == 64 && BN == 128) return VLM_GEMM_NS128;
+  return 2;
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N == 6 || N == 8 || N == 12 || N == 16, "add the immediate");
+  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+}
+
 template <int BM, int BN, int EPI, bool GLDS, bool PARTIAL = false, bool W4 = false>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                         const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
@@ -202,30 +222,29 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + (size_t)kt * BK),
                                          (__attribute__((address_space(3))) void*)(ws + (uw * W_IT + j) * 1024), 16, 0, 0);
     };
-    if constexpr ((BM == 64 || BM == 32) && BN == 64) {
+    constexpr int NS = gemm_stages<BM, BN>();
+    if constexpr (NS > 2) {
       // 64x64 tiles carry ~100 cycles of MFMA per K tile: with one tile of prefetch every iteration waited a full
-      // memory latency (~0.8 us per K tile measured on the M = 386 prefill GEMMs).  Four 16 KiB stages, three tiles in
-      // flight, COUNTED waits (4 DMA instructions per wave and tile; tile indices clamped at the end so the count
-      // never changes), raw barriers (__syncthreads would drain vmcnt(0)).  Stage kt % 4 is refilled with tile kt + 4
+      // memory latency (~0.8 us per K tile measured on the M = 386 prefill GEMMs).  NS stages, NS - 1 tiles in
+      // flight, COUNTED waits (PER DMA instructions per wave and tile; tile indices clamped at the end so the count
+      // never changes), raw barriers (__syncthreads would drain vmcnt(0)).  Stage kt % NS is refilled with tile kt + NS
       // in iteration kt + 1, after the barrier that ends its last read.
       // (round 6) BM = 32, for GEMMs of <= 32 rows: half the A tile, 12 KiB stages - three workgroups per CU instead of two
       // (a weight stream wants bytes in flight) and 3 DMA instructions per wave and tile.
-      constexpr int NS = 4, PER = A_IT + W_IT;
-      static_assert(PER == 4 || PER == 3, "vmcnt immediates below: 4 or 3 DMA instructions per wave and tile");
-      issue(0, 0);
-      issue(min(1, nk - 1), 1);
-      issue(min(2, nk - 1), 2);
-      if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 landed (tiles 1, 2 may be in flight)
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      // (round 6) the loop is generic in the stage count; the 128-wide tiles were tried at 3 and 4 stages (-DVLM_GEMM_NS128=3 / 4)
+      // and keep their double buffer: the deeper pipeline costs the second workgroup of the CU (fc1 at M = 1024: 24.8 -> 33 us).
+      constexpr int PER = A_IT + W_IT, WAITN = (NS - 2) * PER;
+#pragma unroll
+      for (int t = 0; t < NS - 1; ++t) issue(min(t, nk - 1), t);
+      wait_vmcnt<WAITN>();                                  // tile 0 landed (tiles 1 .. NS - 2 may be in flight)
       __builtin_amdgcn_s_barrier();
       for (int kt = 0; kt < nk; ++kt) {
-        issue(min(kt + 3, nk - 1), (kt + 3) % NS);
+        issue(min(kt + NS - 1, nk - 1), (kt + NS - 1) % NS);
         __builtin_amdgcn_sched_barrier(0);
         compute(kt % NS);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile kt + 1 landed (this wave's pieces) ...
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                       // ... and everybody's; stage kt % 4 is free again
+        wait_vmcnt<WAITN>();                                // tile kt + 1 landed (this wave's pieces) ...
+        __builtin_amdgcn_s_barrier();                       // ... and everybody's; stage kt % NS is free again
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // clamped reloads still target LDS
       __builtin_amdgcn_s_barrier();
@@ -692,7 +711,12 @@ template <int BM, int BN, int EPI, bool GLDS>
 int launch_cfg(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
                int ldw, int ldc, int ldres, hipStream_t st) {
   const int tiles_m = vlm_cdiv(M, BM), tiles_n = vlm_cdiv(N, BN), nwg = tiles_m * tiles_n;
-  const size_t lds = (((BM == 64 || BM == 32) && BN == 64 && GLDS) ? 4 : 2) * (size_t)(BM + BN) * ROWB;
+  const size_t lds = (GLDS ? gemm_stages<BM, BN>() : 2) * (size_t)(BM + BN) * ROWB;
+  if (lds > 65536) {          // beyond the default dynamic-LDS limit: raised once per instantiation
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, EPI, GLDS>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return VLM_ERR_HIP + (int)attr;
+  }
   hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, GLDS>), dim3(nwg), dim3(256), lds, st, (const bf16_t*)A, (const bf16_t*)W,
                      (const bf16_t*)bias, (const bf16_t*)res, (bf16_t*)C, M, N, K, lda, ldw, ldc, ldres, tiles_n, nwg, 0);
   hipError_t e = hipGetLastError();
