@@ -79,7 +79,12 @@ int vlm_gemm_w4(const void* A, const void* Wq, const void* Wsb, const void* bias
  * LDS-DMA staging, 3 = 256x256 phased kernel whenever legal (K % 64 == 0, K >= 128, no SwiGLU), 4 = its 2-phase
  * variant, 5 = automatic with the 2-phase variant, 6 / 7 = as 3 with 256x192 / 256x256 tiles forced, 8 = as 2 (named
  * "no split-K"), 9 = 128 kernel family with split-K x4 forced, 10 = as 3 with the persistent tile loop.  Modes 1-8 are bit-identical to each other; split-K (automatic
- * for few tiles and K >= 2048, or mode 9) sums fp32 partials of K ranges and agrees to fp32 summation order. */
+ * for few tiles and K >= 2048, or mode 9) sums fp32 partials of K ranges and agrees to fp32 summation order.
+ * 100 + 10 * splits + cfg (round 6, tile sweeps - scripts/r06/gemm_tiles.py): the plain kernels only, tile cfg 1 = 64 x 64,
+ * 2 = 64 x 128, 3 = 128 x 128 (0 = the policy), split-K forced to `splits` K ranges (0 / 1 = never).
+ * The automatic policy since round 6: up to 64 rows (wide decode steps, short prompts) 64 x 64 tiles - 32 x 64 up to 32 rows -
+ * and split-K from K = 1024, because such a launch is a weight stream and wants workgroups (VLM_GEMM_SKINNY64=0 /
+ * VLM_GEMM_SKINNY32=0 in the environment restore the policy of rounds 1-5 for A/B runs). */
 int vlm_gemm_set_staging(int mode);
 
 /* y[M,N] = epi(x[M,K] . W[N,K]^T) for the decode step, M in {1,2,4,8}; weight streaming.
