@@ -623,6 +623,7 @@ constexpr size_t SPLITK_WS_BYTES = 34u << 20;
 constexpr int MAX_SPLITK_WS = 8;
 SplitkWs g_splitk_ws[MAX_SPLITK_WS];
 int g_n_splitk_ws = 0;
+const bool g_midsize = [] { const char* e = getenv("VLM_GEMM_MIDSIZE"); return !e || atoi(e) != 0; }();   // A/B knob: 0 = the mid-size tile / split policy of rounds 1-5
 const bool g_skinny32 = [] { const char* e = getenv("VLM_GEMM_SKINNY32"); return !e || atoi(e) != 0; }();   // A/B knob: 0 = 64-row A tiles for <= 32 rows too
 const bool g_skinny64 = [] { const char* e = getenv("VLM_GEMM_SKINNY64"); return !e || atoi(e) != 0; }();   // A/B knob: 0 = the tile policy of rounds 1-5
 int g_force_cfg = 0;   // tile of the plain kernels forced (vlm_gemm_set_staging mode 100 + 10 * splits + cfg): 1 = 64 x 64, 2 = 64 x 128, 3 = 128 x 128
@@ -794,6 +795,10 @@ int launch_epi(const void* A, const void* W, const void* bias, const void* res, 
       splits = (int)std::min<long>(8, std::max<long>(2, (512 + t64 - 1) / t64));
       while (splits > 1 && K / splits < 4 * BK) --splits;
     }
+    // ... and 256 .. 640 tiles over a VERY long K (the 7B down projection of a prompt of a few hundred tokens: 392 tiles x 296 K
+    // tiles): three K ranges - T = 386: 137 -> 125 us, T = 640: 206 -> 179 (profiles/r06_wide_step.txt, item 6).  At K = 14336
+    // and below the partials cost what the split gains.
+    if (!splits && g_midsize && t64 >= 256 && t64 < 640 && K >= 16384) splits = 3;
     if (splits > 1 && K / splits >= 4 * BK) {
       if (float* ws = splitk_workspace((size_t)splits * M * N * sizeof(float), st))
         return launch_splitk<EPI>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, splits, ws, st);
@@ -811,7 +816,10 @@ int launch_epi(const void* A, const void* W, const void* bias, const void* res, 
   if (M <= 32 && g_skinny64 && g_skinny32 && glds) return launch_cfg<32, 64, EPI, true>(A, W, bias, res, C, M, N, K, lda, ldw, ldc, ldres, st);
   if (M <= 64 && g_skinny64) return CFG(64, 64);
   if (t128 >= 200) return CFG(128, 128);
-  if (t64n >= 200) return CFG(64, 128);
+  // 64 x 128 tiles prefetch ONE K tile, the 64 x 64 kernel three: below ~3 tiles of 64 x 64 per CU and from K = 2048 the smaller
+  // tile wins (Idefics2 down at T = 386: 183 -> 108 us, 7B down at T = 640: 241 -> 206, 7B qkv at T = 640: 38.8 -> 36.6; from
+  // ~900 tiles the wider one is ahead again: profiles/r06_wide_step.txt, item 6)
+  if (t64n >= 200 && !(g_midsize && glds && K >= 2048 && (long)vlm_cdiv(M, 64) * vlm_cdiv(N, 64) < 768)) return CFG(64, 128);
   return CFG(64, 64);
 #undef CFG
 }
