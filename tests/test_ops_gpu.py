@@ -245,6 +245,7 @@ def test_attn_prefill(vops, D, Hq, Hkv, causal, lens):
     (128, 12, 2, True, [300, 64, 700], [257, 0, 699]),        # a prefix past two query blocks, none, all but one row
     (128, 4, 4, True, [130, 2049], [1, 2000]),
     (80, 4, 4, False, [200, 576], [100, 575]),
+    (64, 2, 1, True, [300, 129], [200, 128]),
 ])
 def test_attn_prefill_query_start_rows_before_it_are_keys_only(vops, D, Hq, Hkv, causal, lens, starts):
     """causal bit 2 / ops.attn_prefill(q_start=...) (round 6: a prompt chunk onto a non-empty cache - the cached prefix rows are
